@@ -1,0 +1,164 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules (test infrastructure).
+
+Run in the build container only (needs /root/reference, read-only):
+
+    python -m oracle.gen_golden pem      # Pose_Estimation_Model Net + known-answer case
+    python -m oracle.gen_golden sam      # SAM ImageEncoderViT (mini config + ViT-H)
+    python -m oracle.gen_golden ism      # ISM scoring chain
+
+PEM and ISM must run in separate processes (both trees own top-level names).  The
+reference modules are imported unmodified through oracle/refharness.py; weights and inputs
+come from sam6d_amd.utils.{seeded,synth}, so tests regenerate identical tensors without
+this script, /root/reference or any checkpoint.  Large tensors are stored as a strided
+sample plus sums (fixtures stay small); small ones are stored whole.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+from sam6d_amd.utils import seeded, synth
+
+from . import refharness as rh
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+PEM_CASE = dict(B=2, weight_seed=1, input_seed=1, rand_seed=7)
+SAM_MINI_CASE = dict(weight_seed=3, input_seed=5)
+SAM_H_CASE = dict(weight_seed=3, input_seed=5)
+ISM_CASE = dict(P=64, O=3, T=42, seed=11)
+
+
+def digest(t, stride=97):
+    """(sum, abs-sum, strided sample) of a big tensor -- the fixture form of a large output."""
+    t = t.detach().double().reshape(-1)
+    return np.array([t.sum().item(), t.abs().sum().item()]), t[::stride].float().numpy()
+
+
+def gen_pem():
+    ns = rh.pem()
+    cfg = rh.pem_cfg()
+    net = ns.pose_estimation_model.Net(cfg.model).eval()
+    seeded.load_seeded(net, PEM_CASE["weight_seed"])
+    B = PEM_CASE["B"]
+    inp = synth.pem_inputs(B, seed=PEM_CASE["input_seed"])
+    ep = {k: inp[k] for k in ("pts", "rgb", "rgb_choose", "model", "dense_po", "dense_fo")}
+    rec = {}
+    with torch.no_grad():
+        # --- full Net.forward (ViT features are from random weights: pose is arbitrary but fixed)
+        torch.manual_seed(PEM_CASE["rand_seed"])  # the reference draws torch.rand(B,18000) from this
+        out = net(dict(ep))
+        for k in ("init_R", "init_t", "pred_R", "pred_t", "pred_pose_score"):
+            rec["net_" + k] = out[k].numpy()
+        # --- stages, by calling the reference sub-modules in Net.forward's order
+        dense_pm, dense_fm, dense_po, dense_fo, radius = net.feature_extraction(dict(ep))
+        rec["fe_radius"] = radius.numpy()
+        rec["fe_dense_fm_sum"], rec["fe_dense_fm_smp"] = digest(dense_fm)
+        # --- known-answer case: observed features = template features + noise (no ViT)
+        dense_fm = inp["dense_fm_kat"]
+        bg = torch.ones(B, 1, 3) * 100
+        sp_m, sf_m, idx_m = ns.model_utils.sample_pts_feats(dense_pm, dense_fm, 196, return_index=True)
+        geo_m = net.geo_embedding(torch.cat([bg, sp_m], 1))
+        sp_o, sf_o, idx_o = ns.model_utils.sample_pts_feats(dense_po, dense_fo, 196, return_index=True)
+        geo_o = net.geo_embedding(torch.cat([bg, sp_o], 1))
+        rec["kat_fps_idx_m"], rec["kat_fps_idx_o"] = idx_m.numpy(), idx_o.numpy()
+        rec["kat_geo_m_sum"], rec["kat_geo_m_smp"] = digest(geo_m, 9973)
+        e = {"model": ep["model"]}
+        torch.manual_seed(PEM_CASE["rand_seed"])
+        e = net.coarse_point_matching(sp_m, sf_m, geo_m, sp_o, sf_o, geo_o, radius, e)
+        e = net.fine_point_matching(dense_pm, dense_fm, geo_m, idx_m, dense_po, dense_fo, geo_o, idx_o, radius, e)
+        for k in ("init_R", "init_t", "pred_R", "pred_t", "pred_pose_score"):
+            rec["kat_" + k] = e[k].numpy()
+        rec["kat_gt_R"], rec["kat_gt_t"] = inp["gt_R"].numpy(), inp["gt_t"].numpy()
+        # --- PositionalEncoding alone (ball query + grouping + SharedMLP + max-pool)
+        pe = net.fine_point_matching.PE(dense_po)
+        rec["pe_sum"], rec["pe_smp"] = digest(pe, 997)
+    rec["state_keys"] = np.array(sorted(net.state_dict().keys()))
+    rec["state_shapes"] = np.array([str(tuple(net.state_dict()[k].shape)) for k in sorted(net.state_dict().keys())])
+    rec["case"] = np.array(str(PEM_CASE))
+    np.savez_compressed(os.path.join(OUT, "pem_b2.npz"), **rec)
+    print("pem_b2.npz", {k: (v.shape if hasattr(v, "shape") else v) for k, v in rec.items() if not k.startswith("state")})
+    dR = np.linalg.norm(rec["kat_pred_R"] - rec["kat_gt_R"], axis=(1, 2))
+    print("KAT |dR|_F", dR, "score", rec["kat_pred_pose_score"], "t", rec["kat_pred_t"])
+
+
+def _sam_ref(cfg, weight_seed):
+    enc = rh.sam_encoder()
+    from functools import partial
+    m = enc.ImageEncoderViT(
+        depth=cfg["depth"], embed_dim=cfg["dim"], img_size=cfg["img_size"], mlp_ratio=4,
+        norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_heads=cfg["heads"], patch_size=16,
+        qkv_bias=True, use_rel_pos=True, global_attn_indexes=cfg["global_idx"], window_size=cfg["window"],
+        out_chans=cfg["out_chans"]).eval()
+    seeded.load_seeded(m, weight_seed)
+    return m
+
+
+def gen_sam():
+    from . import sam as osam
+    rec = {}
+    with torch.no_grad():
+        m = _sam_ref(osam.MINI, SAM_MINI_CASE["weight_seed"])
+        x = synth.sam_input(1, SAM_MINI_CASE["input_seed"], osam.MINI["img_size"])
+        rec["mini_out"] = m(x).numpy()
+        rec["mini_keys"] = np.array(sorted(m.state_dict().keys()))
+        m = _sam_ref(osam.VIT_H, SAM_H_CASE["weight_seed"])
+        x = synth.sam_input(1, SAM_H_CASE["input_seed"], 1024)
+        y = m(x)
+        rec["h_sum"], rec["h_smp"] = digest(y, 251)
+        rec["h_keys"] = np.array(sorted(m.state_dict().keys()))
+        rec["h_shapes"] = np.array([str(tuple(m.state_dict()[k].shape)) for k in sorted(m.state_dict().keys())])
+        # token map after 2 blocks (one windowed-with-padding pair) for a per-block check
+        t = m.patch_embed(x) + m.pos_embed
+        for blk in m.blocks[:2]:
+            t = blk(t)
+        rec["h_blk2_sum"], rec["h_blk2_smp"] = digest(t, 1009)
+    np.savez_compressed(os.path.join(OUT, "sam_enc.npz"), **rec)
+    print("sam_enc.npz", {k: v.shape for k, v in rec.items()})
+
+
+def gen_ism():
+    ns = rh.ism()
+    c = ISM_CASE
+    inp = synth.ism_inputs(P=c["P"], O=c["O"], T=c["T"], seed=c["seed"])
+    Det = ns.detector.Instance_Segmentation_Model
+    fake = types.SimpleNamespace()
+    fake.ref_data = dict(descriptors=inp["ref_cls"], appe_descriptors=inp["ref_patch"], poses=inp["poses"],
+                         pointcloud=inp["pointcloud"])
+    fake.matching_config = types.SimpleNamespace(metric=ns.loss.PairwiseSimilarity(), aggregation_function="avg_5",
+                                                 confidence_thresh=0.2)
+    for name in ("best_template_pose", "compute_semantic_score", "compute_appearance_score",
+                 "compute_geometric_score", "project_template_to_image", "Calculate_the_query_translation"):
+        setattr(fake, name, types.MethodType(getattr(Det, name), fake))
+    rec = {}
+    with torch.no_grad():
+        rec["pairwise"] = fake.matching_config.metric(inp["qry_cls"], inp["ref_cls"]).numpy()
+        sel, pobj, sem, bt = fake.compute_semantic_score(inp["qry_cls"])
+        qp = inp["qry_patch"][sel]
+        appe, ref = fake.compute_appearance_score(bt, pobj, qp)
+        batch = dict(depth=[inp["depth"]], cam_intrinsic=[inp["K"]], depth_scale=1.0)
+        uv = fake.project_template_to_image(bt, pobj, batch, inp["masks"][sel].clone())
+        dets = types.SimpleNamespace(boxes=inp["boxes"][sel])
+        geo, vr = fake.compute_geometric_score(uv, dets, qp, ref, visible_thred=0.5)
+        final = (sem + appe + geo * vr) / (1 + 1 + vr)
+        # second geometry case: boxes that all overlap the projections -> non-degenerate IoU (quirk Q3 off)
+        xyxy = torch.cat((uv.min(1).values, uv.max(1).values), -1).float()
+        boxes2 = xyxy + torch.tensor([-3.0, -2.0, 4.0, 5.0])
+        iou2 = ns.bbox_utils.compute_iou(xyxy, boxes2)
+        rec.update(sel=sel.numpy(), pred_obj=pobj.numpy(), semantic=sem.numpy(), best_template=bt.numpy(),
+                   appearance=appe.numpy(), image_uv=uv.numpy(), visible_ratio=vr.numpy(),
+                   iou=np.asarray(geo if not torch.is_tensor(geo) else geo.numpy(), dtype=np.float32),
+                   final=final.numpy(), iou2=iou2.numpy(), boxes2=boxes2.numpy(),
+                   translation=fake.Calculate_the_query_translation(inp["masks"][sel].clone(), inp["depth"], inp["K"], 1.0).numpy())
+    rec["case"] = np.array(str(c))
+    np.savez_compressed(os.path.join(OUT, "ism_scoring.npz"), **rec)
+    print("ism_scoring.npz", {k: (v.shape if hasattr(v, "shape") else v) for k, v in rec.items()})
+    print("selected", len(rec["sel"]), "iou", rec["iou"], "vr", rec["visible_ratio"][:5], "final", rec["final"][:5])
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(os.cpu_count())
+    {"pem": gen_pem, "sam": gen_sam, "ism": gen_ism}[sys.argv[1]]()

@@ -1,0 +1,148 @@
+/*
+ * oracle/pn2_oracle.c -- TEST INFRASTRUCTURE ONLY (the parity checker).
+ *
+ * Plain-C CPU restatement of the four point-cloud ops the reference ships as
+ * a CUDA-only extension (reference: SAM-6D/Pose_Estimation_Model/model/
+ * pointnet2/_ext_src/src/{sampling,ball_query,group_points}_gpu.cu).  The reference sources cannot be built here
+ * (CUDA-only, every CPU branch is TORCH_CHECK(false)), so the oracle follows
+ * the kernels statement by statement, including the launch geometry that
+ * decides tie-breaks.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; nothing under sam6d_amd/ does.
+ *
+ * Floating-point contract: the reference is compiled by nvcc with its default
+ * --fmad=true, which contracts  a*a + b*b + c*c  into
+ * fma(c,c, fma(b,b, a*a)).  Both this oracle and the HIP kernels spell that
+ * contraction out with fmaf() and are built with -ffp-contract=off so that
+ * nothing else is fused; index outputs are therefore comparable bit for bit.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* cuda_utils.h:18-23  opt_n_threads(): largest power of two <= work_size,
+ * clamped to [1, 512]. */
+int s6d_oracle_opt_n_threads(int work_size) {
+  int p = 1;
+  if (work_size < 1) return 1;
+  while ((p << 1) <= work_size && (p << 1) <= 512) p <<= 1;
+  return p;
+}
+
+static inline float sqdist3(float ax, float ay, float az, float bx, float by,
+                            float bz) {
+  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+}
+
+/* sampling_gpu.cu:74-178 furthest_point_sampling_kernel<block_size>, host
+ * wrapper sampling.cpp:70-91 (temp initialised to 1e10, idxs zeros).
+ * xyz (B,N,3) f32 -> idx (B,M) i32.  The thread/tree structure is emulated
+ * literally: thread `tid` scans k = tid, tid+bs, ... keeping the first
+ * maximum (strict >), then a shared-memory tree where the lower slot wins
+ * ties (__update: v2 > v1 ? i2 : i1). */
+int s6d_oracle_fps(const float *xyz, int B, int N, int M, int32_t *idx) {
+  if (B < 0 || N <= 0 || M < 0) return 1;
+  if (M == 0 || B == 0) return 0;
+  const int bs = s6d_oracle_opt_n_threads(N);
+  float *temp = (float *)malloc(sizeof(float) * (size_t)N);
+  float *dists = (float *)malloc(sizeof(float) * (size_t)bs);
+  int *dists_i = (int *)malloc(sizeof(int) * (size_t)bs);
+  if (!temp || !dists || !dists_i) return 2;
+  for (int b = 0; b < B; ++b) {
+    const float *p = xyz + (size_t)b * N * 3;
+    int32_t *out = idx + (size_t)b * M;
+    for (int k = 0; k < N; ++k) temp[k] = 1e10f;
+    int old = 0;
+    out[0] = 0;
+    for (int j = 1; j < M; ++j) {
+      const float x1 = p[old * 3 + 0], y1 = p[old * 3 + 1], z1 = p[old * 3 + 2];
+      for (int tid = 0; tid < bs; ++tid) {
+        int besti = 0;
+        float best = -1.f;
+        for (int k = tid; k < N; k += bs) {
+          const float d = sqdist3(p[k * 3 + 0], p[k * 3 + 1], p[k * 3 + 2], x1, y1, z1);
+          const float d2 = d < temp[k] ? d : temp[k]; /* min(d, temp[k]) */
+          temp[k] = d2;
+          besti = d2 > best ? k : besti;
+          best = d2 > best ? d2 : best;
+        }
+        dists[tid] = best;
+        dists_i[tid] = besti;
+      }
+      for (int s = bs >> 1; s >= 1; s >>= 1) {
+        for (int tid = 0; tid < s; ++tid) {
+          const float v1 = dists[tid], v2 = dists[tid + s];
+          const int i1 = dists_i[tid], i2 = dists_i[tid + s];
+          dists[tid] = v1 > v2 ? v1 : v2; /* max(v1, v2) */
+          dists_i[tid] = v2 > v1 ? i2 : i1;
+        }
+      }
+      old = dists_i[0];
+      out[j] = old;
+    }
+  }
+  free(temp);
+  free(dists);
+  free(dists_i);
+  return 0;
+}
+
+/* sampling_gpu.cu:13-25 gather_points_kernel.
+ * points (B,C,N) f32, idx (B,M) i32 -> out (B,C,M). */
+int s6d_oracle_gather(const float *points, const int32_t *idx, int B, int C,
+                      int N, int M, float *out) {
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < C; ++c)
+      for (int j = 0; j < M; ++j) {
+        const int a = idx[(size_t)b * M + j];
+        if (a < 0 || a >= N) return 3;
+        out[((size_t)b * C + c) * M + j] = points[((size_t)b * C + c) * N + a];
+      }
+  return 0;
+}
+
+/* ball_query_gpu.cu:14-49 query_ball_point_kernel; host ball_query.cpp
+ * allocates idx with torch::zeros, so a centre with no neighbour keeps 0s.
+ * new_xyz (B,M,3), xyz (B,N,3) -> idx (B,M,nsample).  First hit is broadcast
+ * to every slot, then slots are filled in scan order; strict d2 < r*r. */
+int s6d_oracle_ball_query(const float *new_xyz, const float *xyz, int B, int N,
+                          int M, float radius, int nsample, int32_t *idx) {
+  const float r2 = radius * radius;
+  memset(idx, 0, sizeof(int32_t) * (size_t)B * M * nsample);
+  for (int b = 0; b < B; ++b) {
+    const float *q = new_xyz + (size_t)b * M * 3;
+    const float *p = xyz + (size_t)b * N * 3;
+    int32_t *o = idx + (size_t)b * M * nsample;
+    for (int j = 0; j < M; ++j) {
+      const float nx = q[j * 3 + 0], ny = q[j * 3 + 1], nz = q[j * 3 + 2];
+      int cnt = 0;
+      for (int k = 0; k < N && cnt < nsample; ++k) {
+        const float d2 = sqdist3(nx, ny, nz, p[k * 3 + 0], p[k * 3 + 1], p[k * 3 + 2]);
+        if (d2 < r2) {
+          if (cnt == 0)
+            for (int l = 0; l < nsample; ++l) o[(size_t)j * nsample + l] = k;
+          o[(size_t)j * nsample + cnt] = k;
+          ++cnt;
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+/* group_points_gpu.cu:13-33 group_points_kernel.
+ * points (B,C,N), idx (B,M,S) -> out (B,C,M,S). */
+int s6d_oracle_group_points(const float *points, const int32_t *idx, int B,
+                            int C, int N, int M, int S, float *out) {
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < C; ++c)
+      for (int j = 0; j < M; ++j)
+        for (int k = 0; k < S; ++k) {
+          const int ii = idx[((size_t)b * M + j) * S + k];
+          if (ii < 0 || ii >= N) return 3;
+          out[(((size_t)b * C + c) * M + j) * S + k] =
+              points[((size_t)b * C + c) * N + ii];
+        }
+  return 0;
+}

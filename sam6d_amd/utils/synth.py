@@ -1,0 +1,101 @@
+"""Seeded synthetic inputs for the SAM-6D per-frame hot path.
+
+No BOP data, templates or checkpoints are reachable offline, so parity tests,
+golden generation and bench.py all draw their inputs here.  Everything is
+generated on the CPU with an explicit torch.Generator, so the same arguments
+give the same tensors in the build container and on the GPU box.
+"""
+import math
+
+import torch
+
+
+def _g(seed):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(int(seed))
+    return g
+
+
+def random_rotations(B, g):
+    """Haar-distributed rotations from normalised quaternions."""
+    q = torch.randn(B, 4, generator=g)
+    q = q / q.norm(dim=1, keepdim=True)
+    w, x, y, z = q.unbind(1)
+    R = torch.stack([
+        1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+        2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+        2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1)
+    return R.reshape(B, 3, 3)
+
+
+def pem_inputs(B, seed=1, n_pts=2048, n_model=1024, feat_dim=256, img=224, with_rgb=True):
+    """One PEM batch (Net.forward keys: pts, rgb, rgb_choose, model, dense_po, dense_fo)
+    plus the ground truth of the synthetic rigid motion and a known-answer feature set.
+
+    dense_po: n_pts points uniform in a ball of radius 0.1 m (object frame);
+    pts = dense_po R^T + t + N(0, 1e-3 * 0.1);  t = (0.1, -0.05, 0.8);
+    dense_fo ~ N(0,1); ``dense_fm_kat`` = dense_fo + 0.1 N(0,1) is the known-answer
+    observed feature (bypasses the ViT): with it the matcher must recover (R, t).
+    """
+    g = _g(seed)
+    d = torch.randn(B, n_pts, 3, generator=g)
+    d = d / d.norm(dim=2, keepdim=True)
+    r = torch.rand(B, n_pts, 1, generator=g) ** (1.0 / 3.0)
+    dense_po = 0.1 * d * r
+    R = random_rotations(B, g)
+    t = torch.tensor([0.1, -0.05, 0.8]).expand(B, 3).contiguous()
+    pts = dense_po @ R.transpose(1, 2) + t.unsqueeze(1) + 1e-4 * torch.randn(B, n_pts, 3, generator=g)
+    dense_fo = torch.randn(B, n_pts, feat_dim, generator=g)
+    dense_fm_kat = dense_fo + 0.1 * torch.randn(B, n_pts, feat_dim, generator=g)
+    model = dense_po[:, torch.randperm(n_pts, generator=g)[:n_model]].contiguous()
+    out = dict(pts=pts.contiguous(), model=model, dense_po=dense_po.contiguous(), dense_fo=dense_fo,
+               gt_R=R, gt_t=t, dense_fm_kat=dense_fm_kat)
+    if with_rgb:
+        out["rgb"] = torch.randn(B, 3, img, img, generator=g)
+        out["rgb_choose"] = torch.randint(0, img * img, (B, n_pts), generator=g)
+    return out
+
+
+def coarse_uniforms(B, seed=1, n=18000):
+    """The uniform samples compute_coarse_Rt draws (model_utils.py:219): an INPUT here.
+    Equal to ``torch.manual_seed(seed); torch.rand(B, n)`` on the CPU generator."""
+    return torch.rand(B, n, generator=_g(seed))
+
+
+def sam_input(B=1, seed=1, size=1024):
+    return torch.randn(B, 3, size, size, generator=_g(seed))
+
+
+def ism_inputs(P=128, O=8, T=42, C=1024, n_patch=256, H=480, W=640, seed=1, n_model_pts=2048):
+    """Proposal / reference descriptors and masks for the ISM scoring path (a6-a9)."""
+    g = _g(seed)
+    ref_cls = torch.randn(O, T, C, generator=g)
+    # make every proposal resemble one (object, template) so that thresholds are exercised
+    obj = torch.randint(0, O, (P,), generator=g)
+    tem = torch.randint(0, T, (P,), generator=g)
+    mix = torch.rand(P, 1, generator=g)
+    qry_cls = mix * ref_cls[obj, tem] + (1 - mix) * torch.randn(P, C, generator=g)
+    ref_patch = torch.nn.functional.normalize(torch.randn(O, T, n_patch, C, generator=g), dim=-1)
+    ref_patch = ref_patch * (torch.rand(O, T, n_patch, 1, generator=g) > 0.3)
+    qry_patch = torch.nn.functional.normalize(
+        0.7 * ref_patch[obj, tem] + 0.3 * torch.nn.functional.normalize(torch.randn(P, n_patch, C, generator=g), dim=-1),
+        dim=-1)
+    qry_patch = qry_patch * (torch.rand(P, n_patch, 1, generator=g) > 0.3)
+    # axis-aligned box masks and boxes (xyxy)
+    x0 = torch.randint(0, W - 80, (P,), generator=g)
+    y0 = torch.randint(0, H - 80, (P,), generator=g)
+    bw = torch.randint(24, 80, (P,), generator=g)
+    bh = torch.randint(24, 80, (P,), generator=g)
+    ys = torch.arange(H).view(1, H, 1)
+    xs = torch.arange(W).view(1, 1, W)
+    masks = ((ys >= y0.view(-1, 1, 1)) & (ys < (y0 + bh).view(-1, 1, 1)) &
+             (xs >= x0.view(-1, 1, 1)) & (xs < (x0 + bw).view(-1, 1, 1))).float()
+    boxes = torch.stack([x0, y0, x0 + bw - 1, y0 + bh - 1], 1).float()
+    depth = (1000.0 + 50.0 * torch.rand(H, W, generator=g)).round()
+    depth[torch.rand(H, W, generator=g) < 0.05] = 0  # holes
+    K = torch.tensor([[572.4114, 0.0, 325.2611], [0.0, 573.57043, 242.04899], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    pc = 0.05 * torch.randn(O, n_model_pts, 3, generator=g)
+    poses = torch.eye(4).repeat(T, 1, 1)
+    poses[:, :3, :3] = random_rotations(T, g)
+    return dict(qry_cls=qry_cls, ref_cls=ref_cls, qry_patch=qry_patch, ref_patch=ref_patch, masks=masks,
+                boxes=boxes, depth=depth, K=K, pointcloud=pc, poses=poses, gt_obj=obj, gt_tem=tem)

@@ -1,0 +1,181 @@
+"""Pins the CPU oracle (oracle/*.py, oracle/pn2_oracle.c) against the golden fixtures that
+oracle/gen_golden.py produced from the reference's own modules.  CPU only."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ism as oism
+from oracle import pem as opem
+from oracle import pn2 as opn2
+from oracle import sam as osam
+from sam6d_amd.utils import seeded, synth
+from tests import util
+
+
+@pytest.fixture(scope="module")
+def pem_case():
+    g = util.golden("pem_b2.npz")
+    case = ast.literal_eval(str(g["case"]))
+    W = util.pem_weights(case["weight_seed"])
+    inp = synth.pem_inputs(case["B"], seed=case["input_seed"])
+    return g, case, W, inp
+
+
+def test_pem_net_forward_matches_reference(pem_case):
+    g, case, W, inp = pem_case
+    ep = {k: inp[k] for k in ("pts", "rgb", "rgb_choose", "model", "dense_po", "dense_fo")}
+    with torch.no_grad():
+        out = opem.net_forward(W, ep, synth.coarse_uniforms(case["B"], case["rand_seed"]), True)
+    for k in ("init_R", "init_t", "pred_R", "pred_t", "pred_pose_score"):
+        np.testing.assert_allclose(out[k].numpy(), g["net_" + k], rtol=0, atol=1e-6, err_msg=k)
+    util.assert_digest_close(out["dense_fm"], g["fe_dense_fm_sum"], g["fe_dense_fm_smp"], 97, 1e-5, 1e-6, "dense_fm")
+
+
+def test_pem_known_answer_matches_reference_and_truth(pem_case):
+    g, case, W, inp = pem_case
+    radius = torch.norm(inp["dense_po"], dim=2).max(1)[0]
+    s = radius.reshape(-1, 1, 1) + 1e-6
+    with torch.no_grad():
+        out = opem.matching_forward(W, inp["pts"] / s, inp["dense_fm_kat"], inp["dense_po"] / s, inp["dense_fo"],
+                                    radius, inp["model"], synth.coarse_uniforms(case["B"], case["rand_seed"]), True)
+    assert np.array_equal(out["fps_idx_m"].numpy(), g["kat_fps_idx_m"])
+    assert np.array_equal(out["fps_idx_o"].numpy(), g["kat_fps_idx_o"])
+    util.assert_digest_close(out["geo_m"], g["kat_geo_m_sum"], g["kat_geo_m_smp"], 9973, 1e-5, 1e-6, "geo_m")
+    for k in ("init_R", "init_t", "pred_R", "pred_t", "pred_pose_score"):
+        np.testing.assert_allclose(out[k].numpy(), g["kat_" + k], rtol=0, atol=1e-6, err_msg=k)
+    # known answer: the synthetic rigid motion is recovered
+    assert np.linalg.norm(out["pred_R"].numpy() - g["kat_gt_R"], axis=(1, 2)).max() < 1e-3
+    assert np.abs(out["pred_t"].numpy() - g["kat_gt_t"]).max() < 1e-4
+
+
+def test_pem_positional_encoding_matches_reference(pem_case):
+    g, case, W, inp = pem_case
+    radius = torch.norm(inp["dense_po"], dim=2).max(1)[0]
+    with torch.no_grad():
+        pe = opem.positional_encoding(W, "fine_point_matching.PE", inp["dense_po"] / (radius.reshape(-1, 1, 1) + 1e-6))
+    util.assert_digest_close(pe, g["pe_sum"], g["pe_smp"], 997, 1e-5, 1e-6, "PE")
+
+
+def test_sam_mini_encoder_matches_reference():
+    g = util.golden("sam_enc.npz")
+    ref = _sam_shapes(osam.MINI)
+    assert sorted(ref) == [str(k) for k in g["mini_keys"]]
+    W = seeded.seeded_state(ref, 3)
+    with torch.no_grad():
+        y = osam.encoder_forward(W, synth.sam_input(1, 5, osam.MINI["img_size"]), osam.MINI)
+    np.testing.assert_allclose(y.numpy(), g["mini_out"], rtol=1e-4, atol=1e-5)
+
+
+def _sam_shapes(cfg):
+    """state_dict surface of ImageEncoderViT (image_encoder.py:58-104,151-162,212-222)."""
+    D, n = cfg["dim"], cfg["img_size"] // cfg["patch"]
+    hd = D // cfg["heads"]
+    s = {"pos_embed": (1, n, n, D), "patch_embed.proj.weight": (D, 3, 16, 16), "patch_embed.proj.bias": (D,),
+         "neck.0.weight": (cfg["out_chans"], D, 1, 1), "neck.1.weight": (cfg["out_chans"],), "neck.1.bias": (cfg["out_chans"],),
+         "neck.2.weight": (cfg["out_chans"], cfg["out_chans"], 3, 3), "neck.3.weight": (cfg["out_chans"],),
+         "neck.3.bias": (cfg["out_chans"],)}
+    for i in range(cfg["depth"]):
+        L = (2 * n - 1) if i in cfg["global_idx"] else (2 * cfg["window"] - 1)
+        p = f"blocks.{i}."
+        s.update({p + "norm1.weight": (D,), p + "norm1.bias": (D,), p + "norm2.weight": (D,), p + "norm2.bias": (D,),
+                  p + "attn.qkv.weight": (3 * D, D), p + "attn.qkv.bias": (3 * D,), p + "attn.proj.weight": (D, D),
+                  p + "attn.proj.bias": (D,), p + "attn.rel_pos_h": (L, hd), p + "attn.rel_pos_w": (L, hd),
+                  p + "mlp.lin1.weight": (4 * D, D), p + "mlp.lin1.bias": (4 * D,), p + "mlp.lin2.weight": (D, 4 * D),
+                  p + "mlp.lin2.bias": (D,)})
+    return s
+
+
+@pytest.mark.slow
+def test_sam_vit_h_encoder_matches_reference():
+    g = util.golden("sam_enc.npz")
+    shapes = util.shapes_from_golden(g, "h_keys", "h_shapes")
+    assert shapes == {k: tuple(v) for k, v in _sam_shapes(osam.VIT_H).items()}
+    W = seeded.seeded_state(shapes, 3)
+    x = synth.sam_input(1, 5, 1024)
+    with torch.no_grad():
+        t = osam.encoder_forward(W, x, osam.VIT_H, upto=2)
+        util.assert_digest_close(t, g["h_blk2_sum"], g["h_blk2_smp"], 1009, 1e-4, 1e-5, "blk2")
+        y = osam.encoder_forward(W, x, osam.VIT_H)
+    util.assert_digest_close(y, g["h_sum"], g["h_smp"], 251, 1e-3, 1e-4, "vit-h out")
+
+
+def test_ism_scoring_matches_reference():
+    g = util.golden("ism_scoring.npz")
+    c = ast.literal_eval(str(g["case"]))
+    inp = synth.ism_inputs(P=c["P"], O=c["O"], T=c["T"], seed=c["seed"])
+    np.testing.assert_allclose(oism.pairwise_similarity(inp["qry_cls"], inp["ref_cls"]).numpy(), g["pairwise"], atol=1e-6)
+    out = oism.score_frame(inp)
+    assert np.array_equal(out["sel"].numpy(), g["sel"])
+    assert np.array_equal(out["pred_obj"].numpy(), g["pred_obj"])
+    assert np.array_equal(out["best_template"].numpy(), g["best_template"])
+    assert np.array_equal(out["image_uv"].numpy(), g["image_uv"])
+    for k in ("semantic", "appearance", "visible_ratio", "iou", "final"):
+        np.testing.assert_allclose(out[k].numpy(), g[k], rtol=1e-6, atol=1e-6, err_msg=k)
+    t = oism.mean_translation(inp["masks"][out["sel"]], inp["depth"], inp["K"])
+    np.testing.assert_allclose(t.numpy(), g["translation"], rtol=1e-6, atol=1e-7)
+    xyxy = torch.cat((out["image_uv"].min(1).values, out["image_uv"].max(1).values), -1).float()
+    np.testing.assert_allclose(oism.compute_iou(xyxy, torch.from_numpy(g["boxes2"])).numpy(), g["iou2"], rtol=1e-6)
+    # quirk Q3: one empty intersection zeroes everything
+    b = torch.from_numpy(g["boxes2"]).clone()
+    b[0] = torch.tensor([0.0, 0.0, 1.0, 1.0]) + 10000
+    assert oism.compute_iou(xyxy, b) == 0.0
+
+
+# ----------------------------------------------------------------------------- PN2 (no reference vectors exist)
+def _fps_numpy(p, m):
+    """Independent restatement (float32 numpy, first-max) -- agrees with the tree emulation
+    whenever no exact distance ties occur (true for continuous random clouds)."""
+    n = p.shape[0]
+    temp = np.full(n, 1e10, np.float32)
+    out = np.zeros(m, np.int32)
+    for j in range(1, m):
+        d = p - p[out[j - 1]]
+        d0 = d[:, 0] * d[:, 0]
+        d1 = np.float32(np.float64(d[:, 1]) * np.float64(d[:, 1]) + np.float64(d0))      # fma: one rounding
+        d2 = np.float32(np.float64(d[:, 2]) * np.float64(d[:, 2]) + np.float64(d1))
+        temp = np.minimum(temp, d2)
+        out[j] = int(np.argmax(temp))
+    return out
+
+
+def test_pn2_fps_semantics():
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(3, 700, 3, generator=g)
+    idx = opn2.furthest_point_sampling(x, 64).numpy()
+    for b in range(3):
+        assert np.array_equal(idx[b], _fps_numpy(x[b].numpy(), 64))
+    # tie-break: all points identical -> every distance ties at 0 -> slot 0 of the tree wins
+    z = torch.zeros(1, 600, 3)
+    assert np.array_equal(opn2.furthest_point_sampling(z, 5).numpy(), np.zeros((1, 5), np.int32))
+    # duplicated far point: lowest (k mod block_size, k) wins; n=600 -> block 512
+    y = torch.zeros(1, 600, 3)
+    y[0, 520] = 1.0  # tid 8
+    y[0, 9] = 1.0    # tid 9
+    assert opn2.furthest_point_sampling(y, 2).numpy()[0, 1] == 520
+    assert opn2.lib().s6d_oracle_opt_n_threads(2048) == 512 and opn2.lib().s6d_oracle_opt_n_threads(196) == 128
+
+
+def test_pn2_ball_query_group_gather_semantics():
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(2, 300, 3, generator=g)
+    q = x[:, :50].contiguous()
+    idx = opn2.ball_query(q, x, 0.2, 16).numpy()
+    d2 = ((q[:, :, None] - x[:, None]) ** 2).sum(-1).numpy()
+    for b in range(2):
+        for j in range(50):
+            hits = np.nonzero(d2[b, j] < np.float32(0.2) ** 2 - 1e-6)[0][:16]
+            assert len(hits) > 0  # the centre itself
+            exp = np.full(16, hits[0])
+            exp[: len(hits)] = hits
+            # boundary points (|d2 - r2| < 1e-6) may differ by rounding; none in this seed
+            assert np.array_equal(idx[b, j], exp)
+    far = torch.full((1, 4, 3), 50.0)
+    assert np.array_equal(opn2.ball_query(far, x[:1], 0.2, 8).numpy(), np.zeros((1, 4, 8), np.int32))
+    ch = x.transpose(1, 2).contiguous()
+    ti = torch.from_numpy(idx)
+    grp = opn2.group_points(ch, ti)
+    assert torch.equal(grp, torch.gather(ch.unsqueeze(2).expand(-1, -1, 50, -1), 3, ti.long().unsqueeze(1).expand(-1, 3, -1, -1)))
+    gi = torch.randint(0, 300, (2, 40), generator=g, dtype=torch.int32)
+    assert torch.equal(opn2.gather_points(ch, gi), torch.gather(ch, 2, gi.long().unsqueeze(1).expand(-1, 3, -1)))

@@ -1,0 +1,37 @@
+"""Shared helpers for the test-suite (golden fixtures, seeded weights)."""
+import ast
+import os
+
+import numpy as np
+import torch
+
+from sam6d_amd.utils import seeded
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def shapes_from_golden(g, keys="state_keys", shapes="state_shapes"):
+    return {str(k): ast.literal_eval(str(s)) for k, s in zip(g[keys], g[shapes])}
+
+
+def pem_weights(seed=1):
+    """Flat {reference state_dict key: tensor}; constructor-computed buffers added by hand."""
+    g = golden("pem_b2.npz")
+    W = seeded.seeded_state(shapes_from_golden(g), seed)
+    return W
+
+
+def digest(t, stride):
+    t = t.detach().double().reshape(-1).cpu()
+    return np.array([t.sum().item(), t.abs().sum().item()]), t[::stride].float().numpy()
+
+
+def assert_digest_close(t, gsum, gsmp, stride, rtol, atol, what=""):
+    s, smp = digest(t, stride)
+    np.testing.assert_allclose(smp, gsmp, rtol=rtol, atol=atol, err_msg=f"{what}: strided sample")
+    # abs-sum compared relatively (sum itself may cancel)
+    assert abs(s[1] - gsum[1]) <= rtol * abs(gsum[1]) + atol * t.numel(), f"{what}: abs-sum {s[1]} vs {gsum[1]}"

@@ -1,0 +1,72 @@
+/*
+ * sam6d_hip.h -- C ABI of libsam6d_hip.so: the MI355X (gfx950) hot path of SAM-6D.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *     the name ends in _host.  Tensors are dense, row-major, in the layout the
+ *     comment gives.  No ownership is taken; outputs are caller-allocated.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  All
+ *     entry points only enqueue work on that stream; none synchronises.
+ *   - return value: S6D_OK (0) or a negative S6D_E* code; s6d_strerror() names
+ *     it.  Unlike the reference extension (cuda_utils.h:35-44: launch failure
+ *     -> exit(-1)) a failed launch is reported to the caller.
+ *
+ * Each entry point cites the reference interface it replaces
+ * (paths relative to SAM-6D/ in the reference tree).
+ */
+#ifndef SAM6D_HIP_H
+#define SAM6D_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S6D_OK 0
+#define S6D_EINVAL (-1)   /* bad size / null pointer / unsupported shape */
+#define S6D_ELAUNCH (-2)  /* hipLaunchKernel / hipGetLastError failure    */
+#define S6D_EUNSUPPORTED (-3)
+
+int s6d_version(void);
+const char *s6d_strerror(int code);
+/* last HIP error string seen by this thread (empty if none) */
+const char *s6d_last_hip_error(void);
+
+/* ---------------------------------------------------------------- PointNet++ ops
+ * Replace pybind module pointnet2._ext
+ * (Pose_Estimation_Model/model/pointnet2/_ext_src/src/bindings.cpp:11-24). */
+
+/* furthest_point_sampling(points (B,N,3) f32, nsamples) -> idx (B,M) i32
+ * ref: _ext_src/src/sampling.cpp:70-91, sampling_gpu.cu:74-178.
+ * `tmp` (B*N f32 scratch) is only needed when N > 4096 (may be NULL otherwise).
+ * Bit-exact with the reference's selection rule incl. its tie-break
+ * (lowest k mod opt_n_threads(N), then lowest k). */
+int s6d_fps_f32(const float *xyz, int B, int N, int M, float *tmp, int32_t *idx, void *stream);
+
+/* gather_points(points (B,C,N) f32, idx (B,M) i32) -> out (B,C,M)
+ * ref: _ext_src/src/sampling.cpp:18-43, sampling_gpu.cu:13-25. */
+int s6d_gather_points_f32(const float *points, const int32_t *idx, int B, int C, int N, int M,
+                          float *out, void *stream);
+
+/* ball_query(new_xyz (B,M,3), xyz (B,N,3), radius, nsample) -> idx (B,M,nsample) i32
+ * ref: _ext_src/src/ball_query.cpp:13-37, ball_query_gpu.cu:14-49 (first-hit fill,
+ * strict d2 < r*r, zeros when a centre has no neighbour). */
+int s6d_ball_query_f32(const float *new_xyz, const float *xyz, int B, int N, int M, float radius,
+                       int nsample, int32_t *idx, void *stream);
+
+/* group_points(points (B,C,N) f32, idx (B,M,S) i32) -> out (B,C,M,S)
+ * ref: _ext_src/src/group_points.cpp:14-38, group_points_gpu.cu:13-33. */
+int s6d_group_points_f32(const float *points, const int32_t *idx, int B, int C, int N, int M, int S,
+                         float *out, void *stream);
+
+/* Row gather used by the product modules instead of transpose+gather_points+transpose
+ * (Pose_Estimation_Model/utils/model_utils.py:53-66, model/transformer.py:651-658):
+ * src (B,N,C) f32, idx (B,M) i32 -> out (B,M,C). */
+int s6d_gather_rows_f32(const float *src, const int32_t *idx, int B, int N, int C, int M, float *out,
+                        void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAM6D_HIP_H */

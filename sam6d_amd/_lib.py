@@ -1,0 +1,84 @@
+"""Build + load libsam6d_hip.so (the C-ABI library declared in include/sam6d_hip.h).
+
+The library is built in-tree with hipcc for gfx950 (cross-compiles without a GPU) and
+loaded with ctypes.  There is NO CPU fallback: if the library is missing or fails to
+load, importing any op raises.
+"""
+import ctypes
+import glob
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(_HERE, "libsam6d_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+
+_lib = None
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(_CSRC, "*.hip")))
+
+
+def _stale():
+    if not os.path.exists(SO_PATH):
+        return True
+    t = os.path.getmtime(SO_PATH)
+    deps = sources() + glob.glob(os.path.join(_CSRC, "*.h")) + glob.glob(os.path.join(_HERE, "..", "include", "*.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every csrc/*.hip into libsam6d_hip.so (gfx950)."""
+    if not force and not _stale():
+        return SO_PATH
+    if not os.path.exists(HIPCC):
+        raise RuntimeError(f"hipcc not found at {HIPCC}; cannot build libsam6d_hip.so")
+    cmd = [HIPCC] + FLAGS + ["-o", SO_PATH] + sources()
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=_CSRC)
+    return SO_PATH
+
+
+def lib():
+    """The loaded library.  torch is imported first so that the HIP runtime torch ships
+    (same soname libamdhip64.so.7) is the one this library binds to: streams and device
+    pointers are then shared with torch."""
+    global _lib
+    if _lib is None:
+        import torch  # noqa: F401  (must precede the CDLL)
+
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(the HIP extension is mandatory; there is no fallback path)")
+        L = ctypes.CDLL(SO_PATH)
+        L.s6d_strerror.restype = ctypes.c_char_p
+        L.s6d_strerror.argtypes = [ctypes.c_int]
+        L.s6d_last_hip_error.restype = ctypes.c_char_p
+        L.s6d_version.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+class S6DError(RuntimeError):
+    pass
+
+
+def check(code, what):
+    if code != 0:
+        L = lib()
+        raise S6DError(f"{what}: {L.s6d_strerror(code).decode()} [{L.s6d_last_hip_error().decode()}]")
+
+
+def declared_symbols():
+    """Entry points declared in include/sam6d_hip.h (used by the export test)."""
+    import re
+
+    hdr = open(os.path.join(_HERE, "..", "include", "sam6d_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(s6d_[a-z0-9_]+)\s*\(", hdr)))

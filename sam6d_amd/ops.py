@@ -1,0 +1,96 @@
+"""Thin torch-tensor front-end of the C ABI (include/sam6d_hip.h).
+
+torch is plumbing here: device memory, the current HIP stream and dtype/shape checks.
+Every function enqueues hand-written gfx950 kernels on torch's current stream and
+returns freshly allocated outputs; none of them has a CPU implementation.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_vp = ctypes.c_void_p
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return _vp(t.data_ptr())
+
+
+def _chk(t, dtype, name, ndim=None):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")  # same wording as the reference's CHECK_CUDA
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be a contiguous tensor")
+    if t.dtype != dtype:
+        kind = {torch.float32: "a float", torch.int32: "an int", torch.bfloat16: "a bfloat16"}.get(dtype, str(dtype))
+        raise RuntimeError(f"{name} must be {kind} tensor")
+    if ndim is not None and t.dim() != ndim:
+        raise RuntimeError(f"{name} must have {ndim} dimensions")
+
+
+def _call(fn_name, *args):
+    fn = getattr(_lib.lib(), fn_name)
+    fn.restype = ctypes.c_int
+    _lib.check(fn(*args), fn_name)
+
+
+# ------------------------------------------------------------------ PointNet++ ops
+def furthest_point_sampling(points, nsamples):
+    """(B,N,3) f32 -> (B,nsamples) i32   [pointnet2._ext.furthest_point_sampling]"""
+    _chk(points, torch.float32, "points", 3)
+    B, N, _ = points.shape
+    out = torch.empty(B, nsamples, dtype=torch.int32, device=points.device)
+    tmp = torch.empty(B, N, dtype=torch.float32, device=points.device) if N > 4096 else None
+    _call("s6d_fps_f32", _ptr(points), B, N, int(nsamples), _ptr(tmp) if tmp is not None else _vp(0), _ptr(out),
+          _stream())
+    return out
+
+
+def gather_points(points, idx):
+    """(B,C,N) f32, (B,M) i32 -> (B,C,M)   [pointnet2._ext.gather_points]"""
+    _chk(points, torch.float32, "points", 3)
+    _chk(idx, torch.int32, "idx", 2)
+    B, C, N = points.shape
+    M = idx.shape[1]
+    out = torch.empty(B, C, M, dtype=torch.float32, device=points.device)
+    _call("s6d_gather_points_f32", _ptr(points), _ptr(idx), B, C, N, M, _ptr(out), _stream())
+    return out
+
+
+def gather_rows(src, idx):
+    """(B,N,C) f32, (B,M) i32 -> (B,M,C)."""
+    _chk(src, torch.float32, "src", 3)
+    _chk(idx, torch.int32, "idx", 2)
+    B, N, C = src.shape
+    M = idx.shape[1]
+    out = torch.empty(B, M, C, dtype=torch.float32, device=src.device)
+    _call("s6d_gather_rows_f32", _ptr(src), _ptr(idx), B, N, C, M, _ptr(out), _stream())
+    return out
+
+
+def ball_query(new_xyz, xyz, radius, nsample):
+    """(B,M,3), (B,N,3) -> (B,M,nsample) i32   [pointnet2._ext.ball_query]"""
+    _chk(new_xyz, torch.float32, "new_xyz", 3)
+    _chk(xyz, torch.float32, "xyz", 3)
+    B, M, _ = new_xyz.shape
+    N = xyz.shape[1]
+    out = torch.empty(B, M, int(nsample), dtype=torch.int32, device=xyz.device)
+    _call("s6d_ball_query_f32", _ptr(new_xyz), _ptr(xyz), B, N, M, ctypes.c_float(radius), int(nsample), _ptr(out),
+          _stream())
+    return out
+
+
+def group_points(points, idx):
+    """(B,C,N) f32, (B,M,S) i32 -> (B,C,M,S)   [pointnet2._ext.group_points]"""
+    _chk(points, torch.float32, "points", 3)
+    _chk(idx, torch.int32, "idx", 3)
+    B, C, N = points.shape
+    _, M, S = idx.shape
+    out = torch.empty(B, C, M, S, dtype=torch.float32, device=points.device)
+    _call("s6d_group_points_f32", _ptr(points), _ptr(idx), B, C, N, M, S, _ptr(out), _stream())
+    return out

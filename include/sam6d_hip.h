@@ -40,8 +40,9 @@ const char *s6d_last_hip_error(void);
 /* furthest_point_sampling(points (B,N,3) f32, nsamples) -> idx (B,M) i32
  * ref: _ext_src/src/sampling.cpp:70-91, sampling_gpu.cu:74-178.
  * `tmp` (B*N f32 scratch) is only needed when N > 4096 (may be NULL otherwise).
- * Bit-exact with the reference's selection rule incl. its tie-break
- * (lowest k mod opt_n_threads(N), then lowest k). */
+ * Bit-exact with the reference's selection rule incl. its tie-break (ties go to the
+ * smallest bit-reversed slot k mod opt_n_threads(N) of the shared-memory tree, then
+ * to the lowest k). */
 int s6d_fps_f32(const float *xyz, int B, int N, int M, float *tmp, int32_t *idx, void *stream);
 
 /* gather_points(points (B,C,N) f32, idx (B,M) i32) -> out (B,C,M)

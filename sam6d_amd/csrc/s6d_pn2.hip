@@ -19,18 +19,24 @@ __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx,
   return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
 }
 
-// Selection key: larger distance wins; ties -> lower (k mod ref_bs), then lower k, which is
-// what the reference's per-thread strict '>' scan plus lower-slot-wins tree produce
-// (sampling_gpu.cu:64-70,113-114) for block size ref_bs = opt_n_threads(N).
+// Selection key: larger distance wins.  Ties follow the reference's reduction exactly: a thread
+// keeps its FIRST maximum (strict '>', sampling_gpu.cu:113-114) and the shared-memory tree
+// halves the stride from block_size/2 down to 1 with the lower slot winning (__update,
+// :64-70), so two tied slots meet at the stride of their lowest differing bit and the slot
+// whose bit is 0 survives: the winner is the smallest BIT-REVERSED slot id, then the lowest k
+// within that thread.  ref_bs = opt_n_threads(N) (cuda_utils.h:18-23).
 __device__ __forceinline__ unsigned long long fps_key(float d, int k, int ref_bs_log2) {
   const unsigned tid = (unsigned)k & ((1u << ref_bs_log2) - 1u);
+  const unsigned rev = ref_bs_log2 ? (__brev(tid) >> (32 - ref_bs_log2)) : 0u;
   const unsigned q = (unsigned)k >> ref_bs_log2;
-  const unsigned tie = (tid << 22) | q;  // q < 2^22  <=>  N < 2^31 for ref_bs = 512
+  const unsigned tie = (rev << 22) | q;  // q < 2^22  <=>  N < 2^31 for ref_bs = 512
   return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(0xffffffffu - tie);
 }
 __device__ __forceinline__ int fps_key_index(unsigned long long key, int ref_bs_log2) {
   const unsigned tie = 0xffffffffu - (unsigned)(key & 0xffffffffull);
-  return (int)(((tie & 0x3fffffu) << ref_bs_log2) | (tie >> 22));
+  const unsigned rev = tie >> 22;
+  const unsigned tid = ref_bs_log2 ? (__brev(rev) >> (32 - ref_bs_log2)) : 0u;
+  return (int)(((tie & 0x3fffffu) << ref_bs_log2) | tid);
 }
 
 // One workgroup per cloud; the cloud and its running min-distances live in registers

@@ -41,6 +41,10 @@ def test_fps_tie_break_rule(ops):
     y[0, 520] = 1.0
     y[0, 9] = 1.0
     assert ops.furthest_point_sampling(y.cuda(), 2).cpu()[0, 1].item() == 520
+    w = torch.zeros(1, 700, 3)
+    w[0, 180] = 1.0
+    w[0, 530] = 1.0
+    assert ops.furthest_point_sampling(w.cuda(), 2).cpu()[0, 1].item() == 180  # bit-reversed slot order
     z = torch.zeros(2, 2048, 3)
     assert torch.equal(ops.furthest_point_sampling(z.cuda(), 7).cpu(), torch.zeros(2, 7, dtype=torch.int32))
 

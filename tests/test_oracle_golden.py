@@ -154,6 +154,12 @@ def test_pn2_fps_semantics():
     y[0, 520] = 1.0  # tid 8
     y[0, 9] = 1.0    # tid 9
     assert opn2.furthest_point_sampling(y, 2).numpy()[0, 1] == 520
+    # tree order is NOT lowest-slot-first: slots 18 and 180 meet at stride 2 where 180's lineage
+    # sits in slot 0 -> k=180 beats k=530 (slot 18); (smallest bit-reversed slot id wins)
+    w = torch.zeros(1, 700, 3)
+    w[0, 180] = 1.0
+    w[0, 530] = 1.0
+    assert opn2.furthest_point_sampling(w, 2).numpy()[0, 1] == 180
     assert opn2.lib().s6d_oracle_opt_n_threads(2048) == 512 and opn2.lib().s6d_oracle_opt_n_threads(196) == 128
 
 

@@ -94,3 +94,23 @@ def group_points(points, idx):
     out = torch.empty(B, C, M, S, dtype=torch.float32, device=points.device)
     _call("s6d_group_points_f32", _ptr(points), _ptr(idx), B, C, N, M, S, _ptr(out), _stream())
     return out
+
+
+# ------------------------------------------------------------------ fused-op registry
+# Names of fused gfx950 ops the loaded library exports.  Product modules ask ``have(name)``
+# and otherwise express the same math with library GEMMs on the device (never on the CPU).
+_FUSED = {}
+
+
+def have(name):
+    if name not in _FUSED:
+        sym = {"rpe_attention": "s6d_rpe_attention_f32", "geo_embedding": "s6d_geo_embedding_f32",
+               "fine_assign": "s6d_fine_assign_f32", "upsample_gather": "s6d_upsample_gather_f32",
+               "min_dist": "s6d_min_dist_f32", "win_attention": "s6d_win_attention_bf16",
+               "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
+               "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
+               "pe_group": "s6d_pe_group_f32", "masked_depth_mean": "s6d_masked_depth_mean_f32"}.get(name)
+        import os
+        disabled = name in os.environ.get("S6D_DISABLE_FUSED", "").split(",")
+        _FUSED[name] = (not disabled) and sym is not None and hasattr(_lib.lib(), sym)
+    return _FUSED[name]

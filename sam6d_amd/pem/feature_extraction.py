@@ -1,0 +1,201 @@
+"""ViT feature extractor of the Pose Estimation Model, MI355X build.
+
+State-dict surface follows Pose_Estimation_Model/model/feature_extraction.py (ViT / ViT_AE /
+ViTEncoder) on top of timm's VisionTransformer naming (cls_token, pos_embed,
+patch_embed.proj, blocks.N.{norm1,attn.qkv,attn.proj,norm2,mlp.fc1,mlp.fc2}, norm, head);
+timm itself is not needed.
+
+Hardware-first differences from the reference forward:
+  * the (B,256,224,224) bilinearly upsampled map (51 MB per instance) is never built: the
+    2048 chosen pixels are interpolated straight out of the (B,196,16*256) up-projection
+    (feature_extraction.py:111-114 + model_utils.py:69-81 fused).
+  * compute dtype is configurable (``S6D_PEM_VIT_DTYPE`` = fp32 | bf16, default fp32).
+"""
+import os
+from functools import partial
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+def _vit_dtype():
+    return {"fp32": torch.float32, "bf16": torch.bfloat16}[os.environ.get("S6D_PEM_VIT_DTYPE", "fp32")]
+
+
+class _Attn(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.num_heads = heads
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        hd = C // self.num_heads
+        qkv = self.qkv(x).view(B, N, 3, self.num_heads, hd).permute(2, 0, 3, 1, 4)
+        a = torch.softmax((qkv[0] * hd ** -0.5) @ qkv[1].transpose(-1, -2), dim=-1)
+        return self.proj((a @ qkv[2]).transpose(1, 2).reshape(B, N, C))
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(x)))
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, heads, mlp_ratio, norm_layer):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = _Attn(dim, heads)
+        self.norm2 = norm_layer(dim)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+
+    def forward(self, x):
+        x = x + self.attn(self.norm1(x))
+        return x + self.mlp(self.norm2(x))
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, patch, dim):
+        super().__init__()
+        self.proj = nn.Conv2d(3, dim, kernel_size=patch, stride=patch)
+
+
+class ViT(nn.Module):
+    """feature_extraction.py:17-35: returns norm(x) after blocks d-3n-1, d-2n-1, d-n-1, d-1."""
+
+    def __init__(self, patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True,
+                 norm_layer=None, img_size=224, num_classes=1000):
+        super().__init__()
+        norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)
+        self.patch_embed = _PatchEmbed(patch_size, embed_dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, (img_size // patch_size) ** 2 + 1, embed_dim))
+        self.blocks = nn.ModuleList([_Block(embed_dim, num_heads, mlp_ratio, norm_layer) for _ in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.head = nn.Linear(embed_dim, num_classes)  # present in the checkpoint, unused here
+        self.patch = patch_size
+
+    def forward(self, x):
+        B = x.shape[0]
+        p = self.patch
+        # 16x16/16 conv == GEMM on unfolded patches
+        h = x.shape[2] // p
+        x = x.view(B, 3, h, p, h, p).permute(0, 2, 4, 1, 3, 5).reshape(B, h * h, 3 * p * p)
+        x = F.linear(x, self.patch_embed.proj.weight.view(self.patch_embed.proj.weight.shape[0], -1),
+                     self.patch_embed.proj.bias)
+        x = torch.cat([self.cls_token.expand(B, -1, -1), x], dim=1) + self.pos_embed
+        d = len(self.blocks)
+        n = d // 4
+        taps = (d - 3 * n - 1, d - 2 * n - 1, d - n - 1, d - 1)
+        out = []
+        for i, blk in enumerate(self.blocks):
+            x = blk(x)
+            if i in taps:
+                out.append(self.norm(x))
+        return out
+
+
+class ViT_AE(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        assert cfg.vit_type == "vit_base" and cfg.up_type == "linear" and cfg.use_pyramid_feat, \
+            "MI355X build covers the released configuration (config/base.yaml:19-25)"
+        self.embed_dim, self.out_dim = cfg.embed_dim, cfg.out_dim
+        self.vit = ViT(patch_size=16, embed_dim=cfg.embed_dim, depth=12, num_heads=12, mlp_ratio=4)
+        self.output_upscaling = nn.Linear(cfg.embed_dim * 4, 16 * cfg.out_dim, bias=True)
+
+    def tokens_up(self, x):
+        """(B,3,224,224) -> (B,196,16*out_dim): the up-projection before pixel shuffle."""
+        dt = _vit_dtype()
+        if dt != torch.float32:
+            with torch.autocast(device_type=x.device.type, dtype=dt):
+                taps = self.vit(x)
+                return self.output_upscaling(torch.cat([t[:, 1:] for t in taps], dim=2)).float()
+        taps = self.vit(x)
+        return self.output_upscaling(torch.cat([t[:, 1:] for t in taps], dim=2))
+
+    def forward(self, x):
+        """Reference-shaped output (B,out_dim,H,W) + cls tokens (feature_extraction.py:98-117);
+        only used by callers that want the dense map.  The hot path uses sample()."""
+        B, _, H, W = x.shape
+        taps = self.vit(x)
+        up = self.output_upscaling(torch.cat([t[:, 1:] for t in taps], dim=2))
+        m = up.view(B, 14, 14, 4, 4, self.out_dim).permute(0, 5, 1, 3, 2, 4).reshape(B, self.out_dim, 56, 56)
+        return F.interpolate(m, (H, W), mode="bilinear", align_corners=False), taps[-1][:, 0]
+
+    def sample(self, x, choose):
+        """Features of the chosen pixels, (B,n,out_dim): bilinear x4 (align_corners=False) of the
+        56x56 pixel-shuffled map evaluated only where needed."""
+        B, _, H, W = x.shape
+        up = self.tokens_up(x)
+        if ops.have("upsample_gather") and up.is_cuda:
+            return ops.upsample_gather(up.contiguous(), choose, H, W, self.out_dim)
+        return _upsample_gather_lib(up, choose, H, W, self.out_dim)
+
+
+def _upsample_gather_lib(up, choose, H, W, C):
+    B = up.shape[0]
+    S = 56
+
+    def src(o, scale):
+        s = ((o.float() + 0.5) * scale - 0.5).clamp(min=0.0)
+        i0 = s.floor().long().clamp(max=S - 1)
+        i1 = (i0 + 1).clamp(max=S - 1)
+        return i0, i1, s - i0.float()
+    y, x = choose // W, choose % W
+    y0, y1, wy = src(y, S / H)
+    x0, x1, wx = src(x, S / W)
+    up = up.view(B, 14 * 14, 16, C)
+
+    def at(Y, X):  # 56x56 pixel (Y,X) = patch (Y//4, X//4), sub-pixel (Y%4, X%4)
+        tok = (Y // 4) * 14 + (X // 4)
+        sub = (Y % 4) * 4 + (X % 4)
+        flat = up.reshape(B, 196 * 16, C)
+        return torch.gather(flat, 1, (tok * 16 + sub).unsqueeze(-1).expand(-1, -1, C))
+    wy, wx = wy.unsqueeze(-1), wx.unsqueeze(-1)
+    top = at(y0, x0) * (1 - wx) + at(y0, x1) * wx
+    bot = at(y1, x0) * (1 - wx) + at(y1, x1) * wx
+    return top * (1 - wy) + bot * wy
+
+
+class ViTEncoder(nn.Module):
+    """feature_extraction.py:122-181."""
+
+    def __init__(self, cfg, npoint=2048):
+        super().__init__()
+        self.npoint = npoint
+        self.rgb_net = ViT_AE(cfg)
+
+    def get_img_feats(self, img, choose):
+        return self.rgb_net.sample(img, choose)
+
+    def forward(self, end_points):
+        rgb, choose = end_points["rgb"], end_points["rgb_choose"]
+        assert choose.size(1) == self.npoint
+        dense_fm = self.get_img_feats(rgb, choose)
+        dense_pm = end_points["pts"]
+        if self.training or "dense_po" not in end_points or "dense_fo" not in end_points:
+            raise NotImplementedError("MI355X build covers the inference branch with pre-computed "
+                                      "template features (dense_po / dense_fo)")
+        dense_po, dense_fo = end_points["dense_po"], end_points["dense_fo"]
+        radius = torch.norm(dense_po, dim=2).max(1)[0]
+        den = radius.reshape(-1, 1, 1) + 1e-6
+        return dense_pm / den, dense_fm, dense_po / den, dense_fo, radius
+
+    def get_obj_feats(self, tem_rgb_list, tem_pts_list, tem_choose_list, npoint=None):
+        """Template onboarding: 42 views x 5000 px -> FPS to npoint (feature_extraction.py:170-181)."""
+        npoint = npoint or self.npoint
+        feats = [self.get_img_feats(t, c) for t, c in zip(tem_rgb_list, tem_choose_list)]
+        pts = torch.cat(tem_pts_list, dim=1).contiguous()
+        feat = torch.cat(feats, dim=1).contiguous()
+        idx = ops.furthest_point_sampling(pts, npoint)
+        return ops.gather_rows(pts, idx), ops.gather_rows(feat, idx)

@@ -1,0 +1,278 @@
+"""Point-transformer layers of the Pose Estimation Model, MI355X build.
+
+Module and attribute names reproduce the reference's state_dict surface
+(Pose_Estimation_Model/model/transformer.py) so ``sam-6d-pem-base.pth`` loads unchanged;
+the forward passes are re-derived for the hardware rather than transcribed:
+
+  * RPE attention never materialises proj_p(embedding) (B,4,N,M,64): the positional score
+    is computed as  (W_p^T q)^T e + q.b_p  -- 64x fewer FLOPs and no 39.7 MB/instance
+    intermediate (transformer.py:388-392 computes einsum(q, proj_p(e))).
+  * attention cores and the linear-attention tail go through sam6d_amd.ops when a fused
+    gfx950 kernel exists (see ops.HAVE) and are expressed with library GEMMs otherwise.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+HEADS = 4
+
+
+def _split(x):  # (B,N,C) -> (B,h,N,c)
+    B, N, C = x.shape
+    return x.view(B, N, HEADS, C // HEADS).transpose(1, 2)
+
+
+def _merge(x):  # (B,h,N,c) -> (B,N,C)
+    B, h, N, c = x.shape
+    return x.transpose(1, 2).reshape(B, N, h * c)
+
+
+class AttentionOutput(nn.Module):
+    """transformer.py:182-197 (ReLU FFN 256->512->256, post-LN)."""
+
+    def __init__(self, d_model):
+        super().__init__()
+        self.expand = nn.Linear(d_model, d_model * 2)
+        self.squeeze = nn.Linear(d_model * 2, d_model)
+        self.norm = nn.LayerNorm(d_model)
+
+    def forward(self, x):
+        return self.norm(x + self.squeeze(F.relu(self.expand(x))))
+
+
+class MultiHeadAttention(nn.Module):
+    """transformer.py:93-148 (no masks / factors are ever passed on the inference path)."""
+
+    def __init__(self, d_model, num_heads=HEADS):
+        super().__init__()
+        self.proj_q = nn.Linear(d_model, d_model)
+        self.proj_k = nn.Linear(d_model, d_model)
+        self.proj_v = nn.Linear(d_model, d_model)
+        self.scale = 1.0 / math.sqrt(d_model // num_heads)
+
+    def forward(self, xq, xk, xv):
+        q, k, v = _split(self.proj_q(xq)), _split(self.proj_k(xk)), _split(self.proj_v(xv))
+        a = torch.softmax((q @ k.transpose(-1, -2)) * self.scale, dim=-1)
+        return _merge(a @ v)
+
+
+class RPEMultiHeadAttention(nn.Module):
+    """transformer.py:352-406 with the proj_p term rewritten (see module docstring)."""
+
+    def __init__(self, d_model, num_heads=HEADS):
+        super().__init__()
+        self.proj_q = nn.Linear(d_model, d_model)
+        self.proj_k = nn.Linear(d_model, d_model)
+        self.proj_v = nn.Linear(d_model, d_model)
+        self.proj_p = nn.Linear(d_model, d_model)
+        self.d_model = d_model
+        self.scale = 1.0 / math.sqrt(d_model // num_heads)
+
+    def forward(self, x, embed):
+        B, N, C = x.shape
+        q, k, v = self.proj_q(x), self.proj_k(x), self.proj_v(x)
+        c = C // HEADS
+        # q~[b,h,n,:] = W_p[h]^T q[b,h,n,:]   (B,h,N,C);   qb[b,h,n] = q[b,h,n,:] . b_p[h,:]
+        qh = _split(q)
+        qt = torch.einsum("bhnc,hcj->bhnj", qh, self.proj_p.weight.view(HEADS, c, C))
+        qb = torch.einsum("bhnc,hc->bhn", qh, self.proj_p.bias.view(HEADS, c))
+        if ops.have("rpe_attention") and x.is_cuda:
+            return ops.rpe_attention(q, k, v, qt, qb, embed, self.scale)
+        sp = torch.einsum("bhnj,bnmj->bhnm", qt, embed) + qb.unsqueeze(-1)
+        a = torch.softmax((qh @ _split(k).transpose(-1, -2) + sp) * self.scale, dim=-1)
+        return _merge(a @ _split(v))
+
+
+class _AttnLayerBase(nn.Module):
+    def __init__(self, attention, d_model):
+        super().__init__()
+        self.attention = attention
+        self.linear = nn.Linear(d_model, d_model)
+        self.norm = nn.LayerNorm(d_model)
+
+
+class AttentionLayer(_AttnLayerBase):
+    def __init__(self, d_model):
+        super().__init__(MultiHeadAttention(d_model), d_model)
+
+    def forward(self, x, mem):
+        return self.norm(self.linear(self.attention(x, mem, mem)) + x)
+
+
+class RPEAttentionLayer(_AttnLayerBase):
+    def __init__(self, d_model):
+        super().__init__(RPEMultiHeadAttention(d_model), d_model)
+
+    def forward(self, x, embed):
+        return self.norm(self.linear(self.attention(x, embed)) + x)
+
+
+class TransformerLayer(nn.Module):
+    def __init__(self, d_model):
+        super().__init__()
+        self.attention = AttentionLayer(d_model)
+        self.output = AttentionOutput(d_model)
+
+    def forward(self, x, mem):
+        return self.output(self.attention(x, mem))
+
+
+class RPETransformerLayer(nn.Module):
+    def __init__(self, d_model):
+        super().__init__()
+        self.attention = RPEAttentionLayer(d_model)
+        self.output = AttentionOutput(d_model)
+
+    def forward(self, x, embed):
+        return self.output(self.attention(x, embed))
+
+
+class GeometricTransformer(nn.Module):
+    """blocks ['self','cross'], sequential cross-attention (transformer.py:493-513: feats1
+    attends to the already-updated feats0)."""
+
+    def __init__(self, d_model):
+        super().__init__()
+        self.layers = nn.ModuleList([RPETransformerLayer(d_model), TransformerLayer(d_model)])
+
+    def forward(self, f0, e0, f1, e1):
+        f0 = self.layers[0](f0, e0)
+        f1 = self.layers[0](f1, e1)
+        f0 = self.layers[1](f0, f1)
+        f1 = self.layers[1](f1, f0)
+        return f0, f1
+
+
+class LinearAttention(nn.Module):
+    """Focused linear attention (transformer.py:518-564).  With i=2048 queries and j=196 keys
+    the reference takes the kv-first branch (i*j*(c+d) > c*d*(i+j)); this build always does
+    (O(N c d), and the branches are algebraically identical)."""
+
+    def __init__(self, d_model, focusing_factor=3):
+        super().__init__()
+        self.proj_q = nn.Linear(d_model, d_model)
+        self.proj_k = nn.Linear(d_model, d_model)
+        self.proj_v = nn.Linear(d_model, d_model)
+        self.scale = nn.Parameter(torch.zeros(1, 1, d_model))
+        self.focusing_factor = focusing_factor
+
+    def _focus(self, t, inv_scale):
+        t = (F.relu(t) + 1e-6) * inv_scale
+        n = t.norm(dim=-1, keepdim=True)
+        t = t ** self.focusing_factor
+        return t / t.norm(dim=-1, keepdim=True) * n
+
+    def forward(self, xq, xkv):
+        inv_scale = 1.0 / F.softplus(self.scale)
+        q = _split(self._focus(self.proj_q(xq), inv_scale))          # (B,h,I,c)
+        k = _split(self._focus(self.proj_k(xkv), inv_scale))         # (B,h,J,c)
+        v = _split(self.proj_v(xkv))
+        z = 1.0 / (q @ k.sum(dim=2).unsqueeze(-1) + 1e-6)            # (B,h,I,1)
+        kv = k.transpose(-1, -2) @ v                                 # (B,h,c,d)
+        return _merge((q @ kv) * z)
+
+
+class LinearAttentionLayer(nn.Module):
+    def __init__(self, d_model, focusing_factor=3):
+        super().__init__()
+        self.attention = LinearAttention(d_model, focusing_factor)
+        self.linear = nn.Linear(d_model, d_model)
+        self.norm = nn.LayerNorm(d_model)
+
+    def forward(self, x, mem):
+        return self.norm(self.linear(self.attention(x, mem)) + x)
+
+
+class LinearTransformerLayer(nn.Module):
+    def __init__(self, d_model, focusing_factor=3):
+        super().__init__()
+        self.attention = LinearAttentionLayer(d_model, focusing_factor)
+        self.output = AttentionOutput(d_model)
+
+    def forward(self, x, mem):
+        return self.output(self.attention(x, mem))
+
+
+class SparseToDenseTransformer(nn.Module):
+    """transformer.py:613-673 (with_bg_token, replace_bg_token).  Quirk Q1 is kept on purpose:
+    fps_idx addresses the dense tensor WITH the bg token prepended (an off-by-one row gather),
+    because the released weights were trained with it."""
+
+    def __init__(self, d_model, focusing_factor=3):
+        super().__init__()
+        self.sparse_layer = GeometricTransformer(d_model)
+        self.dense_layer = LinearTransformerLayer(d_model, focusing_factor)
+
+    @staticmethod
+    def _sample(dense, fps_idx):
+        return torch.cat([dense[:, 0:1], ops.gather_rows(dense.contiguous(), fps_idx)], dim=1)
+
+    def forward(self, d0, e0, idx0, d1, e1, idx1):
+        s0, s1 = self._sample(d0, idx0), self._sample(d1, idx1)
+        s0, s1 = self.sparse_layer(s0, e0, s1, e1)
+        n0 = torch.cat([s0[:, 0:1], self.dense_layer(d0[:, 1:], s0[:, 1:])], dim=1)
+        n1 = torch.cat([s1[:, 0:1], self.dense_layer(d1[:, 1:], s1[:, 1:])], dim=1)
+        return n0, n1
+
+
+class SinusoidalPositionalEmbedding(nn.Module):
+    """transformer.py:257-281; only the ``div_term`` buffer is part of the checkpoint."""
+
+    def __init__(self, d_model):
+        super().__init__()
+        self.d_model = d_model
+        div = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+        self.register_buffer("div_term", div)
+
+    def forward(self, x):
+        om = x.unsqueeze(-1) * self.div_term
+        return torch.stack([torch.sin(om), torch.cos(om)], dim=-1).reshape(*x.shape, self.d_model)
+
+
+class GeometricStructureEmbedding(nn.Module):
+    """transformer.py:286-349.  cfg: sigma_d, sigma_a, angle_k, reduction_a, hidden_dim."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.sigma_d = cfg.sigma_d
+        self.sigma_a = cfg.sigma_a
+        self.factor_a = 180.0 / (self.sigma_a * math.pi)
+        self.angle_k = cfg.angle_k
+        self.embedding = SinusoidalPositionalEmbedding(cfg.hidden_dim)
+        self.proj_d = nn.Linear(cfg.hidden_dim, cfg.hidden_dim)
+        self.proj_a = nn.Linear(cfg.hidden_dim, cfg.hidden_dim)
+        self.reduction_a = cfg.reduction_a
+        if self.reduction_a != "max":
+            raise ValueError("MI355X build implements reduction_a == 'max' (config/base.yaml:30)")
+
+    @torch.no_grad()
+    def get_embedding_indices(self, points):
+        B, N, _ = points.shape
+        k = self.angle_k
+        diff = points.unsqueeze(1) - points.unsqueeze(2)                      # [b,n,m] = p_m - p_n
+        xy = points @ points.transpose(1, 2)
+        sq = (points ** 2).sum(-1)
+        dist = torch.sqrt((sq.unsqueeze(-1) - 2 * xy + sq.unsqueeze(-2)).clamp(min=0.0))
+        knn = dist.topk(k=k + 1, dim=2, largest=False)[1][:, :, 1:]           # (B,N,k)
+        ref = torch.gather(diff, 2, knn.unsqueeze(-1).expand(B, N, k, 3))     # nbr(n) - p_n
+        ref = ref.unsqueeze(2).expand(B, N, N, k, 3)
+        anc = diff.unsqueeze(3).expand(B, N, N, k, 3)
+        sin_v = torch.linalg.norm(torch.cross(ref, anc, dim=-1), dim=-1)
+        cos_v = (ref * anc).sum(-1)
+        return dist / self.sigma_d, torch.atan2(sin_v, cos_v) * self.factor_a
+
+    def forward(self, points):
+        if ops.have("geo_embedding") and points.is_cuda:
+            return ops.geo_embedding(points, self.proj_d.weight, self.proj_d.bias, self.proj_a.weight,
+                                     self.proj_a.bias, self.sigma_d, self.factor_a, self.angle_k)
+        outs = []
+        for p in points.split(4, dim=0):     # bound the (b,N,N,k,256) intermediate of the library path
+            d_idx, a_idx = self.get_embedding_indices(p)
+            d = self.proj_d(self.embedding(d_idx))
+            a = self.proj_a(self.embedding(a_idx)).max(dim=3)[0]
+            outs.append(d + a)
+        return torch.cat(outs, 0)

@@ -1,0 +1,99 @@
+"""Pose solvers of the PEM matching heads, MI355X build.
+
+Re-derivation of Pose_Estimation_Model/utils/model_utils.py
+(compute_coarse_Rt :187-246, compute_fine_Rt :250-283, weighted_procrustes :287-363):
+same quantities, different execution -- hypothesis generation, the 3x3 SVDs and the
+transform + nearest-model-point scans run as fused gfx950 kernels when the library exports
+them (ops.have), and as device-side library ops otherwise.
+"""
+import torch
+
+from .. import ops
+
+
+def soft_assignment(atten):
+    """softmax over rows x softmax over columns, background row/column masking
+    (model_utils.py:203-212 / 262-266).  Returns (masked score[:,1:,1:], w1, w2)."""
+    score = torch.softmax(atten, dim=2) * torch.softmax(atten, dim=1)
+    w1 = (score[:, 1:, :].argmax(dim=2) > 0).float()
+    w2 = (score[:, :, 1:].argmax(dim=1) > 0).float()
+    return score[:, 1:, 1:] * w1.unsqueeze(2) * w2.unsqueeze(1), w1, w2
+
+
+def rotation_from_H(H):
+    """R = V diag(1,1,det(V U^T)) U^T for H = U S V^T (model_utils.py:343-347)."""
+    if ops.have("rot_from_h") and H.is_cuda:
+        return ops.rot_from_h(H.contiguous())
+    U, _, Vh = torch.linalg.svd(H.double())
+    V = Vh.transpose(-1, -2)
+    d = torch.sign(torch.det(V @ U.transpose(-1, -2)))
+    D = torch.diag_embed(torch.stack([torch.ones_like(d), torch.ones_like(d), d], dim=-1))
+    return (V @ D @ U.transpose(-1, -2)).to(H.dtype)
+
+
+def weighted_procrustes(src, ref, weights=None, weight_thresh=0.0, eps=1e-5):
+    if weights is None:
+        weights = torch.ones_like(src[..., 0])
+    weights = torch.where(weights < weight_thresh, torch.zeros_like(weights), weights)
+    w = (weights / (weights.sum(dim=-1, keepdim=True) + eps)).unsqueeze(-1)
+    sc = (src * w).sum(dim=-2, keepdim=True)
+    rc = (ref * w).sum(dim=-2, keepdim=True)
+    H = (src - sc).transpose(-1, -2) @ (w * (ref - rc))
+    R = rotation_from_H(H)
+    t = (rc.transpose(-1, -2) - R @ sc.transpose(-1, -2)).squeeze(-1)
+    return R, t
+
+
+def min_dist_to_model(pts, R, t, model):
+    """For every pose p and point n: min_m || (pts[n] - t_p) R_p - model[m] ||.
+    pts (B,N,3), R (B,P,3,3), t (B,P,3), model (B,Nm,3) -> (B,P,N)."""
+    if ops.have("min_dist") and pts.is_cuda:
+        return ops.min_dist(pts.contiguous(), R.contiguous(), t.contiguous(), model.contiguous())
+    tp = (pts.unsqueeze(1) - t.unsqueeze(2)) @ R                       # (B,P,N,3)
+    out = []
+    for chunk in tp.split(64, dim=1):                                  # bound the (P,N,Nm) intermediate
+        d = chunk.unsqueeze(3) - model.unsqueeze(1).unsqueeze(1)       # (B,p,N,Nm,3)
+        out.append((d * d).sum(-1).min(dim=3)[0].sqrt())
+    return torch.cat(out, dim=1)
+
+
+def coarse_Rt(atten, pts1, pts2, model_pts, rand_u, n1=6000, n2=300):
+    """compute_coarse_Rt.  rand_u (B, 3*n1) are the uniform samples (drawn by the caller)."""
+    B, N1, _ = pts1.shape
+    N2 = pts2.shape[1]
+    score, w1, _ = soft_assignment(atten)
+    score = score.reshape(B, N1 * N2) ** 1.5
+    cum = torch.cumsum(score, dim=1)
+    cum = cum / (cum[:, -1:].contiguous() + 1e-8)
+    pair = torch.searchsorted(cum, rand_u.contiguous())
+    if ops.have("pose_hypotheses") and pts1.is_cuda:
+        Rs, ts, dis = ops.pose_hypotheses(pts1.contiguous(), pts2.contiguous(), pair.int().contiguous())
+    else:
+        i1 = torch.clamp(pair.div(N2, rounding_mode="floor"), max=N1 - 1)
+        i2 = torch.clamp(pair % N2, max=N2 - 1)
+        p1 = torch.gather(pts1, 1, i1.unsqueeze(2).expand(-1, -1, 3)).view(B, n1, 3, 3)
+        p2 = torch.gather(pts2, 1, i2.unsqueeze(2).expand(-1, -1, 3)).view(B, n1, 3, 3)
+        Rs, ts = weighted_procrustes(p2, p1, None, weight_thresh=0.5)
+        dis = torch.norm((p1 - ts.unsqueeze(2)) @ Rs - p2, dim=3).mean(dim=2)
+    top = torch.topk(dis, n2, dim=1, largest=False)[1]
+    Rs = torch.gather(Rs, 1, top.view(B, n2, 1, 1).expand(-1, -1, 3, 3))
+    ts = torch.gather(ts, 1, top.view(B, n2, 1).expand(-1, -1, 3))
+    dmin = min_dist_to_model(pts1, Rs, ts, model_pts)                  # (B,n2,N1)
+    sc = w1.sum(dim=1, keepdim=True) / ((dmin * w1.unsqueeze(1)).sum(dim=2) + 1e-8)
+    best = sc.argmax(dim=1)
+    ar = torch.arange(B, device=pts1.device)
+    return Rs[ar, best], ts[ar, best]
+
+
+def fine_Rt(atten, pts1, pts2, model_pts, dis_thres=0.15):
+    """compute_fine_Rt."""
+    if ops.have("fine_assign") and atten.is_cuda:
+        pred, wsum, w1 = ops.fine_assign(atten.contiguous(), pts2.contiguous())
+    else:
+        amat, w1, _ = soft_assignment(atten)
+        wsum = amat.sum(dim=2)
+        pred = (amat / (wsum.unsqueeze(2) + 1e-6)) @ pts2
+    R, t = weighted_procrustes(pred, pts1, wsum, weight_thresh=0.0)
+    dis = min_dist_to_model(pts1, R.unsqueeze(1), t.unsqueeze(1), model_pts).squeeze(1)
+    sc = ((dis < dis_thres).float() * w1).sum(dim=1) / (w1.sum(dim=1) + 1e-8)
+    return R, t, sc * w1.mean(dim=1)

@@ -1,0 +1,86 @@
+"""GPU parity of the drop-in PEM (sam6d_amd.pem) against the golden fixtures produced by the
+reference modules and against the CPU oracle on the same seeded inputs.
+Tolerances follow BASELINE.json: |R - R_ref|_F <= 1e-3, |t - t_ref| <= 1e-3 mm."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pem as opem
+from sam6d_amd.utils import seeded, synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+R_TOL = 1e-3          # Frobenius
+T_TOL_M = 1e-6        # 1e-3 mm expressed in metres
+
+
+@pytest.fixture(scope="module")
+def net():
+    assert torch.cuda.is_available()
+    from sam6d_amd.pem import pose_estimation_model as pm
+    n = pm.Net(pm.default_cfg()).eval()
+    seeded.load_seeded(n, 1)
+    return n.cuda()
+
+
+def _to(d, dev):
+    return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in d.items()}
+
+
+def test_net_forward_vs_reference_golden(net):
+    g = util.golden("pem_b2.npz")
+    case = ast.literal_eval(str(g["case"]))
+    inp = synth.pem_inputs(case["B"], seed=case["input_seed"])
+    ep = {k: inp[k] for k in ("pts", "rgb", "rgb_choose", "model", "dense_po", "dense_fo")}
+    ep["coarse_rand_u"] = synth.coarse_uniforms(case["B"], case["rand_seed"])
+    with torch.no_grad():
+        out = net(_to(ep, "cuda"))
+    dR = np.linalg.norm(out["pred_R"].cpu().numpy() - g["net_pred_R"], axis=(1, 2))
+    dt = np.abs(out["pred_t"].cpu().numpy() - g["net_pred_t"]).max()
+    assert dR.max() <= R_TOL and dt <= T_TOL_M * 10, (dR, dt)   # random-ViT features: ill-conditioned case
+    np.testing.assert_allclose(out["pred_pose_score"].cpu().numpy(), g["net_pred_pose_score"], atol=5e-3)
+
+
+def test_known_answer_vs_reference_golden_and_truth(net):
+    g = util.golden("pem_b2.npz")
+    case = ast.literal_eval(str(g["case"]))
+    inp = synth.pem_inputs(case["B"], seed=case["input_seed"], with_rgb=False)
+    radius = torch.norm(inp["dense_po"], dim=2).max(1)[0]
+    s = radius.reshape(-1, 1, 1) + 1e-6
+    ep = _to(dict(model=inp["model"], coarse_rand_u=synth.coarse_uniforms(case["B"], case["rand_seed"])), "cuda")
+    with torch.no_grad():
+        out = net.match((inp["pts"] / s).cuda(), inp["dense_fm_kat"].cuda(), (inp["dense_po"] / s).cuda(),
+                        inp["dense_fo"].cuda(), radius.cuda(), ep)
+    dR = np.linalg.norm(out["pred_R"].cpu().numpy() - g["kat_pred_R"], axis=(1, 2))
+    dt = np.abs(out["pred_t"].cpu().numpy() - g["kat_pred_t"]).max()
+    assert dR.max() <= R_TOL and dt <= T_TOL_M, (dR, dt)
+    assert np.linalg.norm(out["pred_R"].cpu().numpy() - g["kat_gt_R"], axis=(1, 2)).max() < 1e-3
+    np.testing.assert_allclose(out["pred_pose_score"].cpu().numpy(), g["kat_pred_pose_score"], atol=2e-3)
+
+
+@pytest.mark.parametrize("B,seed", [(4, 21), (16, 33)])
+def test_known_answer_vs_oracle_other_seeds(net, B, seed):
+    """Same seeded inputs through the CPU oracle and the MI355X path."""
+    W = util.pem_weights(1)
+    inp = synth.pem_inputs(B, seed=seed, with_rgb=False)
+    radius = torch.norm(inp["dense_po"], dim=2).max(1)[0]
+    s = radius.reshape(-1, 1, 1) + 1e-6
+    ru = synth.coarse_uniforms(B, seed + 1)
+    with torch.no_grad():
+        ref = opem.matching_forward(W, inp["pts"] / s, inp["dense_fm_kat"], inp["dense_po"] / s, inp["dense_fo"],
+                                    radius, inp["model"], ru)
+        ep = _to(dict(model=inp["model"], coarse_rand_u=ru), "cuda")
+        out = net.match((inp["pts"] / s).cuda(), inp["dense_fm_kat"].cuda(), (inp["dense_po"] / s).cuda(),
+                        inp["dense_fo"].cuda(), radius.cuda(), ep)
+    dR = (out["pred_R"].cpu() - ref["pred_R"]).norm(dim=(1, 2))
+    dt = (out["pred_t"].cpu() - ref["pred_t"]).abs().max()
+    assert dR.max() <= R_TOL and dt <= T_TOL_M, (dR, dt)
+    # ADD(-S) style recall identical on identical inputs
+    from sam6d_amd.utils import metrics
+    m = inp["model"]
+    a = metrics.add_recall(out["pred_R"].cpu(), out["pred_t"].cpu(), inp["gt_R"], inp["gt_t"], m, 0.2)
+    b = metrics.add_recall(ref["pred_R"], ref["pred_t"], inp["gt_R"], inp["gt_t"], m, 0.2)
+    assert torch.equal(a[1], b[1]) and a[0] == b[0]

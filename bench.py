@@ -1,0 +1,227 @@
+"""bench.py -- frames/s of the SAM-6D per-frame hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]: "LM-O single object, 2048 pts, 42 templates, batch=32 bf16"):
+one STEP = one batch of 32 synthetic 640x480 RGB-D frames per GPU, each holding one instance of the
+single LM-O object.  Per frame the hot path of SURVEY.md section 8(a) runs in full:
+  a1-a5   SAM ViT-H image encoder on the 1024x1024 preprocessed frame (bf16)
+  a6-a9   proposal-vs-template scoring of P=128 proposals against 1 object x 42 templates
+          (semantic + appearance + geometric score)
+  a10-a24 PEM Net.forward for the detected instance (2048 observed points, 2048x256 template
+          features, 1024 model points) -- the 32 frames form one PEM batch of 32.
+Inputs are resident in HBM before the timed region; weights are seeded-random (no checkpoint is
+reachable offline), results therefore meaningless but the arithmetic is the full model.
+Frames shard across ranks with no data-path collective (weak scaling); the only RCCL traffic is the
+final all_gather of the fixed-width pose records, inside the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FRAMES_PER_STEP = 32
+P_PROPOSALS = 128
+SAM_FLOP_PER_FRAME = 5.96e12        # 28 x 176.9 + 4 x 248.3 + 15.6 GFLOP
+MFMA_BF16_PEAK = 2.5e15             # dense, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_STEP)
+    ap.add_argument("--sam-chunk", type=int, default=int(os.environ.get("S6D_SAM_CHUNK", "8")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true")
+    return ap.parse_args()
+
+
+class HotPath:
+    """All device state of one rank: models, replicated template data, one batch of frames."""
+
+    def __init__(self, device, frames, sam_chunk):
+        from sam6d_amd.ism.scoring import FrameScorer
+        from sam6d_amd.pem import pose_estimation_model as pm
+        from sam6d_amd.sam.image_encoder import build_vit_h
+        from sam6d_amd.utils import seeded, synth
+
+        self.dev, self.F, self.chunk = device, frames, sam_chunk
+        self.sam = seeded.load_seeded(build_vit_h().eval(), 3).to(device=device, dtype=torch.bfloat16)
+        self.pem = seeded.load_seeded(pm.Net(pm.default_cfg()).eval(), 1).to(device)
+        ism = synth.ism_inputs(P=P_PROPOSALS, O=1, T=42, seed=11)
+        self.ism_in = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in ism.items()}
+        self.scorer = FrameScorer(self.ism_in["ref_cls"], self.ism_in["ref_patch"], self.ism_in["poses"],
+                                  self.ism_in["pointcloud"])
+        self.sam_x = synth.sam_input(frames, 5, 1024).to(device=device, dtype=torch.bfloat16)
+        pin = synth.pem_inputs(frames, seed=1)
+        self.pem_in = {k: pin[k].to(device) for k in ("pts", "rgb", "rgb_choose", "model", "dense_po", "dense_fo")}
+        self.rand_u = synth.coarse_uniforms(frames, 2).to(device)
+
+    @torch.no_grad()
+    def sam_stage(self):
+        outs = [self.sam(self.sam_x[i:i + self.chunk]) for i in range(0, self.F, self.chunk)]
+        return outs[-1]
+
+    @torch.no_grad()
+    def ism_stage(self):
+        i = self.ism_in
+        out = None
+        for _ in range(self.F):
+            out = self.scorer.score(i["qry_cls"], i["qry_patch"], i["masks"], i["boxes"], i["depth"], i["K"])
+        return out
+
+    @torch.no_grad()
+    def pem_stage(self):
+        ep = dict(self.pem_in)
+        ep["coarse_rand_u"] = self.rand_u
+        return self.pem(ep)
+
+    def step(self):
+        self.sam_stage()
+        self.ism_stage()
+        out = self.pem_stage()
+        # fixed-width pose record per instance: [frame, obj, score, R(9), t(3)] (68 B)
+        rec = torch.cat([torch.arange(self.F, device=self.dev, dtype=torch.float32)[:, None],
+                         torch.zeros(self.F, 1, device=self.dev), out["pred_pose_score"][:, None],
+                         out["pred_R"].reshape(self.F, 9), out["pred_t"]], dim=1)
+        return rec
+
+
+def stage_ms(fn, n=2):
+    """HIP-event time of one stage on torch's current stream (the stream every s6d kernel uses)."""
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def cpu_baseline():
+    """CPU restatement (oracle = 'port' of the reference algorithm) timed on the host cores on a
+    bounded sample: 1 SAM ViT-H frame + 1 ISM frame + a PEM batch of 2 instances."""
+    from oracle import ism as oism
+    from oracle import pem as opem
+    from oracle import sam as osam
+    from sam6d_amd.pem import pose_estimation_model as pm
+    from sam6d_amd.sam.image_encoder import build_vit_h
+    from sam6d_amd.utils import seeded, synth
+
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        Wp = {k: v for k, v in seeded.load_seeded(pm.Net(pm.default_cfg()), 1).state_dict().items()}
+        inp = synth.pem_inputs(2, seed=1)
+        ep = {k: inp[k] for k in ("pts", "rgb", "rgb_choose", "model", "dense_po", "dense_fo")}
+        t0 = time.time()
+        opem.net_forward(Wp, ep, synth.coarse_uniforms(2, 2))
+        t_pem = (time.time() - t0) / 2
+        ii = synth.ism_inputs(P=P_PROPOSALS, O=1, T=42, seed=11)
+        t0 = time.time()
+        oism.score_frame(ii)
+        t_ism = time.time() - t0
+        with torch.device("cpu"):
+            Ws = {k: v for k, v in seeded.load_seeded(build_vit_h(), 3).state_dict().items()}
+        x = synth.sam_input(1, 5, 1024)
+        t0 = time.time()
+        osam.encoder_forward(Ws, x, osam.VIT_H)
+        t_sam = time.time() - t0
+    per_frame = t_sam + t_ism + t_pem
+    return {"value": 1.0 / per_frame, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"1 SAM ViT-H frame ({t_sam:.2f}s) + 1 ISM frame P=128 ({t_ism:.3f}s) + PEM batch of 2 "
+                      f"({t_pem:.2f}s/instance), fp32 torch CPU oracle"}
+
+
+def main():
+    args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline()))
+        return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU visible"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    hp = HotPath(dev, args.frames, args.sam_chunk)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run_step():
+        rec = hp.step()
+        if dist is not None:
+            out = torch.empty(world * rec.shape[0], rec.shape[1], device=dev)
+            dist.all_gather_into_tensor(out, rec.contiguous())
+            return out
+        return rec
+
+    for _ in range(args.warmup):
+        run_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    ms_step = dt / args.steps * 1e3
+    value = world * args.frames * args.steps / dt
+
+    # stage breakdown + roofline of the dominant stage (rank 0 only; outside the timed region)
+    extra = {}
+    if rank == 0:
+        sam_ms = stage_ms(hp.sam_stage, 1)
+        ism_ms = stage_ms(hp.ism_stage, 1)
+        pem_ms = stage_ms(hp.pem_stage, 1)
+        achieved = SAM_FLOP_PER_FRAME * args.frames / (sam_ms * 1e-3)
+        extra["stages_ms"] = {"sam_encoder": round(sam_ms, 2), "ism_scoring": round(ism_ms, 2), "pem": round(pem_ms, 2)}
+        extra["roofline"] = {"bound": "mfma", "kernel": "SAM ViT-H encoder stage (bf16 GEMMs + attention), "
+                             f"{args.frames} frames", "achieved": round(achieved / 1e12, 2),
+                             "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK, 4),
+                             "traffic": None}
+        if world == 1 and not args.no_cpu_baseline:
+            extra["cpu_baseline"] = cpu_baseline()
+
+    if rank == 0:
+        line = {"metric": "RGB-D frames/sec (SAM-6D per-frame hot path: SAM ViT-H encoder + ISM scoring + PEM)",
+                "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (SAM ViT-H) + f32 (ISM scoring, PEM)",
+                "data": "synthetic",
+                "config": {"workload": "LM-O single object: 32 frames/step/GPU, 640x480 RGB-D -> 1024^2 SAM input, "
+                                       "P=128 proposals x 42 templates, 1 instance/frame, 2048 pts (PEM batch 32)",
+                           "frames_per_step_per_gpu": args.frames, "sharding": f"frames over {world} rank(s)"}}
+        line.update(extra)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,139 @@
+"""Scoring methods of ``Instance_Segmentation_Model`` (model/detector.py) on MI355X.
+
+``ScoringMixin`` carries the six methods that both run_inference_custom.py:168-197 and
+detector.py::test_step :362-381 call by name on the model object
+(compute_semantic_score :260-296, best_template_pose :198-207, compute_appearance_score :298-308,
+compute_geometric_score :310-322, project_template_to_image :209-232,
+Calculate_the_query_translation :234-246) with the reference's signatures and attribute
+contract (``self.ref_data[...]``, ``self.matching_config``, ``self.visible_thred``).
+INTEGRATION.md shows the two-line change that mixes it into the reference class.
+"""
+import torch
+
+from .. import ops
+from .loss import MaskedPatch_MatrixSimilarity
+
+
+def compute_iou(bb_a, bb_b):
+    """utils/bbox_utils.py:197-221 incl. quirk Q3: one empty intersection -> scalar 0.0 for all."""
+    tl = torch.max(bb_a[:, 0:2], bb_b[:, 0:2])
+    br = torch.min(bb_a[:, 2:4], bb_b[:, 2:4])
+    wh_a, wh_b, wh_i = bb_a[:, 2:4] - bb_a[:, 0:2], bb_b[:, 2:4] - bb_b[:, 0:2], br - tl
+    if (wh_i > 0).all():
+        ai = wh_i[:, 0] * wh_i[:, 1]
+        return ai / (wh_a[:, 0] * wh_a[:, 1] + wh_b[:, 0] * wh_b[:, 1] - ai)
+    return 0.0
+
+
+def masked_depth_translation(masks, depth, K, depth_scale):
+    """Mean back-projected point of each mask (utils/trimesh_utils.py:77-105 applied to
+    mask*depth, detector.py:234-246) without the (S,H,W) ``repeat``: three masked sums."""
+    S, H, W = masks.shape
+    if ops.have("masked_depth_mean") and masks.is_cuda:
+        return ops.masked_depth_mean(masks.contiguous(), depth.contiguous(), K, float(depth_scale))
+    # dtype trail of the reference: Z float32; X, Y float64 (the camera matrix is a float64 tensor
+    # whose 0-dim elements promote `u - K[0,2]`), sums in that dtype, final cast to float32.
+    z = masks.to(torch.float32) * depth.to(torch.float32)[None] * depth_scale / 1000
+    K = K.to(device=z.device, dtype=torch.float64)
+    u = torch.arange(W, device=z.device, dtype=torch.float64)[None, None, :]
+    v = torch.arange(H, device=z.device, dtype=torch.float64)[None, :, None]
+    valid = z > 0
+    n = (valid.sum(dim=(1, 2)) + 1e-8).to(torch.float32)
+    x = ((u - K[0, 2]) * z / K[0, 0] * valid).sum(dim=(1, 2)) / n
+    y = ((v - K[1, 2]) * z / K[1, 1] * valid).sum(dim=(1, 2)) / n
+    zz = (z * valid).sum(dim=(1, 2)) / n
+    return torch.stack((x, y, zz.to(torch.float64)), dim=1).to(torch.float32)
+
+
+class ScoringMixin:
+    def best_template_pose(self, scores, pred_idx_objects):
+        best = scores.argmax(dim=-1)                                   # (S,O)
+        return torch.gather(best, 1, pred_idx_objects[:, None])[:, 0]
+
+    def compute_semantic_score(self, proposal_decriptors):
+        cfg = self.matching_config
+        scores = cfg.metric(proposal_decriptors, self.ref_data["descriptors"])     # (P,O,T)
+        agg = cfg.aggregation_function
+        if agg == "mean":
+            per_obj = scores.sum(dim=-1) / scores.shape[-1]
+        elif agg == "median":
+            per_obj = torch.median(scores, dim=-1)[0]
+        elif agg == "max":
+            per_obj = scores.max(dim=-1)[0]
+        elif agg == "avg_5":
+            per_obj = torch.topk(scores, k=5, dim=-1)[0].mean(dim=-1)
+        else:
+            raise NotImplementedError
+        score_per_proposal, assigned = per_obj.max(dim=-1)
+        idx_selected = torch.arange(len(score_per_proposal), device=score_per_proposal.device)[
+            score_per_proposal > cfg.confidence_thresh]
+        pred_idx_objects = assigned[idx_selected]
+        best_template = self.best_template_pose(scores[idx_selected, ...], pred_idx_objects)
+        return idx_selected, pred_idx_objects, score_per_proposal[idx_selected], best_template
+
+    def compute_appearance_score(self, best_pose, pred_objects_idx, qurey_appe_descriptors):
+        ref = self.ref_data["appe_descriptors"][pred_objects_idx, best_pose, ...]
+        metric = MaskedPatch_MatrixSimilarity(metric="cosine", chunk_size=64)
+        appe, ratio = metric.both(qurey_appe_descriptors, ref, getattr(self, "visible_thred", 0.5))
+        self._cached_visible = (qurey_appe_descriptors.data_ptr(), ref.data_ptr(),
+                                getattr(self, "visible_thred", 0.5), ratio)
+        return appe, ref
+
+    def compute_geometric_score(self, image_uv, proposals, appe_descriptors, ref_aux_descriptor, visible_thred=0.5):
+        c = getattr(self, "_cached_visible", None)
+        if c is not None and c[0] == appe_descriptors.data_ptr() and c[1] == ref_aux_descriptor.data_ptr() \
+                and c[2] == visible_thred:
+            visible_ratio = c[3]                       # same GEMM as the appearance score: reuse it
+        else:
+            visible_ratio = MaskedPatch_MatrixSimilarity().compute_visible_ratio(
+                appe_descriptors, ref_aux_descriptor, visible_thred)
+        xyxy = torch.cat((image_uv.min(dim=1).values, image_uv.max(dim=1).values), dim=-1)
+        return compute_iou(xyxy, proposals.boxes), visible_ratio
+
+    def Calculate_the_query_translation(self, proposal, depth, cam_intrinsic, depth_scale):
+        proposal = proposal.squeeze_()               # quirk Q7: in-place squeeze of detections.masks
+        if proposal.dim() == 2:
+            proposal = proposal[None]
+        return masked_depth_translation(proposal, depth, cam_intrinsic, depth_scale)
+
+    def project_template_to_image(self, best_pose, pred_object_idx, batch, proposals):
+        R = self.ref_data["poses"][best_pose, 0:3, 0:3]
+        pc = self.ref_data["pointcloud"][pred_object_idx, ...]
+        depth, K = batch["depth"][0], batch["cam_intrinsic"][0]
+        t = self.Calculate_the_query_translation(proposals, depth, K, batch["depth_scale"])
+        posed = pc @ R.transpose(1, 2) + t[:, None, :]
+        Kf = K.to(torch.float32)
+        homo = posed @ Kf.t()
+        uv = (homo / homo[:, :, -1:])[:, :, 0:2].to(torch.int)
+        H, W = depth.shape
+        uv[:, :, 0].clamp_(min=0, max=W - 1)
+        uv[:, :, 1].clamp_(min=0, max=H - 1)
+        return uv
+
+
+class FrameScorer(ScoringMixin):
+    """Stand-alone holder of the mixin's attribute contract (what bench.py and the tests drive
+    when the Lightning/Hydra shell of the reference is not installed)."""
+
+    def __init__(self, ref_descriptors, ref_appe_descriptors, poses, pointcloud, confidence_thresh=0.2,
+                 aggregation_function="avg_5", visible_thred=0.5):
+        from types import SimpleNamespace
+        from .loss import PairwiseSimilarity
+        self.ref_data = dict(descriptors=ref_descriptors, appe_descriptors=ref_appe_descriptors, poses=poses,
+                             pointcloud=pointcloud)
+        self.matching_config = SimpleNamespace(metric=PairwiseSimilarity(), aggregation_function=aggregation_function,
+                                               confidence_thresh=confidence_thresh)
+        self.visible_thred = visible_thred
+
+    def score(self, qry_cls, qry_patch, masks, boxes, depth, K, depth_scale=1.0):
+        """Matching stage of run_inference_custom.py:168-200 for one frame."""
+        from types import SimpleNamespace
+        sel, pobj, sem, bt = self.compute_semantic_score(qry_cls)
+        qp = qry_patch[sel]
+        appe, ref = self.compute_appearance_score(bt, pobj, qp)
+        batch = dict(depth=[depth], cam_intrinsic=[K], depth_scale=depth_scale)
+        uv = self.project_template_to_image(bt, pobj, batch, masks[sel])
+        geo, vr = self.compute_geometric_score(uv, SimpleNamespace(boxes=boxes[sel]), qp, ref, self.visible_thred)
+        final = (sem + appe + geo * vr) / (1 + 1 + vr)
+        return dict(sel=sel, pred_obj=pobj, semantic=sem, best_template=bt, appearance=appe, iou=geo,
+                    visible_ratio=vr, final=final, image_uv=uv)

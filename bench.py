@@ -119,7 +119,7 @@ def cpu_baseline():
     from sam6d_amd.sam.image_encoder import build_vit_h
     from sam6d_amd.utils import seeded, synth
 
-    cores = os.cpu_count()
+    cores = min(os.cpu_count(), 32)          # torch CPU kernels stop scaling (and regress) beyond ~32 threads
     torch.set_num_threads(cores)
     with torch.no_grad():
         Wp = {k: v for k, v in seeded.load_seeded(pm.Net(pm.default_cfg()), 1).state_dict().items()}

@@ -67,6 +67,37 @@ int s6d_group_points_f32(const float *points, const int32_t *idx, int B, int C, 
 int s6d_gather_rows_f32(const float *src, const int32_t *idx, int B, int N, int C, int M, float *out,
                         void *stream);
 
+/* ---------------------------------------------------------------- PEM pose solvers
+ * Replace the library-op chains of Pose_Estimation_Model/utils/model_utils.py. */
+
+/* R = V diag(1,1,det(V U^T)) U^T for H = U S V^T, n matrices: H (n,3,3) f32 -> R (n,3,3) f32.
+ * ref: weighted_procrustes, utils/model_utils.py:341-347 (torch.svd + det fix). */
+int s6d_rot_from_h_f32(const float *H, int n, float *R, void *stream);
+
+/* Pose hypotheses of compute_coarse_Rt (utils/model_utils.py:216-231).
+ * pts1 (B,N1,3), pts2 (B,N2,3) f32; pair (B,n_hyp,3) i32 = searchsorted() bins, decoded as
+ * (i1, i2) = (pair / N2, pair % N2), clamped like the reference.  Outputs R (B,n_hyp,3,3),
+ * t (B,n_hyp,3), dis (B,n_hyp) = mean_i |(p1_i - t) R - p2_i|. */
+int s6d_pose_hypotheses_f32(const float *pts1, const float *pts2, const int32_t *pair, int B, int N1,
+                            int N2, int n_hyp, float *R, float *t, float *dis, void *stream);
+
+/* dmin[b,p,n] = min_m |(pts[b,n] - t[b,p]) R[b,p] - model[b,m]|
+ * pts (B,N,3), R (B,P,3,3), t (B,P,3), model (B,Nm,3) -> dmin (B,P,N).
+ * ref: compute_coarse_Rt :234-239 (P = 300) and compute_fine_Rt :272-275 (P = 1). */
+int s6d_min_dist_f32(const float *pts, const float *R, const float *t, const float *model, int B, int N,
+                     int P, int Nm, float *dmin, void *stream);
+
+/* ---------------------------------------------------------------- PEM point transformer */
+
+/* RPE attention core: softmax_m((q.k + q~.e + qb) * scale) v, heads = 4, C = 256.
+ * q,k,v (B,N,C) f32 (projected, heads interleaved "(h c)"); qt (B,4,N,C) = W_p[h]^T q[b,h,n];
+ * qb (B,4,N) = q[b,h,n].b_p[h]; embed (B,N,N,C) geometric structure embedding -> out (B,N,C).
+ * ref: RPEMultiHeadAttention.forward, Pose_Estimation_Model/model/transformer.py:368-406
+ * (which materialises proj_p(embed) (B,4,N,N,64); here embed is streamed once). */
+int s6d_rpe_attention_f32(const float *q, const float *k, const float *v, const float *qt, const float *qb,
+                          const float *embed, int B, int N, int C, int heads, float scale, float *out,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -157,14 +157,19 @@ def attention_output(W, p, x):
     return lnorm(W, p + ".norm", x + lin(W, p + ".squeeze", F.relu(lin(W, p + ".expand", x))))
 
 
-def rpe_layer(W, p, x, emb):
-    """RPETransformerLayer (transformer.py:352-465) with memory == input."""
-    a = p + ".attention.attention"
+def rpe_attention(W, a, x, emb):
+    """RPEMultiHeadAttention.forward (transformer.py:368-406), memory == input; returns the
+    merged-head hidden states (B,N,C)."""
     q, k, v = (_heads(lin(W, f"{a}.proj_{n}", x)) for n in "qkv")
     B, N, _ = x.shape
     pe = lin(W, a + ".proj_p", emb).reshape(B, N, N, 4, 64).permute(0, 3, 1, 2, 4)   # (B,h,N,M,c)
     s = (torch.einsum("bhnc,bhmc->bhnm", q, k) + torch.einsum("bhnc,bhnmc->bhnm", q, pe)) / 8.0
-    h = (s.softmax(-1) @ v).transpose(1, 2).reshape(B, N, -1)
+    return (s.softmax(-1) @ v).transpose(1, 2).reshape(B, N, -1)
+
+
+def rpe_layer(W, p, x, emb):
+    """RPETransformerLayer (transformer.py:352-465) with memory == input."""
+    h = rpe_attention(W, p + ".attention.attention", x, emb)
     h = lnorm(W, p + ".attention.norm", lin(W, p + ".attention.linear", h) + x)
     return attention_output(W, p + ".output", h)
 

@@ -1,0 +1,119 @@
+// RPE attention core of the geometric transformer (gfx950).
+//
+// Reference: RPEMultiHeadAttention.forward, Pose_Estimation_Model/model/transformer.py:368-406
+//   p = proj_p(embed)                      (B,N,N,256) -> (B,4,N,N,64)   5.09 GFLOP, 39.7 MB / call
+//   s = (q k^T + einsum(q, p)) / 8 ; softmax over keys ; @ v
+// Here the positional term is  q~ . e + q.b_p  with q~ = W_p^T q computed by the caller
+// (see sam6d_amd/pem/layers.py), so the kernel streams the geometric embedding exactly once:
+// one WAVEFRONT per query row (b,n): 64 lanes x float4 = one 256-channel row per load, the four
+// head dot-products are folded with a 7-shuffle butterfly, softmax and P.V stay in the wave
+// (scores in LDS).  HBM-bound on the embedding: N*256*4 B per row.
+#include "s6d_common.h"
+
+namespace s6d {
+
+__device__ __forceinline__ float dot4(const float4 a, const float4 b) {
+  return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void rpe_attention_kernel(
+    const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+    const float *__restrict__ qt, const float *__restrict__ qb, const float *__restrict__ embed,
+    int B, int N, float scale, float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int Np = (N + 3) & ~3;
+  float *sc = reinterpret_cast<float *>(smem) + (size_t)wave * 4 * Np;   // [4][Np] scores of this wave
+  const long row = (long)blockIdx.x * WAVES + wave;                       // b*N + n
+  if (row >= (long)B * N) return;                                         // whole wave exits together
+  const int b = (int)(row / N), n = (int)(row % N);
+  const int g = lane >> 4;                                                // head owned by this lane group
+  const int c4 = lane * 4;                                                // channels c4..c4+3 (head = c4/64 = g)
+
+  const float4 q4 = *reinterpret_cast<const float4 *>(q + row * 256 + c4);
+  float4 t0, t1, t2, t3;                                                  // q~ of the four heads
+  {
+    const float *base = qt + ((size_t)b * 4 * N + n) * 256 + c4;         // (B,4,N,256)
+    t0 = *reinterpret_cast<const float4 *>(base);
+    t1 = *reinterpret_cast<const float4 *>(base + (size_t)N * 256);
+    t2 = *reinterpret_cast<const float4 *>(base + (size_t)2 * N * 256);
+    t3 = *reinterpret_cast<const float4 *>(base + (size_t)3 * N * 256);
+  }
+  const float qbg = qb[((size_t)b * 4 + g) * N + n];
+  const float *erow = embed + (size_t)row * N * 256 + c4;
+  const float *krow = k + (size_t)b * N * 256 + c4;
+  const float *vrow = v + (size_t)b * N * 256 + c4;
+  const bool hi32 = lane & 32, hi16 = lane & 16;
+
+  // ---- scores -------------------------------------------------------------------------------
+  for (int m = 0; m < N; ++m) {
+    const float4 e4 = *reinterpret_cast<const float4 *>(erow + (size_t)m * 256);
+    const float4 k4 = *reinterpret_cast<const float4 *>(krow + (size_t)m * 256);
+    const float p0 = dot4(t0, e4), p1 = dot4(t1, e4), p2 = dot4(t2, e4), p3 = dot4(t3, e4);
+    // fold 4 partials -> 1: lanes 0-31 keep heads {0,1}, 32-63 keep {2,3}; then bit 4 picks one
+    float ka = hi32 ? p2 : p0, kb = hi32 ? p3 : p1;
+    const float sa = hi32 ? p0 : p2, sb = hi32 ? p1 : p3;
+    ka += __shfl_xor(sa, 32);
+    kb += __shfl_xor(sb, 32);
+    float mine = hi16 ? kb : ka;
+    const float send = hi16 ? ka : kb;
+    mine += __shfl_xor(send, 16);
+    mine += dot4(q4, k4);                       // q.k for this lane's head (channels of head g)
+    mine += __shfl_xor(mine, 8);
+    mine += __shfl_xor(mine, 4);
+    mine += __shfl_xor(mine, 2);
+    mine += __shfl_xor(mine, 1);
+    if ((lane & 15) == 0) sc[g * Np + m] = (mine + qbg) * scale;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // ---- softmax over keys, per head (16 lanes per head) ---------------------------------------
+  float mx = -3.4e38f;
+  for (int m = lane & 15; m < N; m += 16) mx = fmaxf(mx, sc[g * Np + m]);
+  mx = fmaxf(mx, __shfl_xor(mx, 8));
+  mx = fmaxf(mx, __shfl_xor(mx, 4));
+  mx = fmaxf(mx, __shfl_xor(mx, 2));
+  mx = fmaxf(mx, __shfl_xor(mx, 1));
+  float sum = 0.f;
+  for (int m = lane & 15; m < N; m += 16) {
+    const float e = __expf(sc[g * Np + m] - mx);
+    sc[g * Np + m] = e;
+    sum += e;
+  }
+  sum += __shfl_xor(sum, 8);
+  sum += __shfl_xor(sum, 4);
+  sum += __shfl_xor(sum, 2);
+  sum += __shfl_xor(sum, 1);
+  const float inv = 1.0f / sum;
+  __builtin_amdgcn_wave_barrier();
+  // ---- P.V ------------------------------------------------------------------------------------
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int m = 0; m < N; ++m) {
+    const float a = sc[g * Np + m];
+    const float4 v4 = *reinterpret_cast<const float4 *>(vrow + (size_t)m * 256);
+    acc.x += a * v4.x; acc.y += a * v4.y; acc.z += a * v4.z; acc.w += a * v4.w;
+  }
+  acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+  *reinterpret_cast<float4 *>(out + row * 256 + c4) = acc;
+}
+
+}  // namespace s6d
+
+using namespace s6d;
+
+extern "C" int s6d_rpe_attention_f32(const float *q, const float *k, const float *v, const float *qt,
+                                     const float *qb, const float *embed, int B, int N, int C, int heads,
+                                     float scale, float *out, void *stream) {
+  if (B < 0 || N <= 0) return S6D_EINVAL;
+  if (C != 256 || heads != 4) return S6D_EUNSUPPORTED;   // released model: d_model 256, 4 heads
+  if (B == 0) return S6D_OK;
+  if (!q || !k || !v || !qt || !qb || !embed || !out) return S6D_EINVAL;
+  constexpr int WAVES = 4;
+  const long rows = (long)B * N;
+  const int Np = (N + 3) & ~3;
+  const size_t lds = (size_t)WAVES * 4 * Np * sizeof(float);
+  if (lds > 64 * 1024) return S6D_EUNSUPPORTED;
+  hipLaunchKernelGGL((rpe_attention_kernel<WAVES>), dim3((unsigned)((rows + WAVES - 1) / WAVES)), dim3(WAVES * 64),
+                     lds, as_stream(stream), q, k, v, qt, qb, embed, B, N, scale, out);
+  return launch_status();
+}

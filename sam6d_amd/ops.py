@@ -96,6 +96,56 @@ def group_points(points, idx):
     return out
 
 
+# ------------------------------------------------------------------ PEM pose solvers
+def rot_from_h(H):
+    """(...,3,3) f32 cross-covariances -> proper rotations (Procrustes)."""
+    _chk(H, torch.float32, "H")
+    n = H.numel() // 9
+    out = torch.empty_like(H)
+    _call("s6d_rot_from_h_f32", _ptr(H), n, _ptr(out), _stream())
+    return out
+
+
+def pose_hypotheses(pts1, pts2, pair):
+    """pts1 (B,N1,3), pts2 (B,N2,3) f32, pair (B,3*n) i32 -> R (B,n,3,3), t (B,n,3), dis (B,n)."""
+    _chk(pts1, torch.float32, "pts1", 3)
+    _chk(pts2, torch.float32, "pts2", 3)
+    _chk(pair, torch.int32, "pair", 2)
+    B, N1, _ = pts1.shape
+    N2 = pts2.shape[1]
+    n = pair.shape[1] // 3
+    R = torch.empty(B, n, 3, 3, dtype=torch.float32, device=pts1.device)
+    t = torch.empty(B, n, 3, dtype=torch.float32, device=pts1.device)
+    dis = torch.empty(B, n, dtype=torch.float32, device=pts1.device)
+    _call("s6d_pose_hypotheses_f32", _ptr(pts1), _ptr(pts2), _ptr(pair), B, N1, N2, n, _ptr(R), _ptr(t), _ptr(dis),
+          _stream())
+    return R, t, dis
+
+
+def min_dist(pts, R, t, model):
+    """pts (B,N,3), R (B,P,3,3), t (B,P,3), model (B,Nm,3) -> (B,P,N)."""
+    for a, nm, nd in ((pts, "pts", 3), (R, "R", 4), (t, "t", 3), (model, "model", 3)):
+        _chk(a, torch.float32, nm, nd)
+    B, N, _ = pts.shape
+    P, Nm = R.shape[1], model.shape[1]
+    out = torch.empty(B, P, N, dtype=torch.float32, device=pts.device)
+    _call("s6d_min_dist_f32", _ptr(pts), _ptr(R), _ptr(t), _ptr(model), B, N, P, Nm, _ptr(out), _stream())
+    return out
+
+
+# ------------------------------------------------------------------ PEM point transformer
+def rpe_attention(q, k, v, qt, qb, embed, scale):
+    """q,k,v (B,N,256); qt (B,4,N,256); qb (B,4,N); embed (B,N,N,256) -> (B,N,256), all f32."""
+    q, k, v, qt, qb = (t.contiguous() for t in (q, k, v, qt, qb))
+    for a, nm in ((q, "q"), (k, "k"), (v, "v"), (qt, "qt"), (qb, "qb"), (embed, "embed")):
+        _chk(a, torch.float32, nm)
+    B, N, C = q.shape
+    out = torch.empty_like(q)
+    _call("s6d_rpe_attention_f32", _ptr(q), _ptr(k), _ptr(v), _ptr(qt), _ptr(qb), _ptr(embed), B, N, C, 4,
+          ctypes.c_float(scale), _ptr(out), _stream())
+    return out
+
+
 # ------------------------------------------------------------------ fused-op registry
 # Names of fused gfx950 ops the loaded library exports.  Product modules ask ``have(name)``
 # and otherwise express the same math with library GEMMs on the device (never on the CPU).
@@ -106,7 +156,7 @@ def have(name):
     if name not in _FUSED:
         sym = {"rpe_attention": "s6d_rpe_attention_f32", "geo_embedding": "s6d_geo_embedding_f32",
                "fine_assign": "s6d_fine_assign_f32", "upsample_gather": "s6d_upsample_gather_f32",
-               "min_dist": "s6d_min_dist_f32", "win_attention": "s6d_win_attention_bf16",
+               "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "win_attention": "s6d_win_attention_bf16",
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
                "pe_group": "s6d_pe_group_f32", "masked_depth_mean": "s6d_masked_depth_mean_f32"}.get(name)

@@ -1,0 +1,86 @@
+"""GPU parity of the pose-solver kernels vs the CPU oracle (oracle/pem.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pem as opem
+from sam6d_amd.utils import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from sam6d_amd import ops
+    return ops
+
+
+def test_rot_from_h_vs_svd(ops):
+    g = torch.Generator().manual_seed(0)
+    H = torch.randn(4096, 3, 3, generator=g)
+    U, _, V = torch.svd(H.double())
+    eye = torch.eye(3, dtype=torch.float64).repeat(len(H), 1, 1)
+    eye[:, -1, -1] = torch.sign(torch.det(V @ U.transpose(1, 2)))
+    ref = (V @ eye @ U.transpose(1, 2)).float()
+    out = ops.rot_from_h(H.cuda()).cpu()
+    s = torch.linalg.svdvals(H.double())
+    well = (s[:, 1] - s[:, 2] > 1e-3 * s[:, 0])
+    assert (out - ref)[well].abs().max() < 1e-5
+
+
+def test_pose_hypotheses_vs_oracle(ops):
+    B, N, n = 3, 196, 6000
+    inp = synth.pem_inputs(B, seed=5, n_pts=N, with_rgb=False)
+    p1, p2 = inp["pts"] * 5, inp["dense_po"] * 5
+    g = torch.Generator().manual_seed(1)
+    pair = torch.randint(0, N * N, (B, 3 * n), generator=g)
+    pair[:, :5] = N * N  # searchsorted can return the end bin: exercises the clamps
+    i1 = torch.clamp(pair.div(N, rounding_mode="floor"), max=N - 1)
+    i2 = torch.clamp(pair % N, max=N - 1)
+    a = torch.gather(p1, 1, i1.unsqueeze(2).expand(-1, -1, 3)).reshape(B * n, 3, 3)
+    b = torch.gather(p2, 1, i2.unsqueeze(2).expand(-1, -1, 3)).reshape(B * n, 3, 3)
+    Rr, tr = opem.weighted_procrustes(b, a, None, weight_thresh=0.5)
+    dr = torch.norm((a - tr.unsqueeze(1)) @ Rr - b, dim=2).mean(1)
+    R, t, d = ops.pose_hypotheses(p1.cuda(), p2.cuda(), pair.int().cuda())
+    R, t, d = R.cpu().reshape(-1, 3, 3), t.cpu().reshape(-1, 3), d.cpu().reshape(-1)
+    H = (b - b.mean(1, keepdim=True)).transpose(1, 2) @ (a - a.mean(1, keepdim=True))
+    s = torch.linalg.svdvals(H.double())
+    well = (s[:, 1] > 1e-3 * s[:, 0]) & (s[:, 0] - s[:, 1] > 1e-3 * s[:, 0])   # non-degenerate triangles
+    assert well.float().mean() > 0.9
+    assert (R - Rr)[well].abs().max() < 2e-3 and (R - Rr)[well].abs().mean() < 1e-5
+    assert (d - dr)[well].abs().max() < 1e-3
+    assert (t - tr)[well].abs().max() < 5e-3
+
+
+@pytest.mark.parametrize("N,P", [(196, 300), (2048, 1)])
+def test_min_dist_vs_oracle(ops, N, P):
+    B, Nm = 2, 1024
+    g = torch.Generator().manual_seed(N)
+    pts = torch.randn(B, N, 3, generator=g)
+    model = torch.randn(B, Nm, 3, generator=g)
+    R = synth.random_rotations(B * P, g).reshape(B, P, 3, 3)
+    t = 0.1 * torch.randn(B, P, 3, generator=g)
+    tp = ((pts.unsqueeze(1) - t.unsqueeze(2)) @ R).double()
+    ref = torch.cdist(tp.reshape(B * P, N, 3), model.double().repeat_interleave(P, 0)).min(2)[0].reshape(B, P, N)
+    out = ops.min_dist(pts.cuda(), R.cuda(), t.cuda(), model.cuda()).cpu()
+    assert (out.double() - ref).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("B,N", [(2, 197), (3, 50)])
+def test_rpe_attention_vs_oracle(ops, B, N):
+    """Fused RPE attention (q~.e rewrite, streamed embedding) vs the reference formulation."""
+    from sam6d_amd.pem.layers import RPEMultiHeadAttention
+    from sam6d_amd.utils import seeded
+    from tests import util
+    m = RPEMultiHeadAttention(256).eval()
+    seeded.load_seeded(m, 4)
+    W = {"a." + k: v for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(B * 100 + N)
+    x = torch.randn(B, N, 256, generator=g)
+    emb = 0.5 * torch.randn(B, N, N, 256, generator=g)
+    with torch.no_grad():
+        ref = opem.rpe_attention(W, "a", x, emb)
+        assert ops.have("rpe_attention")
+        out = m.cuda()(x.cuda(), emb.cuda()).cpu()
+    assert (out - ref).abs().max() < 2e-5, (out - ref).abs().max()

@@ -98,6 +98,27 @@ int s6d_rpe_attention_f32(const float *q, const float *k, const float *v, const 
                           const float *embed, int B, int N, int C, int heads, float scale, float *out,
                           void *stream);
 
+/* ---------------------------------------------------------------- SAM image encoder */
+
+/* Fused (windowed or global) multi-head attention with decomposed relative-position bias.
+ * qkv (B,H,W,3,nh,hd) bf16 = output of the qkv Linear on the REAL tokens (no window padding);
+ * qkv_bias (3,nh,hd) bf16 = q/k/v of out-of-image window slots (the reference pads zeros after
+ * norm1, so those tokens equal the qkv bias and take part as keys); rel_h, rel_w (2S-1,hd) bf16
+ * (S = window, or H for window == 0 -> global attention; may both be NULL = no bias);
+ * out (B,H,W,nh*hd) bf16.  softmax(scale*q.k + q.rel_h[qy-ky+S-1] + q.rel_w[qx-kx+S-1]) v.
+ * hd in {64, 80}.
+ * ref: segment_anything/modeling/image_encoder.py Block.forward :166-182, Attention.forward
+ * :224-240, add_decomposed_rel_pos :325-361, window_partition/unpartition :243-289. */
+int s6d_win_attention_bf16(const void *qkv, const void *qkv_bias, const void *rel_h, const void *rel_w, int B,
+                           int H, int W, int num_heads, int head_dim, int window, float scale, void *out,
+                           void *stream);
+
+/* x_out = x + delta (skipped when delta == NULL: x_out may be NULL), y_out = LayerNorm_C(x_out)*gamma+beta.
+ * x, delta, x_out, y_out (rows,C) bf16; gamma, beta (C) f32; fp32 statistics; C % 8 == 0, C <= 2048.
+ * ref: the residual adds and norm1/norm2 of Block.forward, segment_anything/modeling/image_encoder.py:166-182. */
+int s6d_add_layernorm_bf16(const void *x, const void *delta, const float *gamma, const float *beta, float eps,
+                           long rows, int C, void *x_out, void *y_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -146,6 +146,46 @@ def rpe_attention(q, k, v, qt, qb, embed, scale):
     return out
 
 
+# ------------------------------------------------------------------ SAM image encoder
+def window_attention(qkv, qkv_bias, rel_h, rel_w, num_heads, window, scale):
+    """qkv (B,H,W,3C) bf16, qkv_bias (3C) bf16, rel_h/rel_w (2S-1,hd) bf16 or None -> (B,H,W,C) bf16."""
+    _chk(qkv, torch.bfloat16, "qkv", 4)
+    _chk(qkv_bias, torch.bfloat16, "qkv_bias", 1)
+    B, H, W, C3 = qkv.shape
+    C = C3 // 3
+    hd = C // num_heads
+    if rel_h is not None:
+        _chk(rel_h, torch.bfloat16, "rel_h", 2)
+        _chk(rel_w, torch.bfloat16, "rel_w", 2)
+        S = window if window > 0 else H
+        if rel_h.shape != (2 * S - 1, hd) or rel_w.shape != (2 * S - 1, hd):
+            raise RuntimeError("rel_pos tables must be (2S-1, head_dim)")
+    out = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=qkv.device)
+    _call("s6d_win_attention_bf16", _ptr(qkv), _ptr(qkv_bias), _ptr(rel_h) if rel_h is not None else _vp(0),
+          _ptr(rel_w) if rel_w is not None else _vp(0), B, H, W, int(num_heads), int(hd), int(window),
+          ctypes.c_float(scale), _ptr(out), _stream())
+    return out
+
+
+def add_layernorm(x, delta, gamma, beta, eps):
+    """x (...,C) bf16, delta same shape or None, gamma/beta (C) f32 -> (x + delta, LN(x + delta)) bf16."""
+    _chk(x, torch.bfloat16, "x")
+    _chk(gamma, torch.float32, "gamma", 1)
+    _chk(beta, torch.float32, "beta", 1)
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty_like(x)
+    if delta is not None:
+        _chk(delta, torch.bfloat16, "delta")
+        xo = torch.empty_like(x)
+    else:
+        xo = x
+    _call("s6d_add_layernorm_bf16", _ptr(x), _ptr(delta) if delta is not None else _vp(0), _ptr(gamma), _ptr(beta),
+          ctypes.c_float(eps), ctypes.c_long(rows), int(C), _ptr(xo) if delta is not None else _vp(0), _ptr(y),
+          _stream())
+    return xo, y
+
+
 # ------------------------------------------------------------------ fused-op registry
 # Names of fused gfx950 ops the loaded library exports.  Product modules ask ``have(name)``
 # and otherwise express the same math with library GEMMs on the device (never on the CPU).
@@ -156,7 +196,7 @@ def have(name):
     if name not in _FUSED:
         sym = {"rpe_attention": "s6d_rpe_attention_f32", "geo_embedding": "s6d_geo_embedding_f32",
                "fine_assign": "s6d_fine_assign_f32", "upsample_gather": "s6d_upsample_gather_f32",
-               "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "win_attention": "s6d_win_attention_bf16",
+               "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "add_layernorm": "s6d_add_layernorm_bf16", "win_attention": "s6d_win_attention_bf16",
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
                "pe_group": "s6d_pe_group_f32", "masked_depth_mean": "s6d_masked_depth_mean_f32"}.get(name)

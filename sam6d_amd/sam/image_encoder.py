@@ -181,20 +181,68 @@ class ImageEncoderViT(nn.Module):
         x = self.patch_embed(x)
         if self.pos_embed is not None:
             x = x + self.pos_embed.to(x.dtype)
+        if x.is_cuda and x.dtype == torch.bfloat16 and ops.have("add_layernorm"):
+            return self._blocks_fused(x, upto)
         for i, blk in enumerate(self.blocks):
             if upto is not None and i >= upto:
                 break
             x = blk(x)
         return x
 
+    @staticmethod
+    def _ln_f32(norm):
+        """fp32 copies of a LayerNorm's affine parameters, cached until the parameters change."""
+        key = (norm.weight._version, norm.bias._version, norm.weight.data_ptr())
+        c = getattr(norm, "_s6d_f32", None)
+        if c is None or c[0] != key:
+            c = (key, norm.weight.detach().float().contiguous(), norm.bias.detach().float().contiguous())
+            norm._s6d_f32 = c
+        return c[1], c[2]
+
+    def _blocks_fused(self, x, upto):
+        """Same dataflow as Block.forward with every residual add folded into the following LayerNorm
+        pass (one fused kernel): x += branch; h = LN(x)."""
+        x = x.contiguous()
+        delta = None
+        for i, blk in enumerate(self.blocks):
+            if upto is not None and i >= upto:
+                break
+            g, b = self._ln_f32(blk.norm1)
+            x, h = ops.add_layernorm(x, delta, g, b, blk.norm1.eps)
+            a = blk.attn(h, blk.window_size)
+            g, b = self._ln_f32(blk.norm2)
+            x, h = ops.add_layernorm(x, a.contiguous(), g, b, blk.norm2.eps)
+            delta = blk.mlp(h).contiguous()
+        return x if delta is None else x + delta
+
+    def neck_nhwc(self, t):
+        """neck (image_encoder.py:90-104) on the (B,H,W,C) token map, channels-last throughout:
+        1x1 conv = GEMM, LayerNorm2d = LN over the last dim, 3x3 conv = 9 shifted GEMMs accumulated
+        (MIOpen's bf16 NHWC 3x3 falls back to a naive kernel: 29 ms/call measured, profiles/r01_sam8_*)."""
+        c1, n1, c3, n2 = self.neck[0], self.neck[1], self.neck[2], self.neck[3]
+        B, H, W, C = t.shape
+        dt = t.dtype
+        y = F.linear(t, c1.weight.flatten(1).to(dt))
+        y = F.layer_norm(y.float(), (y.shape[-1],), n1.weight.float(), n1.bias.float(), n1.eps).to(dt)
+        Co = y.shape[-1]
+        yp = F.pad(y, (0, 0, 1, 1, 1, 1))                                   # zero pad H and W by 1
+        w = c3.weight.to(dt)                                                # (Co, Ci, 3, 3)
+        acc = None
+        for dy in range(3):
+            for dx in range(3):
+                part = F.linear(yp[:, dy:dy + H, dx:dx + W, :], w[:, :, dy, dx])
+                acc = part.float() if acc is None else acc + part.float()
+        z = F.layer_norm(acc, (Co,), n2.weight.float(), n2.bias.float(), n2.eps)
+        return z.permute(0, 3, 1, 2)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         dt = _dtype()
         in_dtype = x.dtype
         if dt != torch.float32 and x.is_cuda:
             with torch.autocast(device_type="cuda", dtype=dt):
-                y = self.neck(self.forward_tokens(x.to(dt)).permute(0, 3, 1, 2))
-            return y.to(in_dtype)
-        return self.neck(self.forward_tokens(x).permute(0, 3, 1, 2))
+                t = self.forward_tokens(x.to(dt))
+            return self.neck_nhwc(t.to(dt)).to(in_dtype)
+        return self.neck_nhwc(self.forward_tokens(x)).to(in_dtype)
 
 
 def build_vit_h():

@@ -45,8 +45,13 @@ struct AttnParams {
   int T;               // tokens per attention problem = S*S
   int nwx, nwy;        // windows per image along x / y (1,1 for global)
   int LT;              // padded table length (multiple of 16, >= 2S-1)
-  float scale;
+  unsigned magicS;     // ceil(2^32 / S): n / S == umulhi(n, magicS) for n < 2^32 / S
+  float scale_log2;    // softmax scale * log2(e): scores live in the exp2 domain
 };
+
+constexpr float kLog2e = 1.4426950408889634f;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+#define S6D_LDS(T) __attribute__((address_space(3))) T
 
 template <int HD>
 struct Cfg {
@@ -54,37 +59,40 @@ struct Cfg {
   static constexpr int HDP = KS * 32;           // padded head dim
   static constexpr int DT = HD / 16;            // 16-wide d tiles of the output
   static constexpr int KROW = HDP + 8;          // K image row stride (bf16 elements): +16 B pad
+  static constexpr int VROW = HD + 8;           // V image row stride (row-major [key][d]): +16 B pad
   static constexpr int KT = 64;                 // keys per tile
-  static constexpr int VROW = KT + 4;           // V^T image row stride per tile (bf16 elements): +8 B pad
+  static constexpr int KPARTS = HDP / 8, VPARTS = HD / 8;
 };
 
-// global element offset of token slot `t` of problem (b, wy, wx); returns false for an out-of-image slot
+__device__ __forceinline__ int div_S(const AttnParams &p, int n) { return (int)__umulhi((unsigned)n, p.magicS); }
+
+// global token index of slot `t` of problem (b, wy, wx); false for an out-of-image / out-of-range slot
 __device__ __forceinline__ bool token_offset(const AttnParams &p, int b, int wy, int wx, int t, size_t &off) {
-  const int ty = t / p.S, tx = t - ty * p.S;
+  const int ty = div_S(p, t), tx = t - ty * p.S;
   const int y = (p.ws ? wy * p.ws : 0) + ty, x = (p.ws ? wx * p.ws : 0) + tx;
   off = ((size_t)(b * p.H + y) * p.W + x);
   return (y < p.H) && (x < p.W) && (t < p.T);
 }
 
-// 8 consecutive head-dim elements [d0, d0+8) of q/k/v (which = 0/1/2) for a token slot, as bf16x8
+// 8 consecutive head-dim elements [d0, d0+8) of q/k/v (which = 0/1/2) for a token slot
 template <int HD>
 __device__ __forceinline__ uint4 load_chunk(const AttnParams &p, int which, int head, bool valid, size_t tok, int d0) {
-  uint4 r = make_uint4(0, 0, 0, 0);
-  if (d0 >= HD) return r;
+  if (d0 >= HD) return make_uint4(0, 0, 0, 0);
   const int C = p.nh * HD;
   const u16 *src = valid ? p.qkv + tok * (size_t)(3 * C) + (size_t)which * C + head * HD + d0
                          : p.qkv_bias + (size_t)which * C + head * HD + d0;
   return *reinterpret_cast<const uint4 *>(src);
 }
 
-// One KV tile (64 key slots, LDS resident) against one 16-query strip.
-//   Kl : K image of the tile  [64][KROW]      (row = key slot, zero padded head dim)
-//   Vt : V^T image of the tile [HD][VROW]     (row = d, col = key slot inside the tile)
-template <int HD>
-__device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl, const u16 *Vt, int key0,
+// MODE 0: bias from per-query LDS tables th/tw (any S);  MODE 1: aligned fast path (S == 64, one key row per
+// tile): th value is one LDS word per tile, tw lives in 16 registers;  MODE 2: no positional bias.
+//   Kl : K image of the tile [64][KROW];  Vl : V image of the tile [64][VROW] (row-major, read with
+//   ds_read_b64_tr_b16: lane c of a 16-lane group receives column c of a 4-key block).
+template <int HD, int MODE>
+__device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl, const u16 *Vl, int key0,
                                              const bf16x8 (&qf)[Cfg<HD>::KS], const float *th, const float *tw,
-                                             int qy, int qx, float &m_run, float &l_run,
-                                             f32x4 (&oacc)[Cfg<HD>::DT], int lane) {
+                                             int qy, int qx, float thv, const float (&twr)[16], float &m_run,
+                                             float &l_run, f32x4 (&oacc)[Cfg<HD>::DT], int lane) {
   using C = Cfg<HD>;
   const int g = lane >> 4, c = lane & 15;
   float s[4][4];
@@ -98,18 +106,20 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int kk = key0 + sub * 16 + g * 4 + r;         // key slot of this score; query = lane & 15
-      float v = acc[r] * p.scale;
-      if (p.rel_h) {
-        const int ky = kk / p.S, kx = kk - ky * p.S;
-        const int jh = qy - ky + p.S - 1, jw = qx - kx + p.S - 1;
-        const bool ok = kk < p.T;
-        v += ok ? (th[c * p.LT + jh] + tw[c * p.LT + jw]) : 0.f;
+      float v = acc[r] * p.scale_log2;
+      if (MODE == 1) {
+        s[sub][r] = v + thv + twr[sub * 4 + r];
+      } else {
+        const int kk = key0 + sub * 16 + g * 4 + r;       // key slot of this score; query = lane & 15
+        if (MODE == 0) {
+          const int ky = div_S(p, kk), kx = kk - ky * p.S;
+          const int jh = min(max(qy - ky + p.S - 1, 0), p.LT - 1), jw = qx - kx + p.S - 1;
+          v += th[c * p.LT + jh] + tw[c * p.LT + jw];
+        }
+        s[sub][r] = kk < p.T ? v : -1e30f;
       }
-      s[sub][r] = kk < p.T ? v : -1e30f;
     }
   }
-  // online softmax, one query per lane column (c); the 4 lane groups hold disjoint keys
   float mx = s[0][0];
 #pragma unroll
   for (int sub = 0; sub < 4; ++sub)
@@ -118,13 +128,13 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
   mx = fmaxf(mx, __shfl_xor(mx, 16));
   mx = fmaxf(mx, __shfl_xor(mx, 32));
   const float m_new = fmaxf(m_run, mx);
-  const float alpha = __expf(m_run - m_new);
+  const float alpha = exp2f(m_run - m_new);
   float psum = 0.f;
 #pragma unroll
   for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      s[sub][r] = __expf(s[sub][r] - m_new);
+      s[sub][r] = exp2f(s[sub][r] - m_new);
       psum += s[sub][r];
     }
   psum += __shfl_xor(psum, 16);
@@ -133,7 +143,7 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
   m_run = m_new;
 #pragma unroll
   for (int dt = 0; dt < C::DT; ++dt) oacc[dt] *= alpha;
-  // O^T += V^T P^T : two k-steps of 32 keys; k-index e<4 -> sub 2j, e>=4 -> sub 2j+1 (same permutation on both operands)
+  // O^T += V^T P^T: k-step j covers keys [32j, 32j+32); MFMA k-index e<4 -> key 32j+g*4+e, e>=4 -> 32j+16+g*4+(e-4)
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     union { bf16x8 v; u16 h[8]; } pb;
@@ -142,91 +152,105 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
       pb.h[e] = f2bf(s[2 * j][e]);
       pb.h[4 + e] = f2bf(s[2 * j + 1][e]);
     }
+    const u16 *vrow = Vl + (32 * j + g * 4 + (c >> 2)) * C::VROW + (c & 3) * 4;
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) {
-      union { bf16x8 v; uint2 u[2]; } va;
-      const u16 *row = Vt + (dt * 16 + c) * C::VROW + 32 * j + g * 4;
-      va.u[0] = *reinterpret_cast<const uint2 *>(row);
-      va.u[1] = *reinterpret_cast<const uint2 *>(row + 16);
+      union { bf16x8 v; s16x4 q[2]; } va;
+      va.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + dt * 16));
+      va.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + 16 * C::VROW + dt * 16));
       oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va.v, pb.v, oacc[dt], 0, 0, 0);
     }
   }
 }
 
-// Stage key slots [key0, key0+64) of problem (b,wy,wx,head) into the LDS images.
+// ---- staging: global -> registers -> LDS, split so the loads can fly under the previous tile's math ------
 template <int HD, int THREADS>
-__device__ __forceinline__ void stage_tile(const AttnParams &p, int b, int wy, int wx, int head, int key0, u16 *Kl,
-                                           u16 *Vt, int tid) {
+struct Stager {
   using C = Cfg<HD>;
-  constexpr int KPARTS = C::HDP / 8;
-  for (int i = tid; i < 64 * KPARTS; i += THREADS) {
-    const int key = i / KPARTS, part = i - key * KPARTS;
-    size_t tok;
-    const bool valid = token_offset(p, b, wy, wx, key0 + key, tok);
-    *reinterpret_cast<uint4 *>(Kl + key * C::KROW + part * 8) = load_chunk<HD>(p, 1, head, valid, tok, part * 8);
-  }
-  constexpr int VPARTS = HD / 8;
-  for (int i = tid; i < 64 * VPARTS; i += THREADS) {
-    const int key = i & 63, part = i >> 6;
-    size_t tok;
-    const bool valid = token_offset(p, b, wy, wx, key0 + key, tok);
-    union { uint4 u; u16 h[8]; } v;
-    v.u = load_chunk<HD>(p, 2, head, valid, tok, part * 8);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) Vt[(part * 8 + e) * C::VROW + key] = v.h[e];
-  }
-}
+  static constexpr int NK = (64 * C::KPARTS + THREADS - 1) / THREADS;
+  static constexpr int NV = (64 * C::VPARTS + THREADS - 1) / THREADS;
+  uint4 k[NK], v[NV];
 
-// Strip prologue: Q fragments, (qy,qx) of the lane's query and the two bias tables of the strip.
+  __device__ __forceinline__ void load(const AttnParams &p, int b, int wy, int wx, int head, int key0, int tid) {
+#pragma unroll
+    for (int n = 0; n < NK; ++n) {
+      const int i = tid + n * THREADS;
+      const int key = i / C::KPARTS, part = i - key * C::KPARTS;
+      size_t tok;
+      const bool valid = token_offset(p, b, wy, wx, key0 + key, tok);
+      k[n] = (i < 64 * C::KPARTS) ? load_chunk<HD>(p, 1, head, valid, tok, part * 8) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const int i = tid + n * THREADS;
+      const int key = i / C::VPARTS, part = i - key * C::VPARTS;
+      size_t tok;
+      const bool valid = token_offset(p, b, wy, wx, key0 + key, tok);
+      v[n] = (i < 64 * C::VPARTS) ? load_chunk<HD>(p, 2, head, valid, tok, part * 8) : make_uint4(0, 0, 0, 0);
+    }
+  }
+  __device__ __forceinline__ void store(u16 *Kl, u16 *Vl, int tid) const {
+#pragma unroll
+    for (int n = 0; n < NK; ++n) {
+      const int i = tid + n * THREADS;
+      const int key = i / C::KPARTS, part = i - key * C::KPARTS;
+      if (i < 64 * C::KPARTS) *reinterpret_cast<uint4 *>(Kl + key * C::KROW + part * 8) = k[n];
+    }
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const int i = tid + n * THREADS;
+      const int key = i / C::VPARTS, part = i - key * C::VPARTS;
+      if (i < 64 * C::VPARTS) *reinterpret_cast<uint4 *>(Vl + key * C::VROW + part * 8) = v[n];
+    }
+  }
+};
+
 template <int HD>
-__device__ __forceinline__ void load_strip(const AttnParams &p, int b, int wy, int wx, int head, int q0,
-                                           bf16x8 (&qf)[Cfg<HD>::KS], float *th, float *tw, int lane) {
-  using C = Cfg<HD>;
+__device__ __forceinline__ void load_q(const AttnParams &p, int b, int wy, int wx, int head, int q0,
+                                       bf16x8 (&qf)[Cfg<HD>::KS], int lane) {
   const int g = lane >> 4, c = lane & 15;
   size_t tok;
   const bool valid = token_offset(p, b, wy, wx, q0 + c, tok);
 #pragma unroll
-  for (int ks = 0; ks < C::KS; ++ks) {
+  for (int ks = 0; ks < Cfg<HD>::KS; ++ks) {
     union { uint4 u; bf16x8 v; } x;
     x.u = load_chunk<HD>(p, 0, head, valid, tok, ks * 32 + g * 8);
     qf[ks] = x.v;
   }
-  if (!p.rel_h) return;
-  const int L = 2 * p.S - 1;
-  for (int jt = 0; jt < p.LT / 16; ++jt) {
-    f32x4 ah = {0.f, 0.f, 0.f, 0.f}, aw = {0.f, 0.f, 0.f, 0.f};
-    const int j = jt * 16 + c;
+}
+
+// dst[c*ld + jj] = log2(e) * rel[j0 + sgn*jj] . q_c   for jj in [0, 16*njt), rows outside [0, L) give 0
+template <int HD>
+__device__ __forceinline__ void build_table(const u16 *rel, int L, int j0, int sgn, int njt,
+                                            const bf16x8 (&qf)[Cfg<HD>::KS], float *dst, int ld, int lane) {
+  const int g = lane >> 4, c = lane & 15;
+  for (int jt = 0; jt < njt; ++jt) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    const int j = j0 + sgn * (jt * 16 + c);
 #pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) {
+    for (int ks = 0; ks < Cfg<HD>::KS; ++ks) {
       const int d0 = ks * 32 + g * 8;
-      union { uint4 u; bf16x8 v; } rh, rw;
-      rh.u = make_uint4(0, 0, 0, 0);
-      rw.u = make_uint4(0, 0, 0, 0);
-      if (j < L && d0 < HD) {
-        rh.u = *reinterpret_cast<const uint4 *>(p.rel_h + (size_t)j * HD + d0);
-        rw.u = *reinterpret_cast<const uint4 *>(p.rel_w + (size_t)j * HD + d0);
-      }
-      ah = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh.v, qf[ks], ah, 0, 0, 0);
-      aw = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rw.v, qf[ks], aw, 0, 0, 0);
+      union { uint4 u; bf16x8 v; } r;
+      r.u = make_uint4(0, 0, 0, 0);
+      if (j >= 0 && j < L && d0 < HD) r.u = *reinterpret_cast<const uint4 *>(rel + (size_t)j * HD + d0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r.v, qf[ks], a, 0, 0, 0);
     }
-    // C layout: row j = jt*16 + g*4 + r, col = query c  ->  table[c][j]
-    *reinterpret_cast<float4 *>(th + c * p.LT + jt * 16 + g * 4) = make_float4(ah[0], ah[1], ah[2], ah[3]);
-    *reinterpret_cast<float4 *>(tw + c * p.LT + jt * 16 + g * 4) = make_float4(aw[0], aw[1], aw[2], aw[3]);
+    // C layout: row jj = jt*16 + g*4 + r, col = query c
+    *reinterpret_cast<float4 *>(dst + c * ld + jt * 16 + g * 4) =
+        make_float4(a[0] * kLog2e, a[1] * kLog2e, a[2] * kLog2e, a[3] * kLog2e);
   }
 }
 
 template <int HD>
 __device__ __forceinline__ void store_strip(const AttnParams &p, int b, int wy, int wx, int head, int q0, float l_run,
                                             const f32x4 (&oacc)[Cfg<HD>::DT], int lane) {
-  using C = Cfg<HD>;
   const int g = lane >> 4, c = lane & 15;
   size_t tok;
-  const bool valid = token_offset(p, b, wy, wx, q0 + c, tok);
-  if (!valid) return;
+  if (!token_offset(p, b, wy, wx, q0 + c, tok)) return;
   const float inv = 1.0f / l_run;
   u16 *dst = p.out + tok * (size_t)(p.nh * HD) + head * HD;
 #pragma unroll
-  for (int dt = 0; dt < C::DT; ++dt) {
+  for (int dt = 0; dt < Cfg<HD>::DT; ++dt) {
     union { uint2 u; u16 h[4]; } o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) o.h[r] = f2bf(oacc[dt][r] * inv);
@@ -234,15 +258,16 @@ __device__ __forceinline__ void store_strip(const AttnParams &p, int b, int wy, 
   }
 }
 
-// ---- windowed: one workgroup per (image, window, head); all key slots LDS resident ------------------
-template <int HD, int WAVES>
+// ---- windowed: one workgroup per (image, window, head); every key slot LDS resident ------------------------
+template <int HD, int WAVES, bool BIAS>
 __global__ __launch_bounds__(WAVES * 64) void attn_window_kernel(AttnParams p) {
   using C = Cfg<HD>;
+  constexpr int MODE = BIAS ? 0 : 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int ntile = (p.T + 63) / 64;
   u16 *Kl = reinterpret_cast<u16 *>(smem);                         // [ntile*64][KROW]
-  u16 *Vt = Kl + (size_t)ntile * 64 * C::KROW;                     // [ntile][HD][VROW]
-  float *tabs = reinterpret_cast<float *>(Vt + (size_t)ntile * HD * C::VROW);
+  u16 *Vl = Kl + (size_t)ntile * 64 * C::KROW;                     // [ntile*64][VROW]
+  float *tabs = reinterpret_cast<float *>(Vl + (size_t)ntile * 64 * C::VROW);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   float *th = tabs + (size_t)wave * 2 * 16 * p.LT, *tw = th + 16 * p.LT;
 
@@ -251,38 +276,51 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window_kernel(AttnParams p) {
   const int wx = id % p.nwx; id /= p.nwx;
   const int wy = id % p.nwy; id /= p.nwy;
   const int b = id;
-  for (int t = 0; t < ntile; ++t)
-    stage_tile<HD, WAVES * 64>(p, b, wy, wx, head, t * 64, Kl + (size_t)t * 64 * C::KROW, Vt + (size_t)t * HD * C::VROW, tid);
+  {
+    Stager<HD, WAVES * 64> st;
+    for (int t = 0; t < ntile; ++t) {
+      st.load(p, b, wy, wx, head, t * 64, tid);
+      st.store(Kl + (size_t)t * 64 * C::KROW, Vl + (size_t)t * 64 * C::VROW, tid);
+    }
+  }
   __syncthreads();
 
   const int nstrip = (p.T + 15) / 16;
+  const float twr[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int strip = wave; strip < nstrip; strip += WAVES) {
     const int q0 = strip * 16;
     bf16x8 qf[C::KS];
-    load_strip<HD>(p, b, wy, wx, head, q0, qf, th, tw, lane);
-    const int qi = q0 + (lane & 15);
-    const int qy = qi / p.S, qx = qi - qy * p.S;
+    load_q<HD>(p, b, wy, wx, head, q0, qf, lane);
+    if (BIAS) {
+      const int L = 2 * p.S - 1;
+      build_table<HD>(p.rel_h, L, 0, 1, p.LT / 16, qf, th, p.LT, lane);
+      build_table<HD>(p.rel_w, L, 0, 1, p.LT / 16, qf, tw, p.LT, lane);
+    }
+    const int qi = min(q0 + (lane & 15), p.T - 1);
+    const int qy = div_S(p, qi), qx = qi - qy * p.S;
     float m_run = -1e30f, l_run = 0.f;
     f32x4 oacc[C::DT];
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < ntile; ++t)
-      process_tile<HD>(p, Kl + (size_t)t * 64 * C::KROW, Vt + (size_t)t * HD * C::VROW, t * 64, qf, th, tw, qy, qx,
-                       m_run, l_run, oacc, lane);
+      process_tile<HD, MODE>(p, Kl + (size_t)t * 64 * C::KROW, Vl + (size_t)t * 64 * C::VROW, t * 64, qf, th, tw, qy,
+                             qx, 0.f, twr, m_run, l_run, oacc, lane);
     store_strip<HD>(p, b, wy, wx, head, q0, l_run, oacc, lane);
   }
 }
 
-// ---- global: one workgroup per (image, head, 64-query tile); KV tiles stream through LDS ---------------
-template <int HD, int WAVES>
+// ---- global: one workgroup per (image, head, 64-query tile); KV tiles stream through a 2-deep LDS ring -----
+template <int HD, int WAVES, int MODE>
 __global__ __launch_bounds__(WAVES * 64) void attn_global_kernel(AttnParams p) {
   using C = Cfg<HD>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  u16 *Kl = reinterpret_cast<u16 *>(smem);                         // [64][KROW]
-  u16 *Vt = Kl + (size_t)64 * C::KROW;                             // [HD][VROW]
-  float *tabs = reinterpret_cast<float *>(Vt + (size_t)HD * C::VROW);
+  constexpr int KBYTES = 64 * C::KROW * 2, VBYTES = 64 * C::VROW * 2;
+  // ring slot r: K image at r*(KBYTES+VBYTES), V image right behind it
+  auto Kbuf = [&](int r) { return reinterpret_cast<u16 *>(smem + r * (KBYTES + VBYTES)); };
+  auto Vbuf = [&](int r) { return reinterpret_cast<u16 *>(smem + r * (KBYTES + VBYTES) + KBYTES); };
+  float *tabs = reinterpret_cast<float *>(smem + 2 * (KBYTES + VBYTES));
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  float *th = tabs + (size_t)wave * 2 * 16 * p.LT, *tw = th + 16 * p.LT;
+  const int g = lane >> 4, c = lane & 15;
 
   const int nqt = (p.T + WAVES * 16 - 1) / (WAVES * 16);
   int id = blockIdx.x;
@@ -291,19 +329,50 @@ __global__ __launch_bounds__(WAVES * 64) void attn_global_kernel(AttnParams p) {
   const int b = id;
   const int q0 = (qt * WAVES + wave) * 16;
   bf16x8 qf[C::KS];
-  load_strip<HD>(p, b, 0, 0, head, q0, qf, th, tw, lane);
-  const int qi = q0 + (lane & 15);
-  const int qy = qi / p.S, qx = qi - qy * p.S;
+  load_q<HD>(p, b, 0, 0, head, q0, qf, lane);
+  const int qi = min(q0 + c, p.T - 1);
+  const int qy = div_S(p, qi), qx = qi - qy * p.S;
+  float twr[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) twr[i] = 0.f;
+  float *th = nullptr, *tw = nullptr;
+  if (MODE == 0) {
+    th = tabs + (size_t)wave * 2 * 16 * p.LT;
+    tw = th + 16 * p.LT;
+    const int L = 2 * p.S - 1;
+    build_table<HD>(p.rel_h, L, 0, 1, p.LT / 16, qf, th, p.LT, lane);
+    build_table<HD>(p.rel_w, L, 0, 1, p.LT / 16, qf, tw, p.LT, lane);
+  } else if (MODE == 1) {
+    // S == 64: the strip's 16 queries share qy (q0 % 16 == 0); tile t is key row ky = t.
+    //   th[c][t] = rel_h[qy - t + 63] . q_c ;  tw needs rel_w[qx_c - kx + 63], qx_c = q0x + c: build
+    //   G[c][jj] = rel_w[q0x + jj] . q_c (jj < 80) in scratch (aliases the ring, not yet in use) and gather.
+    th = tabs + (size_t)wave * 16 * 64;
+    float *G = reinterpret_cast<float *>(smem) + (size_t)wave * 16 * 80;
+    const int q0y = div_S(p, q0), q0x = q0 - q0y * p.S;
+    build_table<HD>(p.rel_h, 127, q0y + 63, -1, 4, qf, th, 64, lane);
+    build_table<HD>(p.rel_w, 127, q0x, 1, 5, qf, G, 80, lane);
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) twr[sub * 4 + r] = G[c * 80 + (c + 63 - (sub * 16 + g * 4 + r))];
+  }
   float m_run = -1e30f, l_run = 0.f;
   f32x4 oacc[C::DT];
 #pragma unroll
   for (int dt = 0; dt < C::DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int ntile = (p.T + 63) / 64;
+  Stager<HD, WAVES * 64> st;
+  st.load(p, b, 0, 0, head, 0, tid);
+  __syncthreads();                                  // table scratch (aliasing the ring) fully consumed
+  st.store(Kbuf(0), Vbuf(0), tid);
+  __syncthreads();
   for (int t = 0; t < ntile; ++t) {
-    __syncthreads();                                               // previous tile fully consumed
-    stage_tile<HD, WAVES * 64>(p, b, 0, 0, head, t * 64, Kl, Vt, tid);
+    const int cur = t & 1;
+    if (t + 1 < ntile) st.load(p, b, 0, 0, head, (t + 1) * 64, tid);      // flies under this tile's math
+    const float thv = (MODE == 1) ? th[c * 64 + t] : 0.f;
+    process_tile<HD, MODE>(p, Kbuf(cur), Vbuf(cur), t * 64, qf, th, tw, qy, qx, thv, twr, m_run, l_run, oacc, lane);
+    if (t + 1 < ntile) st.store(Kbuf(cur ^ 1), Vbuf(cur ^ 1), tid);       // ring slot last read in iteration t-1
     __syncthreads();
-    process_tile<HD>(p, Kl, Vt, t * 64, qf, th, tw, qy, qx, m_run, l_run, oacc, lane);
   }
   store_strip<HD>(p, b, 0, 0, head, q0, l_run, oacc, lane);
 }
@@ -311,24 +380,42 @@ __global__ __launch_bounds__(WAVES * 64) void attn_global_kernel(AttnParams p) {
 template <int HD>
 static int launch_attn(AttnParams p, hipStream_t st) {
   using C = Cfg<HD>;
-  constexpr int WAVES = 4;
-  const size_t tab = (size_t)WAVES * 2 * 16 * p.LT * sizeof(float);
+  const bool bias = p.rel_h != nullptr;
   if (p.ws > 0) {
+    constexpr int WAVES = 8;
     const int ntile = (p.T + 63) / 64;
-    const size_t lds = (size_t)ntile * 64 * C::KROW * 2 + (size_t)ntile * HD * C::VROW * 2 + tab;
+    const size_t lds = (size_t)ntile * 64 * (C::KROW + C::VROW) * 2 + (bias ? (size_t)WAVES * 2 * 16 * p.LT * 4 : 0);
     if (lds > 160 * 1024) return S6D_EUNSUPPORTED;
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_window_kernel<HD, WAVES>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const unsigned grid = (unsigned)(p.B * p.nwy * p.nwx * p.nh);
-    hipLaunchKernelGGL((attn_window_kernel<HD, WAVES>), dim3(grid), dim3(WAVES * 64), lds, st, p);
+    if (bias) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_window_kernel<HD, WAVES, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((attn_window_kernel<HD, WAVES, true>), dim3(grid), dim3(WAVES * 64), lds, st, p);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_window_kernel<HD, WAVES, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((attn_window_kernel<HD, WAVES, false>), dim3(grid), dim3(WAVES * 64), lds, st, p);
+    }
   } else {
-    const size_t lds = (size_t)64 * C::KROW * 2 + (size_t)HD * C::VROW * 2 + tab;
-    if (lds > 160 * 1024) return S6D_EUNSUPPORTED;
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_global_kernel<HD, WAVES>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    constexpr int WAVES = 4;
+    const size_t ring = (size_t)2 * 64 * (C::KROW + C::VROW) * 2;
     const int nqt = (p.T + WAVES * 16 - 1) / (WAVES * 16);
     const unsigned grid = (unsigned)(p.B * p.nh * nqt);
-    hipLaunchKernelGGL((attn_global_kernel<HD, WAVES>), dim3(grid), dim3(WAVES * 64), lds, st, p);
+#define S6D_GLB(MODE, LDS)                                                                                     \
+  do {                                                                                                         \
+    if ((LDS) > 160 * 1024) return S6D_EUNSUPPORTED;                                                           \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_global_kernel<HD, WAVES, MODE>),            \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS));                         \
+    hipLaunchKernelGGL((attn_global_kernel<HD, WAVES, MODE>), dim3(grid), dim3(WAVES * 64), (LDS), st, p);     \
+  } while (0)
+    if (!bias) {
+      S6D_GLB(2, ring);
+    } else if (p.S == 64 && ring >= (size_t)WAVES * 16 * 80 * 4) {
+      S6D_GLB(1, ring + (size_t)WAVES * 16 * 64 * 4);
+    } else {
+      S6D_GLB(0, ring + (size_t)WAVES * 2 * 16 * p.LT * 4);
+    }
+#undef S6D_GLB
   }
   return launch_status();
 }
@@ -352,7 +439,8 @@ extern "C" int s6d_win_attention_bf16(const void *qkv, const void *qkv_bias, con
   p.nwx = window ? (W + window - 1) / window : 1;
   p.nwy = window ? (H + window - 1) / window : 1;
   p.LT = ((2 * p.S - 1) + 15) / 16 * 16;
-  p.scale = scale;
+  p.magicS = (unsigned)(((1ull << 32) + (unsigned)p.S - 1) / (unsigned)p.S);
+  p.scale_log2 = scale * kLog2e;
   hipStream_t st = as_stream(stream);
   switch (head_dim) {
     case 80: return launch_attn<80>(p, st);

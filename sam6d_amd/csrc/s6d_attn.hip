@@ -26,10 +26,10 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef unsigned short u16;
 
-__device__ __forceinline__ u16 f2bf(float f) {  // round-to-nearest-even
-  unsigned u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (u16)(u >> 16);
+__device__ __forceinline__ u16 f2bf(float f) {  // round-to-nearest-even (v_cvt_pk_bf16_f32 on gfx950)
+  union { __bf16 b; u16 u; } x;
+  x.b = (__bf16)f;
+  return x.u;
 }
 __device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((unsigned)h) << 16); }
 
@@ -68,6 +68,10 @@ __device__ __forceinline__ int div_S(const AttnParams &p, int n) { return (int)_
 
 // global token index of slot `t` of problem (b, wy, wx); false for an out-of-image / out-of-range slot
 __device__ __forceinline__ bool token_offset(const AttnParams &p, int b, int wy, int wx, int t, size_t &off) {
+  if (p.ws == 0) {                      // global attention: slots are the image tokens in raster order
+    off = (size_t)b * p.T + t;
+    return t < p.T;
+  }
   const int ty = div_S(p, t), tx = t - ty * p.S;
   const int y = (p.ws ? wy * p.ws : 0) + ty, x = (p.ws ? wx * p.ws : 0) + tx;
   off = ((size_t)(b * p.H + y) * p.W + x);
@@ -309,6 +313,134 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window_kernel(AttnParams p) {
   }
 }
 
+// ---- windowed, row-padded (S <= 16): key slot = ky*16 + kx, so every 16-key MFMA sub-tile is ONE key row and
+// every 16-query strip is ONE query row: the decomposed bias costs one LDS word per sub-tile (rel_h) plus four
+// registers (rel_w, kx = g*4+r fixed per lane; out-of-window columns carry -1e30 there, which is the mask).
+template <int HD, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p) {
+  using C = Cfg<HD>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int S = p.S, SR = (S + 1) & ~1;                            // key rows, rounded up to a 32-key k-step
+  u16 *Kl = reinterpret_cast<u16 *>(smem);                         // [SR*16][KROW]
+  u16 *Vl = Kl + (size_t)SR * 16 * C::KROW;                        // [SR*16][VROW]
+  float *tabs = reinterpret_cast<float *>(Vl + (size_t)SR * 16 * C::VROW);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int g = lane >> 4, c = lane & 15;
+  float *th = tabs + (size_t)wave * 2 * 16 * 32, *tw = th + 16 * 32;
+
+  int id = blockIdx.x;
+  const int head = id % p.nh; id /= p.nh;
+  const int wx = id % p.nwx; id /= p.nwx;
+  const int wy = id % p.nwy; id /= p.nwy;
+  const int b = id;
+  const int Cc = p.nh * HD;
+  // stage K and V of the whole window (bias vector for out-of-image slots, zeros for padding slots)
+  for (int i = tid; i < SR * 16 * (C::KPARTS + C::VPARTS); i += WAVES * 64) {
+    const bool isv = i >= SR * 16 * C::KPARTS;
+    const int ii = isv ? i - SR * 16 * C::KPARTS : i;
+    const int parts = isv ? C::VPARTS : C::KPARTS;
+    const int slot = ii / parts, part = ii - slot * parts;
+    const int ky = slot >> 4, kx = slot & 15;
+    const int y = wy * p.ws + ky, x = wx * p.ws + kx;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (ky < S && kx < S && part * 8 < HD) {
+      const bool img = (y < p.H) && (x < p.W);
+      const u16 *src = img ? p.qkv + ((size_t)(b * p.H + y) * p.W + x) * (size_t)(3 * Cc) + (isv ? 2 : 1) * Cc + head * HD + part * 8
+                           : p.qkv_bias + (isv ? 2 : 1) * Cc + head * HD + part * 8;
+      v = *reinterpret_cast<const uint4 *>(src);
+    }
+    u16 *dst = isv ? Vl + slot * C::VROW + part * 8 : Kl + slot * C::KROW + part * 8;
+    *reinterpret_cast<uint4 *>(dst) = v;
+  }
+  __syncthreads();
+
+  const int L = 2 * S - 1;
+  for (int qy = wave; qy < S; qy += WAVES) {                      // one query row per strip; query column = c
+    const int y = wy * p.ws + qy, x = wx * p.ws + c;
+    const bool qwin = c < S, qimg = qwin && (y < p.H) && (x < p.W);
+    bf16x8 qf[C::KS];
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      union { uint4 u; bf16x8 v; } t;
+      const int d0 = ks * 32 + g * 8;
+      t.u = make_uint4(0, 0, 0, 0);
+      if (qwin && d0 < HD) {
+        const u16 *src = qimg ? p.qkv + ((size_t)(b * p.H + y) * p.W + x) * (size_t)(3 * Cc) + head * HD + d0
+                              : p.qkv_bias + head * HD + d0;
+        t.u = *reinterpret_cast<const uint4 *>(src);
+      }
+      qf[ks] = t.v;
+    }
+    build_table<HD>(p.rel_h, L, 0, 1, 2, qf, th, 32, lane);
+    build_table<HD>(p.rel_w, L, 0, 1, 2, qf, tw, 32, lane);
+    float twr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int kx = g * 4 + r;
+      twr[r] = kx < S ? tw[c * 32 + min(c - kx + S - 1, 31)] : -1e30f;
+    }
+    float m_run = -1e30f, l_run = 0.f;
+    f32x4 oacc[C::DT];
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < SR; u += 2) {                             // 32 keys = key rows u, u+1
+      float s[2][4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ky = u + h;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8 *>(Kl + (ky * 16 + c) * C::KROW + ks * 32 + g * 8);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], acc, 0, 0, 0);
+        }
+        const float thv = ky < S ? th[c * 32 + (qy - ky + S - 1)] : -1e30f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[h][r] = acc[r] * p.scale_log2 + thv + twr[r];
+      }
+      float mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])),
+                       fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(fmaxf(m_run, mx), -1e29f);        // stays finite even if a whole row is padding
+      const float alpha = exp2f(m_run - m_new);
+      float psum = 0.f;
+      union { bf16x8 v; u16 hh[8]; } pb;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = exp2f(s[h][r] - m_new);
+          psum += e;
+          pb.hh[h * 4 + r] = f2bf(e);
+        }
+      psum += __shfl_xor(psum, 16);
+      psum += __shfl_xor(psum, 32);
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+      const u16 *vrow = Vl + (u * 16 + g * 4 + (c >> 2)) * C::VROW + (c & 3) * 4;
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) {
+        union { bf16x8 v; s16x4 q[2]; } va;
+        va.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + dt * 16));
+        va.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + 16 * C::VROW + dt * 16));
+        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va.v, pb.v, oacc[dt] * alpha, 0, 0, 0);
+      }
+    }
+    if (qimg) {
+      const float inv = 1.0f / l_run;
+      u16 *dst = p.out + ((size_t)(b * p.H + y) * p.W + x) * (size_t)Cc + head * HD;
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) {
+        union { uint2 u2; u16 hh[4]; } o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o.hh[r] = f2bf(oacc[dt][r] * inv);
+        *reinterpret_cast<uint2 *>(dst + dt * 16 + g * 4) = o.u2;
+      }
+    }
+  }
+}
+
 // ---- global: one workgroup per (image, head, 64-query tile); KV tiles stream through a 2-deep LDS ring -----
 template <int HD, int WAVES, int MODE>
 __global__ __launch_bounds__(WAVES * 64) void attn_global_kernel(AttnParams p) {
@@ -381,7 +513,16 @@ template <int HD>
 static int launch_attn(AttnParams p, hipStream_t st) {
   using C = Cfg<HD>;
   const bool bias = p.rel_h != nullptr;
-  if (p.ws > 0) {
+  if (p.ws > 0 && bias && p.S <= 16) {
+    constexpr int WAVES = 7;                                      // 14 query rows / 7 waves for the SAM window
+    const int SR = (p.S + 1) & ~1;
+    const size_t lds = (size_t)SR * 16 * (C::KROW + C::VROW) * 2 + (size_t)WAVES * 2 * 16 * 32 * 4;
+    if (lds > 160 * 1024) return S6D_EUNSUPPORTED;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_window16_kernel<HD, WAVES>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const unsigned grid = (unsigned)(p.B * p.nwy * p.nwx * p.nh);
+    hipLaunchKernelGGL((attn_window16_kernel<HD, WAVES>), dim3(grid), dim3(WAVES * 64), lds, st, p);
+  } else if (p.ws > 0) {
     constexpr int WAVES = 8;
     const int ntile = (p.T + 63) / 64;
     const size_t lds = (size_t)ntile * 64 * (C::KROW + C::VROW) * 2 + (bias ? (size_t)WAVES * 2 * 16 * p.LT * 4 : 0);

@@ -334,31 +334,14 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
   const int wy = id % p.nwy; id /= p.nwy;
   const int b = id;
   const int Cc = p.nh * HD;
-  // stage K and V of the whole window (bias vector for out-of-image slots, zeros for padding slots)
-  for (int i = tid; i < SR * 16 * (C::KPARTS + C::VPARTS); i += WAVES * 64) {
-    const bool isv = i >= SR * 16 * C::KPARTS;
-    const int ii = isv ? i - SR * 16 * C::KPARTS : i;
-    const int parts = isv ? C::VPARTS : C::KPARTS;
-    const int slot = ii / parts, part = ii - slot * parts;
-    const int ky = slot >> 4, kx = slot & 15;
-    const int y = wy * p.ws + ky, x = wx * p.ws + kx;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (ky < S && kx < S && part * 8 < HD) {
-      const bool img = (y < p.H) && (x < p.W);
-      const u16 *src = img ? p.qkv + ((size_t)(b * p.H + y) * p.W + x) * (size_t)(3 * Cc) + (isv ? 2 : 1) * Cc + head * HD + part * 8
-                           : p.qkv_bias + (isv ? 2 : 1) * Cc + head * HD + part * 8;
-      v = *reinterpret_cast<const uint4 *>(src);
-    }
-    u16 *dst = isv ? Vl + slot * C::VROW + part * 8 : Kl + slot * C::KROW + part * 8;
-    *reinterpret_cast<uint4 *>(dst) = v;
-  }
-  __syncthreads();
-
-  const int L = 2 * S - 1;
-  for (int qy = wave; qy < S; qy += WAVES) {                      // one query row per strip; query column = c
+  // Q fragments of every query row this wave owns are fetched first so their latency hides under the staging
+  constexpr int MAXROWS = (16 + WAVES - 1) / WAVES;
+  bf16x8 qfa[MAXROWS][C::KS];
+#pragma unroll
+  for (int i = 0; i < MAXROWS; ++i) {
+    const int qy = wave + i * WAVES;
     const int y = wy * p.ws + qy, x = wx * p.ws + c;
-    const bool qwin = c < S, qimg = qwin && (y < p.H) && (x < p.W);
-    bf16x8 qf[C::KS];
+    const bool qwin = c < S && qy < S, qimg = qwin && (y < p.H) && (x < p.W);
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) {
       union { uint4 u; bf16x8 v; } t;
@@ -369,8 +352,53 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
                               : p.qkv_bias + head * HD + d0;
         t.u = *reinterpret_cast<const uint4 *>(src);
       }
-      qf[ks] = t.v;
+      qfa[i][ks] = t.v;
     }
+  }
+  // stage K and V of the whole window (bias vector for out-of-image slots, zeros for padding slots);
+  // UN independent 16-byte loads are in flight per thread before any is written to LDS
+  {
+    constexpr int UN = 6;
+    const int total = SR * 16 * (C::KPARTS + C::VPARTS);
+    for (int i0 = tid; i0 < total; i0 += UN * WAVES * 64) {
+      uint4 v[UN];
+      u16 *dst[UN];
+#pragma unroll
+      for (int n = 0; n < UN; ++n) {
+        const int i = i0 + n * WAVES * 64;
+        const bool isv = i >= SR * 16 * C::KPARTS;
+        const int ii = isv ? i - SR * 16 * C::KPARTS : i;
+        const int parts = isv ? C::VPARTS : C::KPARTS;
+        const int slot = ii / parts, part = ii - slot * parts;
+        const int ky = slot >> 4, kx = slot & 15;
+        const int y = wy * p.ws + ky, x = wx * p.ws + kx;
+        v[n] = make_uint4(0, 0, 0, 0);
+        dst[n] = nullptr;
+        if (i < total) {
+          dst[n] = isv ? Vl + slot * C::VROW + part * 8 : Kl + slot * C::KROW + part * 8;
+          if (ky < S && kx < S && part * 8 < HD) {
+            const bool img = (y < p.H) && (x < p.W);
+            const u16 *src = img ? p.qkv + ((size_t)(b * p.H + y) * p.W + x) * (size_t)(3 * Cc) + (isv ? 2 : 1) * Cc + head * HD + part * 8
+                                 : p.qkv_bias + (isv ? 2 : 1) * Cc + head * HD + part * 8;
+            v[n] = *reinterpret_cast<const uint4 *>(src);
+          }
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < UN; ++n)
+        if (dst[n]) *reinterpret_cast<uint4 *>(dst[n]) = v[n];
+    }
+  }
+  __syncthreads();
+
+  const int L = 2 * S - 1;
+#pragma unroll
+  for (int i = 0; i < MAXROWS; ++i) {                             // one query row per strip; query column = c
+    const int qy = wave + i * WAVES;
+    if (qy >= S) break;
+    const int y = wy * p.ws + qy, x = wx * p.ws + c;
+    const bool qimg = c < S && (y < p.H) && (x < p.W);
+    const bf16x8 (&qf)[C::KS] = qfa[i];
     build_table<HD>(p.rel_h, L, 0, 1, 2, qf, th, 32, lane);
     build_table<HD>(p.rel_w, L, 0, 1, 2, qf, tw, 32, lane);
     float twr[4];
@@ -454,11 +482,22 @@ __global__ __launch_bounds__(WAVES * 64) void attn_global_kernel(AttnParams p) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int g = lane >> 4, c = lane & 15;
 
+  // Workgroup -> (image, head, query tile).  All query tiles of one (image, head) re-read the same 1.3 MB of
+  // K/V: keep them on ONE XCD (observed placement: block id % 8) so the re-reads hit that XCD's 4 MB L2
+  // instead of streaming from HBM once per query tile.  Pure speed choice; any placement is correct.
   const int nqt = (p.T + WAVES * 16 - 1) / (WAVES * 16);
   int id = blockIdx.x;
-  const int qt = id % nqt; id /= nqt;
-  const int head = id % p.nh; id /= p.nh;
-  const int b = id;
+  const int nbh = p.B * p.nh;
+  int qt, bh;
+  if ((nbh & 7) == 0) {
+    const int xcd = id & 7, loc = id >> 3;
+    qt = loc % nqt;
+    bh = (loc / nqt) * 8 + xcd;
+  } else {
+    qt = id % nqt;
+    bh = id / nqt;
+  }
+  const int head = bh % p.nh, b = bh / p.nh;
   const int q0 = (qt * WAVES + wave) * 16;
   bf16x8 qf[C::KS];
   load_q<HD>(p, b, 0, 0, head, q0, qf, lane);

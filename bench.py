@@ -89,11 +89,10 @@ class HotPath:
         self.sam_stage()
         self.ism_stage()
         out = self.pem_stage()
-        # fixed-width pose record per instance: [frame, obj, score, R(9), t(3)] (68 B)
-        rec = torch.cat([torch.arange(self.F, device=self.dev, dtype=torch.float32)[:, None],
-                         torch.zeros(self.F, 1, device=self.dev), out["pred_pose_score"][:, None],
-                         out["pred_R"].reshape(self.F, 9), out["pred_t"]], dim=1)
-        return rec
+        # fixed-width pose record per instance (68 B)
+        from sam6d_amd.utils import shard
+        return shard.pack_records(0, torch.arange(self.F, device=self.dev), 5, out["pred_pose_score"],
+                                  out["pred_R"], out["pred_t"], 0.0)
 
 
 def stage_ms(fn, n=2):

@@ -14,7 +14,10 @@ _CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libsam6d_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+# -amdgpu-mfma-vgpr-form: MFMA accumulators live in VGPRs (gfx950 has a unified register file); removes the
+# v_accvgpr_read/write traffic around every softmax rescale (+6 % on the attention kernels, measured).
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 _lib = None
 
@@ -37,7 +40,7 @@ def build(force=False, verbose=False):
         return SO_PATH
     if not os.path.exists(HIPCC):
         raise RuntimeError(f"hipcc not found at {HIPCC}; cannot build libsam6d_hip.so")
-    cmd = [HIPCC] + FLAGS + ["-o", SO_PATH] + sources()
+    cmd = [HIPCC] + FLAGS + os.environ.get("S6D_EXTRA_HIPCC_FLAGS", "").split() + ["-o", SO_PATH] + sources()
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=_CSRC)

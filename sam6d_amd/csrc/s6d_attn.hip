@@ -19,6 +19,7 @@
 //   The decomposed bias  rel_h[q,ky] + rel_w[q,kx]  comes from two per-query tables
 //   T[j][q] = rel_pos[j] . q  (2S-1 entries) built with the same MFMA shape in the strip prologue.
 #include "s6d_common.h"
+#include <stdlib.h>
 
 namespace s6d {
 
@@ -47,6 +48,7 @@ struct AttnParams {
   int LT;              // padded table length (multiple of 16, >= 2S-1)
   unsigned magicS;     // ceil(2^32 / S): n / S == umulhi(n, magicS) for n < 2^32 / S
   float scale_log2;    // softmax scale * log2(e): scores live in the exp2 domain
+  int dbg;             // ablation switches for profiling (S6D_ATTN_DBG): 1 = no K/V loads, 2 = no tile math
 };
 
 constexpr float kLog2e = 1.4426950408889634f;
@@ -67,25 +69,30 @@ struct Cfg {
 __device__ __forceinline__ int div_S(const AttnParams &p, int n) { return (int)__umulhi((unsigned)n, p.magicS); }
 
 // global token index of slot `t` of problem (b, wy, wx); false for an out-of-image / out-of-range slot
+// (`off` is always a valid token index -- clamped -- so loads through it may be issued unconditionally)
 __device__ __forceinline__ bool token_offset(const AttnParams &p, int b, int wy, int wx, int t, size_t &off) {
   if (p.ws == 0) {                      // global attention: slots are the image tokens in raster order
-    off = (size_t)b * p.T + t;
+    off = (size_t)b * p.T + min(t, p.T - 1);
     return t < p.T;
   }
   const int ty = div_S(p, t), tx = t - ty * p.S;
-  const int y = (p.ws ? wy * p.ws : 0) + ty, x = (p.ws ? wx * p.ws : 0) + tx;
-  off = ((size_t)(b * p.H + y) * p.W + x);
+  const int y = wy * p.ws + ty, x = wx * p.ws + tx;
+  off = ((size_t)(b * p.H + min(y, p.H - 1)) * p.W + min(x, p.W - 1));
   return (y < p.H) && (x < p.W) && (t < p.T);
 }
 
-// 8 consecutive head-dim elements [d0, d0+8) of q/k/v (which = 0/1/2) for a token slot
+// 8 consecutive head-dim elements [d0, d0+8) of q/k/v (which = 0/1/2) for a token slot.  Branch-free on
+// purpose: the load is unconditional (clamped address, pointer select), zeros are selected afterwards, so the
+// compiler can keep a whole batch of these in flight instead of one exec-masked load + vmcnt(0) each.
+// `tok` must be a valid token index even when !valid (callers clamp).
 template <int HD>
 __device__ __forceinline__ uint4 load_chunk(const AttnParams &p, int which, int head, bool valid, size_t tok, int d0) {
-  if (d0 >= HD) return make_uint4(0, 0, 0, 0);
   const int C = p.nh * HD;
-  const u16 *src = valid ? p.qkv + tok * (size_t)(3 * C) + (size_t)which * C + head * HD + d0
-                         : p.qkv_bias + (size_t)which * C + head * HD + d0;
-  return *reinterpret_cast<const uint4 *>(src);
+  const int dc = d0 < HD ? d0 : HD - 8;
+  const u16 *a = p.qkv + tok * (size_t)(3 * C) + (size_t)which * C + head * HD + dc;
+  const u16 *bsrc = p.qkv_bias + (size_t)which * C + head * HD + dc;
+  const uint4 v = *reinterpret_cast<const uint4 *>(valid ? a : bsrc);
+  return d0 < HD ? v : make_uint4(0, 0, 0, 0);
 }
 
 // MODE 0: bias from per-query LDS tables th/tw (any S);  MODE 1: aligned fast path (S == 64, one key row per
@@ -131,8 +138,11 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
     for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[sub][r]);
   mx = fmaxf(mx, __shfl_xor(mx, 16));
   mx = fmaxf(mx, __shfl_xor(mx, 32));
-  const float m_new = fmaxf(m_run, mx);
-  const float alpha = exp2f(m_run - m_new);
+  // deferred rescaling: keep the old running max while no query's max grew by more than 2^kDefer
+  // (P stays <= 2^kDefer, exact in bf16's exponent range); the O / l rescale is skipped on those tiles.
+  constexpr float kDefer = 6.0f;
+  const bool grow = __any(mx - m_run > kDefer);
+  const float m_new = grow ? fmaxf(m_run, mx) : m_run;
   float psum = 0.f;
 #pragma unroll
   for (int sub = 0; sub < 4; ++sub)
@@ -143,10 +153,14 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
     }
   psum += __shfl_xor(psum, 16);
   psum += __shfl_xor(psum, 32);
-  l_run = l_run * alpha + psum;
-  m_run = m_new;
+  if (grow) {                                       // wave-uniform
+    const float alpha = exp2f(m_run - m_new);
+    l_run *= alpha;
 #pragma unroll
-  for (int dt = 0; dt < C::DT; ++dt) oacc[dt] *= alpha;
+    for (int dt = 0; dt < C::DT; ++dt) oacc[dt] *= alpha;
+    m_run = m_new;
+  }
+  l_run += psum;
   // O^T += V^T P^T: k-step j covers keys [32j, 32j+32); MFMA k-index e<4 -> key 32j+g*4+e, e>=4 -> 32j+16+g*4+(e-4)
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -178,19 +192,19 @@ struct Stager {
   __device__ __forceinline__ void load(const AttnParams &p, int b, int wy, int wx, int head, int key0, int tid) {
 #pragma unroll
     for (int n = 0; n < NK; ++n) {
-      const int i = tid + n * THREADS;
+      const int i = min(tid + n * THREADS, 64 * C::KPARTS - 1);     // surplus lanes repeat the last chunk
       const int key = i / C::KPARTS, part = i - key * C::KPARTS;
       size_t tok;
       const bool valid = token_offset(p, b, wy, wx, key0 + key, tok);
-      k[n] = (i < 64 * C::KPARTS) ? load_chunk<HD>(p, 1, head, valid, tok, part * 8) : make_uint4(0, 0, 0, 0);
+      k[n] = load_chunk<HD>(p, 1, head, valid, tok, part * 8);
     }
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
-      const int i = tid + n * THREADS;
+      const int i = min(tid + n * THREADS, 64 * C::VPARTS - 1);
       const int key = i / C::VPARTS, part = i - key * C::VPARTS;
       size_t tok;
       const bool valid = token_offset(p, b, wy, wx, key0 + key, tok);
-      v[n] = (i < 64 * C::VPARTS) ? load_chunk<HD>(p, 2, head, valid, tok, part * 8) : make_uint4(0, 0, 0, 0);
+      v[n] = load_chunk<HD>(p, 2, head, valid, tok, part * 8);
     }
   }
   __device__ __forceinline__ void store(u16 *Kl, u16 *Vl, int tid) const {
@@ -206,6 +220,52 @@ struct Stager {
       const int key = i / C::VPARTS, part = i - key * C::VPARTS;
       if (i < 64 * C::VPARTS) *reinterpret_cast<uint4 *>(Vl + key * C::VROW + part * 8) = v[n];
     }
+  }
+};
+
+// Global attention, T % 64 == 0: token slots are contiguous in memory, so each thread's chunk addresses are
+// fixed up to a per-tile stride -- pointers and LDS offsets are computed once, a tile costs 6 loads + 6 adds.
+template <int HD, int THREADS>
+struct StagerLinear {
+  using C = Cfg<HD>;
+  static constexpr int NK = (64 * C::KPARTS + THREADS - 1) / THREADS;
+  static constexpr int NV = (64 * C::VPARTS + THREADS - 1) / THREADS;
+  uint4 k[NK], v[NV];
+  const u16 *kp[NK], *vp[NV];
+  int ko[NK], vo[NV];                    // LDS element offsets (-1: surplus lane, nothing to store)
+  bool kz[NK];                           // chunk lies in the zero padding of the head dim
+
+  __device__ __forceinline__ void init(const AttnParams &p, int b, int head, int tid) {
+    const int Cc = p.nh * HD;
+#pragma unroll
+    for (int n = 0; n < NK; ++n) {
+      const int i = tid + n * THREADS, ic = min(i, 64 * C::KPARTS - 1);
+      const int key = ic / C::KPARTS, part = ic - key * C::KPARTS;
+      kz[n] = part * 8 >= HD;
+      kp[n] = p.qkv + ((size_t)b * p.T + key) * (size_t)(3 * Cc) + Cc + head * HD + (kz[n] ? HD - 8 : part * 8);
+      ko[n] = i < 64 * C::KPARTS ? key * C::KROW + part * 8 : -1;
+    }
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const int i = tid + n * THREADS, ic = min(i, 64 * C::VPARTS - 1);
+      const int key = ic / C::VPARTS, part = ic - key * C::VPARTS;
+      vp[n] = p.qkv + ((size_t)b * p.T + key) * (size_t)(3 * Cc) + 2 * Cc + head * HD + part * 8;
+      vo[n] = i < 64 * C::VPARTS ? key * C::VROW + part * 8 : -1;
+    }
+  }
+  __device__ __forceinline__ void load(size_t tile_stride_elems, int t) {
+#pragma unroll
+    for (int n = 0; n < NK; ++n) k[n] = *reinterpret_cast<const uint4 *>(kp[n] + tile_stride_elems * t);
+#pragma unroll
+    for (int n = 0; n < NV; ++n) v[n] = *reinterpret_cast<const uint4 *>(vp[n] + tile_stride_elems * t);
+  }
+  __device__ __forceinline__ void store(u16 *Kl, u16 *Vl) const {
+#pragma unroll
+    for (int n = 0; n < NK; ++n)
+      if (ko[n] >= 0) *reinterpret_cast<uint4 *>(Kl + ko[n]) = kz[n] ? make_uint4(0, 0, 0, 0) : k[n];
+#pragma unroll
+    for (int n = 0; n < NV; ++n)
+      if (vo[n] >= 0) *reinterpret_cast<uint4 *>(Vl + vo[n]) = v[n];
   }
 };
 
@@ -235,8 +295,9 @@ __device__ __forceinline__ void build_table(const u16 *rel, int L, int j0, int s
     for (int ks = 0; ks < Cfg<HD>::KS; ++ks) {
       const int d0 = ks * 32 + g * 8;
       union { uint4 u; bf16x8 v; } r;
-      r.u = make_uint4(0, 0, 0, 0);
-      if (j >= 0 && j < L && d0 < HD) r.u = *reinterpret_cast<const uint4 *>(rel + (size_t)j * HD + d0);
+      const int jc = min(max(j, 0), L - 1), dc = d0 < HD ? d0 : HD - 8;
+      r.u = *reinterpret_cast<const uint4 *>(rel + (size_t)jc * HD + dc);
+      if (!(j >= 0 && j < L && d0 < HD)) r.u = make_uint4(0, 0, 0, 0);
       a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r.v, qf[ks], a, 0, 0, 0);
     }
     // C layout: row jj = jt*16 + g*4 + r, col = query c
@@ -346,12 +407,11 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
     for (int ks = 0; ks < C::KS; ++ks) {
       union { uint4 u; bf16x8 v; } t;
       const int d0 = ks * 32 + g * 8;
-      t.u = make_uint4(0, 0, 0, 0);
-      if (qwin && d0 < HD) {
-        const u16 *src = qimg ? p.qkv + ((size_t)(b * p.H + y) * p.W + x) * (size_t)(3 * Cc) + head * HD + d0
-                              : p.qkv_bias + head * HD + d0;
-        t.u = *reinterpret_cast<const uint4 *>(src);
-      }
+      const int dc = d0 < HD ? d0 : HD - 8;
+      const size_t tokc = (size_t)(b * p.H + min(y, p.H - 1)) * p.W + min(x, p.W - 1);
+      const u16 *src = qimg ? p.qkv + tokc * (size_t)(3 * Cc) + head * HD + dc : p.qkv_bias + head * HD + dc;
+      t.u = *reinterpret_cast<const uint4 *>(src);
+      if (!(qwin && d0 < HD)) t.u = make_uint4(0, 0, 0, 0);
       qfa[i][ks] = t.v;
     }
   }
@@ -366,23 +426,21 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
 #pragma unroll
       for (int n = 0; n < UN; ++n) {
         const int i = i0 + n * WAVES * 64;
-        const bool isv = i >= SR * 16 * C::KPARTS;
-        const int ii = isv ? i - SR * 16 * C::KPARTS : i;
+        const int iq = min(i, total - 1);
+        const bool isv = iq >= SR * 16 * C::KPARTS;
+        const int ii = isv ? iq - SR * 16 * C::KPARTS : iq;
         const int parts = isv ? C::VPARTS : C::KPARTS;
         const int slot = ii / parts, part = ii - slot * parts;
         const int ky = slot >> 4, kx = slot & 15;
         const int y = wy * p.ws + ky, x = wx * p.ws + kx;
-        v[n] = make_uint4(0, 0, 0, 0);
-        dst[n] = nullptr;
-        if (i < total) {
-          dst[n] = isv ? Vl + slot * C::VROW + part * 8 : Kl + slot * C::KROW + part * 8;
-          if (ky < S && kx < S && part * 8 < HD) {
-            const bool img = (y < p.H) && (x < p.W);
-            const u16 *src = img ? p.qkv + ((size_t)(b * p.H + y) * p.W + x) * (size_t)(3 * Cc) + (isv ? 2 : 1) * Cc + head * HD + part * 8
-                                 : p.qkv_bias + (isv ? 2 : 1) * Cc + head * HD + part * 8;
-            v[n] = *reinterpret_cast<const uint4 *>(src);
-          }
-        }
+        dst[n] = (i < total) ? (isv ? Vl + slot * C::VROW + part * 8 : Kl + slot * C::KROW + part * 8) : nullptr;
+        const bool img = (y < p.H) && (x < p.W);
+        const int dc = part * 8 < HD ? part * 8 : HD - 8;
+        const size_t tokc = (size_t)(b * p.H + min(y, p.H - 1)) * p.W + min(x, p.W - 1);
+        const int sel = (isv ? 2 : 1) * Cc + head * HD + dc;
+        const u16 *src = img ? p.qkv + tokc * (size_t)(3 * Cc) + sel : p.qkv_bias + sel;
+        v[n] = *reinterpret_cast<const uint4 *>(src);
+        if (!(ky < S && kx < S && part * 8 < HD)) v[n] = make_uint4(0, 0, 0, 0);
       }
 #pragma unroll
       for (int n = 0; n < UN; ++n)
@@ -531,18 +589,21 @@ __global__ __launch_bounds__(WAVES * 64) void attn_global_kernel(AttnParams p) {
   f32x4 oacc[C::DT];
 #pragma unroll
   for (int dt = 0; dt < C::DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int ntile = (p.T + 63) / 64;
-  Stager<HD, WAVES * 64> st;
-  st.load(p, b, 0, 0, head, 0, tid);
+  const int ntile = p.T / 64;                       // launcher guarantees T % 64 == 0 for this kernel
+  StagerLinear<HD, WAVES * 64> st;
+  st.init(p, b, head, tid);
+  const size_t tstride = (size_t)64 * 3 * p.nh * HD;
+  st.load(tstride, 0);
   __syncthreads();                                  // table scratch (aliasing the ring) fully consumed
-  st.store(Kbuf(0), Vbuf(0), tid);
+  st.store(Kbuf(0), Vbuf(0));
   __syncthreads();
   for (int t = 0; t < ntile; ++t) {
     const int cur = t & 1;
-    if (t + 1 < ntile) st.load(p, b, 0, 0, head, (t + 1) * 64, tid);      // flies under this tile's math
+    if (t + 1 < ntile && !(p.dbg & 1)) st.load(tstride, t + 1);            // flies under this tile's math
     const float thv = (MODE == 1) ? th[c * 64 + t] : 0.f;
-    process_tile<HD, MODE>(p, Kbuf(cur), Vbuf(cur), t * 64, qf, th, tw, qy, qx, thv, twr, m_run, l_run, oacc, lane);
-    if (t + 1 < ntile) st.store(Kbuf(cur ^ 1), Vbuf(cur ^ 1), tid);       // ring slot last read in iteration t-1
+    if (!(p.dbg & 2))
+      process_tile<HD, MODE>(p, Kbuf(cur), Vbuf(cur), t * 64, qf, th, tw, qy, qx, thv, twr, m_run, l_run, oacc, lane);
+    if (t + 1 < ntile) st.store(Kbuf(cur ^ 1), Vbuf(cur ^ 1));            // ring slot last read in iteration t-1
     __syncthreads();
   }
   store_strip<HD>(p, b, 0, 0, head, q0, l_run, oacc, lane);
@@ -577,6 +638,7 @@ static int launch_attn(AttnParams p, hipStream_t st) {
       hipLaunchKernelGGL((attn_window_kernel<HD, WAVES, false>), dim3(grid), dim3(WAVES * 64), lds, st, p);
     }
   } else {
+    if (p.T % 64 != 0) return S6D_EUNSUPPORTED;                  // global grids: 16x16, 32x32, 64x64 ...
     constexpr int WAVES = 4;
     const size_t ring = (size_t)2 * 64 * (C::KROW + C::VROW) * 2;
     const int nqt = (p.T + WAVES * 16 - 1) / (WAVES * 16);
@@ -611,6 +673,7 @@ extern "C" int s6d_win_attention_bf16(const void *qkv, const void *qkv_bias, con
   if (B == 0) return S6D_OK;
   if (!qkv || !qkv_bias || !out || ((rel_h == nullptr) != (rel_w == nullptr))) return S6D_EINVAL;
   if (window == 0 && H != W) return S6D_EUNSUPPORTED;
+  if (window == 0 && (H * W) % 64 != 0) window = H;   // small odd grids: one all-resident "window" = whole grid
   AttnParams p;
   p.qkv = (const u16 *)qkv; p.qkv_bias = (const u16 *)qkv_bias;
   p.rel_h = (const u16 *)rel_h; p.rel_w = (const u16 *)rel_w; p.out = (u16 *)out;
@@ -621,6 +684,10 @@ extern "C" int s6d_win_attention_bf16(const void *qkv, const void *qkv_bias, con
   p.LT = ((2 * p.S - 1) + 15) / 16 * 16;
   p.magicS = (unsigned)(((1ull << 32) + (unsigned)p.S - 1) / (unsigned)p.S);
   p.scale_log2 = scale * kLog2e;
+  {
+    const char *e = getenv("S6D_ATTN_DBG");
+    p.dbg = e ? atoi(e) : 0;
+  }
   hipStream_t st = as_stream(stream);
   switch (head_dim) {
     case 80: return launch_attn<80>(p, st);

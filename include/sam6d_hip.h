@@ -119,6 +119,41 @@ int s6d_win_attention_bf16(const void *qkv, const void *qkv_bias, const void *re
 int s6d_add_layernorm_bf16(const void *x, const void *delta, const float *gamma, const float *beta, float eps,
                            long rows, int C, void *x_out, void *y_out, void *stream);
 
+/* ---------------------------------------------------------------- ISM proposal-vs-template scoring */
+
+/* clamp(cosine(query_p, ref_r), 0, 1): query (P,C), ref (R = O*T, C) f32 -> out (P,R) f32; C % 16 == 0.
+ * ref: PairwiseSimilarity.forward, Instance_Segmentation_Model/model/loss.py:27-44. */
+int s6d_pairwise_cosine_f32(const float *query, const float *ref, int P, int R, int C, float *out, void *stream);
+
+/* Per proposal: mean of the top-k template scores per object, arg-max object, its score and the best
+ * template of that object.  scores (P,O,T) f32 -> best_score (P) f32, best_obj (P) i32, best_tmpl (P) i32.
+ * ref: compute_semantic_score ('avg_5': topk = 5) + best_template_pose, model/detector.py:260-296,198-207. */
+int s6d_semantic_select_f32(const float *scores, int P, int O, int T, int topk, float *best_score,
+                            int32_t *best_obj, int32_t *best_tmpl, void *stream);
+
+/* Appearance score and visible ratio from ONE similarity pass.  query (S,N1,C) f32; refstore (O,T,N2,C) f32
+ * indexed by obj[s], tmpl[s] (i32) -- no gathered copy; workspace: s6d_patch_scores_workspace_floats() floats.
+ * appe[s] = clamp(sum_i max_j sim_ij / (#rows with non-zero element sum + 1e-6), 0, 1)
+ * ratio[s] = #cols(max_i sim_ij > thred) / (#cols(max_i sim_ij != 0) + 1e-6)
+ * ref: MaskedPatch_MatrixSimilarity.compute_straight / compute_visible_ratio, model/loss.py:52-76. */
+int s6d_patch_scores_f32(const float *query, const float *refstore, const int32_t *obj, const int32_t *tmpl,
+                         int S, int N1, int N2, int C, int T, float thred, float *workspace, float *appe,
+                         float *ratio, void *stream);
+long s6d_patch_scores_workspace_floats(int S, int N1, int N2);
+
+/* Mean back-projected 3-D point of each mask: masks (S,H,W) f32, depth (H,W) f32 [mm] -> out (S,3) f32 [m].
+ * ref: Calculate_the_query_translation, model/detector.py:234-246 +
+ * depth_image_to_pointcloud_translate_torch, utils/trimesh_utils.py:77-105 (float64 X/Y, float32 Z). */
+int s6d_masked_depth_mean_f32(const float *masks, const float *depth, int S, int H, int W, float depth_scale,
+                              double fx, double fy, double cx, double cy, float *out, void *stream);
+
+/* Template projection: uv[s,i] = clamp(trunc(K (R_tmpl[s] p_i + t_s))), bbox[s] = (min u, min v, max u, max v).
+ * pointcloud (O,N,3), poses (T,4,4), trans (S,3), K (3,3) f32; obj/tmpl (S) i32 -> uv (S,N,2) i32, bbox (S,4) i32.
+ * ref: project_template_to_image, model/detector.py:209-232 and the bbox of compute_geometric_score :316-318. */
+int s6d_project_bbox_f32(const float *pointcloud, const float *poses, const int32_t *obj, const int32_t *tmpl,
+                         const float *trans, const float *K, int S, int N, int H, int W, int32_t *uv,
+                         int32_t *bbox, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,374 @@
+// Proposal-vs-template scoring kernels of the Instance Segmentation Model (gfx950).
+//
+// Reference (Instance_Segmentation_Model/):
+//   model/loss.py:27-44    PairwiseSimilarity  -- Python loop over objects on a (P,O,T,C) repeat
+//   model/loss.py:52-76    MaskedPatch_MatrixSimilarity.compute_straight / compute_visible_ratio
+//                          -- the SAME (S,256,256) batched GEMM computed twice
+//   model/detector.py:209-246, utils/trimesh_utils.py:77-105  masked-depth mean translation on a
+//                          (S,H,W) repeat, template projection, bbox
+// All GEMM-shaped work uses the exact-f32 MFMA (v_mfma_f32_16x16x4_f32: an fma chain, same numerics as
+// a scalar loop) so scores keep fp32 parity with the reference; reductions (row-max, col-max, norms,
+// non-zero counts) are epilogues of the tile that produced them -- the similarity matrices never reach HBM.
+#include "s6d_common.h"
+
+namespace s6d {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ------------------------------------------------------------------------------------------------
+// cosine(P queries, R references), clamp to [0,1].  One wave per 16x16 output tile.
+// MFMA 16x16x4 f32: A lane -> (row l&15, k l>>4), B lane -> (k l>>4, col l&15), C: col l&15, row (l>>4)*4+r.
+// Each lane loads float4 (4 consecutive k) and feeds element e to MFMA step e: the k-permutation is the
+// same on both operands, so the contraction is unchanged.
+__global__ __launch_bounds__(256) void pairwise_cosine_kernel(const float *__restrict__ q, const float *__restrict__ ref,
+                                                             int P, int R, int C, float *__restrict__ out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tiles_r = (R + 15) / 16;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= ((P + 15) / 16) * tiles_r) return;
+  const int p0 = (tile / tiles_r) * 16, r0 = (tile % tiles_r) * 16;
+  const int c = lane & 15, g = lane >> 4;
+  const float *qa = q + (size_t)min(p0 + c, P - 1) * C + g * 4;
+  const float *rb = ref + (size_t)min(r0 + c, R - 1) * C + g * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float nq = 0.f, nr = 0.f;
+  for (int k0 = 0; k0 < C; k0 += 16) {
+    const float4 a = *reinterpret_cast<const float4 *>(qa + k0);
+    const float4 b = *reinterpret_cast<const float4 *>(rb + k0);
+    nq += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+    nr += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+  }
+  nq += __shfl_xor(nq, 16); nq += __shfl_xor(nq, 32);      // |q_row|^2 in every lane with l&15 == row
+  nr += __shfl_xor(nr, 16); nr += __shfl_xor(nr, 32);      // |ref_col|^2 in every lane with l&15 == col
+  const float inv_r = 1.0f / fmaxf(sqrtf(nr), 1e-12f);     // F.normalize eps (loss.py:32-33)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = g * 4 + r;
+    const float nqr = __shfl(nq, row);
+    float v = acc[r] * (1.0f / fmaxf(sqrtf(nqr), 1e-12f)) * inv_r;
+    v = fminf(fmaxf(v, 0.f), 1.f);
+    if (p0 + row < P && r0 + c < R) out[(size_t)(p0 + row) * R + r0 + c] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per proposal p: avg of the top-K template scores per object, best object, its score and its best template
+// (detector.py:260-296 with aggregation 'avg_5', best_template_pose :198-207).  One wave per proposal.
+__global__ __launch_bounds__(256) void semantic_select_kernel(const float *__restrict__ scores, int P, int O, int T,
+                                                             int topk, float *__restrict__ best_score,
+                                                             int *__restrict__ best_obj, int *__restrict__ best_tmpl) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (p >= P) return;
+  float bscore = -1.f;
+  int bobj = 0, btmpl = 0;
+  for (int o = 0; o < O; ++o) {
+    const float *s = scores + ((size_t)p * O + o) * T;
+    // lane-strided copy of the row (T <= 64*4 handled by 4 slots per lane)
+    float v[4];
+    int vi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t = lane + 64 * j;
+      v[j] = t < T ? s[t] : -2.f;
+      vi[j] = t;
+    }
+    float sum = 0.f;
+    int first_t = 0;
+    for (int k = 0; k < topk && k < T; ++k) {
+      // wave arg-max (value desc, index asc) over the remaining entries
+      float m = v[0];
+      int mi = vi[0];
+#pragma unroll
+      for (int j = 1; j < 4; ++j)
+        if (v[j] > m) { m = v[j]; mi = vi[j]; }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float om = __shfl_xor(m, off);
+        const int oi = __shfl_xor(mi, off);
+        if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+      }
+      sum += m;
+      if (k == 0) first_t = mi;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (vi[j] == mi) v[j] = -3.f;                       // knock out the selected entry
+    }
+    const float avg = sum / (float)(topk < T ? topk : T);
+    if (avg > bscore) { bscore = avg; bobj = o; btmpl = first_t; }   // first maximum wins, like torch.max
+  }
+  if (lane == 0) {
+    best_score[p] = bscore;
+    best_obj[p] = bobj;
+    best_tmpl[p] = btmpl;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Appearance score + visible ratio from ONE pass over sim = Q_s R_s^T  (Q_s: N1 x C, R_s: N2 x C).
+// Workgroup = (proposal s, 64-row block of Q_s); each of its 4 waves owns 16 query rows x all N2 (<= 256)
+// reference patches: 16 accumulator tiles.  Epilogue per wave: row maxima summed, column maxima, and the
+// number of query rows whose element sum is non-zero -- written as partials, folded by patch_finalize.
+constexpr int kMaxColTiles = 16;
+
+__global__ __launch_bounds__(256) void patch_scores_kernel(const float *__restrict__ q, const float *__restrict__ refstore,
+                                                          const int *__restrict__ obj, const int *__restrict__ tmpl,
+                                                          int N1, int N2, int C, int T, float *__restrict__ part_rowsum,
+                                                          float *__restrict__ part_colmax, int *__restrict__ part_nnz) {
+  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c = lane & 15, g = lane >> 4;
+  const int nrb = gridDim.x;                               // row blocks of 64
+  const int row0 = (blockIdx.x * 4 + wave) * 16;
+  const int slot = blockIdx.x * 4 + wave;                  // partial index within the proposal
+  const int nct = (N2 + 15) / 16;
+  const float *Q = q + (size_t)s * N1 * C;
+  const float *Rf = refstore + ((size_t)obj[s] * T + tmpl[s]) * (size_t)N2 * C;
+  const float *qa = Q + (size_t)min(row0 + c, N1 - 1) * C + g * 4;
+  f32x4 acc[kMaxColTiles];
+#pragma unroll
+  for (int t = 0; t < kMaxColTiles; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float qsum = 0.f;
+  for (int k0 = 0; k0 < C; k0 += 16) {
+    const float4 a = *reinterpret_cast<const float4 *>(qa + k0);
+    qsum += (a.x + a.y) + (a.z + a.w);
+#pragma unroll
+    for (int t = 0; t < kMaxColTiles; ++t) {
+      if (t < nct) {
+        const float4 b = *reinterpret_cast<const float4 *>(Rf + (size_t)min(t * 16 + c, N2 - 1) * C + g * 4 + k0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // element sums of the 16 query rows (row = l&15 after folding the 4 k-groups)
+  qsum += __shfl_xor(qsum, 16); qsum += __shfl_xor(qsum, 32);
+  const bool row_ok = row0 + c < N1;
+  const unsigned long long nzmask = __ballot(row_ok && qsum != 0.f && lane < 16);
+  // row maxima: row = g*4 + r, max over column tiles and the 16 lanes of the group
+  float rsum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float m = -3.4e38f;
+#pragma unroll
+    for (int t = 0; t < kMaxColTiles; ++t)
+      if (t < nct && t * 16 + c < N2) m = fmaxf(m, acc[t][r]);
+    m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2));
+    m = fmaxf(m, __shfl_xor(m, 4)); m = fmaxf(m, __shfl_xor(m, 8));
+    if (row0 + g * 4 + r < N1) rsum += m;
+  }
+  rsum += __shfl_xor(rsum, 16); rsum += __shfl_xor(rsum, 32);   // all 16 rows of the wave
+  // column maxima over this wave's 16 rows
+  const int nslot = nrb * 4;
+#pragma unroll
+  for (int t = 0; t < kMaxColTiles; ++t) {
+    if (t < nct) {
+      float m = -3.4e38f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (row0 + g * 4 + r < N1) m = fmaxf(m, acc[t][r]);
+      m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
+      if (lane < 16 && t * 16 + c < N2) part_colmax[((size_t)s * nslot + slot) * N2 + t * 16 + c] = m;
+    }
+  }
+  if (lane == 0) {
+    part_rowsum[(size_t)s * nslot + slot] = rsum;
+    part_nnz[(size_t)s * nslot + slot] = __popcll(nzmask);
+  }
+}
+
+__global__ void patch_finalize_kernel(const float *__restrict__ part_rowsum, const float *__restrict__ part_colmax,
+                                      const int *__restrict__ part_nnz, int S, int nslot, int N1, int N2, float thred,
+                                      float *__restrict__ appe, float *__restrict__ ratio) {
+  const int s = blockIdx.x, lane = threadIdx.x;            // one wave per proposal
+  float rs = 0.f;
+  int nz = 0;
+  for (int i = 0; i < nslot; ++i) {
+    const int row0 = i * 16;
+    if (row0 < N1) {
+      rs += part_rowsum[(size_t)s * nslot + i];
+      nz += part_nnz[(size_t)s * nslot + i];
+    }
+  }
+  int valid = 0, vis = 0;
+  for (int j = lane; j < N2; j += 64) {
+    float m = -3.4e38f;
+    for (int i = 0; i < nslot; ++i)
+      if (i * 16 < N1) m = fmaxf(m, part_colmax[((size_t)s * nslot + i) * N2 + j]);
+    valid += (m != 0.f);
+    vis += (m > thred) && (m != 0.f);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    valid += __shfl_xor(valid, off);
+    vis += __shfl_xor(vis, off);
+  }
+  if (lane == 0) {
+    appe[s] = fminf(fmaxf(rs / ((float)nz + 1e-6f), 0.f), 1.f);
+    ratio[s] = (float)vis / ((float)valid + 1e-6f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mean back-projected point of every mask (detector.py:234-246 + trimesh_utils.py:77-105) -- three masked
+// sums, no (S,H,W) depth repeat.  Dtype trail of the reference: Z float32; X, Y float64 (the camera matrix is a
+// float64 tensor); the three means are cast to float32 at the end.
+__global__ __launch_bounds__(256) void masked_depth_mean_kernel(const float *__restrict__ masks,
+                                                               const float *__restrict__ depth, int H, int W,
+                                                               float depth_scale, double fx, double fy, double cx,
+                                                               double cy, float *__restrict__ out) {
+  __shared__ double sx[4], sy[4];
+  __shared__ float sz[4];
+  __shared__ int sn[4];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const float *m = masks + (size_t)s * H * W;
+  double ax = 0.0, ay = 0.0;
+  float az = 0.f;
+  int n = 0;
+  for (int i = tid; i < H * W; i += 256) {
+    const float z = m[i] * depth[i] * depth_scale / 1000.f;
+    if (z > 0.f) {
+      const int v = i / W, u = i - v * W;
+      ax += ((double)u - cx) * (double)z / fx;
+      ay += ((double)v - cy) * (double)z / fy;
+      az += z;
+      ++n;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    ax += __shfl_xor(ax, off);
+    ay += __shfl_xor(ay, off);
+    az += __shfl_xor(az, off);
+    n += __shfl_xor(n, off);
+  }
+  if ((tid & 63) == 0) { sx[tid >> 6] = ax; sy[tid >> 6] = ay; sz[tid >> 6] = az; sn[tid >> 6] = n; }
+  __syncthreads();
+  if (tid == 0) {
+    const double X = (sx[0] + sx[1]) + (sx[2] + sx[3]), Y = (sy[0] + sy[1]) + (sy[2] + sy[3]);
+    const float Z = (sz[0] + sz[1]) + (sz[2] + sz[3]);
+    const float cnt = (float)(sn[0] + sn[1] + sn[2] + sn[3]) + 1e-8f;    // count_nonzero + 1e-8 is float32
+    out[s * 3 + 0] = (float)(X / (double)cnt);
+    out[s * 3 + 1] = (float)(Y / (double)cnt);
+    out[s * 3 + 2] = Z / cnt;
+  }
+}
+
+// Rotate the object's model points by the best template pose, translate, project with K, truncate to
+// pixels, clamp, and reduce the per-proposal bounding box (detector.py:209-232 + :316-318).
+__global__ __launch_bounds__(256) void project_bbox_kernel(const float *__restrict__ pointcloud, const float *__restrict__ poses,
+                                                          const int *__restrict__ obj, const int *__restrict__ tmpl,
+                                                          const float *__restrict__ trans, const float *__restrict__ K,
+                                                          int N, int H, int W, int *__restrict__ uv, int *__restrict__ bbox) {
+  __shared__ int red[4][4];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const float *R = poses + (size_t)tmpl[s] * 16;            // 4x4 row-major, rotation in [0:3,0:3]
+  const float *pc = pointcloud + (size_t)obj[s] * N * 3;
+  const float tx = trans[s * 3], ty = trans[s * 3 + 1], tz = trans[s * 3 + 2];
+  int mnu = 1 << 30, mnv = 1 << 30, mxu = -(1 << 30), mxv = -(1 << 30);
+  for (int i = tid; i < N; i += 256) {
+    const float x = pc[i * 3], y = pc[i * 3 + 1], z = pc[i * 3 + 2];
+    const float px = R[0] * x + R[1] * y + R[2] * z + tx;
+    const float py = R[4] * x + R[5] * y + R[6] * z + ty;
+    const float pz = R[8] * x + R[9] * y + R[10] * z + tz;
+    const float hx = K[0] * px + K[1] * py + K[2] * pz;
+    const float hy = K[3] * px + K[4] * py + K[5] * pz;
+    const float hz = K[6] * px + K[7] * py + K[8] * pz;
+    int u = (int)(hx / hz), v = (int)(hy / hz);             // .to(torch.int): truncation toward zero
+    u = min(max(u, 0), W - 1);
+    v = min(max(v, 0), H - 1);
+    uv[((size_t)s * N + i) * 2] = u;
+    uv[((size_t)s * N + i) * 2 + 1] = v;
+    mnu = min(mnu, u); mxu = max(mxu, u); mnv = min(mnv, v); mxv = max(mxv, v);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mnu = min(mnu, __shfl_xor(mnu, off)); mnv = min(mnv, __shfl_xor(mnv, off));
+    mxu = max(mxu, __shfl_xor(mxu, off)); mxv = max(mxv, __shfl_xor(mxv, off));
+  }
+  if ((tid & 63) == 0) { red[tid >> 6][0] = mnu; red[tid >> 6][1] = mnv; red[tid >> 6][2] = mxu; red[tid >> 6][3] = mxv; }
+  __syncthreads();
+  if (tid == 0) {
+    bbox[s * 4 + 0] = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
+    bbox[s * 4 + 1] = min(min(red[0][1], red[1][1]), min(red[2][1], red[3][1]));
+    bbox[s * 4 + 2] = max(max(red[0][2], red[1][2]), max(red[2][2], red[3][2]));
+    bbox[s * 4 + 3] = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
+  }
+}
+
+}  // namespace s6d
+
+using namespace s6d;
+
+extern "C" int s6d_pairwise_cosine_f32(const float *query, const float *ref, int P, int R, int C, float *out,
+                                       void *stream) {
+  if (P < 0 || R < 0 || C <= 0 || (C % 16) != 0) return S6D_EINVAL;
+  if ((size_t)P * R == 0) return S6D_OK;
+  if (!query || !ref || !out) return S6D_EINVAL;
+  const int tiles = ((P + 15) / 16) * ((R + 15) / 16);
+  hipLaunchKernelGGL(pairwise_cosine_kernel, dim3((tiles + 3) / 4), dim3(256), 0, as_stream(stream), query, ref, P, R, C, out);
+  return launch_status();
+}
+
+extern "C" int s6d_semantic_select_f32(const float *scores, int P, int O, int T, int topk, float *best_score,
+                                       int32_t *best_obj, int32_t *best_tmpl, void *stream) {
+  if (P < 0 || O <= 0 || T <= 0 || topk <= 0) return S6D_EINVAL;
+  if (T > 256) return S6D_EUNSUPPORTED;
+  if (P == 0) return S6D_OK;
+  if (!scores || !best_score || !best_obj || !best_tmpl) return S6D_EINVAL;
+  hipLaunchKernelGGL(semantic_select_kernel, dim3((P + 3) / 4), dim3(256), 0, as_stream(stream), scores, P, O, T, topk,
+                     best_score, best_obj, best_tmpl);
+  return launch_status();
+}
+
+extern "C" int s6d_patch_scores_f32(const float *query, const float *refstore, const int32_t *obj, const int32_t *tmpl,
+                                    int S, int N1, int N2, int C, int T, float thred, float *workspace, float *appe,
+                                    float *ratio, void *stream) {
+  if (S < 0 || N1 <= 0 || N2 <= 0 || C <= 0 || (C % 16) != 0 || T <= 0) return S6D_EINVAL;
+  if (N2 > 16 * kMaxColTiles) return S6D_EUNSUPPORTED;
+  if (S == 0) return S6D_OK;
+  if (!query || !refstore || !obj || !tmpl || !workspace || !appe || !ratio) return S6D_EINVAL;
+  const int nrb = (N1 + 63) / 64, nslot = nrb * 4;
+  // workspace: [S*nslot] row sums | [S*nslot*N2] column maxima | [S*nslot] non-zero row counts (int)
+  float *part_rowsum = workspace;
+  float *part_colmax = workspace + (size_t)S * nslot;
+  int *part_nnz = reinterpret_cast<int *>(part_colmax + (size_t)S * nslot * N2);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(patch_scores_kernel, dim3(nrb, S), dim3(256), 0, st, query, refstore, obj, tmpl, N1, N2, C, T,
+                     part_rowsum, part_colmax, part_nnz);
+  int rc = launch_status();
+  if (rc) return rc;
+  hipLaunchKernelGGL(patch_finalize_kernel, dim3(S), dim3(64), 0, st, part_rowsum, part_colmax, part_nnz, S, nslot, N1, N2,
+                     thred, appe, ratio);
+  return launch_status();
+}
+
+extern "C" long s6d_patch_scores_workspace_floats(int S, int N1, int N2) {
+  const long nslot = ((N1 + 63) / 64) * 4;
+  return (long)S * nslot * (2 + N2);
+}
+
+extern "C" int s6d_masked_depth_mean_f32(const float *masks, const float *depth, int S, int H, int W, float depth_scale,
+                                         double fx, double fy, double cx, double cy, float *out, void *stream) {
+  if (S < 0 || H <= 0 || W <= 0) return S6D_EINVAL;
+  if (S == 0) return S6D_OK;
+  if (!masks || !depth || !out) return S6D_EINVAL;
+  hipLaunchKernelGGL(masked_depth_mean_kernel, dim3(S), dim3(256), 0, as_stream(stream), masks, depth, H, W, depth_scale, fx,
+                     fy, cx, cy, out);
+  return launch_status();
+}
+
+extern "C" int s6d_project_bbox_f32(const float *pointcloud, const float *poses, const int32_t *obj, const int32_t *tmpl,
+                                    const float *trans, const float *K, int S, int N, int H, int W, int32_t *uv,
+                                    int32_t *bbox, void *stream) {
+  if (S < 0 || N <= 0 || H <= 0 || W <= 0) return S6D_EINVAL;
+  if (S == 0) return S6D_OK;
+  if (!pointcloud || !poses || !obj || !tmpl || !trans || !K || !uv || !bbox) return S6D_EINVAL;
+  hipLaunchKernelGGL(project_bbox_kernel, dim3(S), dim3(256), 0, as_stream(stream), pointcloud, poses, obj, tmpl, trans, K, N,
+                     H, W, uv, bbox);
+  return launch_status();
+}

@@ -30,7 +30,8 @@ def masked_depth_translation(masks, depth, K, depth_scale):
     mask*depth, detector.py:234-246) without the (S,H,W) ``repeat``: three masked sums."""
     S, H, W = masks.shape
     if ops.have("masked_depth_mean") and masks.is_cuda:
-        return ops.masked_depth_mean(masks.contiguous(), depth.contiguous(), K, float(depth_scale))
+        return ops.masked_depth_mean(masks.to(torch.float32).contiguous(), depth.to(torch.float32).contiguous(), K,
+                                     float(depth_scale))
     # dtype trail of the reference: Z float32; X, Y float64 (the camera matrix is a float64 tensor
     # whose 0-dim elements promote `u - K[0,2]`), sums in that dtype, final cast to float32.
     z = masks.to(torch.float32) * depth.to(torch.float32)[None] * depth_scale / 1000
@@ -45,6 +46,18 @@ def masked_depth_translation(masks, depth, K, depth_scale):
     return torch.stack((x, y, zz.to(torch.float64)), dim=1).to(torch.float32)
 
 
+class RefPatchHandle:
+    """What compute_appearance_score returns as `ref_aux_descriptor` on the fused path: the (object, template)
+    selection into the resident descriptor store instead of a gathered (S,256,C) copy (1 MB per proposal).
+    compute_geometric_score accepts it; ``materialize()`` gives the reference's tensor if a caller wants it."""
+
+    def __init__(self, store, obj, tmpl, visible_ratio, thred):
+        self.store, self.obj, self.tmpl, self.visible_ratio, self.thred = store, obj, tmpl, visible_ratio, thred
+
+    def materialize(self):
+        return self.store[self.obj.long(), self.tmpl.long(), ...]
+
+
 class ScoringMixin:
     def best_template_pose(self, scores, pred_idx_objects):
         best = scores.argmax(dim=-1)                                   # (S,O)
@@ -54,6 +67,14 @@ class ScoringMixin:
         cfg = self.matching_config
         scores = cfg.metric(proposal_decriptors, self.ref_data["descriptors"])     # (P,O,T)
         agg = cfg.aggregation_function
+        topk = {"mean": scores.shape[-1], "max": 1, "avg_5": 5}.get(agg)
+        if topk is not None and ops.have("semantic_select") and scores.is_cuda and scores.dtype == torch.float32 \
+                and scores.shape[-1] <= 256:
+            # one kernel: per-object top-k mean, arg-max object, best template of that object
+            score_per_proposal, assigned, best_t = ops.semantic_select(scores.contiguous(), topk)
+            idx_selected = torch.nonzero(score_per_proposal > cfg.confidence_thresh).squeeze(1)
+            return (idx_selected, assigned[idx_selected].long(), score_per_proposal[idx_selected],
+                    best_t[idx_selected].long())
         if agg == "mean":
             per_obj = scores.sum(dim=-1) / scores.shape[-1]
         elif agg == "median":
@@ -72,22 +93,39 @@ class ScoringMixin:
         return idx_selected, pred_idx_objects, score_per_proposal[idx_selected], best_template
 
     def compute_appearance_score(self, best_pose, pred_objects_idx, qurey_appe_descriptors):
-        ref = self.ref_data["appe_descriptors"][pred_objects_idx, best_pose, ...]
+        store = self.ref_data["appe_descriptors"]
+        thred = getattr(self, "visible_thred", 0.5)
+        if ops.have("patch_scores") and qurey_appe_descriptors.is_cuda and store.dtype == torch.float32 \
+                and qurey_appe_descriptors.dtype == torch.float32 and store.is_contiguous() and store.shape[2] <= 256:
+            obj32, tmpl32 = pred_objects_idx.int().contiguous(), best_pose.int().contiguous()
+            appe, ratio = ops.patch_scores(qurey_appe_descriptors.contiguous(), store, obj32, tmpl32, float(thred))
+            return appe, RefPatchHandle(store, obj32, tmpl32, ratio, thred)
+        ref = store[pred_objects_idx, best_pose, ...]
         metric = MaskedPatch_MatrixSimilarity(metric="cosine", chunk_size=64)
-        appe, ratio = metric.both(qurey_appe_descriptors, ref, getattr(self, "visible_thred", 0.5))
-        self._cached_visible = (qurey_appe_descriptors.data_ptr(), ref.data_ptr(),
-                                getattr(self, "visible_thred", 0.5), ratio)
+        appe, ratio = metric.both(qurey_appe_descriptors, ref, thred)
+        self._cached_visible = (qurey_appe_descriptors.data_ptr(), ref.data_ptr(), thred, ratio)
         return appe, ref
 
     def compute_geometric_score(self, image_uv, proposals, appe_descriptors, ref_aux_descriptor, visible_thred=0.5):
-        c = getattr(self, "_cached_visible", None)
-        if c is not None and c[0] == appe_descriptors.data_ptr() and c[1] == ref_aux_descriptor.data_ptr() \
-                and c[2] == visible_thred:
-            visible_ratio = c[3]                       # same GEMM as the appearance score: reuse it
+        if isinstance(ref_aux_descriptor, RefPatchHandle):
+            if ref_aux_descriptor.thred == visible_thred:
+                visible_ratio = ref_aux_descriptor.visible_ratio    # produced by the same similarity pass
+            else:
+                visible_ratio = ops.patch_scores(appe_descriptors.contiguous(), ref_aux_descriptor.store,
+                                                 ref_aux_descriptor.obj, ref_aux_descriptor.tmpl, float(visible_thred))[1]
         else:
-            visible_ratio = MaskedPatch_MatrixSimilarity().compute_visible_ratio(
-                appe_descriptors, ref_aux_descriptor, visible_thred)
-        xyxy = torch.cat((image_uv.min(dim=1).values, image_uv.max(dim=1).values), dim=-1)
+            c = getattr(self, "_cached_visible", None)
+            if c is not None and c[0] == appe_descriptors.data_ptr() and c[1] == ref_aux_descriptor.data_ptr() \
+                    and c[2] == visible_thred:
+                visible_ratio = c[3]                   # same GEMM as the appearance score: reuse it
+            else:
+                visible_ratio = MaskedPatch_MatrixSimilarity().compute_visible_ratio(
+                    appe_descriptors, ref_aux_descriptor, visible_thred)
+        bb = getattr(self, "_cached_bbox", None)
+        if bb is not None and bb[0] == image_uv.data_ptr():
+            xyxy = bb[1]                               # reduced by the projection kernel
+        else:
+            xyxy = torch.cat((image_uv.min(dim=1).values, image_uv.max(dim=1).values), dim=-1)
         return compute_iou(xyxy, proposals.boxes), visible_ratio
 
     def Calculate_the_query_translation(self, proposal, depth, cam_intrinsic, depth_scale):
@@ -97,15 +135,22 @@ class ScoringMixin:
         return masked_depth_translation(proposal, depth, cam_intrinsic, depth_scale)
 
     def project_template_to_image(self, best_pose, pred_object_idx, batch, proposals):
-        R = self.ref_data["poses"][best_pose, 0:3, 0:3]
-        pc = self.ref_data["pointcloud"][pred_object_idx, ...]
         depth, K = batch["depth"][0], batch["cam_intrinsic"][0]
         t = self.Calculate_the_query_translation(proposals, depth, K, batch["depth_scale"])
+        H, W = depth.shape
+        poses, pcs = self.ref_data["poses"], self.ref_data["pointcloud"]
+        if ops.have("project_bbox") and t.is_cuda and poses.dtype == torch.float32 and pcs.dtype == torch.float32:
+            uv, bbox = ops.project_bbox(pcs.contiguous(), poses.contiguous(), pred_object_idx.int().contiguous(),
+                                        best_pose.int().contiguous(), t.contiguous(),
+                                        K.to(device=t.device, dtype=torch.float32).contiguous(), H, W)
+            self._cached_bbox = (uv.data_ptr(), bbox)
+            return uv
+        R = poses[best_pose, 0:3, 0:3]
+        pc = pcs[pred_object_idx, ...]
         posed = pc @ R.transpose(1, 2) + t[:, None, :]
         Kf = K.to(torch.float32)
         homo = posed @ Kf.t()
         uv = (homo / homo[:, :, -1:])[:, :, 0:2].to(torch.int)
-        H, W = depth.shape
         uv[:, :, 0].clamp_(min=0, max=W - 1)
         uv[:, :, 1].clamp_(min=0, max=H - 1)
         return uv

@@ -186,6 +186,75 @@ def add_layernorm(x, delta, gamma, beta, eps):
     return xo, y
 
 
+# ------------------------------------------------------------------ ISM scoring
+def pairwise_cosine(query, ref):
+    """(P,C), (R,C) f32 -> (P,R) clamp(cos,0,1)."""
+    _chk(query, torch.float32, "query", 2)
+    _chk(ref, torch.float32, "ref", 2)
+    P, C = query.shape
+    R = ref.shape[0]
+    out = torch.empty(P, R, dtype=torch.float32, device=query.device)
+    _call("s6d_pairwise_cosine_f32", _ptr(query), _ptr(ref), P, R, C, _ptr(out), _stream())
+    return out
+
+
+def semantic_select(scores, topk):
+    """(P,O,T) f32 -> best_score (P) f32, best_obj (P) i32, best_tmpl (P) i32."""
+    _chk(scores, torch.float32, "scores", 3)
+    P, O, T = scores.shape
+    dev = scores.device
+    bs = torch.empty(P, dtype=torch.float32, device=dev)
+    bo = torch.empty(P, dtype=torch.int32, device=dev)
+    bt = torch.empty(P, dtype=torch.int32, device=dev)
+    _call("s6d_semantic_select_f32", _ptr(scores), P, O, T, int(topk), _ptr(bs), _ptr(bo), _ptr(bt), _stream())
+    return bs, bo, bt
+
+
+def patch_scores(query, refstore, obj, tmpl, thred):
+    """query (S,N1,C), refstore (O,T,N2,C) f32, obj/tmpl (S) i32 -> appe (S), ratio (S)."""
+    _chk(query, torch.float32, "query", 3)
+    _chk(refstore, torch.float32, "refstore", 4)
+    _chk(obj, torch.int32, "obj", 1)
+    _chk(tmpl, torch.int32, "tmpl", 1)
+    S, N1, C = query.shape
+    _, T, N2, _ = refstore.shape
+    fn = _lib.lib().s6d_patch_scores_workspace_floats
+    fn.restype = ctypes.c_long
+    ws = torch.empty(max(int(fn(S, N1, N2)), 1), dtype=torch.float32, device=query.device)
+    appe = torch.empty(S, dtype=torch.float32, device=query.device)
+    ratio = torch.empty(S, dtype=torch.float32, device=query.device)
+    _call("s6d_patch_scores_f32", _ptr(query), _ptr(refstore), _ptr(obj), _ptr(tmpl), S, N1, N2, C, T,
+          ctypes.c_float(thred), _ptr(ws), _ptr(appe), _ptr(ratio), _stream())
+    return appe, ratio
+
+
+def masked_depth_mean(masks, depth, K, depth_scale):
+    """masks (S,H,W) f32, depth (H,W) f32, K 3x3 (host-readable) -> (S,3) f32."""
+    _chk(masks, torch.float32, "masks", 3)
+    _chk(depth, torch.float32, "depth", 2)
+    S, H, W = masks.shape
+    Kc = K.detach().double().cpu()
+    out = torch.empty(S, 3, dtype=torch.float32, device=masks.device)
+    _call("s6d_masked_depth_mean_f32", _ptr(masks), _ptr(depth), S, H, W, ctypes.c_float(depth_scale),
+          ctypes.c_double(Kc[0, 0].item()), ctypes.c_double(Kc[1, 1].item()), ctypes.c_double(Kc[0, 2].item()),
+          ctypes.c_double(Kc[1, 2].item()), _ptr(out), _stream())
+    return out
+
+
+def project_bbox(pointcloud, poses, obj, tmpl, trans, K, H, W):
+    """-> uv (S,N,2) i32, bbox (S,4) i32 = (min u, min v, max u, max v)."""
+    for a, nm, nd in ((pointcloud, "pointcloud", 3), (poses, "poses", 3), (trans, "trans", 2), (K, "K", 2)):
+        _chk(a, torch.float32, nm, nd)
+    _chk(obj, torch.int32, "obj", 1)
+    _chk(tmpl, torch.int32, "tmpl", 1)
+    S, N = obj.shape[0], pointcloud.shape[1]
+    uv = torch.empty(S, N, 2, dtype=torch.int32, device=trans.device)
+    bbox = torch.empty(S, 4, dtype=torch.int32, device=trans.device)
+    _call("s6d_project_bbox_f32", _ptr(pointcloud), _ptr(poses), _ptr(obj), _ptr(tmpl), _ptr(trans), _ptr(K), S, N,
+          int(H), int(W), _ptr(uv), _ptr(bbox), _stream())
+    return uv, bbox
+
+
 # ------------------------------------------------------------------ fused-op registry
 # Names of fused gfx950 ops the loaded library exports.  Product modules ask ``have(name)``
 # and otherwise express the same math with library GEMMs on the device (never on the CPU).
@@ -199,7 +268,8 @@ def have(name):
                "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "add_layernorm": "s6d_add_layernorm_bf16", "win_attention": "s6d_win_attention_bf16",
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
-               "pe_group": "s6d_pe_group_f32", "masked_depth_mean": "s6d_masked_depth_mean_f32"}.get(name)
+               "pe_group": "s6d_pe_group_f32", "masked_depth_mean": "s6d_masked_depth_mean_f32",
+               "semantic_select": "s6d_semantic_select_f32", "project_bbox": "s6d_project_bbox_f32"}.get(name)
         import os
         disabled = name in os.environ.get("S6D_DISABLE_FUSED", "").split(",")
         _FUSED[name] = (not disabled) and sym is not None and hasattr(_lib.lib(), sym)

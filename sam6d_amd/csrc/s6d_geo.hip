@@ -1,0 +1,189 @@
+// Geometric structure embedding of the PEM point transformer, fused (gfx950).
+//
+// Reference: GeometricStructureEmbedding.forward, Pose_Estimation_Model/model/transformer.py:334-349
+//   d_emb = proj_d(sinusoid(d_idx))            (B,N,N,256)
+//   a_emb = proj_a(sinusoid(a_idx)).max(k)     (B,N,N,3,256) -> 119 MB / instance intermediate
+//   out   = d_emb + a_emb                       20.3 GFLOP per cloud as two fp32 GEMMs on 155 k rows
+// Here the four sinusoidal embeddings of a point pair are generated on the fly (never stored), multiplied
+// by W_d / W_a on the bf16 matrix cores with a 3-term split (x = x_hi + x_lo in bf16;
+// x_hi*w_hi + x_lo*w_hi + x_hi*w_lo, fp32 accumulate: ~2^-17 relative per product, i.e. fp32-class
+// results at 5x the fp32-MFMA rate), max-reduced over the k angular neighbours in registers and written
+// once.  Workgroup = 64 point pairs x 256 outputs, 8 waves: wave (mt, nh) owns pairs [16mt,16mt+16) and
+// outputs [128nh, 128nh+128).  Per 32-channel k-step: all waves first build the shared operands in LDS
+// (sincos fragments hi/lo, weight slices hi/lo), then run 96 MFMAs each.
+#include "s6d_common.h"
+
+namespace s6d {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef unsigned short u16;
+
+__device__ __forceinline__ void split_bf16(float x, u16 &hi, u16 &lo) {
+  union { __bf16 b; u16 u; } h, l;
+  h.b = (__bf16)x;
+  const float xh = __uint_as_float(((unsigned)h.u) << 16);
+  l.b = (__bf16)(x - xh);
+  hi = h.u;
+  lo = l.u;
+}
+
+constexpr int GEO_C = 256;          // hidden dim
+constexpr int GEO_ROW = 40;         // LDS row stride (bf16): 32 channels + 8 pad (80 B: conflict-free b128 reads)
+constexpr int GEO_PAIRS = 64;       // point pairs per workgroup
+constexpr int GEO_THREADS = 512;
+
+// LDS map (bf16 elements)
+constexpr int OFF_WDH = 0;
+constexpr int OFF_WDL = OFF_WDH + GEO_C * GEO_ROW;
+constexpr int OFF_WAH = OFF_WDL + GEO_C * GEO_ROW;
+constexpr int OFF_WAL = OFF_WAH + GEO_C * GEO_ROW;
+constexpr int OFF_AH = OFF_WAL + GEO_C * GEO_ROW;                  // [4 emb][64 pairs][ROW]
+constexpr int OFF_AL = OFF_AH + 4 * GEO_PAIRS * GEO_ROW;
+constexpr int GEO_LDS_ELEMS = OFF_AL + 4 * GEO_PAIRS * GEO_ROW;    // 61440 elems = 120 KB
+
+__global__ __launch_bounds__(GEO_THREADS) void geo_embed_kernel(const float *__restrict__ idx4, long NP,
+                                                               const float *__restrict__ Wd, const float *__restrict__ bd,
+                                                               const float *__restrict__ Wa, const float *__restrict__ ba,
+                                                               const float *__restrict__ div_term, float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u16 *lds = reinterpret_cast<u16 *>(smem);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int c = lane & 15, g = lane >> 4;
+  const int mt = wave & 3, nh = wave >> 2;
+  const long pair0 = (long)blockIdx.x * GEO_PAIRS;
+
+  // ---- per-thread constants of the operand builders -------------------------------------------------
+  // weights: each k-step slice is 256 rows x 32 fp32 per matrix = 2048 float4 per matrix; 512 threads x 4
+  // phase-1 items: (pair p, embedding e, channel group q of 8) = 64*4*4 = 1024 -> 2 per thread
+  float xval[2];
+  int item_p[2], item_e[2], item_q[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int it = tid + n * GEO_THREADS;
+    item_q[n] = it & 3;
+    item_e[n] = (it >> 2) & 3;
+    item_p[n] = it >> 4;
+    const long pr = min(pair0 + item_p[n], NP - 1);
+    xval[n] = idx4[pr * 4 + item_e[n]];
+  }
+  float4 wreg[8];                                                  // prefetched weight slice (4 of W_d, 4 of W_a)
+  auto wload = [&](int ks) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int it = tid + n * GEO_THREADS;                        // 0..2047: row = it/8, float4 col = it%8
+      const int row = it >> 3, col = it & 7;
+      wreg[n] = *reinterpret_cast<const float4 *>(Wd + (size_t)row * GEO_C + ks * 32 + col * 4);
+      wreg[4 + n] = *reinterpret_cast<const float4 *>(Wa + (size_t)row * GEO_C + ks * 32 + col * 4);
+    }
+  };
+  auto wstore = [&]() {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int it = tid + n * GEO_THREADS;
+      const int row = it >> 3, col = it & 7;
+      union { uint2 u; u16 h[4]; } dh, dl, ah, al;
+      const float dv[4] = {wreg[n].x, wreg[n].y, wreg[n].z, wreg[n].w};
+      const float av[4] = {wreg[4 + n].x, wreg[4 + n].y, wreg[4 + n].z, wreg[4 + n].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        split_bf16(dv[e], dh.h[e], dl.h[e]);
+        split_bf16(av[e], ah.h[e], al.h[e]);
+      }
+      const int o = row * GEO_ROW + col * 4;
+      *reinterpret_cast<uint2 *>(lds + OFF_WDH + o) = dh.u;
+      *reinterpret_cast<uint2 *>(lds + OFF_WDL + o) = dl.u;
+      *reinterpret_cast<uint2 *>(lds + OFF_WAH + o) = ah.u;
+      *reinterpret_cast<uint2 *>(lds + OFF_WAL + o) = al.u;
+    }
+  };
+
+  f32x4 accd[8], acca[3][8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    accd[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) acca[k][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  wload(0);
+  for (int ks = 0; ks < GEO_C / 32; ++ks) {
+    // ---- phase 1: build shared operands of this k-step --------------------------------------------
+    wstore();
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      union { uint4 u; u16 h[8]; } hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float w = div_term[ks * 16 + item_q[n] * 4 + j];
+        float sn, cs;
+        sincosf(xval[n] * w, &sn, &cs);                            // same fp32 product as the reference (:275)
+        split_bf16(sn, hi.h[2 * j], lo.h[2 * j]);                  // interleaved [sin w, cos w] layout (:279-280)
+        split_bf16(cs, hi.h[2 * j + 1], lo.h[2 * j + 1]);
+      }
+      const int o = (item_e[n] * GEO_PAIRS + item_p[n]) * GEO_ROW + item_q[n] * 8;
+      *reinterpret_cast<uint4 *>(lds + OFF_AH + o) = hi.u;
+      *reinterpret_cast<uint4 *>(lds + OFF_AL + o) = lo.u;
+    }
+    __syncthreads();
+    if (ks + 1 < GEO_C / 32) wload(ks + 1);                        // next slice flies under the MFMAs
+    // ---- phase 2: 96 MFMAs per wave ------------------------------------------------------------------
+    bf16x8 ah[4], al[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int o = (e * GEO_PAIRS + mt * 16 + c) * GEO_ROW + g * 8;
+      ah[e] = *reinterpret_cast<const bf16x8 *>(lds + OFF_AH + o);
+      al[e] = *reinterpret_cast<const bf16x8 *>(lds + OFF_AL + o);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int o = (nh * 128 + t * 16 + c) * GEO_ROW + g * 8;
+      const bf16x8 wdh = *reinterpret_cast<const bf16x8 *>(lds + OFF_WDH + o);
+      const bf16x8 wdl = *reinterpret_cast<const bf16x8 *>(lds + OFF_WDL + o);
+      const bf16x8 wah = *reinterpret_cast<const bf16x8 *>(lds + OFF_WAH + o);
+      const bf16x8 wal = *reinterpret_cast<const bf16x8 *>(lds + OFF_WAL + o);
+      accd[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], wdh, accd[t], 0, 0, 0);
+      accd[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[0], wdh, accd[t], 0, 0, 0);
+      accd[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], wdl, accd[t], 0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        acca[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1 + k], wah, acca[k][t], 0, 0, 0);
+        acca[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[1 + k], wah, acca[k][t], 0, 0, 0);
+        acca[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1 + k], wal, acca[k][t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: + biases, max over the k angular neighbours, one write --------------------------------
+  // A = pairs (rows), B = outputs (cols): C layout row = pair g*4+r, col = output c
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int n = nh * 128 + t * 16 + c;
+    const float bias = bd[n] + ba[n];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long pr = pair0 + mt * 16 + g * 4 + r;
+      const float v = accd[t][r] + fmaxf(fmaxf(acca[0][t][r], acca[1][t][r]), acca[2][t][r]) + bias;
+      if (pr < NP) out[pr * GEO_C + n] = v;
+    }
+  }
+}
+
+}  // namespace s6d
+
+using namespace s6d;
+
+extern "C" int s6d_geo_embedding_f32(const float *idx4, long NP, const float *Wd, const float *bd, const float *Wa,
+                                     const float *ba, const float *div_term, int C, int K, float *out, void *stream) {
+  if (NP < 0) return S6D_EINVAL;
+  if (C != GEO_C || K != 3) return S6D_EUNSUPPORTED;      // released model: hidden_dim 256, angle_k 3
+  if (NP == 0) return S6D_OK;
+  if (!idx4 || !Wd || !bd || !Wa || !ba || !div_term || !out) return S6D_EINVAL;
+  const size_t lds = (size_t)GEO_LDS_ELEMS * 2;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&geo_embed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  const unsigned grid = (unsigned)((NP + GEO_PAIRS - 1) / GEO_PAIRS);
+  hipLaunchKernelGGL(geo_embed_kernel, dim3(grid), dim3(GEO_THREADS), lds, as_stream(stream), idx4, NP, Wd, bd, Wa, ba,
+                     div_term, out);
+  return launch_status();
+}

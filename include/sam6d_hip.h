@@ -154,6 +154,15 @@ int s6d_project_bbox_f32(const float *pointcloud, const float *poses, const int3
                          const float *trans, const float *K, int S, int N, int H, int W, int32_t *uv,
                          int32_t *bbox, void *stream);
 
+/* Geometric structure embedding, fused: out[p,:] = W_d s(idx4[p,0]) + b_d + max_k (W_a s(idx4[p,1+k]) + b_a)
+ * with s(x) the interleaved sinusoidal embedding [sin(x w_i), cos(x w_i)] (w = div_term (C/2)).
+ * idx4 (NP,4) f32 = [d_idx, a_idx_0..2] per point pair (NP = B*N*N); W_d, W_a (C,C) f32 row-major (out,in);
+ * out (NP,C) f32.  C = 256, K = 3.  bf16 matrix cores with a 3-term hi/lo split (fp32-class accuracy).
+ * ref: GeometricStructureEmbedding.forward, Pose_Estimation_Model/model/transformer.py:334-349 and
+ * SinusoidalPositionalEmbedding.forward :263-281. */
+int s6d_geo_embedding_f32(const float *idx4, long NP, const float *Wd, const float *bd, const float *Wa,
+                          const float *ba, const float *div_term, int C, int K, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

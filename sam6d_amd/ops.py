@@ -186,6 +186,17 @@ def add_layernorm(x, delta, gamma, beta, eps):
     return xo, y
 
 
+def geo_embedding(idx4, Wd, bd, Wa, ba, div_term):
+    """idx4 (...,4) f32 [d_idx, a_idx x3] -> (...,256) f32 geometric structure embedding."""
+    for a, nm in ((idx4, "idx4"), (Wd, "Wd"), (bd, "bd"), (Wa, "Wa"), (ba, "ba"), (div_term, "div_term")):
+        _chk(a, torch.float32, nm)
+    NP = idx4.numel() // 4
+    out = torch.empty(*idx4.shape[:-1], Wd.shape[0], dtype=torch.float32, device=idx4.device)
+    _call("s6d_geo_embedding_f32", _ptr(idx4), ctypes.c_long(NP), _ptr(Wd), _ptr(bd), _ptr(Wa), _ptr(ba),
+          _ptr(div_term), int(Wd.shape[0]), int(idx4.shape[-1] - 1), _ptr(out), _stream())
+    return out
+
+
 # ------------------------------------------------------------------ ISM scoring
 def pairwise_cosine(query, ref):
     """(P,C), (R,C) f32 -> (P,R) clamp(cos,0,1)."""

@@ -266,9 +266,11 @@ class GeometricStructureEmbedding(nn.Module):
         return dist / self.sigma_d, torch.atan2(sin_v, cos_v) * self.factor_a
 
     def forward(self, points):
-        if ops.have("geo_embedding") and points.is_cuda:
-            return ops.geo_embedding(points, self.proj_d.weight, self.proj_d.bias, self.proj_a.weight,
-                                     self.proj_a.bias, self.sigma_d, self.factor_a, self.angle_k)
+        if ops.have("geo_embedding") and points.is_cuda and self.angle_k == 3 and self.proj_d.weight.shape[0] == 256:
+            d_idx, a_idx = self.get_embedding_indices(points)
+            idx4 = torch.cat([d_idx.unsqueeze(-1), a_idx], dim=-1).contiguous()          # (B,N,N,4)
+            return ops.geo_embedding(idx4, self.proj_d.weight.contiguous(), self.proj_d.bias, self.proj_a.weight.contiguous(),
+                                     self.proj_a.bias, self.embedding.div_term.contiguous())
         outs = []
         for p in points.split(4, dim=0):     # bound the (b,N,N,k,256) intermediate of the library path
             d_idx, a_idx = self.get_embedding_indices(p)

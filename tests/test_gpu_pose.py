@@ -84,3 +84,26 @@ def test_rpe_attention_vs_oracle(ops, B, N):
         assert ops.have("rpe_attention")
         out = m.cuda()(x.cuda(), emb.cuda()).cpu()
     assert (out - ref).abs().max() < 2e-5, (out - ref).abs().max()
+
+
+@pytest.mark.parametrize("B,N", [(2, 197), (1, 37)])
+def test_geo_embedding_vs_oracle(ops, B, N):
+    """Fused sincos -> split-bf16 MFMA -> max kernel vs the fp32 reference formulation."""
+    from sam6d_amd.pem.layers import GeometricStructureEmbedding
+    from sam6d_amd.pem.pose_estimation_model import default_cfg
+    from sam6d_amd.utils import seeded
+    m = GeometricStructureEmbedding(default_cfg().geo_embedding).eval()
+    seeded.load_seeded(m, 2)
+    W = {"geo_embedding." + k: v for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(N)
+    pts = torch.randn(B, N, 3, generator=g) * 0.5
+    pts[:, 0] = 100.0                                   # the background point of pose_estimation_model.py:27
+    with torch.no_grad():
+        ref = opem.geo_embedding(W, pts)
+        assert ops.have("geo_embedding")
+        out = m.cuda()(pts.cuda()).cpu()
+    # entry (0,0) is the reference's own noise floor (sqrt of a cancelling x^2-2xy+y^2 at |x|^2 = 3e4)
+    mask = torch.ones(B, N, N, dtype=torch.bool)
+    mask[:, 0, 0] = False
+    err = (out - ref).abs()[mask]
+    assert err.max() < 2e-3 and err.mean() < 2e-5, (err.max().item(), err.mean().item())

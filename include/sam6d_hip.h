@@ -110,8 +110,10 @@ int s6d_rpe_attention_f32(const float *q, const float *k, const float *v, const 
  * ref: segment_anything/modeling/image_encoder.py Block.forward :166-182, Attention.forward
  * :224-240, add_decomposed_rel_pos :325-361, window_partition/unpartition :243-289. */
 int s6d_win_attention_bf16(const void *qkv, const void *qkv_bias, const void *rel_h, const void *rel_w, int B,
-                           int H, int W, int num_heads, int head_dim, int window, float scale, void *out,
-                           void *stream);
+                           int H, int W, int num_heads, int head_dim, int window, float scale, void *rel_scratch,
+                           void *out, void *stream);
+/* bytes of `rel_scratch` (zero-padded copies of the two tables; may be NULL when rel_h == NULL) */
+long s6d_win_attention_scratch_bytes(int H, int window, int head_dim);
 
 /* x_out = x + delta (skipped when delta == NULL: x_out may be NULL), y_out = LayerNorm_C(x_out)*gamma+beta.
  * x, delta, x_out, y_out (rows,C) bf16; gamma, beta (C) f32; fp32 statistics; C % 8 == 0, C <= 2048.

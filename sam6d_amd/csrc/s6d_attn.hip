@@ -52,6 +52,8 @@ struct AttnParams {
 };
 
 constexpr float kLog2e = 1.4426950408889634f;
+// v_exp_f32 without the denormal-range fix-up of fast_exp2(): arguments here are <= 2^kDefer and tiny results may flush
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 #define S6D_LDS(T) __attribute__((address_space(3))) T
 
@@ -119,7 +121,7 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
     for (int r = 0; r < 4; ++r) {
       float v = acc[r] * p.scale_log2;
       if (MODE == 1) {
-        s[sub][r] = v + thv + twr[sub * 4 + r];
+        s[sub][r] = v + twr[sub * 4 + r];                 // thv (constant over the tile for this lane) is added to the max only
       } else {
         const int kk = key0 + sub * 16 + g * 4 + r;       // key slot of this score; query = lane & 15
         if (MODE == 0) {
@@ -138,23 +140,25 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
     for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[sub][r]);
   mx = fmaxf(mx, __shfl_xor(mx, 16));
   mx = fmaxf(mx, __shfl_xor(mx, 32));
+  if (MODE == 1) mx += thv;                               // true score maximum of the tile
   // deferred rescaling: keep the old running max while no query's max grew by more than 2^kDefer
   // (P stays <= 2^kDefer, exact in bf16's exponent range); the O / l rescale is skipped on those tiles.
   constexpr float kDefer = 6.0f;
   const bool grow = __any(mx - m_run > kDefer);
   const float m_new = grow ? fmaxf(m_run, mx) : m_run;
+  const float m_sub = (MODE == 1) ? m_new - thv : m_new;  // exp2(s + thv - m_new) = exp2(s - (m_new - thv))
   float psum = 0.f;
 #pragma unroll
   for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      s[sub][r] = exp2f(s[sub][r] - m_new);
+      s[sub][r] = fast_exp2(s[sub][r] - m_sub);
       psum += s[sub][r];
     }
   psum += __shfl_xor(psum, 16);
   psum += __shfl_xor(psum, 32);
   if (grow) {                                       // wave-uniform
-    const float alpha = exp2f(m_run - m_new);
+    const float alpha = fast_exp2(m_run - m_new);
     l_run *= alpha;
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) oacc[dt] *= alpha;
@@ -283,26 +287,42 @@ __device__ __forceinline__ void load_q(const AttnParams &p, int b, int wy, int w
   }
 }
 
-// dst[c*ld + jj] = log2(e) * rel[j0 + sgn*jj] . q_c   for jj in [0, 16*njt), rows outside [0, L) give 0
-template <int HD>
-__device__ __forceinline__ void build_table(const u16 *rel, int L, int j0, int sgn, int njt,
-                                            const bf16x8 (&qf)[Cfg<HD>::KS], float *dst, int ld, int lane) {
+// dst[c*ld + jj] = log2(e) * rel[j0 + sgn*jj] . q_c   for jj in [0, 16*njt).  `rel` is the zero-padded copy
+// [rows >= max j + 1][HDP] made by pad_rel_kernel, so every load is unconditional: all njt*KS loads of a table
+// are issued back to back (the bounds-checked form compiled to one exec-masked load + vmcnt(0) per MFMA).
+template <int HD, int NJT>
+__device__ __forceinline__ void build_table(const u16 *rel, int j0, int sgn, const bf16x8 (&qf)[Cfg<HD>::KS],
+                                            float *dst, int ld, int lane) {
+  using C = Cfg<HD>;
   const int g = lane >> 4, c = lane & 15;
-  for (int jt = 0; jt < njt; ++jt) {
-    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  union { uint4 u; bf16x8 v; } r[NJT][C::KS];
+#pragma unroll
+  for (int jt = 0; jt < NJT; ++jt) {
     const int j = j0 + sgn * (jt * 16 + c);
 #pragma unroll
-    for (int ks = 0; ks < Cfg<HD>::KS; ++ks) {
-      const int d0 = ks * 32 + g * 8;
-      union { uint4 u; bf16x8 v; } r;
-      const int jc = min(max(j, 0), L - 1), dc = d0 < HD ? d0 : HD - 8;
-      r.u = *reinterpret_cast<const uint4 *>(rel + (size_t)jc * HD + dc);
-      if (!(j >= 0 && j < L && d0 < HD)) r.u = make_uint4(0, 0, 0, 0);
-      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r.v, qf[ks], a, 0, 0, 0);
-    }
+    for (int ks = 0; ks < C::KS; ++ks)
+      r[jt][ks].u = *reinterpret_cast<const uint4 *>(rel + (size_t)j * C::HDP + ks * 32 + g * 8);
+  }
+#pragma unroll
+  for (int jt = 0; jt < NJT; ++jt) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r[jt][ks].v, qf[ks], a, 0, 0, 0);
     // C layout: row jj = jt*16 + g*4 + r, col = query c
     *reinterpret_cast<float4 *>(dst + c * ld + jt * 16 + g * 4) =
         make_float4(a[0] * kLog2e, a[1] * kLog2e, a[2] * kLog2e, a[3] * kLog2e);
+  }
+}
+
+// rel (L,HD) -> padded (rows,HDP), zero filled
+__global__ void pad_rel_kernel(const u16 *__restrict__ rel_h, const u16 *__restrict__ rel_w, int L, int HD, int HDP,
+                               int rows, u16 *__restrict__ out) {
+  const int n = rows * HDP;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n; i += gridDim.x * blockDim.x) {
+    const int which = i >= n, ii = which ? i - n : i;
+    const int j = ii / HDP, d = ii - j * HDP;
+    const u16 *src = which ? rel_w : rel_h;
+    out[i] = (j < L && d < HD) ? src[j * HD + d] : (u16)0;
   }
 }
 
@@ -357,9 +377,10 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window_kernel(AttnParams p) {
     bf16x8 qf[C::KS];
     load_q<HD>(p, b, wy, wx, head, q0, qf, lane);
     if (BIAS) {
-      const int L = 2 * p.S - 1;
-      build_table<HD>(p.rel_h, L, 0, 1, p.LT / 16, qf, th, p.LT, lane);
-      build_table<HD>(p.rel_w, L, 0, 1, p.LT / 16, qf, tw, p.LT, lane);
+      for (int jt = 0; jt < p.LT / 16; ++jt) {
+        build_table<HD, 1>(p.rel_h, jt * 16, 1, qf, th + jt * 16, p.LT, lane);
+        build_table<HD, 1>(p.rel_w, jt * 16, 1, qf, tw + jt * 16, p.LT, lane);
+      }
     }
     const int qi = min(q0 + (lane & 15), p.T - 1);
     const int qy = div_S(p, qi), qx = qi - qy * p.S;
@@ -449,7 +470,6 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
   }
   __syncthreads();
 
-  const int L = 2 * S - 1;
 #pragma unroll
   for (int i = 0; i < MAXROWS; ++i) {                             // one query row per strip; query column = c
     const int qy = wave + i * WAVES;
@@ -457,8 +477,8 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
     const int y = wy * p.ws + qy, x = wx * p.ws + c;
     const bool qimg = c < S && (y < p.H) && (x < p.W);
     const bf16x8 (&qf)[C::KS] = qfa[i];
-    build_table<HD>(p.rel_h, L, 0, 1, 2, qf, th, 32, lane);
-    build_table<HD>(p.rel_w, L, 0, 1, 2, qf, tw, 32, lane);
+    build_table<HD, 2>(p.rel_h, 0, 1, qf, th, 32, lane);
+    build_table<HD, 2>(p.rel_w, 0, 1, qf, tw, 32, lane);
     float twr[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -489,14 +509,14 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       const float m_new = fmaxf(fmaxf(m_run, mx), -1e29f);        // stays finite even if a whole row is padding
-      const float alpha = exp2f(m_run - m_new);
+      const float alpha = fast_exp2(m_run - m_new);
       float psum = 0.f;
       union { bf16x8 v; u16 hh[8]; } pb;
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = exp2f(s[h][r] - m_new);
+          const float e = fast_exp2(s[h][r] - m_new);
           psum += e;
           pb.hh[h * 4 + r] = f2bf(e);
         }
@@ -568,9 +588,10 @@ __global__ __launch_bounds__(WAVES * 64) void attn_global_kernel(AttnParams p) {
   if (MODE == 0) {
     th = tabs + (size_t)wave * 2 * 16 * p.LT;
     tw = th + 16 * p.LT;
-    const int L = 2 * p.S - 1;
-    build_table<HD>(p.rel_h, L, 0, 1, p.LT / 16, qf, th, p.LT, lane);
-    build_table<HD>(p.rel_w, L, 0, 1, p.LT / 16, qf, tw, p.LT, lane);
+    for (int jt = 0; jt < p.LT / 16; ++jt) {
+      build_table<HD, 1>(p.rel_h, jt * 16, 1, qf, th + jt * 16, p.LT, lane);
+      build_table<HD, 1>(p.rel_w, jt * 16, 1, qf, tw + jt * 16, p.LT, lane);
+    }
   } else if (MODE == 1) {
     // S == 64: the strip's 16 queries share qy (q0 % 16 == 0); tile t is key row ky = t.
     //   th[c][t] = rel_h[qy - t + 63] . q_c ;  tw needs rel_w[qx_c - kx + 63], qx_c = q0x + c: build
@@ -578,8 +599,8 @@ __global__ __launch_bounds__(WAVES * 64) void attn_global_kernel(AttnParams p) {
     th = tabs + (size_t)wave * 16 * 64;
     float *G = reinterpret_cast<float *>(smem) + (size_t)wave * 16 * 80;
     const int q0y = div_S(p, q0), q0x = q0 - q0y * p.S;
-    build_table<HD>(p.rel_h, 127, q0y + 63, -1, 4, qf, th, 64, lane);
-    build_table<HD>(p.rel_w, 127, q0x, 1, 5, qf, G, 80, lane);
+    build_table<HD, 4>(p.rel_h, q0y + 63, -1, qf, th, 64, lane);
+    build_table<HD, 5>(p.rel_w, q0x, 1, qf, G, 80, lane);
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
@@ -666,9 +687,15 @@ static int launch_attn(AttnParams p, hipStream_t st) {
 
 using namespace s6d;
 
+extern "C" long s6d_win_attention_scratch_bytes(int H, int window, int head_dim) {
+  const int S = window ? window : H;
+  const int LT = ((2 * S - 1) + 15) / 16 * 16, HDP = (head_dim + 31) / 32 * 32;
+  return 2L * (LT + 16) * HDP * 2;
+}
+
 extern "C" int s6d_win_attention_bf16(const void *qkv, const void *qkv_bias, const void *rel_h, const void *rel_w,
                                       int B, int H, int W, int num_heads, int head_dim, int window, float scale,
-                                      void *out, void *stream) {
+                                      void *rel_scratch, void *out, void *stream) {
   if (B < 0 || H <= 0 || W <= 0 || num_heads <= 0 || window < 0) return S6D_EINVAL;
   if (B == 0) return S6D_OK;
   if (!qkv || !qkv_bias || !out || ((rel_h == nullptr) != (rel_w == nullptr))) return S6D_EINVAL;
@@ -689,6 +716,14 @@ extern "C" int s6d_win_attention_bf16(const void *qkv, const void *qkv_bias, con
     p.dbg = e ? atoi(e) : 0;
   }
   hipStream_t st = as_stream(stream);
+  if (rel_h) {                                   // zero-padded table copies: unconditional loads in the kernels
+    if (!rel_scratch) return S6D_EINVAL;
+    const int HDP = (head_dim + 31) / 32 * 32, rows = p.LT + 16;
+    hipLaunchKernelGGL(pad_rel_kernel, dim3(16), dim3(256), 0, st, p.rel_h, p.rel_w, 2 * p.S - 1, head_dim, HDP, rows,
+                       (u16 *)rel_scratch);
+    p.rel_h = (const u16 *)rel_scratch;
+    p.rel_w = p.rel_h + (size_t)rows * HDP;
+  }
   switch (head_dim) {
     case 80: return launch_attn<80>(p, st);
     case 64: return launch_attn<64>(p, st);

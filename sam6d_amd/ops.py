@@ -161,9 +161,14 @@ def window_attention(qkv, qkv_bias, rel_h, rel_w, num_heads, window, scale):
         if rel_h.shape != (2 * S - 1, hd) or rel_w.shape != (2 * S - 1, hd):
             raise RuntimeError("rel_pos tables must be (2S-1, head_dim)")
     out = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=qkv.device)
+    scratch = None
+    if rel_h is not None:
+        fn = _lib.lib().s6d_win_attention_scratch_bytes
+        fn.restype = ctypes.c_long
+        scratch = torch.empty(int(fn(H, int(window), int(hd))), dtype=torch.uint8, device=qkv.device)
     _call("s6d_win_attention_bf16", _ptr(qkv), _ptr(qkv_bias), _ptr(rel_h) if rel_h is not None else _vp(0),
           _ptr(rel_w) if rel_w is not None else _vp(0), B, H, W, int(num_heads), int(hd), int(window),
-          ctypes.c_float(scale), _ptr(out), _stream())
+          ctypes.c_float(scale), _ptr(scratch) if scratch is not None else _vp(0), _ptr(out), _stream())
     return out
 
 

@@ -147,7 +147,9 @@ long s6d_patch_scores_workspace_floats(int S, int N1, int N2);
  * ref: Calculate_the_query_translation, model/detector.py:234-246 +
  * depth_image_to_pointcloud_translate_torch, utils/trimesh_utils.py:77-105 (float64 X/Y, float32 Z). */
 int s6d_masked_depth_mean_f32(const float *masks, const float *depth, int S, int H, int W, float depth_scale,
-                              double fx, double fy, double cx, double cy, float *out, void *stream);
+                              double fx, double fy, double cx, double cy, void *workspace, float *out,
+                              void *stream);
+long s6d_masked_depth_mean_workspace_bytes(int S);   /* W % 4 == 0 */
 
 /* Template projection: uv[s,i] = clamp(trunc(K (R_tmpl[s] p_i + t_s))), bbox[s] = (min u, min v, max u, max v).
  * pointcloud (O,N,3), poses (T,4,4), trans (S,3), K (3,3) f32; obj/tmpl (S) i32 -> uv (S,N,2) i32, bbox (S,4) i32.

@@ -131,19 +131,32 @@ __global__ __launch_bounds__(256) void patch_scores_kernel(const float *__restri
 #pragma unroll
   for (int t = 0; t < kMaxColTiles; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   float qsum = 0.f;
+  // reference-patch row pointers of the 16 column tiles (clamped: surplus tiles re-read the last row and are
+  // masked in the epilogue), then a 2-deep software pipeline: chunk k+1 is in flight while chunk k feeds 64 MFMAs
+  const float *rp[kMaxColTiles];
+#pragma unroll
+  for (int t = 0; t < kMaxColTiles; ++t) rp[t] = Rf + (size_t)min(t * 16 + c, N2 - 1) * C + g * 4;
+  float4 a_cur = *reinterpret_cast<const float4 *>(qa);
+  float4 b_cur[kMaxColTiles];
+#pragma unroll
+  for (int t = 0; t < kMaxColTiles; ++t) b_cur[t] = *reinterpret_cast<const float4 *>(rp[t]);
   for (int k0 = 0; k0 < C; k0 += 16) {
-    const float4 a = *reinterpret_cast<const float4 *>(qa + k0);
-    qsum += (a.x + a.y) + (a.z + a.w);
+    const int kn = min(k0 + 16, C - 16);                    // last iteration re-loads (unused) in-bounds data
+    const float4 a_nxt = *reinterpret_cast<const float4 *>(qa + kn);
+    float4 b_nxt[kMaxColTiles];
+#pragma unroll
+    for (int t = 0; t < kMaxColTiles; ++t) b_nxt[t] = *reinterpret_cast<const float4 *>(rp[t] + kn);
+    qsum += (a_cur.x + a_cur.y) + (a_cur.z + a_cur.w);
 #pragma unroll
     for (int t = 0; t < kMaxColTiles; ++t) {
-      if (t < nct) {
-        const float4 b = *reinterpret_cast<const float4 *>(Rf + (size_t)min(t * 16 + c, N2 - 1) * C + g * 4 + k0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[t], 0, 0, 0);
-      }
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.x, b_cur[t].x, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.y, b_cur[t].y, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.z, b_cur[t].z, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.w, b_cur[t].w, acc[t], 0, 0, 0);
     }
+    a_cur = a_nxt;
+#pragma unroll
+    for (int t = 0; t < kMaxColTiles; ++t) b_cur[t] = b_nxt[t];
   }
   // element sums of the 16 query rows (row = l&15 after folding the 4 k-groups)
   qsum += __shfl_xor(qsum, 16); qsum += __shfl_xor(qsum, 32);
@@ -217,27 +230,38 @@ __global__ void patch_finalize_kernel(const float *__restrict__ part_rowsum, con
 // Mean back-projected point of every mask (detector.py:234-246 + trimesh_utils.py:77-105) -- three masked
 // sums, no (S,H,W) depth repeat.  Dtype trail of the reference: Z float32; X, Y float64 (the camera matrix is a
 // float64 tensor); the three means are cast to float32 at the end.
-__global__ __launch_bounds__(256) void masked_depth_mean_kernel(const float *__restrict__ masks,
-                                                               const float *__restrict__ depth, int H, int W,
-                                                               float depth_scale, double fx, double fy, double cx,
-                                                               double cy, float *__restrict__ out) {
-  __shared__ double sx[4], sy[4];
-  __shared__ float sz[4];
+constexpr int kDepthChunks = 16;       // workgroups per mask
+
+__global__ __launch_bounds__(256) void masked_depth_partial_kernel(const float *__restrict__ masks,
+                                                                  const float *__restrict__ depth, int H, int W,
+                                                                  unsigned magicW, float depth_scale, double fx,
+                                                                  double fy, double cx, double cy,
+                                                                  double *__restrict__ part) {
+  __shared__ double sx[4], sy[4], sz[4];
   __shared__ int sn[4];
-  const int s = blockIdx.x, tid = threadIdx.x;
-  const float *m = masks + (size_t)s * H * W;
-  double ax = 0.0, ay = 0.0;
-  float az = 0.f;
+  const int s = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+  const int n4 = (H * W) / 4;                               // W % 4 == 0 (checked by the launcher)
+  const int per = (n4 + kDepthChunks - 1) / kDepthChunks;
+  const int i0 = ch * per, i1 = min(i0 + per, n4);
+  const float4 *m4 = reinterpret_cast<const float4 *>(masks + (size_t)s * H * W);
+  const float4 *d4 = reinterpret_cast<const float4 *>(depth);
+  double ax = 0.0, ay = 0.0, az = 0.0;
   int n = 0;
-  for (int i = tid; i < H * W; i += 256) {
-    const float z = m[i] * depth[i] * depth_scale / 1000.f;
-    if (z > 0.f) {
-      const int v = i / W, u = i - v * W;
-      ax += ((double)u - cx) * (double)z / fx;
-      ay += ((double)v - cy) * (double)z / fy;
-      az += z;
-      ++n;
-    }
+  for (int i = i0 + tid; i < i1; i += 256) {
+    const float4 m = m4[i], d = d4[i];
+    const int pix = i * 4;
+    const int v = (int)__umulhi((unsigned)pix, magicW), u = pix - v * W;   // the 4 pixels share the row
+    const float z[4] = {m.x * d.x * depth_scale / 1000.f, m.y * d.y * depth_scale / 1000.f,
+                        m.z * d.z * depth_scale / 1000.f, m.w * d.w * depth_scale / 1000.f};
+    const double yv = ((double)v - cy) / fy;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (z[e] > 0.f) {
+        ax += ((double)(u + e) - cx) * (double)z[e] / fx;
+        ay += yv * (double)z[e];
+        az += (double)z[e];
+        ++n;
+      }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -249,13 +273,26 @@ __global__ __launch_bounds__(256) void masked_depth_mean_kernel(const float *__r
   if ((tid & 63) == 0) { sx[tid >> 6] = ax; sy[tid >> 6] = ay; sz[tid >> 6] = az; sn[tid >> 6] = n; }
   __syncthreads();
   if (tid == 0) {
-    const double X = (sx[0] + sx[1]) + (sx[2] + sx[3]), Y = (sy[0] + sy[1]) + (sy[2] + sy[3]);
-    const float Z = (sz[0] + sz[1]) + (sz[2] + sz[3]);
-    const float cnt = (float)(sn[0] + sn[1] + sn[2] + sn[3]) + 1e-8f;    // count_nonzero + 1e-8 is float32
-    out[s * 3 + 0] = (float)(X / (double)cnt);
-    out[s * 3 + 1] = (float)(Y / (double)cnt);
-    out[s * 3 + 2] = Z / cnt;
+    double *o = part + ((size_t)s * kDepthChunks + ch) * 4;
+    o[0] = (sx[0] + sx[1]) + (sx[2] + sx[3]);
+    o[1] = (sy[0] + sy[1]) + (sy[2] + sy[3]);
+    o[2] = (sz[0] + sz[1]) + (sz[2] + sz[3]);
+    o[3] = (double)(sn[0] + sn[1] + sn[2] + sn[3]);
   }
+}
+
+__global__ void masked_depth_final_kernel(const double *__restrict__ part, int S, float *__restrict__ out) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  double X = 0, Y = 0, Z = 0, N = 0;
+  for (int ch = 0; ch < kDepthChunks; ++ch) {              // fixed order: deterministic
+    const double *o = part + ((size_t)s * kDepthChunks + ch) * 4;
+    X += o[0]; Y += o[1]; Z += o[2]; N += o[3];
+  }
+  const float cnt = (float)N + 1e-8f;                      // count_nonzero + 1e-8 is float32 in the reference
+  out[s * 3 + 0] = (float)(X / (double)cnt);
+  out[s * 3 + 1] = (float)(Y / (double)cnt);
+  out[s * 3 + 2] = (float)Z / cnt;
 }
 
 // Rotate the object's model points by the best template pose, translate, project with K, truncate to
@@ -352,13 +389,22 @@ extern "C" long s6d_patch_scores_workspace_floats(int S, int N1, int N2) {
   return (long)S * nslot * (2 + N2);
 }
 
+extern "C" long s6d_masked_depth_mean_workspace_bytes(int S) { return (long)S * kDepthChunks * 4 * sizeof(double); }
+
 extern "C" int s6d_masked_depth_mean_f32(const float *masks, const float *depth, int S, int H, int W, float depth_scale,
-                                         double fx, double fy, double cx, double cy, float *out, void *stream) {
+                                         double fx, double fy, double cx, double cy, void *workspace, float *out,
+                                         void *stream) {
   if (S < 0 || H <= 0 || W <= 0) return S6D_EINVAL;
+  if ((W % 4) != 0) return S6D_EUNSUPPORTED;
   if (S == 0) return S6D_OK;
-  if (!masks || !depth || !out) return S6D_EINVAL;
-  hipLaunchKernelGGL(masked_depth_mean_kernel, dim3(S), dim3(256), 0, as_stream(stream), masks, depth, H, W, depth_scale, fx,
-                     fy, cx, cy, out);
+  if (!masks || !depth || !out || !workspace) return S6D_EINVAL;
+  const unsigned magicW = (unsigned)(((1ull << 32) + (unsigned)W - 1) / (unsigned)W);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(masked_depth_partial_kernel, dim3(kDepthChunks, S), dim3(256), 0, st, masks, depth, H, W, magicW,
+                     depth_scale, fx, fy, cx, cy, (double *)workspace);
+  int rc = launch_status();
+  if (rc) return rc;
+  hipLaunchKernelGGL(masked_depth_final_kernel, dim3((S + 63) / 64), dim3(64), 0, st, (const double *)workspace, S, out);
   return launch_status();
 }
 

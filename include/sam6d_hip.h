@@ -167,6 +167,16 @@ int s6d_project_bbox_f32(const float *pointcloud, const float *poses, const int3
 int s6d_geo_embedding_f32(const float *idx4, long NP, const float *Wd, const float *bd, const float *Wa,
                           const float *ba, const float *div_term, int C, int K, float *out, void *stream);
 
+/* Soft-assignment head of compute_fine_Rt (Pose_Estimation_Model/utils/model_utils.py:262-270), fused.
+ * atten (B,M1,M2) f32 similarity / temp (row 0 / col 0 = background token), pts2 (B,M2-1,3) f32 ->
+ *   w1   (B,M1-1)   1 if the row's arg-max over softmax(dim=2)*softmax(dim=1) is not the background column
+ *   wsum (B,M1-1)   row sums of the masked assignment a_ij = p_ij w1_i w2_j   (i,j >= 1)
+ *   pred (B,M1-1,3) (a_i / (wsum_i + 1e-6)) @ pts2
+ * |atten| must stay below ~80 (it is cosine/temp = +-10): exp() is taken without a max shift.  M2 <= 2112. */
+int s6d_fine_assign_f32(const float *atten, const float *pts2, int B, int M1, int M2, void *workspace, float *pred,
+                        float *wsum, float *w1, void *stream);
+long s6d_fine_assign_workspace_bytes(int B, int M1, int M2);
+
 #ifdef __cplusplus
 }
 #endif

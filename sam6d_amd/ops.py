@@ -202,6 +202,23 @@ def geo_embedding(idx4, Wd, bd, Wa, ba, div_term):
     return out
 
 
+def fine_assign(atten, pts2):
+    """atten (B,M1,M2) f32, pts2 (B,M2-1,3) f32 -> pred (B,M1-1,3), wsum (B,M1-1), w1 (B,M1-1)."""
+    _chk(atten, torch.float32, "atten", 3)
+    _chk(pts2, torch.float32, "pts2", 3)
+    B, M1, M2 = atten.shape
+    dev = atten.device
+    fn = _lib.lib().s6d_fine_assign_workspace_bytes
+    fn.restype = ctypes.c_long
+    ws = torch.empty(int(fn(B, M1, M2)), dtype=torch.uint8, device=dev)
+    pred = torch.empty(B, M1 - 1, 3, dtype=torch.float32, device=dev)
+    wsum = torch.empty(B, M1 - 1, dtype=torch.float32, device=dev)
+    w1 = torch.empty(B, M1 - 1, dtype=torch.float32, device=dev)
+    _call("s6d_fine_assign_f32", _ptr(atten), _ptr(pts2), B, M1, M2, _ptr(ws), _ptr(pred), _ptr(wsum), _ptr(w1),
+          _stream())
+    return pred, wsum, w1
+
+
 # ------------------------------------------------------------------ ISM scoring
 def pairwise_cosine(query, ref):
     """(P,C), (R,C) f32 -> (P,R) clamp(cos,0,1)."""

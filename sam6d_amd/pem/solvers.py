@@ -87,7 +87,7 @@ def coarse_Rt(atten, pts1, pts2, model_pts, rand_u, n1=6000, n2=300):
 
 def fine_Rt(atten, pts1, pts2, model_pts, dis_thres=0.15):
     """compute_fine_Rt."""
-    if ops.have("fine_assign") and atten.is_cuda:
+    if ops.have("fine_assign") and atten.is_cuda and atten.shape[2] <= 2112 and pts2.shape[1] == atten.shape[2] - 1:
         pred, wsum, w1 = ops.fine_assign(atten.contiguous(), pts2.contiguous())
     else:
         amat, w1, _ = soft_assignment(atten)

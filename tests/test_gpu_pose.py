@@ -107,3 +107,20 @@ def test_geo_embedding_vs_oracle(ops, B, N):
     mask[:, 0, 0] = False
     err = (out - ref).abs()[mask]
     assert err.max() < 2e-3 and err.mean() < 2e-5, (err.max().item(), err.mean().item())
+
+
+@pytest.mark.parametrize("B,M", [(2, 2049), (3, 300), (1, 17)])
+def test_fine_assign_vs_oracle(ops, B, M):
+    """3-pass fused dual-softmax / masking / normalised assignment vs the reference chain."""
+    g = torch.Generator().manual_seed(M)
+    f1 = torch.nn.functional.normalize(torch.randn(B, M, 64, generator=g), dim=2)
+    f2 = torch.nn.functional.normalize(f1[:, torch.randperm(M, generator=g)] + 0.3 * torch.randn(B, M, 64, generator=g), dim=2)
+    atten = f1 @ f2.transpose(1, 2) / 0.1
+    pts2 = torch.randn(B, M - 1, 3, generator=g)
+    amat, w1, _ = opem.soft_assignment(atten)
+    wsum = amat.sum(2)
+    pred = (amat / (wsum.unsqueeze(2) + 1e-6)) @ pts2
+    p, ws, w = (t.cpu() for t in ops.fine_assign(atten.cuda(), pts2.cuda()))
+    assert torch.equal(w, w1)
+    assert (ws - wsum).abs().max() < 1e-5 * max(1.0, wsum.abs().max().item())
+    assert (p - pred).abs().max() < 2e-5

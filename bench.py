@@ -108,6 +108,84 @@ def stage_ms(fn, n=2):
     return e0.elapsed_time(e1) / n
 
 
+def _event_ms(fn, n):
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def kernel_rooflines(dev, sam_chunk, frames):
+    """Per-launch roofline of the hand-written kernels at the exact shapes the step uses, timed with HIP events on
+    torch's current stream (the stream every s6d_* kernel is launched on).  Algorithmic work per launch:
+      attn_global   4*T^2*hd*nh*Bc FLOP (QK^T + PV), T = 4096, hd = 80, nh = 16, Bc = frames per SAM chunk
+      attn_window16 4*196^2*hd * 25 windows * nh * Bc FLOP
+      rpe_attention B*N * (N*256*4) bytes  (the geometric embedding is streamed exactly once), N = 197
+      geo_embed     B*N*N * 4 embeddings * 2*256*256 FLOP (as written in the reference, fp32)
+    Peaks: 2.5 PFLOP/s dense bf16 MFMA, 157.3 TFLOP/s fp32, 8.0 TB/s HBM (MI355X_MICROARCH.md)."""
+    from sam6d_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(0)
+    out = []
+    nh, hd, H = 16, 80, 64
+    qkv = torch.randn(sam_chunk, H, H, 3 * nh * hd, generator=g).to(dev).to(torch.bfloat16)
+    bias = torch.randn(3 * nh * hd, generator=g).to(dev).to(torch.bfloat16)
+    for name, ws, S in (("attn_global_kernel<80,4,1>", 0, 64), ("attn_window16_kernel<80,7>", 14, 14)):
+        rh = torch.randn(2 * S - 1, hd, generator=g).to(dev).to(torch.bfloat16)
+        rw = torch.randn(2 * S - 1, hd, generator=g).to(dev).to(torch.bfloat16)
+        ms = _event_ms(lambda: ops.window_attention(qkv, bias, rh, rw, nh, ws, hd ** -0.5), 10)
+        nwin = 1 if ws == 0 else 25
+        flop = 4.0 * (S * S) ** 2 * hd * nwin * nh * sam_chunk
+        out.append({"kernel": name, "bound": "mfma", "achieved": round(flop / ms / 1e9, 1), "peak": 2500.0,
+                    "unit": "TFLOP/s", "frac": round(flop / ms / 1e9 / 2500.0, 4), "avg_ms": round(ms, 4),
+                    "launches_per_step": (4 if ws == 0 else 28) * (frames // sam_chunk)})
+    B, N = frames, 197
+    q, k, v = (torch.randn(B, N, 256, generator=g).to(dev) for _ in range(3))
+    qt = torch.randn(B, 4, N, 256, generator=g).to(dev)
+    qb = torch.randn(B, 4, N, generator=g).to(dev)
+    emb = torch.randn(B, N, N, 256, generator=g).to(dev)
+    ms = _event_ms(lambda: ops.rpe_attention(q, k, v, qt, qb, emb, 0.125), 10)
+    nbytes = float(B) * N * N * 256 * 4
+    out.append({"kernel": "rpe_attention_kernel<4>", "bound": "hbm", "achieved": round(nbytes / ms / 1e6, 1),
+                "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / 8000.0, 4), "avg_ms": round(ms, 4),
+                "launches_per_step": 12})
+    idx4 = torch.rand(B, N, N, 4, generator=g).to(dev) * 10
+    Wd, Wa = torch.randn(256, 256, generator=g).to(dev) / 16, torch.randn(256, 256, generator=g).to(dev) / 16
+    bd, ba = torch.randn(256, generator=g).to(dev), torch.randn(256, generator=g).to(dev)
+    div = torch.exp(torch.arange(0, 256, 2).float() * (-9.210340371976184 / 256)).to(dev)
+    ms = _event_ms(lambda: ops.geo_embedding(idx4, Wd, bd, Wa, ba, div), 5)
+    flop = float(B) * N * N * 4 * 2 * 256 * 256
+    out.append({"kernel": "geo_embed_kernel", "bound": "mfma", "achieved": round(flop / ms / 1e9, 1), "peak": 157.3,
+                "unit": "TFLOP/s (fp32-equivalent; runs as 3x bf16 MFMA)", "frac": round(flop / ms / 1e9 / 157.3, 4),
+                "avg_ms": round(ms, 4), "launches_per_step": 2})
+    # the library GEMM that dominates the SAM stage, for context (hipBLASLt through torch): MLP lin1 shape
+    x = torch.randn(sam_chunk * 4096, 1280, generator=g).to(dev).to(torch.bfloat16)
+    w = torch.randn(5120, 1280, generator=g).to(dev).to(torch.bfloat16)
+    bb = torch.randn(5120, generator=g).to(dev).to(torch.bfloat16)
+    ms = _event_ms(lambda: torch.nn.functional.linear(x, w, bb), 10)
+    flop = 2.0 * x.shape[0] * 1280 * 5120
+    out.append({"kernel": "library GEMM (hipBLASLt) mlp.lin1 M=%d" % x.shape[0], "bound": "mfma",
+                "achieved": round(flop / ms / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                "frac": round(flop / ms / 1e9 / 2500.0, 4), "avg_ms": round(ms, 4), "launches_per_step": 32 * (frames // sam_chunk)})
+    return out
+
+
+def _pmc_traffic(kernel_name):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_summary.json), if present."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        for k, v in d.items():
+            if kernel_name.startswith(k):
+                return v.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline():
     """CPU restatement (oracle = 'port' of the reference algorithm) timed on the host cores on a
     bounded sample: 1 SAM ViT-H frame + 1 ISM frame + a PEM batch of 2 instances."""
@@ -200,10 +278,18 @@ def main():
         pem_ms = stage_ms(hp.pem_stage, 1)
         achieved = SAM_FLOP_PER_FRAME * args.frames / (sam_ms * 1e-3)
         extra["stages_ms"] = {"sam_encoder": round(sam_ms, 2), "ism_scoring": round(ism_ms, 2), "pem": round(pem_ms, 2)}
-        extra["roofline"] = {"bound": "mfma", "kernel": "SAM ViT-H encoder stage (bf16 GEMMs + attention), "
-                             f"{args.frames} frames", "achieved": round(achieved / 1e12, 2),
-                             "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK, 4),
-                             "traffic": None}
+        kr = kernel_rooflines(dev, args.sam_chunk, args.frames)
+        dom = max((k for k in kr if not k["kernel"].startswith("library")),
+                  key=lambda k: k["avg_ms"] * k["launches_per_step"])
+        # dominant HAND-WRITTEN kernel (largest avg duration x launches per step); library GEMMs, which take more
+        # time than any of them, are listed in `kernels` for context
+        extra["roofline"] = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"],
+                             "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
+                             "avg_launch_ms": dom["avg_ms"], "traffic": _pmc_traffic(dom["kernel"])}
+        extra["kernels"] = kr
+        extra["stage_roofline"] = {"stage": f"SAM ViT-H encoder, {args.frames} frames (bf16 GEMMs + fused attention)",
+                                   "bound": "mfma", "achieved": round(achieved / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12,
+                                   "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK, 4)}
         if world == 1 and not args.no_cpu_baseline:
             extra["cpu_baseline"] = cpu_baseline()
 

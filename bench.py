@@ -54,6 +54,7 @@ class HotPath:
         from sam6d_amd.sam.image_encoder import build_vit_h
         from sam6d_amd.utils import seeded, synth
 
+        os.environ.setdefault("S6D_PEM_VIT_DTYPE", "bf16")          # BASELINE configs[1]: bf16 (both ViTs run bf16)
         self.dev, self.F, self.chunk = device, frames, sam_chunk
         self.sam = seeded.load_seeded(build_vit_h().eval(), 3).to(device=device, dtype=torch.bfloat16)
         self.pem = seeded.load_seeded(pm.Net(pm.default_cfg()).eval(), 1).to(device)
@@ -299,7 +300,7 @@ def main():
         line = {"metric": "RGB-D frames/sec (SAM-6D per-frame hot path: SAM ViT-H encoder + ISM scoring + PEM)",
                 "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (SAM ViT-H) + f32 (ISM scoring, PEM)",
+                "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (SAM ViT-H, PEM ViT-B) + f32 (ISM scoring, PEM point transformer and pose solvers)",
                 "data": "synthetic",
                 "config": {"workload": "LM-O single object: 32 frames/step/GPU, 640x480 RGB-D -> 1024^2 SAM input, "
                                        "P=128 proposals x 42 templates, 1 instance/frame, 2048 pts (PEM batch 32)",

@@ -177,6 +177,12 @@ int s6d_fine_assign_f32(const float *atten, const float *pts2, int B, int M1, in
                         float *wsum, float *w1, void *stream);
 long s6d_fine_assign_workspace_bytes(int B, int M1, int M2);
 
+/* Plain multi-head self-attention over a token sequence (no positional bias): qkv (B,N,3,nh,hd) bf16 ->
+ * out (B,N,nh*hd) bf16, softmax(scale q.k) v; all N key slots LDS-resident (N <= ~500 at hd 64).  hd in {64, 80}.
+ * ref: the timm ViT attention used by Pose_Estimation_Model/model/feature_extraction.py:17-35 (N = 197, hd = 64). */
+int s6d_seq_attention_bf16(const void *qkv, int B, int N, int num_heads, int head_dim, float scale, void *out,
+                           void *stream);
+
 #ifdef __cplusplus
 }
 #endif

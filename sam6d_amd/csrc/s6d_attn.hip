@@ -101,86 +101,103 @@ __device__ __forceinline__ uint4 load_chunk(const AttnParams &p, int which, int 
 // tile): th value is one LDS word per tile, tw lives in 16 registers;  MODE 2: no positional bias.
 //   Kl : K image of the tile [64][KROW];  Vl : V image of the tile [64][VROW] (row-major, read with
 //   ds_read_b64_tr_b16: lane c of a 16-lane group receives column c of a 4-key block).
-template <int HD, int MODE>
+// NS query strips (16 queries each) are processed against the same K / V fragments: every LDS operand read
+// feeds NS MFMAs.
+template <int HD, int NS>
+struct StripState {
+  bf16x8 qf[NS][Cfg<HD>::KS];
+  float twr[NS][16];
+  float m_run[NS], l_run[NS];
+  f32x4 oacc[NS][Cfg<HD>::DT];
+  const float *th[NS], *tw[NS];
+  int qy[NS], qx[NS];
+};
+
+template <int HD, int MODE, int NS>
 __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl, const u16 *Vl, int key0,
-                                             const bf16x8 (&qf)[Cfg<HD>::KS], const float *th, const float *tw,
-                                             int qy, int qx, float thv, const float (&twr)[16], float &m_run,
-                                             float &l_run, f32x4 (&oacc)[Cfg<HD>::DT], int lane) {
+                                             StripState<HD, NS> &st, const float (&thv)[NS], int lane) {
   using C = Cfg<HD>;
   const int g = lane >> 4, c = lane & 15;
-  float s[4][4];
+  float s[NS][4][4];
 #pragma unroll
   for (int sub = 0; sub < 4; ++sub) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[NS];
+#pragma unroll
+    for (int n = 0; n < NS; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) {
       const bf16x8 a = *reinterpret_cast<const bf16x8 *>(Kl + (sub * 16 + c) * C::KROW + ks * 32 + g * 8);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], acc, 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < NS; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, st.qf[n][ks], acc[n], 0, 0, 0);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v = acc[r] * p.scale_log2;
-      if (MODE == 1) {
-        s[sub][r] = v + twr[sub * 4 + r];                 // thv (constant over the tile for this lane) is added to the max only
-      } else {
-        const int kk = key0 + sub * 16 + g * 4 + r;       // key slot of this score; query = lane & 15
-        if (MODE == 0) {
-          const int ky = div_S(p, kk), kx = kk - ky * p.S;
-          const int jh = min(max(qy - ky + p.S - 1, 0), p.LT - 1), jw = qx - kx + p.S - 1;
-          v += th[c * p.LT + jh] + tw[c * p.LT + jw];
+    for (int n = 0; n < NS; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[n][r] * p.scale_log2;
+        if (MODE == 1) {
+          s[n][sub][r] = v + st.twr[n][sub * 4 + r];      // thv (constant over the tile for this lane) joins the max only
+        } else {
+          const int kk = key0 + sub * 16 + g * 4 + r;     // key slot of this score; query = lane & 15
+          if (MODE == 0) {
+            const int ky = div_S(p, kk), kx = kk - ky * p.S;
+            const int jh = min(max(st.qy[n] - ky + p.S - 1, 0), p.LT - 1), jw = st.qx[n] - kx + p.S - 1;
+            v += st.th[n][c * p.LT + jh] + st.tw[n][c * p.LT + jw];
+          }
+          s[n][sub][r] = kk < p.T ? v : -1e30f;
         }
-        s[sub][r] = kk < p.T ? v : -1e30f;
       }
-    }
   }
-  float mx = s[0][0];
+  union PB { bf16x8 v; u16 h[8]; };
+  PB pb[NS][2];
 #pragma unroll
-  for (int sub = 0; sub < 4; ++sub)
+  for (int n = 0; n < NS; ++n) {
+    float mx = s[n][0][0];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[sub][r]);
-  mx = fmaxf(mx, __shfl_xor(mx, 16));
-  mx = fmaxf(mx, __shfl_xor(mx, 32));
-  if (MODE == 1) mx += thv;                               // true score maximum of the tile
-  // deferred rescaling: keep the old running max while no query's max grew by more than 2^kDefer
-  // (P stays <= 2^kDefer, exact in bf16's exponent range); the O / l rescale is skipped on those tiles.
-  constexpr float kDefer = 6.0f;
-  const bool grow = __any(mx - m_run > kDefer);
-  const float m_new = grow ? fmaxf(m_run, mx) : m_run;
-  const float m_sub = (MODE == 1) ? m_new - thv : m_new;  // exp2(s + thv - m_new) = exp2(s - (m_new - thv))
-  float psum = 0.f;
+    for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-  for (int sub = 0; sub < 4; ++sub)
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[n][sub][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (MODE == 1) mx += thv[n];                          // true score maximum of the tile
+    // deferred rescaling: keep the old running max while no query's max grew by more than 2^kDefer
+    // (P stays <= 2^kDefer, exact in bf16's exponent range); the O / l rescale is skipped on those tiles.
+    constexpr float kDefer = 6.0f;
+    const bool grow = __any(mx - st.m_run[n] > kDefer);
+    const float m_new = grow ? fmaxf(st.m_run[n], mx) : st.m_run[n];
+    const float m_sub = (MODE == 1) ? m_new - thv[n] : m_new;
+    float psum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      s[sub][r] = fast_exp2(s[sub][r] - m_sub);
-      psum += s[sub][r];
+    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = fast_exp2(s[n][sub][r] - m_sub);
+        psum += e;
+        pb[n][sub >> 1].h[(sub & 1) * 4 + r] = f2bf(e);
+      }
+    psum += __shfl_xor(psum, 16);
+    psum += __shfl_xor(psum, 32);
+    if (grow) {                                           // wave-uniform
+      const float alpha = fast_exp2(st.m_run[n] - m_new);
+      st.l_run[n] *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) st.oacc[n][dt] *= alpha;
+      st.m_run[n] = m_new;
     }
-  psum += __shfl_xor(psum, 16);
-  psum += __shfl_xor(psum, 32);
-  if (grow) {                                       // wave-uniform
-    const float alpha = fast_exp2(m_run - m_new);
-    l_run *= alpha;
-#pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt) oacc[dt] *= alpha;
-    m_run = m_new;
+    st.l_run[n] += psum;
   }
-  l_run += psum;
   // O^T += V^T P^T: k-step j covers keys [32j, 32j+32); MFMA k-index e<4 -> key 32j+g*4+e, e>=4 -> 32j+16+g*4+(e-4)
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    union { bf16x8 v; u16 h[8]; } pb;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      pb.h[e] = f2bf(s[2 * j][e]);
-      pb.h[4 + e] = f2bf(s[2 * j + 1][e]);
-    }
     const u16 *vrow = Vl + (32 * j + g * 4 + (c >> 2)) * C::VROW + (c & 3) * 4;
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) {
       union { bf16x8 v; s16x4 q[2]; } va;
       va.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + dt * 16));
       va.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + 16 * C::VROW + dt * 16));
-      oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va.v, pb.v, oacc[dt], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < NS; ++n)
+        st.oacc[n][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va.v, pb[n][j].v, st.oacc[n][dt], 0, 0, 0);
     }
   }
 }
@@ -371,27 +388,136 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window_kernel(AttnParams p) {
   __syncthreads();
 
   const int nstrip = (p.T + 15) / 16;
-  const float twr[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int strip = wave; strip < nstrip; strip += WAVES) {
     const int q0 = strip * 16;
-    bf16x8 qf[C::KS];
-    load_q<HD>(p, b, wy, wx, head, q0, qf, lane);
+    StripState<HD, 1> st;
+    load_q<HD>(p, b, wy, wx, head, q0, st.qf[0], lane);
+    st.th[0] = th; st.tw[0] = tw;
     if (BIAS) {
       for (int jt = 0; jt < p.LT / 16; ++jt) {
-        build_table<HD, 1>(p.rel_h, jt * 16, 1, qf, th + jt * 16, p.LT, lane);
-        build_table<HD, 1>(p.rel_w, jt * 16, 1, qf, tw + jt * 16, p.LT, lane);
+        build_table<HD, 1>(p.rel_h, jt * 16, 1, st.qf[0], th + jt * 16, p.LT, lane);
+        build_table<HD, 1>(p.rel_w, jt * 16, 1, st.qf[0], tw + jt * 16, p.LT, lane);
       }
     }
     const int qi = min(q0 + (lane & 15), p.T - 1);
-    const int qy = div_S(p, qi), qx = qi - qy * p.S;
-    float m_run = -1e30f, l_run = 0.f;
-    f32x4 oacc[C::DT];
+    st.qy[0] = div_S(p, qi); st.qx[0] = qi - st.qy[0] * p.S;
+    st.m_run[0] = -1e30f; st.l_run[0] = 0.f;
 #pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 16; ++i) st.twr[0][i] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) st.oacc[0][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float thv[1] = {0.f};
     for (int t = 0; t < ntile; ++t)
-      process_tile<HD, MODE>(p, Kl + (size_t)t * 64 * C::KROW, Vl + (size_t)t * 64 * C::VROW, t * 64, qf, th, tw, qy,
-                             qx, 0.f, twr, m_run, l_run, oacc, lane);
-    store_strip<HD>(p, b, wy, wx, head, q0, l_run, oacc, lane);
+      process_tile<HD, MODE, 1>(p, Kl + (size_t)t * 64 * C::KROW, Vl + (size_t)t * 64 * C::VROW, t * 64, st, thv, lane);
+    store_strip<HD>(p, b, wy, wx, head, q0, st.l_run[0], st.oacc[0], lane);
+  }
+}
+
+// One pass of the row-padded window kernel: NS query rows (qy0, qy0 + rstride) against all key rows; the rows share
+// every K / V fragment read.  qf: Q fragments of the rows; tabs: NS x [rel_h | rel_w][16][32] floats of LDS.
+template <int HD, int NS>
+__device__ __forceinline__ void win16_pass(const AttnParams &p, const u16 *Kl, const u16 *Vl, int S, int SR, int b,
+                                           int wy, int wx, int head, int qy0, int rstride,
+                                           const bf16x8 (&qf)[NS][Cfg<HD>::KS], float *tabs, int lane) {
+  using C = Cfg<HD>;
+  const int g = lane >> 4, c = lane & 15;
+  const int Cc = p.nh * HD;
+  int qy[NS];
+  bool qimg[NS];
+  float twr[NS][4], m_run[NS], l_run[NS];
+  f32x4 oacc[NS][C::DT];
+  float *thn[NS];
+#pragma unroll
+  for (int n = 0; n < NS; ++n) {
+    qy[n] = qy0 + n * rstride;
+    const int y = wy * p.ws + qy[n], x = wx * p.ws + c;
+    qimg[n] = (qy[n] < S) && c < S && (y < p.H) && (x < p.W);
+    thn[n] = tabs + n * 2 * 16 * 32;
+    float *twn = thn[n] + 16 * 32;
+    build_table<HD, 2>(p.rel_h, 0, 1, qf[n], thn[n], 32, lane);
+    build_table<HD, 2>(p.rel_w, 0, 1, qf[n], twn, 32, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int kx = g * 4 + r;
+      twr[n][r] = kx < S ? twn[c * 32 + min(c - kx + S - 1, 31)] : -1e30f;
+    }
+    m_run[n] = -1e30f;
+    l_run[n] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) oacc[n][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    qy[n] = min(qy[n], S - 1);                                      // an out-of-window second row is computed but not stored
+  }
+  for (int u = 0; u < SR; u += 2) {                               // 32 keys = key rows u, u+1
+    float sc[NS][2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int ky = u + h;
+      f32x4 acc[NS];
+#pragma unroll
+      for (int n = 0; n < NS; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(Kl + (ky * 16 + c) * C::KROW + ks * 32 + g * 8);
+#pragma unroll
+        for (int n = 0; n < NS; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[n][ks], acc[n], 0, 0, 0);
+      }
+#pragma unroll
+      for (int n = 0; n < NS; ++n) {
+        const float thv = ky < S ? thn[n][c * 32 + (qy[n] - ky + S - 1)] : -1e30f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[n][h][r] = acc[n][r] * p.scale_log2 + thv + twr[n][r];
+      }
+    }
+    union PB { bf16x8 v; u16 hh[8]; };
+    PB pb[NS];
+    float alpha[NS];
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+      float mx = fmaxf(fmaxf(fmaxf(sc[n][0][0], sc[n][0][1]), fmaxf(sc[n][0][2], sc[n][0][3])),
+                       fmaxf(fmaxf(sc[n][1][0], sc[n][1][1]), fmaxf(sc[n][1][2], sc[n][1][3])));
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(fmaxf(m_run[n], mx), -1e29f);       // stays finite even if a whole row is padding
+      alpha[n] = fast_exp2(m_run[n] - m_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = fast_exp2(sc[n][h][r] - m_new);
+          psum += e;
+          pb[n].hh[h * 4 + r] = f2bf(e);
+        }
+      psum += __shfl_xor(psum, 16);
+      psum += __shfl_xor(psum, 32);
+      l_run[n] = l_run[n] * alpha[n] + psum;
+      m_run[n] = m_new;
+    }
+    const u16 *vrow = Vl + (u * 16 + g * 4 + (c >> 2)) * C::VROW + (c & 3) * 4;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) {
+      union { bf16x8 v; s16x4 q[2]; } va;
+      va.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + dt * 16));
+      va.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + 16 * C::VROW + dt * 16));
+#pragma unroll
+      for (int n = 0; n < NS; ++n)
+        oacc[n][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va.v, pb[n].v, oacc[n][dt] * alpha[n], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NS; ++n) {
+    if (qimg[n]) {
+      const int y = wy * p.ws + qy[n], x = wx * p.ws + c;
+      const float inv = 1.0f / l_run[n];
+      u16 *dst = p.out + ((size_t)(b * p.H + y) * p.W + x) * (size_t)Cc + head * HD;
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) {
+        union { uint2 u2; u16 hh[4]; } o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o.hh[r] = f2bf(oacc[n][dt][r] * inv);
+        *reinterpret_cast<uint2 *>(dst + dt * 16 + g * 4) = o.u2;
+      }
+    }
   }
 }
 
@@ -408,7 +534,8 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
   float *tabs = reinterpret_cast<float *>(Vl + (size_t)SR * 16 * C::VROW);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int g = lane >> 4, c = lane & 15;
-  float *th = tabs + (size_t)wave * 2 * 16 * 32, *tw = th + 16 * 32;
+  const int nset = S > WAVES ? 2 : 1;                              // a second query row per wave only exists if S > WAVES
+  float *th = tabs + (size_t)wave * nset * 2 * 16 * 32;           // [rows][rel_h | rel_w][16][32]
 
   int id = blockIdx.x;
   const int head = id % p.nh; id /= p.nh;
@@ -417,7 +544,8 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
   const int b = id;
   const int Cc = p.nh * HD;
   // Q fragments of every query row this wave owns are fetched first so their latency hides under the staging
-  constexpr int MAXROWS = (16 + WAVES - 1) / WAVES;
+  constexpr int MAXROWS = 2;                                      // rows (wave, wave + WAVES); WAVES >= 8 covers S <= 16
+  static_assert(2 * WAVES >= 16, "two rows per wave must cover 16 query rows");
   bf16x8 qfa[MAXROWS][C::KS];
 #pragma unroll
   for (int i = 0; i < MAXROWS; ++i) {
@@ -441,7 +569,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
   {
     constexpr int UN = 6;
     const int total = SR * 16 * (C::KPARTS + C::VPARTS);
-    for (int i0 = tid; i0 < total; i0 += UN * WAVES * 64) {
+    for (int i0 = tid; i0 < total && !(p.dbg & 1); i0 += UN * WAVES * 64) {
       uint4 v[UN];
       u16 *dst[UN];
 #pragma unroll
@@ -470,87 +598,26 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
   }
   __syncthreads();
 
-#pragma unroll
-  for (int i = 0; i < MAXROWS; ++i) {                             // one query row per strip; query column = c
-    const int qy = wave + i * WAVES;
-    if (qy >= S) break;
-    const int y = wy * p.ws + qy, x = wx * p.ws + c;
-    const bool qimg = c < S && (y < p.H) && (x < p.W);
-    const bf16x8 (&qf)[C::KS] = qfa[i];
-    build_table<HD, 2>(p.rel_h, 0, 1, qf, th, 32, lane);
-    build_table<HD, 2>(p.rel_w, 0, 1, qf, tw, 32, lane);
-    float twr[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int kx = g * 4 + r;
-      twr[r] = kx < S ? tw[c * 32 + min(c - kx + S - 1, 31)] : -1e30f;
+  // S <= WAVES: one query row per wave (TLP hides the LDS round trips); otherwise two rows per wave share
+  // every K / V fragment read: rows (wave, wave + WAVES).
+  if (S <= WAVES) {
+    if (wave < S && !(p.dbg & 2)) {
+      const bf16x8 (&q1)[1][C::KS] = reinterpret_cast<const bf16x8 (&)[1][C::KS]>(qfa[0]);
+      win16_pass<HD, 1>(p, Kl, Vl, S, SR, b, wy, wx, head, wave, WAVES, q1, th, lane);
     }
-    float m_run = -1e30f, l_run = 0.f;
-    f32x4 oacc[C::DT];
-#pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int u = 0; u < SR; u += 2) {                             // 32 keys = key rows u, u+1
-      float s[2][4];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int ky = u + h;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8 *>(Kl + (ky * 16 + c) * C::KROW + ks * 32 + g * 8);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], acc, 0, 0, 0);
-        }
-        const float thv = ky < S ? th[c * 32 + (qy - ky + S - 1)] : -1e30f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s[h][r] = acc[r] * p.scale_log2 + thv + twr[r];
-      }
-      float mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])),
-                       fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(fmaxf(m_run, mx), -1e29f);        // stays finite even if a whole row is padding
-      const float alpha = fast_exp2(m_run - m_new);
-      float psum = 0.f;
-      union { bf16x8 v; u16 hh[8]; } pb;
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = fast_exp2(s[h][r] - m_new);
-          psum += e;
-          pb.hh[h * 4 + r] = f2bf(e);
-        }
-      psum += __shfl_xor(psum, 16);
-      psum += __shfl_xor(psum, 32);
-      l_run = l_run * alpha + psum;
-      m_run = m_new;
-      const u16 *vrow = Vl + (u * 16 + g * 4 + (c >> 2)) * C::VROW + (c & 3) * 4;
-#pragma unroll
-      for (int dt = 0; dt < C::DT; ++dt) {
-        union { bf16x8 v; s16x4 q[2]; } va;
-        va.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + dt * 16));
-        va.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + 16 * C::VROW + dt * 16));
-        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va.v, pb.v, oacc[dt] * alpha, 0, 0, 0);
-      }
-    }
-    if (qimg) {
-      const float inv = 1.0f / l_run;
-      u16 *dst = p.out + ((size_t)(b * p.H + y) * p.W + x) * (size_t)Cc + head * HD;
-#pragma unroll
-      for (int dt = 0; dt < C::DT; ++dt) {
-        union { uint2 u2; u16 hh[4]; } o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o.hh[r] = f2bf(oacc[dt][r] * inv);
-        *reinterpret_cast<uint2 *>(dst + dt * 16 + g * 4) = o.u2;
-      }
-    }
+  } else if (!(p.dbg & 2)) {
+    static_assert(MAXROWS >= 2 || WAVES >= 16, "row bookkeeping");
+    const bf16x8 (&q2)[2][C::KS] = reinterpret_cast<const bf16x8 (&)[2][C::KS]>(qfa[0]);
+    win16_pass<HD, 2>(p, Kl, Vl, S, SR, b, wy, wx, head, wave, WAVES, q2, th, lane);
   }
 }
 
-// ---- global: one workgroup per (image, head, 64-query tile); KV tiles stream through a 2-deep LDS ring -----
+// ---- global: one workgroup per (image, head, 128-query tile); KV tiles stream through a 2-deep LDS ring -----
+// Each wave owns NS = 2 strips (32 queries): K/V fragments and every staged tile are shared by twice the math.
 template <int HD, int WAVES, int MODE>
 __global__ __launch_bounds__(WAVES * 64) void attn_global_kernel(AttnParams p) {
   using C = Cfg<HD>;
+  constexpr int NS = 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KBYTES = 64 * C::KROW * 2, VBYTES = 64 * C::VROW * 2;
   // ring slot r: K image at r*(KBYTES+VBYTES), V image right behind it
@@ -563,7 +630,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_global_kernel(AttnParams p) {
   // Workgroup -> (image, head, query tile).  All query tiles of one (image, head) re-read the same 1.3 MB of
   // K/V: keep them on ONE XCD (observed placement: block id % 8) so the re-reads hit that XCD's 4 MB L2
   // instead of streaming from HBM once per query tile.  Pure speed choice; any placement is correct.
-  const int nqt = (p.T + WAVES * 16 - 1) / (WAVES * 16);
+  const int nqt = (p.T + WAVES * 16 * NS - 1) / (WAVES * 16 * NS);
   int id = blockIdx.x;
   const int nbh = p.B * p.nh;
   int qt, bh;
@@ -576,58 +643,74 @@ __global__ __launch_bounds__(WAVES * 64) void attn_global_kernel(AttnParams p) {
     bh = id / nqt;
   }
   const int head = bh % p.nh, b = bh / p.nh;
-  const int q0 = (qt * WAVES + wave) * 16;
-  bf16x8 qf[C::KS];
-  load_q<HD>(p, b, 0, 0, head, q0, qf, lane);
-  const int qi = min(q0 + c, p.T - 1);
-  const int qy = div_S(p, qi), qx = qi - qy * p.S;
-  float twr[16];
+  StripState<HD, NS> st;
+  int q0[NS];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) twr[i] = 0.f;
-  float *th = nullptr, *tw = nullptr;
+  for (int n = 0; n < NS; ++n) {
+    q0[n] = ((qt * WAVES + wave) * NS + n) * 16;
+    load_q<HD>(p, b, 0, 0, head, q0[n], st.qf[n], lane);
+    const int qi = min(q0[n] + c, p.T - 1);
+    st.qy[n] = div_S(p, qi);
+    st.qx[n] = qi - st.qy[n] * p.S;
+    st.m_run[n] = -1e30f;
+    st.l_run[n] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st.twr[n][i] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) st.oacc[n][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    st.th[n] = nullptr;
+    st.tw[n] = nullptr;
+  }
+  float *thm[NS] = {nullptr, nullptr};
   if (MODE == 0) {
-    th = tabs + (size_t)wave * 2 * 16 * p.LT;
-    tw = th + 16 * p.LT;
-    for (int jt = 0; jt < p.LT / 16; ++jt) {
-      build_table<HD, 1>(p.rel_h, jt * 16, 1, qf, th + jt * 16, p.LT, lane);
-      build_table<HD, 1>(p.rel_w, jt * 16, 1, qf, tw + jt * 16, p.LT, lane);
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+      float *th = tabs + (size_t)(wave * NS + n) * 2 * 16 * p.LT, *tw = th + 16 * p.LT;
+      for (int jt = 0; jt < p.LT / 16; ++jt) {
+        build_table<HD, 1>(p.rel_h, jt * 16, 1, st.qf[n], th + jt * 16, p.LT, lane);
+        build_table<HD, 1>(p.rel_w, jt * 16, 1, st.qf[n], tw + jt * 16, p.LT, lane);
+      }
+      st.th[n] = th;
+      st.tw[n] = tw;
     }
   } else if (MODE == 1) {
-    // S == 64: the strip's 16 queries share qy (q0 % 16 == 0); tile t is key row ky = t.
+    // S == 64: a strip's 16 queries share qy (q0 % 16 == 0); tile t is key row ky = t.
     //   th[c][t] = rel_h[qy - t + 63] . q_c ;  tw needs rel_w[qx_c - kx + 63], qx_c = q0x + c: build
     //   G[c][jj] = rel_w[q0x + jj] . q_c (jj < 80) in scratch (aliases the ring, not yet in use) and gather.
-    th = tabs + (size_t)wave * 16 * 64;
-    float *G = reinterpret_cast<float *>(smem) + (size_t)wave * 16 * 80;
-    const int q0y = div_S(p, q0), q0x = q0 - q0y * p.S;
-    build_table<HD, 4>(p.rel_h, q0y + 63, -1, qf, th, 64, lane);
-    build_table<HD, 5>(p.rel_w, q0x, 1, qf, G, 80, lane);
 #pragma unroll
-    for (int sub = 0; sub < 4; ++sub)
+    for (int n = 0; n < NS; ++n) {
+      float *th = tabs + (size_t)(wave * NS + n) * 16 * 64;
+      float *G = reinterpret_cast<float *>(smem) + (size_t)wave * 16 * 80;      // per-wave scratch, reused by both strips
+      const int q0y = div_S(p, q0[n]), q0x = q0[n] - q0y * p.S;
+      build_table<HD, 4>(p.rel_h, q0y + 63, -1, st.qf[n], th, 64, lane);
+      build_table<HD, 5>(p.rel_w, q0x, 1, st.qf[n], G, 80, lane);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) twr[sub * 4 + r] = G[c * 80 + (c + 63 - (sub * 16 + g * 4 + r))];
+      for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st.twr[n][sub * 4 + r] = G[c * 80 + (c + 63 - (sub * 16 + g * 4 + r))];
+      thm[n] = th;
+    }
   }
-  float m_run = -1e30f, l_run = 0.f;
-  f32x4 oacc[C::DT];
-#pragma unroll
-  for (int dt = 0; dt < C::DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int ntile = p.T / 64;                       // launcher guarantees T % 64 == 0 for this kernel
-  StagerLinear<HD, WAVES * 64> st;
-  st.init(p, b, head, tid);
+  StagerLinear<HD, WAVES * 64> sg;
+  sg.init(p, b, head, tid);
   const size_t tstride = (size_t)64 * 3 * p.nh * HD;
-  st.load(tstride, 0);
+  sg.load(tstride, 0);
   __syncthreads();                                  // table scratch (aliasing the ring) fully consumed
-  st.store(Kbuf(0), Vbuf(0));
+  sg.store(Kbuf(0), Vbuf(0));
   __syncthreads();
   for (int t = 0; t < ntile; ++t) {
     const int cur = t & 1;
-    if (t + 1 < ntile && !(p.dbg & 1)) st.load(tstride, t + 1);            // flies under this tile's math
-    const float thv = (MODE == 1) ? th[c * 64 + t] : 0.f;
-    if (!(p.dbg & 2))
-      process_tile<HD, MODE>(p, Kbuf(cur), Vbuf(cur), t * 64, qf, th, tw, qy, qx, thv, twr, m_run, l_run, oacc, lane);
-    if (t + 1 < ntile) st.store(Kbuf(cur ^ 1), Vbuf(cur ^ 1));            // ring slot last read in iteration t-1
+    if (t + 1 < ntile && !(p.dbg & 1)) sg.load(tstride, t + 1);            // flies under this tile's math
+    float thv[NS];
+#pragma unroll
+    for (int n = 0; n < NS; ++n) thv[n] = (MODE == 1) ? thm[n][c * 64 + t] : 0.f;
+    if (!(p.dbg & 2)) process_tile<HD, MODE, NS>(p, Kbuf(cur), Vbuf(cur), t * 64, st, thv, lane);
+    if (t + 1 < ntile) sg.store(Kbuf(cur ^ 1), Vbuf(cur ^ 1));            // ring slot last read in iteration t-1
     __syncthreads();
   }
-  store_strip<HD>(p, b, 0, 0, head, q0, l_run, oacc, lane);
+#pragma unroll
+  for (int n = 0; n < NS; ++n) store_strip<HD>(p, b, 0, 0, head, q0[n], st.l_run[n], st.oacc[n], lane);
 }
 
 template <int HD>
@@ -635,9 +718,10 @@ static int launch_attn(AttnParams p, hipStream_t st) {
   using C = Cfg<HD>;
   const bool bias = p.rel_h != nullptr;
   if (p.ws > 0 && bias && p.S <= 16) {
-    constexpr int WAVES = 7;                                      // 14 query rows / 7 waves for the SAM window
+    constexpr int WAVES = 8;                                      // rows (wave, wave + 8): two query rows per wave share every
+                                                                  // K / V fragment read (measured: 8x2 rows 0.23 ms vs 14x1 rows 0.25 ms per 8 frames)
     const int SR = (p.S + 1) & ~1;
-    const size_t lds = (size_t)SR * 16 * (C::KROW + C::VROW) * 2 + (size_t)WAVES * 2 * 16 * 32 * 4;
+    const size_t lds = (size_t)SR * 16 * (C::KROW + C::VROW) * 2 + (size_t)WAVES * (p.S > WAVES ? 2 : 1) * 2 * 16 * 32 * 4;
     if (lds > 160 * 1024) return S6D_EUNSUPPORTED;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_window16_kernel<HD, WAVES>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -661,8 +745,9 @@ static int launch_attn(AttnParams p, hipStream_t st) {
   } else {
     if (p.T % 64 != 0) return S6D_EUNSUPPORTED;                  // global grids: 16x16, 32x32, 64x64 ...
     constexpr int WAVES = 4;
+    constexpr int NS = 2;
     const size_t ring = (size_t)2 * 64 * (C::KROW + C::VROW) * 2;
-    const int nqt = (p.T + WAVES * 16 - 1) / (WAVES * 16);
+    const int nqt = (p.T + WAVES * 16 * NS - 1) / (WAVES * 16 * NS);
     const unsigned grid = (unsigned)(p.B * p.nh * nqt);
 #define S6D_GLB(MODE, LDS)                                                                                     \
   do {                                                                                                         \
@@ -674,9 +759,9 @@ static int launch_attn(AttnParams p, hipStream_t st) {
     if (!bias) {
       S6D_GLB(2, ring);
     } else if (p.S == 64 && ring >= (size_t)WAVES * 16 * 80 * 4) {
-      S6D_GLB(1, ring + (size_t)WAVES * 16 * 64 * 4);
+      S6D_GLB(1, ring + (size_t)WAVES * NS * 16 * 64 * 4);
     } else {
-      S6D_GLB(0, ring + (size_t)WAVES * 2 * 16 * p.LT * 4);
+      S6D_GLB(0, ring + (size_t)WAVES * NS * 2 * 16 * p.LT * 4);
     }
 #undef S6D_GLB
   }
@@ -724,6 +809,28 @@ extern "C" int s6d_win_attention_bf16(const void *qkv, const void *qkv_bias, con
     p.rel_h = (const u16 *)rel_scratch;
     p.rel_w = p.rel_h + (size_t)rows * HDP;
   }
+  switch (head_dim) {
+    case 80: return launch_attn<80>(p, st);
+    case 64: return launch_attn<64>(p, st);
+    default: return S6D_EUNSUPPORTED;
+  }
+}
+
+extern "C" int s6d_seq_attention_bf16(const void *qkv, int B, int N, int num_heads, int head_dim, float scale, void *out,
+                                      void *stream) {
+  if (B < 0 || N <= 0 || num_heads <= 0) return S6D_EINVAL;
+  if (B == 0) return S6D_OK;
+  if (!qkv || !out) return S6D_EINVAL;
+  // a 1 x N "image" attended as ONE all-resident window of N key slots, no positional bias
+  AttnParams p;
+  p.qkv = (const u16 *)qkv; p.qkv_bias = (const u16 *)qkv;        // never read: every slot < N is in-image
+  p.rel_h = nullptr; p.rel_w = nullptr; p.out = (u16 *)out;
+  p.B = B; p.H = 1; p.W = N; p.nh = num_heads; p.ws = N;
+  p.S = N; p.T = N; p.nwx = 1; p.nwy = 1; p.LT = 16;
+  p.magicS = (unsigned)(((1ull << 32) + (unsigned)N - 1) / (unsigned)N);
+  p.scale_log2 = scale * kLog2e;
+  p.dbg = 0;
+  hipStream_t st = as_stream(stream);
   switch (head_dim) {
     case 80: return launch_attn<80>(p, st);
     case 64: return launch_attn<64>(p, st);

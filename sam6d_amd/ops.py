@@ -172,6 +172,17 @@ def window_attention(qkv, qkv_bias, rel_h, rel_w, num_heads, window, scale):
     return out
 
 
+def seq_attention(qkv, num_heads, scale):
+    """qkv (B,N,3C) bf16 -> (B,N,C) bf16: softmax(scale q k^T) v per head, no positional bias."""
+    _chk(qkv, torch.bfloat16, "qkv", 3)
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    out = torch.empty(B, N, C, dtype=torch.bfloat16, device=qkv.device)
+    _call("s6d_seq_attention_bf16", _ptr(qkv), B, N, int(num_heads), int(C // num_heads), ctypes.c_float(scale),
+          _ptr(out), _stream())
+    return out
+
+
 def add_layernorm(x, delta, gamma, beta, eps):
     """x (...,C) bf16, delta same shape or None, gamma/beta (C) f32 -> (x + delta, LN(x + delta)) bf16."""
     _chk(x, torch.bfloat16, "x")
@@ -322,7 +333,7 @@ def have(name):
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
                "pe_group": "s6d_pe_group_f32", "masked_depth_mean": "s6d_masked_depth_mean_f32",
-               "semantic_select": "s6d_semantic_select_f32", "project_bbox": "s6d_project_bbox_f32"}.get(name)
+               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "project_bbox": "s6d_project_bbox_f32"}.get(name)
         import os
         disabled = name in os.environ.get("S6D_DISABLE_FUSED", "").split(",")
         _FUSED[name] = (not disabled) and sym is not None and hasattr(_lib.lib(), sym)

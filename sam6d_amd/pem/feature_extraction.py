@@ -96,12 +96,49 @@ class ViT(nn.Module):
         d = len(self.blocks)
         n = d // 4
         taps = (d - 3 * n - 1, d - 2 * n - 1, d - n - 1, d - 1)
+        if x.is_cuda and x.dtype == torch.bfloat16 and ops.have("seq_attention") and ops.have("add_layernorm"):
+            return self._forward_fused(x, taps)
         out = []
         for i, blk in enumerate(self.blocks):
             x = blk(x)
             if i in taps:
                 out.append(self.norm(x))
         return out
+
+
+def _ln_f32(norm):
+    key = (norm.weight._version, norm.bias._version, norm.weight.data_ptr())
+    c = getattr(norm, "_s6d_f32", None)
+    if c is None or c[0] != key:
+        c = (key, norm.weight.detach().float().contiguous(), norm.bias.detach().float().contiguous())
+        norm._s6d_f32 = c
+    return c[1], c[2]
+
+
+def _vit_forward_fused(self, x, taps):
+    """bf16 pipeline on the gfx950 kernels: every residual add is folded into the next LayerNorm pass
+    (s6d_add_layernorm_bf16), attention runs in the fused MFMA kernel (s6d_seq_attention_bf16); the four
+    library GEMMs per block stay library GEMMs.  A tap is norm(x_i) of the residual stream after block i."""
+    x = x.contiguous()
+    delta = None
+    out = []
+    for i, blk in enumerate(self.blocks):
+        g, b = _ln_f32(blk.norm1)
+        x, h = ops.add_layernorm(x, delta, g, b, blk.norm1.eps)
+        qkv = blk.attn.qkv(h)
+        a = blk.attn.proj(ops.seq_attention(qkv.contiguous(), blk.attn.num_heads, (x.shape[-1] // blk.attn.num_heads) ** -0.5))
+        g, b = _ln_f32(blk.norm2)
+        x, h = ops.add_layernorm(x, a.contiguous(), g, b, blk.norm2.eps)
+        delta = blk.mlp(h).contiguous()
+        if i in taps:
+            g, b = _ln_f32(self.norm)
+            x, t = ops.add_layernorm(x, delta, g, b, self.norm.eps)
+            delta = None
+            out.append(t)
+    return out
+
+
+ViT._forward_fused = _vit_forward_fused
 
 
 class ViT_AE(nn.Module):
@@ -118,7 +155,7 @@ class ViT_AE(nn.Module):
         dt = _vit_dtype()
         if dt != torch.float32:
             with torch.autocast(device_type=x.device.type, dtype=dt):
-                taps = self.vit(x)
+                taps = self.vit(x.to(dt))
                 return self.output_upscaling(torch.cat([t[:, 1:] for t in taps], dim=2)).float()
         taps = self.vit(x)
         return self.output_upscaling(torch.cat([t[:, 1:] for t in taps], dim=2))

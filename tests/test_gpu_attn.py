@@ -71,3 +71,14 @@ def test_add_layernorm_bf16(rows, C):
     x2, y2 = ops.add_layernorm(x, None, w, b, 1e-6)
     assert x2 is x
     assert (y2.float() - torch.nn.functional.layer_norm(x.float(), (C,), w, b, 1e-6)).abs().max() < 2e-2
+
+
+@pytest.mark.parametrize("B,N,nh,hd", [(3, 197, 12, 64), (2, 50, 2, 80), (1, 257, 4, 64)])
+def test_seq_attention_vs_torch(B, N, nh, hd):
+    from sam6d_amd import ops
+    g = torch.Generator().manual_seed(N)
+    qkv = torch.randn(B, N, 3 * nh * hd, generator=g).cuda().to(torch.bfloat16)
+    out = ops.seq_attention(qkv, nh, hd ** -0.5).float()
+    q, k, v = qkv.float().view(B, N, 3, nh, hd).permute(2, 0, 3, 1, 4).unbind(0)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v).transpose(1, 2).reshape(B, N, nh * hd)
+    assert (out - ref).abs().max() < 3e-2 and (out - ref).abs().mean() < 3e-3

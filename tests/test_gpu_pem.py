@@ -84,3 +84,25 @@ def test_known_answer_vs_oracle_other_seeds(net, B, seed):
     a = metrics.add_recall(out["pred_R"].cpu(), out["pred_t"].cpu(), inp["gt_R"], inp["gt_t"], m, 0.2)
     b = metrics.add_recall(ref["pred_R"], ref["pred_t"], inp["gt_R"], inp["gt_t"], m, 0.2)
     assert torch.equal(a[1], b[1]) and a[0] == b[0]
+
+
+def test_bf16_vit_features_keep_the_pose(net, monkeypatch):
+    """bench.py runs the PEM ViT-B in bf16 (BASELINE config: bf16).  With template features taken from the same
+    (fp32) feature extractor, the matcher must recover the synthetic pose with either ViT precision, and the two
+    runs must agree within the parity tolerance."""
+    B = 4
+    inp = synth.pem_inputs(B, seed=77)
+    ep = {k: inp[k].cuda() for k in ("pts", "rgb", "rgb_choose", "model", "dense_po")}
+    with torch.no_grad():
+        monkeypatch.setenv("S6D_PEM_VIT_DTYPE", "fp32")
+        ep["dense_fo"] = net.feature_extraction.get_img_feats(ep["rgb"], ep["rgb_choose"])
+        ru = synth.coarse_uniforms(B, 78).cuda()
+        out32 = net(dict(ep, coarse_rand_u=ru))
+        monkeypatch.setenv("S6D_PEM_VIT_DTYPE", "bf16")
+        out16 = net(dict(ep, coarse_rand_u=ru))
+    gt = inp["gt_R"]
+    e32 = (out32["pred_R"].cpu() - gt).norm(dim=(1, 2))
+    e16 = (out16["pred_R"].cpu() - gt).norm(dim=(1, 2))
+    d = (out16["pred_R"] - out32["pred_R"]).norm(dim=(1, 2)).cpu()
+    assert e32.max() < 2e-3 and e16.max() < 2e-3 and d.max() < 2e-3, (e32, e16, d)
+    assert (out16["pred_t"] - out32["pred_t"]).abs().max().item() < 2e-4

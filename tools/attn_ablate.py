@@ -35,6 +35,7 @@ def run(B, H, nh, hd, ws, dbg, n=5):
 if __name__ == "__main__":
     for dbg in (0, 1, 2, 3):
         run(8, 64, 16, 80, 0, dbg)
-    run(8, 64, 16, 80, 14, 0)
+    for dbg in (0, 1, 2, 3):
+        run(8, 64, 16, 80, 14, dbg)
     run(1, 64, 16, 80, 0, 0)
     run(1, 64, 16, 80, 14, 0)

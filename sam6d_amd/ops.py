@@ -230,6 +230,22 @@ def fine_assign(atten, pts2):
     return pred, wsum, w1
 
 
+def pe_group_mlp(pts, idx, W0, b0, W1, b1, W2, b2):
+    """pts (B,N,3) f32, idx (B,N,ns) i32, folded MLP weights -> (B,N,128) f32 (max over neighbours)."""
+    _chk(pts, torch.float32, "pts", 3)
+    _chk(idx, torch.int32, "idx", 3)
+    ws = [w.contiguous() for w in (W0, b0, W1, b1, W2, b2)]
+    for w, shp in zip(ws, ((32, 6), (32,), (64, 32), (64,), (128, 64), (128,))):
+        _chk(w, torch.float32, "mlp weight")
+        if tuple(w.shape) != shp:
+            raise RuntimeError(f"SharedMLP [6,32,64,128] expected, got weight of shape {tuple(w.shape)}")
+    B, N, _ = pts.shape
+    out = torch.empty(B, N, 128, dtype=torch.float32, device=pts.device)
+    _call("s6d_pe_group_mlp_f32", _ptr(pts), _ptr(idx), B, N, int(idx.shape[2]), *[_ptr(w) for w in ws], _ptr(out),
+          _stream())
+    return out
+
+
 # ------------------------------------------------------------------ ISM scoring
 def pairwise_cosine(query, ref):
     """(P,C), (R,C) f32 -> (P,R) clamp(cos,0,1)."""
@@ -332,7 +348,7 @@ def have(name):
                "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "add_layernorm": "s6d_add_layernorm_bf16", "win_attention": "s6d_win_attention_bf16",
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
-               "pe_group": "s6d_pe_group_f32", "masked_depth_mean": "s6d_masked_depth_mean_f32",
+               "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_f32",
                "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "project_bbox": "s6d_project_bbox_f32"}.get(name)
         import os
         disabled = name in os.environ.get("S6D_DISABLE_FUSED", "").split(",")

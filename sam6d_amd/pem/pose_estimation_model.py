@@ -116,6 +116,10 @@ class PositionalEncoding(nn.Module):
         outs = []
         for mlp, (r, ns) in zip((self.mlp1, self.mlp2), self.scales):
             idx = ops.ball_query(pts, pts, r, ns)                                   # (B,N,ns) i32
+            if ops.have("pe_group") and pts.is_cuda and not self.training:
+                (W0, b0), (W1, b1), (W2, b2) = (layer.folded() for layer in mlp.layers())
+                outs.append(ops.pe_group_mlp(pts, idx, W0, b0, W1, b1, W2, b2))     # (B,N,128), nothing else hits HBM
+                continue
             nbr = ops.gather_rows(pts, idx.view(B, N * ns)).view(B, N, ns, 3)       # absolute xyz
             x = torch.cat([nbr - pts.unsqueeze(2), nbr], dim=-1)                    # (B,N,ns,6)
             for layer in mlp.layers():

@@ -124,3 +124,19 @@ def test_fine_assign_vs_oracle(ops, B, M):
     assert torch.equal(w, w1)
     assert (ws - wsum).abs().max() < 1e-5 * max(1.0, wsum.abs().max().item())
     assert (p - pred).abs().max() < 2e-5
+
+
+def test_positional_encoding_fused_vs_oracle(ops):
+    """Fused ball-query-group + SharedMLP + max kernel (exact-f32 MFMA chain) vs the reference PositionalEncoding."""
+    from sam6d_amd.pem.pose_estimation_model import PositionalEncoding
+    from sam6d_amd.utils import seeded
+    pe = PositionalEncoding(256).eval()
+    seeded.load_seeded(pe, 6)
+    W = {"PE." + k: v for k, v in pe.state_dict().items()}
+    inp = synth.pem_inputs(2, seed=9, with_rgb=False)
+    pts = inp["dense_po"] / (inp["dense_po"].norm(dim=2).max(1)[0].reshape(-1, 1, 1) + 1e-6)
+    with torch.no_grad():
+        ref = opem.positional_encoding(W, "PE", pts)
+        assert ops.have("pe_group")
+        out = pe.cuda()(pts.cuda()).cpu()
+    assert (out - ref).abs().max() < 5e-5, (out - ref).abs().max()

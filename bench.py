@@ -45,6 +45,23 @@ def parse():
     return ap.parse_args()
 
 
+def _use_tuned_library_gemms():
+    """Library GEMMs (qkv / proj / MLP of the ViTs) go through hipBLASLt via torch; pick the solutions recorded
+    by PyTorch TunableOp on this exact stack (profiles/tunableop_gfx950_sam_chunk8.csv: +7 % on the SAM stage,
+    59 s of tuning, done once offline).  Validators in the file pin torch / hipBLASLt / arch versions; on any
+    mismatch TunableOp silently falls back to the default heuristics.  No tuning happens inside the bench."""
+    path = os.path.join(ROOT, "profiles", "tunableop_gfx950_sam_chunk8.csv")
+    if os.environ.get("S6D_NO_TUNABLEOP") or not os.path.exists(path):
+        return
+    try:
+        import torch.cuda.tunable as tn
+        tn.enable(True)
+        tn.tuning_enable(False)
+        tn.read_file(path)
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench] TunableOp file not used: {e}", file=sys.stderr)
+
+
 class HotPath:
     """All device state of one rank: models, replicated template data, one batch of frames."""
 
@@ -55,6 +72,7 @@ class HotPath:
         from sam6d_amd.utils import seeded, synth
 
         os.environ.setdefault("S6D_PEM_VIT_DTYPE", "bf16")          # BASELINE configs[1]: bf16 (both ViTs run bf16)
+        _use_tuned_library_gemms()
         self.dev, self.F, self.chunk = device, frames, sam_chunk
         self.sam = seeded.load_seeded(build_vit_h().eval(), 3).to(device=device, dtype=torch.bfloat16)
         self.pem = seeded.load_seeded(pm.Net(pm.default_cfg()).eval(), 1).to(device)

@@ -80,15 +80,21 @@ class HotPath:
         self.ism_in = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in ism.items()}
         self.scorer = FrameScorer(self.ism_in["ref_cls"], self.ism_in["ref_patch"], self.ism_in["poses"],
                                   self.ism_in["pointcloud"])
-        self.sam_x = synth.sam_input(frames, 5, 1024).to(device=device, dtype=torch.bfloat16)
+        # 640x480 frames resized to long side 1024 (ResizeLongestSide, done by the caller) -> (3,768,1024) float RGB
+        g = torch.Generator().manual_seed(5)
+        self.sam_raw = (torch.rand(frames, 3, 768, 1024, generator=g) * 255).to(device)
         pin = synth.pem_inputs(frames, seed=1)
         self.pem_in = {k: pin[k].to(device) for k in ("pts", "rgb", "rgb_choose", "model", "dense_po", "dense_fo")}
         self.rand_u = synth.coarse_uniforms(frames, 2).to(device)
 
     @torch.no_grad()
     def sam_stage(self):
-        outs = [self.sam(self.sam_x[i:i + self.chunk]) for i in range(0, self.F, self.chunk)]
-        return outs[-1]
+        from sam6d_amd.sam.image_encoder import preprocess
+        out = None
+        for i in range(0, self.F, self.chunk):
+            x = preprocess(self.sam_raw[i:i + self.chunk], 1024, out_dtype=torch.bfloat16)     # a1: Sam.preprocess
+            out = self.sam(x)                                                                  # a2-a5
+        return out
 
     @torch.no_grad()
     def ism_stage(self):

@@ -193,6 +193,20 @@ int s6d_pe_group_mlp_f32(const float *pts, const int32_t *idx, int B, int N, int
                          const float *W1, const float *b1, const float *W2, const float *b2, float *out,
                          void *stream);
 
+/* Sam.preprocess: out[b,c,y,x] = (in[b,c,y,x] - mean[c]) / std[c] for y < h, x < w, else 0 (zero pad to S x S),
+ * written in the encoder's dtype (out_bf16 != 0: bf16, else f32).  in (B,3,h,w) f32; mean/std: 3 floats in HOST
+ * memory.  ref: segment_anything/modeling/sam.py:164-174. */
+int s6d_sam_preprocess_f32(const float *in, int B, int h, int w, int S, const float *mean3_host,
+                           const float *std3_host, int out_bf16, void *out, void *stream);
+
+/* Features of chosen pixels of the x4-upsampled feature map without materialising it.
+ * up (B, G*G, P*P, C) f32 = output_upscaling(tokens) before the pixel shuffle (G = 14 patches, P = 4, C = 256);
+ * choose (B,n) int64 pixel ids in the H x W image -> out (B,n,C) f32, bilinear (align_corners = False).
+ * ref: ViT_AE.forward, Pose_Estimation_Model/model/feature_extraction.py:111-114 + get_chosen_pixel_feats,
+ * utils/model_utils.py:69-81. */
+int s6d_upsample_gather_f32(const float *up, const int64_t *choose, int B, int n, int G, int P, int C, int H, int W,
+                            float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -146,6 +146,34 @@ def rpe_attention(q, k, v, qt, qb, embed, scale):
     return out
 
 
+# ------------------------------------------------------------------ edges of the path
+def sam_preprocess(x, mean, std, img_size, out_dtype=torch.bfloat16):
+    """(B,3,h,w) f32 -> (B,3,S,S) normalised + zero padded, in `out_dtype` (bf16 or f32).  [Sam.preprocess]"""
+    _chk(x, torch.float32, "x", 4)
+    B, C, h, w = x.shape
+    if C != 3:
+        raise RuntimeError("x must have 3 channels")
+    out = torch.empty(B, 3, img_size, img_size, dtype=out_dtype, device=x.device)
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    _call("s6d_sam_preprocess_f32", _ptr(x), B, h, w, int(img_size), m, s, 1 if out_dtype == torch.bfloat16 else 0,
+          _ptr(out), _stream())
+    return out
+
+
+def upsample_gather(up, choose, H, W, C):
+    """up (B,196,16*C) f32, choose (B,n) int64 -> (B,n,C): bilinear x4 of the pixel-shuffled map at chosen pixels."""
+    _chk(up, torch.float32, "up", 3)
+    _chk(choose, torch.int64, "choose", 2)
+    B, T, PC = up.shape
+    G = int(round(T ** 0.5))
+    P = int(round((PC // C) ** 0.5))
+    n = choose.shape[1]
+    out = torch.empty(B, n, C, dtype=torch.float32, device=up.device)
+    _call("s6d_upsample_gather_f32", _ptr(up), _ptr(choose), B, n, G, P, int(C), int(H), int(W), _ptr(out), _stream())
+    return out
+
+
 # ------------------------------------------------------------------ SAM image encoder
 def window_attention(qkv, qkv_bias, rel_h, rel_w, num_heads, window, scale):
     """qkv (B,H,W,3C) bf16, qkv_bias (3C) bf16, rel_h/rel_w (2S-1,hd) bf16 or None -> (B,H,W,C) bf16."""
@@ -349,7 +377,7 @@ def have(name):
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
                "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_f32",
-               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "project_bbox": "s6d_project_bbox_f32"}.get(name)
+               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "project_bbox": "s6d_project_bbox_f32"}.get(name)
         import os
         disabled = name in os.environ.get("S6D_DISABLE_FUSED", "").split(",")
         _FUSED[name] = (not disabled) and sym is not None and hasattr(_lib.lib(), sym)

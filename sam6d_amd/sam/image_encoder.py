@@ -245,6 +245,21 @@ class ImageEncoderViT(nn.Module):
         return self.neck_nhwc(self.forward_tokens(x)).to(in_dtype)
 
 
+PIXEL_MEAN = (123.675, 116.28, 103.53)      # build_sam.py:95-96
+PIXEL_STD = (58.395, 57.12, 57.375)
+
+
+def preprocess(x, img_size=1024, pixel_mean=PIXEL_MEAN, pixel_std=PIXEL_STD, out_dtype=None):
+    """Drop-in for ``Sam.preprocess`` (segment_anything/modeling/sam.py:164-174): normalise colours and zero-pad
+    to a square input, fused with the cast to the encoder's compute dtype.  x: (B,3,h,w) or (3,h,w) float."""
+    squeeze = x.dim() == 3
+    if squeeze:
+        x = x[None]
+    out_dtype = out_dtype or _dtype()
+    y = ops.sam_preprocess(x.float().contiguous(), pixel_mean, pixel_std, img_size, out_dtype)
+    return y[0] if squeeze else y
+
+
 def build_vit_h():
     """ViT-H configuration of segment_anything/build_sam.py:14-21,55-80."""
     from functools import partial

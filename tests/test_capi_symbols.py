@@ -1,0 +1,37 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol include/sam6d_hip.h declares
+(no compute calls: there is no GPU here)."""
+import ctypes
+
+from sam6d_amd import _lib
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = _lib.lib()
+    names = _lib.declared_symbols()
+    assert len(names) >= 25
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert L.s6d_version() >= 100
+    assert L.s6d_strerror(-1).decode().startswith("invalid argument")
+
+
+def test_argument_validation_without_a_gpu():
+    """Entry points validate sizes/pointers before touching the device: callable on a CPU-only host."""
+    L = _lib.lib()
+    L.s6d_fps_f32.restype = ctypes.c_int
+    assert L.s6d_fps_f32(None, 1, 0, 1, None, None, None) == -1          # N <= 0
+    assert L.s6d_fps_f32(None, 0, 10, 4, None, None, None) == 0           # B == 0: nothing to do
+    assert L.s6d_fps_f32(None, 1, 10, 4, None, None, None) == -1          # null pointers
+    L.s6d_rpe_attention_f32.restype = ctypes.c_int
+    assert L.s6d_rpe_attention_f32(None, None, None, None, None, None, 1, 197, 128, 4, ctypes.c_float(1.0), None, None) == -3
+
+
+def test_ops_refuse_cpu_tensors():
+    import pytest
+    import torch
+    from sam6d_amd import ops
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        ops.ball_query(torch.zeros(1, 4, 3), torch.zeros(1, 4, 3), 0.1, 4)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        ops.rpe_attention(*([torch.zeros(1, 4, 256)] * 3), torch.zeros(1, 4, 4, 256), torch.zeros(1, 4, 4),
+                          torch.zeros(1, 4, 4, 256), 0.125)

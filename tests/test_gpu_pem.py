@@ -106,3 +106,19 @@ def test_bf16_vit_features_keep_the_pose(net, monkeypatch):
     d = (out16["pred_R"] - out32["pred_R"]).norm(dim=(1, 2)).cpu()
     assert e32.max() < 2e-3 and e16.max() < 2e-3 and d.max() < 2e-3, (e32, e16, d)
     assert (out16["pred_t"] - out32["pred_t"]).abs().max().item() < 2e-4
+
+
+def test_upsample_gather_kernel_vs_dense_reference(net):
+    """Chosen-pixel features without the 224x224 map (fused kernel) == reference-shaped dense map + gather."""
+    from sam6d_amd import ops
+    assert ops.have("upsample_gather")
+    ae = net.feature_extraction.rgb_net
+    inp = synth.pem_inputs(2, seed=3)
+    g = torch.Generator().manual_seed(4)
+    choose = torch.randint(0, 224 * 224, (2, 2048), generator=g)
+    choose[:, :6] = torch.tensor([0, 223, 224 * 223, 224 * 224 - 1, 3, 224 * 3])      # borders / clamps
+    with torch.no_grad():
+        fm, _ = ae(inp["rgb"].cuda())
+        exp = torch.gather(fm.flatten(2), 2, choose.cuda().unsqueeze(1).expand(-1, 256, -1)).transpose(1, 2)
+        got = ae.sample(inp["rgb"].cuda(), choose.cuda())
+    assert torch.allclose(got, exp, atol=2e-5, rtol=1e-5), (got - exp).abs().max()

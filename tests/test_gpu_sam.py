@@ -56,3 +56,14 @@ def test_vit_h_two_blocks_and_full_vs_reference_golden(monkeypatch):
     smp = y.reshape(-1)[::251].numpy()
     assert np.corrcoef(smp, g["h_smp"])[0, 1] > 0.995, np.corrcoef(smp, g["h_smp"])[0, 1]
     assert np.abs(smp - g["h_smp"]).mean() < 5e-2
+
+
+def test_preprocess_matches_oracle():
+    from sam6d_amd.sam.image_encoder import preprocess
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(2, 3, 768, 1024, generator=g) * 255
+    ref = torch.stack([osam.preprocess(x[i]) for i in range(2)])
+    out32 = preprocess(x.cuda(), out_dtype=torch.float32).cpu()
+    assert out32.shape == (2, 3, 1024, 1024) and (out32 - ref).abs().max() < 1e-5
+    out16 = preprocess(x.cuda(), out_dtype=torch.bfloat16).float().cpu()
+    assert (out16 - ref).abs().max() < 2e-2 and (out16[:, :, 768:] == 0).all()

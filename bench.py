@@ -111,9 +111,28 @@ class HotPath:
         return self.pem(ep)
 
     def step(self):
-        self.sam_stage()
-        self.ism_stage()
-        out = self.pem_stage()
+        """One batch of frames through all three stages.  The stages of a batch are launched on three HIP streams:
+        in a running pipeline batch k's SAM encode overlaps batch k-1's scoring and pose estimation (the stages only
+        depend on each other through the previous batch's outputs), and the small launch-bound ISM / PEM kernels
+        fill the gaps between the SAM GEMMs.  Every stage still runs in full for every batch; the step ends when
+        all three streams have drained (S6D_BENCH_SERIAL=1 runs them back to back on one stream)."""
+        if os.environ.get("S6D_BENCH_SERIAL"):
+            self.sam_stage()
+            self.ism_stage()
+            out = self.pem_stage()
+        else:
+            if not hasattr(self, "_streams"):
+                self._streams = [torch.cuda.Stream(device=self.dev) for _ in range(2)]
+            cur = torch.cuda.current_stream()
+            for st in self._streams:
+                st.wait_stream(cur)
+            with torch.cuda.stream(self._streams[0]):
+                self.sam_stage()
+            with torch.cuda.stream(self._streams[1]):
+                self.ism_stage()
+            out = self.pem_stage()                      # current stream
+            for st in self._streams:
+                cur.wait_stream(st)
         # fixed-width pose record per instance (68 B, SURVEY 8e)
         from sam6d_amd.utils import shard
         return shard.pack_records(0, torch.arange(self.F, device=self.dev), 5, out["pred_pose_score"],

@@ -1,0 +1,90 @@
+"""Edge cases and BASELINE-size property checks on the GPU (empty / ragged inputs, maximum sizes, collisions)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ism as oism
+from oracle import pn2 as opn2
+from sam6d_amd.utils import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from sam6d_amd import ops
+    return ops
+
+
+def test_empty_batches_are_no_ops(ops):
+    dev = "cuda"
+    assert ops.furthest_point_sampling(torch.zeros(0, 16, 3, device=dev), 4).shape == (0, 4)
+    assert ops.ball_query(torch.zeros(0, 5, 3, device=dev), torch.zeros(0, 9, 3, device=dev), 0.1, 8).shape == (0, 5, 8)
+    assert ops.gather_rows(torch.zeros(2, 7, 4, device=dev), torch.zeros(2, 0, dtype=torch.int32, device=dev)).shape == (2, 0, 4)
+    assert ops.pairwise_cosine(torch.zeros(0, 1024, device=dev), torch.zeros(5, 1024, device=dev)).shape == (0, 5)
+    a, r = ops.patch_scores(torch.zeros(0, 256, 1024, device=dev), torch.zeros(1, 1, 256, 1024, device=dev),
+                            torch.zeros(0, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.int32, device=dev), 0.5)
+    assert a.shape == (0,) and r.shape == (0,)
+
+
+def test_fps_all_points_and_single_point(ops):
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(2, 130, 3, generator=g)
+    idx = ops.furthest_point_sampling(x.cuda(), 130).cpu()           # M == N: a permutation
+    assert torch.equal(idx, opn2.furthest_point_sampling(x, 130))
+    assert all(sorted(r.tolist()) == list(range(130)) for r in idx)
+    assert torch.equal(ops.furthest_point_sampling(x[:, :1].contiguous().cuda(), 1).cpu(), torch.zeros(2, 1, dtype=torch.int32))
+
+
+def test_ball_query_nsample_larger_than_cloud_and_coincident_points(ops):
+    x = torch.zeros(1, 40, 3)                                        # every point coincides: all in range
+    x[0, 20:] = 5.0
+    out = ops.ball_query(x.cuda(), x.cuda(), 0.1, 64).cpu()
+    assert torch.equal(out, opn2.ball_query(x, x, 0.1, 64))
+    assert (out[0, 0, :20] == torch.arange(20)).all() and (out[0, 0, 20:] == 0).all()     # first-hit fill
+
+
+def test_template_onboarding_size_fps(ops):
+    """210000 -> 2048 (42 views x 5000 px, feature_extraction.py:170-181): bit-exact at the maximum size."""
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(1, 210000, 3, generator=g)
+    assert torch.equal(ops.furthest_point_sampling(x.cuda(), 2048).cpu(), opn2.furthest_point_sampling(x, 2048))
+
+
+def test_tless_size_scoring_vs_oracle():
+    """BASELINE configs[3]: T-LESS, 30 objects x 42 templates, many proposals (P = 256)."""
+    from sam6d_amd.ism.scoring import FrameScorer
+    inp = synth.ism_inputs(P=256, O=30, T=42, seed=5)
+    ref = oism.score_frame(inp)
+    dev = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp.items()}
+    fs = FrameScorer(dev["ref_cls"], dev["ref_patch"], dev["poses"], dev["pointcloud"])
+    out = fs.score(dev["qry_cls"], dev["qry_patch"], dev["masks"], dev["boxes"], dev["depth"], dev["K"])
+    for k in ("sel", "pred_obj", "best_template"):
+        assert torch.equal(out[k].cpu().long(), ref[k].long()), k
+    for k, tol in (("semantic", 1e-5), ("appearance", 1e-5), ("visible_ratio", 1e-5)):
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k].numpy(), rtol=0, atol=tol, err_msg=k)
+    d = (out["image_uv"].cpu() - ref["image_uv"]).abs()
+    assert d.max() <= 1 and (d > 0).float().mean() < 1e-3
+
+
+def test_pem_batch32_properties():
+    """BASELINE configs[1] size (B = 32): rotations are proper, scores in [0,1], known answer recovered."""
+    from sam6d_amd.pem import pose_estimation_model as pm
+    from sam6d_amd.utils import seeded
+    net = seeded.load_seeded(pm.Net(pm.default_cfg()).eval(), 1).cuda()
+    B = 32
+    inp = synth.pem_inputs(B, seed=123, with_rgb=False)
+    radius = torch.norm(inp["dense_po"], dim=2).max(1)[0]
+    s = radius.reshape(-1, 1, 1) + 1e-6
+    ep = dict(model=inp["model"].cuda(), coarse_rand_u=synth.coarse_uniforms(B, 9).cuda())
+    with torch.no_grad():
+        out = net.match((inp["pts"] / s).cuda(), inp["dense_fm_kat"].cuda(), (inp["dense_po"] / s).cuda(),
+                        inp["dense_fo"].cuda(), radius.cuda(), ep)
+    R = out["pred_R"].cpu()
+    assert torch.allclose(R @ R.transpose(1, 2), torch.eye(3).expand(B, 3, 3), atol=1e-5)
+    assert torch.allclose(torch.det(R), torch.ones(B), atol=1e-5)
+    assert (R - inp["gt_R"]).norm(dim=(1, 2)).max() < 1e-3
+    assert (out["pred_t"].cpu() - inp["gt_t"]).abs().max() < 1e-4
+    sc = out["pred_pose_score"].cpu()
+    assert (sc >= 0).all() and (sc <= 1).all()

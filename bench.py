@@ -90,10 +90,26 @@ class HotPath:
     @torch.no_grad()
     def sam_stage(self):
         from sam6d_amd.sam.image_encoder import preprocess
+        nst = int(os.environ.get("S6D_SAM_STREAMS", "1"))   # measured: 1 = 2 > 4 streams (GEMMs already fill the GPU)
         out = None
-        for i in range(0, self.F, self.chunk):
-            x = preprocess(self.sam_raw[i:i + self.chunk], 1024, out_dtype=torch.bfloat16)     # a1: Sam.preprocess
-            out = self.sam(x)                                                                  # a2-a5
+        if nst <= 1:
+            for i in range(0, self.F, self.chunk):
+                x = preprocess(self.sam_raw[i:i + self.chunk], 1024, out_dtype=torch.bfloat16)     # a1: Sam.preprocess
+                out = self.sam(x)                                                                  # a2-a5
+            return out
+        # chunks alternate between HIP streams: one chunk's latency-bound attention / LayerNorm phases run under
+        # the other chunk's GEMMs
+        if not hasattr(self, "_sam_streams"):
+            self._sam_streams = [torch.cuda.Stream(device=self.dev) for _ in range(nst)]
+        cur = torch.cuda.current_stream()
+        for st in self._sam_streams:
+            st.wait_stream(cur)
+        for j, i in enumerate(range(0, self.F, self.chunk)):
+            with torch.cuda.stream(self._sam_streams[j % nst]):
+                x = preprocess(self.sam_raw[i:i + self.chunk], 1024, out_dtype=torch.bfloat16)
+                out = self.sam(x)
+        for st in self._sam_streams:
+            cur.wait_stream(st)
         return out
 
     @torch.no_grad()

@@ -207,6 +207,18 @@ int s6d_sam_preprocess_f32(const float *in, int B, int h, int w, int S, const fl
 int s6d_upsample_gather_f32(const float *up, const int64_t *choose, int B, int n, int G, int P, int C, int H, int W,
                             float *out, void *stream);
 
+/* Plain multi-head attention rows (no positional term): q (B,N,C), k, v (B,M,C) f32 projected, heads "(h c)" ->
+ * out (B,N,C).  C = 256, heads = 4.  ref: MultiHeadAttention.forward, Pose_Estimation_Model/model/transformer.py:93-148
+ * (the cross-attention of GeometricTransformer; no masks / factors on the inference path). */
+int s6d_mha_f32(const float *q, const float *k, const float *v, int B, int N, int M, int C, int heads, float scale,
+                float *out, void *stream);
+
+/* Focused linear attention feature map: t = (relu(x) + 1e-6) * inv_scale; y = t^p / |t^p| * |t| per row.
+ * x, y (rows,256) f32; inv_scale (256) = 1 / softplus(scale).  ref: LinearAttention.forward,
+ * Pose_Estimation_Model/model/transformer.py:536-547. */
+int s6d_linear_attn_focus_f32(const float *x, const float *inv_scale, long rows, int C, int power, float *y,
+                              void *stream);
+
 #ifdef __cplusplus
 }
 #endif

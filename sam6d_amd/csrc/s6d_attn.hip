@@ -124,11 +124,13 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
     f32x4 acc[NS];
 #pragma unroll
     for (int n = 0; n < NS; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!(p.dbg & 16)) {
 #pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8 *>(Kl + (sub * 16 + c) * C::KROW + ks * 32 + g * 8);
+      for (int ks = 0; ks < C::KS; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(Kl + (sub * 16 + c) * C::KROW + ks * 32 + g * 8);
 #pragma unroll
-      for (int n = 0; n < NS; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, st.qf[n][ks], acc[n], 0, 0, 0);
+        for (int n = 0; n < NS; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, st.qf[n][ks], acc[n], 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int n = 0; n < NS; ++n)
@@ -150,6 +152,14 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
   }
   union PB { bf16x8 v; u16 h[8]; };
   PB pb[NS][2];
+  if (p.dbg & 4) {                                          // ablation: no softmax arithmetic
+#pragma unroll
+    for (int n = 0; n < NS; ++n)
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pb[n][sub >> 1].h[(sub & 1) * 4 + r] = f2bf(s[n][sub][r]);
+  } else
 #pragma unroll
   for (int n = 0; n < NS; ++n) {
     float mx = s[n][0][0];
@@ -187,6 +197,11 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
     st.l_run[n] += psum;
   }
   // O^T += V^T P^T: k-step j covers keys [32j, 32j+32); MFMA k-index e<4 -> key 32j+g*4+e, e>=4 -> 32j+16+g*4+(e-4)
+  if (p.dbg & 8) {                                          // ablation: no PV (keep P live)
+#pragma unroll
+    for (int n = 0; n < NS; ++n) st.l_run[n] += (float)pb[n][0].h[0] + (float)pb[n][1].h[7];
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const u16 *vrow = Vl + (32 * j + g * 4 + (c >> 2)) * C::VROW + (c & 3) * 4;

@@ -16,14 +16,16 @@ __device__ __forceinline__ float dot4(const float4 a, const float4 b) {
   return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
 }
 
-template <int WAVES>
+// RPE == false: plain multi-head attention of N query rows over M keys (cross attention of the sparse
+// transformer, transformer.py:93-148): the same one-wave-per-query-row structure without the embedding stream.
+template <int WAVES, bool RPE>
 __global__ __launch_bounds__(WAVES * 64) void rpe_attention_kernel(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ qt, const float *__restrict__ qb, const float *__restrict__ embed,
-    int B, int N, float scale, float *__restrict__ out) {
+    int B, int N, int M, float scale, float *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int Np = (N + 3) & ~3;
+  const int Np = (M + 3) & ~3;
   float *sc = reinterpret_cast<float *>(smem) + (size_t)wave * 4 * Np;   // [4][Np] scores of this wave
   const long row = (long)blockIdx.x * WAVES + wave;                       // b*N + n
   if (row >= (long)B * N) return;                                         // whole wave exits together
@@ -32,33 +34,38 @@ __global__ __launch_bounds__(WAVES * 64) void rpe_attention_kernel(
   const int c4 = lane * 4;                                                // channels c4..c4+3 (head = c4/64 = g)
 
   const float4 q4 = *reinterpret_cast<const float4 *>(q + row * 256 + c4);
-  float4 t0, t1, t2, t3;                                                  // q~ of the four heads
-  {
+  float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0, t2 = t0, t3 = t0;  // q~ of the four heads
+  float qbg = 0.f;
+  const float *erow = nullptr;
+  if (RPE) {
     const float *base = qt + ((size_t)b * 4 * N + n) * 256 + c4;         // (B,4,N,256)
     t0 = *reinterpret_cast<const float4 *>(base);
     t1 = *reinterpret_cast<const float4 *>(base + (size_t)N * 256);
     t2 = *reinterpret_cast<const float4 *>(base + (size_t)2 * N * 256);
     t3 = *reinterpret_cast<const float4 *>(base + (size_t)3 * N * 256);
+    qbg = qb[((size_t)b * 4 + g) * N + n];
+    erow = embed + (size_t)row * M * 256 + c4;
   }
-  const float qbg = qb[((size_t)b * 4 + g) * N + n];
-  const float *erow = embed + (size_t)row * N * 256 + c4;
-  const float *krow = k + (size_t)b * N * 256 + c4;
-  const float *vrow = v + (size_t)b * N * 256 + c4;
+  const float *krow = k + (size_t)b * M * 256 + c4;
+  const float *vrow = v + (size_t)b * M * 256 + c4;
   const bool hi32 = lane & 32, hi16 = lane & 16;
 
   // ---- scores -------------------------------------------------------------------------------
-  for (int m = 0; m < N; ++m) {
-    const float4 e4 = *reinterpret_cast<const float4 *>(erow + (size_t)m * 256);
+  for (int m = 0; m < M; ++m) {
     const float4 k4 = *reinterpret_cast<const float4 *>(krow + (size_t)m * 256);
-    const float p0 = dot4(t0, e4), p1 = dot4(t1, e4), p2 = dot4(t2, e4), p3 = dot4(t3, e4);
-    // fold 4 partials -> 1: lanes 0-31 keep heads {0,1}, 32-63 keep {2,3}; then bit 4 picks one
-    float ka = hi32 ? p2 : p0, kb = hi32 ? p3 : p1;
-    const float sa = hi32 ? p0 : p2, sb = hi32 ? p1 : p3;
-    ka += __shfl_xor(sa, 32);
-    kb += __shfl_xor(sb, 32);
-    float mine = hi16 ? kb : ka;
-    const float send = hi16 ? ka : kb;
-    mine += __shfl_xor(send, 16);
+    float mine = 0.f;
+    if (RPE) {
+      const float4 e4 = *reinterpret_cast<const float4 *>(erow + (size_t)m * 256);
+      const float p0 = dot4(t0, e4), p1 = dot4(t1, e4), p2 = dot4(t2, e4), p3 = dot4(t3, e4);
+      // fold 4 partials -> 1: lanes 0-31 keep heads {0,1}, 32-63 keep {2,3}; then bit 4 picks one
+      float ka = hi32 ? p2 : p0, kb = hi32 ? p3 : p1;
+      const float sa = hi32 ? p0 : p2, sb = hi32 ? p1 : p3;
+      ka += __shfl_xor(sa, 32);
+      kb += __shfl_xor(sb, 32);
+      mine = hi16 ? kb : ka;
+      const float send = hi16 ? ka : kb;
+      mine += __shfl_xor(send, 16);
+    }
     mine += dot4(q4, k4);                       // q.k for this lane's head (channels of head g)
     mine += __shfl_xor(mine, 8);
     mine += __shfl_xor(mine, 4);
@@ -69,13 +76,13 @@ __global__ __launch_bounds__(WAVES * 64) void rpe_attention_kernel(
   __builtin_amdgcn_wave_barrier();
   // ---- softmax over keys, per head (16 lanes per head) ---------------------------------------
   float mx = -3.4e38f;
-  for (int m = lane & 15; m < N; m += 16) mx = fmaxf(mx, sc[g * Np + m]);
+  for (int m = lane & 15; m < M; m += 16) mx = fmaxf(mx, sc[g * Np + m]);
   mx = fmaxf(mx, __shfl_xor(mx, 8));
   mx = fmaxf(mx, __shfl_xor(mx, 4));
   mx = fmaxf(mx, __shfl_xor(mx, 2));
   mx = fmaxf(mx, __shfl_xor(mx, 1));
   float sum = 0.f;
-  for (int m = lane & 15; m < N; m += 16) {
+  for (int m = lane & 15; m < M; m += 16) {
     const float e = __expf(sc[g * Np + m] - mx);
     sc[g * Np + m] = e;
     sum += e;
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(WAVES * 64) void rpe_attention_kernel(
   __builtin_amdgcn_wave_barrier();
   // ---- P.V ------------------------------------------------------------------------------------
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int m = 0; m < N; ++m) {
+  for (int m = 0; m < M; ++m) {
     const float a = sc[g * Np + m];
     const float4 v4 = *reinterpret_cast<const float4 *>(vrow + (size_t)m * 256);
     acc.x += a * v4.x; acc.y += a * v4.y; acc.z += a * v4.z; acc.w += a * v4.w;
@@ -113,7 +120,62 @@ extern "C" int s6d_rpe_attention_f32(const float *q, const float *k, const float
   const int Np = (N + 3) & ~3;
   const size_t lds = (size_t)WAVES * 4 * Np * sizeof(float);
   if (lds > 64 * 1024) return S6D_EUNSUPPORTED;
-  hipLaunchKernelGGL((rpe_attention_kernel<WAVES>), dim3((unsigned)((rows + WAVES - 1) / WAVES)), dim3(WAVES * 64),
-                     lds, as_stream(stream), q, k, v, qt, qb, embed, B, N, scale, out);
+  hipLaunchKernelGGL((rpe_attention_kernel<WAVES, true>), dim3((unsigned)((rows + WAVES - 1) / WAVES)), dim3(WAVES * 64),
+                     lds, as_stream(stream), q, k, v, qt, qb, embed, B, N, N, scale, out);
+  return launch_status();
+}
+
+extern "C" int s6d_mha_f32(const float *q, const float *k, const float *v, int B, int N, int M, int C, int heads,
+                           float scale, float *out, void *stream) {
+  if (B < 0 || N <= 0 || M <= 0) return S6D_EINVAL;
+  if (C != 256 || heads != 4) return S6D_EUNSUPPORTED;
+  if (B == 0) return S6D_OK;
+  if (!q || !k || !v || !out) return S6D_EINVAL;
+  constexpr int WAVES = 4;
+  const long rows = (long)B * N;
+  const int Np = (M + 3) & ~3;
+  const size_t lds = (size_t)WAVES * 4 * Np * sizeof(float);
+  if (lds > 64 * 1024) return S6D_EUNSUPPORTED;
+  hipLaunchKernelGGL((rpe_attention_kernel<WAVES, false>), dim3((unsigned)((rows + WAVES - 1) / WAVES)), dim3(WAVES * 64),
+                     lds, as_stream(stream), q, k, v, nullptr, nullptr, nullptr, B, N, M, scale, out);
+  return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Focused-linear-attention feature map (LinearAttention.forward, transformer.py:536-547), one pass:
+//   t = (relu(x) + 1e-6) / softplus(scale);  y = t^p / |t^p| * |t|      (p = focusing_factor = 3)
+// The reference spends ~9 element-wise / reduction passes over (B,2048,256) per call.  One wave per row.
+__global__ __launch_bounds__(256) void focus_kernel(const float *__restrict__ x, const float *__restrict__ inv_scale,
+                                                    long rows, int p, float *__restrict__ y) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float4 a = *reinterpret_cast<const float4 *>(x + row * 256 + lane * 4);
+  const float4 is = *reinterpret_cast<const float4 *>(inv_scale + lane * 4);
+  float t[4] = {(fmaxf(a.x, 0.f) + 1e-6f) * is.x, (fmaxf(a.y, 0.f) + 1e-6f) * is.y, (fmaxf(a.z, 0.f) + 1e-6f) * is.z,
+                (fmaxf(a.w, 0.f) + 1e-6f) * is.w};
+  float n1 = t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
+  float u[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float r = t[e];
+    for (int i = 1; i < p; ++i) r *= t[e];
+    u[e] = r;
+  }
+  float n3 = u[0] * u[0] + u[1] * u[1] + u[2] * u[2] + u[3] * u[3];
+  n1 = wave_sum(n1);
+  n3 = wave_sum(n3);
+  const float f = sqrtf(n1) / sqrtf(n3);
+  *reinterpret_cast<float4 *>(y + row * 256 + lane * 4) = make_float4(u[0] * f, u[1] * f, u[2] * f, u[3] * f);
+}
+
+extern "C" int s6d_linear_attn_focus_f32(const float *x, const float *inv_scale, long rows, int C, int power, float *y,
+                                         void *stream) {
+  if (rows < 0 || power < 1) return S6D_EINVAL;
+  if (C != 256) return S6D_EUNSUPPORTED;
+  if (rows == 0) return S6D_OK;
+  if (!x || !inv_scale || !y) return S6D_EINVAL;
+  hipLaunchKernelGGL(focus_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), x, inv_scale, rows,
+                     power, y);
   return launch_status();
 }

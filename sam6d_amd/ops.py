@@ -274,6 +274,30 @@ def pe_group_mlp(pts, idx, W0, b0, W1, b1, W2, b2):
     return out
 
 
+def mha(q, k, v, scale):
+    """q (B,N,256), k/v (B,M,256) f32 -> (B,N,256): 4-head softmax attention, one wavefront per query row."""
+    q, k, v = (t.contiguous() for t in (q, k, v))
+    for a, nm in ((q, "q"), (k, "k"), (v, "v")):
+        _chk(a, torch.float32, nm, 3)
+    B, N, C = q.shape
+    out = torch.empty_like(q)
+    _call("s6d_mha_f32", _ptr(q), _ptr(k), _ptr(v), B, N, int(k.shape[1]), C, 4, ctypes.c_float(scale), _ptr(out),
+          _stream())
+    return out
+
+
+def linear_attn_focus(x, inv_scale, power):
+    """x (...,256) f32, inv_scale (256) -> focused feature map, same shape."""
+    x = x.contiguous()
+    _chk(x, torch.float32, "x")
+    inv_scale = inv_scale.reshape(-1).contiguous()
+    _chk(inv_scale, torch.float32, "inv_scale", 1)
+    y = torch.empty_like(x)
+    _call("s6d_linear_attn_focus_f32", _ptr(x), _ptr(inv_scale), ctypes.c_long(x.numel() // x.shape[-1]),
+          int(x.shape[-1]), int(power), _ptr(y), _stream())
+    return y
+
+
 # ------------------------------------------------------------------ ISM scoring
 def pairwise_cosine(query, ref):
     """(P,C), (R,C) f32 -> (P,R) clamp(cos,0,1)."""
@@ -377,7 +401,8 @@ def have(name):
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
                "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_f32",
-               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "project_bbox": "s6d_project_bbox_f32"}.get(name)
+               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "mha": "s6d_mha_f32",
+               "linear_attn_focus": "s6d_linear_attn_focus_f32", "project_bbox": "s6d_project_bbox_f32"}.get(name)
         import os
         disabled = name in os.environ.get("S6D_DISABLE_FUSED", "").split(",")
         _FUSED[name] = (not disabled) and sym is not None and hasattr(_lib.lib(), sym)

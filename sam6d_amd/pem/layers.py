@@ -55,6 +55,8 @@ class MultiHeadAttention(nn.Module):
         self.scale = 1.0 / math.sqrt(d_model // num_heads)
 
     def forward(self, xq, xk, xv):
+        if ops.have("mha") and xq.is_cuda and xq.shape[-1] == 256:
+            return ops.mha(self.proj_q(xq), self.proj_k(xk), self.proj_v(xv), self.scale)
         q, k, v = _split(self.proj_q(xq)), _split(self.proj_k(xk)), _split(self.proj_v(xv))
         a = torch.softmax((q @ k.transpose(-1, -2)) * self.scale, dim=-1)
         return _merge(a @ v)
@@ -168,8 +170,12 @@ class LinearAttention(nn.Module):
 
     def forward(self, xq, xkv):
         inv_scale = 1.0 / F.softplus(self.scale)
-        q = _split(self._focus(self.proj_q(xq), inv_scale))          # (B,h,I,c)
-        k = _split(self._focus(self.proj_k(xkv), inv_scale))         # (B,h,J,c)
+        if ops.have("linear_attn_focus") and xq.is_cuda and xq.shape[-1] == 256:
+            focus = lambda t: ops.linear_attn_focus(t, inv_scale, self.focusing_factor)   # noqa: E731  one fused pass
+        else:
+            focus = lambda t: self._focus(t, inv_scale)                                    # noqa: E731
+        q = _split(focus(self.proj_q(xq)))                           # (B,h,I,c)
+        k = _split(focus(self.proj_k(xkv)))                          # (B,h,J,c)
         v = _split(self.proj_v(xkv))
         z = 1.0 / (q @ k.sum(dim=2).unsqueeze(-1) + 1e-6)            # (B,h,I,1)
         kv = k.transpose(-1, -2) @ v                                 # (B,h,c,d)

@@ -140,3 +140,25 @@ def test_positional_encoding_fused_vs_oracle(ops):
         assert ops.have("pe_group")
         out = pe.cuda()(pts.cuda()).cpu()
     assert (out - ref).abs().max() < 5e-5, (out - ref).abs().max()
+
+
+def test_cross_attention_and_linear_attention_vs_oracle(ops):
+    """Fused MHA rows kernel and focused-feature-map kernel inside the product layers vs the oracle layers."""
+    from sam6d_amd.pem.layers import LinearTransformerLayer, TransformerLayer
+    from sam6d_amd.utils import seeded
+    g = torch.Generator().manual_seed(8)
+    x, mem = torch.randn(3, 197, 256, generator=g), torch.randn(3, 150, 256, generator=g)
+    tl = seeded.load_seeded(TransformerLayer(256).eval(), 5)
+    W = {"t." + k: v for k, v in tl.state_dict().items()}
+    with torch.no_grad():
+        ref = opem.cross_layer(W, "t", x, mem)
+        assert ops.have("mha") and ops.have("linear_attn_focus")
+        out = tl.cuda()(x.cuda(), mem.cuda()).cpu()
+    assert (out - ref).abs().max() < 2e-5
+    ll = seeded.load_seeded(LinearTransformerLayer(256).eval(), 6)
+    W = {"l." + k: v for k, v in ll.state_dict().items()}
+    xd, ms = torch.randn(2, 2048, 256, generator=g), torch.randn(2, 196, 256, generator=g)
+    with torch.no_grad():
+        ref = opem.linear_layer(W, "l", xd, ms)
+        out = ll.cuda()(xd.cuda(), ms.cuda()).cpu()
+    assert (out - ref).abs().max() < 5e-5, (out - ref).abs().max()

@@ -33,7 +33,7 @@ def run(B, H, nh, hd, ws, dbg, n=5):
 
 
 if __name__ == "__main__":
-    for dbg in (0, 1, 2, 3):
+    for dbg in (0, 1, 2, 3, 1 + 4, 1 + 8, 1 + 16, 1 + 4 + 8, 1 + 4 + 16, 1 + 8 + 16, 1 + 4 + 8 + 16):
         run(8, 64, 16, 80, 0, dbg)
     for dbg in (0, 1, 2, 3):
         run(8, 64, 16, 80, 14, dbg)

@@ -63,7 +63,9 @@ struct Cfg {
   static constexpr int HDP = KS * 32;           // padded head dim
   static constexpr int DT = HD / 16;            // 16-wide d tiles of the output
   static constexpr int KROW = HDP + 8;          // K image row stride (bf16 elements): +16 B pad
-  static constexpr int VROW = HD + 8;           // V image row stride (row-major [key][d]): +16 B pad
+  // V image row stride (row-major [key][d]): an ODD multiple of 16 elements (32 B), so the 8 key rows that one
+  // half-wave of a ds_read_b64_tr_b16 touches start on 8 distinct 32-byte bank groups (HD + 8 was 2-way conflicted)
+  static constexpr int VROW = (((HD + 15) / 16) | 1) * 16;
   static constexpr int KT = 64;                 // keys per tile
   static constexpr int KPARTS = HDP / 8, VPARTS = HD / 8;
 };
@@ -375,6 +377,29 @@ __device__ __forceinline__ void store_strip(const AttnParams &p, int b, int wy, 
   }
 }
 
+// Work item id -> (image, window, head).  All heads of a window read the same token rows (each head a 160-byte run
+// of every 7.7 KB row), so they should run on ONE XCD at about the same time: consecutive ids go round-robin over
+// the 8 XCDs (observed placement: id % 8), and an XCD's ids walk head-fastest through ITS windows -- the other heads'
+// halves of every cache line then hit that XCD's L2 instead of being fetched from HBM once per XCD.
+struct WinItem {
+  int b, wy, wx, head;
+  __device__ __forceinline__ void decode(const AttnParams &p, int id) {
+    const int nwin = p.B * p.nwy * p.nwx, cut = (nwin & ~7) * p.nh;
+    int win;
+    if (id < cut) {
+      const int xcd = id & 7, loc = id >> 3;
+      head = loc % p.nh;
+      win = (loc / p.nh) * 8 + xcd;
+    } else {
+      head = id % p.nh;
+      win = id / p.nh;
+    }
+    wx = win % p.nwx; win /= p.nwx;
+    wy = win % p.nwy; win /= p.nwy;
+    b = win;
+  }
+};
+
 // ---- windowed: one workgroup per (image, window, head); every key slot LDS resident ------------------------
 template <int HD, int WAVES, bool BIAS>
 __global__ __launch_bounds__(WAVES * 64) void attn_window_kernel(AttnParams p) {
@@ -388,11 +413,9 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window_kernel(AttnParams p) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   float *th = tabs + (size_t)wave * 2 * 16 * p.LT, *tw = th + 16 * p.LT;
 
-  int id = blockIdx.x;
-  const int head = id % p.nh; id /= p.nh;
-  const int wx = id % p.nwx; id /= p.nwx;
-  const int wy = id % p.nwy; id /= p.nwy;
-  const int b = id;
+  WinItem item;
+  item.decode(p, blockIdx.x);
+  const int head = item.head, wx = item.wx, wy = item.wy, b = item.b;
   {
     Stager<HD, WAVES * 64> st;
     for (int t = 0; t < ntile; ++t) {
@@ -430,100 +453,181 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window_kernel(AttnParams p) {
 
 // One pass of the row-padded window kernel: NS query rows (qy0, qy0 + rstride) against all key rows; the rows share
 // every K / V fragment read.  qf: Q fragments of the rows; tabs: NS x [rel_h | rel_w][16][32] floats of LDS.
-template <int HD, int NS>
-__device__ __forceinline__ void win16_pass(const AttnParams &p, const u16 *Kl, const u16 *Vl, int S, int SR, int b,
-                                           int wy, int wx, int head, int qy0, int rstride,
-                                           const bf16x8 (&qf)[NS][Cfg<HD>::KS], float *tabs, int lane) {
+// A window holds at most 16 key rows, so the whole score strip of a query row (SRC x 4 values per lane) stays in
+// registers: one pass of QK^T MFMAs, ONE max / sum exchange per query row, one pass of PV MFMAs -- no running
+// max, no rescale of the accumulators, no per-tile cross-lane round trips.  SRC = compile-time key-row count
+// (even); EXACT: S == SRC, nothing to mask but the kx >= S columns (carried by twr).
+// Per-query bias tables of NR query rows (qy0, qy0 + rstride): rel_h / rel_w dot q, through the wave's own LDS
+// scratch `tabs` (NR x [rel_h | rel_w][16][32] floats).  rel_w collapses to 4 registers per row (kx = g*4+r is fixed
+// per lane; out-of-window columns carry -1e30 there, which is the column mask).  Depends only on Q and the
+// position tables, so the kernel runs it while the K / V staging loads are in flight.
+template <int HD>
+struct RelFrags {                                                   // MFMA A fragments of the padded position tables, rows 0..31
+  union { uint4 u; bf16x8 v; } rh[2][Cfg<HD>::KS], rw[2][Cfg<HD>::KS];
+  __device__ __forceinline__ void load(const AttnParams &p, int lane) {
+    using C = Cfg<HD>;
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        rh[jt][ks].u = *reinterpret_cast<const uint4 *>(p.rel_h + (size_t)(jt * 16 + c) * C::HDP + ks * 32 + g * 8);
+        rw[jt][ks].u = *reinterpret_cast<const uint4 *>(p.rel_w + (size_t)(jt * 16 + c) * C::HDP + ks * 32 + g * 8);
+      }
+  }
+};
+
+constexpr int W16_LT = 36;   // scratch table row stride (floats): 144 B rows keep the float4 writes and the per-query
+                             // word reads (16 distinct rows per instruction) on distinct banks; 32 was 8-way conflicted
+
+// Bias registers of NR query rows: rel_w / rel_h dot q through the wave's own LDS scratch `tab` ([16][W16_LT]
+// floats, reused table after table: same-wave LDS operations execute in order).  Per lane (query c, group g):
+//   twr[n][r]  = log2e * rel_w[c - kx + S - 1] . q_c, kx = g*4 + r   (-1e30 for kx >= S: the column mask)
+//   thv[n][ky] = log2e * rel_h[qy_n - ky + S - 1] . q_c             (-1e30 for ky >= S: the row mask)
+// Depends only on Q and the position tables: the kernel runs it while the K / V staging loads are in flight.
+template <int HD, int NR, int SRC>
+__device__ __forceinline__ void win16_tables(const RelFrags<HD> &rf, int S, int qy0, int rstride,
+                                             const bf16x8 (*qf)[Cfg<HD>::KS], float *tab, float (*twr)[4],
+                                             float (*thv)[16], int lane) {
   using C = Cfg<HD>;
   const int g = lane >> 4, c = lane & 15;
-  const int Cc = p.nh * HD;
-  int qy[NS];
-  bool qimg[NS];
-  float twr[NS][4], m_run[NS], l_run[NS];
-  f32x4 oacc[NS][C::DT];
-  float *thn[NS];
 #pragma unroll
-  for (int n = 0; n < NS; ++n) {
-    qy[n] = qy0 + n * rstride;
-    const int y = wy * p.ws + qy[n], x = wx * p.ws + c;
-    qimg[n] = (qy[n] < S) && c < S && (y < p.H) && (x < p.W);
-    thn[n] = tabs + n * 2 * 16 * 32;
-    float *twn = thn[n] + 16 * 32;
-    build_table<HD, 2>(p.rel_h, 0, 1, qf[n], thn[n], 32, lane);
-    build_table<HD, 2>(p.rel_w, 0, 1, qf[n], twn, 32, lane);
+  for (int n = 0; n < NR; ++n) {
+    const int qy = min(qy0 + n * rstride, S - 1);                   // an out-of-window second row is computed, not stored
+    f32x4 ah[2], aw[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      ah[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      aw[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        aw[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rf.rw[jt][ks].v, qf[n][ks], aw[jt], 0, 0, 0);
+        ah[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rf.rh[jt][ks].v, qf[n][ks], ah[jt], 0, 0, 0);
+      }
+    }
+    // C layout: row jj = jt*16 + g*4 + r, col = query c
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+      *reinterpret_cast<float4 *>(tab + c * W16_LT + jt * 16 + g * 4) =
+          make_float4(aw[jt][0] * kLog2e, aw[jt][1] * kLog2e, aw[jt][2] * kLog2e, aw[jt][3] * kLog2e);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int kx = g * 4 + r;
-      twr[n][r] = kx < S ? twn[c * 32 + min(c - kx + S - 1, 31)] : -1e30f;
+      const float v = tab[c * W16_LT + min(max(c - kx + S - 1, 0), 31)];
+      twr[n][r] = (kx < S && c < S) ? v : -1e30f;
     }
-    m_run[n] = -1e30f;
-    l_run[n] = 0.f;
 #pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt) oacc[n][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    qy[n] = min(qy[n], S - 1);                                      // an out-of-window second row is computed but not stored
+    for (int jt = 0; jt < 2; ++jt)
+      *reinterpret_cast<float4 *>(tab + c * W16_LT + jt * 16 + g * 4) =
+          make_float4(ah[jt][0] * kLog2e, ah[jt][1] * kLog2e, ah[jt][2] * kLog2e, ah[jt][3] * kLog2e);
+#pragma unroll
+    for (int ky = 0; ky < SRC; ++ky) {
+      const float v = tab[c * W16_LT + min(max(qy - ky + S - 1, 0), 31)];
+      thv[n][ky] = ky < S ? v : -1e30f;
+    }
   }
-  for (int u = 0; u < SR; u += 2) {                               // 32 keys = key rows u, u+1
-    float sc[NS][2][4];
+}
+
+// One pass of the row-padded window kernel: NS query rows against all key rows; the rows share every K / V
+// fragment read.  A window holds at most 16 key rows, so a query row's whole score strip (SRC x 4 values per
+// lane) stays in registers and the softmax is exact two-pass, not online:
+//   A  S^T = K Q^T for every key row; s' = scale*acc + twr (one FMA), row maxima join a per-lane running max;
+//   B  one cross-lane exchange for the strip maximum;
+//   C  per 32-key step: P = exp2(s' - (m - thv)), then O^T += V^T P^T -- the V fragments of the step are requested
+//      before the exponentials so their LDS latency hides under them, and the MFMAs of step u run under the
+//      exponentials of step u+1.  The row sum comes from the matrix core too (an all-ones A fragment), so it is the
+//      sum of the SAME bf16-rounded P that multiplies V and costs no VALU adds or lane exchanges.
+// SRC = compile-time key-row count (even); EXACT: S == SRC (no unstaged key rows to skip).
+template <int HD, int NS, int SRC, bool EXACT>
+__device__ __forceinline__ void win16_pass(const AttnParams &p, const u16 *Kl, const u16 *Vl, int S, int SR, int b,
+                                           int wy, int wx, int head, int qy0, int rstride,
+                                           const bf16x8 (&qf)[NS][Cfg<HD>::KS], const float (*twr)[4],
+                                           const float (*thv)[16], int lane) {
+  using C = Cfg<HD>;
+  const int g = lane >> 4, c = lane & 15;
+  const int Cc = p.nh * HD;
+  // ---- A: scores of every key row: S^T[key row ky][kx = g*4+r][query c] ----------------------------------
+  float sp[NS][SRC][4], m[NS];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int ky = u + h;
-      f32x4 acc[NS];
+  for (int n = 0; n < NS; ++n) m[n] = -1e29f;                     // finite even if a whole strip is padding
+  bf16x8 kf[2][C::KS];
+  auto kload = [&](int ky, bf16x8 (&dst)[C::KS]) {
+    const int kyc = EXACT ? ky : min(ky, SR - 1);                   // rows >= SR are not staged: re-read a staged one
 #pragma unroll
-      for (int n = 0; n < NS; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < C::KS; ++ks)
+      dst[ks] = *reinterpret_cast<const bf16x8 *>(Kl + (kyc * 16 + c) * C::KROW + ks * 32 + g * 8);
+  };
+  kload(0, kf[0]);
 #pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(Kl + (ky * 16 + c) * C::KROW + ks * 32 + g * 8);
+  for (int ky = 0; ky < SRC; ++ky) {
+    if (ky + 1 < SRC) kload(ky + 1, kf[(ky + 1) & 1]);
+    f32x4 acc[NS];
 #pragma unroll
-        for (int n = 0; n < NS; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[n][ks], acc[n], 0, 0, 0);
-      }
+    for (int n = 0; n < NS; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int n = 0; n < NS; ++n) {
-        const float thv = ky < S ? thn[n][c * 32 + (qy[n] - ky + S - 1)] : -1e30f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sc[n][h][r] = acc[n][r] * p.scale_log2 + thv + twr[n][r];
-      }
-    }
-    union PB { bf16x8 v; u16 hh[8]; };
-    PB pb[NS];
-    float alpha[NS];
-#pragma unroll
-    for (int n = 0; n < NS; ++n) {
-      float mx = fmaxf(fmaxf(fmaxf(sc[n][0][0], sc[n][0][1]), fmaxf(sc[n][0][2], sc[n][0][3])),
-                       fmaxf(fmaxf(sc[n][1][0], sc[n][1][1]), fmaxf(sc[n][1][2], sc[n][1][3])));
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(fmaxf(m_run[n], mx), -1e29f);       // stays finite even if a whole row is padding
-      alpha[n] = fast_exp2(m_run[n] - m_new);
-      float psum = 0.f;
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = fast_exp2(sc[n][h][r] - m_new);
-          psum += e;
-          pb[n].hh[h * 4 + r] = f2bf(e);
-        }
-      psum += __shfl_xor(psum, 16);
-      psum += __shfl_xor(psum, 32);
-      l_run[n] = l_run[n] * alpha[n] + psum;
-      m_run[n] = m_new;
-    }
-    const u16 *vrow = Vl + (u * 16 + g * 4 + (c >> 2)) * C::VROW + (c & 3) * 4;
-#pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt) {
-      union { bf16x8 v; s16x4 q[2]; } va;
-      va.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + dt * 16));
-      va.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + 16 * C::VROW + dt * 16));
+    for (int ks = 0; ks < C::KS; ++ks)
 #pragma unroll
       for (int n = 0; n < NS; ++n)
-        oacc[n][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va.v, pb[n].v, oacc[n][dt] * alpha[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ky & 1][ks], qf[n][ks], acc[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sp[n][ky][r] = acc[n][r] * p.scale_log2 + twr[n][r];
+      const float mk = fmaxf(fmaxf(sp[n][ky][0], sp[n][ky][1]), fmaxf(sp[n][ky][2], sp[n][ky][3])) + thv[n][ky];
+      m[n] = fmaxf(m[n], mk);
+    }
+  }
+  // ---- B: strip maximum ----------------------------------------------------------------------------------------
+#pragma unroll
+  for (int n = 0; n < NS; ++n) {
+    m[n] = fmaxf(m[n], __shfl_xor(m[n], 16));
+    m[n] = fmaxf(m[n], __shfl_xor(m[n], 32));
+  }
+  // ---- C: P and O^T = V^T P^T over 32-key steps (key rows u, u+1) -------------------------------------------
+  f32x4 oacc[NS][C::DT], lacc[NS];
+#pragma unroll
+  for (int n = 0; n < NS; ++n) {
+    lacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) oacc[n][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  union { bf16x8 v; u16 hh[8]; } ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones.hh[i] = 0x3F80;                // bf16 1.0
+#pragma unroll
+  for (int u = 0; u < SRC; u += 2) {
+    if (EXACT || u < SR) {                                          // wave-uniform; K / V rows >= SR are not staged
+      union { bf16x8 v; s16x4 q[2]; } va[C::DT];
+      const u16 *vrow = Vl + (u * 16 + g * 4 + (c >> 2)) * C::VROW + (c & 3) * 4;
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) {
+        va[dt].q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + dt * 16));
+        va[dt].q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + 16 * C::VROW + dt * 16));
+      }
+      union { bf16x8 v; u16 hh[8]; } pb[NS];
+#pragma unroll
+      for (int n = 0; n < NS; ++n)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float off = m[n] - thv[n][u + h];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pb[n].hh[h * 4 + r] = f2bf(fast_exp2(sp[n][u + h][r] - off));
+        }
+#pragma unroll
+      for (int n = 0; n < NS; ++n) lacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, pb[n].v, lacc[n], 0, 0, 0);
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+        for (int n = 0; n < NS; ++n)
+          oacc[n][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[dt].v, pb[n].v, oacc[n][dt], 0, 0, 0);
     }
   }
 #pragma unroll
   for (int n = 0; n < NS; ++n) {
-    if (qimg[n]) {
-      const int y = wy * p.ws + qy[n], x = wx * p.ws + c;
-      const float inv = 1.0f / l_run[n];
+    const int qy = qy0 + n * rstride;
+    const int y = wy * p.ws + qy, x = wx * p.ws + c;
+    if ((qy < S) && c < S && (y < p.H) && (x < p.W)) {
+      const float inv = 1.0f / lacc[n][0];                          // every row of the ones-product is the strip's row sum
       u16 *dst = p.out + ((size_t)(b * p.H + y) * p.W + x) * (size_t)Cc + head * HD;
 #pragma unroll
       for (int dt = 0; dt < C::DT; ++dt) {
@@ -549,14 +653,11 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
   float *tabs = reinterpret_cast<float *>(Vl + (size_t)SR * 16 * C::VROW);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int g = lane >> 4, c = lane & 15;
-  const int nset = S > WAVES ? 2 : 1;                              // a second query row per wave only exists if S > WAVES
-  float *th = tabs + (size_t)wave * nset * 2 * 16 * 32;           // [rows][rel_h | rel_w][16][32]
+  float *tab = tabs + (size_t)wave * 16 * W16_LT;                 // one [16][W16_LT] scratch table per wave
 
-  int id = blockIdx.x;
-  const int head = id % p.nh; id /= p.nh;
-  const int wx = id % p.nwx; id /= p.nwx;
-  const int wy = id % p.nwy; id /= p.nwy;
-  const int b = id;
+  WinItem item;
+  item.decode(p, blockIdx.x);
+  const int head = item.head, wx = item.wx, wy = item.wy, b = item.b;
   const int Cc = p.nh * HD;
   // Q fragments of every query row this wave owns are fetched first so their latency hides under the staging
   constexpr int MAXROWS = 2;                                      // rows (wave, wave + WAVES); WAVES >= 8 covers S <= 16
@@ -579,51 +680,78 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
       qfa[i][ks] = t.v;
     }
   }
-  // stage K and V of the whole window (bias vector for out-of-image slots, zeros for padding slots);
-  // UN independent 16-byte loads are in flight per thread before any is written to LDS
-  {
-    constexpr int UN = 6;
-    const int total = SR * 16 * (C::KPARTS + C::VPARTS);
-    for (int i0 = tid; i0 < total && !(p.dbg & 1); i0 += UN * WAVES * 64) {
-      uint4 v[UN];
-      u16 *dst[UN];
+  RelFrags<HD> rf;
+  rf.load(p, lane);
+  // stage K and V of the whole window (bias vector for out-of-image slots, zeros for padding slots): UN
+  // independent 16-byte loads per thread are in flight before any is written to LDS, and the first batch
+  // flies under the bias-table MFMAs (which need only Q and the position tables).
+  constexpr int UN = 10;
+  const int total = SR * 16 * (C::KPARTS + C::VPARTS);
+  uint4 sv[UN];
+  u16 *sdst[UN];
+  auto issue = [&](int i0) {
 #pragma unroll
-      for (int n = 0; n < UN; ++n) {
-        const int i = i0 + n * WAVES * 64;
-        const int iq = min(i, total - 1);
-        const bool isv = iq >= SR * 16 * C::KPARTS;
-        const int ii = isv ? iq - SR * 16 * C::KPARTS : iq;
-        const int parts = isv ? C::VPARTS : C::KPARTS;
-        const int slot = ii / parts, part = ii - slot * parts;
-        const int ky = slot >> 4, kx = slot & 15;
-        const int y = wy * p.ws + ky, x = wx * p.ws + kx;
-        dst[n] = (i < total) ? (isv ? Vl + slot * C::VROW + part * 8 : Kl + slot * C::KROW + part * 8) : nullptr;
-        const bool img = (y < p.H) && (x < p.W);
-        const int dc = part * 8 < HD ? part * 8 : HD - 8;
-        const size_t tokc = (size_t)(b * p.H + min(y, p.H - 1)) * p.W + min(x, p.W - 1);
-        const int sel = (isv ? 2 : 1) * Cc + head * HD + dc;
-        const u16 *src = img ? p.qkv + tokc * (size_t)(3 * Cc) + sel : p.qkv_bias + sel;
-        v[n] = *reinterpret_cast<const uint4 *>(src);
-        if (!(ky < S && kx < S && part * 8 < HD)) v[n] = make_uint4(0, 0, 0, 0);
-      }
+    for (int n = 0; n < UN; ++n) {
+      const int i = i0 + n * WAVES * 64;
+      const int iq = min(i, total - 1);
+      const bool isv = iq >= SR * 16 * C::KPARTS;
+      const int ii = isv ? iq - SR * 16 * C::KPARTS : iq;
+      const int parts = isv ? C::VPARTS : C::KPARTS;
+      const int slot = ii / parts, part = ii - slot * parts;
+      const int ky = slot >> 4, kx = slot & 15;
+      const int y = wy * p.ws + ky, x = wx * p.ws + kx;
+      sdst[n] = (i < total) ? (isv ? Vl + slot * C::VROW + part * 8 : Kl + slot * C::KROW + part * 8) : nullptr;
+      const bool img = (y < p.H) && (x < p.W);
+      const int dc = part * 8 < HD ? part * 8 : HD - 8;
+      const size_t tokc = (size_t)(b * p.H + min(y, p.H - 1)) * p.W + min(x, p.W - 1);
+      const int sel = (isv ? 2 : 1) * Cc + head * HD + dc;
+      const u16 *src = img ? p.qkv + tokc * (size_t)(3 * Cc) + sel : p.qkv_bias + sel;
+      sv[n] = *reinterpret_cast<const uint4 *>(src);
+      if (!(ky < S && kx < S && part * 8 < HD)) sv[n] = make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto commit = [&]() {
 #pragma unroll
-      for (int n = 0; n < UN; ++n)
-        if (dst[n]) *reinterpret_cast<uint4 *>(dst[n]) = v[n];
+    for (int n = 0; n < UN; ++n)
+      if (sdst[n]) *reinterpret_cast<uint4 *>(sdst[n]) = sv[n];
+  };
+  const bool stage = !(p.dbg & 1);
+  if (stage) issue(tid);
+  // bias registers; tables are instantiated for the key-row count the pass will use
+  float twr[MAXROWS][4], thv[MAXROWS][16];
+  if (!(p.dbg & 2)) {
+    if (S > WAVES) {
+      if (S == 14)
+        win16_tables<HD, 2, 14>(rf, S, wave, WAVES, qfa, tab, twr, thv, lane);
+      else
+        win16_tables<HD, 2, 16>(rf, S, wave, WAVES, qfa, tab, twr, thv, lane);
+    } else if (wave < S) {
+      win16_tables<HD, 1, 8>(rf, S, wave, WAVES, qfa, tab, twr, thv, lane);
+    }
+  }
+  if (stage) {
+    commit();
+    for (int i0 = tid + UN * WAVES * 64; i0 < total; i0 += UN * WAVES * 64) {
+      issue(i0);
+      commit();
     }
   }
   __syncthreads();
 
-  // S <= WAVES: one query row per wave (TLP hides the LDS round trips); otherwise two rows per wave share
-  // every K / V fragment read: rows (wave, wave + WAVES).
+  // S <= WAVES: one query row per wave; otherwise two rows per wave share every K / V fragment read:
+  // rows (wave, wave + WAVES).
   if (S <= WAVES) {
     if (wave < S && !(p.dbg & 2)) {
       const bf16x8 (&q1)[1][C::KS] = reinterpret_cast<const bf16x8 (&)[1][C::KS]>(qfa[0]);
-      win16_pass<HD, 1>(p, Kl, Vl, S, SR, b, wy, wx, head, wave, WAVES, q1, th, lane);
+      win16_pass<HD, 1, 8, false>(p, Kl, Vl, S, SR, b, wy, wx, head, wave, WAVES, q1, twr, thv, lane);
     }
   } else if (!(p.dbg & 2)) {
     static_assert(MAXROWS >= 2 || WAVES >= 16, "row bookkeeping");
     const bf16x8 (&q2)[2][C::KS] = reinterpret_cast<const bf16x8 (&)[2][C::KS]>(qfa[0]);
-    win16_pass<HD, 2>(p, Kl, Vl, S, SR, b, wy, wx, head, wave, WAVES, q2, th, lane);
+    if (S == 14) {
+      win16_pass<HD, 2, 14, true>(p, Kl, Vl, S, SR, b, wy, wx, head, wave, WAVES, q2, twr, thv, lane);
+    } else
+      win16_pass<HD, 2, 16, false>(p, Kl, Vl, S, SR, b, wy, wx, head, wave, WAVES, q2, twr, thv, lane);
   }
 }
 
@@ -736,7 +864,7 @@ static int launch_attn(AttnParams p, hipStream_t st) {
     constexpr int WAVES = 8;                                      // rows (wave, wave + 8): two query rows per wave share every
                                                                   // K / V fragment read (measured: 8x2 rows 0.23 ms vs 14x1 rows 0.25 ms per 8 frames)
     const int SR = (p.S + 1) & ~1;
-    const size_t lds = (size_t)SR * 16 * (C::KROW + C::VROW) * 2 + (size_t)WAVES * (p.S > WAVES ? 2 : 1) * 2 * 16 * 32 * 4;
+    const size_t lds = (size_t)SR * 16 * (C::KROW + C::VROW) * 2 + (size_t)WAVES * 16 * W16_LT * 4;
     if (lds > 160 * 1024) return S6D_EUNSUPPORTED;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_window16_kernel<HD, WAVES>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

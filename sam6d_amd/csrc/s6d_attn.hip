@@ -48,8 +48,15 @@ struct AttnParams {
   int LT;              // padded table length (multiple of 16, >= 2S-1)
   unsigned magicS;     // ceil(2^32 / S): n / S == umulhi(n, magicS) for n < 2^32 / S
   float scale_log2;    // softmax scale * log2(e): scores live in the exp2 domain
-  int dbg;             // ablation switches for profiling (S6D_ATTN_DBG): 1 = no K/V loads, 2 = no tile math
 };
+
+// Ablation switches for profiling are COMPILE-time (-DS6D_ATTN_ABLATE=mask through S6D_EXTRA_HIPCC_FLAGS): 1 = no K/V
+// loads, 2 = no tile math, 4 = no softmax arithmetic, 8 = no PV, 16 = no QK^T.  As run-time branches they cut the
+// tile loop into a dozen basic blocks and kept the scheduler from placing MFMAs beside the softmax VALU work.
+#ifndef S6D_ATTN_ABLATE
+#define S6D_ATTN_ABLATE 0
+#endif
+constexpr int kAbl = S6D_ATTN_ABLATE;
 
 constexpr float kLog2e = 1.4426950408889634f;
 // v_exp_f32 without the denormal-range fix-up of fast_exp2(): arguments here are <= 2^kDefer and tiny results may flush
@@ -109,7 +116,8 @@ template <int HD, int NS>
 struct StripState {
   bf16x8 qf[NS][Cfg<HD>::KS];
   float twr[NS][16];
-  float m_run[NS], l_run[NS];
+  float m_run[NS];
+  f32x4 lacc[NS];                          // running row sums: every element of lacc[n] is the sum for query lane & 15
   f32x4 oacc[NS][Cfg<HD>::DT];
   const float *th[NS], *tw[NS];
   int qy[NS], qx[NS];
@@ -126,7 +134,7 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
     f32x4 acc[NS];
 #pragma unroll
     for (int n = 0; n < NS; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!(p.dbg & 16)) {
+    if (!(kAbl & 16)) {
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
         const bf16x8 a = *reinterpret_cast<const bf16x8 *>(Kl + (sub * 16 + c) * C::KROW + ks * 32 + g * 8);
@@ -154,59 +162,72 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
   }
   union PB { bf16x8 v; u16 h[8]; };
   PB pb[NS][2];
-  if (p.dbg & 4) {                                          // ablation: no softmax arithmetic
+  if (kAbl & 4) {                                          // ablation: no softmax arithmetic
 #pragma unroll
     for (int n = 0; n < NS; ++n)
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
         for (int r = 0; r < 4; ++r) pb[n][sub >> 1].h[(sub & 1) * 4 + r] = f2bf(s[n][sub][r]);
-  } else
-#pragma unroll
-  for (int n = 0; n < NS; ++n) {
-    float mx = s[n][0][0];
-#pragma unroll
-    for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[n][sub][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    if (MODE == 1) mx += thv[n];                          // true score maximum of the tile
-    // deferred rescaling: keep the old running max while no query's max grew by more than 2^kDefer
-    // (P stays <= 2^kDefer, exact in bf16's exponent range); the O / l rescale is skipped on those tiles.
+  } else {
+    // deferred rescaling: keep the old running max while no query's max grew by more than 2^kDefer (P stays
+    // <= 2^kDefer, exact in bf16's exponent range); the O / l rescale is skipped on those tiles.  Both strips'
+    // decisions are taken first, so the (rare) rescale is ONE wave-uniform branch and the rest of the tile is
+    // straight-line code the scheduler can interleave with the MFMAs.
     constexpr float kDefer = 6.0f;
-    const bool grow = __any(mx - st.m_run[n] > kDefer);
-    const float m_new = grow ? fmaxf(st.m_run[n], mx) : st.m_run[n];
-    const float m_sub = (MODE == 1) ? m_new - thv[n] : m_new;
-    float psum = 0.f;
+    float mx[NS];
+    bool grow[NS], any_grow = false;
 #pragma unroll
-    for (int sub = 0; sub < 4; ++sub)
+    for (int n = 0; n < NS; ++n) {
+      float v = s[n][0][0];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = fast_exp2(s[n][sub][r] - m_sub);
-        psum += e;
-        pb[n][sub >> 1].h[(sub & 1) * 4 + r] = f2bf(e);
-      }
-    psum += __shfl_xor(psum, 16);
-    psum += __shfl_xor(psum, 32);
-    if (grow) {                                           // wave-uniform
-      const float alpha = fast_exp2(st.m_run[n] - m_new);
-      st.l_run[n] *= alpha;
+      for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-      for (int dt = 0; dt < C::DT; ++dt) st.oacc[n][dt] *= alpha;
-      st.m_run[n] = m_new;
+        for (int r = 0; r < 4; ++r) v = fmaxf(v, s[n][sub][r]);
+      v = fmaxf(v, __shfl_xor(v, 16));
+      v = fmaxf(v, __shfl_xor(v, 32));
+      if (MODE == 1) v += thv[n];                             // true score maximum of the tile
+      mx[n] = v;
+      grow[n] = __any(v - st.m_run[n] > kDefer);
+      any_grow |= grow[n];
     }
-    st.l_run[n] += psum;
-  }
-  // O^T += V^T P^T: k-step j covers keys [32j, 32j+32); MFMA k-index e<4 -> key 32j+g*4+e, e>=4 -> 32j+16+g*4+(e-4)
-  if (p.dbg & 8) {                                          // ablation: no PV (keep P live)
+    if (any_grow) {                                           // wave-uniform
 #pragma unroll
-    for (int n = 0; n < NS; ++n) st.l_run[n] += (float)pb[n][0].h[0] + (float)pb[n][1].h[7];
+      for (int n = 0; n < NS; ++n)
+        if (grow[n]) {
+          const float m_new = fmaxf(st.m_run[n], mx[n]);
+          const float alpha = fast_exp2(st.m_run[n] - m_new);
+          st.lacc[n] *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < C::DT; ++dt) st.oacc[n][dt] *= alpha;
+          st.m_run[n] = m_new;
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+      const float m_sub = (MODE == 1) ? st.m_run[n] - thv[n] : st.m_run[n];
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pb[n][sub >> 1].h[(sub & 1) * 4 + r] = f2bf(fast_exp2(s[n][sub][r] - m_sub));
+    }
+  }
+  // O^T += V^T P^T: k-step j covers keys [32j, 32j+32); MFMA k-index e<4 -> key 32j+g*4+e, e>=4 -> 32j+16+g*4+(e-4).
+  // The row sums ride the matrix core too: an all-ones A fragment makes every row of lacc the sum over keys of the
+  // SAME bf16-rounded P that multiplies V (no VALU adds, no lane exchange).
+  if (kAbl & 8) {                                          // ablation: no PV (keep P live)
+#pragma unroll
+    for (int n = 0; n < NS; ++n) st.lacc[n][0] += (float)pb[n][0].h[0] + (float)pb[n][1].h[7];
     return;
   }
+  union { bf16x8 v; u16 h[8]; } ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones.h[i] = 0x3F80;                  // bf16 1.0
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const u16 *vrow = Vl + (32 * j + g * 4 + (c >> 2)) * C::VROW + (c & 3) * 4;
+#pragma unroll
+    for (int n = 0; n < NS; ++n) st.lacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, pb[n][j].v, st.lacc[n], 0, 0, 0);
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) {
       union { bf16x8 v; s16x4 q[2]; } va;
@@ -270,8 +291,12 @@ struct StagerLinear {
   static constexpr int NV = (64 * C::VPARTS + THREADS - 1) / THREADS;
   uint4 k[NK], v[NV];
   const u16 *kp[NK], *vp[NV];
-  int ko[NK], vo[NV];                    // LDS element offsets (-1: surplus lane, nothing to store)
+  // LDS element offsets from the ring slot's K image.  Surplus lanes (chunk counts are not multiples of the
+  // workgroup size) store into the unused 16-byte pad that ends each K row, so every store is unconditional:
+  // exec-masked stores would cut the tile loop into extra basic blocks.
+  int ko[NK], vo[NV];
   bool kz[NK];                           // chunk lies in the zero padding of the head dim
+  static_assert(Cfg<HD>::KROW - Cfg<HD>::HDP == 8, "K rows end in a 16-byte pad");
 
   __device__ __forceinline__ void init(const AttnParams &p, int b, int head, int tid) {
     const int Cc = p.nh * HD;
@@ -281,14 +306,14 @@ struct StagerLinear {
       const int key = ic / C::KPARTS, part = ic - key * C::KPARTS;
       kz[n] = part * 8 >= HD;
       kp[n] = p.qkv + ((size_t)b * p.T + key) * (size_t)(3 * Cc) + Cc + head * HD + (kz[n] ? HD - 8 : part * 8);
-      ko[n] = i < 64 * C::KPARTS ? key * C::KROW + part * 8 : -1;
+      ko[n] = i < 64 * C::KPARTS ? key * C::KROW + part * 8 : (tid & 63) * C::KROW + C::HDP;
     }
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
       const int i = tid + n * THREADS, ic = min(i, 64 * C::VPARTS - 1);
       const int key = ic / C::VPARTS, part = ic - key * C::VPARTS;
       vp[n] = p.qkv + ((size_t)b * p.T + key) * (size_t)(3 * Cc) + 2 * Cc + head * HD + part * 8;
-      vo[n] = i < 64 * C::VPARTS ? key * C::VROW + part * 8 : -1;
+      vo[n] = i < 64 * C::VPARTS ? 64 * C::KROW + key * C::VROW + part * 8 : (tid & 63) * C::KROW + C::HDP;
     }
   }
   __device__ __forceinline__ void load(size_t tile_stride_elems, int t) {
@@ -297,13 +322,11 @@ struct StagerLinear {
 #pragma unroll
     for (int n = 0; n < NV; ++n) v[n] = *reinterpret_cast<const uint4 *>(vp[n] + tile_stride_elems * t);
   }
-  __device__ __forceinline__ void store(u16 *Kl, u16 *Vl) const {
+  __device__ __forceinline__ void store(u16 *Kl) const {            // Kl: K image of the ring slot, V image right behind
 #pragma unroll
-    for (int n = 0; n < NK; ++n)
-      if (ko[n] >= 0) *reinterpret_cast<uint4 *>(Kl + ko[n]) = kz[n] ? make_uint4(0, 0, 0, 0) : k[n];
+    for (int n = 0; n < NK; ++n) *reinterpret_cast<uint4 *>(Kl + ko[n]) = kz[n] ? make_uint4(0, 0, 0, 0) : k[n];
 #pragma unroll
-    for (int n = 0; n < NV; ++n)
-      if (vo[n] >= 0) *reinterpret_cast<uint4 *>(Vl + vo[n]) = v[n];
+    for (int n = 0; n < NV; ++n) *reinterpret_cast<uint4 *>(Kl + vo[n]) = v[n];
   }
 };
 
@@ -439,7 +462,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window_kernel(AttnParams p) {
     }
     const int qi = min(q0 + (lane & 15), p.T - 1);
     st.qy[0] = div_S(p, qi); st.qx[0] = qi - st.qy[0] * p.S;
-    st.m_run[0] = -1e30f; st.l_run[0] = 0.f;
+    st.m_run[0] = -1e30f; st.lacc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 16; ++i) st.twr[0][i] = 0.f;
 #pragma unroll
@@ -447,7 +470,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window_kernel(AttnParams p) {
     const float thv[1] = {0.f};
     for (int t = 0; t < ntile; ++t)
       process_tile<HD, MODE, 1>(p, Kl + (size_t)t * 64 * C::KROW, Vl + (size_t)t * 64 * C::VROW, t * 64, st, thv, lane);
-    store_strip<HD>(p, b, wy, wx, head, q0, st.l_run[0], st.oacc[0], lane);
+    store_strip<HD>(p, b, wy, wx, head, q0, st.lacc[0][0], st.oacc[0], lane);
   }
 }
 
@@ -715,11 +738,11 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
     for (int n = 0; n < UN; ++n)
       if (sdst[n]) *reinterpret_cast<uint4 *>(sdst[n]) = sv[n];
   };
-  const bool stage = !(p.dbg & 1);
+  const bool stage = !(kAbl & 1);
   if (stage) issue(tid);
   // bias registers; tables are instantiated for the key-row count the pass will use
   float twr[MAXROWS][4], thv[MAXROWS][16];
-  if (!(p.dbg & 2)) {
+  if (!(kAbl & 2)) {
     if (S > WAVES) {
       if (S == 14)
         win16_tables<HD, 2, 14>(rf, S, wave, WAVES, qfa, tab, twr, thv, lane);
@@ -741,11 +764,11 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
   // S <= WAVES: one query row per wave; otherwise two rows per wave share every K / V fragment read:
   // rows (wave, wave + WAVES).
   if (S <= WAVES) {
-    if (wave < S && !(p.dbg & 2)) {
+    if (wave < S && !(kAbl & 2)) {
       const bf16x8 (&q1)[1][C::KS] = reinterpret_cast<const bf16x8 (&)[1][C::KS]>(qfa[0]);
       win16_pass<HD, 1, 8, false>(p, Kl, Vl, S, SR, b, wy, wx, head, wave, WAVES, q1, twr, thv, lane);
     }
-  } else if (!(p.dbg & 2)) {
+  } else if (!(kAbl & 2)) {
     static_assert(MAXROWS >= 2 || WAVES >= 16, "row bookkeeping");
     const bf16x8 (&q2)[2][C::KS] = reinterpret_cast<const bf16x8 (&)[2][C::KS]>(qfa[0]);
     if (S == 14) {
@@ -796,7 +819,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_global_kernel(AttnParams p) {
     st.qy[n] = div_S(p, qi);
     st.qx[n] = qi - st.qy[n] * p.S;
     st.m_run[n] = -1e30f;
-    st.l_run[n] = 0.f;
+    st.lacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 16; ++i) st.twr[n][i] = 0.f;
 #pragma unroll
@@ -840,20 +863,23 @@ __global__ __launch_bounds__(WAVES * 64) void attn_global_kernel(AttnParams p) {
   const size_t tstride = (size_t)64 * 3 * p.nh * HD;
   sg.load(tstride, 0);
   __syncthreads();                                  // table scratch (aliasing the ring) fully consumed
-  sg.store(Kbuf(0), Vbuf(0));
+  sg.store(Kbuf(0));
   __syncthreads();
-  for (int t = 0; t < ntile; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < ntile && !(p.dbg & 1)) sg.load(tstride, t + 1);            // flies under this tile's math
+  auto tile = [&](int t) {
     float thv[NS];
 #pragma unroll
     for (int n = 0; n < NS; ++n) thv[n] = (MODE == 1) ? thm[n][c * 64 + t] : 0.f;
-    if (!(p.dbg & 2)) process_tile<HD, MODE, NS>(p, Kbuf(cur), Vbuf(cur), t * 64, st, thv, lane);
-    if (t + 1 < ntile) sg.store(Kbuf(cur ^ 1), Vbuf(cur ^ 1));            // ring slot last read in iteration t-1
+    if (!(kAbl & 2)) process_tile<HD, MODE, NS>(p, Kbuf(t & 1), Vbuf(t & 1), t * 64, st, thv, lane);
+  };
+  for (int t = 0; t + 1 < ntile; ++t) {                           // steady state: branch-free body
+    if (!(kAbl & 1)) sg.load(tstride, t + 1);                     // flies under this tile's math
+    tile(t);
+    sg.store(Kbuf((t & 1) ^ 1));                                  // ring slot last read in iteration t-1
     __syncthreads();
   }
+  tile(ntile - 1);
 #pragma unroll
-  for (int n = 0; n < NS; ++n) store_strip<HD>(p, b, 0, 0, head, q0[n], st.l_run[n], st.oacc[n], lane);
+  for (int n = 0; n < NS; ++n) store_strip<HD>(p, b, 0, 0, head, q0[n], st.lacc[n][0], st.oacc[n], lane);
 }
 
 template <int HD>
@@ -939,10 +965,6 @@ extern "C" int s6d_win_attention_bf16(const void *qkv, const void *qkv_bias, con
   p.LT = ((2 * p.S - 1) + 15) / 16 * 16;
   p.magicS = (unsigned)(((1ull << 32) + (unsigned)p.S - 1) / (unsigned)p.S);
   p.scale_log2 = scale * kLog2e;
-  {
-    const char *e = getenv("S6D_ATTN_DBG");
-    p.dbg = e ? atoi(e) : 0;
-  }
   hipStream_t st = as_stream(stream);
   if (rel_h) {                                   // zero-padded table copies: unconditional loads in the kernels
     if (!rel_scratch) return S6D_EINVAL;
@@ -972,7 +994,6 @@ extern "C" int s6d_seq_attention_bf16(const void *qkv, int B, int N, int num_hea
   p.S = N; p.T = N; p.nwx = 1; p.nwy = 1; p.LT = 16;
   p.magicS = (unsigned)(((1ull << 32) + (unsigned)N - 1) / (unsigned)N);
   p.scale_log2 = scale * kLog2e;
-  p.dbg = 0;
   hipStream_t st = as_stream(stream);
   switch (head_dim) {
     case 80: return launch_attn<80>(p, st);

@@ -9,7 +9,7 @@ from sam6d_amd import ops  # noqa: E402
 
 
 def run(B, H, nh, hd, ws, dbg, n=5):
-    os.environ["S6D_ATTN_DBG"] = str(dbg)
+    # ablation masks are compile-time now: rebuild with S6D_EXTRA_HIPCC_FLAGS=-DS6D_ATTN_ABLATE=<dbg>
     g = torch.Generator().manual_seed(0)
     S = ws if ws else H
     qkv = torch.randn(B, H, H, 3 * nh * hd, generator=g).cuda().to(torch.bfloat16)

@@ -184,7 +184,7 @@ def kernel_rooflines(dev, sam_chunk, frames):
     """Per-launch roofline of the hand-written kernels at the exact shapes the step uses, timed with HIP events on
     torch's current stream (the stream every s6d_* kernel is launched on).  Algorithmic work per launch:
       attn_global   4*T^2*hd*nh*Bc FLOP (QK^T + PV), T = 4096, hd = 80, nh = 16, Bc = frames per SAM chunk
-      attn_window16 4*196^2*hd * 25 windows * nh * Bc FLOP
+      attn_window16 4*196^2*hd * 25 windows * nh * Bc FLOP; HBM-bound: Bc*4096 tokens * (3+1)*1280 * 2 bytes
       rpe_attention B*N * (N*256*4) bytes  (the geometric embedding is streamed exactly once), N = 197
       geo_embed     B*N*N * 4 embeddings * 2*256*256 FLOP (as written in the reference, fp32)
     Peaks: 2.5 PFLOP/s dense bf16 MFMA, 157.3 TFLOP/s fp32, 8.0 TB/s HBM (MI355X_MICROARCH.md)."""
@@ -200,9 +200,18 @@ def kernel_rooflines(dev, sam_chunk, frames):
         ms = _event_ms(lambda: ops.window_attention(qkv, bias, rh, rw, nh, ws, hd ** -0.5), 10)
         nwin = 1 if ws == 0 else 25
         flop = 4.0 * (S * S) ** 2 * hd * nwin * nh * sam_chunk
-        out.append({"kernel": name, "bound": "mfma", "achieved": round(flop / ms / 1e9, 1), "peak": 2500.0,
-                    "unit": "TFLOP/s", "frac": round(flop / ms / 1e9 / 2500.0, 4), "avg_ms": round(ms, 4),
-                    "launches_per_step": (4 if ws == 0 else 28) * (frames // sam_chunk)})
+        if ws == 0:
+            out.append({"kernel": name, "bound": "mfma", "achieved": round(flop / ms / 1e9, 1), "peak": 2500.0,
+                        "unit": "TFLOP/s", "frac": round(flop / ms / 1e9 / 2500.0, 4), "avg_ms": round(ms, 4),
+                        "launches_per_step": 4 * (frames // sam_chunk)})
+        else:
+            # 14x14 windows: 39 GFLOP against q,k,v read once + out written once = 117 FLOP/B, below the
+            # 2500/8 = 312 FLOP/B ridge -> the HBM roofline (42 us) binds, not the MFMA one (16 us)
+            nbytes = float(sam_chunk) * H * H * 4 * nh * hd * 2
+            out.append({"kernel": name, "bound": "hbm", "achieved": round(nbytes / ms / 1e6, 1), "peak": 8000.0,
+                        "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / 8000.0, 4), "avg_ms": round(ms, 4),
+                        "launches_per_step": 28 * (frames // sam_chunk),
+                        "mfma_tflops": round(flop / ms / 1e9, 1)})
     B, N = frames, 197
     q, k, v = (torch.randn(B, N, 256, generator=g).to(dev) for _ in range(3))
     qt = torch.randn(B, 4, N, 256, generator=g).to(dev)
@@ -241,7 +250,7 @@ def _pmc_traffic(kernel_name):
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
         for k, v in d.items():
-            if kernel_name.replace(" ", "").startswith(k.replace(" ", "")):
+            if kernel_name.split("<")[0] == k.split("<")[0]:
                 return v.get("hbm_bytes_per_launch")
     except Exception:
         pass

@@ -219,6 +219,18 @@ int s6d_mha_f32(const float *q, const float *k, const float *v, int B, int N, in
 int s6d_linear_attn_focus_f32(const float *x, const float *inv_scale, long rows, int C, int power, float *y,
                               void *stream);
 
+/* Proposal crops for the descriptor model, fused: normalise . mask . crop . nearest resize . zero pad . nearest resize.
+ * image (H,W,3) u8, masks (P,H,W) f32 {0,1}, params: P records of 12 int32 / float32 words
+ *   {x1, y1, h, w, h1, w1, top, left, S2, float inv1, float inv2, 0}
+ * (crop origin and size, size after the first resize, padding in front, padded square side, float(1/scale) of the two
+ * resizes -- the host mirrors the reference loop's double-precision size arithmetic).  out_rgb (P,3,T,T) and/or
+ * out_mask (P,T,T) f32, either may be NULL.  mean / std: 3 floats in HOST memory.  Bit-exact with the reference.
+ * ref: CustomDINOv2.process_rgb_proposals / process_masks_proposals, Instance_Segmentation_Model/model/dinov2.py:131-144,
+ * 178-189; CropResizePad.__call__, utils/bbox_utils.py:98-126 (+ torchvision ToTensor / Normalize, dinov2.py:115-120). */
+int s6d_crop_resize_pad_f32(const unsigned char *image, const float *masks, const void *params, int P, int H, int W,
+                            int T, const float *mean3_host, const float *std3_host, float *out_rgb, float *out_mask,
+                            void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,7 @@ PEM_CASE = dict(B=2, weight_seed=1, input_seed=1, rand_seed=7)
 SAM_MINI_CASE = dict(weight_seed=3, input_seed=5)
 SAM_H_CASE = dict(weight_seed=3, input_seed=5)
 ISM_CASE = dict(P=64, O=3, T=42, seed=11)
+DINO_CASE = dict(P=8, input_seed=4, weight_seed=6, mini_target=56, n_full=2)
 
 
 def digest(t, stride=97):
@@ -158,7 +159,66 @@ def gen_ism():
     print("selected", len(rec["sel"]), "iou", rec["iou"], "vr", rec["visible_ratio"][:5], "final", rec["final"][:5])
 
 
+def gen_dinov2():
+    """Reference CustomDINOv2 methods (crop pipeline + masked patch features) and DinoVisionTransformer, run
+    unmodified; only rgb_normalize (torchvision ToTensor + Normalize, un-vendored) is supplied by the oracle."""
+    import importlib
+
+    from . import dinov2 as od
+    rh.ism()
+    vt = importlib.import_module("model.vision_transformer")
+    dv = importlib.import_module("model.dinov2")
+    bu = importlib.import_module("utils.bbox_utils")
+    c = DINO_CASE
+    inp = synth.dinov2_inputs(P=c["P"], seed=c["input_seed"])
+
+    def custom(model, target, cfg):
+        o = object.__new__(dv.CustomDINOv2)               # the constructor needs a checkpoint file + torchvision
+        torch.nn.Module.__init__(o)
+        o.model, o.chunk_size, o.patch_size, o.proposal_size = model, 4, cfg["patch"], target
+        o.validpatch_thresh, o.token_name = 0.5, "x_norm_clstoken"
+        o.rgb_normalize = od.rgb_normalize
+        o.rgb_proposal_processor = bu.CropResizePad(target)
+        o.patch_kernel = torch.nn.AvgPool2d(kernel_size=cfg["patch"], stride=cfg["patch"])
+        return o
+
+    def props():
+        return types.SimpleNamespace(masks=inp["masks"].clone(), boxes=inp["boxes"].clone())
+    rec = {}
+    with torch.no_grad():
+        cfg = od.MINI
+        m = vt.DinoVisionTransformer(img_size=cfg["img_size"], patch_size=cfg["patch"], embed_dim=cfg["dim"],
+                                     depth=cfg["depth"], num_heads=cfg["heads"], mlp_ratio=4, init_values=1.0,
+                                     block_chunks=0).eval()
+        seeded.load_seeded(m, c["weight_seed"])
+        o = custom(m, c["mini_target"], cfg)
+        rec["mini_rgbs"] = o.process_rgb_proposals(inp["image"], inp["masks"].clone(), inp["boxes"]).numpy()
+        rec["mini_masks"] = o.process_masks_proposals(inp["masks"].clone(), inp["boxes"]).numpy()
+        cls, patch = o.forward(inp["image"], props())
+        rec["mini_cls"], rec["mini_patch"] = cls.numpy(), patch.numpy()
+        rec["mini_cls_only"] = o.forward_cls_token(inp["image"], props()).numpy()
+        rec["mini_patch_only"] = o.forward_patch_tokens(inp["image"], props()).numpy()
+        rec["mini_keys"] = np.array(sorted(m.state_dict().keys()))
+        # released configuration: ViT-L/14 at 224 (pos_embed interpolated 37x37 -> 16x16), full-size frame crops
+        cfg = od.VIT_L14
+        m = vt.vit_large(patch_size=14, img_size=518, init_values=1.0, ffn_layer="mlp", block_chunks=0).eval()
+        seeded.load_seeded(m, c["weight_seed"])
+        o = custom(m, 224, cfg)
+        rgbs = o.process_rgb_proposals(inp["image"], inp["masks"].clone(), inp["boxes"])
+        pm = o.process_masks_proposals(inp["masks"].clone(), inp["boxes"])
+        rec["l_rgbs_sum"], rec["l_rgbs_smp"] = digest(rgbs, 1009)
+        rec["l_masks_sum"], rec["l_masks_smp"] = digest(pm, 1009)
+        cls, patch = o.compute_cls_and_patch_features(rgbs[: c["n_full"]], pm[: c["n_full"]])
+        rec["l_cls"] = cls.numpy()
+        rec["l_patch_sum"], rec["l_patch_smp"] = digest(patch, 53)
+        rec["l_keys"] = np.array(sorted(m.state_dict().keys()))
+        rec["l_shapes"] = np.array([str(tuple(m.state_dict()[k].shape)) for k in sorted(m.state_dict().keys())])
+    rec["case"] = np.array(str(c))
+    np.savez_compressed(os.path.join(OUT, "dinov2.npz"), **rec)
+    print("dinov2.npz", {k: (v.shape if hasattr(v, "shape") else v) for k, v in rec.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    {"pem": gen_pem, "sam": gen_sam, "ism": gen_ism}[sys.argv[1]]()
+    {"pem": gen_pem, "sam": gen_sam, "ism": gen_ism, "dinov2": gen_dinov2}[sys.argv[1]]()

@@ -161,6 +161,29 @@ def sam_preprocess(x, mean, std, img_size, out_dtype=torch.bfloat16):
     return out
 
 
+def crop_resize_pad(image_u8, masks, params, target, mean, std, rgb=True, mask=True):
+    """Fused proposal crops [CustomDINOv2.process_rgb_proposals / process_masks_proposals].
+    image_u8 (H,W,3) uint8, masks (P,H,W) f32, params (P,12) int32 records (sam6d_amd.ism.dinov2.crop_params)
+    -> (rgbs (P,3,T,T) f32 or None, masks (P,T,T) f32 or None)."""
+    _chk(masks, torch.float32, "masks", 3)
+    _chk(params, torch.int32, "params", 2)
+    P, H, W = masks.shape
+    if rgb:
+        _chk(image_u8, torch.uint8, "image", 3)
+        if tuple(image_u8.shape) != (H, W, 3):
+            raise RuntimeError("crop_resize_pad: image must be (H,W,3) like the masks")
+    if tuple(params.shape) != (P, 12):
+        raise RuntimeError("crop_resize_pad: params must be (P,12)")
+    T = int(target)
+    o_rgb = torch.empty(P, 3, T, T, dtype=torch.float32, device=masks.device) if rgb else None
+    o_mask = torch.empty(P, T, T, dtype=torch.float32, device=masks.device) if mask else None
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    sd = (ctypes.c_float * 3)(*[float(v) for v in std])
+    _call("s6d_crop_resize_pad_f32", _ptr(image_u8) if rgb else _vp(0), _ptr(masks), _ptr(params), P, H, W, T, m, sd,
+          _ptr(o_rgb) if rgb else _vp(0), _ptr(o_mask) if mask else _vp(0), _stream())
+    return o_rgb, o_mask
+
+
 def upsample_gather(up, choose, H, W, C):
     """up (B,196,16*C) f32, choose (B,n) int64 -> (B,n,C): bilinear x4 of the pixel-shuffled map at chosen pixels."""
     _chk(up, torch.float32, "up", 3)
@@ -401,7 +424,7 @@ def have(name):
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
                "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_f32",
-               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "mha": "s6d_mha_f32",
+               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "crop_resize_pad": "s6d_crop_resize_pad_f32", "mha": "s6d_mha_f32",
                "linear_attn_focus": "s6d_linear_attn_focus_f32", "project_bbox": "s6d_project_bbox_f32"}.get(name)
         import os
         disabled = name in os.environ.get("S6D_DISABLE_FUSED", "").split(",")

@@ -99,3 +99,46 @@ def ism_inputs(P=128, O=8, T=42, C=1024, n_patch=256, H=480, W=640, seed=1, n_mo
     poses[:, :3, :3] = random_rotations(T, g)
     return dict(qry_cls=qry_cls, ref_cls=ref_cls, qry_patch=qry_patch, ref_patch=ref_patch, masks=masks,
                 boxes=boxes, depth=depth, K=K, pointcloud=pc, poses=poses, gt_obj=obj, gt_tem=tem)
+
+
+def dinov2_inputs(P=8, H=480, W=640, seed=1):
+    """RGB frame (H,W,3) uint8 + proposal masks (P,H,W) float {0,1} + xyxy long boxes for the DINOv2 crop path.
+    Proposals 0..4 pin the branches of CropResizePad: square 100x100 crop (no padding; most other square sizes make
+    the reference itself raise in torch.stack, its second resize flooring to target-1), very tall, very wide, tiny, near-full
+    frame; the rest are random.  Masks are ellipses inscribed in their boxes (so masked-out pixels occur inside
+    the crop), boxes are the mask extents as SAM's batched_mask_to_box reports them (inclusive max corner)."""
+    g = _g(seed)
+    img = (torch.rand(H // 8, W // 8, 3, generator=g) * 255).repeat_interleave(8, 0).repeat_interleave(8, 1)
+    img = (img + 20 * torch.randn(H, W, 3, generator=g)).clamp(0, 255).to(torch.uint8)
+    fixed = [(40, 30, 101, 101), (200, 10, 24, 300), (10, 400, 500, 30), (320, 240, 5, 4), (2, 3, W - 6, H - 8)]
+    rects = []
+    for i in range(P):
+        if i < len(fixed):
+            rects.append(fixed[i])
+        else:
+            bw = int(torch.randint(12, W // 2, (1,), generator=g))
+            bh = int(torch.randint(12, H // 2, (1,), generator=g))
+            rects.append((int(torch.randint(0, W - bw, (1,), generator=g)), int(torch.randint(0, H - bh, (1,), generator=g)), bw, bh))
+    ys = torch.arange(H).view(H, 1).float()
+    xs = torch.arange(W).view(1, W).float()
+    masks, boxes = [], []
+    for x0, y0, bw, bh in rects:
+        cx, cy = x0 + (bw - 1) / 2, y0 + (bh - 1) / 2
+        m = (((xs - cx) / (bw / 2)) ** 2 + ((ys - cy) / (bh / 2)) ** 2 <= 1.0).float()
+        yy, xx = torch.nonzero(m, as_tuple=True)
+        masks.append(m)
+        boxes.append(torch.stack([xx.min(), yy.min(), xx.max(), yy.max()]))
+    return dict(image=img.numpy(), masks=torch.stack(masks), boxes=torch.stack(boxes).long())
+
+
+def random_boxes(P, H, W, g):
+    """xyxy long boxes of every aspect ratio with sides from 2 px to the full frame, minus the shapes on which the
+    reference's CropResizePad itself raises (square crops, sides that vanish after the resize)."""
+    x1 = torch.randint(0, W - 3, (P,), generator=g)
+    y1 = torch.randint(0, H - 3, (P,), generator=g)
+    x2 = (x1 + 2 + (torch.rand(P, generator=g) ** 2 * (W - x1 - 2)).long()).clamp(max=W)
+    y2 = (y1 + 2 + (torch.rand(P, generator=g) ** 2 * (H - y1 - 2)).long()).clamp(max=H)
+    boxes = torch.stack([x1, y1, x2, y2], 1)
+    w, h = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+    ok = (w != h) & (torch.minimum(w, h).float() * 224 / torch.maximum(w, h).float() >= 1.5)
+    return boxes[ok]

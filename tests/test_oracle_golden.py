@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import dinov2 as odino
 from oracle import ism as oism
 from oracle import pem as opem
 from oracle import pn2 as opn2
@@ -124,6 +125,48 @@ def test_ism_scoring_matches_reference():
 
 
 # ----------------------------------------------------------------------------- PN2 (no reference vectors exist)
+def _dino_case():
+    g = util.golden("dinov2.npz")
+    c = ast.literal_eval(str(g["case"]))
+    return g, c, synth.dinov2_inputs(P=c["P"], seed=c["input_seed"])
+
+
+def test_dinov2_crops_and_mini_descriptors_match_reference():
+    """Crop/resize/pad of masked proposals (rgb + mask) and cls / masked-patch descriptors, mini ViT."""
+    g, c, inp = _dino_case()
+    ref = util.dinov2_shapes(odino.MINI)
+    assert sorted(ref) == [str(k) for k in g["mini_keys"]]
+    W = seeded.seeded_state(ref, c["weight_seed"])
+    with torch.no_grad():
+        rgbs = odino.process_rgb_proposals(inp["image"], inp["masks"], inp["boxes"], c["mini_target"])
+        pm = odino.process_masks_proposals(inp["masks"], inp["boxes"], c["mini_target"])
+        np.testing.assert_array_equal(rgbs.numpy(), g["mini_rgbs"])           # index arithmetic + 3 float ops: exact
+        np.testing.assert_array_equal(pm.numpy(), g["mini_masks"])
+        cls, patch = odino.cls_and_patch_features(W, rgbs, pm, odino.MINI)
+    np.testing.assert_allclose(cls.numpy(), g["mini_cls"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(patch.numpy(), g["mini_patch"], rtol=1e-4, atol=1e-5)
+    # the reference's cls-only and patch-only entry points return the same tensors as forward()
+    np.testing.assert_array_equal(g["mini_cls_only"], g["mini_cls"])
+    np.testing.assert_array_equal(g["mini_patch_only"], g["mini_patch"])
+
+
+@pytest.mark.slow
+def test_dinov2_vit_l14_matches_reference():
+    g, c, inp = _dino_case()
+    shapes = util.shapes_from_golden(g, "l_keys", "l_shapes")
+    assert shapes == {k: tuple(v) for k, v in util.dinov2_shapes(odino.VIT_L14).items()}
+    W = seeded.seeded_state(shapes, c["weight_seed"])
+    with torch.no_grad():
+        rgbs = odino.process_rgb_proposals(inp["image"], inp["masks"], inp["boxes"], 224)
+        pm = odino.process_masks_proposals(inp["masks"], inp["boxes"], 224)
+        util.assert_digest_close(rgbs, g["l_rgbs_sum"], g["l_rgbs_smp"], 1009, 0, 0, "224 crops")
+        util.assert_digest_close(pm, g["l_masks_sum"], g["l_masks_smp"], 1009, 0, 0, "224 masks")
+        n = c["n_full"]
+        cls, patch = odino.cls_and_patch_features(W, rgbs[:n], pm[:n], odino.VIT_L14)
+    np.testing.assert_allclose(cls.numpy(), g["l_cls"], rtol=1e-3, atol=1e-4)
+    util.assert_digest_close(patch, g["l_patch_sum"], g["l_patch_smp"], 53, 1e-3, 1e-5, "vit-l patch descriptors")
+
+
 def _fps_numpy(p, m):
     """Independent restatement (float32 numpy, first-max) -- agrees with the tree emulation
     whenever no exact distance ties occur (true for continuous random clouds)."""

@@ -35,3 +35,19 @@ def assert_digest_close(t, gsum, gsmp, stride, rtol, atol, what=""):
     np.testing.assert_allclose(smp, gsmp, rtol=rtol, atol=atol, err_msg=f"{what}: strided sample")
     # abs-sum compared relatively (sum itself may cancel)
     assert abs(s[1] - gsum[1]) <= rtol * abs(gsum[1]) + atol * t.numel(), f"{what}: abs-sum {s[1]} vs {gsum[1]}"
+
+
+def dinov2_shapes(cfg):
+    """state_dict surface of DinoVisionTransformer (vision_transformer.py:107-170, layers/block.py:53-78)."""
+    D, n = cfg["dim"], cfg["img_size"] // cfg["patch"]
+    s = {"cls_token": (1, 1, D), "pos_embed": (1, n * n + 1, D), "mask_token": (1, D),
+         "patch_embed.proj.weight": (D, 3, cfg["patch"], cfg["patch"]), "patch_embed.proj.bias": (D,),
+         "norm.weight": (D,), "norm.bias": (D,)}
+    for i in range(cfg["depth"]):
+        p = f"blocks.{i}."
+        s.update({p + "norm1.weight": (D,), p + "norm1.bias": (D,), p + "norm2.weight": (D,), p + "norm2.bias": (D,),
+                  p + "attn.qkv.weight": (3 * D, D), p + "attn.qkv.bias": (3 * D,), p + "attn.proj.weight": (D, D),
+                  p + "attn.proj.bias": (D,), p + "ls1.gamma": (D,), p + "ls2.gamma": (D,),
+                  p + "mlp.fc1.weight": (4 * D, D), p + "mlp.fc1.bias": (4 * D,), p + "mlp.fc2.weight": (D, 4 * D),
+                  p + "mlp.fc2.bias": (D,)})
+    return s

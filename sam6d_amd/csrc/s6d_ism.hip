@@ -108,89 +108,166 @@ __global__ __launch_bounds__(256) void semantic_select_kernel(const float *__res
 }
 
 // ------------------------------------------------------------------------------------------------
-// Appearance score + visible ratio from ONE pass over sim = Q_s R_s^T  (Q_s: N1 x C, R_s: N2 x C).
-// Workgroup = (proposal s, 64-row block of Q_s); each of its 4 waves owns 16 query rows x all N2 (<= 256)
-// reference patches: 16 accumulator tiles.  Epilogue per wave: row maxima summed, column maxima, and the
-// number of query rows whose element sum is non-zero -- written as partials, folded by patch_finalize.
+// Appearance score + visible ratio from ONE pass over sim = Q_s R_s^T  (Q_s: N1 x C, R_s: N2 x C, fp32).
+// The product runs on the bf16 matrix cores with a 3-term split (x = x_hi + x_lo in bf16; hi*hi + lo*hi + hi*lo,
+// fp32 accumulate: ~2^-17 relative per product, |error| ~ 3e-7 on these unit-vector cosines, exact zeros stay
+// exact) -- 5x the rate of the fp32 MFMA the first version used.  Workgroup = (proposal s, 256-row block of Q_s),
+// 8 waves; a wave owns 32 query rows (two 16-row strips sharing every B fragment) x all N2 (<= 256) reference
+// patches = 32 accumulator tiles.  Per 32-channel k-step the workgroup converts the reference slice to hi / lo bf16
+// ONCE into LDS (double buffered; the next slice's global loads fly under the MFMAs), every wave converts its own
+// A fragments in registers.  Epilogue per wave: row maxima summed, column maxima, and the number of query rows
+// whose element sum is non-zero -- written as partials, folded by patch_finalize.
 constexpr int kMaxColTiles = 16;
+constexpr int kPsRow = 40;                 // LDS row stride (bf16): 32 channels + 8 pad (80 B: conflict-free b128 reads)
+constexpr int kPsThreads = 512;
+constexpr int kPsRowsPerWave = 32;
+constexpr int kPsLdsBytes = 2 * 2 * 256 * kPsRow * 2;   // [buffer][hi | lo][256 rows][kPsRow] bf16 = 80 KB
 
-__global__ __launch_bounds__(256) void patch_scores_kernel(const float *__restrict__ q, const float *__restrict__ refstore,
-                                                          const int *__restrict__ obj, const int *__restrict__ tmpl,
-                                                          int N1, int N2, int C, int T, float *__restrict__ part_rowsum,
-                                                          float *__restrict__ part_colmax, int *__restrict__ part_nnz) {
-  const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+typedef __attribute__((ext_vector_type(8))) __bf16 ps_bf16x8;
+
+__device__ __forceinline__ void ps_split(float x, unsigned short &hi, unsigned short &lo) {
+  union { __bf16 b; unsigned short u; } h, l;
+  h.b = (__bf16)x;
+  l.b = (__bf16)(x - __uint_as_float(((unsigned)h.u) << 16));
+  hi = h.u;
+  lo = l.u;
+}
+
+__global__ __launch_bounds__(kPsThreads) void patch_scores_kernel(const float *__restrict__ q,
+                                                                 const float *__restrict__ refstore,
+                                                                 const int *__restrict__ obj, const int *__restrict__ tmpl,
+                                                                 int N1, int N2, int C, int T,
+                                                                 float *__restrict__ part_rowsum,
+                                                                 float *__restrict__ part_colmax,
+                                                                 int *__restrict__ part_nnz) {
+  extern __shared__ __attribute__((aligned(16))) char ps_smem[];
+  unsigned short *lds = reinterpret_cast<unsigned short *>(ps_smem);
+  const int s = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int c = lane & 15, g = lane >> 4;
-  const int nrb = gridDim.x;                               // row blocks of 64
-  const int row0 = (blockIdx.x * 4 + wave) * 16;
-  const int slot = blockIdx.x * 4 + wave;                  // partial index within the proposal
+  const int nslot = gridDim.x * 8;
+  const int slot = blockIdx.x * 8 + wave;                  // partial index within the proposal
+  const int row0 = slot * kPsRowsPerWave;
   const int nct = (N2 + 15) / 16;
   const float *Q = q + (size_t)s * N1 * C;
   const float *Rf = refstore + ((size_t)obj[s] * T + tmpl[s]) * (size_t)N2 * C;
-  const float *qa = Q + (size_t)min(row0 + c, N1 - 1) * C + g * 4;
-  f32x4 acc[kMaxColTiles];
+  const float *qa[2];
 #pragma unroll
-  for (int t = 0; t < kMaxColTiles; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float qsum = 0.f;
-  // reference-patch row pointers of the 16 column tiles (clamped: surplus tiles re-read the last row and are
-  // masked in the epilogue), then a 2-deep software pipeline: chunk k+1 is in flight while chunk k feeds 64 MFMAs
-  const float *rp[kMaxColTiles];
+  for (int n = 0; n < 2; ++n) qa[n] = Q + (size_t)min(row0 + n * 16 + c, N1 - 1) * C + g * 8;
+  // staging of the reference slice: 256 rows x 32 channels = 2048 float4, 4 per thread (rows past N2 re-read the
+  // last row; their columns are masked in the epilogue)
+  const float *bp[4];
+  int bo[4];
 #pragma unroll
-  for (int t = 0; t < kMaxColTiles; ++t) rp[t] = Rf + (size_t)min(t * 16 + c, N2 - 1) * C + g * 4;
-  float4 a_cur = *reinterpret_cast<const float4 *>(qa);
-  float4 b_cur[kMaxColTiles];
+  for (int j = 0; j < 4; ++j) {
+    const int it = tid + j * kPsThreads, row = it >> 3, c4 = it & 7;
+    bp[j] = Rf + (size_t)min(row, N2 - 1) * C + c4 * 4;
+    bo[j] = row * kPsRow + c4 * 4;
+  }
+  float4 breg[4], areg[2][2];
+  auto gload = [&](int k0) {
 #pragma unroll
-  for (int t = 0; t < kMaxColTiles; ++t) b_cur[t] = *reinterpret_cast<const float4 *>(rp[t]);
-  for (int k0 = 0; k0 < C; k0 += 16) {
-    const int kn = min(k0 + 16, C - 16);                    // last iteration re-loads (unused) in-bounds data
-    const float4 a_nxt = *reinterpret_cast<const float4 *>(qa + kn);
-    float4 b_nxt[kMaxColTiles];
+    for (int j = 0; j < 4; ++j) breg[j] = *reinterpret_cast<const float4 *>(bp[j] + k0);
 #pragma unroll
-    for (int t = 0; t < kMaxColTiles; ++t) b_nxt[t] = *reinterpret_cast<const float4 *>(rp[t] + kn);
-    qsum += (a_cur.x + a_cur.y) + (a_cur.z + a_cur.w);
+    for (int n = 0; n < 2; ++n) {
+      areg[n][0] = *reinterpret_cast<const float4 *>(qa[n] + k0);
+      areg[n][1] = *reinterpret_cast<const float4 *>(qa[n] + k0 + 4);
+    }
+  };
+  auto bstore = [&](int buf) {
+    unsigned short *hi = lds + (size_t)buf * 2 * 256 * kPsRow, *lo = hi + 256 * kPsRow;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      union { uint2 u; unsigned short h[4]; } vh, vl;
+      const float v[4] = {breg[j].x, breg[j].y, breg[j].z, breg[j].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ps_split(v[e], vh.h[e], vl.h[e]);
+      *reinterpret_cast<uint2 *>(hi + bo[j]) = vh.u;
+      *reinterpret_cast<uint2 *>(lo + bo[j]) = vl.u;
+    }
+  };
+  f32x4 acc[2][kMaxColTiles];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int t = 0; t < kMaxColTiles; ++t) acc[n][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float qsum[2] = {0.f, 0.f};
+  gload(0);
+  bstore(0);
+  __syncthreads();
+  const int nk = C / 32;
+  for (int ks = 0; ks < nk; ++ks) {
+    // this step's A fragments (registers), then the next slice's loads take off under the MFMAs
+    union { ps_bf16x8 v; unsigned short h[8]; } ah[2], al[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const float v[8] = {areg[n][0].x, areg[n][0].y, areg[n][0].z, areg[n][0].w,
+                          areg[n][1].x, areg[n][1].y, areg[n][1].z, areg[n][1].w};
+      float sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        ps_split(v[e], ah[n].h[e], al[n].h[e]);
+        sum += v[e];
+      }
+      qsum[n] += sum;
+    }
+    gload(min(ks + 1, nk - 1) * 32);                         // the last iteration re-loads in-bounds data (unused)
+    const unsigned short *hi = lds + (size_t)(ks & 1) * 2 * 256 * kPsRow, *lo = hi + 256 * kPsRow;
 #pragma unroll
     for (int t = 0; t < kMaxColTiles; ++t) {
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.x, b_cur[t].x, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.y, b_cur[t].y, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.z, b_cur[t].z, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.w, b_cur[t].w, acc[t], 0, 0, 0);
+      const int o = (t * 16 + c) * kPsRow + g * 8;
+      const ps_bf16x8 bh = *reinterpret_cast<const ps_bf16x8 *>(hi + o);
+      const ps_bf16x8 bl = *reinterpret_cast<const ps_bf16x8 *>(lo + o);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        acc[n][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[n].v, bh, acc[n][t], 0, 0, 0);
+        acc[n][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[n].v, bh, acc[n][t], 0, 0, 0);
+        acc[n][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[n].v, bl, acc[n][t], 0, 0, 0);
+      }
     }
-    a_cur = a_nxt;
-#pragma unroll
-    for (int t = 0; t < kMaxColTiles; ++t) b_cur[t] = b_nxt[t];
+    if (ks + 1 < nk) bstore((ks + 1) & 1);                   // the other buffer: last read in iteration ks-1
+    __syncthreads();
   }
-  // element sums of the 16 query rows (row = l&15 after folding the 4 k-groups)
-  qsum += __shfl_xor(qsum, 16); qsum += __shfl_xor(qsum, 32);
-  const bool row_ok = row0 + c < N1;
-  const unsigned long long nzmask = __ballot(row_ok && qsum != 0.f && lane < 16);
-  // row maxima: row = g*4 + r, max over column tiles and the 16 lanes of the group
+  // ---- epilogue: A = query rows, B = reference rows -> C layout row = query g*4+r, col = reference c -----------
+  int nnz = 0;
   float rsum = 0.f;
+  float cmax[kMaxColTiles];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float m = -3.4e38f;
+  for (int t = 0; t < kMaxColTiles; ++t) cmax[t] = -3.4e38f;
 #pragma unroll
-    for (int t = 0; t < kMaxColTiles; ++t)
-      if (t < nct && t * 16 + c < N2) m = fmaxf(m, acc[t][r]);
-    m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2));
-    m = fmaxf(m, __shfl_xor(m, 4)); m = fmaxf(m, __shfl_xor(m, 8));
-    if (row0 + g * 4 + r < N1) rsum += m;
+  for (int n = 0; n < 2; ++n) {
+    const int r0 = row0 + n * 16;
+    float qs = qsum[n];
+    qs += __shfl_xor(qs, 16);
+    qs += __shfl_xor(qs, 32);                               // element sum of query row r0 + c
+    nnz += __popcll(__ballot(r0 + c < N1 && qs != 0.f && lane < 16));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                           // row maxima: max over column tiles and the group's 16 lanes
+      float m = -3.4e38f;
+#pragma unroll
+      for (int t = 0; t < kMaxColTiles; ++t)
+        if (t < nct && t * 16 + c < N2) m = fmaxf(m, acc[n][t][r]);
+      m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2));
+      m = fmaxf(m, __shfl_xor(m, 4)); m = fmaxf(m, __shfl_xor(m, 8));
+      if (r0 + g * 4 + r < N1) rsum += m;
+    }
+#pragma unroll
+    for (int t = 0; t < kMaxColTiles; ++t)                  // column maxima over this strip's 16 rows
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (r0 + g * 4 + r < N1) cmax[t] = fmaxf(cmax[t], acc[n][t][r]);
   }
-  rsum += __shfl_xor(rsum, 16); rsum += __shfl_xor(rsum, 32);   // all 16 rows of the wave
-  // column maxima over this wave's 16 rows
-  const int nslot = nrb * 4;
+  rsum += __shfl_xor(rsum, 16); rsum += __shfl_xor(rsum, 32);   // all 32 rows of the wave (lanes of a group agree)
 #pragma unroll
   for (int t = 0; t < kMaxColTiles; ++t) {
     if (t < nct) {
-      float m = -3.4e38f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (row0 + g * 4 + r < N1) m = fmaxf(m, acc[t][r]);
+      float m = cmax[t];
       m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
       if (lane < 16 && t * 16 + c < N2) part_colmax[((size_t)s * nslot + slot) * N2 + t * 16 + c] = m;
     }
   }
   if (lane == 0) {
     part_rowsum[(size_t)s * nslot + slot] = rsum;
-    part_nnz[(size_t)s * nslot + slot] = __popcll(nzmask);
+    part_nnz[(size_t)s * nslot + slot] = nnz;
   }
 }
 
@@ -201,7 +278,7 @@ __global__ void patch_finalize_kernel(const float *__restrict__ part_rowsum, con
   float rs = 0.f;
   int nz = 0;
   for (int i = 0; i < nslot; ++i) {
-    const int row0 = i * 16;
+    const int row0 = i * kPsRowsPerWave;
     if (row0 < N1) {
       rs += part_rowsum[(size_t)s * nslot + i];
       nz += part_nnz[(size_t)s * nslot + i];
@@ -211,7 +288,7 @@ __global__ void patch_finalize_kernel(const float *__restrict__ part_rowsum, con
   for (int j = lane; j < N2; j += 64) {
     float m = -3.4e38f;
     for (int i = 0; i < nslot; ++i)
-      if (i * 16 < N1) m = fmaxf(m, part_colmax[((size_t)s * nslot + i) * N2 + j]);
+      if (i * kPsRowsPerWave < N1) m = fmaxf(m, part_colmax[((size_t)s * nslot + i) * N2 + j]);
     valid += (m != 0.f);
     vis += (m > thred) && (m != 0.f);
   }
@@ -365,18 +442,20 @@ extern "C" int s6d_semantic_select_f32(const float *scores, int P, int O, int T,
 extern "C" int s6d_patch_scores_f32(const float *query, const float *refstore, const int32_t *obj, const int32_t *tmpl,
                                     int S, int N1, int N2, int C, int T, float thred, float *workspace, float *appe,
                                     float *ratio, void *stream) {
-  if (S < 0 || N1 <= 0 || N2 <= 0 || C <= 0 || (C % 16) != 0 || T <= 0) return S6D_EINVAL;
+  if (S < 0 || N1 <= 0 || N2 <= 0 || C <= 0 || (C % 32) != 0 || T <= 0) return S6D_EINVAL;
   if (N2 > 16 * kMaxColTiles) return S6D_EUNSUPPORTED;
   if (S == 0) return S6D_OK;
   if (!query || !refstore || !obj || !tmpl || !workspace || !appe || !ratio) return S6D_EINVAL;
-  const int nrb = (N1 + 63) / 64, nslot = nrb * 4;
+  const int nrb = (N1 + 255) / 256, nslot = nrb * 8;
   // workspace: [S*nslot] row sums | [S*nslot*N2] column maxima | [S*nslot] non-zero row counts (int)
   float *part_rowsum = workspace;
   float *part_colmax = workspace + (size_t)S * nslot;
   int *part_nnz = reinterpret_cast<int *>(part_colmax + (size_t)S * nslot * N2);
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(patch_scores_kernel, dim3(nrb, S), dim3(256), 0, st, query, refstore, obj, tmpl, N1, N2, C, T,
-                     part_rowsum, part_colmax, part_nnz);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&patch_scores_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kPsLdsBytes);
+  hipLaunchKernelGGL(patch_scores_kernel, dim3(nrb, S), dim3(kPsThreads), kPsLdsBytes, st, query, refstore, obj, tmpl, N1,
+                     N2, C, T, part_rowsum, part_colmax, part_nnz);
   int rc = launch_status();
   if (rc) return rc;
   hipLaunchKernelGGL(patch_finalize_kernel, dim3(S), dim3(64), 0, st, part_rowsum, part_colmax, part_nnz, S, nslot, N1, N2,
@@ -385,7 +464,7 @@ extern "C" int s6d_patch_scores_f32(const float *query, const float *refstore, c
 }
 
 extern "C" long s6d_patch_scores_workspace_floats(int S, int N1, int N2) {
-  const long nslot = ((N1 + 63) / 64) * 4;
+  const long nslot = ((N1 + 255) / 256) * 8;
   return (long)S * nslot * (2 + N2);
 }
 

@@ -5,6 +5,8 @@ Run in the build container only (needs /root/reference, read-only):
     python -m oracle.gen_golden pem      # Pose_Estimation_Model Net + known-answer case
     python -m oracle.gen_golden sam      # SAM ImageEncoderViT (mini config + ViT-H)
     python -m oracle.gen_golden ism      # ISM scoring chain
+    python -m oracle.gen_golden dinov2   # DINOv2 crops + descriptors (next row 8f-1)
+    python -m oracle.gen_golden sam_decoder   # SAM prompt encoder + mask decoder (next row 8f-2)
 
 PEM and ISM must run in separate processes (both trees own top-level names).  The
 reference modules are imported unmodified through oracle/refharness.py; weights and inputs
@@ -29,6 +31,7 @@ PEM_CASE = dict(B=2, weight_seed=1, input_seed=1, rand_seed=7)
 SAM_MINI_CASE = dict(weight_seed=3, input_seed=5)
 SAM_H_CASE = dict(weight_seed=3, input_seed=5)
 ISM_CASE = dict(P=64, O=3, T=42, seed=11)
+SAMDEC_CASE = dict(weight_seed=2, input_seed=9, n_mini=9, n_full=4, mini_input_size=(96, 128), mini_orig=(60, 80))
 DINO_CASE = dict(P=8, input_seed=4, weight_seed=6, mini_target=56, n_full=2)
 
 
@@ -159,6 +162,61 @@ def gen_ism():
     print("selected", len(rec["sel"]), "iou", rec["iou"], "vr", rec["visible_ratio"][:5], "final", rec["final"][:5])
 
 
+def _samdec_ref(ns, cfg, seed):
+    pe = ns.PromptEncoder(embed_dim=cfg["dim"], image_embedding_size=(cfg["emb"],) * 2,
+                          input_image_size=(cfg["img"],) * 2, mask_in_chans=16)
+    md = ns.MaskDecoder(num_multimask_outputs=cfg["n_multi"],
+                        transformer=ns.TwoWayTransformer(depth=cfg["depth"], embedding_dim=cfg["dim"], mlp_dim=cfg["mlp"],
+                                                         num_heads=cfg["heads"]),
+                        transformer_dim=cfg["dim"], iou_head_depth=cfg["iou_depth"], iou_head_hidden_dim=cfg["iou_hidden"])
+    m = torch.nn.Module()
+    m.prompt_encoder, m.mask_decoder = pe, md
+    return seeded.load_seeded(m.eval(), seed)
+
+
+def gen_sam_decoder():
+    """Reference PromptEncoder + MaskDecoder (+ TwoWayTransformer) run unmodified, as Sam.forward / SamPredictor
+    call them; Sam.postprocess_masks is three lines of F.interpolate and is restated by the oracle."""
+    from . import sam_decoder as od
+    ns = rh.sam_decoder()
+    c = SAMDEC_CASE
+    rec = {}
+
+    def run(m, emb, **kw):
+        s, d = m.prompt_encoder(points=kw.get("points"), boxes=kw.get("boxes"), masks=None)
+        mk, iou = m.mask_decoder(image_embeddings=emb, image_pe=m.prompt_encoder.get_dense_pe(),
+                                 sparse_prompt_embeddings=s, dense_prompt_embeddings=d,
+                                 multimask_output=kw.get("multi", True))
+        return s, mk, iou
+    with torch.no_grad():
+        cfg = od.MINI
+        m = _samdec_ref(ns, cfg, c["weight_seed"])
+        inp = synth.sam_decoder_inputs(cfg, c["n_mini"], c["input_seed"])
+        s, mk, iou = run(m, inp["emb"], points=(inp["points"], inp["labels"]))
+        rec["mini_sparse"], rec["mini_masks"], rec["mini_iou"] = s.numpy(), mk.numpy(), iou.numpy()
+        rec["mini_dense_pe"] = m.prompt_encoder.get_dense_pe().numpy()
+        s, mk, iou = run(m, inp["emb"], points=(inp["points2"], inp["labels2"]), multi=False)
+        rec["mini_sparse2"], rec["mini_masks2"], rec["mini_iou2"] = s.numpy(), mk.numpy(), iou.numpy()
+        s, mk, iou = run(m, inp["emb"], boxes=inp["boxes"])
+        rec["mini_sparse_box"], rec["mini_masks_box"], rec["mini_iou_box"] = s.numpy(), mk.numpy(), iou.numpy()
+        rec["mini_post"] = od.postprocess_masks(torch.from_numpy(rec["mini_masks"][:3]), cfg["img"], c["mini_input_size"],
+                                                c["mini_orig"]).numpy()
+        rec["mini_keys"] = np.array(sorted(m.state_dict().keys()))
+        rec["mini_shapes"] = np.array([str(tuple(m.state_dict()[k].shape)) for k in sorted(m.state_dict().keys())])
+        cfg = od.SAM
+        m = _samdec_ref(ns, cfg, c["weight_seed"])
+        inp = synth.sam_decoder_inputs(cfg, c["n_full"], c["input_seed"])
+        s, mk, iou = run(m, inp["emb"], points=(inp["points"], inp["labels"]))
+        rec["sam_iou"] = iou.numpy()
+        rec["sam_masks_sum"], rec["sam_masks_smp"] = digest(mk, 211)
+        rec["sam_keys"] = np.array(sorted(m.state_dict().keys()))
+        rec["sam_shapes"] = np.array([str(tuple(m.state_dict()[k].shape)) for k in sorted(m.state_dict().keys())])
+    rec["case"] = np.array(str(c))
+    np.savez_compressed(os.path.join(OUT, "sam_decoder.npz"), **rec)
+    print("sam_decoder.npz", {k: (v.shape if hasattr(v, "shape") else v) for k, v in rec.items()})
+    print("mini iou", rec["mini_iou"][:2], "mask |max|", np.abs(rec["mini_masks"]).max(), "sam iou", rec["sam_iou"][:2])
+
+
 def gen_dinov2():
     """Reference CustomDINOv2 methods (crop pipeline + masked patch features) and DinoVisionTransformer, run
     unmodified; only rgb_normalize (torchvision ToTensor + Normalize, un-vendored) is supplied by the oracle."""
@@ -221,4 +279,4 @@ def gen_dinov2():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    {"pem": gen_pem, "sam": gen_sam, "ism": gen_ism, "dinov2": gen_dinov2}[sys.argv[1]]()
+    {"pem": gen_pem, "sam": gen_sam, "ism": gen_ism, "dinov2": gen_dinov2, "sam_decoder": gen_sam_decoder}[sys.argv[1]]()

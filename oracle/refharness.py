@@ -134,6 +134,23 @@ def sam_encoder():
     return _load_by_path(pkgname + ".image_encoder", os.path.join(base, "image_encoder.py"), pkgname)
 
 
+def sam_decoder():
+    """segment_anything/modeling/{common,prompt_encoder,transformer,mask_decoder}.py loaded by file path (same
+    package trick as sam_encoder()).  Returns a namespace with PromptEncoder, MaskDecoder, TwoWayTransformer."""
+    assert available()
+    base = os.path.join(ISM, "segment_anything", "modeling")
+    pkgname = "_s6d_ref_sa_modeling"
+    sam_encoder()                                                    # creates the package + common
+    ns = types.SimpleNamespace()
+    for name in ("prompt_encoder", "transformer", "mask_decoder"):
+        full = pkgname + "." + name
+        ns.__dict__[name] = sys.modules.get(full) or _load_by_path(full, os.path.join(base, name + ".py"), pkgname)
+    ns.PromptEncoder = ns.prompt_encoder.PromptEncoder
+    ns.MaskDecoder = ns.mask_decoder.MaskDecoder
+    ns.TwoWayTransformer = ns.transformer.TwoWayTransformer
+    return ns
+
+
 def ism():
     """Reference ISM scoring code: model.loss classes, detector scoring methods,
     compute_iou and the masked-depth translation helper."""

@@ -1,0 +1,335 @@
+"""SAM prompt encoder + two-way mask decoder on MI355X -- drop-in for segment_anything/modeling/
+{prompt_encoder.py, transformer.py, mask_decoder.py} (first slice: the 3.7 TFLOP/frame term).
+
+Same class names, constructor arguments, forward signatures and state_dict keys as the reference
+(``PromptEncoder`` prompt_encoder.py:16-166, ``PositionEmbeddingRandom`` :169-214, ``TwoWayTransformer`` /
+``TwoWayAttentionBlock`` / ``Attention`` transformer.py:16-240, ``MaskDecoder`` / ``MLP`` mask_decoder.py:16-176), so
+``build_sam._build_sam`` (build_sam.py:54-107) can construct them unchanged and ``sam.load_state_dict`` loads the released
+checkpoint strictly; ``SamPredictor.predict_torch`` (predictor.py:169-243) and ``Sam.forward`` call them as before.
+
+Two execution paths:
+  * library path (any shape, fp32 or autocast): the reference's op sequence on channels-last token tensors.
+  * restructured path (``MaskDecoder._predict_masks_shared``; the automatic mask generator's case: point / box prompts,
+    no mask inputs, so the dense embedding is one broadcast vector): exact algebra, less work --
+      - the image tokens entering layer 0 are the SAME for every prompt: their k / v / q projections (and the
+        positional-encoding parts of every later projection, W(x + pe) = Wx + W pe) are computed once per image, not
+        once per prompt;
+      - projections that read the same tensor are one GEMM (layer 1: [k | v | q_image->token]; final: [k | v | first
+        transposed conv], a 2x2/2 transposed conv being a GEMM with 4x the output channels);
+      - image->token attention has only n_tok <= 8 keys per head: out_proj(softmax(q k^T) v) = softmax(q k^T) (v W_o^T),
+        i.e. one (4096 x 64) x (64 x 256) product per prompt with W_o folded into the 7 value rows.
+    As written the decoder costs ~3.6 GFLOP per prompt; restructured ~2.2 GFLOP.
+Compute dtype: ``S6D_SAM_DECODER_DTYPE`` = bf16 (default, autocast: GEMMs bf16, LayerNorm / softmax fp32) | fp32.
+"""
+import math
+import os
+from typing import Optional, Tuple, Type
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .image_encoder import LayerNorm2d, MLPBlock
+
+
+def _dtype():
+    return {"fp32": torch.float32, "bf16": torch.bfloat16}[os.environ.get("S6D_SAM_DECODER_DTYPE", "bf16")]
+
+
+# ---- prompt encoder ------------------------------------------------------------------------------------------------
+class PositionEmbeddingRandom(nn.Module):
+    def __init__(self, num_pos_feats: int = 64, scale: Optional[float] = None) -> None:
+        super().__init__()
+        if scale is None or scale <= 0.0:
+            scale = 1.0
+        self.register_buffer("positional_encoding_gaussian_matrix", scale * torch.randn((2, num_pos_feats)))
+
+    def _pe_encoding(self, coords):
+        coords = (2 * coords - 1) @ self.positional_encoding_gaussian_matrix
+        coords = 2 * np.pi * coords
+        return torch.cat([torch.sin(coords), torch.cos(coords)], dim=-1)
+
+    def forward(self, size: Tuple[int, int]):
+        h, w = size
+        grid = torch.ones((h, w), device=self.positional_encoding_gaussian_matrix.device, dtype=torch.float32)
+        y = (grid.cumsum(dim=0) - 0.5) / h
+        x = (grid.cumsum(dim=1) - 0.5) / w
+        return self._pe_encoding(torch.stack([x, y], dim=-1)).permute(2, 0, 1)
+
+    def forward_with_coords(self, coords_input, image_size: Tuple[int, int]):
+        coords = coords_input.clone()
+        coords[:, :, 0] = coords[:, :, 0] / image_size[1]
+        coords[:, :, 1] = coords[:, :, 1] / image_size[0]
+        return self._pe_encoding(coords.to(torch.float))
+
+
+class PromptEncoder(nn.Module):
+    def __init__(self, embed_dim: int, image_embedding_size: Tuple[int, int], input_image_size: Tuple[int, int],
+                 mask_in_chans: int, activation: Type[nn.Module] = nn.GELU) -> None:
+        super().__init__()
+        self.embed_dim, self.input_image_size, self.image_embedding_size = embed_dim, input_image_size, image_embedding_size
+        self.pe_layer = PositionEmbeddingRandom(embed_dim // 2)
+        self.num_point_embeddings = 4
+        self.point_embeddings = nn.ModuleList([nn.Embedding(1, embed_dim) for _ in range(4)])
+        self.not_a_point_embed = nn.Embedding(1, embed_dim)
+        self.mask_input_size = (4 * image_embedding_size[0], 4 * image_embedding_size[1])
+        self.mask_downscaling = nn.Sequential(
+            nn.Conv2d(1, mask_in_chans // 4, kernel_size=2, stride=2), LayerNorm2d(mask_in_chans // 4), activation(),
+            nn.Conv2d(mask_in_chans // 4, mask_in_chans, kernel_size=2, stride=2), LayerNorm2d(mask_in_chans), activation(),
+            nn.Conv2d(mask_in_chans, embed_dim, kernel_size=1))
+        self.no_mask_embed = nn.Embedding(1, embed_dim)
+
+    def get_dense_pe(self):
+        """(1,C,h,w); depends on the buffer only -> cached per buffer version."""
+        G = self.pe_layer.positional_encoding_gaussian_matrix
+        key = (G._version, G.data_ptr(), G.device)
+        c = getattr(self, "_s6d_dense_pe", None)
+        if c is None or c[0] != key:
+            c = (key, self.pe_layer(self.image_embedding_size).unsqueeze(0))
+            self._s6d_dense_pe = c
+        return c[1]
+
+    def _embed_points(self, points, labels, pad: bool):
+        points = points + 0.5
+        if pad:
+            points = torch.cat([points, torch.zeros((points.shape[0], 1, 2), device=points.device)], dim=1)
+            labels = torch.cat([labels, -torch.ones((labels.shape[0], 1), device=labels.device)], dim=1)
+        e = self.pe_layer.forward_with_coords(points, self.input_image_size)
+        # masked writes without host syncs (the reference's boolean-index assignments, prompt_encoder.py:86-89)
+        lab = labels.unsqueeze(-1)
+        e = torch.where(lab == -1, self.not_a_point_embed.weight.expand_as(e), e)
+        e = e + (lab == 0) * self.point_embeddings[0].weight + (lab == 1) * self.point_embeddings[1].weight
+        return e
+
+    def _embed_boxes(self, boxes):
+        coords = (boxes + 0.5).reshape(-1, 2, 2)
+        e = self.pe_layer.forward_with_coords(coords, self.input_image_size)
+        return e + torch.stack([self.point_embeddings[2].weight, self.point_embeddings[3].weight], dim=1)
+
+    def _get_device(self):
+        return self.point_embeddings[0].weight.device
+
+    def forward(self, points, boxes, masks):
+        if points is not None:
+            bs = points[0].shape[0]
+        elif boxes is not None:
+            bs = boxes.shape[0]
+        elif masks is not None:
+            bs = masks.shape[0]
+        else:
+            bs = 1
+        sparse = torch.empty((bs, 0, self.embed_dim), device=self._get_device())
+        if points is not None:
+            sparse = torch.cat([sparse, self._embed_points(points[0], points[1], pad=(boxes is None))], dim=1)
+        if boxes is not None:
+            sparse = torch.cat([sparse, self._embed_boxes(boxes)], dim=1)
+        if masks is not None:
+            dense = self.mask_downscaling(masks)
+        else:
+            dense = self.no_mask_embed.weight.reshape(1, -1, 1, 1).expand(bs, -1, self.image_embedding_size[0],
+                                                                          self.image_embedding_size[1])
+        return sparse, dense
+
+
+# ---- two-way transformer ---------------------------------------------------------------------------------------------
+class Attention(nn.Module):
+    def __init__(self, embedding_dim: int, num_heads: int, downsample_rate: int = 1) -> None:
+        super().__init__()
+        self.embedding_dim, self.internal_dim, self.num_heads = embedding_dim, embedding_dim // downsample_rate, num_heads
+        assert self.internal_dim % num_heads == 0, "num_heads must divide embedding_dim."
+        self.q_proj = nn.Linear(embedding_dim, self.internal_dim)
+        self.k_proj = nn.Linear(embedding_dim, self.internal_dim)
+        self.v_proj = nn.Linear(embedding_dim, self.internal_dim)
+        self.out_proj = nn.Linear(self.internal_dim, embedding_dim)
+
+    def _heads(self, x):
+        b, n, c = x.shape
+        return x.reshape(b, n, self.num_heads, c // self.num_heads).transpose(1, 2)
+
+    def attend(self, q, k, v):
+        """Projected q (B,Nq,Ci), k, v (B|1,Nk,Ci) -> out_proj(softmax(q k^T / sqrt(d)) v)."""
+        q, k, v = self._heads(q), self._heads(k), self._heads(v)
+        a = torch.softmax((q @ k.transpose(-1, -2)).float() / math.sqrt(q.shape[-1]), dim=-1).to(v.dtype)
+        o = (a @ v).transpose(1, 2)
+        return self.out_proj(o.reshape(o.shape[0], o.shape[1], -1))
+
+    def forward(self, q, k, v):
+        return self.attend(self.q_proj(q), self.k_proj(k), self.v_proj(v))
+
+
+class TwoWayAttentionBlock(nn.Module):
+    def __init__(self, embedding_dim: int, num_heads: int, mlp_dim: int = 2048, activation: Type[nn.Module] = nn.ReLU,
+                 attention_downsample_rate: int = 2, skip_first_layer_pe: bool = False) -> None:
+        super().__init__()
+        self.self_attn = Attention(embedding_dim, num_heads)
+        self.norm1 = nn.LayerNorm(embedding_dim)
+        self.cross_attn_token_to_image = Attention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
+        self.norm2 = nn.LayerNorm(embedding_dim)
+        self.mlp = MLPBlock(embedding_dim, mlp_dim, activation)
+        self.norm3 = nn.LayerNorm(embedding_dim)
+        self.norm4 = nn.LayerNorm(embedding_dim)
+        self.cross_attn_image_to_token = Attention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
+        self.skip_first_layer_pe = skip_first_layer_pe
+
+    def token_side(self, queries, query_pe, k_img, v_img):
+        """Steps (1)-(3) of the block given the image-side k / v of the token->image attention (already projected)."""
+        if self.skip_first_layer_pe:
+            queries = self.self_attn(q=queries, k=queries, v=queries)
+        else:
+            q = queries + query_pe
+            queries = queries + self.self_attn(q=q, k=q, v=queries)
+        queries = self.norm1(queries)
+        ca = self.cross_attn_token_to_image
+        queries = self.norm2(queries + ca.attend(ca.q_proj(queries + query_pe), k_img, v_img))
+        return self.norm3(queries + self.mlp(queries))
+
+    def forward(self, queries, keys, query_pe, key_pe):
+        ca = self.cross_attn_token_to_image
+        queries = self.token_side(queries, query_pe, ca.k_proj(keys + key_pe), ca.v_proj(keys))
+        q = queries + query_pe
+        keys = self.norm4(keys + self.cross_attn_image_to_token(q=keys + key_pe, k=q, v=queries))
+        return queries, keys
+
+
+class TwoWayTransformer(nn.Module):
+    def __init__(self, depth: int, embedding_dim: int, num_heads: int, mlp_dim: int,
+                 activation: Type[nn.Module] = nn.ReLU, attention_downsample_rate: int = 2) -> None:
+        super().__init__()
+        self.depth, self.embedding_dim, self.num_heads, self.mlp_dim = depth, embedding_dim, num_heads, mlp_dim
+        self.layers = nn.ModuleList([
+            TwoWayAttentionBlock(embedding_dim, num_heads, mlp_dim, activation, attention_downsample_rate,
+                                 skip_first_layer_pe=(i == 0)) for i in range(depth)])
+        self.final_attn_token_to_image = Attention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
+        self.norm_final_attn = nn.LayerNorm(embedding_dim)
+
+    def forward_tokens(self, keys, key_pe, point_embedding):
+        """Channels-last statement of forward(): keys, key_pe (B|1,N,C) image tokens, point_embedding (B,n,C)."""
+        queries = point_embedding
+        for layer in self.layers:
+            queries, keys = layer(queries=queries, keys=keys, query_pe=point_embedding, key_pe=key_pe)
+        q = queries + point_embedding
+        queries = self.norm_final_attn(queries + self.final_attn_token_to_image(q=q, k=keys + key_pe, v=keys))
+        return queries, keys
+
+    def forward(self, image_embedding, image_pe, point_embedding):
+        return self.forward_tokens(image_embedding.flatten(2).permute(0, 2, 1), image_pe.flatten(2).permute(0, 2, 1),
+                                   point_embedding)
+
+
+# ---- mask decoder ----------------------------------------------------------------------------------------------------
+class MLP(nn.Module):
+    def __init__(self, input_dim: int, hidden_dim: int, output_dim: int, num_layers: int, sigmoid_output: bool = False):
+        super().__init__()
+        self.num_layers = num_layers
+        h = [hidden_dim] * (num_layers - 1)
+        self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
+        self.sigmoid_output = sigmoid_output
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = F.relu(layer(x)) if i < self.num_layers - 1 else layer(x)
+        return torch.sigmoid(x) if self.sigmoid_output else x
+
+
+class MaskDecoder(nn.Module):
+    def __init__(self, *, transformer_dim: int, transformer: nn.Module, num_multimask_outputs: int = 3,
+                 activation: Type[nn.Module] = nn.GELU, iou_head_depth: int = 3, iou_head_hidden_dim: int = 256) -> None:
+        super().__init__()
+        self.transformer_dim, self.transformer = transformer_dim, transformer
+        self.num_multimask_outputs = num_multimask_outputs
+        self.iou_token = nn.Embedding(1, transformer_dim)
+        self.num_mask_tokens = num_multimask_outputs + 1
+        self.mask_tokens = nn.Embedding(self.num_mask_tokens, transformer_dim)
+        self.output_upscaling = nn.Sequential(
+            nn.ConvTranspose2d(transformer_dim, transformer_dim // 4, kernel_size=2, stride=2),
+            LayerNorm2d(transformer_dim // 4), activation(),
+            nn.ConvTranspose2d(transformer_dim // 4, transformer_dim // 8, kernel_size=2, stride=2), activation())
+        self.output_hypernetworks_mlps = nn.ModuleList(
+            [MLP(transformer_dim, transformer_dim, transformer_dim // 8, 3) for _ in range(self.num_mask_tokens)])
+        self.iou_prediction_head = MLP(transformer_dim, iou_head_hidden_dim, self.num_mask_tokens, iou_head_depth)
+
+    def forward(self, image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings,
+                multimask_output: bool):
+        masks, iou_pred = self.predict_masks(image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings)
+        sl = slice(1, None) if multimask_output else slice(0, 1)
+        return masks[:, sl, :, :], iou_pred[:, sl]
+
+    # -- shared pieces ---------------------------------------------------------------------------------------------
+    def _tokens(self, sparse):
+        out = torch.cat([self.iou_token.weight, self.mask_tokens.weight], dim=0)
+        return torch.cat((out.unsqueeze(0).expand(sparse.size(0), -1, -1), sparse.to(out.dtype)), dim=1)
+
+    def _upscale(self, y0, b, h, w):
+        """y0 (B, h*w, 4*C1): first transposed conv as a GEMM, columns ordered (c, dy, dx).  -> (B, 4h*4w, C2) channels
+        last with pixel order (y, dy, dy2, x, dx, dx2) == row-major over the 4h x 4w grid."""
+        ct1, ln, act1, ct2, act2 = self.output_upscaling
+        c1, c2 = ct1.out_channels, ct2.out_channels
+        u = y0.view(b, h, w, c1, 2, 2).permute(0, 1, 4, 2, 5, 3)                 # (b, h, dy, w, dx, c1)
+        u = act1(F.layer_norm(u.float(), (c1,), ln.weight.float(), ln.bias.float(), ln.eps)).to(y0.dtype)
+        w2 = ct2.weight.reshape(c1, c2 * 4).to(u.dtype)                           # (c1, (c2, dy2, dx2))
+        v = act2(F.linear(u, w2.t(), ct2.bias.repeat_interleave(4).to(u.dtype)))  # (b, h, dy, w, dx, c2*4)
+        v = v.view(b, h, 2, w, 2, c2, 2, 2).permute(0, 1, 2, 6, 3, 4, 7, 5)        # (b, h, dy, dy2, w, dx, dx2, c2)
+        return v.reshape(b, 16 * h * w, c2)
+
+    def _heads_out(self, hs, up, b, h, w):
+        iou_tok, mask_toks = hs[:, 0, :], hs[:, 1:1 + self.num_mask_tokens, :]
+        hyper = torch.stack([self.output_hypernetworks_mlps[i](mask_toks[:, i, :]) for i in range(self.num_mask_tokens)], 1)
+        masks = (hyper.to(up.dtype) @ up.transpose(1, 2)).view(b, -1, 4 * h, 4 * w)
+        return masks.float(), self.iou_prediction_head(iou_tok).float()
+
+    # -- the two paths ---------------------------------------------------------------------------------------------
+    def predict_masks(self, image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings):
+        dt = _dtype() if image_embeddings.is_cuda else torch.float32
+        shared = (image_embeddings.shape[0] == 1 and dense_prompt_embeddings.dim() == 4 and
+                  dense_prompt_embeddings.stride(0) == 0 and dense_prompt_embeddings.stride(2) == 0 and
+                  dense_prompt_embeddings.stride(3) == 0 and len(self.transformer.layers) == 2)
+        with torch.autocast(device_type=image_embeddings.device.type, dtype=dt, enabled=dt != torch.float32):
+            if shared:
+                return self._predict_masks_shared(image_embeddings, image_pe, sparse_prompt_embeddings,
+                                                  dense_prompt_embeddings)
+            return self._predict_masks_lib(image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings)
+
+    def _predict_masks_lib(self, image_embeddings, image_pe, sparse, dense):
+        """The reference's sequence (mask_decoder.py:106-143) on channels-last tokens."""
+        tokens = self._tokens(sparse)
+        B = tokens.shape[0]
+        _, c, h, w = image_embeddings.shape
+        keys = (torch.repeat_interleave(image_embeddings, B, dim=0) + dense).flatten(2).permute(0, 2, 1)
+        hs, keys = self.transformer.forward_tokens(keys, image_pe.flatten(2).permute(0, 2, 1), tokens)
+        ct1 = self.output_upscaling[0]
+        w1 = ct1.weight.reshape(c, -1)                                            # (C, (c1, dy, dx))
+        y0 = F.linear(keys, w1.t().to(keys.dtype), ct1.bias.repeat_interleave(4).to(keys.dtype))
+        return self._heads_out(hs, self._upscale(y0, B, h, w), B, h, w)
+
+    def _predict_masks_shared(self, image_embeddings, image_pe, sparse, dense):
+        """Every prompt sees the same image tokens at the input of layer 0 (see the module docstring)."""
+        tr = self.transformer
+        L0, L1, fin = tr.layers[0], tr.layers[1], tr.final_attn_token_to_image
+        tokens = self._tokens(sparse)
+        B = tokens.shape[0]
+        _, c, h, w = image_embeddings.shape
+        keys0 = (image_embeddings + dense[:1]).flatten(2).permute(0, 2, 1)        # (1, N, C)
+        pe = image_pe.flatten(2).permute(0, 2, 1)                                 # (1, N, C)
+        kp0 = keys0 + pe
+        # ---- layer 0: all image-side projections are per image -----------------------------------------------
+        ca, ci = L0.cross_attn_token_to_image, L0.cross_attn_image_to_token
+        queries = L0.token_side(tokens, tokens, ca.k_proj(kp0), ca.v_proj(keys0))
+        keys1 = L0.norm4(keys0 + ci.attend(ci.q_proj(kp0), ci.k_proj(queries + tokens), ci.v_proj(queries)))   # (B,N,C)
+        # ---- layer 1: one GEMM for [k | v | q] of the per-prompt image tokens; W pe terms per image -------------
+        ca, ci = L1.cross_attn_token_to_image, L1.cross_attn_image_to_token
+        d = ca.internal_dim
+        wcat = torch.cat([ca.k_proj.weight, ca.v_proj.weight, ci.q_proj.weight], 0)
+        bcat = torch.cat([ca.k_proj.bias, ca.v_proj.bias, ci.q_proj.bias], 0)
+        kvq = F.linear(keys1, wcat.to(keys1.dtype), bcat.to(keys1.dtype))
+        k_pe, q_pe = F.linear(pe, ca.k_proj.weight.to(pe.dtype)), F.linear(pe, ci.q_proj.weight.to(pe.dtype))
+        queries = L1.token_side(queries, tokens, kvq[..., :d] + k_pe, kvq[..., d:2 * d])
+        keys2 = L1.norm4(keys1 + ci.attend(kvq[..., 2 * d:] + q_pe, ci.k_proj(queries + tokens), ci.v_proj(queries)))
+        # ---- final token->image attention + first transposed conv: one GEMM on keys2 --------------------------------
+        ct1 = self.output_upscaling[0]
+        wcat = torch.cat([fin.k_proj.weight, fin.v_proj.weight, ct1.weight.reshape(c, -1).t()], 0)
+        bcat = torch.cat([fin.k_proj.bias, fin.v_proj.bias, ct1.bias.repeat_interleave(4)], 0)
+        kvu = F.linear(keys2, wcat.to(keys2.dtype), bcat.to(keys2.dtype))
+        k_pe = F.linear(pe, fin.k_proj.weight.to(pe.dtype))
+        hs = tr.norm_final_attn(queries + fin.attend(fin.q_proj(queries + tokens), kvu[..., :d] + k_pe, kvu[..., d:2 * d]))
+        return self._heads_out(hs, self._upscale(kvu[..., 2 * d:], B, h, w), B, h, w)

@@ -41,6 +41,8 @@ def seeded_tensor(name, shape, seed=1, dtype=torch.float32):
         return (1.0 + 0.1 * torch.randn(shape, generator=g)).to(dtype)
     if leaf == "scale":  # LinearAttention.scale, zero-initialised in the reference
         return (0.1 * torch.randn(shape, generator=g)).to(dtype)
+    if leaf == "positional_encoding_gaussian_matrix":  # SAM's random Fourier features: N(0,1) like the constructor
+        return torch.randn(shape, generator=g).to(dtype)
     if leaf == "gamma":  # LayerScale gains (DINOv2): positive, O(0.3) like the trained checkpoints' deeper blocks
         return (0.3 + 0.05 * torch.randn(shape, generator=g)).to(dtype)
     if leaf in ("rel_pos_h", "rel_pos_w"):

@@ -142,3 +142,24 @@ def random_boxes(P, H, W, g):
     w, h = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
     ok = (w != h) & (torch.minimum(w, h).float() * 224 / torch.maximum(w, h).float() >= 1.5)
     return boxes[ok]
+
+
+def sam_decoder_inputs(cfg, n_prompts, seed=1):
+    """Image embedding (1,C,h,w) like the encoder neck's output (LayerNorm2d-normalised scale), point prompts in
+    input-image pixels (a regular grid like the automatic mask generator's, plus label-0 and two-point cases) and
+    xyxy box prompts."""
+    g = _g(seed)
+    emb = torch.randn(1, cfg["dim"], cfg["emb"], cfg["emb"], generator=g)
+    side = int(n_prompts ** 0.5) or 1
+    off = 1.0 / (2 * side)
+    gx = torch.linspace(off, 1 - off, side)
+    grid = torch.stack(torch.meshgrid(gx, gx, indexing="xy"), -1).reshape(-1, 2)[:n_prompts] * cfg["img"]
+    if grid.shape[0] < n_prompts:
+        grid = torch.cat([grid, torch.rand(n_prompts - grid.shape[0], 2, generator=g) * cfg["img"]])
+    points = grid.unsqueeze(1)                                       # (B,1,2): one foreground point per prompt
+    labels = torch.ones(n_prompts, 1)
+    points2 = torch.rand(3, 2, 2, generator=g) * cfg["img"]          # two points, second one background
+    labels2 = torch.tensor([[1.0, 0.0]]).repeat(3, 1)
+    xy = torch.rand(3, 2, generator=g) * cfg["img"] * 0.5
+    boxes = torch.cat([xy, xy + 0.1 * cfg["img"] + torch.rand(3, 2, generator=g) * cfg["img"] * 0.4], dim=1)
+    return dict(emb=emb, points=points, labels=labels, points2=points2, labels2=labels2, boxes=boxes)

@@ -11,6 +11,7 @@ from oracle import ism as oism
 from oracle import pem as opem
 from oracle import pn2 as opn2
 from oracle import sam as osam
+from oracle import sam_decoder as osd
 from sam6d_amd.utils import seeded, synth
 from tests import util
 
@@ -125,6 +126,42 @@ def test_ism_scoring_matches_reference():
 
 
 # ----------------------------------------------------------------------------- PN2 (no reference vectors exist)
+def _samdec_case(cfg_name):
+    g = util.golden("sam_decoder.npz")
+    c = ast.literal_eval(str(g["case"]))
+    cfg = osd.MINI if cfg_name == "mini" else osd.SAM
+    W = seeded.seeded_state(util.shapes_from_golden(g, cfg_name + "_keys", cfg_name + "_shapes"), c["weight_seed"])
+    inp = synth.sam_decoder_inputs(cfg, c["n_mini"] if cfg_name == "mini" else c["n_full"], c["input_seed"])
+    return g, c, cfg, W, inp
+
+
+def test_sam_decoder_mini_matches_reference():
+    """Prompt encoder (points, two-point, box prompts) + two-way mask decoder + postprocess, small config."""
+    g, c, cfg, W, inp = _samdec_case("mini")
+    with torch.no_grad():
+        pe = osd.dense_pe(W, cfg)
+        np.testing.assert_allclose(pe.numpy(), g["mini_dense_pe"], rtol=1e-5, atol=1e-6)
+        for tag, kw, multi in (("", dict(points=inp["points"], labels=inp["labels"]), True),
+                               ("2", dict(points=inp["points2"], labels=inp["labels2"]), False),
+                               ("_box", dict(boxes=inp["boxes"]), True)):
+            s, d = osd.prompt_encoder(W, cfg, **kw)
+            np.testing.assert_allclose(s.numpy(), g["mini_sparse" + tag], rtol=1e-5, atol=1e-6)
+            mk, iou = osd.mask_decoder(W, cfg, inp["emb"], pe, s, d, multi)
+            np.testing.assert_allclose(mk.numpy(), g["mini_masks" + tag], rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(iou.numpy(), g["mini_iou" + tag], rtol=1e-4, atol=1e-5)
+        post = osd.postprocess_masks(torch.from_numpy(g["mini_masks"][:3]), cfg["img"], c["mini_input_size"], c["mini_orig"])
+    np.testing.assert_allclose(post.numpy(), g["mini_post"], rtol=1e-6, atol=1e-7)
+
+
+def test_sam_decoder_released_config_matches_reference():
+    g, c, cfg, W, inp = _samdec_case("sam")
+    with torch.no_grad():
+        s, d = osd.prompt_encoder(W, cfg, inp["points"], inp["labels"])
+        mk, iou = osd.mask_decoder(W, cfg, inp["emb"], osd.dense_pe(W, cfg), s, d)
+    np.testing.assert_allclose(iou.numpy(), g["sam_iou"], rtol=1e-4, atol=1e-5)
+    util.assert_digest_close(mk, g["sam_masks_sum"], g["sam_masks_smp"], 211, 1e-4, 1e-5, "low-res mask logits")
+
+
 def _dino_case():
     g = util.golden("dinov2.npz")
     c = ast.literal_eval(str(g["case"]))

@@ -1,0 +1,51 @@
+"""Stage timing of the SAM prompt encoder + mask decoder (section 8f-2) at the automatic-mask-generator shape:
+1024 point prompts per frame against one (1,256,64,64) image embedding (run on the GPU box).
+usage: sam_decoder_time.py [n_prompts] [chunk]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from oracle import sam_decoder as osd  # noqa: E402  (config dict only)
+from sam6d_amd.utils import seeded, synth  # noqa: E402
+from tests.test_host_sam_decoder import build  # noqa: E402
+
+
+def ev(fn, n):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    cfg = osd.SAM
+    m = seeded.load_seeded(build(cfg), 1).cuda()
+    inp = {k: v.cuda() for k, v in synth.sam_decoder_inputs(cfg, n, 3).items()}
+
+    def frame(lib):
+        outs = []
+        with torch.no_grad():
+            for a in range(0, n, chunk):
+                s, d = m.prompt_encoder(points=(inp["points"][a:a + chunk], inp["labels"][a:a + chunk]), boxes=None, masks=None)
+                if lib:
+                    d = d.contiguous()
+                outs.append(m.mask_decoder(image_embeddings=inp["emb"], image_pe=m.prompt_encoder.get_dense_pe(),
+                                           sparse_prompt_embeddings=s, dense_prompt_embeddings=d, multimask_output=True))
+        return outs
+    for dt in ("bf16", "fp32"):
+        os.environ["S6D_SAM_DECODER_DTYPE"] = dt
+        for lib in (False, True):
+            if lib and chunk > 64:
+                continue                          # the as-written path materialises (chunk,4096,256) repeats: keep it small
+            ms = ev(lambda: frame(lib), 3)
+            print(f"{dt} {'reference op sequence' if lib else 'restructured'}: {n} prompts, chunk {chunk}: {ms:.2f} ms/frame "
+                  f"-> {3.6e9 * n / ms / 1e9:.0f} TFLOP/s as-written-equivalent", flush=True)

@@ -231,6 +231,28 @@ int s6d_crop_resize_pad_f32(const unsigned char *image, const float *masks, cons
                             int T, const float *mean3_host, const float *std3_host, float *out_rgb, float *out_mask,
                             void *stream);
 
+/* SAM mask decoder, image -> token cross attention of a two-way block, fused with out_proj, the residual add and
+ * norm4:  out = LayerNorm(resid + softmax(q k^T / sqrt(16)) (v W_o^T) + b_o)  for every image token, 8 heads x 16, at
+ * most 8 prompt tokens.  q (1|B,N,128) bf16 projected image tokens, row stride q_ld elements (+ q_add (N,128) bf16, e.g.
+ * W_q pe, or NULL);
+ * kexp (B,64,128) bf16: row h*8+t = k_t / 4 in head h's 16 columns, zeros elsewhere; vpt (B,256,64) bf16:
+ * vpt[n][h*8+t] = sum_d v_t[h*16+d] W_o[n][h*16+d]; resid (1|B,N,256) bf16; out_bias, ln_w, ln_b (256) f32 ->
+ * out (B,N,256) bf16.  q_shared / resid_shared: that operand has no batch dimension (layer 0).
+ * ref: TwoWayAttentionBlock.forward step (4), segment_anything/modeling/transformer.py:174-180; Attention.forward
+ * :222-240. */
+int s6d_samdec_img2tok_bf16(const void *q, const void *q_add, const void *kexp, const void *vpt, const void *resid,
+                            const float *out_bias, const float *ln_w, const float *ln_b, float ln_eps, int B, int N,
+                            int n_tok, int q_ld, int q_shared, int resid_shared, void *out, void *stream);
+
+/* SAM mask decoder, output head after the first transposed conv: LayerNorm2d + GELU, second 2x2/2 transposed conv,
+ * GELU, and the hypernetwork product, per output pixel.  y0 (B,h*w,4*64) bf16, row stride y_ld elements = first
+ * transposed conv as a GEMM with columns ordered (dy,dx,c); w2t (128,64) bf16: row (dy2*2+dx2)*32+ch; hyper (B,M,32) f32, M <= 4 ->
+ * masks (B,M,4h,4w) f32 logits.  GELU is the exact (erf) form, erf to 1.5e-7.
+ * ref: MaskDecoder.predict_masks, segment_anything/modeling/mask_decoder.py:126-139 (output_upscaling :53-59). */
+int s6d_samdec_upscale_heads_bf16(const void *y0, const float *ln_w, const float *ln_b, float ln_eps, const void *w2t,
+                                  const float *b2, const float *hyper, int B, int M, int h, int w, int y_ld,
+                                  float *masks, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,325 @@
+// SAM two-way mask decoder, image-side kernels (gfx950) -- the per-prompt work of SURVEY.md section 8f-2.
+//
+// Reference: segment_anything/modeling/transformer.py TwoWayAttentionBlock.forward :151-182 step (4)
+//     keys = norm4(keys + cross_attn_image_to_token(q = keys + key_pe, k = queries + query_pe, v = queries))
+// and mask_decoder.py MaskDecoder.predict_masks :126-139
+//     upscaled = output_upscaling(src) ; masks = hyper_in @ upscaled.view(b, c, h*w)
+// As written both stream (B, 4096, 256) fp32 token tensors through ~10 elementwise / GEMM kernels per layer.
+//
+// img2tok_kernel: every image token attends to only n_tok <= 8 prompt tokens per head, so
+//     out_proj(softmax(q k^T / 4) v) = softmax(q k^T / 4) (v W_o^T)
+// is, per prompt, a (N x 64) x (64 x 256) product whose left factor is the softmax itself: scores by MFMA against
+// a block-diagonal expansion of the 8 x 8 (head, token) keys, softmax in the accumulator layout (two lanes per
+// (token, head): one DPP exchange), the probabilities re-used in place as the B operand of the value product,
+// then + bias + residual and LayerNorm over the 256 channels in registers.  One read of q (and the residual), one
+// write of the new keys: HBM-bound.
+//
+// upscale_heads_kernel: LayerNorm2d + GELU, the second 2x2/2 transposed conv (as a 64 -> 4x32 GEMM), GELU and the
+// hypernetwork product per output pixel, from the first transposed conv's GEMM output: the (B, 65536, 32) upscaled
+// embedding is never materialised.
+#include "s6d_common.h"
+
+namespace s6d {
+
+typedef unsigned short u16;
+typedef __attribute__((ext_vector_type(8))) __bf16 sd_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float sd_f32x4;
+
+__device__ __forceinline__ float sd_bf2f(u16 h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ u16 sd_f2bf(float f) {
+  union { __bf16 b; u16 u; } x;
+  x.b = (__bf16)f;
+  return x.u;
+}
+
+constexpr int kSdC = 256;        // embedding dim
+constexpr int kSdD = 128;        // internal dim of the cross attentions (downsample rate 2)
+constexpr int kSdJ = 64;         // (head, token slot) pairs: 8 heads x 8 slots
+constexpr int kSdKRow = kSdD + 8;   // LDS row stride of the expanded keys (bf16): 272 B, conflict-free b128 reads
+constexpr int kSdVRow = kSdJ + 8;   // LDS row stride of the folded values (bf16): 144 B
+
+// q (Bq,N,128) bf16 with row stride q_ld (+ q_add (N,128) bf16 or null), kexp (B,64,128) bf16: row j = h*8+t holds scale * k_t in the 16
+// columns of head h, zeros elsewhere; vpt (B,256,64) bf16: vpt[n][j] = (v_t W_o^T)[n] restricted to head h;
+// resid (Br,N,256) bf16; obias, gamma, beta (256) f32 -> out (B,N,256) bf16.  Bq, Br in {1, B}.
+__global__ __launch_bounds__(256, 2) void img2tok_kernel(const u16 *__restrict__ q, const u16 *__restrict__ q_add,
+                                                      const u16 *__restrict__ kexp, const u16 *__restrict__ vpt,
+                                                      const u16 *__restrict__ resid, const float *__restrict__ obias,
+                                                      const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                      float eps, int N, int n_tok, int q_ld, long q_bstride,
+                                                      long r_bstride, u16 *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char sd_smem[];
+  u16 *Kl = reinterpret_cast<u16 *>(sd_smem);                       // [64][kSdKRow]
+  u16 *Vl = Kl + kSdJ * kSdKRow;                                    // [256][kSdVRow]
+  float *pl = reinterpret_cast<float *>(Vl + kSdC * kSdVRow);       // [3][256]: obias, gamma, beta
+  const int b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int c = lane & 15, g = lane >> 4;
+  for (int i = tid; i < kSdJ * kSdD / 8; i += 256) {                // 16-byte chunks
+    const int row = i / (kSdD / 8), ch = i - row * (kSdD / 8);
+    *reinterpret_cast<uint4 *>(Kl + row * kSdKRow + ch * 8) =
+        *reinterpret_cast<const uint4 *>(kexp + ((size_t)b * kSdJ + row) * kSdD + ch * 8);
+  }
+  for (int i = tid; i < kSdC * kSdJ / 8; i += 256) {
+    const int row = i / (kSdJ / 8), ch = i - row * (kSdJ / 8);
+    *reinterpret_cast<uint4 *>(Vl + row * kSdVRow + ch * 8) =
+        *reinterpret_cast<const uint4 *>(vpt + ((size_t)b * kSdC + row) * kSdJ + ch * 8);
+  }
+  pl[tid] = obias[tid];
+  pl[256 + tid] = gamma[tid];
+  pl[512 + tid] = beta[tid];
+  __syncthreads();
+  const u16 *qb = q + (size_t)b * q_bstride, *rb = resid + (size_t)b * r_bstride;
+  u16 *ob = out + (size_t)b * N * kSdC;
+  // this workgroup's tokens: gridDim.x workgroups share the N tokens of the prompt in 16-token strips
+  const int nstrip = N / 16;
+  for (int strip = blockIdx.x * 4 + wave; strip < nstrip; strip += gridDim.x * 4) {
+    const int tok = strip * 16 + c;
+    // ---- scores^T (64 x 16) = Kexp (64 x 128) . Q^T ------------------------------------------------------------
+    sd_f32x4 s[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) s[t] = sd_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      union { uint4 u; sd_bf16x8 v; u16 h[8]; } qa;
+      qa.u = *reinterpret_cast<const uint4 *>(qb + (size_t)tok * q_ld + ks * 32 + g * 8);
+      if (q_add) {                                                   // + W_q pe (shared by every prompt)
+        union { uint4 u; u16 h[8]; } pa;
+        pa.u = *reinterpret_cast<const uint4 *>(q_add + (size_t)tok * kSdD + ks * 32 + g * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qa.h[e] = sd_f2bf(sd_bf2f(qa.h[e]) + sd_bf2f(pa.h[e]));
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const sd_bf16x8 ka = *reinterpret_cast<const sd_bf16x8 *>(Kl + (t * 16 + c) * kSdKRow + ks * 32 + g * 8);
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qa.v, s[t], 0, 0, 0);
+      }
+    }
+    // ---- softmax over the 8 token slots of a head: row j = tile*16 + g*4 + r = h*8 + slot -> h = 2*tile + (g>>1),
+    //      slot = (g&1)*4 + r: four registers here and four in the lane 16 away --------------------------------------
+    union { sd_bf16x8 v; u16 h[8]; } pb[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = ((g & 1) * 4 + r < n_tok) ? s[t][r] : -1e30f;
+      float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+      m = fmaxf(m, __shfl_xor(m, 16));
+      float e[4], sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        e[r] = __expf(v[r] - m);
+        sum += e[r];
+      }
+      sum += __shfl_xor(sum, 16);
+      const float inv = 1.0f / sum;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pb[t >> 1].h[(t & 1) * 4 + r] = sd_f2bf(e[r] * inv);
+    }
+    // ---- O^T (256 x 16) = V'^T (256 x 64) . P^T: k-step ks covers j in [32ks, 32ks+32); element e < 4 is
+    //      j = 32ks + g*4 + e, e >= 4 is j = 32ks + 16 + g*4 + (e-4): exactly what pb[ks] already holds ---------------
+    sd_f32x4 o[16];
+#pragma unroll
+    for (int nt = 0; nt < 16; ++nt) {
+      o[nt] = sd_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        union { sd_bf16x8 v; uint2 d[2]; } va;
+        const u16 *vr = Vl + (nt * 16 + c) * kSdVRow + ks * 32 + g * 4;
+        va.d[0] = *reinterpret_cast<const uint2 *>(vr);
+        va.d[1] = *reinterpret_cast<const uint2 *>(vr + 16);
+        o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va.v, pb[ks].v, o[nt], 0, 0, 0);
+      }
+      if ((nt & 3) == 3) __builtin_amdgcn_sched_barrier(0);         // keep the fragment reads of later tiles from piling up
+    }
+    // ---- + out_proj bias + residual, LayerNorm over the 256 channels of token c (channel n = nt*16 + g*4 + r:
+    //      64 here, the rest in the lanes 16 / 32 / 48 away) -----------------------------------------------------------
+    float sum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 16; ++nt) {
+      union { uint2 u; u16 h[4]; } rr;
+      rr.u = *reinterpret_cast<const uint2 *>(rb + (size_t)tok * kSdC + nt * 16 + g * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        o[nt][r] += pl[nt * 16 + g * 4 + r] + sd_bf2f(rr.h[r]);
+        sum += o[nt][r];
+      }
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / kSdC);
+    float var = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 16; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = o[nt][r] - mean;
+        var += d * d;
+      }
+    var += __shfl_xor(var, 16);
+    var += __shfl_xor(var, 32);
+    const float rstd = rsqrtf(var * (1.0f / kSdC) + eps);
+#pragma unroll
+    for (int nt = 0; nt < 16; ++nt) {
+      union { uint2 u; u16 h[4]; } w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = nt * 16 + g * 4 + r;
+        w.h[r] = sd_f2bf((o[nt][r] - mean) * rstd * pl[256 + n] + pl[512 + n]);
+      }
+      *reinterpret_cast<uint2 *>(ob + (size_t)tok * kSdC + nt * 16 + g * 4) = w.u;
+    }
+  }
+}
+
+// erf by Abramowitz & Stegun 7.1.26 (|error| < 1.5e-7, far below the bf16 grid of the inputs): exact-GELU semantics
+__device__ __forceinline__ float sd_gelu(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float p = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - p * __expf(-z * z);
+  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+
+constexpr int kUpC1 = 64, kUpC2 = 32;
+constexpr int kUpWRow = kUpC1 + 8;   // LDS row stride of W2^T (bf16): 144 B
+
+// y0 (B,N,4*64) bf16, row stride y_ld: first transposed conv as a GEMM, columns ordered (dy, dx, c);  ln_w, ln_b (64) f32;
+// w2t (128,64) bf16: row (dy2*2+dx2)*32 + ch of the second transposed conv, transposed; b2 (32) f32;
+// hyper (B,M,32) f32 -> masks (B,M,4h,4w) f32.
+__global__ __launch_bounds__(256, 2) void upscale_heads_kernel(const u16 *__restrict__ y0, const float *__restrict__ ln_w,
+                                                            const float *__restrict__ ln_b, float ln_eps,
+                                                            const u16 *__restrict__ w2t, const float *__restrict__ b2,
+                                                            const float *__restrict__ hyper, int M, int h, int w,
+                                                            int y_ld, float *__restrict__ masks) {
+  __shared__ __attribute__((aligned(16))) u16 Wl[4 * kUpC2 * kUpWRow];
+  __shared__ float hy[4 * kUpC2], lw[kUpC1], lb[kUpC1], bb[kUpC2];
+  const int b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int c = lane & 15, g = lane >> 4;
+  const int N = h * w;
+  for (int i = tid; i < 4 * kUpC2 * kUpC1 / 8; i += 256) {
+    const int row = i / (kUpC1 / 8), ch = i - row * (kUpC1 / 8);
+    *reinterpret_cast<uint4 *>(Wl + row * kUpWRow + ch * 8) = *reinterpret_cast<const uint4 *>(w2t + row * kUpC1 + ch * 8);
+  }
+  if (tid < 4 * kUpC2) hy[tid] = (tid < M * kUpC2) ? hyper[(size_t)b * M * kUpC2 + tid] : 0.f;
+  if (tid < kUpC1) { lw[tid] = ln_w[tid]; lb[tid] = ln_b[tid]; }
+  if (tid < kUpC2) bb[tid] = b2[tid];
+  __syncthreads();
+  // a strip = 16 tokens x one sub-pixel (dy, dx): 4N/16 strips per prompt
+  const int nstrip = N / 16 * 4;
+  for (int strip = blockIdx.x * 4 + wave; strip < nstrip; strip += gridDim.x * 4) {
+    const int sp = strip & 3, tok = (strip >> 2) * 16 + c;           // token of this lane's column
+    // ---- LayerNorm2d + GELU on the 64-vector of (token, sub-pixel): 16 channels here, 48 in the lanes 16/32/48 away
+    float x[2][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      union { uint4 u; u16 hh[8]; } a;
+      a.u = *reinterpret_cast<const uint4 *>(y0 + ((size_t)b * N + tok) * y_ld + sp * kUpC1 + ks * 32 + g * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        x[ks][e] = sd_bf2f(a.hh[e]);
+        sum += x[ks][e];
+      }
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / kUpC1);
+    float var = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = x[ks][e] - mean;
+        var += d * d;
+      }
+    var += __shfl_xor(var, 16);
+    var += __shfl_xor(var, 32);
+    const float rstd = __frsqrt_rn(var * (1.0f / kUpC1) + ln_eps);
+    union { sd_bf16x8 v; u16 hh[8]; } ua[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ch = ks * 32 + g * 8 + e;
+        ua[ks].hh[e] = sd_f2bf(sd_gelu((x[ks][e] - mean) * rstd * lw[ch] + lb[ch]));
+      }
+    // ---- second transposed conv: V^T (128 x 16) = W2^T (128 x 64) . U^T; row n = s2*32 + ch, s2 = dy2*2 + dx2 -----
+    float logit[4][4];                                               // [s2][mask]: partial over this lane's 8 channels
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) logit[s2][m] = 0.f;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int nt = s2 * 2 + half;
+        sd_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const sd_bf16x8 wa = *reinterpret_cast<const sd_bf16x8 *>(Wl + (nt * 16 + c) * kUpWRow + ks * 32 + g * 8);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, ua[ks].v, acc, 0, 0, 0);
+        }
+        // C layout: row n_local = g*4 + r -> ch = half*16 + g*4 + r, col = token c
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ch = half * 16 + g * 4 + r;
+          const float v = sd_gelu(acc[r] + bb[ch]);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) logit[s2][m] += v * hy[m * kUpC2 + ch];
+        }
+      }
+    }
+    // ---- fold the four channel groups (lanes 16 / 32 / 48 away), then lane group g writes mask g ------------------
+    float mine[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        float v = logit[s2][m];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (m == g) mine[s2] = v;
+      }
+    if (g < M) {
+      const int ty = tok / w, tx = tok - ty * w;
+      const int py = 4 * ty + 2 * (sp >> 1), px = 4 * tx + 2 * (sp & 1);
+      float *dst = masks + (((size_t)b * M + g) * (4 * h) + py) * (size_t)(4 * w) + px;
+      *reinterpret_cast<float2 *>(dst) = make_float2(mine[0], mine[1]);
+      *reinterpret_cast<float2 *>(dst + 4 * w) = make_float2(mine[2], mine[3]);
+    }
+  }
+}
+
+}  // namespace s6d
+
+using namespace s6d;
+
+extern "C" int s6d_samdec_img2tok_bf16(const void *q, const void *q_add, const void *kexp, const void *vpt,
+                                       const void *resid, const float *out_bias, const float *ln_w, const float *ln_b,
+                                       float ln_eps, int B, int N, int n_tok, int q_ld, int q_shared, int resid_shared,
+                                       void *out, void *stream) {
+  if (B < 0 || N <= 0 || (N % 16) != 0 || n_tok <= 0 || n_tok > 8 || q_ld < kSdD || (q_ld % 8) != 0) return S6D_EINVAL;
+  if (B == 0) return S6D_OK;
+  if (!q || !kexp || !vpt || !resid || !out_bias || !ln_w || !ln_b || !out) return S6D_EINVAL;
+  const size_t lds = (size_t)(kSdJ * kSdKRow + kSdC * kSdVRow) * 2 + 3 * 256 * 4;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&img2tok_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  const int nstrip = N / 16;
+  const int gx = nstrip >= 64 ? 16 : (nstrip + 3) / 4;              // 16 workgroups x 4 waves x 4 strips at N = 4096
+  hipLaunchKernelGGL(img2tok_kernel, dim3(gx, B), dim3(256), lds, as_stream(stream), (const u16 *)q, (const u16 *)q_add,
+                     (const u16 *)kexp, (const u16 *)vpt, (const u16 *)resid, out_bias, ln_w, ln_b, ln_eps, N, n_tok, q_ld,
+                     q_shared ? 0L : (long)N * q_ld, resid_shared ? 0L : (long)N * kSdC, (u16 *)out);
+  return launch_status();
+}
+
+extern "C" int s6d_samdec_upscale_heads_bf16(const void *y0, const float *ln_w, const float *ln_b, float ln_eps,
+                                             const void *w2t, const float *b2, const float *hyper, int B, int M, int h,
+                                             int w, int y_ld, float *masks, void *stream) {
+  if (B < 0 || M <= 0 || M > 4 || h <= 0 || w <= 0 || ((h * w) % 16) != 0 || y_ld < 4 * kUpC1 || (y_ld % 8) != 0)
+    return S6D_EINVAL;
+  if (B == 0) return S6D_OK;
+  if (!y0 || !ln_w || !ln_b || !w2t || !b2 || !hyper || !masks) return S6D_EINVAL;
+  const int nstrip = h * w / 16 * 4;
+  const int gx = nstrip >= 256 ? 64 : (nstrip + 3) / 4;
+  hipLaunchKernelGGL(upscale_heads_kernel, dim3(gx, B), dim3(256), 0, as_stream(stream), (const u16 *)y0, ln_w, ln_b,
+                     ln_eps, (const u16 *)w2t, b2, hyper, M, h, w, y_ld, masks);
+  return launch_status();
+}

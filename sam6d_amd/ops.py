@@ -184,6 +184,53 @@ def crop_resize_pad(image_u8, masks, params, target, mean, std, rgb=True, mask=T
     return o_rgb, o_mask
 
 
+def samdec_img2tok(q, q_add, kexp, vpt, resid, out_bias, ln_w, ln_b, eps, n_tok):
+    """Image->token cross attention + folded out_proj + residual + LayerNorm of SAM's two-way block.
+    q (1|B,N,128) bf16 (last-dim slice of a wider tensor allowed), q_add (N,128) bf16 or None, kexp (B,64,128) bf16,
+    vpt (B,256,64) bf16, resid (1|B,N,256) bf16 -> (B,N,256) bf16."""
+    B, N = kexp.shape[0], resid.shape[1]
+    for t, nm in ((kexp, "kexp"), (vpt, "vpt"), (resid, "resid")):
+        _chk(t, torch.bfloat16, nm, 3)
+    for t, nm in ((out_bias, "out_bias"), (ln_w, "ln_w"), (ln_b, "ln_b")):
+        _chk(t, torch.float32, nm, 1)
+    if q.dtype != torch.bfloat16 or q.dim() != 3 or q.shape[-1] != 128 or q.stride(2) != 1 or not q.is_cuda:
+        raise RuntimeError("q must be a (.,N,128) bfloat16 CUDA tensor with unit channel stride")
+    q_ld = q.stride(1)
+    if q.shape[0] > 1 and q.stride(0) != N * q_ld:
+        raise RuntimeError("q batch stride must be N * row stride")
+    if q_add is not None:
+        _chk(q_add, torch.bfloat16, "q_add", 2)
+    if tuple(kexp.shape) != (B, 64, 128) or tuple(vpt.shape) != (B, 256, 64) or resid.shape[2] != 256 or q.shape[1] != N:
+        raise RuntimeError("samdec_img2tok: shape mismatch")
+    out = torch.empty(B, N, 256, dtype=torch.bfloat16, device=kexp.device)
+    _call("s6d_samdec_img2tok_bf16", _ptr(q), _ptr(q_add) if q_add is not None else _vp(0), _ptr(kexp), _ptr(vpt),
+          _ptr(resid), _ptr(out_bias), _ptr(ln_w), _ptr(ln_b), ctypes.c_float(eps), B, N, int(n_tok), int(q_ld),
+          1 if q.shape[0] == 1 and B > 1 else 0, 1 if resid.shape[0] == 1 and B > 1 else 0, _ptr(out), _stream())
+    return out
+
+
+def samdec_upscale_heads(y0, ln_w, ln_b, eps, w2t, b2, hyper, h, w):
+    """Output head of SAM's mask decoder after the first transposed conv (columns ordered (dy,dx,c)).
+    y0 (B,h*w,256) bf16 (last-dim slice allowed), w2t (128,64) bf16, hyper (B,M,32) f32 -> masks (B,M,4h,4w) f32."""
+    if y0.dtype != torch.bfloat16 or y0.dim() != 3 or y0.shape[-1] != 256 or y0.stride(2) != 1 or not y0.is_cuda:
+        raise RuntimeError("y0 must be a (B,h*w,256) bfloat16 CUDA tensor with unit channel stride")
+    B, N = y0.shape[0], y0.shape[1]
+    y_ld = y0.stride(1)
+    if B > 1 and y0.stride(0) != N * y_ld:
+        raise RuntimeError("y0 batch stride must be N * row stride")
+    _chk(w2t, torch.bfloat16, "w2t", 2)
+    _chk(hyper, torch.float32, "hyper", 3)
+    for t, nm in ((ln_w, "ln_w"), (ln_b, "ln_b"), (b2, "b2")):
+        _chk(t, torch.float32, nm, 1)
+    M = hyper.shape[1]
+    if N != h * w or tuple(w2t.shape) != (128, 64) or hyper.shape[2] != 32 or hyper.shape[0] != B:
+        raise RuntimeError("samdec_upscale_heads: shape mismatch")
+    masks = torch.empty(B, M, 4 * h, 4 * w, dtype=torch.float32, device=y0.device)
+    _call("s6d_samdec_upscale_heads_bf16", _ptr(y0), _ptr(ln_w), _ptr(ln_b), ctypes.c_float(eps), _ptr(w2t), _ptr(b2),
+          _ptr(hyper), B, M, int(h), int(w), int(y_ld), _ptr(masks), _stream())
+    return masks
+
+
 def upsample_gather(up, choose, H, W, C):
     """up (B,196,16*C) f32, choose (B,n) int64 -> (B,n,C): bilinear x4 of the pixel-shuffled map at chosen pixels."""
     _chk(up, torch.float32, "up", 3)
@@ -424,7 +471,7 @@ def have(name):
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
                "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_f32",
-               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "crop_resize_pad": "s6d_crop_resize_pad_f32", "mha": "s6d_mha_f32",
+               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "crop_resize_pad": "s6d_crop_resize_pad_f32", "samdec_img2tok": "s6d_samdec_img2tok_bf16", "samdec_upscale_heads": "s6d_samdec_upscale_heads_bf16", "mha": "s6d_mha_f32",
                "linear_attn_focus": "s6d_linear_attn_focus_f32", "project_bbox": "s6d_project_bbox_f32"}.get(name)
         import os
         disabled = name in os.environ.get("S6D_DISABLE_FUSED", "").split(",")

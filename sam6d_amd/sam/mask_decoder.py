@@ -30,6 +30,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
 from .image_encoder import LayerNorm2d, MLPBlock
 
 
@@ -285,6 +286,9 @@ class MaskDecoder(nn.Module):
                   dense_prompt_embeddings.stride(0) == 0 and dense_prompt_embeddings.stride(2) == 0 and
                   dense_prompt_embeddings.stride(3) == 0 and len(self.transformer.layers) == 2)
         with torch.autocast(device_type=image_embeddings.device.type, dtype=dt, enabled=dt != torch.float32):
+            if shared and dt == torch.bfloat16 and self._fusable(image_embeddings, sparse_prompt_embeddings):
+                return self._predict_masks_fused(image_embeddings, image_pe, sparse_prompt_embeddings,
+                                                 dense_prompt_embeddings)
             if shared:
                 return self._predict_masks_shared(image_embeddings, image_pe, sparse_prompt_embeddings,
                                                   dense_prompt_embeddings)
@@ -333,3 +337,96 @@ class MaskDecoder(nn.Module):
         k_pe = F.linear(pe, fin.k_proj.weight.to(pe.dtype))
         hs = tr.norm_final_attn(queries + fin.attend(fin.q_proj(queries + tokens), kvu[..., :d] + k_pe, kvu[..., d:2 * d]))
         return self._heads_out(hs, self._upscale(kvu[..., 2 * d:], B, h, w), B, h, w)
+
+    # -- restructured path on the gfx950 kernels -------------------------------------------------------------------------
+    def _fusable(self, emb, sparse):
+        tr = self.transformer
+        ci = tr.layers[0].cross_attn_image_to_token
+        return (emb.is_cuda and self.transformer_dim == 256 and tr.num_heads == 8 and ci.internal_dim == 128 and
+                self.num_mask_tokens + 1 + sparse.shape[1] <= 8 and self.num_mask_tokens <= 4 and
+                (emb.shape[2] * emb.shape[3]) % 16 == 0 and ops.have("samdec_img2tok") and ops.have("samdec_upscale_heads"))
+
+    def _prep(self, pe):
+        """Weight-only (and positional-encoding-only) operands of the fused path, cached per weight version."""
+        tr = self.transformer
+        L1, fin = tr.layers[1], tr.final_attn_token_to_image
+        ct1, ln, _, ct2, _ = self.output_upscaling
+        srcs = [L1.cross_attn_token_to_image.k_proj.weight, L1.cross_attn_token_to_image.v_proj.weight,
+                L1.cross_attn_image_to_token.q_proj.weight, fin.k_proj.weight, fin.v_proj.weight, ct1.weight, ct2.weight,
+                ln.weight, pe]
+        key = tuple((t._version, t.data_ptr()) for t in srcs)
+        c = getattr(self, "_s6d_prep", None)
+        if c is None or c[0] != key:
+            with torch.no_grad(), torch.autocast(device_type="cuda", enabled=False):
+                bf = torch.bfloat16
+                ca, ci = L1.cross_attn_token_to_image, L1.cross_attn_image_to_token
+                C = self.transformer_dim
+                pe32 = pe.float()
+                d = dict(
+                    w_kvq=torch.cat([ca.k_proj.weight, ca.v_proj.weight, ci.q_proj.weight], 0).to(bf).contiguous(),
+                    b_kvq=torch.cat([ca.k_proj.bias, ca.v_proj.bias, ci.q_proj.bias], 0).to(bf).contiguous(),
+                    kpe1=F.linear(pe32, ca.k_proj.weight.float()).to(bf).contiguous()[0],
+                    qpe1=F.linear(pe32, ci.q_proj.weight.float()).to(bf).contiguous()[0],
+                    # first transposed conv as GEMM rows ordered (dy, dx, c): each sub-pixel's 64 channels contiguous
+                    w_kvu=torch.cat([fin.k_proj.weight, fin.v_proj.weight,
+                                     ct1.weight.permute(2, 3, 1, 0).reshape(-1, C)], 0).to(bf).contiguous(),
+                    b_kvu=torch.cat([fin.k_proj.bias, fin.v_proj.bias, ct1.bias.repeat(4)], 0).to(bf).contiguous(),
+                    kpef=F.linear(pe32, fin.k_proj.weight.float()).to(bf).contiguous()[0],
+                    w2t=ct2.weight.permute(2, 3, 1, 0).reshape(4 * ct2.out_channels, ct2.in_channels).to(bf).contiguous(),
+                    b2=ct2.bias.float().contiguous(), ln_w=ln.weight.float().contiguous(), ln_b=ln.bias.float().contiguous())
+            c = (key, d)
+            self._s6d_prep = c
+        return c[1]
+
+    @staticmethod
+    def _expand(att, queries, tokens):
+        """Operands of s6d_samdec_img2tok_bf16 from the prompt tokens: block-diagonal scaled keys (B,64,128) and the
+        values with out_proj folded in (B,256,64); slot j = head * 8 + token."""
+        B, T, _ = queries.shape
+        H, hd = att.num_heads, att.internal_dim // att.num_heads
+        kt = (att.k_proj(queries + tokens).float() / math.sqrt(hd)).view(B, T, H, hd)
+        vt = att.v_proj(queries).float().view(B, T, H, hd)
+        eye = torch.eye(H, device=kt.device, dtype=kt.dtype)
+        kexp = F.pad(torch.einsum("bthd,hg->bhtgd", kt, eye), (0, 0, 0, 0, 0, 8 - T)).reshape(B, 8 * H, H * hd)
+        wo = att.out_proj.weight.float().view(-1, H, hd)
+        vpt = F.pad(torch.einsum("bthd,nhd->bnht", vt, wo), (0, 8 - T)).reshape(B, wo.shape[0], 8 * H)
+        return kexp.to(torch.bfloat16).contiguous(), vpt.to(torch.bfloat16).contiguous()
+
+    def _predict_masks_fused(self, image_embeddings, image_pe, sparse, dense):
+        """_predict_masks_shared with the per-prompt image-side work on the fused kernels: bf16 token tensors, one
+        kernel per image->token attention block (incl. out_proj, residual, norm4), one for the whole output head."""
+        tr = self.transformer
+        L0, L1, fin = tr.layers[0], tr.layers[1], tr.final_attn_token_to_image
+        bf = torch.bfloat16
+        tokens = self._tokens(sparse)
+        B, T = tokens.shape[0], tokens.shape[1]
+        _, c, h, w = image_embeddings.shape
+        keys0 = (image_embeddings + dense[:1]).flatten(2).permute(0, 2, 1)        # (1, N, C) fp32
+        pe = image_pe.flatten(2).permute(0, 2, 1)
+        P = self._prep(pe)
+        kp0 = keys0 + pe
+        # ---- layer 0 (image side shared by every prompt) -----------------------------------------------------------
+        ca, ci = L0.cross_attn_token_to_image, L0.cross_attn_image_to_token
+        queries = L0.token_side(tokens, tokens, ca.k_proj(kp0), ca.v_proj(keys0))
+        kexp, vpt = self._expand(ci, queries, tokens)
+        n4 = L0.norm4
+        keys1 = ops.samdec_img2tok(ci.q_proj(kp0).to(bf).contiguous(), None, kexp, vpt, keys0.to(bf).contiguous(),
+                                   ci.out_proj.bias.float(), n4.weight.float(), n4.bias.float(), n4.eps, T)
+        # ---- layer 1 -----------------------------------------------------------------------------------------------
+        ca, ci = L1.cross_attn_token_to_image, L1.cross_attn_image_to_token
+        d = ca.internal_dim
+        kvq = F.linear(keys1, P["w_kvq"], P["b_kvq"])                              # (B, N, 3d) bf16
+        queries = L1.token_side(queries, tokens, kvq[..., :d] + P["kpe1"], kvq[..., d:2 * d])
+        kexp, vpt = self._expand(ci, queries, tokens)
+        n4 = L1.norm4
+        keys2 = ops.samdec_img2tok(kvq[..., 2 * d:], P["qpe1"], kexp, vpt, keys1, ci.out_proj.bias.float(),
+                                   n4.weight.float(), n4.bias.float(), n4.eps, T)
+        # ---- final token->image attention + output head ---------------------------------------------------------------
+        kvu = F.linear(keys2, P["w_kvu"], P["b_kvu"])                              # (B, N, 2d + 4*c1) bf16
+        hs = tr.norm_final_attn(queries + fin.attend(fin.q_proj(queries + tokens), kvu[..., :d] + P["kpef"],
+                                                     kvu[..., d:2 * d]))
+        iou_tok, mask_toks = hs[:, 0, :], hs[:, 1:1 + self.num_mask_tokens, :]
+        hyper = torch.stack([self.output_hypernetworks_mlps[i](mask_toks[:, i, :]) for i in range(self.num_mask_tokens)], 1)
+        masks = ops.samdec_upscale_heads(kvu[..., 2 * d:], P["ln_w"], P["ln_b"], self.output_upscaling[1].eps, P["w2t"],
+                                         P["b2"], hyper.float().contiguous(), h, w)
+        return masks, self.iou_prediction_head(iou_tok).float()

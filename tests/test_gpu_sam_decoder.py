@@ -54,3 +54,55 @@ def test_postprocess_matches_oracle():
     x = torch.from_numpy(g["mini_masks"][:3]).cuda()
     y = osd.postprocess_masks(x, cfg["img"], c["mini_input_size"], c["mini_orig"])      # torch ops on the device
     np.testing.assert_allclose(y.cpu().numpy(), g["mini_post"], rtol=1e-5, atol=1e-6)
+
+
+def test_img2tok_kernel_vs_library_ops():
+    """s6d_samdec_img2tok_bf16 against the same computation in torch fp32 on the same bf16 operands, shared and
+    per-prompt q / residual, strided q, 5..8 prompt tokens."""
+    from sam6d_amd import ops
+    g = torch.Generator().manual_seed(1)
+    B, N = 5, 256
+    for T, shared in ((7, True), (8, False), (5, False)):
+        Bq = 1 if shared else B
+        qw = (torch.randn(Bq, N, 384, generator=g) * 0.5).cuda().to(torch.bfloat16)
+        q = qw[..., 256:]                                               # last-dim slice: row stride 384
+        q_add = None if shared else (torch.randn(N, 128, generator=g) * 0.5).cuda().to(torch.bfloat16)
+        kexp = torch.zeros(B, 8, 8, 8, 16)
+        kt = torch.randn(B, 8, T, 16, generator=g) * 0.5
+        for hh in range(8):
+            kexp[:, hh, :T, hh] = kt[:, hh]
+        kexp = kexp.reshape(B, 64, 128).cuda().to(torch.bfloat16)
+        vpt = torch.zeros(B, 256, 8, 8)
+        vpt[..., :T] = torch.randn(B, 256, 8, T, generator=g)
+        vpt = vpt.reshape(B, 256, 64).cuda().to(torch.bfloat16)
+        resid = torch.randn(Bq, N, 256, generator=g).cuda().to(torch.bfloat16)
+        bo, lw, lb = (torch.randn(256, generator=g).cuda() for _ in range(3))
+        out = ops.samdec_img2tok(q, q_add, kexp, vpt, resid, bo, lw, lb, 1e-5, T).float()
+        qq = q.float() if q_add is None else (q.float() + q_add.float()).to(torch.bfloat16).float()
+        s = torch.einsum("bnk,bjk->bnj", qq.expand(B, -1, -1), kexp.float()).view(B, N, 8, 8)
+        s[..., T:] = -1e30
+        p = torch.softmax(s, -1).to(torch.bfloat16).float().view(B, N, 64)
+        y = torch.einsum("bnj,bcj->bnc", p, vpt.float()) + bo + resid.float()
+        ref = torch.nn.functional.layer_norm(y, (256,), lw, lb, 1e-5)
+        err = (out - ref).abs()
+        assert err.max() < 0.06 and err.mean() < 4e-3, (T, shared, err.max().item(), err.mean().item())
+
+
+def test_upscale_heads_kernel_vs_library_ops():
+    from sam6d_amd import ops
+    g = torch.Generator().manual_seed(2)
+    B, h, w, M = 3, 8, 8, 4
+    yw = torch.randn(B, h * w, 512, generator=g).cuda().to(torch.bfloat16)
+    y0 = yw[..., 256:]
+    lw, lb = (1 + 0.1 * torch.randn(64, generator=g)).cuda(), (0.1 * torch.randn(64, generator=g)).cuda()
+    w2t = (torch.randn(128, 64, generator=g) / 8).cuda().to(torch.bfloat16)
+    b2 = (0.1 * torch.randn(32, generator=g)).cuda()
+    hyper = torch.randn(B, M, 32, generator=g).cuda()
+    masks = ops.samdec_upscale_heads(y0, lw, lb, 1e-6, w2t, b2, hyper, h, w)
+    x = y0.float().view(B, h, w, 2, 2, 64)                              # (b, y, x, dy, dx, c)
+    u = torch.nn.functional.gelu(torch.nn.functional.layer_norm(x, (64,), lw, lb, 1e-6)).to(torch.bfloat16).float()
+    v = torch.nn.functional.gelu(u @ w2t.float().t() + b2.repeat(4))    # (..., (dy2, dx2, ch))
+    v = v.view(B, h, w, 2, 2, 2, 2, 32)
+    lg = torch.einsum("byxijklc,bmc->bmyikxjl", v, hyper).reshape(B, M, 4 * h, 4 * w)
+    err = (masks - lg).abs()
+    assert err.max() < 5e-3 * lg.abs().max() + 1e-3, (err.max().item(), lg.abs().max().item())

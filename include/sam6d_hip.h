@@ -244,6 +244,16 @@ int s6d_samdec_img2tok_bf16(const void *q, const void *q_add, const void *kexp, 
                             const float *out_bias, const float *ln_w, const float *ln_b, float ln_eps, int B, int N,
                             int n_tok, int q_ld, int q_shared, int resid_shared, void *out, void *stream);
 
+/* SAM mask decoder, token -> image cross attention before out_proj: softmax(q_t k^T / sqrt(16)) v over the N image
+ * tokens, 8 heads x 16.  qt (B,8,128) f32 projected prompt tokens (pad unused rows with anything finite; their output
+ * rows are meaningless); k and v are the 128-wide column ranges [k_off, k_off+128), [v_off, v_off+128) of a bf16 tensor
+ * kv (1|B,N,ld) (kv_shared: no batch dimension); k_pe (N,128) bf16 is added to k (bf16 rounding) or NULL;
+ * scale = 1/sqrt(16) -> out (B,8,128) f32.
+ * ref: TwoWayAttentionBlock.forward steps (2), segment_anything/modeling/transformer.py:160-165; TwoWayTransformer.forward
+ * :98-103; Attention.forward :222-240. */
+int s6d_samdec_tok2img_f32(const float *qt, const void *kv, int ld, int k_off, int v_off, int kv_shared, const void *k_pe,
+                           int B, int N, float scale, float *out, void *stream);
+
 /* SAM mask decoder, output head after the first transposed conv: LayerNorm2d + GELU, second 2x2/2 transposed conv,
  * GELU, and the hypernetwork product, per output pixel.  y0 (B,h*w,4*64) bf16, row stride y_ld elements = first
  * transposed conv as a GEMM with columns ordered (dy,dx,c); w2t (128,64) bf16: row (dy2*2+dx2)*32+ch; hyper (B,M,32) f32, M <= 4 ->

@@ -288,9 +288,96 @@ __global__ __launch_bounds__(256, 2) void upscale_heads_kernel(const u16 *__rest
   }
 }
 
+// token -> image attention of the two-way block, before out_proj: 8 heads x (<= 8 prompt tokens) = 64 (head, token)
+// pairs = the 64 lanes of a wave.  Lane (h, t) keeps q_t's 16 head-h channels in registers and walks the image tokens:
+// score, online softmax and the 16-channel value accumulation are all lane-local (the 8 lanes of a head read the same
+// 32 bytes of k / v: one fetch).  16 waves split the N tokens of a prompt; their (max, sum, acc) partials meet in LDS.
+// qt (B,8,128) f32 projected prompt tokens (rows >= T are ignored by the caller); k, v: bf16 (Bk,N,ld) slices at
+// k_off / v_off of a fused projection (+ k_pe (N,128) bf16 or null); out (B,8,128) f32.
+constexpr int kT2IWaves = 16;
+__global__ __launch_bounds__(kT2IWaves * 64) void tok2img_kernel(const float *__restrict__ qt, const u16 *__restrict__ kv,
+                                                                int ld, int k_off, int v_off, long kv_bstride,
+                                                                const u16 *__restrict__ k_pe, int N, float scale,
+                                                                float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char t2i_smem[];
+  float (*part)[64][18] = reinterpret_cast<float (*)[64][18]>(t2i_smem);   // [wave][lane][m, l, acc[16]]: 72 KB
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int h = lane >> 3, t = lane & 7;
+  float q[16];
+#pragma unroll
+  for (int d = 0; d < 16; ++d) q[d] = qt[((size_t)b * 8 + t) * kSdD + h * 16 + d] * scale;
+  const u16 *base = kv + (size_t)b * kv_bstride;
+  float m = -1e30f, l = 0.f, acc[16];
+#pragma unroll
+  for (int d = 0; d < 16; ++d) acc[d] = 0.f;
+  const int per = (N + kT2IWaves - 1) / kT2IWaves;
+  const int n0 = wave * per, n1 = min(n0 + per, N);
+  for (int n = n0; n < n1; ++n) {
+    union { uint4 u[2]; u16 hh[16]; } kk, vv;
+    const u16 *row = base + (size_t)n * ld;
+    kk.u[0] = *reinterpret_cast<const uint4 *>(row + k_off + h * 16);
+    kk.u[1] = *reinterpret_cast<const uint4 *>(row + k_off + h * 16 + 8);
+    vv.u[0] = *reinterpret_cast<const uint4 *>(row + v_off + h * 16);
+    vv.u[1] = *reinterpret_cast<const uint4 *>(row + v_off + h * 16 + 8);
+    float s = 0.f;
+    if (k_pe) {
+      union { uint4 u[2]; u16 hh[16]; } pp;
+      pp.u[0] = *reinterpret_cast<const uint4 *>(k_pe + (size_t)n * kSdD + h * 16);
+      pp.u[1] = *reinterpret_cast<const uint4 *>(k_pe + (size_t)n * kSdD + h * 16 + 8);
+#pragma unroll
+      for (int d = 0; d < 16; ++d) s += q[d] * sd_bf2f(sd_f2bf(sd_bf2f(kk.hh[d]) + sd_bf2f(pp.hh[d])));
+    } else {
+#pragma unroll
+      for (int d = 0; d < 16; ++d) s += q[d] * sd_bf2f(kk.hh[d]);
+    }
+    const float mn = fmaxf(m, s);
+    const float alpha = __expf(m - mn), p = __expf(s - mn);
+    l = l * alpha + p;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) acc[d] = acc[d] * alpha + p * sd_bf2f(vv.hh[d]);
+    m = mn;
+  }
+  part[wave][lane][0] = m;
+  part[wave][lane][1] = l;
+#pragma unroll
+  for (int d = 0; d < 16; ++d) part[wave][lane][2 + d] = acc[d];
+  __syncthreads();
+  if (wave == 0) {
+    float M = -1e30f;
+    for (int w = 0; w < kT2IWaves; ++w) M = fmaxf(M, part[w][lane][0]);
+    float L = 0.f, o[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) o[d] = 0.f;
+    for (int w = 0; w < kT2IWaves; ++w) {
+      const float f = __expf(part[w][lane][0] - M);
+      L += part[w][lane][1] * f;
+#pragma unroll
+      for (int d = 0; d < 16; ++d) o[d] += part[w][lane][2 + d] * f;
+    }
+    const float inv = 1.0f / L;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) out[((size_t)b * 8 + t) * kSdD + h * 16 + d] = o[d] * inv;
+  }
+}
+
 }  // namespace s6d
 
 using namespace s6d;
+
+extern "C" int s6d_samdec_tok2img_f32(const float *qt, const void *kv, int ld, int k_off, int v_off, int kv_shared,
+                                      const void *k_pe, int B, int N, float scale, float *out, void *stream) {
+  if (B < 0 || N <= 0 || ld < kSdD || (ld % 8) || (k_off % 8) || (v_off % 8) || k_off < 0 || v_off < 0 ||
+      k_off + kSdD > ld || v_off + kSdD > ld)
+    return S6D_EINVAL;
+  if (B == 0) return S6D_OK;
+  if (!qt || !kv || !out) return S6D_EINVAL;
+  const size_t lds = (size_t)kT2IWaves * 64 * 18 * sizeof(float);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tok2img_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  hipLaunchKernelGGL(tok2img_kernel, dim3(B), dim3(kT2IWaves * 64), lds, as_stream(stream), qt, (const u16 *)kv, ld, k_off,
+                     v_off, kv_shared ? 0L : (long)N * ld, (const u16 *)k_pe, N, scale, out);
+  return launch_status();
+}
 
 extern "C" int s6d_samdec_img2tok_bf16(const void *q, const void *q_add, const void *kexp, const void *vpt,
                                        const void *resid, const float *out_bias, const float *ln_w, const float *ln_b,

@@ -209,6 +209,24 @@ def samdec_img2tok(q, q_add, kexp, vpt, resid, out_bias, ln_w, ln_b, eps, n_tok)
     return out
 
 
+def samdec_tok2img(qt, kv, k_off, v_off, k_pe, scale):
+    """Token->image attention before out_proj.  qt (B,T<=8,128) f32, kv (1|B,N,ld) bf16 holding k / v at column
+    offsets k_off / v_off, k_pe (N,128) bf16 or None -> (B,T,128) f32."""
+    _chk(kv, torch.bfloat16, "kv", 3)
+    B, T, _ = qt.shape
+    if qt.dtype != torch.float32 or not qt.is_cuda or qt.shape[2] != 128 or T > 8 or kv.shape[0] not in (1, B):
+        raise RuntimeError("samdec_tok2img: qt must be (B,T<=8,128) float32 CUDA, kv (1|B,N,ld)")
+    q8 = torch.zeros(B, 8, 128, dtype=torch.float32, device=qt.device)
+    q8[:, :T] = qt
+    if k_pe is not None:
+        _chk(k_pe, torch.bfloat16, "k_pe", 2)
+    out = torch.empty(B, 8, 128, dtype=torch.float32, device=qt.device)
+    _call("s6d_samdec_tok2img_f32", _ptr(q8), _ptr(kv), int(kv.shape[2]), int(k_off), int(v_off),
+          1 if kv.shape[0] == 1 and B > 1 else 0, _ptr(k_pe) if k_pe is not None else _vp(0), B, int(kv.shape[1]),
+          ctypes.c_float(scale), _ptr(out), _stream())
+    return out[:, :T]
+
+
 def samdec_upscale_heads(y0, ln_w, ln_b, eps, w2t, b2, hyper, h, w):
     """Output head of SAM's mask decoder after the first transposed conv (columns ordered (dy,dx,c)).
     y0 (B,h*w,256) bf16 (last-dim slice allowed), w2t (128,64) bf16, hyper (B,M,32) f32 -> masks (B,M,4h,4w) f32."""
@@ -471,7 +489,7 @@ def have(name):
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
                "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_f32",
-               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "crop_resize_pad": "s6d_crop_resize_pad_f32", "samdec_img2tok": "s6d_samdec_img2tok_bf16", "samdec_upscale_heads": "s6d_samdec_upscale_heads_bf16", "mha": "s6d_mha_f32",
+               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "crop_resize_pad": "s6d_crop_resize_pad_f32", "samdec_img2tok": "s6d_samdec_img2tok_bf16", "samdec_tok2img": "s6d_samdec_tok2img_f32", "samdec_upscale_heads": "s6d_samdec_upscale_heads_bf16", "mha": "s6d_mha_f32",
                "linear_attn_focus": "s6d_linear_attn_focus_f32", "project_bbox": "s6d_project_bbox_f32"}.get(name)
         import os
         disabled = name in os.environ.get("S6D_DISABLE_FUSED", "").split(",")

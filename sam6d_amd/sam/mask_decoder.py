@@ -173,8 +173,9 @@ class TwoWayAttentionBlock(nn.Module):
         self.cross_attn_image_to_token = Attention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
         self.skip_first_layer_pe = skip_first_layer_pe
 
-    def token_side(self, queries, query_pe, k_img, v_img):
-        """Steps (1)-(3) of the block given the image-side k / v of the token->image attention (already projected)."""
+    def token_side(self, queries, query_pe, k_img, v_img, t2i=None):
+        """Steps (1)-(3) of the block given the image-side k / v of the token->image attention (already projected);
+        t2i(q_projected) -> attention output before out_proj replaces the library attention when given."""
         if self.skip_first_layer_pe:
             queries = self.self_attn(q=queries, k=queries, v=queries)
         else:
@@ -182,7 +183,9 @@ class TwoWayAttentionBlock(nn.Module):
             queries = queries + self.self_attn(q=q, k=q, v=queries)
         queries = self.norm1(queries)
         ca = self.cross_attn_token_to_image
-        queries = self.norm2(queries + ca.attend(ca.q_proj(queries + query_pe), k_img, v_img))
+        qp = ca.q_proj(queries + query_pe)
+        a = ca.attend(qp, k_img, v_img) if t2i is None else ca.out_proj(t2i(qp.float()))
+        queries = self.norm2(queries + a)
         return self.norm3(queries + self.mlp(queries))
 
     def forward(self, queries, keys, query_pe, key_pe):
@@ -407,7 +410,14 @@ class MaskDecoder(nn.Module):
         kp0 = keys0 + pe
         # ---- layer 0 (image side shared by every prompt) -----------------------------------------------------------
         ca, ci = L0.cross_attn_token_to_image, L0.cross_attn_image_to_token
-        queries = L0.token_side(tokens, tokens, ca.k_proj(kp0), ca.v_proj(keys0))
+        t2i = ops.have("samdec_tok2img")
+        sc = 1.0 / math.sqrt(ca.internal_dim // ca.num_heads)
+        if t2i:
+            kv0 = torch.cat([ca.k_proj(kp0), ca.v_proj(keys0)], -1).to(bf).contiguous()           # (1, N, 2d)
+            queries = L0.token_side(tokens, tokens, None, None,
+                                    lambda qp: ops.samdec_tok2img(qp, kv0, 0, ca.internal_dim, None, sc))
+        else:
+            queries = L0.token_side(tokens, tokens, ca.k_proj(kp0), ca.v_proj(keys0))
         kexp, vpt = self._expand(ci, queries, tokens)
         n4 = L0.norm4
         keys1 = ops.samdec_img2tok(ci.q_proj(kp0).to(bf).contiguous(), None, kexp, vpt, keys0.to(bf).contiguous(),
@@ -416,15 +426,23 @@ class MaskDecoder(nn.Module):
         ca, ci = L1.cross_attn_token_to_image, L1.cross_attn_image_to_token
         d = ca.internal_dim
         kvq = F.linear(keys1, P["w_kvq"], P["b_kvq"])                              # (B, N, 3d) bf16
-        queries = L1.token_side(queries, tokens, kvq[..., :d] + P["kpe1"], kvq[..., d:2 * d])
+        if t2i:
+            queries = L1.token_side(queries, tokens, None, None,
+                                    lambda qp: ops.samdec_tok2img(qp, kvq, 0, d, P["kpe1"], sc))
+        else:
+            queries = L1.token_side(queries, tokens, kvq[..., :d] + P["kpe1"], kvq[..., d:2 * d])
         kexp, vpt = self._expand(ci, queries, tokens)
         n4 = L1.norm4
         keys2 = ops.samdec_img2tok(kvq[..., 2 * d:], P["qpe1"], kexp, vpt, keys1, ci.out_proj.bias.float(),
                                    n4.weight.float(), n4.bias.float(), n4.eps, T)
         # ---- final token->image attention + output head ---------------------------------------------------------------
         kvu = F.linear(keys2, P["w_kvu"], P["b_kvu"])                              # (B, N, 2d + 4*c1) bf16
-        hs = tr.norm_final_attn(queries + fin.attend(fin.q_proj(queries + tokens), kvu[..., :d] + P["kpef"],
-                                                     kvu[..., d:2 * d]))
+        qf = fin.q_proj(queries + tokens)
+        if t2i:
+            a = fin.out_proj(ops.samdec_tok2img(qf.float(), kvu, 0, d, P["kpef"], sc))
+        else:
+            a = fin.attend(qf, kvu[..., :d] + P["kpef"], kvu[..., d:2 * d])
+        hs = tr.norm_final_attn(queries + a)
         iou_tok, mask_toks = hs[:, 0, :], hs[:, 1:1 + self.num_mask_tokens, :]
         hyper = torch.stack([self.output_hypernetworks_mlps[i](mask_toks[:, i, :]) for i in range(self.num_mask_tokens)], 1)
         masks = ops.samdec_upscale_heads(kvu[..., 2 * d:], P["ln_w"], P["ln_b"], self.output_upscaling[1].eps, P["w2t"],

@@ -106,3 +106,24 @@ def test_upscale_heads_kernel_vs_library_ops():
     lg = torch.einsum("byxijklc,bmc->bmyikxjl", v, hyper).reshape(B, M, 4 * h, 4 * w)
     err = (masks - lg).abs()
     assert err.max() < 5e-3 * lg.abs().max() + 1e-3, (err.max().item(), lg.abs().max().item())
+
+
+def test_tok2img_kernel_vs_library_ops():
+    from sam6d_amd import ops
+    g = torch.Generator().manual_seed(4)
+    B, N, T = 6, 512, 7
+    qt = torch.randn(B, T, 128, generator=g).cuda()
+    for shared, pe in ((False, True), (True, False)):
+        kv = torch.randn(1 if shared else B, N, 384, generator=g).cuda().to(torch.bfloat16)
+        kpe = torch.randn(N, 128, generator=g).cuda().to(torch.bfloat16) if pe else None
+        out = ops.samdec_tok2img(qt, kv, 128, 256, kpe, 0.25)
+        k = kv[..., 128:256].float()
+        if pe:
+            k = (k + kpe.float()).to(torch.bfloat16).float()
+        v = kv[..., 256:384].float()
+        qh = qt.view(B, T, 8, 16).transpose(1, 2)
+        kh = k.view(-1, N, 8, 16).transpose(1, 2)
+        vh = v.view(-1, N, 8, 16).transpose(1, 2)
+        a = torch.softmax(qh @ kh.transpose(-1, -2) * 0.25, -1) @ vh
+        ref = a.transpose(1, 2).reshape(B, T, 128)
+        assert (out - ref).abs().max() < 2e-4, (shared, (out - ref).abs().max().item())

@@ -290,11 +290,15 @@ __global__ __launch_bounds__(256, 2) void upscale_heads_kernel(const u16 *__rest
 
 // token -> image attention of the two-way block, before out_proj: 8 heads x (<= 8 prompt tokens) = 64 (head, token)
 // pairs = the 64 lanes of a wave.  Lane (h, t) keeps q_t's 16 head-h channels in registers and walks the image tokens:
-// score, online softmax and the 16-channel value accumulation are all lane-local (the 8 lanes of a head read the same
-// 32 bytes of k / v: one fetch).  16 waves split the N tokens of a prompt; their (max, sum, acc) partials meet in LDS.
+// score, online softmax and the 16-channel value accumulation are all lane-local.  The 8 lanes of a head need the same
+// 32 bytes of k and v, so each wave stages 8-token tiles through its own LDS slice (every lane fetches one distinct
+// 16-byte piece; k + pe is rounded once there, not once per lane) and the next tile's pieces are in flight during the
+// arithmetic.  16 waves split the N tokens of a prompt; their (max, sum, acc) partials meet in LDS.
 // qt (B,8,128) f32 projected prompt tokens (rows >= T are ignored by the caller); k, v: bf16 (Bk,N,ld) slices at
 // k_off / v_off of a fused projection (+ k_pe (N,128) bf16 or null); out (B,8,128) f32.
 constexpr int kT2IWaves = 16;
+constexpr int kT2ITile = 8;                       // tokens per staged tile: 8 x (256 B k + 256 B v) = 4 KB per wave
+constexpr int kT2IRow = 2 * kSdD + 8;             // LDS row (bf16): [k | v] + 16 B pad
 __global__ __launch_bounds__(kT2IWaves * 64) void tok2img_kernel(const float *__restrict__ qt, const u16 *__restrict__ kv,
                                                                 int ld, int k_off, int v_off, long kv_bstride,
                                                                 const u16 *__restrict__ k_pe, int N, float scale,
@@ -302,6 +306,7 @@ __global__ __launch_bounds__(kT2IWaves * 64) void tok2img_kernel(const float *__
   extern __shared__ __attribute__((aligned(16))) char t2i_smem[];
   float (*part)[64][18] = reinterpret_cast<float (*)[64][18]>(t2i_smem);   // [wave][lane][m, l, acc[16]]: 72 KB
   const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  u16 *tile = reinterpret_cast<u16 *>(t2i_smem + (size_t)kT2IWaves * 64 * 18 * 4) + (size_t)wave * kT2ITile * kT2IRow;
   const int h = lane >> 3, t = lane & 7;
   float q[16];
 #pragma unroll
@@ -310,32 +315,68 @@ __global__ __launch_bounds__(kT2IWaves * 64) void tok2img_kernel(const float *__
   float m = -1e30f, l = 0.f, acc[16];
 #pragma unroll
   for (int d = 0; d < 16; ++d) acc[d] = 0.f;
-  const int per = (N + kT2IWaves - 1) / kT2IWaves;
+  const int per = ((N + kT2IWaves - 1) / kT2IWaves + kT2ITile - 1) / kT2ITile * kT2ITile;
   const int n0 = wave * per, n1 = min(n0 + per, N);
-  for (int n = n0; n < n1; ++n) {
-    union { uint4 u[2]; u16 hh[16]; } kk, vv;
-    const u16 *row = base + (size_t)n * ld;
-    kk.u[0] = *reinterpret_cast<const uint4 *>(row + k_off + h * 16);
-    kk.u[1] = *reinterpret_cast<const uint4 *>(row + k_off + h * 16 + 8);
-    vv.u[0] = *reinterpret_cast<const uint4 *>(row + v_off + h * 16);
-    vv.u[1] = *reinterpret_cast<const uint4 *>(row + v_off + h * 16 + 8);
-    float s = 0.f;
-    if (k_pe) {
-      union { uint4 u[2]; u16 hh[16]; } pp;
-      pp.u[0] = *reinterpret_cast<const uint4 *>(k_pe + (size_t)n * kSdD + h * 16);
-      pp.u[1] = *reinterpret_cast<const uint4 *>(k_pe + (size_t)n * kSdD + h * 16 + 8);
+  // staging: 8 tokens x 32 pieces of 16 B (16 of k, 16 of v) = 256 pieces, 4 per lane: piece i -> token i>>5, slot i&31
+  uint4 pk[4];
+  auto fetch = [&](int nt) {
 #pragma unroll
-      for (int d = 0; d < 16; ++d) s += q[d] * sd_bf2f(sd_f2bf(sd_bf2f(kk.hh[d]) + sd_bf2f(pp.hh[d])));
-    } else {
-#pragma unroll
-      for (int d = 0; d < 16; ++d) s += q[d] * sd_bf2f(kk.hh[d]);
+    for (int j = 0; j < 4; ++j) {
+      const int i = lane + j * 64, tk = i >> 5, sl = i & 31;
+      const int nc = min(nt + tk, N - 1);
+      const u16 *row = base + (size_t)nc * ld;
+      pk[j] = *reinterpret_cast<const uint4 *>(row + (sl < 16 ? k_off + sl * 8 : v_off + (sl - 16) * 8));
     }
-    const float mn = fmaxf(m, s);
-    const float alpha = __expf(m - mn), p = __expf(s - mn);
-    l = l * alpha + p;
+    if (k_pe) {
 #pragma unroll
-    for (int d = 0; d < 16; ++d) acc[d] = acc[d] * alpha + p * sd_bf2f(vv.hh[d]);
-    m = mn;
+      for (int j = 0; j < 4; ++j) {
+        const int i = lane + j * 64, tk = i >> 5, sl = i & 31;
+        if (sl < 16) {                                                // k pieces only
+          const int nc = min(nt + tk, N - 1);
+          const uint4 e = *reinterpret_cast<const uint4 *>(k_pe + (size_t)nc * kSdD + sl * 8);
+          union { uint4 u; u16 hh[8]; } a, c2;
+          a.u = pk[j];
+          c2.u = e;
+#pragma unroll
+          for (int x = 0; x < 8; ++x) a.hh[x] = sd_f2bf(sd_bf2f(a.hh[x]) + sd_bf2f(c2.hh[x]));
+          pk[j] = a.u;
+        }
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = lane + j * 64, tk = i >> 5, sl = i & 31;
+      *reinterpret_cast<uint4 *>(tile + tk * kT2IRow + sl * 8) = pk[j];
+    }
+  };
+  if (n0 < n1) fetch(n0);
+  for (int nt = n0; nt < n1; nt += kT2ITile) {
+    commit();
+    if (nt + kT2ITile < n1) fetch(nt + kT2ITile);
+    const int cnt = min(kT2ITile, n1 - nt);
+    for (int k = 0; k < cnt; ++k) {
+      union { uint4 u[2]; u16 hh[16]; } kk, vv;
+      const u16 *row = tile + k * kT2IRow;
+      kk.u[0] = *reinterpret_cast<const uint4 *>(row + h * 16);
+      kk.u[1] = *reinterpret_cast<const uint4 *>(row + h * 16 + 8);
+      vv.u[0] = *reinterpret_cast<const uint4 *>(row + kSdD + h * 16);
+      vv.u[1] = *reinterpret_cast<const uint4 *>(row + kSdD + h * 16 + 8);
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int d = 0; d < 16; d += 2) {
+        s0 += q[d] * sd_bf2f(kk.hh[d]);
+        s1 += q[d + 1] * sd_bf2f(kk.hh[d + 1]);
+      }
+      const float s = s0 + s1;
+      const float mn = fmaxf(m, s);
+      const float alpha = __expf(m - mn), p = __expf(s - mn);
+      l = l * alpha + p;
+#pragma unroll
+      for (int d = 0; d < 16; ++d) acc[d] = acc[d] * alpha + p * sd_bf2f(vv.hh[d]);
+      m = mn;
+    }
   }
   part[wave][lane][0] = m;
   part[wave][lane][1] = l;
@@ -371,7 +412,7 @@ extern "C" int s6d_samdec_tok2img_f32(const float *qt, const void *kv, int ld, i
     return S6D_EINVAL;
   if (B == 0) return S6D_OK;
   if (!qt || !kv || !out) return S6D_EINVAL;
-  const size_t lds = (size_t)kT2IWaves * 64 * 18 * sizeof(float);
+  const size_t lds = (size_t)kT2IWaves * 64 * 18 * sizeof(float) + (size_t)kT2IWaves * kT2ITile * kT2IRow * 2;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tok2img_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
   hipLaunchKernelGGL(tok2img_kernel, dim3(B), dim3(kT2IWaves * 64), lds, as_stream(stream), qt, (const u16 *)kv, ld, k_off,

@@ -18,4 +18,4 @@ for _ in range(4): frame()
 torch.cuda.synchronize()
 PY
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_dec -o dec -- python /tmp/dec_once.py > /dev/null 2>&1
-mkdir -p gpurun_out/prof; cp $(find /tmp/prof_dec -name "*kernel_stats.csv" | head -1) gpurun_out/prof/samdec_v1_kernel_stats.csv
+mkdir -p gpurun_out/prof; cp $(find /tmp/prof_dec -name "*kernel_stats.csv" | head -1) gpurun_out/prof/samdec_v2_kernel_stats.csv

@@ -39,10 +39,14 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_STEP)
-    ap.add_argument("--sam-chunk", type=int, default=int(os.environ.get("S6D_SAM_CHUNK", "8")))
+    ap.add_argument("--sam-chunk", type=int, default=int(os.environ.get("S6D_SAM_CHUNK", str(SAM_CHUNK))))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     return ap.parse_args()
+
+
+SAM_CHUNK = 16   # frames per SAM encoder launch group: 16 x 4096 tokens per GEMM (measured on one box: chunk 8 with the
+                 # recorded hipBLASLt solutions 199.0 ms / 32 frames, chunk 16 on the default heuristics 193.0, chunk 32 193.6)
 
 
 def _use_tuned_library_gemms():
@@ -372,7 +376,8 @@ def main():
                 "data": "synthetic",
                 "config": {"workload": "LM-O single object: 32 frames/step/GPU, 640x480 RGB-D -> 1024^2 SAM input, "
                                        "P=128 proposals x 42 templates, 1 instance/frame, 2048 pts (PEM batch 32)",
-                           "frames_per_step_per_gpu": args.frames, "sharding": f"frames over {world} rank(s)"}}
+                           "frames_per_step_per_gpu": args.frames, "sam_frames_per_launch_group": args.sam_chunk,
+                           "sharding": f"frames over {world} rank(s)"}}
         line.update(extra)
         print(json.dumps(line))
     if dist is not None:

@@ -8,6 +8,6 @@ import bench  # noqa: E402
 
 dev = torch.device("cuda", 0)
 for _ in range(2):
-    bench.kernel_rooflines(dev, 8, 32)
+    bench.kernel_rooflines(dev, bench.SAM_CHUNK, 32)
 torch.cuda.synchronize()
 print("done")

@@ -148,9 +148,12 @@ class HotPath:
                 st.wait_stream(cur)
             with torch.cuda.stream(self._streams[0]):
                 self.sam_stage()
+            # the scoring loop is the only stage with host round trips (one torch.nonzero per frame, as in the
+            # reference): it is enqueued LAST, so the host waits on it while the other two streams are already full
+            # (measured: no difference either way -- the step is bound by the sum of kernel time, not by the host)
+            out = self.pem_stage()                      # current stream
             with torch.cuda.stream(self._streams[1]):
                 self.ism_stage()
-            out = self.pem_stage()                      # current stream
             for st in self._streams:
                 cur.wait_stream(st)
         # fixed-width pose record per instance (68 B)

@@ -263,6 +263,17 @@ int s6d_samdec_upscale_heads_bf16(const void *y0, const float *ln_w, const float
                                   const float *b2, const float *hyper, int B, int M, int h, int w, int y_ld,
                                   float *masks, void *stream);
 
+/* Mask post-processing of SAM's automatic mask generator, fused: bilinear upscaling of the (Bm,n,n) f32 mask logits to
+ * the padded square (img_size), crop to (in_h,in_w), bilinear to the frame (H,W) -- evaluated per frame pixel straight
+ * from the low-resolution logits -- then masks (Bm,H,W) u8 = logit > mask_threshold and stats (Bm,6) i32 =
+ * {#(logit > thr + offset), #(logit > thr - offset), x_min, y_min, x_max, y_max of the mask (W, H, -1, -1 if empty)}.
+ * Arithmetic = ATen's CPU upsample_bilinear2d (align_corners = False), operation for operation: bit-identical masks.
+ * ref: Sam.postprocess_masks, segment_anything/modeling/sam.py:133-162; calculate_stability_score / batched_mask_to_box,
+ * segment_anything/utils/amg.py:156-176, 303-346; SamAutomaticMaskGenerator._process_batch :281-312. */
+int s6d_sam_mask_post_f32(const float *low_res, int Bm, int n, int img_size, int in_h, int in_w, int H, int W,
+                          float mask_threshold, float stability_offset, unsigned char *masks, int32_t *stats,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,7 +31,8 @@ PEM_CASE = dict(B=2, weight_seed=1, input_seed=1, rand_seed=7)
 SAM_MINI_CASE = dict(weight_seed=3, input_seed=5)
 SAM_H_CASE = dict(weight_seed=3, input_seed=5)
 ISM_CASE = dict(P=64, O=3, T=42, seed=11)
-SAMDEC_CASE = dict(weight_seed=2, input_seed=9, n_mini=9, n_full=4, mini_input_size=(96, 128), mini_orig=(60, 80))
+SAMDEC_CASE = dict(weight_seed=2, input_seed=9, n_mini=9, n_full=4, mini_input_size=(96, 128), mini_orig=(60, 80),
+                   post_B=3, post_seed=6, post_input_size=(768, 1024), post_orig=(480, 640))
 DINO_CASE = dict(P=8, input_seed=4, weight_seed=6, mini_target=56, n_full=2)
 
 
@@ -211,6 +212,14 @@ def gen_sam_decoder():
         rec["sam_masks_sum"], rec["sam_masks_smp"] = digest(mk, 211)
         rec["sam_keys"] = np.array(sorted(m.state_dict().keys()))
         rec["sam_shapes"] = np.array([str(tuple(m.state_dict()[k].shape)) for k in sorted(m.state_dict().keys())])
+        # mask post-processing of the automatic mask generator: reference amg.py functions on the upscaled logits
+        low = synth.sam_lowres_logits(c["post_B"], 3, 256, c["post_seed"])
+        full = od.postprocess_masks(low, 1024, c["post_input_size"], c["post_orig"]).flatten(0, 1)
+        rec["post_stability"] = ns.amg.calculate_stability_score(full, 0.0, 1.0).numpy()
+        mb = full > 0.0
+        rec["post_boxes"] = ns.amg.batched_mask_to_box(mb).numpy()
+        rec["post_area"] = mb.flatten(1).sum(1).numpy()
+        rec["post_bits"] = np.packbits(mb.numpy().reshape(mb.shape[0], -1)[:, ::7], axis=1)
     rec["case"] = np.array(str(c))
     np.savez_compressed(os.path.join(OUT, "sam_decoder.npz"), **rec)
     print("sam_decoder.npz", {k: (v.shape if hasattr(v, "shape") else v) for k, v in rec.items()})

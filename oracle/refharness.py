@@ -145,6 +145,8 @@ def sam_decoder():
     for name in ("prompt_encoder", "transformer", "mask_decoder"):
         full = pkgname + "." + name
         ns.__dict__[name] = sys.modules.get(full) or _load_by_path(full, os.path.join(base, name + ".py"), pkgname)
+    ns.amg = sys.modules.get("_s6d_ref_sa_amg") or _load_by_path(
+        "_s6d_ref_sa_amg", os.path.join(ISM, "segment_anything", "utils", "amg.py"))
     ns.PromptEncoder = ns.prompt_encoder.PromptEncoder
     ns.MaskDecoder = ns.mask_decoder.MaskDecoder
     ns.TwoWayTransformer = ns.transformer.TwoWayTransformer

@@ -156,3 +156,36 @@ def postprocess_masks(masks, img_size, input_size, original_size):
     m = F.interpolate(masks, (img_size, img_size), mode="bilinear", align_corners=False)
     m = m[..., : input_size[0], : input_size[1]]
     return F.interpolate(m, original_size, mode="bilinear", align_corners=False)
+
+
+def stability_score(masks, mask_threshold, threshold_offset):
+    """utils/amg.py calculate_stability_score :156-176: IoU of the masks thresholded at +-offset (one contains the other)."""
+    inter = (masks > (mask_threshold + threshold_offset)).sum(-1, dtype=torch.int16).sum(-1, dtype=torch.int32)
+    union = (masks > (mask_threshold - threshold_offset)).sum(-1, dtype=torch.int16).sum(-1, dtype=torch.int32)
+    return inter / union
+
+
+def mask_to_box(masks):
+    """utils/amg.py batched_mask_to_box :303-346 for (B,H,W) bool masks: XYXY of the set pixels, [0,0,0,0] if empty."""
+    h, w = masks.shape[-2:]
+    in_h, _ = torch.max(masks, dim=-1)
+    ch = in_h * torch.arange(h, device=masks.device)[None, :]
+    bottom, _ = torch.max(ch, dim=-1)
+    top, _ = torch.min(ch + h * (~in_h), dim=-1)
+    in_w, _ = torch.max(masks, dim=-2)
+    cw = in_w * torch.arange(w, device=masks.device)[None, :]
+    right, _ = torch.max(cw, dim=-1)
+    left, _ = torch.min(cw + w * (~in_w), dim=-1)
+    empty = (right < left) | (bottom < top)
+    return torch.stack([left, top, right, bottom], dim=-1) * (~empty).unsqueeze(-1)
+
+
+def mask_postprocess(low_res, img_size, input_size, original_size, mask_threshold=0.0, stability_offset=1.0):
+    """What SamAutomaticMaskGenerator._process_batch does with the decoder's logits (automatic_mask_generator.py
+    :281-312, through SamPredictor.predict_torch(return_logits=True) predictor.py:229-238): upscale to the frame,
+    stability score on the logits, threshold, boxes.  low_res (B,C,h,w) -> (masks bool (B*C,H,W), stability (B*C,),
+    boxes (B*C,4) long)."""
+    m = postprocess_masks(low_res, img_size, input_size, original_size).flatten(0, 1)
+    st = stability_score(m, mask_threshold, stability_offset)
+    mb = m > mask_threshold
+    return mb, st, mask_to_box(mb)

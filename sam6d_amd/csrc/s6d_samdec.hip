@@ -401,9 +401,120 @@ __global__ __launch_bounds__(kT2IWaves * 64) void tok2img_kernel(const float *__
   }
 }
 
+// ---- mask post-processing of the automatic mask generator, fused ---------------------------------------------------
+// Reference: Sam.postprocess_masks (modeling/sam.py:133-162: bilinear to the padded square, crop, bilinear to the frame),
+// then on the full-resolution logits calculate_stability_score, `> mask_threshold` and batched_mask_to_box
+// (utils/amg.py:156-176, 303-346; automatic_mask_generator.py:281-312).  As written that is 805 MB of fp32 per batch of
+// 64 prompts.  Here every frame pixel is evaluated straight from the 256 x 256 logits (4 taps of the intermediate image,
+// each 4 taps of the logits) and only the binary mask, two counts and a bounding box per mask leave the kernel.
+// The arithmetic is ATen's CPU upsample_bilinear2d form, reproduced operation for operation
+//     src = scale * (dst + 0.5) - 0.5 (clamped at 0), w1 = src - floor(src), w0 = 1 - w1
+//     v = fma(wy0, fma(wx0, v00, wx1 * v01), wy1 * fma(wx0, v10, wx1 * v11))
+// so the thresholded masks are bit-identical to the oracle's.
+struct BilTap { int i0, i1; float w0, w1; };
+__device__ __forceinline__ BilTap bil_tap(int dst, float scale, int in_n) {
+  float sidx = __fsub_rn(__fmul_rn(scale, __fadd_rn((float)dst, 0.5f)), 0.5f);
+  sidx = sidx < 0.f ? 0.f : sidx;
+  BilTap t;
+  t.i0 = (int)sidx;
+  t.i1 = t.i0 + (t.i0 < in_n - 1 ? 1 : 0);
+  t.w1 = __fsub_rn(sidx, (float)t.i0);
+  t.w0 = __fsub_rn(1.0f, t.w1);
+  return t;
+}
+__device__ __forceinline__ float bil_mix(float w0, float a, float w1, float b) { return __fmaf_rn(w0, a, __fmul_rn(w1, b)); }
+
+constexpr int kPostRows = 4;     // frame rows per workgroup
+
+__global__ void mask_post_init_kernel(int *stats, int Bm, int H, int W) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < Bm) {
+    int *s = stats + (size_t)i * 6;
+    s[0] = 0; s[1] = 0; s[2] = W; s[3] = H; s[4] = -1; s[5] = -1;
+  }
+}
+
+__global__ __launch_bounds__(256) void mask_post_kernel(const float *__restrict__ low, int n, int img, int ih, int iw,
+                                                        int H, int W, float thr, float off,
+                                                        unsigned char *__restrict__ masks, int *__restrict__ stats) {
+  __shared__ int red[6][4];
+  const int m = blockIdx.y, y_base = blockIdx.x * kPostRows, tid = threadIdx.x;
+  const float *L = low + (size_t)m * n * n;
+  const float sA = (float)n / (float)img, sBy = (float)ih / (float)H, sBx = (float)iw / (float)W;
+  int inter = 0, uni = 0, xmin = W, ymin = H, xmax = -1, ymax = -1;
+  for (int x = tid; x < W; x += 256) {
+    const BilTap bx = bil_tap(x, sBx, iw);
+    const BilTap ax0 = bil_tap(bx.i0, sA, n), ax1 = bil_tap(bx.i1, sA, n);
+    for (int r = 0; r < kPostRows; ++r) {
+      const int y = y_base + r;
+      if (y >= H) break;
+      const BilTap by = bil_tap(y, sBy, ih);
+      float rowv[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {                                  // the two rows of the intermediate image
+        const BilTap ay = bil_tap(k == 0 ? by.i0 : by.i1, sA, n);
+        const float *r0 = L + (size_t)ay.i0 * n, *r1 = L + (size_t)ay.i1 * n;
+        const float a0 = bil_mix(ay.w0, bil_mix(ax0.w0, r0[ax0.i0], ax0.w1, r0[ax0.i1]), ay.w1,
+                                 bil_mix(ax0.w0, r1[ax0.i0], ax0.w1, r1[ax0.i1]));     // intermediate (Y_k, X_0)
+        const float a1 = bil_mix(ay.w0, bil_mix(ax1.w0, r0[ax1.i0], ax1.w1, r0[ax1.i1]), ay.w1,
+                                 bil_mix(ax1.w0, r1[ax1.i0], ax1.w1, r1[ax1.i1]));     // intermediate (Y_k, X_1)
+        rowv[k] = bil_mix(bx.w0, a0, bx.w1, a1);
+      }
+      const float v = bil_mix(by.w0, rowv[0], by.w1, rowv[1]);
+      const bool on = v > thr;
+      masks[((size_t)m * H + y) * W + x] = on ? 1 : 0;
+      inter += v > thr + off;
+      uni += v > thr - off;
+      if (on) {
+        xmin = min(xmin, x); xmax = max(xmax, x);
+        ymin = min(ymin, y); ymax = max(ymax, y);
+      }
+    }
+  }
+  // workgroup fold, then one atomic per statistic
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    inter += __shfl_xor(inter, o);
+    uni += __shfl_xor(uni, o);
+    xmin = min(xmin, __shfl_xor(xmin, o));
+    ymin = min(ymin, __shfl_xor(ymin, o));
+    xmax = max(xmax, __shfl_xor(xmax, o));
+    ymax = max(ymax, __shfl_xor(ymax, o));
+  }
+  const int wave = tid >> 6;
+  if ((tid & 63) == 0) {
+    red[0][wave] = inter; red[1][wave] = uni; red[2][wave] = xmin; red[3][wave] = ymin; red[4][wave] = xmax;
+    red[5][wave] = ymax;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int *s = stats + (size_t)m * 6;
+    atomicAdd(s + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(s + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    atomicMin(s + 2, min(min(red[2][0], red[2][1]), min(red[2][2], red[2][3])));
+    atomicMin(s + 3, min(min(red[3][0], red[3][1]), min(red[3][2], red[3][3])));
+    atomicMax(s + 4, max(max(red[4][0], red[4][1]), max(red[4][2], red[4][3])));
+    atomicMax(s + 5, max(max(red[5][0], red[5][1]), max(red[5][2], red[5][3])));
+  }
+}
+
 }  // namespace s6d
 
 using namespace s6d;
+
+extern "C" int s6d_sam_mask_post_f32(const float *low_res, int Bm, int n, int img_size, int in_h, int in_w, int H, int W,
+                                     float mask_threshold, float stability_offset, unsigned char *masks, int32_t *stats,
+                                     void *stream) {
+  if (Bm < 0 || n <= 0 || img_size <= 0 || in_h <= 0 || in_w <= 0 || in_h > img_size || in_w > img_size || H <= 0 || W <= 0)
+    return S6D_EINVAL;
+  if (Bm == 0) return S6D_OK;
+  if (!low_res || !masks || !stats) return S6D_EINVAL;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(mask_post_init_kernel, dim3((Bm + 255) / 256), dim3(256), 0, st, stats, Bm, H, W);
+  hipLaunchKernelGGL(mask_post_kernel, dim3((H + kPostRows - 1) / kPostRows, Bm), dim3(256), 0, st, low_res, n, img_size,
+                     in_h, in_w, H, W, mask_threshold, stability_offset, masks, stats);
+  return launch_status();
+}
 
 extern "C" int s6d_samdec_tok2img_f32(const float *qt, const void *kv, int ld, int k_off, int v_off, int kv_shared,
                                       const void *k_pe, int B, int N, float scale, float *out, void *stream) {

@@ -163,3 +163,21 @@ def sam_decoder_inputs(cfg, n_prompts, seed=1):
     xy = torch.rand(3, 2, generator=g) * cfg["img"] * 0.5
     boxes = torch.cat([xy, xy + 0.1 * cfg["img"] + torch.rand(3, 2, generator=g) * cfg["img"] * 0.4], dim=1)
     return dict(emb=emb, points=points, labels=labels, points2=points2, labels2=labels2, boxes=boxes)
+
+
+def sam_lowres_logits(B, C=3, n=256, seed=1):
+    """Low-resolution mask logits (B,C,n,n) with the look of the decoder's output: smooth blobs of logit ~ +-8 with
+    soft edges (so that the +-1 stability band and the zero crossing both cut through many pixels), one empty mask
+    (all negative) and one full mask."""
+    g = _g(seed)
+    ys, xs = torch.meshgrid(torch.arange(n).float(), torch.arange(n).float(), indexing="ij")
+    out = torch.empty(B, C, n, n)
+    for b in range(B):
+        for c in range(C):
+            cx, cy = torch.rand(2, generator=g) * n
+            sx, sy = 8 + torch.rand(2, generator=g) * n / 4
+            blob = 14 * torch.exp(-((xs - cx) ** 2 / (2 * sx ** 2) + (ys - cy) ** 2 / (2 * sy ** 2))) - 6
+            out[b, c] = blob + 0.3 * torch.randn(n, n, generator=g)
+    out[0, 0] = -5 + 0.3 * torch.randn(n, n, generator=g)
+    out[-1, -1] = 5 + 0.3 * torch.randn(n, n, generator=g)
+    return out

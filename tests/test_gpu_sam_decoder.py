@@ -127,3 +127,26 @@ def test_tok2img_kernel_vs_library_ops():
         a = torch.softmax(qh @ kh.transpose(-1, -2) * 0.25, -1) @ vh
         ref = a.transpose(1, 2).reshape(B, T, 128)
         assert (out - ref).abs().max() < 2e-4, (shared, (out - ref).abs().max().item())
+
+
+def test_mask_post_kernel_bit_exact_vs_oracle_and_golden():
+    from sam6d_amd import ops
+    g, c, _, _ = case("mini")
+    from sam6d_amd.utils import synth
+    low = synth.sam_lowres_logits(c["post_B"], 3, 256, c["post_seed"])
+    (ih, iw), (H, W) = c["post_input_size"], c["post_orig"]
+    mb, st, boxes = ops.sam_mask_post(low.cuda(), 1024, (ih, iw), (H, W), 0.0, 1.0)
+    rb, rs, rbox = osd.mask_postprocess(low, 1024, (ih, iw), (H, W))
+    assert torch.equal(mb.cpu(), rb)
+    np.testing.assert_array_equal(st.cpu().numpy(), rs.numpy())
+    np.testing.assert_array_equal(boxes.cpu().numpy(), rbox.numpy())
+    np.testing.assert_array_equal(boxes.cpu().numpy(), g["post_boxes"])
+    np.testing.assert_array_equal(st.cpu().numpy(), g["post_stability"])
+    # odd sizes: non-multiple-of-4 rows, a frame larger than the padded square's valid region, n = 64
+    low2 = synth.sam_lowres_logits(2, 2, 64, 3)
+    mb, st, boxes = ops.sam_mask_post(low2.cuda(), 256, (171, 256), (333, 499), 0.0, 1.0)
+    rb, rs, rbox = osd.mask_postprocess(low2, 256, (171, 256), (333, 499))
+    assert torch.equal(mb.cpu(), rb) and torch.equal(boxes.cpu(), rbox)
+    np.testing.assert_array_equal(st.cpu().numpy(), rs.numpy())
+    e = ops.sam_mask_post(low2[:0].cuda(), 256, (171, 256), (33, 49))
+    assert e[0].shape == (0, 33, 49) and e[1].shape == (0,) and e[2].shape == (0, 4)

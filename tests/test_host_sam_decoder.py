@@ -72,3 +72,44 @@ def test_released_config_shared_path_matches_reference_golden():
         _, mk, iou = run(m, inp["emb"], points=(inp["points"], inp["labels"]))
     np.testing.assert_allclose(iou.numpy(), g["sam_iou"], rtol=1e-4, atol=2e-5)
     util.assert_digest_close(mk, g["sam_masks_sum"], g["sam_masks_smp"], 211, 1e-4, 2e-5, "low-res mask logits")
+
+
+def _bil_np(img, oh, ow, ih, iw):
+    """numpy statement of the arithmetic s6d_sam_mask_post_f32 uses for one bilinear stage (fma emulated in float64:
+    the product of two float32 is exact there)."""
+    f = np.float32
+
+    def taps(out_n, in_n):
+        d = np.arange(out_n, dtype=np.float32)
+        s = np.maximum(f(f(in_n) / f(out_n)) * (d + f(0.5)) - f(0.5), f(0))
+        i0 = s.astype(np.int64)
+        i1 = i0 + (i0 < in_n - 1)
+        w1 = (s - i0.astype(np.float32)).astype(np.float32)
+        return i0, i1, (f(1) - w1).astype(np.float32), w1
+
+    def mix(w0, a, w1, b):
+        return (w0.astype(np.float64) * a.astype(np.float64) + (w1 * b).astype(np.float32).astype(np.float64)).astype(np.float32)
+    y0, y1, wy0, wy1 = taps(oh, ih)
+    x0, x1, wx0, wx1 = taps(ow, iw)
+    WX0, WX1 = np.broadcast_to(wx0[None, :], (oh, ow)), np.broadcast_to(wx1[None, :], (oh, ow))
+    WY0, WY1 = np.broadcast_to(wy0[:, None], (oh, ow)), np.broadcast_to(wy1[:, None], (oh, ow))
+    t0 = mix(WX0, img[np.ix_(y0, x0)], WX1, img[np.ix_(y0, x1)])
+    t1 = mix(WX0, img[np.ix_(y1, x0)], WX1, img[np.ix_(y1, x1)])
+    return mix(WY0, t0, WY1, t1)
+
+
+def test_mask_post_arithmetic_replay_matches_oracle_and_reference_golden():
+    """The kernel's bilinear form (ATen CPU's, operation for operation) reproduces the oracle's upscaled logits bit for
+    bit; stability scores / boxes / areas of the thresholded masks equal the reference amg.py outputs."""
+    g, c, _, _ = case("mini")
+    low = synth.sam_lowres_logits(c["post_B"], 3, 256, c["post_seed"])
+    (ih, iw), (H, W) = c["post_input_size"], c["post_orig"]
+    full = osd.postprocess_masks(low, 1024, (ih, iw), (H, W)).flatten(0, 1).numpy()
+    for m in (1, 4, 8):
+        mine = _bil_np(_bil_np(low.flatten(0, 1)[m].numpy(), 1024, 1024, 256, 256)[:ih, :iw], H, W, ih, iw)
+        np.testing.assert_array_equal(mine, full[m])
+    mb, st, boxes = osd.mask_postprocess(low, 1024, (ih, iw), (H, W))
+    np.testing.assert_array_equal(st.numpy(), g["post_stability"])          # NaN == NaN under assert_array_equal
+    np.testing.assert_array_equal(boxes.numpy(), g["post_boxes"])
+    np.testing.assert_array_equal(mb.flatten(1).sum(1).numpy(), g["post_area"])
+    np.testing.assert_array_equal(np.packbits(mb.numpy().reshape(mb.shape[0], -1)[:, ::7], axis=1), g["post_bits"])

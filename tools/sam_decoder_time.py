@@ -49,3 +49,11 @@ if __name__ == "__main__":
             ms = ev(lambda: frame(lib), 3)
             print(f"{dt} {'reference op sequence' if lib else 'restructured'}: {n} prompts, chunk {chunk}: {ms:.2f} ms/frame "
                   f"-> {3.6e9 * n / ms / 1e9:.0f} TFLOP/s as-written-equivalent", flush=True)
+    # mask post-processing of one batch of 256 prompts x 3 masks -> 480x640 frame
+    from sam6d_amd import ops  # noqa: E402
+    low = synth.sam_lowres_logits(4, 3, 256, 1).cuda().repeat(64, 1, 1, 1)           # (256,3,256,256)
+    ms = ev(lambda: ops.sam_mask_post(low, 1024, (768, 1024), (480, 640), 0.0, 1.0), 5)
+    print(f"mask post-processing (fused), 768 masks -> 480x640: {ms:.3f} ms ({768 * 480 * 640 / ms / 1e6:.1f} Gpixel/s); "
+          f"x4 batches per 1024-prompt frame = {4 * ms:.2f} ms", flush=True)
+    ref = ev(lambda: osd.mask_postprocess(low[:64], 1024, (768, 1024), (480, 640)), 3)
+    print(f"reference op sequence (torch on the device), 192 masks: {ref:.3f} ms -> x16 per frame = {16 * ref:.1f} ms")

@@ -150,3 +150,30 @@ def test_mask_post_kernel_bit_exact_vs_oracle_and_golden():
     np.testing.assert_array_equal(st.cpu().numpy(), rs.numpy())
     e = ops.sam_mask_post(low2[:0].cuda(), 256, (171, 256), (33, 49))
     assert e[0].shape == (0, 33, 49) and e[1].shape == (0,) and e[2].shape == (0, 4)
+
+
+def test_process_point_batch_matches_reference_sequence(monkeypatch):
+    """Generator batch body: decoder -> fused post-processing -> both filters, against the reference's sequence
+    (oracle post-processing + amg-style filtering) applied to the same low-resolution logits."""
+    from sam6d_amd.sam import amg
+    monkeypatch.setenv("S6D_SAM_DECODER_DTYPE", "bf16")
+    g, c, cfg, inp = case("sam")
+    inp = _cuda(inp)
+    m = seeded.load_seeded(build(cfg), c["weight_seed"]).cuda()
+    pts = torch.rand(24, 2, generator=torch.Generator().manual_seed(0)).cuda() * torch.tensor([1024.0, 768.0]).cuda()
+    off = 0.02                                   # seeded weights give |logit| < 0.3: a +-1 band would swallow every mask
+    every = amg.process_point_batch(m.prompt_encoder, m.mask_decoder, inp["emb"], pts, (768, 1024), (480, 640),
+                                    pred_iou_thresh=0.0, stability_score_thresh=0.0, stability_score_offset=off)
+    assert every["masks"].shape == (72, 480, 640)
+    t_iou = every["iou_preds"].float().median().item()
+    t_st = every["stability_score"][torch.isfinite(every["stability_score"])].median().item()
+    out = amg.process_point_batch(m.prompt_encoder, m.mask_decoder, inp["emb"], pts, (768, 1024), (480, 640),
+                                  pred_iou_thresh=t_iou, stability_score_thresh=t_st, stability_score_offset=off)
+    low = out["low_res_logits"].float().cpu()
+    rb, rs, rbox = osd.mask_postprocess(low, 1024, (768, 1024), (480, 640), 0.0, off)
+    keep = (every["iou_preds"].float().cpu() > t_iou) & (rs >= t_st)
+    assert keep.any() and not keep.all()
+    idx = torch.nonzero(keep).squeeze(1)
+    assert torch.equal(out["point_index"].cpu(), idx // 3)
+    assert torch.equal(out["masks"].cpu(), rb[idx]) and torch.equal(out["boxes"].cpu(), rbox[idx])
+    np.testing.assert_array_equal(out["stability_score"].cpu().numpy(), rs[idx].numpy())

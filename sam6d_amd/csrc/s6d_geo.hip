@@ -28,6 +28,19 @@ __device__ __forceinline__ void split_bf16(float x, u16 &hi, u16 &lo) {
   lo = l.u;
 }
 
+// sin / cos of the fp32 product x*w (the reference's argument, transformer.py:275): two-constant Cody-Waite reduction
+// to [-pi, pi] (k = rint(a / 2pi); r = a - k*2pi_hi - k*2pi_lo, both by FMA), then the hardware sine / cosine, which take
+// their argument in revolutions.  Arguments reach ~500 rad (the background point sits 100 units away, sigma_d = 0.2):
+// at that size the reduction keeps |error| < 2e-6 where libm-style sincosf spends ~45 instructions on it and this ~8.
+__device__ __forceinline__ void fast_sincos(float a, float &sn, float &cs) {
+  const float k = rintf(a * 0.15915494309189535f);
+  float r = __fmaf_rn(-k, 6.28318548202514648f, a);                // 2pi rounded to fp32
+  r = __fmaf_rn(-k, -1.74845553e-07f, r);                         // 2pi - fp32(2pi)
+  const float rev = r * 0.15915494309189535f;
+  sn = __builtin_amdgcn_sinf(rev);
+  cs = __builtin_amdgcn_cosf(rev);
+}
+
 constexpr int GEO_C = 256;          // hidden dim
 constexpr int GEO_ROW = 40;         // LDS row stride (bf16): 32 channels + 8 pad (80 B: conflict-free b128 reads)
 constexpr int GEO_PAIRS = 64;       // point pairs per workgroup
@@ -117,7 +130,7 @@ __global__ __launch_bounds__(GEO_THREADS) void geo_embed_kernel(const float *__r
       for (int j = 0; j < 4; ++j) {
         const float w = div_term[ks * 16 + item_q[n] * 4 + j];
         float sn, cs;
-        sincosf(xval[n] * w, &sn, &cs);                            // same fp32 product as the reference (:275)
+        fast_sincos(xval[n] * w, sn, cs);                          // same fp32 product as the reference (:275)
         split_bf16(sn, hi.h[2 * j], lo.h[2 * j]);                  // interleaved [sin w, cos w] layout (:279-280)
         split_bf16(cs, hi.h[2 * j + 1], lo.h[2 * j + 1]);
       }

@@ -5,7 +5,6 @@ golden generation and bench.py all draw their inputs here.  Everything is
 generated on the CPU with an explicit torch.Generator, so the same arguments
 give the same tensors in the build container and on the GPU box.
 """
-import math
 
 import torch
 

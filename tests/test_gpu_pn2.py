@@ -1,6 +1,5 @@
 """GPU parity: hand-written gfx950 PointNet++ ops (through the C ABI) vs the C oracle.
 Bit-exact for every index output."""
-import numpy as np
 import pytest
 import torch
 

@@ -1,5 +1,4 @@
 """GPU parity of the pose-solver kernels vs the CPU oracle (oracle/pem.py)."""
-import numpy as np
 import pytest
 import torch
 
@@ -72,8 +71,7 @@ def test_rpe_attention_vs_oracle(ops, B, N):
     """Fused RPE attention (q~.e rewrite, streamed embedding) vs the reference formulation."""
     from sam6d_amd.pem.layers import RPEMultiHeadAttention
     from sam6d_amd.utils import seeded
-    from tests import util
-    m = RPEMultiHeadAttention(256).eval()
+        m = RPEMultiHeadAttention(256).eval()
     seeded.load_seeded(m, 4)
     W = {"a." + k: v for k, v in m.state_dict().items()}
     g = torch.Generator().manual_seed(B * 100 + N)

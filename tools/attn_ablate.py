@@ -1,5 +1,4 @@
 """Ablation timing of the fused attention kernels (diagnostic; run on the GPU box)."""
-import os
 import sys
 
 import torch

@@ -71,7 +71,7 @@ def test_rpe_attention_vs_oracle(ops, B, N):
     """Fused RPE attention (q~.e rewrite, streamed embedding) vs the reference formulation."""
     from sam6d_amd.pem.layers import RPEMultiHeadAttention
     from sam6d_amd.utils import seeded
-        m = RPEMultiHeadAttention(256).eval()
+    m = RPEMultiHeadAttention(256).eval()
     seeded.load_seeded(m, 4)
     W = {"a." + k: v for k, v in m.state_dict().items()}
     g = torch.Generator().manual_seed(B * 100 + N)

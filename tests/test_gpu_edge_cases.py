@@ -88,3 +88,42 @@ def test_pem_batch32_properties():
     assert (out["pred_t"].cpu() - inp["gt_t"]).abs().max() < 1e-4
     sc = out["pred_pose_score"].cpu()
     assert (sc >= 0).all() and (sc <= 1).all()
+
+
+def test_next_row_entry_points_reject_bad_arguments_and_accept_empty_batches(ops):
+    """C-ABI argument checks of the section-8f kernels: empty batches are no-ops, malformed shapes are refused with
+    S6D_EINVAL (a RuntimeError on the Python side), nothing is launched."""
+    import ctypes
+
+    from sam6d_amd import _lib
+    L = _lib.lib()
+    null = ctypes.c_void_p(0)
+    f3 = (ctypes.c_float * 3)(0, 0, 0)
+    # B = 0: OK without touching any pointer
+    assert L.s6d_crop_resize_pad_f32(null, null, null, 0, 480, 640, 224, f3, f3, null, null, null) == 0
+    assert L.s6d_samdec_img2tok_bf16(null, null, null, null, null, null, null, null, ctypes.c_float(1e-5), 0, 4096, 7, 128, 0,
+                                     0, null, null) == 0
+    assert L.s6d_samdec_tok2img_f32(null, null, 384, 0, 128, 0, null, 0, 4096, ctypes.c_float(0.25), null, null) == 0
+    assert L.s6d_samdec_upscale_heads_bf16(null, null, null, ctypes.c_float(1e-6), null, null, null, 0, 4, 64, 64, 256, null,
+                                           null) == 0
+    assert L.s6d_sam_mask_post_f32(null, 0, 256, 1024, 768, 1024, 480, 640, ctypes.c_float(0), ctypes.c_float(1), null, null,
+                                   null) == 0
+    # malformed: more than 8 prompt tokens, token count not a multiple of 16, k/v windows outside the row, crop
+    # target 0, valid region larger than the padded square, NULL operands with B > 0
+    bad = [
+        L.s6d_samdec_img2tok_bf16(null, null, null, null, null, null, null, null, ctypes.c_float(1e-5), 1, 4096, 9, 128, 0, 0,
+                                  null, null),
+        L.s6d_samdec_img2tok_bf16(null, null, null, null, null, null, null, null, ctypes.c_float(1e-5), 1, 4090, 7, 128, 0, 0,
+                                  null, null),
+        L.s6d_samdec_tok2img_f32(null, null, 384, 300, 128, 0, null, 1, 4096, ctypes.c_float(0.25), null, null),
+        L.s6d_crop_resize_pad_f32(null, null, null, 1, 480, 640, 0, f3, f3, null, null, null),
+        L.s6d_sam_mask_post_f32(null, 1, 256, 1024, 1200, 1024, 480, 640, ctypes.c_float(0), ctypes.c_float(1), null, null, null),
+        L.s6d_sam_mask_post_f32(null, 1, 256, 1024, 768, 1024, 480, 640, ctypes.c_float(0), ctypes.c_float(1), null, null, null),
+        L.s6d_samdec_upscale_heads_bf16(null, null, null, ctypes.c_float(1e-6), null, null, null, 1, 5, 64, 64, 256, null, null),
+    ]
+    assert all(rc != 0 for rc in bad), bad
+    with pytest.raises(RuntimeError):
+        ops.sam_mask_post(torch.zeros(1, 3, 64, 32, device="cuda"), 256, (100, 100), (50, 50))      # not square
+    with pytest.raises(RuntimeError):
+        ops.samdec_tok2img(torch.zeros(2, 9, 128, device="cuda"), torch.zeros(2, 64, 256, device="cuda", dtype=torch.bfloat16),
+                           0, 128, None, 0.25)

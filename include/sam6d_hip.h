@@ -274,6 +274,16 @@ int s6d_sam_mask_post_f32(const float *low_res, int Bm, int n, int img_size, int
                           float mask_threshold, float stability_offset, unsigned char *masks, int32_t *stats,
                           void *stream);
 
+/* Box NMS with torchvision.ops.nms semantics (IoU on float32 XYXY boxes, area = (x2-x1)(y2-y1), suppress if IoU >
+ * threshold, boxes visited in the given score order).  boxes (N,4) f32, order (N) i64 = indices by decreasing score ->
+ * keep_sorted (N) u8: keep_sorted[i] says whether the i-th box IN SCORE ORDER survives.  workspace:
+ * s6d_nms_workspace_bytes(N) bytes; N <= 16384.
+ * ref: batched_nms call sites, segment_anything/automatic_mask_generator.py:251-257 (one category: plain nms);
+ * torchvision (un-vendored dependency, ISM environment.yaml) ops/nms: restated from its published algorithm. */
+int s6d_nms_f32(const float *boxes, const int64_t *order, int N, float iou_threshold, void *workspace,
+                unsigned char *keep_sorted, void *stream);
+long s6d_nms_workspace_bytes(int N);
+
 #ifdef __cplusplus
 }
 #endif

@@ -189,3 +189,22 @@ def mask_postprocess(low_res, img_size, input_size, original_size, mask_threshol
     st = stability_score(m, mask_threshold, stability_offset)
     mb = m > mask_threshold
     return mb, st, mask_to_box(mb)
+
+
+def nms(boxes, scores, iou_threshold):
+    """torchvision.ops.nms restated from its published algorithm (un-vendored dependency of the reference; PARITY
+    UNPINNED at this boundary): visit boxes by decreasing score, drop those whose IoU with a kept one exceeds the
+    threshold; area = (x2-x1)*(y2-y1), float32.  Returns kept indices by decreasing score."""
+    order = torch.sort(scores.float(), descending=True, stable=True)[1]
+    b = boxes.float()[order]
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    keep, dead = [], torch.zeros(len(b), dtype=torch.bool)
+    for i in range(len(b)):
+        if dead[i]:
+            continue
+        keep.append(i)
+        w = (torch.minimum(b[i, 2], b[:, 2]) - torch.maximum(b[i, 0], b[:, 0])).clamp(min=0)
+        h = (torch.minimum(b[i, 3], b[:, 3]) - torch.maximum(b[i, 1], b[:, 1])).clamp(min=0)
+        inter = w * h
+        dead |= (inter / (area[i] + area - inter)) > iou_threshold
+    return order[torch.tensor(keep, dtype=torch.long)]

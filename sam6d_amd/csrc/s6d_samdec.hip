@@ -498,9 +498,63 @@ __global__ __launch_bounds__(256) void mask_post_kernel(const float *__restrict_
   }
 }
 
+// ---- box NMS (torchvision.ops.nms semantics; the generator's duplicate removal, automatic_mask_generator.py:251-257) ---
+// Phase 1: for every pair i < j in score order, bit j of row i says IoU(i, j) > threshold (area = (x2-x1)(y2-y1), no +1,
+// float32, as torchvision's devIoU).  Phase 2: one wave walks the rows in order; lane l owns the 64-bit word l of the
+// "removed" set, so taking a box is one OR per lane.
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ boxes, const long *__restrict__ order, int N,
+                                                      float thresh, unsigned long long *__restrict__ mask) {
+  const int i = blockIdx.x, wcol = blockIdx.y, lane = threadIdx.x;
+  const int nw = (N + 63) / 64;
+  const int j = wcol * 64 + lane;
+  const float *a = boxes + order[i] * 4;
+  bool hit = false;
+  if (j < N && j > i) {
+    const float *b = boxes + order[j] * 4;
+    const float w = fmaxf(fminf(a[2], b[2]) - fmaxf(a[0], b[0]), 0.f), h = fmaxf(fminf(a[3], b[3]) - fmaxf(a[1], b[1]), 0.f);
+    const float inter = w * h, sa = (a[2] - a[0]) * (a[3] - a[1]), sb = (b[2] - b[0]) * (b[3] - b[1]);
+    hit = inter / (sa + sb - inter) > thresh;
+  }
+  const unsigned long long bits = __ballot(hit);
+  if (lane == 0) mask[(size_t)i * nw + wcol] = bits;
+}
+
+__global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long *__restrict__ mask, int N,
+                                                      unsigned char *__restrict__ keep) {
+  const int lane = threadIdx.x, nw = (N + 63) / 64;
+  unsigned long long removed[4] = {0, 0, 0, 0};                     // words lane, lane+64, ... : N <= 16384
+  for (int i = 0; i < N; ++i) {
+    const int w = i >> 6;
+    const unsigned long long word = __shfl(removed[w >> 6], w & 63);   // every lane learns bit i of the removed set
+    const bool dead = (word >> (i & 63)) & 1ull;
+    if (lane == 0) keep[i] = dead ? 0 : 1;
+    if (!dead) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int ww = lane + k * 64;
+        if (ww < nw) removed[k] |= mask[(size_t)i * nw + ww];
+      }
+    }
+  }
+}
+
 }  // namespace s6d
 
 using namespace s6d;
+
+extern "C" long s6d_nms_workspace_bytes(int N) { return (long)N * ((N + 63) / 64) * 8; }
+
+extern "C" int s6d_nms_f32(const float *boxes, const int64_t *order, int N, float iou_threshold, void *workspace,
+                           unsigned char *keep_sorted, void *stream) {
+  if (N < 0 || N > 16384) return N < 0 ? S6D_EINVAL : S6D_EUNSUPPORTED;
+  if (N == 0) return S6D_OK;
+  if (!boxes || !order || !workspace || !keep_sorted) return S6D_EINVAL;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(N, (N + 63) / 64), dim3(64), 0, st, boxes, (const long *)order, N, iou_threshold,
+                     (unsigned long long *)workspace);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, st, (const unsigned long long *)workspace, N, keep_sorted);
+  return launch_status();
+}
 
 extern "C" int s6d_sam_mask_post_f32(const float *low_res, int Bm, int n, int img_size, int in_h, int in_w, int H, int W,
                                      float mask_threshold, float stability_offset, unsigned char *masks, int32_t *stats,

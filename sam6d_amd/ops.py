@@ -245,6 +245,21 @@ def sam_mask_post(low_res, img_size, input_size, original_size, mask_threshold=0
     return masks.bool(), stability, boxes
 
 
+def nms(boxes, scores, iou_threshold):
+    """torchvision.ops.nms: indices of the kept boxes, by decreasing score.  boxes (N,4) f32 XYXY, scores (N,)."""
+    _chk(boxes, torch.float32, "boxes", 2)
+    N = boxes.shape[0]
+    if N == 0:
+        return torch.empty(0, dtype=torch.int64, device=boxes.device)
+    order = torch.sort(scores.float(), descending=True, stable=True)[1].contiguous()
+    fn = _lib.lib().s6d_nms_workspace_bytes
+    fn.restype = ctypes.c_long
+    ws = torch.empty(max(int(fn(N)), 8), dtype=torch.uint8, device=boxes.device)
+    keep = torch.empty(N, dtype=torch.uint8, device=boxes.device)
+    _call("s6d_nms_f32", _ptr(boxes), _ptr(order), N, ctypes.c_float(iou_threshold), _ptr(ws), _ptr(keep), _stream())
+    return order[keep.bool()]
+
+
 def samdec_upscale_heads(y0, ln_w, ln_b, eps, w2t, b2, hyper, h, w):
     """Output head of SAM's mask decoder after the first transposed conv (columns ordered (dy,dx,c)).
     y0 (B,h*w,256) bf16 (last-dim slice allowed), w2t (128,64) bf16, hyper (B,M,32) f32 -> masks (B,M,4h,4w) f32."""
@@ -507,7 +522,7 @@ def have(name):
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
                "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_f32",
-               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "crop_resize_pad": "s6d_crop_resize_pad_f32", "samdec_img2tok": "s6d_samdec_img2tok_bf16", "samdec_tok2img": "s6d_samdec_tok2img_f32", "sam_mask_post": "s6d_sam_mask_post_f32", "samdec_upscale_heads": "s6d_samdec_upscale_heads_bf16", "mha": "s6d_mha_f32",
+               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "crop_resize_pad": "s6d_crop_resize_pad_f32", "samdec_img2tok": "s6d_samdec_img2tok_bf16", "samdec_tok2img": "s6d_samdec_tok2img_f32", "sam_mask_post": "s6d_sam_mask_post_f32", "nms": "s6d_nms_f32", "samdec_upscale_heads": "s6d_samdec_upscale_heads_bf16", "mha": "s6d_mha_f32",
                "linear_attn_focus": "s6d_linear_attn_focus_f32", "project_bbox": "s6d_project_bbox_f32"}.get(name)
         import os
         disabled = name in os.environ.get("S6D_DISABLE_FUSED", "").split(",")

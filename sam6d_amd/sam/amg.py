@@ -39,3 +39,45 @@ def process_point_batch(prompt_encoder, mask_decoder, image_embedding, in_points
     C = low_res.shape[1]
     return dict(masks=masks[idx], iou_preds=iou[idx], stability_score=stability[idx], boxes=boxes[idx],
                 point_index=idx // C, low_res_logits=low_res)
+
+
+def build_point_grid(n_per_side):
+    """utils/amg.py:179-186: n x n points at the pixel-cell centres of the unit square, (x, y), row-major."""
+    import numpy as np
+    offset = 1 / (2 * n_per_side)
+    side = np.linspace(offset, 1 - offset, n_per_side)
+    return np.stack([np.tile(side[None, :], (n_per_side, 1)), np.tile(side[:, None], (1, n_per_side))], axis=-1).reshape(-1, 2)
+
+
+def preprocess_shape(oldh, oldw, long_side):
+    """ResizeLongestSide.get_preprocess_shape (utils/transforms.py:95-102)."""
+    scale = long_side * 1.0 / max(oldh, oldw)
+    return int(oldh * scale + 0.5), int(oldw * scale + 0.5)
+
+
+@torch.no_grad()
+def generate_proposals(prompt_encoder, mask_decoder, image_embedding, original_size, img_size=1024, points_per_side=32,
+                       points_per_batch=256, mask_threshold=0.0, pred_iou_thresh=0.88, stability_score_thresh=0.95,
+                       stability_score_offset=1.0, box_nms_thresh=0.7):
+    """The single-crop path of ``SamAutomaticMaskGenerator._generate_masks`` (crop_n_layers = 0, the configuration the
+    ISM uses: model/sam.py:52-75) from the frame's image embedding to the de-duplicated proposals, entirely on the
+    device: point grid -> batches of prompts (process_point_batch) -> box NMS on the predicted IoUs.  With one crop
+    that spans the frame the crop-edge filter never fires (a box edge near the crop edge is near the image edge too,
+    utils/amg.py:78-88) and uncrop_* are identities; the RLE encode / decode round trip of the reference
+    (automatic_mask_generator.py:308-310, model/sam.py:146-148) is skipped -- the masks stay binary tensors.
+    -> dict(masks bool (K,H,W), boxes (K,4) long XYXY, iou_preds (K,), stability_score (K,), points (K,2) float64)."""
+    H, W = original_size
+    input_size = preprocess_shape(H, W, img_size)
+    grid = build_point_grid(points_per_side) * [[W, H]]                                   # points in the frame (x, y)
+    scale = [[input_size[1] / W, input_size[0] / H]]                                      # apply_coords (transforms.py:33-43)
+    pts = torch.as_tensor(grid * scale, device=image_embedding.device)                    # float64, as in the reference
+    parts = []
+    for a in range(0, pts.shape[0], points_per_batch):
+        r = process_point_batch(prompt_encoder, mask_decoder, image_embedding, pts[a:a + points_per_batch], input_size,
+                                original_size, img_size, mask_threshold, pred_iou_thresh, stability_score_thresh,
+                                stability_score_offset)
+        r["points"] = torch.as_tensor(grid, device=pts.device)[a:a + points_per_batch][r["point_index"]]
+        parts.append(r)
+    cat = {k: torch.cat([p[k] for p in parts]) for k in ("masks", "boxes", "iou_preds", "stability_score", "points")}
+    keep = ops.nms(cat["boxes"].float().contiguous(), cat["iou_preds"].float(), box_nms_thresh)
+    return {k: v[keep] for k, v in cat.items()}

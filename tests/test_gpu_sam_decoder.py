@@ -177,3 +177,44 @@ def test_process_point_batch_matches_reference_sequence(monkeypatch):
     assert torch.equal(out["point_index"].cpu(), idx // 3)
     assert torch.equal(out["masks"].cpu(), rb[idx]) and torch.equal(out["boxes"].cpu(), rbox[idx])
     np.testing.assert_array_equal(out["stability_score"].cpu().numpy(), rs[idx].numpy())
+
+
+def test_nms_kernel_vs_torchvision_algorithm():
+    from sam6d_amd import ops
+    g = torch.Generator().manual_seed(7)
+    for N in (1, 63, 64, 200, 1500):
+        xy = torch.rand(N, 2, generator=g) * 500
+        wh = 10 + torch.rand(N, 2, generator=g) * 120
+        boxes = torch.cat([xy, xy + wh], 1).round()                    # integer-valued like mask boxes (exact IoU ties)
+        scores = torch.rand(N, generator=g)
+        keep = ops.nms(boxes.cuda(), scores.cuda(), 0.7).cpu()
+        assert torch.equal(keep, osd.nms(boxes, scores, 0.7)), N
+    assert ops.nms(torch.zeros(0, 4).cuda(), torch.zeros(0).cuda(), 0.7).shape == (0,)
+    dup = torch.tensor([[0.0, 0, 10, 10]] * 5).cuda()                  # identical boxes: only the best survives
+    assert ops.nms(dup, torch.tensor([0.1, 0.9, 0.5, 0.9, 0.2]).cuda(), 0.7).tolist() == [1]
+
+
+def test_generate_proposals_pipeline(monkeypatch):
+    """Embedding -> proposals on the device: every output mask is one of the batch body's masks, the kept set is what
+    the torchvision-style NMS keeps among the filtered ones, boxes match the masks."""
+    from sam6d_amd.sam import amg
+    monkeypatch.setenv("S6D_SAM_DECODER_DTYPE", "bf16")
+    g, c, cfg, inp = case("sam")
+    inp = _cuda(inp)
+    m = seeded.load_seeded(build(cfg), c["weight_seed"]).cuda()
+    kw = dict(pred_iou_thresh=0.08, stability_score_thresh=0.3, stability_score_offset=0.02, box_nms_thresh=0.7)
+    out = amg.generate_proposals(m.prompt_encoder, m.mask_decoder, inp["emb"], (480, 640), points_per_side=8,
+                                 points_per_batch=24, **kw)
+    K = out["masks"].shape[0]
+    assert 0 < K < 8 * 8 * 3 and out["masks"].shape[1:] == (480, 640) and out["boxes"].shape == (K, 4)
+    assert torch.equal(out["boxes"].cpu(), osd.mask_to_box(out["masks"].cpu()))
+    assert (out["iou_preds"][:-1] >= out["iou_preds"][1:]).all()                   # NMS returns by decreasing score
+    # recompute the candidate set batch by batch and check the NMS decision against the oracle's
+    pts = torch.as_tensor(amg.build_point_grid(8) * [[640, 480]] * [[1024 / 640, 768 / 480]], device="cuda")
+    cand = [amg.process_point_batch(m.prompt_encoder, m.mask_decoder, inp["emb"], pts[a:a + 24], (768, 1024), (480, 640),
+                                    pred_iou_thresh=0.08, stability_score_thresh=0.3, stability_score_offset=0.02)
+            for a in range(0, 64, 24)]
+    boxes = torch.cat([r["boxes"] for r in cand]).float().cpu()
+    scores = torch.cat([r["iou_preds"] for r in cand]).float().cpu()
+    keep = osd.nms(boxes, scores, 0.7)
+    assert torch.equal(out["boxes"].cpu().float(), boxes[keep])

@@ -57,3 +57,11 @@ if __name__ == "__main__":
           f"x4 batches per 1024-prompt frame = {4 * ms:.2f} ms", flush=True)
     ref = ev(lambda: osd.mask_postprocess(low[:64], 1024, (768, 1024), (480, 640)), 3)
     print(f"reference op sequence (torch on the device), 192 masks: {ref:.3f} ms -> x16 per frame = {16 * ref:.1f} ms")
+    # the whole embedding -> proposals stage (grid, 1024 prompts, post-processing, filters, NMS); thresholds chosen so that
+    # about half of the 3072 masks of these seeded weights survive the filters (worst-ish case for the NMS)
+    from sam6d_amd.sam import amg  # noqa: E402
+    os.environ["S6D_SAM_DECODER_DTYPE"] = "bf16"
+    kw = dict(pred_iou_thresh=0.05, stability_score_thresh=0.3, stability_score_offset=0.02, points_per_batch=chunk)
+    out = amg.generate_proposals(m.prompt_encoder, m.mask_decoder, inp["emb"], (480, 640), **kw)
+    ms = ev(lambda: amg.generate_proposals(m.prompt_encoder, m.mask_decoder, inp["emb"], (480, 640), **kw), 3)
+    print(f"generate_proposals: 1024 prompts -> {out['masks'].shape[0]} proposals after filters + NMS: {ms:.2f} ms/frame")

@@ -163,6 +163,37 @@ def gen_ism():
     print("selected", len(rec["sel"]), "iou", rec["iou"], "vr", rec["visible_ratio"][:5], "final", rec["final"][:5])
 
 
+def gen_handoff():
+    """Reference mask_to_rle / Detections.save_to_file / convert_npz_to_json (model/utils.py) and the PEM side's
+    rle_to_binary_mask (Pose_Estimation_Model/utils/data_utils.py), run unmodified on synthetic detections."""
+    import importlib
+    import json
+    import tempfile
+    rh.ism()
+    mu = importlib.import_module("model.utils")
+    g = torch.Generator().manual_seed(12)
+    H, W, N = 37, 53, 6
+    masks = (torch.rand(N, H, W, generator=g) > 0.55)
+    masks[0] = False                                           # empty mask
+    masks[1] = True                                            # full mask (first pixel set: leading zero run of 0)
+    masks[2, :, :7] = True
+    boxes = torch.tensor([[0, 0, 0, 0], [0, 0, W - 1, H - 1], [0, 0, 6, H - 1], [3, 4, 30, 20], [10, 2, 50, 36], [1, 1, 2, 2]])
+    scores = torch.rand(N, generator=g)
+    obj = torch.tensor([0, 1, 2, 3, 7, 5])
+    rec = {}
+    rles = [mu.mask_to_rle(m.numpy().astype(np.uint8)) for m in masks]
+    for ds in ("lmo", "ycbv"):
+        det = mu.Detections({"masks": masks.clone(), "boxes": boxes.clone(), "scores": scores.clone(), "object_ids": obj.clone()})
+        det.to_numpy()
+        with tempfile.TemporaryDirectory() as d:
+            det.save_to_file(2, 17, 0.25, d + "/f", ds)
+            out = mu.convert_npz_to_json(0, [d + "/f.npz"])
+        rec[ds + "_json"] = np.array(json.dumps(out))
+    rec["rle_json"] = np.array(json.dumps(rles))
+    np.savez_compressed(os.path.join(OUT, "handoff.npz"), **rec)
+    print("handoff.npz", {k: len(str(v)) for k, v in rec.items()})
+
+
 def _samdec_ref(ns, cfg, seed):
     pe = ns.PromptEncoder(embed_dim=cfg["dim"], image_embedding_size=(cfg["emb"],) * 2,
                           input_image_size=(cfg["img"],) * 2, mask_in_chans=16)
@@ -288,4 +319,4 @@ def gen_dinov2():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    {"pem": gen_pem, "sam": gen_sam, "ism": gen_ism, "dinov2": gen_dinov2, "sam_decoder": gen_sam_decoder}[sys.argv[1]]()
+    {"pem": gen_pem, "sam": gen_sam, "ism": gen_ism, "dinov2": gen_dinov2, "sam_decoder": gen_sam_decoder, "handoff": gen_handoff}[sys.argv[1]]()

@@ -194,6 +194,23 @@ def gen_handoff():
     print("handoff.npz", {k: len(str(v)) for k, v in rec.items()})
 
 
+def gen_pem_pre():
+    """Reference geometry helpers of the PEM pre-processing (utils/data_utils.py), run unmodified."""
+    du = rh.pem_data_utils()
+    inp = synth.pem_pre_inputs(P=8, seed=3)
+    masks = inp["masks"].numpy()
+    depth, K = inp["depth"].numpy(), inp["K"].numpy()
+    rec = {"bbox": np.array([du.get_bbox(np.logical_and(m, depth > 0)) for m in masks])}
+    cloud = du.get_point_cloud_from_depth(depth, K)                      # float64 under NumPy 2, float32 under 1.x
+    rec["cloud_sum"], rec["cloud_smp"] = digest(torch.from_numpy(cloud.astype(np.float32)), 499)
+    y1, y2, x1, x2 = rec["bbox"][1]
+    rec["cloud_crop_smp"] = du.get_point_cloud_from_depth(depth, K, [y1, y2, x1, x2]).astype(np.float32).reshape(-1, 3)[::61]
+    ch = np.arange(0, (y2 - y1) * (x2 - x1), 37)
+    rec["rgb_choose"] = du.get_resize_rgb_choose(ch, [y1, y2, x1, x2], 224)
+    np.savez_compressed(os.path.join(OUT, "pem_pre.npz"), **rec)
+    print("pem_pre.npz", {k: v.shape for k, v in rec.items()}, rec["bbox"][:4].tolist())
+
+
 def _samdec_ref(ns, cfg, seed):
     pe = ns.PromptEncoder(embed_dim=cfg["dim"], image_embedding_size=(cfg["emb"],) * 2,
                           input_image_size=(cfg["img"],) * 2, mask_in_chans=16)
@@ -319,4 +336,4 @@ def gen_dinov2():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    {"pem": gen_pem, "sam": gen_sam, "ism": gen_ism, "dinov2": gen_dinov2, "sam_decoder": gen_sam_decoder, "handoff": gen_handoff}[sys.argv[1]]()
+    {"pem": gen_pem, "sam": gen_sam, "ism": gen_ism, "dinov2": gen_dinov2, "sam_decoder": gen_sam_decoder, "handoff": gen_handoff, "pem_pre": gen_pem_pre}[sys.argv[1]]()

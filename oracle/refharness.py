@@ -134,6 +134,18 @@ def sam_encoder():
     return _load_by_path(pkgname + ".image_encoder", os.path.join(base, "image_encoder.py"), pkgname)
 
 
+def pem_data_utils():
+    """Pose_Estimation_Model/utils/data_utils.py loaded by file path (imageio / cv2 / PIL stubbed: the geometry helpers
+    used for the goldens are pure numpy)."""
+    assert available()
+    for name in ("imageio", "cv2", "PIL", "PIL.Image"):
+        root = name.split(".")[0]
+        if root not in sys.modules and not _try_import(root):
+            _stub(name)
+    return sys.modules.get("_s6d_ref_pem_data_utils") or _load_by_path(
+        "_s6d_ref_pem_data_utils", os.path.join(PEM, "utils", "data_utils.py"))
+
+
 def sam_decoder():
     """segment_anything/modeling/{common,prompt_encoder,transformer,mask_decoder}.py loaded by file path (same
     package trick as sam_encoder()).  Returns a namespace with PromptEncoder, MaskDecoder, TwoWayTransformer."""

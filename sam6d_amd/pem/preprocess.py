@@ -1,0 +1,141 @@
+"""Per-detection pre-processing of the Pose Estimation Model on the device.
+
+Reference: ``Pose_Estimation_Model/run_inference_custom.py`` get_test_data :197-244 and ``provider/bop_test_dataset.py``
+get_instance :113-156 -- for every detection of a frame: mask AND valid depth, square crop box (utils/data_utils.py
+get_bbox :126-160), back-projection of the masked pixels (get_point_cloud_from_depth :92-110), radius filter around the
+centroid, sampling of 2048 points, the masked colour crop resized to 224 x 224 and normalised, and the index of every
+sampled point in that 224 x 224 grid (get_resize_rgb_choose :113-123).  The reference does this in 16 CPU DataLoader
+workers, one Python loop iteration per detection; here all detections of a frame go through one set of batched tensor
+ops on the device (ragged pixel lists are handled as one sorted (detection, y, x) list with per-detection offsets) and
+two host round trips per FRAME (the pixel-list length and the survivor list), none per detection.
+
+Defined differently from the reference, on purpose (oracle/pem_pre.py explains and mirrors both):
+  * sampling uses INJECTED uniforms (``keys``, one per crop pixel) instead of numpy's global RNG: with replacement
+    idx_i = floor(u_i * n) when n <= n_sample, else the n_sample smallest keys in key order;
+  * the colour crop is bilinear with half-pixel centres in float32, rounded to uint8 (the reference calls cv2.resize,
+    whose fixed-point arithmetic can differ by one grey level).
+"""
+import torch
+
+MEAN = (0.485, 0.456, 0.406)
+STD = (0.229, 0.224, 0.225)
+
+
+def square_boxes(m):
+    """get_bbox for a stack of masks (P,H,W) bool with at least one set pixel each -> (P,4) long [rmin,rmax,cmin,cmax]."""
+    P, H, W = m.shape
+    rows, cols = m.any(2), m.any(1)
+    ar_h, ar_w = torch.arange(H, device=m.device), torch.arange(W, device=m.device)
+    rmin = torch.where(rows, ar_h, H).min(1).values
+    rmax = torch.where(rows, ar_h, -1).max(1).values + 1
+    cmin = torch.where(cols, ar_w, W).min(1).values
+    cmax = torch.where(cols, ar_w, -1).max(1).values + 1
+    b = torch.minimum(torch.maximum(rmax - rmin, cmax - cmin), torch.tensor(min(H, W), device=m.device))
+    cy, cx, half = (rmin + rmax) // 2, (cmin + cmax) // 2, b // 2
+    rmin, rmax, cmin, cmax = cy - half, cy + half, cx - half, cx + half
+    d = (-rmin).clamp(min=0)
+    rmin, rmax = rmin + d, rmax + d
+    d = (-cmin).clamp(min=0)
+    cmin, cmax = cmin + d, cmax + d
+    d = (rmax - H).clamp(min=0)
+    rmin, rmax = rmin - d, rmax - d
+    d = (cmax - W).clamp(min=0)
+    cmin, cmax = cmin - d, cmax - d
+    return torch.stack([rmin, rmax, cmin, cmax], 1)
+
+
+def _crops(image_u8, m, box, img_size, rgb_mask_flag):
+    """Masked, channel-flipped, bilinearly resized, normalised colour crops (P,3,S,S) f32 for boxes (P,4)."""
+    P = box.shape[0]
+    dev = image_u8.device
+    S = img_size
+    y1, y2, x1, x2 = box.unbind(1)
+    o = torch.arange(S, device=dev, dtype=torch.float32) + 0.5
+    # divisors are TENSORS on purpose: `tensor / python_scalar` multiplies by the rounded reciprocal on the device, which
+    # is not the correctly rounded quotient the reference's numpy arithmetic produces
+    S_t, c255 = torch.tensor(float(S), device=dev), torch.tensor(255.0, device=dev)
+
+    def taps(lo, hi):
+        n = (hi - lo).float()
+        s = o[None, :] * (n / S_t)[:, None] - 0.5                                      # (P,S) source coordinate in the crop
+        i0 = s.floor()
+        f = s - i0
+        i0 = i0.long()
+        last = (hi - lo - 1)[:, None]
+        return lo[:, None] + i0.clamp(min=0).minimum(last), lo[:, None] + (i0 + 1).clamp(min=0).minimum(last), f
+    ya, yb, fy = taps(y1, y2)
+    xa, xb, fx = taps(x1, x2)
+    img = image_u8.flip(-1).float()                                                    # [:, :, ::-1] of the reference
+    pidx = torch.arange(P, device=dev)[:, None, None]
+
+    def px(yy, xx):                                                                    # (P,S,S,3) tap values
+        v = img[yy[:, :, None], xx[:, None, :]]
+        if rgb_mask_flag:
+            v = v * m[pidx, yy[:, :, None], xx[:, None, :]].unsqueeze(-1)
+        return v
+    fx_, fy_ = fx[:, None, :, None], fy[:, :, None, None]
+    top = px(ya, xa) * (1 - fx_) + px(ya, xb) * fx_
+    bot = px(yb, xa) * (1 - fx_) + px(yb, xb) * fx_
+    out = (top * (1 - fy_) + bot * fy_ + 0.5).floor().clamp(0, 255)                    # == uint8 crop of the reference path
+    mean = torch.tensor(MEAN, device=dev)
+    std = torch.tensor(STD, device=dev)
+    return ((out / c255 - mean) / std).permute(0, 3, 1, 2).contiguous()
+
+
+@torch.no_grad()
+def observed_inputs(image_u8, depth, K, masks, radius, keys, n_sample=2048, img_size=224, min_points=32, min_inliers=4,
+                    radius_factor=1.2, rgb_mask_flag=True):
+    """image_u8 (H,W,3) uint8 RGB, depth (H,W) f32 metres, K 3x3 (host), masks (P,H,W) bool, keys (P,H*W) f32 uniforms,
+    all tensors on one device.  -> dict(pts (M,n,3) f32, rgb (M,3,S,S) f32, rgb_choose (M,n) i64, kept (M,) i64 indices
+    of the detections that passed the two size tests (> min_points masked pixels, >= min_inliers after the radius
+    filter), bbox (M,4) i64 [y1,y2,x1,x2])."""
+    dev = depth.device
+    P, H, W = masks.shape
+    fx, fy, cx, cy = (float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]))
+    m = (masks > 0) & (depth > 0)[None]
+    cnt = m.flatten(1).sum(1)
+    ok1 = cnt > min_points
+    box = square_boxes(m | ~ok1[:, None, None])                                        # dummy full mask where empty
+    y1, y2, x1, x2 = box.unbind(1)
+    # ---- ragged pixel lists as one (detection, y, x) list, row-major inside each crop ---------------------------------
+    pyx = torch.nonzero(m)                                                             # host round trip #1 (list length)
+    p_, y_, x_ = pyx.unbind(1)
+    inside = (y_ >= y1[p_]) & (y_ < y2[p_]) & (x_ >= x1[p_]) & (x_ < x2[p_]) & ok1[p_]
+    p_, y_, x_ = p_[inside], y_[inside], x_[inside]
+    choose = (y_ - y1[p_]) * (x2 - x1)[p_] + (x_ - x1[p_])
+    z = depth[y_, x_]
+    fx_t, fy_t = torch.tensor(fx, device=dev), torch.tensor(fy, device=dev)            # tensor divisors: true division
+    cloud = torch.stack([(x_.float() - cx) * z / fx_t, (y_.float() - cy) * z / fy_t, z], 1)  # float32, reference order
+    n0 = torch.bincount(p_, minlength=P)
+    center = (torch.zeros(P, 3, dtype=torch.float64, device=dev).index_add_(0, p_, cloud.double())
+              / n0.clamp(min=1)[:, None]).float()
+    dist = torch.linalg.norm(cloud - center[p_], dim=1)
+    flag = dist.double() < radius * radius_factor
+    p_, choose, cloud = p_[flag], choose[flag], cloud[flag]
+    n = torch.bincount(p_, minlength=P)                                                # inliers per detection
+    ok = ok1 & (n >= min_inliers)
+    start = torch.cumsum(n, 0) - n                                                     # offset of each detection's list
+    # ---- the defined sampler ---------------------------------------------------------------------------------------
+    L = int(n.max().item()) if P else 0                                                # host round trip #2
+    L = max(L, n_sample)
+    kk = keys[:, :L].float()
+    ar = torch.arange(L, device=dev)[None, :]
+    # the n_sample smallest keys in (key, position) order == a stable argsort's first n_sample entries, by selection
+    # instead of a full sort: non-negative float32 bit patterns order like the values, the position breaks ties
+    comp = (kk.contiguous().view(torch.int32).long() << 32) | ar
+    comp = torch.where(ar < n[:, None], comp, torch.full_like(comp, torch.iinfo(torch.int64).max))
+    without = torch.topk(comp, n_sample, dim=1, largest=False, sorted=True).values & 0xFFFFFFFF
+    with_r = (kk[:, :n_sample].double() * n[:, None]).floor().long()
+    idx = torch.where((n <= n_sample)[:, None], with_r, without)                       # (P,n_sample) in-list positions
+    kept = torch.nonzero(ok).squeeze(1)
+    g = (start[:, None] + idx)[kept].clamp(max=max(cloud.shape[0] - 1, 0))
+    pts = cloud[g]
+    ch = choose[g]
+    bk = box[kept]
+    rgb = _crops(image_u8, m[kept].float(), bk, img_size, rgb_mask_flag) if len(kept) else \
+        torch.zeros(0, 3, img_size, img_size, device=dev)
+    ch_h, ch_w = (bk[:, 1] - bk[:, 0]), (bk[:, 3] - bk[:, 2])
+    row, col = ch // ch_w[:, None], ch % ch_w[:, None]
+    rgb_choose = ((row.double() * (img_size / ch_h.double())[:, None]).floor() * img_size +
+                  (col.double() * (img_size / ch_w.double())[:, None]).floor()).long()
+    return dict(pts=pts, rgb=rgb, rgb_choose=rgb_choose, kept=kept, bbox=bk)

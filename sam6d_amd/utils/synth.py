@@ -180,3 +180,18 @@ def sam_lowres_logits(B, C=3, n=256, seed=1):
     out[0, 0] = -5 + 0.3 * torch.randn(n, n, generator=g)
     out[-1, -1] = 5 + 0.3 * torch.randn(n, n, generator=g)
     return out
+
+
+def pem_pre_inputs(P=8, H=480, W=640, seed=1):
+    """A frame for the PEM pre-processing: RGB image, proposal masks (dinov2_inputs' shapes: square, tall, wide, tiny,
+    near-full, random), a depth map in metres with holes whose surface bulges under every mask (so the radius filter
+    cuts some points), the LM camera, and one uniform key per pixel and detection for the sampler."""
+    d = dinov2_inputs(P=P, H=H, W=W, seed=seed)
+    g = _g(seed + 100)
+    ys = torch.arange(H).view(H, 1).float()
+    xs = torch.arange(W).view(1, W).float()
+    depth = 0.9 + 0.1 * torch.sin(xs / 37.0) * torch.cos(ys / 29.0) + 0.002 * torch.randn(H, W, generator=g)
+    depth[torch.rand(H, W, generator=g) < 0.05] = 0.0
+    K = torch.tensor([[572.4114, 0.0, 325.2611], [0.0, 573.57043, 242.04899], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    keys = torch.rand(P, H * W, generator=g)
+    return dict(image=d["image"], masks=d["masks"] > 0, depth=depth, K=K, keys=keys)

@@ -1,0 +1,48 @@
+"""PEM per-detection pre-processing: the oracle's geometry helpers against the reference's
+(golden), and the batched device implementation (plain tensor ops: it also runs on the CPU) against the oracle's
+per-detection loop on a frame with square / tall / wide / tiny / near-full / random proposals."""
+import numpy as np
+import torch
+
+from oracle import pem_pre as opre
+from sam6d_amd.pem import preprocess as pre
+from sam6d_amd.utils import synth
+from tests import util
+
+
+def test_oracle_helpers_match_reference_golden():
+    g = util.golden("pem_pre.npz")
+    inp = synth.pem_pre_inputs(P=8, seed=3)
+    masks, depth, K = inp["masks"].numpy(), inp["depth"].numpy(), inp["K"].numpy()
+    bbox = np.array([opre.get_bbox(np.logical_and(m, depth > 0)) for m in masks])
+    np.testing.assert_array_equal(bbox, g["bbox"])
+    cloud = opre.point_cloud(depth, K)
+    util.assert_digest_close(torch.from_numpy(cloud), g["cloud_sum"], g["cloud_smp"], 499, 1e-6, 1e-7, "back-projection")
+    y1, y2, x1, x2 = bbox[1]
+    np.testing.assert_allclose(cloud[y1:y2, x1:x2].reshape(-1, 3)[::61], g["cloud_crop_smp"], rtol=1e-6, atol=1e-7)
+    ch = np.arange(0, (y2 - y1) * (x2 - x1), 37)
+    np.testing.assert_array_equal(opre.resize_rgb_choose(ch, [y1, y2, x1, x2], 224), g["rgb_choose"])
+    # batched boxes of the product == the reference rule, mask by mask
+    m = torch.from_numpy(np.logical_and(masks, depth > 0))
+    np.testing.assert_array_equal(pre.square_boxes(m).numpy(), g["bbox"])
+
+
+def test_batched_preprocessing_matches_oracle_loop():
+    inp = synth.pem_pre_inputs(P=8, seed=3)
+    kw = dict(radius=0.12, n_sample=512, img_size=224, min_points=32, min_inliers=4, radius_factor=1.2)
+    ref = opre.preprocess_frame(inp["image"], inp["depth"].numpy(), inp["K"].numpy(), inp["masks"].numpy(),
+                                keys=inp["keys"].numpy(), **kw)
+    out = pre.observed_inputs(torch.from_numpy(inp["image"]), inp["depth"], inp["K"], inp["masks"], keys=inp["keys"], **kw)
+    assert out["kept"].tolist() == ref["kept"].tolist() and len(ref["kept"]) >= 6          # the 4x3-px proposal is dropped
+    np.testing.assert_array_equal(out["bbox"].numpy(), ref["bbox"])
+    np.testing.assert_array_equal(out["rgb_choose"].numpy(), ref["rgb_choose"])
+    np.testing.assert_array_equal(out["pts"].numpy(), ref["pts"])
+    np.testing.assert_array_equal(out["rgb"].numpy(), ref["rgb"])
+    # both sampler branches were exercised: a detection with fewer inliers than n_sample repeats points
+    assert any(len(np.unique(r)) < 512 for r in ref["rgb_choose"]) and any(len(np.unique(c, axis=0)) == 512 for c in ref["pts"])
+
+
+def test_no_detection_survives():
+    inp = synth.pem_pre_inputs(P=3, seed=5)
+    out = pre.observed_inputs(torch.from_numpy(inp["image"]), inp["depth"] * 0, inp["K"], inp["masks"], 0.1, inp["keys"])
+    assert out["pts"].shape[0] == 0 and out["rgb"].shape == (0, 3, 224, 224) and out["kept"].numel() == 0

@@ -1,0 +1,92 @@
+"""One frame through every stage in one process, everything on the device (the chain SURVEY.md section 8f points at).
+
+    RGB-D frame -> SAM ViT-H embedding -> 1024 point prompts -> masks / boxes (filters + NMS)           [ISM, segmentor]
+               -> masked 224^2 crops -> DINOv2 cls + patch descriptors -> semantic / appearance / geometric scores  [ISM]
+               -> top detections -> point clouds + colour crops (pre-processing) -> PEM Net -> R, t per detection [PEM]
+
+The reference runs this as two programs joined by JSON / npz files (``demo.sh``: run_inference_custom.py of the ISM, then
+of the PEM) with CPU data loading in between.  ``FramePipeline`` holds the five models and the per-object template data
+and passes tensors from stage to stage (``sam6d_amd.ism.handoff.Detections``); each stage is the drop-in module documented
+in INTEGRATION.md, so the arithmetic of every stage is the parity-tested one.  What this class adds is only the glue the
+reference has in its two ``run_inference_custom.py`` scripts (detector.py:331-430 for the ISM side), reduced to tensor ops:
+image resize to the encoder's input (bilinear with antialiasing on the device -- the reference uses PIL, unpinned here),
+dropping tiny detections (``Detections.remove_very_small_detections``, model/utils.py:118-127), keeping the best
+detections by final score.
+"""
+import time
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+
+from .ism.handoff import Detections
+from .pem import preprocess as pem_pre
+from .sam import amg
+from .sam.image_encoder import preprocess as sam_preprocess
+
+
+class FramePipeline:
+    def __init__(self, sam_encoder, prompt_encoder, mask_decoder, descriptor_model, scorer, pem_net, pem_templates,
+                 object_radius, top_k=10, points_per_batch=256, min_box_size=0.05 ** 2, min_mask_size=3e-4 ** 2,
+                 segmentor=None):
+        """descriptor_model: sam6d_amd.ism.dinov2.CustomDINOv2; scorer: sam6d_amd.ism.scoring.FrameScorer (holds the
+        template descriptors); pem_templates: dict(dense_po (1,n,3), dense_fo (1,n,C), model (1,m,3)) of the object;
+        segmentor: keyword overrides of amg.generate_proposals (thresholds)."""
+        self.enc, self.pe, self.md, self.desc, self.scorer, self.pem = (sam_encoder, prompt_encoder, mask_decoder,
+                                                                       descriptor_model, scorer, pem_net)
+        self.tpl, self.radius, self.top_k, self.ppb = pem_templates, object_radius, top_k, points_per_batch
+        self.min_box, self.min_mask = min_box_size, min_mask_size
+        self.seg_kw = segmentor or {}
+        self.times = {}
+
+    def _tick(self, name, t0):
+        torch.cuda.synchronize()
+        self.times[name] = (time.perf_counter() - t0) * 1e3
+        return time.perf_counter()
+
+    @torch.no_grad()
+    def __call__(self, image_u8, depth, K, sample_keys, coarse_rand_u):
+        """image_u8 (H,W,3) uint8 RGB, depth (H,W) f32 metres, K (3,3) float64, all on the device.  sample_keys
+        (top_k, H*W) / coarse_rand_u (top_k, 18000): the injected random numbers of the two sampling steps.
+        -> (Detections of the frame, dict(pred_R, pred_t, pred_pose_score, kept))."""
+        H, W = image_u8.shape[:2]
+        t0 = time.perf_counter()
+        # ---- SAM image encoder ------------------------------------------------------------------------------------
+        ih, iw = amg.preprocess_shape(H, W, self.enc.img_size)
+        x = F.interpolate(image_u8.permute(2, 0, 1)[None].float(), (ih, iw), mode="bilinear", antialias=True,
+                          align_corners=False)
+        emb = self.enc(sam_preprocess(x, self.enc.img_size)).float()
+        t0 = self._tick("sam_encoder", t0)
+        # ---- proposals ----------------------------------------------------------------------------------------------
+        prop = amg.generate_proposals(self.pe, self.md, emb, (H, W), self.enc.img_size, points_per_batch=self.ppb,
+                                      **self.seg_kw)
+        area = prop["masks"].flatten(1).sum(1).float() / (H * W)
+        b = prop["boxes"].float()
+        box_area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]) / (H * W)
+        keep = (box_area > self.min_box) & (area > self.min_mask)
+        masks, boxes = prop["masks"][keep], prop["boxes"][keep]
+        t0 = self._tick("proposals", t0)
+        if masks.shape[0] == 0:
+            return Detections(0, 0, masks, boxes, boxes.new_zeros(0), boxes.new_zeros(0)), None
+        # ---- descriptors + scoring -----------------------------------------------------------------------------------
+        cls, patch = self.desc(image_u8.cpu().numpy(), SimpleNamespace(masks=masks.float(), boxes=boxes))
+        t0 = self._tick("descriptors", t0)
+        sc = self.scorer.score(cls, patch, masks.float(), boxes.float(), depth, K)
+        order = torch.argsort(sc["final"], descending=True)[: self.top_k]
+        sel = sc["sel"][order]
+        det = Detections(0, 0, masks[sel], boxes[sel], sc["final"][order], sc["pred_obj"][order])
+        t0 = self._tick("scoring", t0)
+        # ---- PEM ------------------------------------------------------------------------------------------------------
+        obs = pem_pre.observed_inputs(image_u8, depth, K, det.masks, self.radius, sample_keys[: det.masks.shape[0]])
+        t0 = self._tick("pem_preprocessing", t0)
+        M = obs["pts"].shape[0]
+        if M == 0:
+            return det, None
+        ep = dict(pts=obs["pts"], rgb=obs["rgb"], rgb_choose=obs["rgb_choose"],
+                  model=self.tpl["model"].expand(M, -1, -1).contiguous(),
+                  dense_po=self.tpl["dense_po"].expand(M, -1, -1).contiguous(),
+                  dense_fo=self.tpl["dense_fo"].expand(M, -1, -1).contiguous(), coarse_rand_u=coarse_rand_u[:M])
+        out = self.pem(ep)
+        self._tick("pem", t0)
+        return det, dict(pred_R=out["pred_R"], pred_t=out["pred_t"], pred_pose_score=out["pred_pose_score"],
+                         kept=obs["kept"])

@@ -71,6 +71,16 @@ def generate_proposals(prompt_encoder, mask_decoder, image_embedding, original_s
     grid = build_point_grid(points_per_side) * [[W, H]]                                   # points in the frame (x, y)
     scale = [[input_size[1] / W, input_size[0] / H]]                                      # apply_coords (transforms.py:33-43)
     pts = torch.as_tensor(grid * scale, device=image_embedding.device)                    # float64, as in the reference
+    import os
+    import time
+    prof = os.environ.get("S6D_AMG_PROFILE")
+    tq = [time.perf_counter()]
+
+    def tick(name):
+        if prof:
+            torch.cuda.synchronize()
+            tq.append(time.perf_counter())
+            print(f"[amg] {name}: {(tq[-1] - tq[-2]) * 1e3:.1f} ms", flush=True)
     parts = []
     for a in range(0, pts.shape[0], points_per_batch):
         r = process_point_batch(prompt_encoder, mask_decoder, image_embedding, pts[a:a + points_per_batch], input_size,
@@ -78,6 +88,11 @@ def generate_proposals(prompt_encoder, mask_decoder, image_embedding, original_s
                                 stability_score_offset)
         r["points"] = torch.as_tensor(grid, device=pts.device)[a:a + points_per_batch][r["point_index"]]
         parts.append(r)
+    tick("prompt batches")
     cat = {k: torch.cat([p[k] for p in parts]) for k in ("masks", "boxes", "iou_preds", "stability_score", "points")}
+    tick(f"concatenate {cat['masks'].shape[0]} candidates")
     keep = ops.nms(cat["boxes"].float().contiguous(), cat["iou_preds"].float(), box_nms_thresh)
-    return {k: v[keep] for k, v in cat.items()}
+    tick("nms")
+    out = {k: v[keep] for k, v in cat.items()}
+    tick(f"gather {keep.shape[0]} survivors")
+    return out

@@ -1,0 +1,66 @@
+"""The whole SAM-6D frame in one process on one MI355X: per-stage milliseconds of sam6d_amd.pipeline.FramePipeline with
+seeded weights and a synthetic 480x640 RGB-D frame (run on the GPU box).  Seeded weights give meaningless masks, so the
+segmentor thresholds are set for these weights (a fraction of the 3072 candidates passes) and the frame's proposals are
+what its NMS leaves; when that is fewer than 16 the synthetic proposal set of the DINOv2 tests (128 ellipses) is scored instead, so the
+descriptor / scoring / PEM stages are timed at the bench's sizes."""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+from oracle import sam_decoder as osd  # noqa: E402  (config dict only)
+from sam6d_amd import pipeline  # noqa: E402
+from sam6d_amd.ism import dinov2 as pd  # noqa: E402
+from sam6d_amd.ism.scoring import FrameScorer  # noqa: E402
+from sam6d_amd.pem import pose_estimation_model as pm  # noqa: E402
+from sam6d_amd.sam import amg  # noqa: E402
+from sam6d_amd.sam.image_encoder import build_vit_h  # noqa: E402
+from sam6d_amd.utils import seeded, synth  # noqa: E402
+from tests.test_host_sam_decoder import build as build_decoder  # noqa: E402
+
+dev = torch.device("cuda", 0)
+t0 = time.time()
+enc = seeded.load_seeded(build_vit_h().eval(), 3).to(dev)
+dec = seeded.load_seeded(build_decoder(osd.SAM), 2).to(dev)
+dino = pd.CustomDINOv2.__new__(pd.CustomDINOv2)
+torch.nn.Module.__init__(dino)
+dino.model = seeded.load_seeded(pd._make_dinov2_model(arch_name="vit_large").eval(), 6).to(dev)
+dino.patch_size, dino.validpatch_thresh, dino.chunk_size, dino.proposal_size, dino.token_name = 14, 0.5, 128, 224, "x_norm_clstoken"
+ism = synth.ism_inputs(P=128, O=1, T=42, seed=11)
+scorer = FrameScorer(ism["ref_cls"].to(dev), ism["ref_patch"].to(dev), ism["poses"].to(dev), ism["pointcloud"].to(dev),
+                     confidence_thresh=-1.0)       # seeded descriptors match no template: let every proposal through
+pem = seeded.load_seeded(pm.Net(pm.default_cfg()).eval(), 1).to(dev)
+pin = synth.pem_inputs(1, seed=1)
+tpl = {k: pin[k].to(dev) for k in ("model", "dense_po", "dense_fo")}
+print(f"models ready in {time.time() - t0:.0f} s", flush=True)
+
+frame = synth.pem_pre_inputs(P=128, seed=3)
+img = torch.from_numpy(frame["image"]).to(dev)
+depth, K = frame["depth"].to(dev), frame["K"].to(dev)
+keys = torch.rand(16, 480 * 640, generator=torch.Generator().manual_seed(1)).to(dev)
+rand_u = synth.coarse_uniforms(16, 2).to(dev)
+pipe = pipeline.FramePipeline(enc, dec.prompt_encoder, dec.mask_decoder, dino, scorer, pem, tpl, object_radius=0.12,
+                              top_k=10, segmentor=dict(pred_iou_thresh=0.09, stability_score_thresh=0.3,
+                                                       stability_score_offset=0.02))
+# seeded weights: substitute the synthetic proposals when the generator's own survive in too small a number
+real_generate = amg.generate_proposals
+sub_masks, sub_boxes = frame["masks"].to(dev), synth.dinov2_inputs(P=128, seed=3)["boxes"].to(dev)
+
+
+def generate(*a, **k):
+    r = real_generate(*a, **k)
+    if r["masks"].shape[0] < 16:
+        r = dict(r, masks=sub_masks, boxes=sub_boxes)
+    return r
+
+
+amg.generate_proposals = generate
+for it in range(3):
+    t = time.perf_counter()
+    det, poses = pipe(img, depth, K, keys, rand_u)
+    torch.cuda.synchronize()
+    total = (time.perf_counter() - t) * 1e3
+    n_pose = 0 if poses is None else poses["pred_R"].shape[0]
+    print(f"frame {it}: {total:.1f} ms  -> {det.masks.shape[0]} detections, {n_pose} poses | " +
+          ", ".join(f"{k} {v:.1f}" for k, v in pipe.times.items()), flush=True)

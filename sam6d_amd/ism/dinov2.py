@@ -256,42 +256,65 @@ def _make_dinov2_model(*, arch_name="vit_large", img_size=518, patch_size=14, in
                             interpolate_antialias=interpolate_antialias, interpolate_offset=interpolate_offset, **kwargs)
 
 
-def crop_params(boxes, target):
-    """Geometry of CropResizePad.__call__ (utils/bbox_utils.py:98-126) for every proposal, as the (P,12) int32 record
-    table of s6d_crop_resize_pad_f32.  boxes (P,4) integer xyxy on the HOST.  Mirrors the reference's arithmetic
-    type by type: scale = float32(1 / longest side) * float32(target) read back as a Python float; sizes floor(size * scale) in
-    double; the index scale handed to the resize is float32(1 / scale).  Raises RuntimeError where the reference's
-    torch.stack would (a crop whose second resize does not land on `target`)."""
+def _crop_geometry(boxes, target):
+    """Size arithmetic of CropResizePad.__call__ (utils/bbox_utils.py:98-126) for every proposal, vectorised, plus the
+    three ways the reference fails on a box: empty box / a side that vanishes after the first resize (F.interpolate
+    raises), a non-square padded crop (its assert), a second resize that does not reach `target` (torch.stack raises).
+    Mirrors the reference's arithmetic type by type: scale = float32(1 / longest side) * float32(target) read back as a
+    Python float; sizes floor(size * scale) in double; the index scale handed to the resize is float32(1 / scale)."""
     b = np.asarray(boxes, dtype=np.int64).reshape(-1, 4)
-    P = b.shape[0]
-    rec = np.zeros((P, 12), dtype=np.int32)
-    if P == 0:
-        return rec
     w, h = b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]
-    if (np.minimum(w, h) <= 0).any():
-        raise RuntimeError("crop_params: empty proposal box (the reference fails in F.interpolate on these)")
+    empty = np.minimum(w, h) <= 0
+    ws, hs = np.maximum(w, 1), np.maximum(h, 1)
     # `self.target_max / torch.max(box_sizes)`: int / LongTensor is Tensor.__rtruediv__ = reciprocal() * other, i.e.
     # float32(1 / side) * float32(target) -- one ulp away from float32(target / side) for some sides (446 -> 224 rows,
     # not 223), so it is spelled the reference's way
-    s1 = ((np.float32(1.0) / np.maximum(w, h).astype(np.float32)) * np.float32(target)).astype(np.float64)
-    h1, w1 = np.floor(h * s1).astype(np.int64), np.floor(w * s1).astype(np.int64)
-    if (np.minimum(h1, w1) <= 0).any():
+    s1 = ((np.float32(1.0) / np.maximum(ws, hs).astype(np.float32)) * np.float32(target)).astype(np.float64)
+    h1, w1 = np.floor(hs * s1).astype(np.int64), np.floor(ws * s1).astype(np.int64)
+    vanish = np.minimum(h1, w1) <= 0
+    h1s, w1s = np.maximum(h1, 1), np.maximum(w1, 1)
+    padded = (w1s / h1s) != 1.0                                      # `self.target_ratio != original_ratio`
+    top = np.where(padded, np.maximum((target - h1s) // 2, 0), 0)
+    left = np.where(padded, np.maximum((target - w1s) // 2, 0), 0)
+    Hp = np.where(padded, h1s + top + (target - h1s - top), h1s)      # F.pad with the reference's bottom / right amounts
+    Wp = np.where(padded, w1s + left + (target - w1s - left), w1s)
+    notsquare = Hp != Wp
+    s2 = target / np.maximum(Hp, 1).astype(np.float64)
+    short = np.floor(Hp * s2).astype(np.int64) != target
+    return dict(b=b, h=h, w=w, h1=h1s, w1=w1s, top=top, left=left, Hp=Hp, s1=s1, s2=s2, empty=empty, vanish=vanish,
+                notsquare=notsquare, short=short)
+
+
+def crop_valid(boxes, target):
+    """(P,) bool: the proposals whose crop the reference can produce (see crop_params for the three failure modes)."""
+    g = _crop_geometry(boxes, target)
+    return ~(g["empty"] | g["vanish"] | g["notsquare"] | g["short"])
+
+
+def crop_params(boxes, target):
+    """Geometry of CropResizePad.__call__ for every proposal, as the (P,12) int32 record table of
+    s6d_crop_resize_pad_f32.  boxes (P,4) integer xyxy on the HOST.  Raises where the reference does: RuntimeError for an
+    empty box or a side that vanishes in the first resize, AssertionError for a non-square padded crop, RuntimeError
+    ("stack expects each tensor to be equal size") for a crop whose second resize does not land on `target`."""
+    g = _crop_geometry(boxes, target)
+    P = g["b"].shape[0]
+    rec = np.zeros((P, 12), dtype=np.int32)
+    if P == 0:
+        return rec
+    if g["empty"].any():
+        raise RuntimeError("crop_params: empty proposal box (the reference fails in F.interpolate on these)")
+    if g["vanish"].any():
         raise RuntimeError("crop_params: a proposal side vanishes after the resize (the reference fails here too)")
-    padded = (w1 / h1) != 1.0                                        # `self.target_ratio != original_ratio`
-    top = np.where(padded, np.maximum((target - h1) // 2, 0), 0)
-    left = np.where(padded, np.maximum((target - w1) // 2, 0), 0)
-    Hp = np.where(padded, h1 + top + (target - h1 - top), h1)        # F.pad with the reference's bottom / right amounts
-    Wp = np.where(padded, w1 + left + (target - w1 - left), w1)
-    if (Hp != Wp).any():
+    if g["notsquare"].any():
         raise AssertionError("image is not square after padding")   # bbox_utils.py:120-122
-    s2 = target / Hp.astype(np.float64)
-    if (np.floor(Hp * s2).astype(np.int64) != target).any():
+    if g["short"].any():
         raise RuntimeError("stack expects each tensor to be equal size: a crop's second resize does not reach "
                            f"{target} (reference behaviour for this box shape, bbox_utils.py:123-126)")
-    rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3] = b[:, 0], b[:, 1], h, w
-    rec[:, 4], rec[:, 5], rec[:, 6], rec[:, 7], rec[:, 8] = h1, w1, top, left, Hp
-    rec[:, 9] = (1.0 / s1).astype(np.float32).view(np.int32)
-    rec[:, 10] = (1.0 / s2).astype(np.float32).view(np.int32)
+    b = g["b"]
+    rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3] = b[:, 0], b[:, 1], g["h"], g["w"]
+    rec[:, 4], rec[:, 5], rec[:, 6], rec[:, 7], rec[:, 8] = g["h1"], g["w1"], g["top"], g["left"], g["Hp"]
+    rec[:, 9] = (1.0 / g["s1"]).astype(np.float32).view(np.int32)
+    rec[:, 10] = (1.0 / g["s2"]).astype(np.float32).view(np.int32)
     return rec
 
 

@@ -64,6 +64,10 @@ class FramePipeline:
         b = prop["boxes"].float()
         box_area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]) / (H * W)
         keep = (box_area > self.min_box) & (area > self.min_mask)
+        # proposals whose crop the reference's CropResizePad cannot produce (it raises on most exactly-square crops and on
+        # slivers that vanish in the resize; sam6d_amd/ism/dinov2.py crop_params) are dropped here instead of aborting the frame
+        from .ism.dinov2 import crop_valid
+        keep &= torch.from_numpy(crop_valid(prop["boxes"].cpu().numpy(), self.desc.proposal_size)).to(keep.device)
         masks, boxes = prop["masks"][keep], prop["boxes"][keep]
         t0 = self._tick("proposals", t0)
         if masks.shape[0] == 0:

@@ -1,0 +1,67 @@
+"""One frame through the whole chain (sam6d_amd.pipeline.FramePipeline) with small seeded models: every stage hands
+tensors to the next one and the result is a set of rigid poses."""
+from functools import partial
+
+import pytest
+import torch
+
+from oracle import dinov2 as odino
+from oracle import sam as osam
+from sam6d_amd.utils import seeded, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_frame_through_all_five_models():
+    from sam6d_amd import pipeline
+    from sam6d_amd.ism import dinov2 as pd
+    from sam6d_amd.ism.scoring import FrameScorer
+    from sam6d_amd.pem import pose_estimation_model as pm
+    from sam6d_amd.sam import mask_decoder as md
+    from sam6d_amd.sam.image_encoder import ImageEncoderViT
+    dev = torch.device("cuda", 0)
+    c = osam.MINI                                                   # 512 px, 32 x 32 x 64 embedding
+    enc = seeded.load_seeded(ImageEncoderViT(
+        depth=c["depth"], embed_dim=c["dim"], img_size=c["img_size"], mlp_ratio=4, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6),
+        num_heads=c["heads"], patch_size=16, qkv_bias=True, use_rel_pos=True, global_attn_indexes=c["global_idx"],
+        window_size=c["window"], out_chans=c["out_chans"]).eval(), 3).to(dev)
+    dec = torch.nn.Module()
+    dec.prompt_encoder = md.PromptEncoder(embed_dim=64, image_embedding_size=(32, 32), input_image_size=(512, 512), mask_in_chans=16)
+    dec.mask_decoder = md.MaskDecoder(num_multimask_outputs=3, transformer=md.TwoWayTransformer(depth=2, embedding_dim=64, mlp_dim=96, num_heads=4),
+                                      transformer_dim=64, iou_head_depth=3, iou_head_hidden_dim=48)
+    dec = seeded.load_seeded(dec.eval(), 2).to(dev)
+    dc = odino.MINI
+    dino = pd.CustomDINOv2.__new__(pd.CustomDINOv2)
+    torch.nn.Module.__init__(dino)
+    dino.model = seeded.load_seeded(pd.DinoVisionTransformer(img_size=dc["img_size"], patch_size=14, embed_dim=dc["dim"], depth=dc["depth"],
+                                                             num_heads=dc["heads"], mlp_ratio=4, init_values=1.0, block_chunks=0).eval(), 6).to(dev)
+    dino.patch_size, dino.validpatch_thresh, dino.chunk_size, dino.proposal_size, dino.token_name = 14, 0.5, 64, 56, "x_norm_clstoken"
+    ism = synth.ism_inputs(P=8, O=2, T=6, C=dc["dim"], n_patch=16, H=120, W=160, seed=4)
+    scorer = FrameScorer(ism["ref_cls"].to(dev), ism["ref_patch"].to(dev), ism["poses"].to(dev), ism["pointcloud"].to(dev),
+                         confidence_thresh=-1.0)
+    pem = seeded.load_seeded(pm.Net(pm.default_cfg()).eval(), 1).to(dev)
+    pin = synth.pem_inputs(1, seed=1)
+    tpl = {k: pin[k].to(dev) for k in ("model", "dense_po", "dense_fo")}
+    H, W = 120, 160
+    g = torch.Generator().manual_seed(0)
+    img = (torch.rand(H // 8, W // 8, 3, generator=g) * 255).repeat_interleave(8, 0).repeat_interleave(8, 1).to(torch.uint8).to(dev)
+    depth = (0.8 + 0.05 * torch.rand(H, W, generator=g)).to(dev)
+    K = torch.tensor([[143.0, 0, 80.0], [0, 143.0, 60.0], [0, 0, 1]], dtype=torch.float64).to(dev)
+    keys = torch.rand(4, H * W, generator=g).to(dev)
+    rand_u = synth.coarse_uniforms(4, 2).to(dev)
+    pipe = pipeline.FramePipeline(enc, dec.prompt_encoder, dec.mask_decoder, dino, scorer, pem, tpl, object_radius=10.0, top_k=4,
+                                  points_per_batch=8, min_box_size=0.0, min_mask_size=0.0,
+                                  segmentor=dict(points_per_side=4, pred_iou_thresh=0.0, stability_score_thresh=0.0,
+                                                 box_nms_thresh=1.0))
+    det, poses = pipe(img, depth, K, keys, rand_u)
+    assert set(pipe.times) >= {"sam_encoder", "proposals"}
+    n = det.masks.shape[0]
+    assert 1 <= n <= 4 and det.masks.shape[1:] == (H, W) and det.boxes.shape == (n, 4) and det.scores.shape == (n,)
+    assert (det.scores[:-1] >= det.scores[1:]).all() and torch.isfinite(det.scores).all()
+    assert poses is not None, "no detection survived the PEM pre-processing"
+    M = poses["pred_R"].shape[0]
+    assert 1 <= M <= n and poses["pred_t"].shape == (M, 3) and poses["kept"].shape == (M,)
+    R = poses["pred_R"].double()
+    eye = torch.eye(3, dtype=torch.float64, device=dev).expand(M, 3, 3)
+    assert torch.allclose(R @ R.transpose(1, 2), eye, atol=1e-4) and torch.allclose(torch.linalg.det(R), torch.ones(M, dtype=torch.float64, device=dev), atol=1e-4)
+    assert torch.isfinite(poses["pred_t"]).all() and torch.isfinite(poses["pred_pose_score"]).all()

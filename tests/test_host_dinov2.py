@@ -93,6 +93,16 @@ def test_crop_params_224_digest_and_reference_failure_mode():
     with pytest.raises(RuntimeError):
         pd.crop_params(np.array([[10, 10, 10, 40]]), 224)
     assert pd.crop_params(np.zeros((0, 4), np.int64), 224).shape == (0, 12)
+    # crop_valid flags exactly the boxes on which crop_params raises
+    probe = np.array([[10, 10, 109, 109], [0, 0, 50, 20], [10, 10, 10, 40], [5, 5, 105, 105], [0, 0, 600, 2]])
+    valid = pd.crop_valid(probe, 56)
+    assert valid.tolist() == [False, True, False, True, False]
+    for bx, ok in zip(probe, valid):
+        if ok:
+            pd.crop_params(bx[None], 56)
+        else:
+            with pytest.raises((RuntimeError, AssertionError)):
+                pd.crop_params(bx[None], 56)
 
 
 def test_crop_params_replay_random_boxes_vs_oracle():

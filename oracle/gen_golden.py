@@ -268,6 +268,13 @@ def gen_sam_decoder():
         rec["post_boxes"] = ns.amg.batched_mask_to_box(mb).numpy()
         rec["post_area"] = mb.flatten(1).sum(1).numpy()
         rec["post_bits"] = np.packbits(mb.numpy().reshape(mb.shape[0], -1)[:, ::7], axis=1)
+        # generator bookkeeping: the point grid and the resized-frame shape / prompt coordinates
+        rec["grid32"] = ns.amg.build_point_grid(32)
+        sizes = [(480, 640), (1080, 1920), (333, 499), (1024, 1024), (2000, 1500)]
+        rls = ns.transforms.ResizeLongestSide(1024)
+        rec["pre_shapes"] = np.array([rls.get_preprocess_shape(h, w, 1024) for h, w in sizes])
+        rec["pre_sizes"] = np.array(sizes)
+        rec["coords_480x640"] = rls.apply_coords(rec["grid32"] * np.array([[640, 480]]), (480, 640))
     rec["case"] = np.array(str(c))
     np.savez_compressed(os.path.join(OUT, "sam_decoder.npz"), **rec)
     print("sam_decoder.npz", {k: (v.shape if hasattr(v, "shape") else v) for k, v in rec.items()})

@@ -159,6 +159,13 @@ def sam_decoder():
         ns.__dict__[name] = sys.modules.get(full) or _load_by_path(full, os.path.join(base, name + ".py"), pkgname)
     ns.amg = sys.modules.get("_s6d_ref_sa_amg") or _load_by_path(
         "_s6d_ref_sa_amg", os.path.join(ISM, "segment_anything", "utils", "amg.py"))
+    for name in ("torchvision", "torchvision.transforms", "torchvision.transforms.functional"):
+        if name.split(".")[0] not in sys.modules and not _try_import(name.split(".")[0]):
+            _stub(name)
+        elif isinstance(sys.modules.get(name.split(".")[0]), _StubModule):
+            _stub(name)
+    ns.transforms = sys.modules.get("_s6d_ref_sa_transforms") or _load_by_path(
+        "_s6d_ref_sa_transforms", os.path.join(ISM, "segment_anything", "utils", "transforms.py"))
     ns.PromptEncoder = ns.prompt_encoder.PromptEncoder
     ns.MaskDecoder = ns.mask_decoder.MaskDecoder
     ns.TwoWayTransformer = ns.transformer.TwoWayTransformer

@@ -113,3 +113,16 @@ def test_mask_post_arithmetic_replay_matches_oracle_and_reference_golden():
     np.testing.assert_array_equal(boxes.numpy(), g["post_boxes"])
     np.testing.assert_array_equal(mb.flatten(1).sum(1).numpy(), g["post_area"])
     np.testing.assert_array_equal(np.packbits(mb.numpy().reshape(mb.shape[0], -1)[:, ::7], axis=1), g["post_bits"])
+
+
+def test_generator_bookkeeping_matches_reference():
+    """Point grid, ResizeLongestSide shape and prompt coordinates (utils/amg.py:179-186, utils/transforms.py:33-43,95-102)."""
+    from sam6d_amd.sam import amg
+    g = util.golden("sam_decoder.npz")
+    grid = amg.build_point_grid(32)
+    np.testing.assert_array_equal(grid, g["grid32"])
+    for (h, w), ref in zip(g["pre_sizes"], g["pre_shapes"]):
+        assert amg.preprocess_shape(int(h), int(w), 1024) == tuple(ref)
+    ih, iw = amg.preprocess_shape(480, 640, 1024)
+    pts = (grid * [[640, 480]]) * [[iw / 640, ih / 480]]                 # what generate_proposals feeds the prompt encoder
+    np.testing.assert_array_equal(pts, g["coords_480x640"])

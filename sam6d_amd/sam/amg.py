@@ -1,4 +1,4 @@
-"""Per-batch body of SAM's automatic mask generator on MI355X.
+"""SAM's automatic mask generator on MI355X: the per-batch body and the single-crop generator.
 
 ``process_point_batch`` is what ``SamAutomaticMaskGenerator._process_batch`` (segment_anything/
 automatic_mask_generator.py:266-312) computes between "run the model on this batch of points" and "compress to RLE":
@@ -8,6 +8,10 @@ i.e. it materialises the (64*3, H, W) fp32 logits of every batch; here the decod
 ``s6d_sam_mask_post_f32`` and only binary masks, two counts and a box per mask exist at frame resolution.  The filters
 commute (each is a per-mask predicate), so they are applied together after the one fused pass.
 """
+import os
+import time
+
+import numpy as np
 import torch
 
 from .. import ops
@@ -43,7 +47,6 @@ def process_point_batch(prompt_encoder, mask_decoder, image_embedding, in_points
 
 def build_point_grid(n_per_side):
     """utils/amg.py:179-186: n x n points at the pixel-cell centres of the unit square, (x, y), row-major."""
-    import numpy as np
     offset = 1 / (2 * n_per_side)
     side = np.linspace(offset, 1 - offset, n_per_side)
     return np.stack([np.tile(side[None, :], (n_per_side, 1)), np.tile(side[:, None], (1, n_per_side))], axis=-1).reshape(-1, 2)
@@ -71,9 +74,7 @@ def generate_proposals(prompt_encoder, mask_decoder, image_embedding, original_s
     grid = build_point_grid(points_per_side) * [[W, H]]                                   # points in the frame (x, y)
     scale = [[input_size[1] / W, input_size[0] / H]]                                      # apply_coords (transforms.py:33-43)
     pts = torch.as_tensor(grid * scale, device=image_embedding.device)                    # float64, as in the reference
-    import os
-    import time
-    prof = os.environ.get("S6D_AMG_PROFILE")
+    prof = os.environ.get("S6D_AMG_PROFILE")                                           # per-step milliseconds on stdout
     tq = [time.perf_counter()]
 
     def tick(name):

@@ -275,6 +275,14 @@ def gen_sam_decoder():
         rec["pre_shapes"] = np.array([rls.get_preprocess_shape(h, w, 1024) for h, w in sizes])
         rec["pre_sizes"] = np.array(sizes)
         rec["coords_480x640"] = rls.apply_coords(rec["grid32"] * np.array([[640, 480]]), (480, 640))
+        # claim used by sam6d_amd.sam.amg.generate_proposals: with ONE crop spanning the frame the crop-edge filter of
+        # _process_batch never fires and uncrop_boxes_xyxy is the identity -- checked here with the reference functions
+        gg = torch.Generator().manual_seed(3)
+        xy = (torch.rand(4000, 2, generator=gg) * torch.tensor([640.0, 480.0])).floor()
+        bx = torch.cat([xy, (xy + torch.rand(4000, 2, generator=gg) * 300).minimum(torch.tensor([639.0, 479.0])).floor()], 1)
+        bx = torch.cat([bx, torch.tensor([[0.0, 0, 639, 479], [0, 0, 10, 10], [630, 470, 639, 479], [19, 19, 621, 461]])])
+        assert not ns.amg.is_box_near_crop_edge(bx, [0, 0, 640, 480], [0, 0, 640, 480]).any()
+        assert torch.equal(ns.amg.uncrop_boxes_xyxy(bx, [0, 0, 640, 480]), bx)
     rec["case"] = np.array(str(c))
     np.savez_compressed(os.path.join(OUT, "sam_decoder.npz"), **rec)
     print("sam_decoder.npz", {k: (v.shape if hasattr(v, "shape") else v) for k, v in rec.items()})

@@ -27,7 +27,7 @@ from .sam.image_encoder import preprocess as sam_preprocess
 
 class FramePipeline:
     def __init__(self, sam_encoder, prompt_encoder, mask_decoder, descriptor_model, scorer, pem_net, pem_templates,
-                 object_radius, top_k=10, points_per_batch=256, min_box_size=0.05 ** 2, min_mask_size=3e-4 ** 2,
+                 object_radius, top_k=10, points_per_batch=1024, min_box_size=0.05 ** 2, min_mask_size=3e-4 ** 2,
                  segmentor=None):
         """descriptor_model: sam6d_amd.ism.dinov2.CustomDINOv2; scorer: sam6d_amd.ism.scoring.FrameScorer (holds the
         template descriptors); pem_templates: dict(dense_po (1,n,3), dense_fo (1,n,C), model (1,m,3)) of the object;

@@ -40,7 +40,7 @@ img = torch.from_numpy(frame["image"]).to(dev)
 depth, K = frame["depth"].to(dev), frame["K"].to(dev)
 keys = torch.rand(16, 480 * 640, generator=torch.Generator().manual_seed(1)).to(dev)
 rand_u = synth.coarse_uniforms(16, 2).to(dev)
-pipe = pipeline.FramePipeline(enc, dec.prompt_encoder, dec.mask_decoder, dino, scorer, pem, tpl, object_radius=0.12,
+pipe = pipeline.FramePipeline(enc, dec.prompt_encoder, dec.mask_decoder, dino, scorer, pem, tpl, object_radius=0.12, points_per_batch=int(sys.argv[1]) if len(sys.argv) > 1 else 1024,
                               top_k=10, segmentor=dict(pred_iou_thresh=0.09, stability_score_thresh=0.3,
                                                        stability_score_offset=0.02))
 # seeded weights: substitute the synthetic proposals when the generator's own survive in too small a number

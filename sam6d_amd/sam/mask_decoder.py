@@ -38,6 +38,19 @@ def _dtype():
     return {"fp32": torch.float32, "bf16": torch.bfloat16}[os.environ.get("S6D_SAM_DECODER_DTYPE", "bf16")]
 
 
+def build_sam_decoder(prompt_embed_dim=256, image_size=1024, vit_patch_size=16):
+    """prompt encoder + mask decoder exactly as build_sam._build_sam constructs them (build_sam.py:64-101): a module with
+    ``.prompt_encoder`` and ``.mask_decoder`` whose state_dict keys are the ``Sam`` checkpoint's."""
+    e = image_size // vit_patch_size
+    m = nn.Module()
+    m.prompt_encoder = PromptEncoder(embed_dim=prompt_embed_dim, image_embedding_size=(e, e),
+                                     input_image_size=(image_size, image_size), mask_in_chans=16)
+    m.mask_decoder = MaskDecoder(num_multimask_outputs=3,
+                                 transformer=TwoWayTransformer(depth=2, embedding_dim=prompt_embed_dim, mlp_dim=2048, num_heads=8),
+                                 transformer_dim=prompt_embed_dim, iou_head_depth=3, iou_head_hidden_dim=256)
+    return m.eval()
+
+
 # ---- prompt encoder ------------------------------------------------------------------------------------------------
 class PositionEmbeddingRandom(nn.Module):
     def __init__(self, num_pos_feats: int = 64, scale: Optional[float] = None) -> None:

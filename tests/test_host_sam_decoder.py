@@ -48,6 +48,10 @@ def test_state_dict_surface():
             m = build(cfg)
         mine = {k: tuple(v.shape) for k, v in m.state_dict().items()}
         assert mine == {k: tuple(v) for k, v in util.shapes_from_golden(g, name + "_keys", name + "_shapes").items()}
+    with torch.device("meta"):
+        m = md.build_sam_decoder()                                   # the build_sam._build_sam construction
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == \
+        {k: tuple(v) for k, v in util.shapes_from_golden(g, "sam_keys", "sam_shapes").items()}
 
 
 def test_mini_both_paths_match_reference_golden():

@@ -9,7 +9,6 @@ import time
 import torch
 
 sys.path.insert(0, ".")
-from oracle import sam_decoder as osd  # noqa: E402  (config dict only)
 from sam6d_amd import pipeline  # noqa: E402
 from sam6d_amd.ism import dinov2 as pd  # noqa: E402
 from sam6d_amd.ism.scoring import FrameScorer  # noqa: E402
@@ -17,12 +16,12 @@ from sam6d_amd.pem import pose_estimation_model as pm  # noqa: E402
 from sam6d_amd.sam import amg  # noqa: E402
 from sam6d_amd.sam.image_encoder import build_vit_h  # noqa: E402
 from sam6d_amd.utils import seeded, synth  # noqa: E402
-from tests.test_host_sam_decoder import build as build_decoder  # noqa: E402
+from sam6d_amd.sam.mask_decoder import build_sam_decoder  # noqa: E402
 
 dev = torch.device("cuda", 0)
 t0 = time.time()
 enc = seeded.load_seeded(build_vit_h().eval(), 3).to(dev)
-dec = seeded.load_seeded(build_decoder(osd.SAM), 2).to(dev)
+dec = seeded.load_seeded(build_sam_decoder(), 2).to(dev)
 dino = pd.CustomDINOv2.__new__(pd.CustomDINOv2)
 torch.nn.Module.__init__(dino)
 dino.model = seeded.load_seeded(pd._make_dinov2_model(arch_name="vit_large").eval(), 6).to(dev)

@@ -3,11 +3,10 @@ cat > /tmp/dec_once.py <<'PY'
 import os, sys, torch
 sys.path.insert(0, ".")
 os.environ["S6D_SAM_DECODER_DTYPE"] = "bf16"
-from oracle import sam_decoder as osd
 from sam6d_amd.utils import seeded, synth
-from tests.test_host_sam_decoder import build
-cfg = osd.SAM
-m = seeded.load_seeded(build(cfg), 1).cuda()
+from sam6d_amd.sam.mask_decoder import build_sam_decoder
+cfg = dict(dim=256, emb=64, img=1024)
+m = seeded.load_seeded(build_sam_decoder(), 1).cuda()
 inp = {k: v.cuda() for k, v in synth.sam_decoder_inputs(cfg, 1024, 3).items()}
 def frame():
     with torch.no_grad():

@@ -7,9 +7,8 @@ import sys
 import torch
 
 sys.path.insert(0, ".")
-from oracle import sam_decoder as osd  # noqa: E402  (config dict only)
 from sam6d_amd.utils import seeded, synth  # noqa: E402
-from tests.test_host_sam_decoder import build  # noqa: E402
+from sam6d_amd.sam.mask_decoder import build_sam_decoder  # noqa: E402
 
 
 def ev(fn, n):
@@ -27,8 +26,8 @@ def ev(fn, n):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-    cfg = osd.SAM
-    m = seeded.load_seeded(build(cfg), 1).cuda()
+    cfg = dict(dim=256, emb=64, img=1024)
+    m = seeded.load_seeded(build_sam_decoder(), 1).cuda()
     inp = {k: v.cuda() for k, v in synth.sam_decoder_inputs(cfg, n, 3).items()}
 
     def frame(lib):
@@ -55,8 +54,6 @@ if __name__ == "__main__":
     ms = ev(lambda: ops.sam_mask_post(low, 1024, (768, 1024), (480, 640), 0.0, 1.0), 5)
     print(f"mask post-processing (fused), 768 masks -> 480x640: {ms:.3f} ms ({768 * 480 * 640 / ms / 1e6:.1f} Gpixel/s); "
           f"x4 batches per 1024-prompt frame = {4 * ms:.2f} ms", flush=True)
-    ref = ev(lambda: osd.mask_postprocess(low[:64], 1024, (768, 1024), (480, 640)), 3)
-    print(f"reference op sequence (torch on the device), 192 masks: {ref:.3f} ms -> x16 per frame = {16 * ref:.1f} ms")
     # the whole embedding -> proposals stage (grid, 1024 prompts, post-processing, filters, NMS); thresholds chosen so that
     # about half of the 3072 masks of these seeded weights survive the filters (worst-ish case for the NMS)
     from sam6d_amd.sam import amg  # noqa: E402

@@ -35,3 +35,30 @@ def test_ops_refuse_cpu_tensors():
     with pytest.raises(RuntimeError, match="CUDA tensor"):
         ops.rpe_attention(*([torch.zeros(1, 4, 256)] * 3), torch.zeros(1, 4, 4, 256), torch.zeros(1, 4, 4),
                           torch.zeros(1, 4, 4, 256), 0.125)
+
+
+def test_every_entry_point_refuses_null_operands():
+    """Generated from the header: each `int s6d_*(...)` prototype is called with NULL for every pointer and small positive
+    sizes.  Every one must come back with S6D_EINVAL / S6D_EUNSUPPORTED before anything is dereferenced or launched
+    (this host has no device, so a launch attempt would surface as S6D_ELAUNCH = -2)."""
+    import os
+    import re
+
+    L = _lib.lib()
+    hdr = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "sam6d_hip.h")
+    src = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)
+    protos = re.findall(r"\bint\s+(s6d_\w+)\s*\(([^)]*)\)\s*;", src)
+    assert len(protos) >= 28
+    kinds = {"float": lambda: ctypes.c_float(1.0), "double": lambda: ctypes.c_double(1.0), "long": lambda: ctypes.c_long(16),
+             "int": lambda: ctypes.c_int(16)}
+    rcs = {}
+    for name, args in protos:
+        if args.strip() == "void":
+            continue
+        vals = []
+        for a in (x.strip() for x in args.split(",")):
+            vals.append(ctypes.c_void_p(0) if "*" in a else kinds[a.split()[0]]())
+        fn = getattr(L, name)
+        fn.restype = ctypes.c_int
+        rcs[name] = fn(*vals)
+    assert all(rc in (-1, -3) for rc in rcs.values()), rcs

@@ -194,6 +194,58 @@ def gen_handoff():
     print("handoff.npz", {k: len(str(v)) for k, v in rec.items()})
 
 
+def _ref_statements(path, first, last):
+    """The statements of a reference script between the first line containing `first` and the first later line containing
+    `last` (inclusive), dedented -- for code that lives inline in an entry script and cannot be imported."""
+    import textwrap
+    lines = open(path).read().split("\n")
+    a = next(i for i, l in enumerate(lines) if first in l)
+    b = next(i for i in range(a, len(lines)) if last in lines[i])
+    return textwrap.dedent("\n".join(lines[a:b + 1]))
+
+
+def gen_pem_results():
+    """The reference's pose writers, executed from its own files on synthetic model outputs: the BOP csv lines of
+    Pose_Estimation_Model/test_bop.py ("# write results" .. "lines.append(line)", with the float32 scaling statements just
+    above them) and detection_pem.json of run_inference_custom.py ("if 'pred_pose_score' in out.keys()" .. json.dump)."""
+    import json
+    import tempfile
+    pem = os.path.join(rh.REF_ROOT, "SAM-6D", "Pose_Estimation_Model")
+    g = torch.Generator().manual_seed(77)
+    n = 5
+    R = torch.linalg.qr(torch.randn(n, 3, 3, generator=g))[0]
+    t = torch.randn(n, 3, generator=g) * 0.3 + torch.tensor([0.0, 0.0, 0.8])
+    pose_score = torch.rand(n, generator=g)
+    det_score = torch.rand(n, generator=g)
+    det_score[0] = 0.1
+    pose_score[0] = 1.0
+    obj = torch.tensor([1, 5, 6, 8, 12])
+    rec = dict(R=R.numpy(), t=t.numpy(), pose_score=pose_score.numpy(), det_score=det_score.numpy(), obj=obj.numpy())
+    # ---- test_bop.py ----------------------------------------------------------------------------------------------
+    src = _ref_statements(os.path.join(pem, "test_bop.py"), "pred_Rs = torch.cat(pred_Rs", "image_time = time.time() - end")
+    src2 = _ref_statements(os.path.join(pem, "test_bop.py"), "# write results", "lines.append(line)")
+    import time
+    ns = dict(torch=torch, time=time, end=time.time(), pred_Rs=[R[:2], R[2:]], pred_Ts=[t[:2], t[2:]], pred_scores=[pose_score[:2], pose_score[2:]],
+              data=dict(score=det_score.reshape(1, n, 1), scene_id=torch.tensor([48]), img_id=torch.tensor([1003]), seg_time=torch.tensor([0.0]),
+                        obj_id=obj.reshape(1, n)), n_instance=n, lines=[])
+    exec(src, ns)
+    ns["image_time"] = 0.375                                                           # the wall clock is not reproducible
+    exec(src2, ns)
+    rec["csv"] = np.array("".join(ns["lines"]))
+    # ---- run_inference_custom.py --------------------------------------------------------------------------------------
+    src = _ref_statements(os.path.join(pem, "run_inference_custom.py"), "if 'pred_pose_score' in out.keys():", "json.dump(detections, f)")
+    dets = [dict(scene_id=0, image_id=0, category_id=int(o), bbox=[1, 2, 30 + i, 40], score=float(det_score[i]), time=0.0,
+                 segmentation=dict(counts=[3, 4, 5], size=[3, 4])) for i, o in enumerate(obj)]
+    rec["dets_json"] = np.array(json.dumps(dets))
+    with tempfile.TemporaryDirectory() as d:
+        ns = dict(os=os, json=json, out=dict(pred_pose_score=pose_score, score=det_score, pred_R=R, pred_t=t),
+                  cfg=types.SimpleNamespace(output_dir=d), detections=[dict(x) for x in dets])
+        exec(src, ns)
+        rec["pem_json"] = np.array(open(os.path.join(d, "sam6d_results", "detection_pem.json")).read())
+    np.savez_compressed(os.path.join(OUT, "pem_results.npz"), **rec)
+    print("pem_results.npz"); print(str(rec["csv"])[:400]); print(str(rec["pem_json"])[:300])
+
+
 def gen_pem_pre():
     """Reference geometry helpers of the PEM pre-processing (utils/data_utils.py), run unmodified."""
     du = rh.pem_data_utils()
@@ -351,4 +403,4 @@ def gen_dinov2():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    {"pem": gen_pem, "sam": gen_sam, "ism": gen_ism, "dinov2": gen_dinov2, "sam_decoder": gen_sam_decoder, "handoff": gen_handoff, "pem_pre": gen_pem_pre}[sys.argv[1]]()
+    {"pem": gen_pem, "sam": gen_sam, "ism": gen_ism, "dinov2": gen_dinov2, "sam_decoder": gen_sam_decoder, "handoff": gen_handoff, "pem_pre": gen_pem_pre, "pem_results": gen_pem_results}[sys.argv[1]]()

@@ -94,3 +94,22 @@ class FramePipeline:
         self._tick("pem", t0)
         return det, dict(pred_R=out["pred_R"], pred_t=out["pred_t"], pred_pose_score=out["pred_pose_score"],
                          kept=obs["kept"])
+
+
+def frame_results(det, poses, dataset_name, time_s=0.0):
+    """The three result files of the reference for one frame, from what ``FramePipeline.__call__`` returned: the ISM JSON
+    records (detection_ism.json / result_<ds>.json, sam6d_amd.ism.handoff), and for the detections the PEM kept
+    (``poses['kept']`` indexes ``det``) the BOP csv lines and the detection_pem.json records (sam6d_amd.pem.results).
+    -> dict(ism_records, csv_lines, pem_records); the last two are empty when ``poses`` is None."""
+    from .ism.handoff import detection_records
+    from .pem import results
+
+    ism = detection_records(det, dataset_name) if det.masks.shape[0] else []
+    if poses is None:
+        return dict(ism_records=ism, csv_lines=[], pem_records=[])
+    kept = poses["kept"].cpu().tolist()
+    s = results.combined_scores(poses["pred_pose_score"], det.scores[poses["kept"]])
+    sub = [ism[i] for i in kept]
+    csv = results.bop_csv_lines(det.scene_id, det.image_id, [r["category_id"] for r in sub], s, poses["pred_R"],
+                                poses["pred_t"], time_s)
+    return dict(ism_records=ism, csv_lines=csv, pem_records=results.detection_pem_records(sub, s, poses["pred_R"], poses["pred_t"]))

@@ -56,10 +56,16 @@ def gather_records(rec, group=None):
 
 
 def to_bop_csv_lines(records):
-    """BOP result lines `scene,im,obj,score,R,t(mm),time` exactly as test_bop.py:172-181 writes them."""
+    """BOP result lines `scene,im,obj,score,R,t(mm),time` from the (n,17) float32 record table, printed the way
+    test_bop.py:155-181 prints them: float32 values in their shortest round-tripping decimal form (`str(numpy.float32)`),
+    t scaled to millimetres in float32.  (sam6d_amd/pem/results.py is the per-frame writer; this one serves the gathered
+    table.)"""
+    import numpy as np
+
+    r = records.detach().cpu().numpy().astype(np.float32)
+    t = r[:, 13:16] * 1000
     out = []
-    for r in records.cpu().tolist():
-        R = " ".join(str(v) for v in r[4:13])
-        t = " ".join(str(v * 1000.0) for v in r[13:16])
-        out.append(f"{int(r[0])},{int(r[1])},{int(r[2])},{r[3]},{R},{t},{r[16]}\n")
+    for k in range(r.shape[0]):
+        out.append(",".join((str(int(r[k, 0])), str(int(r[k, 1])), str(int(r[k, 2])), str(r[k, 3]),
+                             " ".join(str(v) for v in r[k, 4:13]), " ".join(str(v) for v in t[k]), f"{float(r[k, 16])}\n")))
     return out

@@ -246,6 +246,54 @@ def gen_pem_results():
     print("pem_results.npz"); print(str(rec["csv"])[:400]); print(str(rec["pem_json"])[:300])
 
 
+def gen_detections_ops():
+    """The reference's Detections list operations (model/utils.py: remove_very_small_detections, apply_nms,
+    apply_nms_per_object_id) and CustomSamAutomaticMaskGenerator.postprocess_resize (model/sam.py), run unmodified.
+    torchvision is not installed: its two functions the code calls are supplied from their published definitions
+    (box_area = (x2-x1)*(y2-y1); nms = oracle/sam_decoder.py nms) -- the NMS boundary stays "parity unpinned"."""
+    import importlib
+    from . import sam_decoder as od
+    rh.ism()
+    mu = importlib.import_module("model.utils")
+    mu.box_area = lambda b: (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    mu.torchvision.ops.nms = od.nms
+    g = torch.Generator().manual_seed(21)
+    N, H, W = 40, 48, 64
+    xy = (torch.rand(N, 2, generator=g) * torch.tensor([W - 20.0, H - 20.0])).floor()
+    wh = (2 + torch.rand(N, 2, generator=g) * 18).floor()
+    boxes = torch.cat([xy, xy + wh], 1).long()
+    boxes[5:9] = boxes[4]                                                   # duplicates: NMS must drop them within an object
+    masks = torch.zeros(N, H, W, dtype=torch.bool)
+    for i, (x1, y1, x2, y2) in enumerate(boxes.tolist()):
+        masks[i, y1:y2, x1:x2] = torch.rand(y2 - y1, x2 - x1, generator=g) > 0.4
+    masks[3] = False
+    scores = torch.rand(N, generator=g)
+    scores[6] = scores[4]                                                   # a score tie between duplicates
+    obj = torch.randint(0, 5, (N,), generator=g)
+    rec = dict(boxes=boxes.numpy(), masks=np.packbits(masks.numpy()), scores=scores.numpy(), obj=obj.numpy(), shape=np.array([N, H, W]))
+
+    def fresh():
+        return mu.Detections({"masks": masks.clone(), "boxes": boxes.clone(), "scores": scores.clone(), "object_ids": obj.clone()})
+    d = fresh()
+    d.remove_very_small_detections(types.SimpleNamespace(min_box_size=0.05, min_mask_size=3e-2))
+    rec["small_scores"] = d.scores.numpy()
+    d = fresh()
+    d.apply_nms(0.5)
+    rec["nms_scores"] = d.scores.numpy()
+    d = fresh()
+    d.apply_nms_per_object_id(0.25)
+    rec["nms_obj_scores"], rec["nms_obj_ids"], rec["nms_obj_boxes"] = d.scores.numpy(), d.object_ids.numpy(), d.boxes.numpy()
+    rec["nms_obj_mask_sums"] = d.masks.sum(dim=(1, 2)).numpy()
+    # ---- postprocess_resize ----------------------------------------------------------------------------------------
+    ms = importlib.import_module("model.sam")
+    for tag, orig in (("same", (48, 64)), ("up", (81, 108))):
+        det = {"masks": masks[:6].clone(), "boxes": boxes[:6].clone()}
+        out = ms.CustomSamAutomaticMaskGenerator.postprocess_resize(types.SimpleNamespace(segmentor_width_size=64), det, orig)
+        rec["pp_masks_" + tag], rec["pp_boxes_" + tag] = out["masks"].numpy(), out["boxes"].numpy()
+    np.savez_compressed(os.path.join(OUT, "detections_ops.npz"), **rec)
+    print("detections_ops.npz", {k: getattr(v, "shape", v) for k, v in rec.items()})
+
+
 def gen_pem_pre():
     """Reference geometry helpers of the PEM pre-processing (utils/data_utils.py), run unmodified."""
     du = rh.pem_data_utils()
@@ -403,4 +451,4 @@ def gen_dinov2():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    {"pem": gen_pem, "sam": gen_sam, "ism": gen_ism, "dinov2": gen_dinov2, "sam_decoder": gen_sam_decoder, "handoff": gen_handoff, "pem_pre": gen_pem_pre, "pem_results": gen_pem_results}[sys.argv[1]]()
+    {"pem": gen_pem, "sam": gen_sam, "ism": gen_ism, "dinov2": gen_dinov2, "sam_decoder": gen_sam_decoder, "handoff": gen_handoff, "pem_pre": gen_pem_pre, "pem_results": gen_pem_results, "detections_ops": gen_detections_ops}[sys.argv[1]]()

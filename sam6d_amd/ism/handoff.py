@@ -29,6 +29,56 @@ class Detections:
     object_ids: torch.Tensor
     runtime: float = 0.0
 
+    # ---- the per-frame list operations of the reference's Detections (model/utils.py:80-132) -----------------------------
+    _FIELDS = ("masks", "boxes", "scores", "object_ids")
+
+    def __len__(self):
+        return self.boxes.shape[0]
+
+    def filter(self, idx):
+        """Keep the rows ``idx`` (bool mask or index tensor) of every per-detection tensor (model/utils.py:filter; fields
+        that are not filled yet -- scores / object_ids before the scoring stage -- are left alone)."""
+        n = len(self)
+        for f in self._FIELDS:
+            v = getattr(self, f)
+            if v is not None and v.shape[0] == n:
+                setattr(self, f, v[idx])
+        return self
+
+    def remove_very_small_detections(self, min_box_size, min_mask_size):
+        """model/utils.py:96-105: keep detections whose box covers more than min_box_size**2 of the frame AND whose mask
+        covers more than min_mask_size of it (the asymmetry -- one threshold squared, the other not -- is the
+        reference's; configs/model/ISM_sam.yaml:15-16 sets 0.05 and 3e-4)."""
+        img_area = self.masks.shape[1] * self.masks.shape[2]
+        b = self.boxes
+        box_areas = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]) / img_area          # torchvision box_area
+        mask_areas = self.masks.sum(dim=(1, 2)) / img_area
+        return self.filter(torch.logical_and(box_areas > min_box_size ** 2, mask_areas > min_mask_size))
+
+    def apply_nms(self, nms_thresh=0.5, nms_fn=None):
+        """model/utils.py:121-126."""
+        nms_fn = nms_fn or _device_nms
+        return self.filter(nms_fn(self.boxes.float(), self.scores.float(), nms_thresh))
+
+    def apply_nms_per_object_id(self, nms_thresh=0.5, nms_fn=None):
+        """model/utils.py:107-119: one NMS per predicted object, survivors concatenated in ascending object id, inside
+        an object by decreasing score.  ``nms_fn(boxes, scores, thresh) -> kept indices by decreasing score``; default the
+        device kernel (sam6d_amd.ops.nms -> s6d_nms_f32)."""
+        nms_fn = nms_fn or _device_nms
+        every = torch.arange(len(self), device=self.boxes.device)
+        keep = []
+        for oid in torch.unique(self.object_ids):
+            sel = self.object_ids == oid
+            keep.append(every[sel][nms_fn(self.boxes[sel].float(), self.scores[sel].float(), nms_thresh)])
+        if not keep:
+            return self                                               # nothing to do for an empty frame (the reference raises)
+        return self.filter(torch.cat(keep))
+
+
+def _device_nms(boxes, scores, thresh):
+    from .. import ops
+    return ops.nms(boxes.contiguous(), scores.contiguous(), thresh)
+
 
 def masks_to_rle(masks):
     """(N,H,W) bool/0-1 tensor (any device) -> list of {"counts": [...], "size": [H, W]}: uncompressed COCO-style RLE in

@@ -10,7 +10,8 @@ and passes tensors from stage to stage (``sam6d_amd.ism.handoff.Detections``); e
 in INTEGRATION.md, so the arithmetic of every stage is the parity-tested one.  What this class adds is only the glue the
 reference has in its two ``run_inference_custom.py`` scripts (detector.py:331-430 for the ISM side), reduced to tensor ops:
 image resize to the encoder's input (bilinear with antialiasing on the device -- the reference uses PIL, unpinned here),
-dropping tiny detections (``Detections.remove_very_small_detections``, model/utils.py:118-127), keeping the best
+dropping tiny detections (``Detections.remove_very_small_detections``, model/utils.py:96-105: box area / frame > 0.05**2 and
+mask area / frame > 3e-4 -- the first threshold squared, the second not, as in the reference), keeping the best
 detections by final score.
 """
 import time
@@ -27,7 +28,7 @@ from .sam.image_encoder import preprocess as sam_preprocess
 
 class FramePipeline:
     def __init__(self, sam_encoder, prompt_encoder, mask_decoder, descriptor_model, scorer, pem_net, pem_templates,
-                 object_radius, top_k=10, points_per_batch=1024, min_box_size=0.05 ** 2, min_mask_size=3e-4 ** 2,
+                 object_radius, top_k=10, points_per_batch=1024, min_box_size=0.05 ** 2, min_mask_size=3e-4,
                  segmentor=None):
         """descriptor_model: sam6d_amd.ism.dinov2.CustomDINOv2; scorer: sam6d_amd.ism.scoring.FrameScorer (holds the
         template descriptors); pem_templates: dict(dense_po (1,n,3), dense_fo (1,n,C), model (1,m,3)) of the object;

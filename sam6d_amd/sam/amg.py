@@ -97,3 +97,25 @@ def generate_proposals(prompt_encoder, mask_decoder, image_embedding, original_s
     out = {k: v[keep] for k, v in cat.items()}
     tick(f"gather {keep.shape[0]} survivors")
     return out
+
+
+def segmentor_input_size(orig_size, segmentor_width_size):
+    """(height, width) the frame is resized to before SAM sees it: CustomSamAutomaticMaskGenerator.preprocess_resize
+    (Instance_Segmentation_Model/model/sam.py:75-81; ``segmentor_width_size`` is 640 in configs/model/ISM_sam.yaml).  The
+    resize itself is cv2.resize on the host in the reference (bilinear, fixed-point; cv2 is an un-vendored dependency --
+    not restated here); for frames that already are that wide -- every 640 x 480 BOP set and the custom demo -- it is the
+    identity."""
+    return int(segmentor_width_size * orig_size[0] / orig_size[1]), int(segmentor_width_size)
+
+
+def postprocess_resize(masks, boxes, orig_size, segmentor_width_size):
+    """CustomSamAutomaticMaskGenerator.postprocess_resize (model/sam.py:83-100): masks (N,h,w) bool/float found on the
+    resized frame -> FLOAT masks (N,H,W) by bilinear interpolation (align_corners=False; the reference keeps the
+    fractional edge values, it does not re-threshold), boxes (N,4) -> float, scaled by W / segmentor_width_size and
+    clamped to the frame.  Same torch ops as the reference, on whatever device the tensors live."""
+    H, W = int(orig_size[0]), int(orig_size[1])
+    m = torch.nn.functional.interpolate(masks.unsqueeze(1).float(), size=(H, W), mode="bilinear", align_corners=False)[:, 0]
+    b = boxes.float() * (W / segmentor_width_size)
+    b[:, [0, 2]] = torch.clamp(b[:, [0, 2]], 0, W - 1)
+    b[:, [1, 3]] = torch.clamp(b[:, [1, 3]], 0, H - 1)
+    return m, b

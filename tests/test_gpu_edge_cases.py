@@ -127,3 +127,25 @@ def test_next_row_entry_points_reject_bad_arguments_and_accept_empty_batches(ops
     with pytest.raises(RuntimeError):
         ops.samdec_tok2img(torch.zeros(2, 9, 128, device="cuda"), torch.zeros(2, 64, 256, device="cuda", dtype=torch.bfloat16),
                            0, 128, None, 0.25)
+
+
+def test_detections_nms_per_object_id_on_the_device():
+    """Detections.apply_nms / apply_nms_per_object_id with the device NMS kernel (the default) reproduce the reference's
+    Detections class on the golden frame (tests/golden/detections_ops.npz)."""
+    import numpy as np
+
+    from tests import util
+    from tests.test_host_detections_ops import inputs
+    g = util.golden("detections_ops.npz")
+
+    def on_device():
+        d = inputs(g)
+        d.masks, d.boxes, d.scores, d.object_ids = d.masks.cuda(), d.boxes.cuda(), d.scores.cuda(), d.object_ids.cuda()
+        return d
+    d = on_device().apply_nms(0.5)
+    np.testing.assert_array_equal(d.scores.cpu().numpy(), g["nms_scores"])
+    d = on_device().apply_nms_per_object_id(0.25)
+    np.testing.assert_array_equal(d.scores.cpu().numpy(), g["nms_obj_scores"])
+    np.testing.assert_array_equal(d.object_ids.cpu().numpy(), g["nms_obj_ids"])
+    np.testing.assert_array_equal(d.boxes.cpu().numpy(), g["nms_obj_boxes"])
+    np.testing.assert_array_equal(d.masks.sum(dim=(1, 2)).cpu().numpy(), g["nms_obj_mask_sums"])

@@ -294,6 +294,34 @@ def gen_detections_ops():
     print("detections_ops.npz", {k: getattr(v, "shape", v) for k, v in rec.items()})
 
 
+def gen_sam_transforms():
+    """The reference's ResizeLongestSide (segment_anything/utils/transforms.py) run unmodified.  torchvision is not
+    installed; the two functions apply_image calls are supplied from their documented behaviour on PIL inputs:
+    to_pil_image(uint8 HWC ndarray) = PIL.Image.fromarray, resize(pil, (h, w)) = pil.resize((w, h), BILINEAR).  Pillow
+    itself is real (installed), so the pixel arithmetic in the golden is Pillow's."""
+    from PIL import Image
+    ns = rh.sam_decoder()
+    tr = ns.transforms
+    tr.to_pil_image = lambda a: Image.fromarray(a)
+    tr.resize = lambda im, size: im.resize((size[1], size[0]), Image.BILINEAR)
+    rng = np.random.default_rng(5)
+    rec = {}
+    for tag, (H, W), L in (("vga", (60, 80), 128), ("tless", (54, 72), 96), ("itodd", (96, 128), 64), ("tall", (75, 31), 96)):
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        img[: H // 2, : W // 2] = (img[: H // 2, : W // 2] // 64) * 64           # flat regions + noise
+        t = tr.ResizeLongestSide(L)
+        pts = rng.uniform(0, [W, H], (7, 2))
+        boxes = np.concatenate([pts[:3], pts[:3] + rng.uniform(1, 20, (3, 2))], 1)
+        rec[tag + "_img"], rec[tag + "_L"] = img, np.array(L)
+        rec[tag + "_out"] = t.apply_image(img)
+        rec[tag + "_pts"], rec[tag + "_pts_out"] = pts, t.apply_coords(pts, (H, W))
+        rec[tag + "_boxes"], rec[tag + "_boxes_out"] = boxes, t.apply_boxes(boxes, (H, W))
+        rec[tag + "_pts_out_t"] = t.apply_coords_torch(torch.from_numpy(pts), (H, W)).numpy()
+        rec[tag + "_boxes_out_t"] = t.apply_boxes_torch(torch.from_numpy(boxes), (H, W)).numpy()
+    np.savez_compressed(os.path.join(OUT, "sam_transforms.npz"), **rec)
+    print("sam_transforms.npz", {k: getattr(v, "shape", v) for k, v in rec.items() if k.endswith("_out")})
+
+
 def gen_pem_pre():
     """Reference geometry helpers of the PEM pre-processing (utils/data_utils.py), run unmodified."""
     du = rh.pem_data_utils()
@@ -451,4 +479,4 @@ def gen_dinov2():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    {"pem": gen_pem, "sam": gen_sam, "ism": gen_ism, "dinov2": gen_dinov2, "sam_decoder": gen_sam_decoder, "handoff": gen_handoff, "pem_pre": gen_pem_pre, "pem_results": gen_pem_results, "detections_ops": gen_detections_ops}[sys.argv[1]]()
+    {"pem": gen_pem, "sam": gen_sam, "ism": gen_ism, "dinov2": gen_dinov2, "sam_decoder": gen_sam_decoder, "handoff": gen_handoff, "pem_pre": gen_pem_pre, "pem_results": gen_pem_results, "detections_ops": gen_detections_ops, "sam_transforms": gen_sam_transforms}[sys.argv[1]]()

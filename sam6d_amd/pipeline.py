@@ -9,7 +9,8 @@ of the PEM) with CPU data loading in between.  ``FramePipeline`` holds the five 
 and passes tensors from stage to stage (``sam6d_amd.ism.handoff.Detections``); each stage is the drop-in module documented
 in INTEGRATION.md, so the arithmetic of every stage is the parity-tested one.  What this class adds is only the glue the
 reference has in its two ``run_inference_custom.py`` scripts (detector.py:331-430 for the ISM side), reduced to tensor ops:
-image resize to the encoder's input (bilinear with antialiasing on the device -- the reference uses PIL, unpinned here),
+image resize to the encoder's input (``sam/transforms.py``: Pillow's fixed-point bilinear resampler restated as integer
+tensor ops on the device, bit-identical with what ``SamPredictor.set_image`` feeds the model),
 dropping tiny detections (``Detections.remove_very_small_detections``, model/utils.py:96-105: box area / frame > 0.05**2 and
 mask area / frame > 3e-4 -- the first threshold squared, the second not, as in the reference), keeping the best
 detections by final score.
@@ -18,12 +19,12 @@ import time
 from types import SimpleNamespace
 
 import torch
-import torch.nn.functional as F
 
 from .ism.handoff import Detections
 from .pem import preprocess as pem_pre
 from .sam import amg
 from .sam.image_encoder import preprocess as sam_preprocess
+from .sam.transforms import ResizeLongestSide
 
 
 class FramePipeline:
@@ -53,9 +54,7 @@ class FramePipeline:
         H, W = image_u8.shape[:2]
         t0 = time.perf_counter()
         # ---- SAM image encoder ------------------------------------------------------------------------------------
-        ih, iw = amg.preprocess_shape(H, W, self.enc.img_size)
-        x = F.interpolate(image_u8.permute(2, 0, 1)[None].float(), (ih, iw), mode="bilinear", antialias=True,
-                          align_corners=False)
+        x = ResizeLongestSide(self.enc.img_size).apply_image(image_u8).permute(2, 0, 1)[None].float()
         emb = self.enc(sam_preprocess(x, self.enc.img_size)).float()
         t0 = self._tick("sam_encoder", t0)
         # ---- proposals ----------------------------------------------------------------------------------------------

@@ -149,3 +149,16 @@ def test_detections_nms_per_object_id_on_the_device():
     np.testing.assert_array_equal(d.object_ids.cpu().numpy(), g["nms_obj_ids"])
     np.testing.assert_array_equal(d.boxes.cpu().numpy(), g["nms_obj_boxes"])
     np.testing.assert_array_equal(d.masks.sum(dim=(1, 2)).cpu().numpy(), g["nms_obj_mask_sums"])
+
+
+def test_frame_resize_on_the_device_is_pillow_exact():
+    """sam/transforms.py integer resampler on cuda:0 against the reference-made golden (Pillow's pixels)."""
+    import numpy as np
+
+    from sam6d_amd.sam.transforms import ResizeLongestSide
+    from tests import util
+    g = util.golden("sam_transforms.npz")
+    for tag in ("vga", "tless", "itodd", "tall"):
+        out = ResizeLongestSide(int(g[tag + "_L"])).apply_image(torch.from_numpy(g[tag + "_img"]).cuda())
+        assert out.is_cuda and out.dtype == torch.uint8
+        np.testing.assert_array_equal(out.cpu().numpy(), g[tag + "_out"])

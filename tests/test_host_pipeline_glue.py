@@ -1,0 +1,85 @@
+"""FramePipeline's glue on a host without a device: the five models are replaced by recording stand-ins, everything
+between them (Pillow-exact resize, small-detection filter, crop validity filter, top-k by final score, PEM pre-processing,
+template expansion, result records) is the real code."""
+import numpy as np
+import torch
+
+from sam6d_amd import pipeline
+from sam6d_amd.sam.transforms import ResizeLongestSide
+
+
+def test_glue_between_the_stages(monkeypatch):
+    H, W, S = 120, 160, 256
+    g = torch.Generator().manual_seed(0)
+    img = torch.randint(0, 256, (H, W, 3), generator=g, dtype=torch.uint8)
+    depth = 0.8 + 0.05 * torch.rand(H, W, generator=g)
+    K = torch.tensor([[143.0, 0, 80.0], [0, 143.0, 60.0], [0, 0, 1]], dtype=torch.float64)
+    seen = {}
+
+    def fake_preprocess(x, img_size):
+        seen["pre_in"] = x.clone()
+        return torch.zeros(1, 3, img_size, img_size)
+    monkeypatch.setattr(pipeline, "sam_preprocess", fake_preprocess)
+    monkeypatch.setattr(pipeline.FramePipeline, "_tick", lambda self, name, t0: self.times.__setitem__(name, 0.0) or t0)
+
+    class Enc:
+        img_size = S
+
+        def __call__(self, x):
+            seen["enc_in"] = tuple(x.shape)
+            return torch.zeros(1, 8, S // 16, S // 16)
+    # six proposals: a tiny one (box below 0.05^2 of the frame), an exactly-square crop the reference cannot process, and
+    # four usable ones
+    boxes = torch.tensor([[2, 2, 6, 6], [10, 10, 59, 59], [20, 10, 90, 70], [60, 30, 150, 110], [5, 50, 70, 115], [80, 5, 155, 60]])
+    masks = torch.zeros(6, H, W, dtype=torch.bool)
+    for i, (x1, y1, x2, y2) in enumerate(boxes.tolist()):
+        masks[i, y1:y2 + 1, x1:x2 + 1] = True
+
+    def fake_proposals(pe, md, emb, orig, img_size, points_per_batch=64, **kw):
+        seen["prop_args"] = (tuple(emb.shape), orig, img_size, points_per_batch, kw)
+        return dict(masks=masks, boxes=boxes)
+    monkeypatch.setattr(pipeline.amg, "generate_proposals", fake_proposals)
+
+    class Desc:
+        proposal_size = 56
+
+        def __call__(self, image_np, prop):
+            seen["desc_n"] = prop.masks.shape[0]
+            assert isinstance(image_np, np.ndarray) and image_np.shape == (H, W, 3)
+            n = prop.masks.shape[0]
+            return torch.zeros(n, 4), torch.zeros(n, 16, 4)
+
+    class Scorer:
+        def score(self, cls, patch, m, b, d, k):
+            n = m.shape[0]
+            final = torch.linspace(0.2, 0.9, n)                                # best = last surviving proposal
+            return dict(final=final, sel=torch.arange(n), pred_obj=torch.zeros(n, dtype=torch.long))
+
+    class Pem:
+        def __call__(self, ep):
+            seen["pem_shapes"] = {k: tuple(v.shape) for k, v in ep.items()}
+            M = ep["pts"].shape[0]
+            return dict(pred_R=torch.eye(3).expand(M, 3, 3).clone(), pred_t=torch.zeros(M, 3), pred_pose_score=torch.full((M,), 0.5))
+    tpl = dict(model=torch.zeros(1, 64, 3), dense_po=torch.zeros(1, 32, 3), dense_fo=torch.zeros(1, 32, 8))
+    pipe = pipeline.FramePipeline(Enc(), None, None, Desc(), Scorer(), Pem(), tpl, object_radius=10.0, top_k=3, points_per_batch=16,
+                                  segmentor=dict(points_per_side=4))
+    keys = torch.rand(3, H * W, generator=g)
+    det, poses = pipe(img, depth, K, keys, torch.rand(3, 18000, generator=g))
+    # resize: the encoder saw Pillow's pixels of the frame, as float, channels first
+    ref = ResizeLongestSide(S).apply_image(img.numpy())
+    assert seen["pre_in"].shape == (1, 3) + ref.shape[:2] and seen["pre_in"].dtype == torch.float32
+    assert np.array_equal(seen["pre_in"][0].permute(1, 2, 0).numpy(), ref.astype(np.float32))
+    assert seen["prop_args"][1:4] == ((H, W), S, 16) and seen["prop_args"][4] == dict(points_per_side=4)
+    # filters: the 5 x 5 box is below 0.05^2 of the frame, the 50 x 50 crop is one the reference's CropResizePad rejects
+    assert seen["desc_n"] == 4
+    # top-k by final score, best first
+    assert det.masks.shape == (3, H, W) and torch.equal(det.boxes, boxes[[5, 4, 3]])
+    assert torch.equal(det.scores, torch.linspace(0.2, 0.9, 4).flip(0)[:3])
+    M = poses["pred_R"].shape[0]
+    assert M == 3 and poses["kept"].tolist() == [0, 1, 2]
+    sh = seen["pem_shapes"]
+    assert sh["pts"] == (3, 2048, 3) and sh["rgb"] == (3, 3, 224, 224) and sh["rgb_choose"] == (3, 2048)
+    assert sh["model"] == (3, 64, 3) and sh["dense_po"] == (3, 32, 3) and sh["dense_fo"] == (3, 32, 8) and sh["coarse_rand_u"] == (3, 18000)
+    out = pipeline.frame_results(det, poses, "ycbv", 0.1)
+    assert len(out["ism_records"]) == 3 and len(out["csv_lines"]) == 3 and out["pem_records"][0]["R"] == np.eye(3).tolist()
+    assert [r["category_id"] for r in out["ism_records"]] == [1, 1, 1]

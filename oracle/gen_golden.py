@@ -335,6 +335,21 @@ def gen_pem_pre():
     rec["cloud_crop_smp"] = du.get_point_cloud_from_depth(depth, K, [y1, y2, x1, x2]).astype(np.float32).reshape(-1, 3)[::61]
     ch = np.arange(0, (y2 - y1) * (x2 - x1), 37)
     rec["rgb_choose"] = du.get_resize_rgb_choose(ch, [y1, y2, x1, x2], 224)
+    # the reference's sampling statements (inline in run_inference_custom.py:224-229 and bop_test_dataset.py:140-145),
+    # executed from its files with numpy's global RNG seeded: pins how many draws a detection consumes and in which form
+    pem = os.path.join(rh.REF_ROOT, "SAM-6D", "Pose_Estimation_Model")
+    counts = [40, 700, 512, 513, 5]
+    for tag, path, ns_extra in (("custom", os.path.join(pem, "run_inference_custom.py"), dict(cfg=types.SimpleNamespace(n_sample_observed_point=512))),
+                                ("bop", os.path.join(pem, "provider", "bop_test_dataset.py"), dict(self=types.SimpleNamespace(n_sample_observed_point=512)))):
+        src = _ref_statements(path, "n_sample_observed_point:", "cloud = cloud[choose_idx]")
+        np.random.seed(11)
+        got = []
+        for c in counts:
+            ns = dict(np=np, choose=np.arange(c) * 3, cloud=np.arange(c * 3, dtype=np.float32).reshape(c, 3), **ns_extra)
+            exec(src, ns)
+            got.append(ns["choose"] // 3)
+        rec["rng_idx_" + tag] = np.stack(got)
+    rec["rng_counts"] = np.array(counts)
     np.savez_compressed(os.path.join(OUT, "pem_pre.npz"), **rec)
     print("pem_pre.npz", {k: v.shape for k, v in rec.items()}, rec["bbox"][:4].tolist())
 

@@ -81,10 +81,10 @@ def resize_bilinear_u8(img, size):
     return np.clip(np.floor(out + np.float32(0.5)), 0, 255).astype(np.uint8)
 
 
-def preprocess_frame(image_u8, depth, K, masks, radius, keys, n_sample=2048, img_size=224, min_points=32, min_inliers=4,
-                     radius_factor=1.2, rgb_mask_flag=True):
+def preprocess_frame(image_u8, depth, K, masks, radius, keys=None, n_sample=2048, img_size=224, min_points=32, min_inliers=4,
+                     radius_factor=1.2, rgb_mask_flag=True, rng=None):
     """get_test_data's per-detection loop.  image_u8 (H,W,3) RGB, depth (H,W) f32 metres, masks (P,H,W) bool, keys
-    (P,H*W) uniforms.  -> dict(pts (M,n,3) f32, rgb (M,3,S,S) f32 normalised BGR->RGB flipped like the reference,
+    (P,H*W) uniforms (or rng = numpy.random / a RandomState for the reference's np.random.choice draws).  -> dict(pts (M,n,3) f32, rgb (M,3,S,S) f32 normalised BGR->RGB flipped like the reference,
     rgb_choose (M,n) i64, kept (M,) indices of the detections that survived the two size tests)."""
     whole = point_cloud(depth, K)
     out = dict(pts=[], rgb=[], rgb_choose=[], kept=[], bbox=[])
@@ -101,7 +101,13 @@ def preprocess_frame(image_u8, depth, K, masks, radius, keys, n_sample=2048, img
         if np.sum(flag) < min_inliers:
             continue
         choose, cloud = choose[flag], cloud[flag]
-        idx = sample_indices(len(choose), n_sample, keys[p])
+        if rng is not None:                                                     # the reference's own draws, :224-227
+            if len(choose) <= n_sample:
+                idx = rng.choice(np.arange(len(choose)), n_sample)
+            else:
+                idx = rng.choice(np.arange(len(choose)), n_sample, replace=False)
+        else:
+            idx = sample_indices(len(choose), n_sample, keys[p])
         choose, cloud = choose[idx], cloud[idx]
         rgb = image_u8[y1:y2, x1:x2, :][:, :, ::-1]
         if rgb_mask_flag:

@@ -11,7 +11,9 @@ two host round trips per FRAME (the pixel-list length and the survivor list), no
 
 Defined differently from the reference, on purpose (oracle/pem_pre.py explains and mirrors both):
   * sampling uses INJECTED uniforms (``keys``, one per crop pixel) instead of numpy's global RNG: with replacement
-    idx_i = floor(u_i * n) when n <= n_sample, else the n_sample smallest keys in key order;
+    idx_i = floor(u_i * n) when n <= n_sample, else the n_sample smallest keys in key order.  (``rng=`` switches to the
+    reference's own draws -- ``np.random.choice`` once per surviving detection, in detection order, :224-227 -- for runs that
+    must reproduce a seeded reference run point for point; it costs one more device->host copy of P counts);
   * the colour crop is bilinear with half-pixel centres in float32, rounded to uint8 (the reference calls cv2.resize,
     whose fixed-point arithmetic can differ by one grey level).
 """
@@ -83,12 +85,15 @@ def _crops(image_u8, m, box, img_size, rgb_mask_flag):
 
 
 @torch.no_grad()
-def observed_inputs(image_u8, depth, K, masks, radius, keys, n_sample=2048, img_size=224, min_points=32, min_inliers=4,
-                    radius_factor=1.2, rgb_mask_flag=True):
+def observed_inputs(image_u8, depth, K, masks, radius, keys=None, n_sample=2048, img_size=224, min_points=32, min_inliers=4,
+                    radius_factor=1.2, rgb_mask_flag=True, rng=None):
     """image_u8 (H,W,3) uint8 RGB, depth (H,W) f32 metres, K 3x3 (host), masks (P,H,W) bool, keys (P,H*W) f32 uniforms,
     all tensors on one device.  -> dict(pts (M,n,3) f32, rgb (M,3,S,S) f32, rgb_choose (M,n) i64, kept (M,) i64 indices
     of the detections that passed the two size tests (> min_points masked pixels, >= min_inliers after the radius
-    filter), bbox (M,4) i64 [y1,y2,x1,x2])."""
+    filter), bbox (M,4) i64 [y1,y2,x1,x2]).  Exactly one of ``keys`` / ``rng`` (``numpy.random`` itself or a RandomState)
+    selects the sampler."""
+    if (keys is None) == (rng is None):
+        raise ValueError("pass either keys (injected uniforms) or rng (numpy-compatible draws)")
     dev = depth.device
     P, H, W = masks.shape
     fx, fy, cx, cy = (float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]))
@@ -115,18 +120,10 @@ def observed_inputs(image_u8, depth, K, masks, radius, keys, n_sample=2048, img_
     n = torch.bincount(p_, minlength=P)                                                # inliers per detection
     ok = ok1 & (n >= min_inliers)
     start = torch.cumsum(n, 0) - n                                                     # offset of each detection's list
-    # ---- the defined sampler ---------------------------------------------------------------------------------------
-    L = int(n.max().item()) if P else 0                                                # host round trip #2
-    L = max(L, n_sample)
-    kk = keys[:, :L].float()
-    ar = torch.arange(L, device=dev)[None, :]
-    # the n_sample smallest keys in (key, position) order == a stable argsort's first n_sample entries, by selection
-    # instead of a full sort: non-negative float32 bit patterns order like the values, the position breaks ties
-    comp = (kk.contiguous().view(torch.int32).long() << 32) | ar
-    comp = torch.where(ar < n[:, None], comp, torch.full_like(comp, torch.iinfo(torch.int64).max))
-    without = torch.topk(comp, n_sample, dim=1, largest=False, sorted=True).values & 0xFFFFFFFF
-    with_r = (kk[:, :n_sample].double() * n[:, None]).floor().long()
-    idx = torch.where((n <= n_sample)[:, None], with_r, without)                       # (P,n_sample) in-list positions
+    if rng is not None:
+        idx = _numpy_choice_indices(n, ok, n_sample, rng).to(dev)
+    else:
+        idx = _keyed_indices(n, keys, n_sample)
     kept = torch.nonzero(ok).squeeze(1)
     g = (start[:, None] + idx)[kept].clamp(max=max(cloud.shape[0] - 1, 0))
     pts = cloud[g]
@@ -139,3 +136,36 @@ def observed_inputs(image_u8, depth, K, masks, radius, keys, n_sample=2048, img_
     rgb_choose = ((row.double() * (img_size / ch_h.double())[:, None]).floor() * img_size +
                   (col.double() * (img_size / ch_w.double())[:, None]).floor()).long()
     return dict(pts=pts, rgb=rgb, rgb_choose=rgb_choose, kept=kept, bbox=bk)
+
+
+def _keyed_indices(n, keys, n_sample):
+    """The defined sampler: (P,n_sample) in-list positions from one uniform per crop pixel."""
+    dev = n.device
+    L = int(n.max().item()) if n.numel() else 0                                        # host round trip #2
+    L = max(L, n_sample)
+    kk = keys[:, :L].float()
+    ar = torch.arange(L, device=dev)[None, :]
+    # the n_sample smallest keys in (key, position) order == a stable argsort's first n_sample entries, by selection
+    # instead of a full sort: non-negative float32 bit patterns order like the values, the position breaks ties
+    comp = (kk.contiguous().view(torch.int32).long() << 32) | ar
+    comp = torch.where(ar < n[:, None], comp, torch.full_like(comp, torch.iinfo(torch.int64).max))
+    without = torch.topk(comp, n_sample, dim=1, largest=False, sorted=True).values & 0xFFFFFFFF
+    with_r = (kk[:, :n_sample].double() * n[:, None]).floor().long()
+    return torch.where((n <= n_sample)[:, None], with_r, without)
+
+
+def _numpy_choice_indices(n, ok, n_sample, rng):
+    """The reference's draws (run_inference_custom.py:224-227 / bop_test_dataset.py:140-145): for every detection that
+    passed both size tests, in order, ONE ``choice`` over arange(n) -- with replacement when n <= n_sample, else without."""
+    import numpy as np
+
+    n_h, ok_h = n.cpu().tolist(), ok.cpu().tolist()
+    idx = np.zeros((len(n_h), n_sample), dtype=np.int64)
+    for i, (cnt, good) in enumerate(zip(n_h, ok_h)):
+        if not good:
+            continue
+        if cnt <= n_sample:
+            idx[i] = rng.choice(np.arange(cnt), n_sample)
+        else:
+            idx[i] = rng.choice(np.arange(cnt), n_sample, replace=False)
+    return torch.from_numpy(idx)

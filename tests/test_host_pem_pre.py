@@ -46,3 +46,35 @@ def test_no_detection_survives():
     inp = synth.pem_pre_inputs(P=3, seed=5)
     out = pre.observed_inputs(torch.from_numpy(inp["image"]), inp["depth"] * 0, inp["K"], inp["masks"], 0.1, inp["keys"])
     assert out["pts"].shape[0] == 0 and out["rgb"].shape == (0, 3, 224, 224) and out["kept"].numel() == 0
+
+
+def test_numpy_rng_mode_reproduces_the_reference_draws():
+    """rng= mode: the same np.random.choice calls, in the same order, as the reference's statements (golden made by
+    executing run_inference_custom.py:224-229 and bop_test_dataset.py:140-145 with numpy's RNG seeded)."""
+    g = util.golden("pem_pre.npz")
+    np.testing.assert_array_equal(g["rng_idx_custom"], g["rng_idx_bop"])          # both entry points draw alike
+    counts = torch.from_numpy(g["rng_counts"])
+    ok = torch.tensor([True] * len(counts))
+    np.random.seed(11)
+    idx = pre._numpy_choice_indices(counts, ok, 512, np.random)
+    np.testing.assert_array_equal(idx.numpy(), g["rng_idx_custom"])
+    # a detection that failed a size test consumes no draw
+    np.random.seed(11)
+    ok2 = torch.tensor([True, False, True, True, True])
+    idx2 = pre._numpy_choice_indices(counts, ok2, 512, np.random)
+    np.testing.assert_array_equal(idx2[0].numpy(), g["rng_idx_custom"][0])
+    assert (idx2[1] == 0).all() and not np.array_equal(idx2[2].numpy(), g["rng_idx_custom"][2])
+    # whole frame: product (batched) == oracle loop with the same seeded stream
+    inp = synth.pem_pre_inputs(P=8, seed=3)
+    kw = dict(radius=0.12, n_sample=512, img_size=224, min_points=32, min_inliers=4, radius_factor=1.2)
+    ref = opre.preprocess_frame(inp["image"], inp["depth"].numpy(), inp["K"].numpy(), inp["masks"].numpy(),
+                                rng=np.random.RandomState(5), **kw)
+    out = pre.observed_inputs(torch.from_numpy(inp["image"]), inp["depth"], inp["K"], inp["masks"], rng=np.random.RandomState(5), **kw)
+    assert out["kept"].tolist() == ref["kept"].tolist()
+    np.testing.assert_array_equal(out["pts"].numpy(), ref["pts"])
+    np.testing.assert_array_equal(out["rgb_choose"].numpy(), ref["rgb_choose"])
+    import pytest
+    with pytest.raises(ValueError):
+        pre.observed_inputs(torch.from_numpy(inp["image"]), inp["depth"], inp["K"], inp["masks"], 0.12)
+    with pytest.raises(ValueError):
+        pre.observed_inputs(torch.from_numpy(inp["image"]), inp["depth"], inp["K"], inp["masks"], 0.12, keys=inp["keys"], rng=np.random)

@@ -322,6 +322,20 @@ def gen_sam_transforms():
     print("sam_transforms.npz", {k: getattr(v, "shape", v) for k, v in rec.items() if k.endswith("_out")})
 
 
+def gen_sam_state_dict():
+    """state_dict keys / shapes of the reference's three Sam builds (build_sam.py run unmodified on the meta device)."""
+    import json
+    mod = rh.sam_builder()
+    rec = {}
+    for name in ("vit_h", "vit_l", "vit_b"):
+        with torch.device("meta"):
+            m = mod.sam_model_registry[name]()
+        rec[name] = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+    with open(os.path.join(OUT, "sam_state_dict.json"), "w") as f:
+        json.dump(rec, f, separators=(",", ":"))
+    print("sam_state_dict.json", {k: len(v) for k, v in rec.items()})
+
+
 def gen_pem_pre():
     """Reference geometry helpers of the PEM pre-processing (utils/data_utils.py), run unmodified."""
     du = rh.pem_data_utils()
@@ -494,4 +508,4 @@ def gen_dinov2():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    {"pem": gen_pem, "sam": gen_sam, "ism": gen_ism, "dinov2": gen_dinov2, "sam_decoder": gen_sam_decoder, "handoff": gen_handoff, "pem_pre": gen_pem_pre, "pem_results": gen_pem_results, "detections_ops": gen_detections_ops, "sam_transforms": gen_sam_transforms}[sys.argv[1]]()
+    {"pem": gen_pem, "sam": gen_sam, "ism": gen_ism, "dinov2": gen_dinov2, "sam_decoder": gen_sam_decoder, "handoff": gen_handoff, "pem_pre": gen_pem_pre, "pem_results": gen_pem_results, "detections_ops": gen_detections_ops, "sam_transforms": gen_sam_transforms, "sam_state_dict": gen_sam_state_dict}[sys.argv[1]]()

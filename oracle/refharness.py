@@ -172,6 +172,27 @@ def sam_decoder():
     return ns
 
 
+def sam_builder():
+    """segment_anything/build_sam.py loaded by file path: a synthetic parent package whose ``.modeling`` exposes the
+    reference's own classes (modeling/sam.py is loaded into the same synthetic modeling package).  Returns the module
+    (sam_model_registry, build_sam_vit_h ...)."""
+    ns = sam_decoder()
+    mp = "_s6d_ref_sa_modeling"
+    base = os.path.join(ISM, "segment_anything")
+    sam_mod = sys.modules.get(mp + ".sam") or _load_by_path(mp + ".sam", os.path.join(base, "modeling", "sam.py"), mp)
+    pkg = sys.modules[mp]
+    pkg.ImageEncoderViT = sys.modules[mp + ".image_encoder"].ImageEncoderViT
+    pkg.MaskDecoder, pkg.PromptEncoder, pkg.TwoWayTransformer, pkg.Sam = ns.MaskDecoder, ns.PromptEncoder, ns.TwoWayTransformer, sam_mod.Sam
+    top = "_s6d_ref_sa"
+    if top not in sys.modules:
+        t = types.ModuleType(top)
+        t.__path__ = [base]
+        t.modeling = pkg
+        sys.modules[top] = t
+        sys.modules[top + ".modeling"] = pkg
+    return sys.modules.get(top + ".build_sam") or _load_by_path(top + ".build_sam", os.path.join(base, "build_sam.py"), top)
+
+
 def ism():
     """Reference ISM scoring code: model.loss classes, detector scoring methods,
     compute_iou and the masked-depth translation helper."""

@@ -30,15 +30,19 @@ from .sam.transforms import ResizeLongestSide
 class FramePipeline:
     def __init__(self, sam_encoder, prompt_encoder, mask_decoder, descriptor_model, scorer, pem_net, pem_templates,
                  object_radius, top_k=10, points_per_batch=1024, min_box_size=0.05 ** 2, min_mask_size=3e-4,
-                 segmentor=None):
+                 segmentor=None, nms_per_object_thresh=None, det_score_thresh=None):
         """descriptor_model: sam6d_amd.ism.dinov2.CustomDINOv2; scorer: sam6d_amd.ism.scoring.FrameScorer (holds the
         template descriptors); pem_templates: dict(dense_po (1,n,3), dense_fo (1,n,C), model (1,m,3)) of the object;
-        segmentor: keyword overrides of amg.generate_proposals (thresholds)."""
+        segmentor: keyword overrides of amg.generate_proposals (thresholds).  nms_per_object_thresh: the BOP flow's
+        ``apply_nms_per_object_id`` after scoring (detector.py:388-390; 0.25 in configs/model/ISM_sam.yaml; the custom
+        demo flow has none).  det_score_thresh: only detections scoring above it go to the PEM
+        (run_inference_custom.py:165-171, default 0.2 there); top_k=None keeps every detection."""
         self.enc, self.pe, self.md, self.desc, self.scorer, self.pem = (sam_encoder, prompt_encoder, mask_decoder,
                                                                        descriptor_model, scorer, pem_net)
         self.tpl, self.radius, self.top_k, self.ppb = pem_templates, object_radius, top_k, points_per_batch
         self.min_box, self.min_mask = min_box_size, min_mask_size
         self.seg_kw = segmentor or {}
+        self.nms_thresh, self.det_thresh = nms_per_object_thresh, det_score_thresh
         self.times = {}
 
     def _tick(self, name, t0):
@@ -76,9 +80,19 @@ class FramePipeline:
         cls, patch = self.desc(image_u8.cpu().numpy(), SimpleNamespace(masks=masks.float(), boxes=boxes))
         t0 = self._tick("descriptors", t0)
         sc = self.scorer.score(cls, patch, masks.float(), boxes.float(), depth, K)
-        order = torch.argsort(sc["final"], descending=True)[: self.top_k]
+        order = torch.argsort(sc["final"], descending=True)
         sel = sc["sel"][order]
         det = Detections(0, 0, masks[sel], boxes[sel], sc["final"][order], sc["pred_obj"][order])
+        if self.nms_thresh is not None:
+            det.apply_nms_per_object_id(self.nms_thresh)
+            det.filter(torch.argsort(det.scores, descending=True, stable=True))       # back to best-first
+        if self.det_thresh is not None:
+            det.filter(det.scores > self.det_thresh)
+        if self.top_k is not None:
+            det.filter(slice(0, self.top_k))
+        if len(det) == 0:
+            self._tick("scoring", t0)
+            return det, None
         t0 = self._tick("scoring", t0)
         # ---- PEM ------------------------------------------------------------------------------------------------------
         obs = pem_pre.observed_inputs(image_u8, depth, K, det.masks, self.radius, sample_keys[: det.masks.shape[0]])

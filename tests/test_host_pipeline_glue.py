@@ -83,3 +83,21 @@ def test_glue_between_the_stages(monkeypatch):
     out = pipeline.frame_results(det, poses, "ycbv", 0.1)
     assert len(out["ism_records"]) == 3 and len(out["csv_lines"]) == 3 and out["pem_records"][0]["R"] == np.eye(3).tolist()
     assert [r["category_id"] for r in out["ism_records"]] == [1, 1, 1]
+    # ---- BOP-flow options: NMS per object id after scoring, detection score threshold, no top-k ---------------------------
+    from oracle import sam_decoder as osd
+    from sam6d_amd.ism import handoff
+    monkeypatch.setattr(handoff, "_device_nms", osd.nms)
+    boxes[4] = torch.tensor([62, 32, 150, 110])                      # now overlaps proposal 3 (IoU > 0.25): the weaker one goes
+    masks[4] = False
+    masks[4, 32:111, 62:151] = True
+    pipe = pipeline.FramePipeline(Enc(), None, None, Desc(), Scorer(), Pem(), tpl, object_radius=10.0, top_k=None, points_per_batch=16,
+                                  nms_per_object_thresh=0.25, det_score_thresh=0.3)
+    det, poses = pipe(img, depth, K, torch.rand(4, H * W, generator=g), torch.rand(4, 18000, generator=g))
+    # survivors of the filters in proposal order: 2, 3, 4, 5 with final scores .2, .433, .667, .9; NMS drops 3 (overlaps 4,
+    # lower score); the score threshold drops 2; best first
+    assert torch.equal(det.boxes, boxes[[5, 4]]) and torch.allclose(det.scores, torch.tensor([0.9, 0.2 + 0.7 * 2 / 3]))
+    assert poses["pred_R"].shape[0] == 2
+    pipe.det_thresh = 0.95
+    det, poses = pipe(img, depth, K, torch.rand(4, H * W, generator=g), torch.rand(4, 18000, generator=g))
+    assert len(det) == 0 and poses is None
+

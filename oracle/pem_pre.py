@@ -97,7 +97,8 @@ def preprocess_frame(image_u8, depth, K, masks, radius, keys=None, n_sample=2048
         choose = m.astype(np.float32).flatten().nonzero()[0]
         cloud = whole[y1:y2, x1:x2, :].reshape(-1, 3)[choose, :]
         center = np.mean(cloud, axis=0)
-        flag = np.linalg.norm(cloud - center[None, :], axis=1) < radius * radius_factor
+        r_p = radius[p] if np.ndim(radius) else radius                          # per-detection radius on multi-object frames
+        flag = np.linalg.norm(cloud - center[None, :], axis=1) < r_p * radius_factor
         if np.sum(flag) < min_inliers:
             continue
         choose, cloud = choose[flag], cloud[flag]

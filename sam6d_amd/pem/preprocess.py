@@ -87,7 +87,8 @@ def _crops(image_u8, m, box, img_size, rgb_mask_flag):
 @torch.no_grad()
 def observed_inputs(image_u8, depth, K, masks, radius, keys=None, n_sample=2048, img_size=224, min_points=32, min_inliers=4,
                     radius_factor=1.2, rgb_mask_flag=True, rng=None):
-    """image_u8 (H,W,3) uint8 RGB, depth (H,W) f32 metres, K 3x3 (host), masks (P,H,W) bool, keys (P,H*W) f32 uniforms,
+    """image_u8 (H,W,3) uint8 RGB, depth (H,W) f32 metres, K 3x3 (host), masks (P,H,W) bool, radius: the object's radius in
+    metres (a number, or a (P,) tensor with one radius per detection when a frame holds several objects), keys (P,H*W) f32 uniforms,
     all tensors on one device.  -> dict(pts (M,n,3) f32, rgb (M,3,S,S) f32, rgb_choose (M,n) i64, kept (M,) i64 indices
     of the detections that passed the two size tests (> min_points masked pixels, >= min_inliers after the radius
     filter), bbox (M,4) i64 [y1,y2,x1,x2]).  Exactly one of ``keys`` / ``rng`` (``numpy.random`` itself or a RandomState)
@@ -115,7 +116,10 @@ def observed_inputs(image_u8, depth, K, masks, radius, keys=None, n_sample=2048,
     center = (torch.zeros(P, 3, dtype=torch.float64, device=dev).index_add_(0, p_, cloud.double())
               / n0.clamp(min=1)[:, None]).float()
     dist = torch.linalg.norm(cloud - center[p_], dim=1)
-    flag = dist.double() < radius * radius_factor
+    if torch.is_tensor(radius) and radius.numel() > 1:                                 # one radius per detection (multi-object frames)
+        flag = dist.double() < (radius.to(dev).double() * radius_factor)[p_]
+    else:
+        flag = dist.double() < float(radius) * radius_factor
     p_, choose, cloud = p_[flag], choose[flag], cloud[flag]
     n = torch.bincount(p_, minlength=P)                                                # inliers per detection
     ok = ok1 & (n >= min_inliers)

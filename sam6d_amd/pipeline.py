@@ -32,7 +32,8 @@ class FramePipeline:
                  object_radius, top_k=10, points_per_batch=1024, min_box_size=0.05 ** 2, min_mask_size=3e-4,
                  segmentor=None, nms_per_object_thresh=None, det_score_thresh=None):
         """descriptor_model: sam6d_amd.ism.dinov2.CustomDINOv2; scorer: sam6d_amd.ism.scoring.FrameScorer (holds the
-        template descriptors); pem_templates: dict(dense_po (1,n,3), dense_fo (1,n,C), model (1,m,3)) of the object;
+        template descriptors); pem_templates: dict(dense_po (O,n,3), dense_fo (O,n,C), model (O,m,3)) of the O objects (O = 1: every detection
+        is that object; O > 1: rows are picked by the ISM's predicted object id); object_radius: a number or an (O,) tensor;
         segmentor: keyword overrides of amg.generate_proposals (thresholds).  nms_per_object_thresh: the BOP flow's
         ``apply_nms_per_object_id`` after scoring (detector.py:388-390; 0.25 in configs/model/ISM_sam.yaml; the custom
         demo flow has none).  det_score_thresh: only detections scoring above it go to the PEM
@@ -95,15 +96,22 @@ class FramePipeline:
             return det, None
         t0 = self._tick("scoring", t0)
         # ---- PEM ------------------------------------------------------------------------------------------------------
-        obs = pem_pre.observed_inputs(image_u8, depth, K, det.masks, self.radius, sample_keys[: det.masks.shape[0]])
+        multi = self.tpl["model"].shape[0] > 1                          # per-object template data, indexed by predicted object
+        radius = self.radius
+        if torch.is_tensor(radius) and radius.numel() > 1:
+            radius = radius.to(det.object_ids.device)[det.object_ids.long()]
+        obs = pem_pre.observed_inputs(image_u8, depth, K, det.masks, radius, sample_keys[: det.masks.shape[0]])
         t0 = self._tick("pem_preprocessing", t0)
         M = obs["pts"].shape[0]
         if M == 0:
             return det, None
-        ep = dict(pts=obs["pts"], rgb=obs["rgb"], rgb_choose=obs["rgb_choose"],
-                  model=self.tpl["model"].expand(M, -1, -1).contiguous(),
-                  dense_po=self.tpl["dense_po"].expand(M, -1, -1).contiguous(),
-                  dense_fo=self.tpl["dense_fo"].expand(M, -1, -1).contiguous(), coarse_rand_u=coarse_rand_u[:M])
+        oid = det.object_ids[obs["kept"]].long()
+
+        def tpl(name):                                                  # test_bop.py:145-147 picks dense_po[obj] / dense_fo[obj]
+            t = self.tpl[name]
+            return (t[oid] if multi else t.expand(M, -1, -1)).contiguous()
+        ep = dict(pts=obs["pts"], rgb=obs["rgb"], rgb_choose=obs["rgb_choose"], model=tpl("model"), dense_po=tpl("dense_po"),
+                  dense_fo=tpl("dense_fo"), coarse_rand_u=coarse_rand_u[:M])
         out = self.pem(ep)
         self._tick("pem", t0)
         return det, dict(pred_R=out["pred_R"], pred_t=out["pred_t"], pred_pose_score=out["pred_pose_score"],

@@ -78,3 +78,22 @@ def test_numpy_rng_mode_reproduces_the_reference_draws():
         pre.observed_inputs(torch.from_numpy(inp["image"]), inp["depth"], inp["K"], inp["masks"], 0.12)
     with pytest.raises(ValueError):
         pre.observed_inputs(torch.from_numpy(inp["image"]), inp["depth"], inp["K"], inp["masks"], 0.12, keys=inp["keys"], rng=np.random)
+
+
+def test_per_detection_radius_on_multi_object_frames():
+    inp = synth.pem_pre_inputs(P=8, seed=3)
+    kw = dict(n_sample=512, img_size=224, min_points=32, min_inliers=4, radius_factor=1.2)
+    # radii chosen so that no point lies within a few micrometres of a detection's radius sphere: the centroid is a sequential
+    # float32 sum in the reference (np.mean over axis 0) and a float64-accumulated mean in the batched code, so points that
+    # close to the boundary can fall on different sides (known gap)
+    radius = np.array([0.12, 0.03, 0.5, 0.12, 0.05, 0.2, 0.12, 0.01])
+    ref = opre.preprocess_frame(inp["image"], inp["depth"].numpy(), inp["K"].numpy(), inp["masks"].numpy(), radius,
+                                keys=inp["keys"].numpy(), **kw)
+    out = pre.observed_inputs(torch.from_numpy(inp["image"]), inp["depth"], inp["K"], inp["masks"], torch.from_numpy(radius),
+                              keys=inp["keys"], **kw)
+    assert out["kept"].tolist() == ref["kept"].tolist()
+    np.testing.assert_array_equal(out["pts"].numpy(), ref["pts"])
+    np.testing.assert_array_equal(out["rgb_choose"].numpy(), ref["rgb_choose"])
+    same = opre.preprocess_frame(inp["image"], inp["depth"].numpy(), inp["K"].numpy(), inp["masks"].numpy(), 0.12,
+                                 keys=inp["keys"].numpy(), **kw)
+    assert not np.array_equal(same["pts"][1], ref["pts"][1])                  # the smaller radius really changed a cloud

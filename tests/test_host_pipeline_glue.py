@@ -100,4 +100,25 @@ def test_glue_between_the_stages(monkeypatch):
     pipe.det_thresh = 0.95
     det, poses = pipe(img, depth, K, torch.rand(4, H * W, generator=g), torch.rand(4, 18000, generator=g))
     assert len(det) == 0 and poses is None
+    # ---- several objects: template rows and radius follow the predicted object id ------------------------------------------
+    class Scorer2(Scorer):
+        def score(self, cls, patch, m, b, d, k):
+            r = super().score(cls, patch, m, b, d, k)
+            r["pred_obj"] = torch.tensor([2, 0, 1, 2])[: m.shape[0]]
+            return r
+    tpl3 = dict(model=torch.arange(3.0)[:, None, None].expand(3, 64, 3).clone(), dense_po=torch.arange(3.0)[:, None, None].expand(3, 32, 3).clone(),
+                dense_fo=torch.zeros(3, 32, 8))
+
+    class Pem2(Pem):
+        def __call__(self, ep):
+            seen["model_rows"] = ep["model"][:, 0, 0].tolist()
+            seen["po_rows"] = ep["dense_po"][:, 0, 0].tolist()
+            return super().__call__(ep)
+    pipe = pipeline.FramePipeline(Enc(), None, None, Desc(), Scorer2(), Pem2(), tpl3, object_radius=torch.tensor([10.0, 10.0, 10.0]),
+                                  top_k=None, points_per_batch=16)
+    det, poses = pipe(img, depth, K, torch.rand(4, H * W, generator=g), torch.rand(4, 18000, generator=g))
+    assert det.object_ids.tolist() == [2, 1, 0, 2]                   # best first: proposals 5, 4, 3, 2 -> objects 2, 1, 0, 2
+    assert seen["model_rows"] == [2.0, 1.0, 0.0, 2.0] == seen["po_rows"]
+    out = pipeline.frame_results(det, poses, "ycbv", 0.0)
+    assert [r["category_id"] for r in out["pem_records"]] == [3, 2, 1, 3] and [l.split(",")[2] for l in out["csv_lines"]] == ["3", "2", "1", "3"]
 

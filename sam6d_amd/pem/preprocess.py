@@ -17,6 +17,8 @@ Defined differently from the reference, on purpose (oracle/pem_pre.py explains a
   * the colour crop is bilinear with half-pixel centres in float32, rounded to uint8 (the reference calls cv2.resize,
     whose fixed-point arithmetic can differ by one grey level).
 """
+import os
+
 import torch
 
 MEAN = (0.485, 0.456, 0.406)
@@ -113,8 +115,15 @@ def observed_inputs(image_u8, depth, K, masks, radius, keys=None, n_sample=2048,
     fx_t, fy_t = torch.tensor(fx, device=dev), torch.tensor(fy, device=dev)            # tensor divisors: true division
     cloud = torch.stack([(x_.float() - cx) * z / fx_t, (y_.float() - cy) * z / fy_t, z], 1)  # float32, reference order
     n0 = torch.bincount(p_, minlength=P)
-    center = (torch.zeros(P, 3, dtype=torch.float64, device=dev).index_add_(0, p_, cloud.double())
-              / n0.clamp(min=1)[:, None]).float()
+    if cloud.is_cuda and os.environ.get("S6D_PEM_SEQ_CENTROID") == "1":
+        # the reference's np.mean(cloud, axis=0): rows added in order into a float32 accumulator, then one float32 division
+        # (s6d_segment_seq_sum_f32).  Opt-in until it has been through the device parity test.
+        from .. import ops
+        center = ops.segment_seq_sum(cloud.contiguous(), (torch.cumsum(n0, 0) - n0).contiguous(), n0.contiguous()) \
+            / n0.clamp(min=1).float()[:, None]
+    else:
+        center = (torch.zeros(P, 3, dtype=torch.float64, device=dev).index_add_(0, p_, cloud.double())
+                  / n0.clamp(min=1)[:, None]).float()
     dist = torch.linalg.norm(cloud - center[p_], dim=1)
     if torch.is_tensor(radius) and radius.numel() > 1:                                 # one radius per detection (multi-object frames)
         flag = dist.double() < (radius.to(dev).double() * radius_factor)[p_]

@@ -1,5 +1,7 @@
 """Host-glue operations on the device (run last: they follow the kernel parity tests): Detections NMS per object id through
 s6d_nms_f32, and the Pillow-exact frame resize as integer tensor ops on cuda:0."""
+import os
+
 import pytest
 import torch
 
@@ -39,3 +41,34 @@ def test_frame_resize_on_the_device_is_pillow_exact():
         out = ResizeLongestSide(int(g[tag + "_L"])).apply_image(torch.from_numpy(g[tag + "_img"]).cuda())
         assert out.is_cuda and out.dtype == torch.uint8
         np.testing.assert_array_equal(out.cpu().numpy(), g[tag + "_out"])
+
+
+@pytest.mark.skipif(os.environ.get("S6D_PEM_SEQ_CENTROID") != "1", reason="opt-in path: set S6D_PEM_SEQ_CENTROID=1")
+def test_sequential_centroid_matches_numpy_row_order():
+    """s6d_segment_seq_sum_f32 == numpy's add.reduce over axis 0, bit for bit, and with it the pre-processing agrees with the
+    oracle at radii whose sphere cuts through dense points (where the float64-accumulated centroid does not)."""
+    import numpy as np
+
+    from oracle import pem_pre as opre
+    from sam6d_amd import ops
+    from sam6d_amd.pem import preprocess as pre
+    from sam6d_amd.utils import synth
+    g = torch.Generator().manual_seed(0)
+    counts = torch.tensor([0, 1, 5, 511, 512, 513, 3000, 70001])
+    x = (torch.randn(int(counts.sum()), 3, generator=g) * torch.tensor([0.3, 0.2, 0.1]) + torch.tensor([0.1, -0.2, 0.8]))
+    start = torch.cumsum(counts, 0) - counts
+    got = ops.segment_seq_sum(x.cuda(), start.cuda(), counts.cuda()).cpu().numpy()
+    for i, (s0, c) in enumerate(zip(start.tolist(), counts.tolist())):
+        want = np.add.reduce(x[s0:s0 + c].numpy(), axis=0) if c else np.zeros(3, np.float32)
+        np.testing.assert_array_equal(got[i], want, err_msg=str(c))
+    inp = synth.pem_pre_inputs(P=8, seed=3)
+    kw = dict(n_sample=512, img_size=224, min_points=32, min_inliers=4, radius_factor=1.2)
+    radius = np.array([0.12, 0.03, 0.5, 0.12, 0.06, 0.2, 0.07, 0.01])
+    ref = opre.preprocess_frame(inp["image"], inp["depth"].numpy(), inp["K"].numpy(), inp["masks"].numpy(), radius,
+                                keys=inp["keys"].numpy(), **kw)
+    out = pre.observed_inputs(torch.from_numpy(inp["image"]).cuda(), inp["depth"].cuda(), inp["K"], inp["masks"].cuda(),
+                              torch.from_numpy(radius).cuda(), keys=inp["keys"].cuda(), **kw)
+    assert out["kept"].cpu().tolist() == ref["kept"].tolist()
+    np.testing.assert_array_equal(out["pts"].cpu().numpy(), ref["pts"])
+    np.testing.assert_array_equal(out["rgb_choose"].cpu().numpy(), ref["rgb_choose"])
+

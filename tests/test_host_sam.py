@@ -36,3 +36,20 @@ def test_vit_h_state_dict_surface():
     mine = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     assert mine == {k: tuple(v) for k, v in util.shapes_from_golden(g, "h_keys", "h_shapes").items()}
     assert m.img_size == 1024
+
+
+def test_mlp_row_chunk_knob_is_the_same_function(monkeypatch):
+    """S6D_SAM_MLP_ROWS (experiment knob, off by default) only changes how many rows go through lin1 -> GELU -> lin2 at a time."""
+    import torch
+
+    from sam6d_amd.sam.image_encoder import MLPBlock
+    torch.manual_seed(0)
+    m = MLPBlock(32, 128).eval()
+    x = torch.randn(2, 5, 7, 32)
+    with torch.no_grad():
+        want = m(x)
+        for rows in ("16", "33", "70", "1000"):
+            monkeypatch.setenv("S6D_SAM_MLP_ROWS", rows)
+            got = m(x)
+            assert got.shape == want.shape and torch.allclose(got, want, atol=1e-6), rows
+

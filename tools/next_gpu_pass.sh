@@ -8,7 +8,8 @@ mkdir -p gpurun_out
 timeout 600 python -m pytest tests/test_gpu_zz_host_glue.py tests/test_gpu_zz_pipeline.py -q 2>&1 | tail -5 > gpurun_out/n1_glue.txt
 S6D_PEM_SEQ_CENTROID=1 timeout 600 python -m pytest tests/test_gpu_zz_host_glue.py -q -k sequential 2>&1 | tail -5 > gpurun_out/n2_seq_centroid.txt
 timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > gpurun_out/n3_gpu_suite.txt
-# 2. the segmentor plugin end to end (mini models are in the pipeline test; this is ViT-H with seeded weights)
+# 2. the segmentor plugin end to end (ViT-H, seeded weights) and the five-model frame chain
+timeout 600 python tools/segmentor_demo.py > gpurun_out/n4_segmentor_demo.txt 2>&1
 timeout 600 python tools/frame_demo.py > gpurun_out/n4_frame_demo.txt 2>&1
 # 3. bench A/B: default vs Infinity-Cache-sized MLP row chunks
 timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/n5_bench_default.json 2> gpurun_out/n5.err

@@ -31,6 +31,7 @@ class Sam(nn.Module):
         self.image_encoder, self.prompt_encoder, self.mask_decoder = image_encoder, prompt_encoder, mask_decoder
         self.register_buffer("pixel_mean", torch.tensor(pixel_mean, dtype=torch.float32).view(-1, 1, 1), False)
         self.register_buffer("pixel_std", torch.tensor(pixel_std, dtype=torch.float32).view(-1, 1, 1), False)
+        self._mean_std = (tuple(float(v) for v in pixel_mean), tuple(float(v) for v in pixel_std))   # host copies: no sync per frame
 
     @property
     def device(self):
@@ -38,8 +39,7 @@ class Sam(nn.Module):
 
     def preprocess(self, x):
         """Normalise colours and zero-pad to the square input (modeling/sam.py:164-174), one fused kernel."""
-        return _preprocess(x, self.image_encoder.img_size, tuple(self.pixel_mean.flatten().tolist()),
-                           tuple(self.pixel_std.flatten().tolist()))
+        return _preprocess(x, self.image_encoder.img_size, *self._mean_std)
 
     def forward(self, *a, **k):
         raise NotImplementedError("Sam.forward (batched prompts end to end) is not on the SAM-6D path; use "

@@ -70,7 +70,8 @@ int s6d_gather_rows_f32(const float *src, const int32_t *idx, int B, int N, int 
 /* Sum of each segment's rows in ROW ORDER, float32 accumulator: numpy's add.reduce over axis 0 of a C-ordered
  * (n, C) array, i.e. the numerator of np.mean(cloud, axis=0) in the PEM pre-processing
  * (Pose_Estimation_Model/run_inference_custom.py:214, provider/bop_test_dataset.py:131).
- * x (N,C) f32, start/count (P) i64 (rows [start, start+count) of x), 1 <= C <= 4 -> out (P,C) f32 (0 for empty). */
+ * x (N,C) f32, start/count (P) i64 (rows [start, start+count) of x), 2 <= C <= 4 -> out (P,C) f32 (0 for empty).
+ * (C = 1 is refused: with a single column the reduced axis is the contiguous one and numpy sums it pairwise.) */
 int s6d_segment_seq_sum_f32(const float *x, const int64_t *start, const int64_t *count, int P, int C, float *out,
                             void *stream);
 

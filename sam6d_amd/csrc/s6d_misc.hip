@@ -7,13 +7,14 @@
 //                    (B,196,16*256) up-projection to (B,256,56,56), bilinearly upsamples to 224x224 (51 MB per
 //                    instance) and then reads 2048 pixels of it.  Here each chosen pixel interpolates its 4
 //                    source texels straight out of the up-projection: 4 KB read + 1 KB written per point.
-//   segment_seq_sum  numpy's reduction over axis 0 of a C-ordered (n, C) float32 array -- what the reference's
+//   segment_seq_sum  numpy's reduction over axis 0 of a C-ordered (n, C >= 2) float32 array -- what the reference's
 //                    ``np.mean(cloud, axis=0)`` computes for the centroid of a detection's point cloud
 //                    (Pose_Estimation_Model/run_inference_custom.py:214, provider/bop_test_dataset.py:131): the rows are
 //                    added one after the other into a float32 accumulator.  A parallel reduction rounds differently, and
 //                    a centroid that is off by a micrometre moves points across the radius filter; so the order is kept:
 //                    one wave per detection stages 512-row chunks in LDS (coalesced), lanes 0..C-1 add them in row order.
 #include "s6d_common.h"
+#include "s6d_seqsum.h"
 
 namespace s6d {
 
@@ -91,40 +92,6 @@ __global__ __launch_bounds__(256) void upsample_gather_kernel(const float *__res
   }
 }
 
-constexpr int kSeqRows = 512;                                        // rows per LDS chunk (<= 8 KB at C = 4)
-
-__global__ __launch_bounds__(64) void segment_seq_sum_kernel(const float *__restrict__ x, const long *__restrict__ start,
-                                                              const long *__restrict__ count, int C,
-                                                              float *__restrict__ out) {
-  __shared__ float buf[kSeqRows * 4];
-  const int p = blockIdx.x, lane = threadIdx.x;
-  const long n = count[p];
-  const float *src = x + start[p] * C;
-  float acc = 0.f;
-  for (long r0 = 0; r0 < n; r0 += kSeqRows) {
-    const int rows = (int)((n - r0 < kSeqRows) ? (n - r0) : kSeqRows);
-    for (int i = lane; i < rows * C; i += 64) buf[i] = src[r0 * C + i];
-    __syncthreads();
-    if (lane < C) {
-      int i = 0;
-      if (r0 == 0) {                                                 // the reduction starts FROM the first row (no 0 + x0)
-        acc = buf[lane];
-        i = 1;
-      }
-      for (; i + 8 <= rows; i += 8) {                                // 8 LDS reads in flight, then the 8 adds in row order
-        float v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = buf[(i + k) * C + lane];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc = acc + v[k];
-      }
-      for (; i < rows; ++i) acc = acc + buf[i * C + lane];           // strictly in row order; nothing to contract
-    }
-    __syncthreads();
-  }
-  if (lane < C) out[(size_t)p * C + lane] = acc;
-}
-
 }  // namespace s6d
 
 using namespace s6d;
@@ -160,7 +127,7 @@ extern "C" int s6d_upsample_gather_f32(const float *up, const int64_t *choose, i
 
 extern "C" int s6d_segment_seq_sum_f32(const float *x, const int64_t *start, const int64_t *count, int P, int C, float *out,
                                        void *stream) {
-  if (P < 0 || C <= 0 || C > 4) return S6D_EINVAL;
+  if (P < 0 || C < 2 || C > 4) return S6D_EINVAL;  // C = 1: numpy reduces a contiguous axis pairwise, not in row order
   if (P == 0) return S6D_OK;
   if (!x || !start || !count || !out) return S6D_EINVAL;
   hipLaunchKernelGGL(segment_seq_sum_kernel, dim3((unsigned)P), dim3(64), 0, as_stream(stream), x, (const long *)start,

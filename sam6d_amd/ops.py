@@ -284,13 +284,13 @@ def samdec_upscale_heads(y0, ln_w, ln_b, eps, w2t, b2, hyper, h, w):
 
 def segment_seq_sum(x, start, count):
     """Row-order float32 sums of segments of x (numpy's add.reduce over axis 0; the centroid numerator of the PEM
-    pre-processing).  x (N,C) f32 with C <= 4, start / count (P,) int64 -> (P,C) f32."""
+    pre-processing).  x (N,C) f32 with 2 <= C <= 4, start / count (P,) int64 -> (P,C) f32."""
     _chk(x, torch.float32, "x", 2)
     _chk(start, torch.int64, "start", 1)
     _chk(count, torch.int64, "count", 1)
     P, C = start.shape[0], x.shape[1]
-    if count.shape[0] != P or not 1 <= C <= 4:
-        raise RuntimeError("segment_seq_sum: start/count must have one entry per segment and C must be 1..4")
+    if count.shape[0] != P or not 2 <= C <= 4:
+        raise RuntimeError("segment_seq_sum: start/count must have one entry per segment and C must be 2..4")
     out = torch.zeros(P, C, dtype=torch.float32, device=x.device)
     _call("s6d_segment_seq_sum_f32", _ptr(x), _ptr(start), _ptr(count), P, C, _ptr(out), _stream())
     return out

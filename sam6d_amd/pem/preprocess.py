@@ -115,11 +115,10 @@ def observed_inputs(image_u8, depth, K, masks, radius, keys=None, n_sample=2048,
     fx_t, fy_t = torch.tensor(fx, device=dev), torch.tensor(fy, device=dev)            # tensor divisors: true division
     cloud = torch.stack([(x_.float() - cx) * z / fx_t, (y_.float() - cy) * z / fy_t, z], 1)  # float32, reference order
     n0 = torch.bincount(p_, minlength=P)
-    if cloud.is_cuda and os.environ.get("S6D_PEM_SEQ_CENTROID") == "1":
+    if os.environ.get("S6D_PEM_SEQ_CENTROID") == "1":
         # the reference's np.mean(cloud, axis=0): rows added in order into a float32 accumulator, then one float32 division
         # (s6d_segment_seq_sum_f32).  Opt-in until it has been through the device parity test.
-        from .. import ops
-        center = ops.segment_seq_sum(cloud.contiguous(), (torch.cumsum(n0, 0) - n0).contiguous(), n0.contiguous()) \
+        center = _segment_seq_sum(cloud.contiguous(), (torch.cumsum(n0, 0) - n0).contiguous(), n0.contiguous()) \
             / n0.clamp(min=1).float()[:, None]
     else:
         center = (torch.zeros(P, 3, dtype=torch.float64, device=dev).index_add_(0, p_, cloud.double())
@@ -182,3 +181,10 @@ def _numpy_choice_indices(n, ok, n_sample, rng):
         else:
             idx[i] = rng.choice(np.arange(cnt), n_sample, replace=False)
     return torch.from_numpy(idx)
+
+
+def _segment_seq_sum(x, start, count):
+    """Row-order float32 segment sums on the device (raises on host tensors: there is no CPU implementation in the product)."""
+    from .. import ops
+    return ops.segment_seq_sum(x, start, count)
+

@@ -3,7 +3,6 @@ import ast
 import os
 
 import numpy as np
-import torch
 
 from sam6d_amd.utils import seeded
 

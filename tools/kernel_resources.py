@@ -3,7 +3,6 @@ from hipcc's -Rpass-analysis=kernel-resource-usage remarks with the flags the li
 
     python tools/kernel_resources.py > profiles/rNN_kernel_resources.txt
 """
-import glob
 import os
 import re
 import subprocess

@@ -533,21 +533,25 @@ __device__ __forceinline__ void win16_tables(const RelFrags<HD> &rf, int S, int 
     for (int jt = 0; jt < 2; ++jt)
       *reinterpret_cast<float4 *>(tab + c * W16_LT + jt * 16 + g * 4) =
           make_float4(aw[jt][0] * kLog2e, aw[jt][1] * kLog2e, aw[jt][2] * kLog2e, aw[jt][3] * kLog2e);
+    // hipemu: wave rendezvous (same-wave LDS order; on the GPU the wave's LDS operations execute in program order)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int kx = g * 4 + r;
       const float v = tab[c * W16_LT + min(max(c - kx + S - 1, 0), 31)];
       twr[n][r] = (kx < S && c < S) ? v : -1e30f;
     }
+    // hipemu: wave rendezvous (same-wave LDS order; on the GPU the wave's LDS operations execute in program order)
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
       *reinterpret_cast<float4 *>(tab + c * W16_LT + jt * 16 + g * 4) =
           make_float4(ah[jt][0] * kLog2e, ah[jt][1] * kLog2e, ah[jt][2] * kLog2e, ah[jt][3] * kLog2e);
+    // hipemu: wave rendezvous (same-wave LDS order; on the GPU the wave's LDS operations execute in program order)
 #pragma unroll
     for (int ky = 0; ky < SRC; ++ky) {
       const float v = tab[c * W16_LT + min(max(qy - ky + S - 1, 0), 31)];
       thv[n][ky] = ky < S ? v : -1e30f;
     }
+    // hipemu: wave rendezvous (same-wave LDS order; on the GPU the wave's LDS operations execute in program order)
   }
 }
 

@@ -1,0 +1,306 @@
+// hipemu -- a functional stand-in for <hip/hip_runtime.h> that lets the kernel sources of sam6d_amd/csrc compile for the HOST
+// and run without a GPU (TEST INFRASTRUCTURE: tests/test_emu_*.py; nothing in the product includes this).
+//
+// Execution model: hipLaunchKernelGGL runs the grid one block at a time; the lanes of a block are fibers (ucontext) on one
+// OS thread, scheduled round-robin; __syncthreads and the wave collectives (__shfl*, __ballot, MFMA, ds_read_tr16_b64) are
+// rendezvous points of the block / of a 64-lane wave.  __shared__ variables are function-local statics (one block runs at a
+// time); dynamic shared memory (`extern __shared__ char name[]`) is a global array the build step points the declaration at.
+// MFMA and the transposing LDS read follow the gfx950 lane layouts the kernels were written against (the latter verified
+// with tools/probes/trprobe.hip on the GPU).  Accumulation order inside an emulated MFMA is k-ascending in float32 -- the
+// hardware's internal order is not documented, so parity tests built on this use tolerances, not bit equality, for MFMA
+// results; integer / index / elementwise kernels are bit-faithful.
+#pragma once
+#include <ucontext.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __host__
+#define __device__
+#define __global__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+#define HIPEMU 1
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint4 {
+  unsigned x, y, z, w;
+};
+struct uint2 {
+  unsigned x, y;
+};
+struct float2 {
+  float x, y;
+};
+struct float4 {
+  float x, y, z, w;
+};
+struct int2 {
+  int x, y;
+};
+struct int4 {
+  int x, y, z, w;
+};
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return {x, y, z, w}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return {x, y}; }
+static inline float2 make_float2(float x, float y) { return {x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
+static inline int2 make_int2(int x, int y) { return {x, y}; }
+static inline int4 make_int4(int x, int y, int z, int w) { return {x, y, z, w}; }
+
+typedef void *hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0 };
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char *hipGetErrorString(hipError_t) { return "hipemu: no error"; }
+template <class F>
+static inline hipError_t hipFuncSetAttribute(F, int, int) { return hipSuccess; }
+
+namespace hipemu {
+
+struct Lane {
+  ucontext_t ctx;
+  std::vector<char> stack;
+  dim3 tid;
+  bool done = false;
+};
+
+struct Block {
+  std::vector<Lane> lanes;
+  dim3 bid, bdim, gdim;
+  int alive = 0;
+  // block barrier
+  int arrived = 0;
+  long gen = 0;
+  // per-wave rendezvous: arrival counters, generations, and 64 exchange slots of 64 bytes
+  std::vector<int> w_arrived;
+  std::vector<long> w_gen;
+  std::vector<int> w_alive;
+  std::vector<unsigned char> xchg;  // [wave][64 lanes][64 bytes]
+  ucontext_t sched;
+  int cur = 0;
+  std::function<void()> body;
+};
+
+extern Block *g_blk;
+extern size_t g_dyn_shared_bytes;
+
+inline Lane &self() { return g_blk->lanes[g_blk->cur]; }
+inline int flat_tid() {
+  const Lane &l = self();
+  return (int)(l.tid.x + g_blk->bdim.x * (l.tid.y + g_blk->bdim.y * l.tid.z));
+}
+inline int wave_of() { return flat_tid() >> 6; }
+inline int lane_of() { return flat_tid() & 63; }
+void yield();
+void block_barrier();
+void wave_barrier();
+void run_grid(dim3 grid, dim3 block, size_t shmem, std::function<void()> body);
+inline unsigned char *slot(int lane) { return g_blk->xchg.data() + ((size_t)wave_of() * 64 + lane) * 64; }
+
+// every lane of the wave contributes `mine`; returns after all have, with a stable view of all 64 contributions until the
+// matching end_exchange() (a second rendezvous that frees the slots)
+template <class T>
+inline void begin_exchange(const T &mine) {
+  static_assert(sizeof(T) <= 64, "exchange slot too small");
+  std::memcpy(slot(lane_of()), &mine, sizeof(T));
+  wave_barrier();
+}
+template <class T>
+inline T peek(int lane) {
+  T v;
+  std::memcpy(&v, slot(lane & 63), sizeof(T));
+  return v;
+}
+inline void end_exchange() { wave_barrier(); }
+
+}  // namespace hipemu
+
+#define threadIdx (hipemu::self().tid)
+#define blockIdx (hipemu::g_blk->bid)
+#define blockDim (hipemu::g_blk->bdim)
+#define gridDim (hipemu::g_blk->gdim)
+#define warpSize 64
+
+static inline void __syncthreads() { hipemu::block_barrier(); }
+static inline void __threadfence() {}
+static inline void __threadfence_block() {}
+// on the GPU a wave runs in lockstep and this is only a scheduling fence; here the lanes are independent fibers, so LDS
+// traffic between lanes of one wave that is ordered by it needs a real rendezvous
+static inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_barrier(); }
+static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline void __builtin_amdgcn_s_barrier() { hipemu::block_barrier(); }
+
+template <class T>
+static inline T __shfl_xor(T v, int mask, int width = 64) {
+  hipemu::begin_exchange(v);
+  const int me = hipemu::lane_of();
+  const int src = ((me ^ mask) & (width - 1)) | (me & ~(width - 1));
+  T r = hipemu::peek<T>(src);
+  hipemu::end_exchange();
+  return r;
+}
+template <class T>
+static inline T __shfl(T v, int src_lane, int width = 64) {
+  hipemu::begin_exchange(v);
+  const int me = hipemu::lane_of();
+  T r = hipemu::peek<T>((src_lane & (width - 1)) | (me & ~(width - 1)));
+  hipemu::end_exchange();
+  return r;
+}
+template <class T>
+static inline T __shfl_down(T v, unsigned delta, int width = 64) {
+  hipemu::begin_exchange(v);
+  const int me = hipemu::lane_of();
+  const int src = ((me & (width - 1)) + (int)delta < width) ? me + (int)delta : me;
+  T r = hipemu::peek<T>(src);
+  hipemu::end_exchange();
+  return r;
+}
+static inline unsigned long long __ballot(int pred) {
+  hipemu::begin_exchange<int>(pred != 0);
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; ++l)
+    if (l < hipemu::g_blk->w_alive[hipemu::wave_of()] && hipemu::peek<int>(l)) m |= 1ull << l;
+  hipemu::end_exchange();
+  return m;
+}
+static inline int __any(int pred) { return __ballot(pred) != 0; }
+static inline int __all(int pred) { return __ballot(!pred) == 0; }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+static inline int __ffs(unsigned v) { return __builtin_ffs((int)v); }
+static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+static inline unsigned __brev(unsigned v) {
+  unsigned r = 0;
+  for (int i = 0; i < 32; ++i) r |= ((v >> i) & 1u) << (31 - i);
+  return r;
+}
+
+// lanes are fibers of ONE OS thread and only switch at rendezvous points: plain read-modify-write is atomic here
+template <class T>
+static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
+template <class T>
+static inline T atomicMax(T *p, T v) { T o = *p; *p = o > v ? o : v; return o; }
+template <class T>
+static inline T atomicMin(T *p, T v) { T o = *p; *p = o < v ? o : v; return o; }
+template <class T>
+static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
+template <class T>
+static inline T atomicExch(T *p, T v) { T o = *p; *p = v; return o; }
+template <class T>
+static inline T atomicCAS(T *p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
+
+#define __expf(x) expf(x)   // glibc declares __expf / __logf itself
+#define __logf(x) logf(x)
+static inline float __fdividef(float a, float b) { return a / b; }
+static inline float __frcp_rn(float a) { return 1.0f / a; }
+static inline float __fsqrt_rn(float a) { return sqrtf(a); }
+static inline float __frsqrt_rn(float a) { return 1.0f / sqrtf(a); }
+static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
+static inline float __saturatef(float a) { return a < 0.f ? 0.f : (a > 1.f ? 1.f : a); }
+static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
+static inline float __builtin_amdgcn_sinf(float x) { return (float)sin(6.283185307179586476925 * (double)x); }   // input in revolutions
+static inline float __builtin_amdgcn_cosf(float x) { return (float)cos(6.283185307179586476925 * (double)x); }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+static inline float __builtin_amdgcn_rsqf(float x) { return 1.0f / sqrtf(x); }
+static inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
+static inline int __float_as_int(float f) { int u; std::memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
+static inline float __int_as_float(int u) { float f; std::memcpy(&f, &u, 4); return f; }
+static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
+static inline float __fmul_rn(float a, float b) { return a * b; }
+static inline float __fadd_rn(float a, float b) { return a + b; }
+static inline float __fsub_rn(float a, float b) { return a - b; }
+using std::max;
+using std::min;
+
+// ---- matrix cores ---------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 hipemu_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float hipemu_f32x4;
+typedef __attribute__((ext_vector_type(4))) short hipemu_s16x4;
+
+static inline float hipemu_bf2f(__bf16 b) {
+  unsigned short u;
+  std::memcpy(&u, &b, 2);
+  return __uint_as_float(((unsigned)u) << 16);
+}
+
+// v_mfma_f32_16x16x32_bf16: A lane l = row l%16, k (l/16)*8..+7; B lane l = column l%16, same k; C/D lane l = column l%16,
+// rows (l/16)*4 + i
+template <class VA, class VC>
+static inline VC hipemu_mfma_16x16x32_bf16(VA a, VA b, VC c) {
+  struct AB {
+    hipemu_bf16x8 a, b;
+  } mine;
+  std::memcpy(&mine.a, &a, 16);
+  std::memcpy(&mine.b, &b, 16);
+  hipemu::begin_exchange(mine);
+  const int l = hipemu::lane_of(), col = l & 15, rb = (l >> 4) * 4;
+  VC d = c;
+  for (int i = 0; i < 4; ++i) {
+    float acc = c[i];
+    for (int k = 0; k < 32; ++k) {
+      const AB ra = hipemu::peek<AB>((rb + i) + 16 * (k >> 3)), rbv = hipemu::peek<AB>(col + 16 * (k >> 3));
+      acc += hipemu_bf2f(ra.a[k & 7]) * hipemu_bf2f(rbv.b[k & 7]);
+    }
+    d[i] = acc;
+  }
+  hipemu::end_exchange();
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) hipemu_mfma_16x16x32_bf16(a, b, c)
+
+// v_mfma_f32_16x16x4_f32: A lane l = row l%16, k = l/16; B lane l = column l%16, k = l/16; C/D as above
+template <class VC>
+static inline VC hipemu_mfma_16x16x4_f32(float a, float b, VC c) {
+  struct AB {
+    float a, b;
+  } mine{a, b};
+  hipemu::begin_exchange(mine);
+  const int l = hipemu::lane_of(), col = l & 15, rb = (l >> 4) * 4;
+  VC d = c;
+  for (int i = 0; i < 4; ++i) {
+    float acc = c[i];
+    for (int k = 0; k < 4; ++k) acc = fmaf(hipemu::peek<AB>((rb + i) + 16 * k).a, hipemu::peek<AB>(col + 16 * k).b, acc);
+    d[i] = acc;
+  }
+  hipemu::end_exchange();
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu_mfma_16x16x4_f32(a, b, c)
+
+// ds_read_b64_tr_b16: every lane points at 4 consecutive 16-bit elements; inside each 16-lane group, result lane i, element j
+// = element (i & 3) of what lane (4 j + (i >> 2)) pointed at  (tools/probes/trprobe.hip, gpurun_out/trprobe.txt)
+template <class P>
+static inline hipemu_s16x4 hipemu_ds_read_tr16_b64(P p) {
+  hipemu_s16x4 mine;
+  std::memcpy(&mine, (const void *)p, 8);
+  hipemu::begin_exchange(mine);
+  const int l = hipemu::lane_of(), g = l & ~15, i = l & 15;
+  hipemu_s16x4 r;
+  for (int j = 0; j < 4; ++j) r[j] = hipemu::peek<hipemu_s16x4>(g + 4 * j + (i >> 2))[i & 3];
+  hipemu::end_exchange();
+  return r;
+}
+#define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) hipemu_ds_read_tr16_b64(p)
+
+// ---- launch -------------------------------------------------------------------------------------------------------------
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                       \
+  do {                                                                                    \
+    (void)(stream);                                                                       \
+    hipemu::run_grid(dim3(grid), dim3(block), (size_t)(shmem), [=]() { kernel(__VA_ARGS__); }); \
+  } while (0)

@@ -354,6 +354,7 @@ __global__ __launch_bounds__(kT2IWaves * 64) void tok2img_kernel(const float *__
   if (n0 < n1) fetch(n0);
   for (int nt = n0; nt < n1; nt += kT2ITile) {
     commit();
+    // hipemu: wave rendezvous (the wave's own LDS tile: its stores and loads execute in program order on the GPU)
     if (nt + kT2ITile < n1) fetch(nt + kT2ITile);
     const int cnt = min(kT2ITile, n1 - nt);
     for (int k = 0; k < cnt; ++k) {
@@ -377,6 +378,7 @@ __global__ __launch_bounds__(kT2IWaves * 64) void tok2img_kernel(const float *__
       for (int d = 0; d < 16; ++d) acc[d] = acc[d] * alpha + p * sd_bf2f(vv.hh[d]);
       m = mn;
     }
+    // hipemu: wave rendezvous (the wave's own LDS tile: its stores and loads execute in program order on the GPU)
   }
   part[wave][lane][0] = m;
   part[wave][lane][1] = l;

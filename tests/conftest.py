@@ -33,17 +33,10 @@ def emu(monkeypatch):
     from tests import hipemu
     monkeypatch.setattr(_lib, "_lib", ctypes.CDLL(hipemu.build()))
     monkeypatch.setattr(ops, "_FUSED", {})
-    real_chk = ops._chk
-
-    class _AsCuda:                                                   # a tensor view whose is_cuda is True for _chk only
-        def __init__(self, t):
-            self.t = t
-
-        def __getattr__(self, k):
-            return True if k == "is_cuda" else getattr(self.t, k)
-
-    monkeypatch.setattr(ops, "_chk", lambda t, dtype, name, ndim=None: real_chk(_AsCuda(t), dtype, name, ndim))
     monkeypatch.setattr(ops, "_stream", lambda: ctypes.c_void_p(0))
+    # product modules pick their fused kernels with `x.is_cuda and ops.have(...)`: host tensors claim to be device tensors
+    # while the fixture is active, so the same dispatch reaches the emulated kernels
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))
     monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
     monkeypatch.setattr(torch.nn.Module, "cuda", lambda self, *a, **k: self)
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)

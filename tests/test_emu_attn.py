@@ -13,3 +13,38 @@ def test_fused_attention_on_the_emulator(emu, B, H, nh, hd, ws):
 @pytest.mark.parametrize("rows,C", [(37, 160), (5, 768)])
 def test_add_layernorm_on_the_emulator(emu, rows, C):
     T.test_add_layernorm_bf16(rows, C)
+
+
+@pytest.mark.parametrize("B,N,nh,hd", [(2, 50, 2, 80), (1, 70, 1, 64)])
+def test_seq_attention_on_the_emulator(emu, B, N, nh, hd):
+    T.test_seq_attention_vs_torch(B, N, nh, hd)
+
+
+def test_segment_seq_sum_and_centroid_path_on_the_emulator(emu, monkeypatch):
+    """s6d_segment_seq_sum_f32 through the C ABI (emulated launch) == numpy's row-order reduction, and the opt-in centroid path
+    of the PEM pre-processing (S6D_PEM_SEQ_CENTROID=1 -> ops.segment_seq_sum) == the oracle loop at boundary-cutting radii."""
+    import numpy as np
+    import torch
+
+    from oracle import pem_pre as opre
+    from sam6d_amd.pem import preprocess as pre
+    from sam6d_amd.utils import synth
+    g = torch.Generator().manual_seed(0)
+    counts = torch.tensor([0, 1, 5, 511, 512, 513, 3000])
+    x = torch.randn(int(counts.sum()), 3, generator=g) * 0.3 + 0.8
+    start = torch.cumsum(counts, 0) - counts
+    got = emu.segment_seq_sum(x, start, counts).numpy()
+    for i, (s0, c) in enumerate(zip(start.tolist(), counts.tolist())):
+        want = np.add.reduce(x[s0:s0 + c].numpy(), axis=0) if c else np.zeros(3, np.float32)
+        np.testing.assert_array_equal(got[i], want)
+    monkeypatch.setenv("S6D_PEM_SEQ_CENTROID", "1")
+    inp = synth.pem_pre_inputs(P=8, seed=3)
+    kw = dict(n_sample=512, img_size=224, min_points=32, min_inliers=4, radius_factor=1.2)
+    radius = np.array([0.12, 0.03, 0.5, 0.12, 0.06, 0.2, 0.07, 0.01])
+    ref = opre.preprocess_frame(inp["image"], inp["depth"].numpy(), inp["K"].numpy(), inp["masks"].numpy(), radius,
+                                keys=inp["keys"].numpy(), **kw)
+    out = pre.observed_inputs(torch.from_numpy(inp["image"]), inp["depth"], inp["K"], inp["masks"], torch.from_numpy(radius),
+                              keys=inp["keys"], **kw)
+    assert out["kept"].tolist() == ref["kept"].tolist()
+    np.testing.assert_array_equal(out["pts"].numpy(), ref["pts"])
+    np.testing.assert_array_equal(out["rgb_choose"].numpy(), ref["rgb_choose"])

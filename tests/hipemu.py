@@ -48,7 +48,7 @@ def build(force=False, files=None):
     dyn = os.path.join(OUT, "_dyn_shared.cc")
     with open(dyn, "w") as g:
         g.write("namespace s6d {\n" + "".join(f"alignas(64) char {n}[160 * 1024];\n" for n in DYN_NAMES) + "}\n")
-    cmd = [CXX, "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-w", "-ffp-contract=off", "-I", EMU, "-I", CSRC, "-I",
+    cmd = [CXX, "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-ffp-contract=off", "-I", EMU, "-I", CSRC, "-I",
            os.path.join(REPO, "include"), "-o", SO, os.path.join(EMU, "hipemu.cc"), dyn] + srcs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode:

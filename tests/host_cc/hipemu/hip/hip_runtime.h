@@ -1,7 +1,7 @@
 // hipemu -- a functional stand-in for <hip/hip_runtime.h> that lets the kernel sources of sam6d_amd/csrc compile for the HOST
 // and run without a GPU (TEST INFRASTRUCTURE: tests/test_emu_*.py; nothing in the product includes this).
 //
-// Execution model: hipLaunchKernelGGL runs the grid one block at a time; the lanes of a block are fibers (ucontext) on one
+// Execution model: hipLaunchKernelGGL runs the grid one block at a time; the lanes of a block are fibers (hand-rolled stack switch) on one
 // OS thread, scheduled round-robin; __syncthreads and the wave collectives (__shfl*, __ballot, MFMA, ds_read_tr16_b64) are
 // rendezvous points of the block / of a 64-lane wave.  __shared__ variables are function-local statics (one block runs at a
 // time); dynamic shared memory (`extern __shared__ char name[]`) is a global array the build step points the declaration at.
@@ -10,8 +10,6 @@
 // hardware's internal order is not documented, so parity tests built on this use tolerances, not bit equality, for MFMA
 // results; integer / index / elementwise kernels are bit-faithful.
 #pragma once
-#include <ucontext.h>
-
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -70,7 +68,7 @@ static inline hipError_t hipFuncSetAttribute(F, int, int) { return hipSuccess; }
 namespace hipemu {
 
 struct Lane {
-  ucontext_t ctx;
+  void *sp = nullptr;                       // saved stack pointer while the lane is switched out
   std::vector<char> stack;
   dim3 tid;
   bool done = false;
@@ -88,7 +86,6 @@ struct Block {
   std::vector<long> w_gen;
   std::vector<int> w_alive;
   std::vector<unsigned char> xchg;  // [wave][64 lanes][64 bytes]
-  ucontext_t sched;
   int cur = 0;
   std::function<void()> body;
 };

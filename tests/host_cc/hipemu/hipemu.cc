@@ -12,7 +12,24 @@ static const size_t kStack = 256 * 1024;
   std::abort();
 }
 
-void yield() { swapcontext(&self().ctx, &g_blk->sched); }
+// Fiber switch without system calls (swapcontext saves / restores the signal mask with two syscalls per switch, which
+// dominated the run time): the callee-saved registers go on the old stack, the stack pointers are exchanged.  x86-64 SysV.
+extern "C" void hipemu_switch(void **save_sp, void *load_sp);
+__asm__(
+    ".text\n"
+    ".globl hipemu_switch\n"
+    ".type hipemu_switch,@function\n"
+    "hipemu_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n"
+    "  movq %rsi, %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n"
+    "  ret\n"
+    ".size hipemu_switch, .-hipemu_switch\n");
+
+static void *g_sched_sp = nullptr;
+
+void yield() { hipemu_switch(&self().sp, g_sched_sp); }
 
 // A rendezvous completes when every lane that is still alive has arrived.  Lanes that returned from the kernel no longer
 // count (their exit re-evaluates pending rendezvous in the scheduler).
@@ -52,7 +69,8 @@ static void trampoline() {
   me.done = true;
   --b.alive;
   --b.w_alive[flat_tid() >> 6];
-  swapcontext(&me.ctx, &b.sched);
+  hipemu_switch(&me.sp, g_sched_sp);
+  die("a finished lane was resumed");
 }
 
 static void run_block(Block &b) {
@@ -72,11 +90,14 @@ static void run_block(Block &b) {
     if (l.stack.size() != kStack) l.stack.resize(kStack);
     l.done = false;
     l.tid = dim3(t % b.bdim.x, (t / b.bdim.x) % b.bdim.y, t / (b.bdim.x * b.bdim.y));
-    getcontext(&l.ctx);
-    l.ctx.uc_stack.ss_sp = l.stack.data();
-    l.ctx.uc_stack.ss_size = l.stack.size();
-    l.ctx.uc_link = nullptr;
-    makecontext(&l.ctx, (void (*)())trampoline, 0);
+    // initial frame: six zeroed callee-saved registers, then the trampoline as the address `ret` jumps to; after that `ret`
+    // the stack pointer is 8 below a 16-byte boundary, as at any function entry
+    uintptr_t top = ((uintptr_t)l.stack.data() + l.stack.size()) & ~(uintptr_t)15;
+    void **sp = (void **)top;
+    *--sp = nullptr;                       // return address slot of the trampoline (it never returns)
+    *--sp = (void *)trampoline;
+    for (int r = 0; r < 6; ++r) *--sp = nullptr;
+    l.sp = (void *)sp;
   }
   // round-robin until every lane has returned; a full pass in which nobody makes progress cannot be detected cheaply, so a
   // generous pass limit guards against a rendezvous that can never complete (e.g. a collective inside divergent control flow)
@@ -85,7 +106,7 @@ static void run_block(Block &b) {
     for (int t = 0; t < n; ++t) {
       if (b.lanes[t].done) continue;
       b.cur = t;
-      swapcontext(&b.sched, &b.lanes[t].ctx);
+      hipemu_switch(&g_sched_sp, b.lanes[t].sp);
       // a lane that just finished may complete a rendezvous the others are waiting in: they re-check when resumed
     }
     if (++passes > 200000000L) die("a block made no progress (collective in divergent code, or a missing barrier partner)");

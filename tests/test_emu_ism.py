@@ -1,10 +1,6 @@
 """ISM scoring kernels executed on the HOST through the emulated HIP runtime: the per-kernel body of tests/test_gpu_ism.py
 (cosine GEMM, top-k selection, split-bf16 MFMA patch scores on non-tile-aligned sizes) and the whole frame-scoring chain
 against the reference golden."""
-import os
-
-import pytest
-
 from tests import test_gpu_ism as T
 
 
@@ -12,6 +8,5 @@ def test_ism_kernels_on_the_emulator(emu):
     T.test_ism_kernels_individually_vs_oracle()
 
 
-@pytest.mark.skipif(os.environ.get("S6D_EMU_SLOW") != "1", reason="~90 s on the emulator: set S6D_EMU_SLOW=1")
 def test_frame_scoring_chain_on_the_emulator(emu):
     T.test_frame_scoring_vs_reference_golden()

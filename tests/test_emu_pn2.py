@@ -22,3 +22,11 @@ def test_ball_query_on_the_emulator(emu, B, N, M, r, ns):
 def test_gathers_on_the_emulator(emu):
     T.test_ball_query_no_neighbour_gives_zeros(emu)
     T.test_gather_group_exact(emu)
+
+
+def test_edge_cases_on_the_emulator(emu):
+    """Bodies of tests/test_gpu_edge_cases.py: M == N permutation, single point, nsample larger than the cloud with coincident
+    points (first-hit fill)."""
+    from tests import test_gpu_edge_cases as E
+    E.test_fps_all_points_and_single_point(emu)
+    E.test_ball_query_nsample_larger_than_cloud_and_coincident_points(emu)

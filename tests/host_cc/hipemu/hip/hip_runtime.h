@@ -108,11 +108,18 @@ inline unsigned char *slot(int lane) { return g_blk->xchg.data() + ((size_t)wave
 
 // every lane of the wave contributes `mine`; returns after all have, with a stable view of all 64 contributions until the
 // matching end_exchange() (a second rendezvous that frees the slots)
+// `kind` names the collective (1 shuffle, 2 ballot, 3 MFMA bf16, 4 MFMA f32, 5 transposing LDS read): if the lanes of a wave
+// meet in DIFFERENT collectives -- a collective inside divergent control flow, which on the GPU is undefined or silently wrong
+// -- the run is aborted instead of exchanging unrelated operands.
+void check_same_kind(int kind);
 template <class T>
-inline void begin_exchange(const T &mine) {
-  static_assert(sizeof(T) <= 64, "exchange slot too small");
-  std::memcpy(slot(lane_of()), &mine, sizeof(T));
+inline void begin_exchange(const T &mine, int kind) {
+  static_assert(sizeof(T) <= 60, "exchange slot too small");
+  unsigned char *s = slot(lane_of());
+  std::memcpy(s, &mine, sizeof(T));
+  std::memcpy(s + 60, &kind, 4);
   wave_barrier();
+  if ((s - g_blk->xchg.data()) % (64 * 64) == 0) check_same_kind(kind);   // lane 0 of the wave checks once per collective
 }
 template <class T>
 inline T peek(int lane) {
@@ -141,7 +148,7 @@ static inline void __builtin_amdgcn_s_barrier() { hipemu::block_barrier(); }
 
 template <class T>
 static inline T __shfl_xor(T v, int mask, int width = 64) {
-  hipemu::begin_exchange(v);
+  hipemu::begin_exchange(v, 1);
   const int me = hipemu::lane_of();
   const int src = ((me ^ mask) & (width - 1)) | (me & ~(width - 1));
   T r = hipemu::peek<T>(src);
@@ -150,7 +157,7 @@ static inline T __shfl_xor(T v, int mask, int width = 64) {
 }
 template <class T>
 static inline T __shfl(T v, int src_lane, int width = 64) {
-  hipemu::begin_exchange(v);
+  hipemu::begin_exchange(v, 1);
   const int me = hipemu::lane_of();
   T r = hipemu::peek<T>((src_lane & (width - 1)) | (me & ~(width - 1)));
   hipemu::end_exchange();
@@ -158,7 +165,7 @@ static inline T __shfl(T v, int src_lane, int width = 64) {
 }
 template <class T>
 static inline T __shfl_down(T v, unsigned delta, int width = 64) {
-  hipemu::begin_exchange(v);
+  hipemu::begin_exchange(v, 1);
   const int me = hipemu::lane_of();
   const int src = ((me & (width - 1)) + (int)delta < width) ? me + (int)delta : me;
   T r = hipemu::peek<T>(src);
@@ -166,7 +173,7 @@ static inline T __shfl_down(T v, unsigned delta, int width = 64) {
   return r;
 }
 static inline unsigned long long __ballot(int pred) {
-  hipemu::begin_exchange<int>(pred != 0);
+  hipemu::begin_exchange<int>(pred != 0, 2);
   unsigned long long m = 0;
   for (int l = 0; l < 64; ++l)
     if (l < hipemu::g_blk->w_alive[hipemu::wave_of()] && hipemu::peek<int>(l)) m |= 1ull << l;
@@ -245,7 +252,7 @@ static inline VC hipemu_mfma_16x16x32_bf16(VA a, VA b, VC c) {
   } mine;
   std::memcpy(&mine.a, &a, 16);
   std::memcpy(&mine.b, &b, 16);
-  hipemu::begin_exchange(mine);
+  hipemu::begin_exchange(mine, 3);
   const int l = hipemu::lane_of(), col = l & 15, rb = (l >> 4) * 4;
   VC d = c;
   for (int i = 0; i < 4; ++i) {
@@ -267,7 +274,7 @@ static inline VC hipemu_mfma_16x16x4_f32(float a, float b, VC c) {
   struct AB {
     float a, b;
   } mine{a, b};
-  hipemu::begin_exchange(mine);
+  hipemu::begin_exchange(mine, 4);
   const int l = hipemu::lane_of(), col = l & 15, rb = (l >> 4) * 4;
   VC d = c;
   for (int i = 0; i < 4; ++i) {
@@ -286,7 +293,7 @@ template <class P>
 static inline hipemu_s16x4 hipemu_ds_read_tr16_b64(P p) {
   hipemu_s16x4 mine;
   std::memcpy(&mine, (const void *)p, 8);
-  hipemu::begin_exchange(mine);
+  hipemu::begin_exchange(mine, 5);
   const int l = hipemu::lane_of(), g = l & ~15, i = l & 15;
   hipemu_s16x4 r;
   for (int j = 0; j < 4; ++j) r[j] = hipemu::peek<hipemu_s16x4>(g + 4 * j + (i >> 2))[i & 3];

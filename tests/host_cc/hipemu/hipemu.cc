@@ -62,6 +62,17 @@ void wave_barrier() {
   }
 }
 
+void check_same_kind(int kind) {
+  Block &b = *g_blk;
+  const int w = wave_of(), base = w * 64, n = (int)std::min<size_t>(64, b.lanes.size() - base);
+  for (int l = 0; l < n; ++l) {
+    if (b.lanes[base + l].done) continue;
+    int k;
+    std::memcpy(&k, b.xchg.data() + ((size_t)w * 64 + l) * 64 + 60, 4);
+    if (k != kind) die("lanes of one wave met in different collectives (a collective inside divergent control flow?)");
+  }
+}
+
 static void trampoline() {
   Block &b = *g_blk;
   b.body();

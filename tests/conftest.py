@@ -31,7 +31,11 @@ def emu(monkeypatch):
 
     from sam6d_amd import _lib, ops
     from tests import hipemu
-    monkeypatch.setattr(_lib, "_lib", ctypes.CDLL(hipemu.build()))
+    L = ctypes.CDLL(hipemu.build())
+    L.s6d_strerror.restype = ctypes.c_char_p                         # as sam6d_amd._lib.lib() sets them on the real library
+    L.s6d_strerror.argtypes = [ctypes.c_int]
+    L.s6d_last_hip_error.restype = ctypes.c_char_p
+    monkeypatch.setattr(_lib, "_lib", L)
     monkeypatch.setattr(ops, "_FUSED", {})
     monkeypatch.setattr(ops, "_stream", lambda: ctypes.c_void_p(0))
     # product modules pick their fused kernels with `x.is_cuda and ops.have(...)`: host tensors claim to be device tensors

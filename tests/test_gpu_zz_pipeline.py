@@ -13,13 +13,17 @@ pytestmark = pytest.mark.gpu
 
 
 def test_frame_through_all_five_models():
+    run_frame(torch.device("cuda", 0))
+
+
+def run_frame(dev):
+    """The body, parametrised by the device so that tests/test_emu_pipeline.py can run it on the emulator."""
     from sam6d_amd import pipeline
     from sam6d_amd.ism import dinov2 as pd
     from sam6d_amd.ism.scoring import FrameScorer
     from sam6d_amd.pem import pose_estimation_model as pm
     from sam6d_amd.sam import mask_decoder as md
     from sam6d_amd.sam.image_encoder import ImageEncoderViT
-    dev = torch.device("cuda", 0)
     c = osam.MINI                                                   # 512 px, 32 x 32 x 64 embedding
     enc = seeded.load_seeded(ImageEncoderViT(
         depth=c["depth"], embed_dim=c["dim"], img_size=c["img_size"], mlp_ratio=4, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6),

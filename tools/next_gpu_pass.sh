@@ -17,3 +17,21 @@ S6D_SAM_MLP_ROWS=16384 timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu
 S6D_SAM_MLP_ROWS=32768 timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/n7_bench_mlp32768.json 2> gpurun_out/n7.err
 for f in gpurun_out/n[1-4]*.txt; do echo "== $f"; cat $f | tail -6; done
 for f in gpurun_out/n[5-7]*.json; do echo "== $f"; python -c "import json,sys; d=json.loads(open('$f').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d.get('stages_ms'))"; done
+# 4. where do the attention kernels' wave cycles go?  (SQ counters, 8 slots per pass; counter runs carry --kernel-trace only)
+mkdir -p gpurun_out/sq
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT \
+  --kernel-trace --output-format csv -d /tmp/pmc_sq1 -o sq1 -- python tools/pmc_attn.py > gpurun_out/sq/pass1.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_WAVES \
+  --kernel-trace --output-format csv -d /tmp/pmc_sq2 -o sq2 -- python tools/pmc_attn.py > gpurun_out/sq/pass2.log 2>&1
+for d in /tmp/pmc_sq1 /tmp/pmc_sq2; do find $d -name "*counter_collection.csv" -exec cp {} gpurun_out/sq/$(basename $d).csv \; ; done
+python - <<'PY'
+import csv, glob, collections
+for f in sorted(glob.glob("gpurun_out/sq/*.csv")):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+    for r in csv.DictReader(open(f)):
+        k = r.get("Kernel_Name", "")[:48]
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
+    print("==", f)
+    for k, d in acc.items():
+        print(k, {c: round(v / max(n[(k, c)], 1)) for c, v in d.items()})
+PY

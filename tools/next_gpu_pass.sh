@@ -11,6 +11,7 @@ timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > gpurun_out/n3_
 # 2. the segmentor plugin end to end (ViT-H, seeded weights) and the five-model frame chain
 timeout 600 python tools/segmentor_demo.py > gpurun_out/n4_segmentor_demo.txt 2>&1
 timeout 600 python tools/frame_demo.py > gpurun_out/n4_frame_demo.txt 2>&1
+timeout 300 python tools/pem_pre_time.py 64 > gpurun_out/n4_pem_pre_stages.txt 2>&1
 # 3. bench A/B: default vs Infinity-Cache-sized MLP row chunks
 timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/n5_bench_default.json 2> gpurun_out/n5.err
 S6D_SAM_MLP_ROWS=16384 timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/n6_bench_mlp16384.json 2> gpurun_out/n6.err

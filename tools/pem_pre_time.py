@@ -12,7 +12,7 @@ from sam6d_amd.utils import synth  # noqa: E402
 
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 inp = synth.pem_pre_inputs(P=P, seed=9)
-dev = torch.device("cuda", 0)
+dev = torch.device("cuda", 0) if torch.cuda.is_available() else torch.device("cpu")   # cpu: dry run of the script only
 image, depth, K, masks, keys = (torch.from_numpy(inp["image"]).to(dev), inp["depth"].to(dev), inp["K"], inp["masks"].to(dev),
                                 inp["keys"].to(dev))
 radius, n_sample, img_size = 0.15, 2048, 224
@@ -20,7 +20,8 @@ marks = []
 
 
 def tick(name):
-    torch.cuda.synchronize()
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
     marks.append((name, time.perf_counter()))
 
 

@@ -75,6 +75,15 @@ int s6d_gather_rows_f32(const float *src, const int32_t *idx, int B, int N, int 
 int s6d_segment_seq_sum_f32(const float *x, const int64_t *start, const int64_t *count, int P, int C, float *out,
                             void *stream);
 
+/* Point sampler of the PEM pre-processing in its defined form (sam6d_amd/pem/preprocess.py header; reference draws:
+ * Pose_Estimation_Model/run_inference_custom.py:224-229, provider/bop_test_dataset.py:140-145).
+ * keys (P, key_stride) f32 non-negative uniforms, count (P) i64 candidate points per detection (count <= key_stride),
+ * 1 <= n_sample <= 2048 <= key_stride -> idx (P, n_sample) i64: count <= n_sample: floor(key_i * count) (with
+ * replacement); else positions of the n_sample smallest (key, position) pairs in ascending order.  overflow (P) i32 is
+ * set to 1 for a detection whose keys are too duplicated for the in-LDS selection (its idx row is then not written). */
+int s6d_pem_sample_indices_f32(const float *keys, long key_stride, const int64_t *count, int P, int n_sample,
+                               int64_t *idx, int32_t *overflow, void *stream);
+
 /* ---------------------------------------------------------------- PEM pose solvers
  * Replace the library-op chains of Pose_Estimation_Model/utils/model_utils.py. */
 

@@ -296,6 +296,21 @@ def segment_seq_sum(x, start, count):
     return out
 
 
+def pem_sample_indices(keys, count, n_sample):
+    """Sampler of the PEM pre-processing (one workgroup per detection: histogram threshold + in-LDS sort).  keys (P,L) f32
+    uniforms in [0,1), count (P,) int64 (<= L) -> (idx (P,n_sample) int64, overflow (P,) int32)."""
+    _chk(keys, torch.float32, "keys", 2)
+    _chk(count, torch.int64, "count", 1)
+    P, L = keys.shape
+    if count.shape[0] != P:
+        raise RuntimeError("pem_sample_indices: one count per row of keys")
+    idx = torch.zeros(P, n_sample, dtype=torch.int64, device=keys.device)
+    overflow = torch.zeros(P, dtype=torch.int32, device=keys.device)
+    _call("s6d_pem_sample_indices_f32", _ptr(keys), ctypes.c_long(L), _ptr(count), P, int(n_sample), _ptr(idx), _ptr(overflow),
+          _stream())
+    return idx, overflow
+
+
 def upsample_gather(up, choose, H, W, C):
     """up (B,196,16*C) f32, choose (B,n) int64 -> (B,n,C): bilinear x4 of the pixel-shuffled map at chosen pixels."""
     _chk(up, torch.float32, "up", 3)

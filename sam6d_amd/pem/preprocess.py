@@ -153,6 +153,13 @@ def observed_inputs(image_u8, depth, K, masks, radius, keys=None, n_sample=2048,
 def _keyed_indices(n, keys, n_sample):
     """The defined sampler: (P,n_sample) in-list positions from one uniform per crop pixel."""
     dev = n.device
+    if os.environ.get("S6D_PEM_SAMPLER") == "kernel" and keys.dtype == torch.float32 and keys.is_contiguous() and n_sample <= 2048:
+        # one workgroup per detection (s6d_pem_sample_indices_f32) instead of a top-k over a (P, L) table of 64-bit keys; no host
+        # round trip for L.  Opt-in until it has been through the device parity test (DESIGN.md section 4b).
+        from .. import ops
+        idx, overflow = ops.pem_sample_indices(keys, n.contiguous(), n_sample)
+        if not bool(overflow.any()):                                # heavily duplicated keys: the library path below
+            return idx
     L = int(n.max().item()) if n.numel() else 0                                        # host round trip #2
     L = max(L, n_sample)
     kk = keys[:, :L].float()

@@ -72,3 +72,19 @@ def test_sequential_centroid_matches_numpy_row_order():
     np.testing.assert_array_equal(out["pts"].cpu().numpy(), ref["pts"])
     np.testing.assert_array_equal(out["rgb_choose"].cpu().numpy(), ref["rgb_choose"])
 
+
+@pytest.mark.skipif(os.environ.get("S6D_PEM_SAMPLER") != "kernel", reason="opt-in path: set S6D_PEM_SAMPLER=kernel")
+def test_sampler_kernel_equals_the_library_path_on_the_device(monkeypatch):
+    """s6d_pem_sample_indices_f32 against the composite-key top-k it replaces, at frame sizes (480 x 640 keys per detection)."""
+    from sam6d_amd import ops
+    from sam6d_amd.pem import preprocess as pre
+    g = torch.Generator().manual_seed(0)
+    L, ns = 480 * 640, 2048
+    n = torch.tensor([0, 1, 100, 2048, 2049, 3000, 10000, 100000, 307200, 5000])
+    keys = torch.rand(len(n), L, generator=g)
+    keys[5] = (keys[5] * 3000).floor() / 3000                       # ties: the position decides
+    monkeypatch.delenv("S6D_PEM_SAMPLER")
+    want = pre._keyed_indices(n.cuda(), keys.cuda(), ns)
+    idx, overflow = ops.pem_sample_indices(keys.cuda(), n.cuda(), ns)
+    assert overflow.cpu().tolist() == [0] * len(n) and torch.equal(idx, want)
+

@@ -84,6 +84,18 @@ int s6d_segment_seq_sum_f32(const float *x, const int64_t *start, const int64_t 
 int s6d_pem_sample_indices_f32(const float *keys, long key_stride, const int64_t *count, int P, int n_sample,
                                int64_t *idx, int32_t *overflow, void *stream);
 
+/* Masked crop pixels of every detection, in row-major crop order, with their back-projected points
+ * (run_inference_custom.py:209-213, utils/data_utils.py:92-110).  m (P,H,W) u8 = mask AND depth > 0, depth (H,W) f32,
+ * box (P,4) i64 [y1,y2,x1,x2], ok (P) u8 (0: detection skipped, n = 0) -> choose (P,cap) i32 crop-flat indices,
+ * cloud (P,cap,3) f32, n (P) i64; cap >= the largest crop area (min(H,W)^2 always suffices). */
+int s6d_pem_compact_cloud_f32(const unsigned char *m, const float *depth, const int64_t *box, const unsigned char *ok, int P,
+                              int H, int W, float fx, float fy, float cx, float cy, long cap, int32_t *choose, float *cloud,
+                              int64_t *n, void *stream);
+/* In place: keep, in order, the points with (double)|cloud - center[p]| < limit[p] (run_inference_custom.py:214-221).
+ * center (P,3) f32, limit (P) f64, choose / cloud / n as above (n is updated). */
+int s6d_pem_radius_filter_f32(const float *center, const double *limit, int P, long cap, int32_t *choose, float *cloud,
+                              int64_t *n, void *stream);
+
 /* ---------------------------------------------------------------- PEM pose solvers
  * Replace the library-op chains of Pose_Estimation_Model/utils/model_utils.py. */
 

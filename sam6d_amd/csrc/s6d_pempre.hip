@@ -14,9 +14,120 @@
 //                    bit patterns then order like their values); if more than 4096 keys share the leading bits up to the
 //                    threshold bin (heavily duplicated keys, never uniform ones) the detection is flagged in `overflow` and the
 //                    caller uses the library path for it.
+//   compact_cloud    "mask -> choose -> cloud" of get_test_data (:209-213): the masked pixels of a detection's square crop in
+//                    row-major crop order (``mask[y1:y2, x1:x2].flatten().nonzero()``) with their back-projected points
+//                    (utils/data_utils.py:92-110: x = (u - cx) z / fx, y = (v - cy) z / fy in float32, that operation order).
+//                    The library version builds ONE list for the frame with nonzero + five boolean-mask indexings (a host round
+//                    trip each).  Here one workgroup per detection walks its crop in chunks of 1024 pixels and compacts in
+//                    order (wave ballot ranks + a 16-entry wave prefix), writing to the detection's fixed-capacity slot.
+//   radius_filter    ``flag = norm(cloud - center) < radius * 1.2`` (:214-221) and the second in-order compaction, in place.
 #include "s6d_common.h"
 
 namespace s6d {
+
+#pragma clang fp contract(off)   // the reference's float32 expressions, operation by operation (no fused multiply-adds)
+
+constexpr int kCmpThreads = 1024;
+
+// in-order compaction step of one 1024-element chunk: returns this lane's output position (or -1) and advances *base
+__device__ __forceinline__ long block_rank(bool keep, long *base, unsigned *wave_tot) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long bal = __ballot(keep);
+  const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) wave_tot[wave] = (unsigned)__popcll(bal);
+  __syncthreads();
+  long off = *base;
+  unsigned tot = 0;
+  for (int w = 0; w < kCmpThreads / 64; ++w) {
+    if (w < wave) off += wave_tot[w];
+    tot += wave_tot[w];
+  }
+  __syncthreads();                                      // everyone has read base / wave_tot before they change
+  if (tid == 0) *base += tot;
+  return keep ? off + rank : -1;
+}
+
+// m (P,H,W) u8 = mask AND depth > 0; box (P,4) i64 [y1,y2,x1,x2]; ok (P) u8 -> choose (P,cap) i32, cloud (P,cap,3) f32, n (P) i64
+__global__ __launch_bounds__(kCmpThreads) void compact_cloud_kernel(const unsigned char *__restrict__ m,
+                                                                   const float *__restrict__ depth,
+                                                                   const long *__restrict__ box,
+                                                                   const unsigned char *__restrict__ ok, int H, int W,
+                                                                   float fx, float fy, float cx, float cy, long cap,
+                                                                   int *__restrict__ choose, float *__restrict__ cloud,
+                                                                   long *__restrict__ n_out) {
+  __shared__ unsigned wave_tot[kCmpThreads / 64];
+  __shared__ long base;
+  const int p = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  if (ok[p]) {
+    const long y1 = box[p * 4 + 0], y2 = box[p * 4 + 1], x1 = box[p * 4 + 2], x2 = box[p * 4 + 3];
+    const long bw = x2 - x1, area = (y2 - y1) * bw;
+    const unsigned char *mp = m + (size_t)p * H * W;
+    for (long c0 = 0; c0 < area; c0 += kCmpThreads) {
+      const long j = c0 + tid;
+      bool keep = false;
+      long y = 0, x = 0;
+      if (j < area) {
+        y = y1 + j / bw;
+        x = x1 + j % bw;
+        keep = mp[y * W + x] != 0;
+      }
+      const long pos = block_rank(keep, &base, wave_tot);
+      if (keep) {
+        const float z = depth[y * W + x];
+        choose[(size_t)p * cap + pos] = (int)j;
+        float *c = cloud + ((size_t)p * cap + pos) * 3;
+        c[0] = ((float)x - cx) * z / fx;
+        c[1] = ((float)y - cy) * z / fy;
+        c[2] = z;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) n_out[p] = base;
+}
+
+// in place: keep the points within lim[p] of center[p], in order.  choose (P,cap) i32, cloud (P,cap,3) f32, n (P) i64 in/out
+__global__ __launch_bounds__(kCmpThreads) void radius_filter_kernel(const float *__restrict__ center,
+                                                                   const double *__restrict__ lim, long cap,
+                                                                   int *__restrict__ choose, float *__restrict__ cloud,
+                                                                   long *__restrict__ n_io) {
+  __shared__ unsigned wave_tot[kCmpThreads / 64];
+  __shared__ long base;
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const long n = n_io[p];
+  if (tid == 0) base = 0;
+  __syncthreads();
+  const float c0 = center[p * 3 + 0], c1 = center[p * 3 + 1], c2 = center[p * 3 + 2];
+  const double limit = lim[p];
+  int *ch = choose + (size_t)p * cap;
+  float *cl = cloud + (size_t)p * cap * 3;
+  for (long s0 = 0; s0 < n; s0 += kCmpThreads) {
+    const long i = s0 + tid;
+    bool keep = false;
+    float vx = 0.f, vy = 0.f, vz = 0.f;
+    int cj = 0;
+    if (i < n) {
+      vx = cl[i * 3 + 0];
+      vy = cl[i * 3 + 1];
+      vz = cl[i * 3 + 2];
+      cj = ch[i];
+      const float dx = vx - c0, dy = vy - c1, dz = vz - c2;
+      const float d = sqrtf((dx * dx + dy * dy) + dz * dz);
+      keep = (double)d < limit;
+    }
+    const long pos = block_rank(keep, &base, wave_tot);   // its barriers also order this chunk's reads before the writes below
+    if (keep) {                                           // pos <= i: never overwrites an element that is still to be read
+      ch[pos] = cj;
+      cl[pos * 3 + 0] = vx;
+      cl[pos * 3 + 1] = vy;
+      cl[pos * 3 + 2] = vz;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) n_io[p] = base;
+}
 
 constexpr int kSelThreads = 1024;
 constexpr int kSelBins = 4096;        // leading 12 bits of the float (sign is 0: 8 exponent + 3 mantissa bits ... see below)
@@ -101,5 +212,26 @@ extern "C" int s6d_pem_sample_indices_f32(const float *keys, long key_stride, co
   if (!keys || !count || !idx || !overflow) return S6D_EINVAL;
   hipLaunchKernelGGL(sample_indices_kernel, dim3((unsigned)P), dim3(kSelThreads), 0, as_stream(stream), keys, key_stride,
                      (const long *)count, n_sample, (long *)idx, overflow);
+  return launch_status();
+}
+
+extern "C" int s6d_pem_compact_cloud_f32(const unsigned char *m, const float *depth, const int64_t *box, const unsigned char *ok,
+                                         int P, int H, int W, float fx, float fy, float cx, float cy, long cap, int32_t *choose,
+                                         float *cloud, int64_t *n, void *stream) {
+  if (P < 0 || H <= 0 || W <= 0 || cap <= 0 || fx == 0.f || fy == 0.f) return S6D_EINVAL;
+  if (P == 0) return S6D_OK;
+  if (!m || !depth || !box || !ok || !choose || !cloud || !n) return S6D_EINVAL;
+  hipLaunchKernelGGL(compact_cloud_kernel, dim3((unsigned)P), dim3(kCmpThreads), 0, as_stream(stream), m, depth,
+                     (const long *)box, ok, H, W, fx, fy, cx, cy, cap, choose, cloud, (long *)n);
+  return launch_status();
+}
+
+extern "C" int s6d_pem_radius_filter_f32(const float *center, const double *limit, int P, long cap, int32_t *choose,
+                                         float *cloud, int64_t *n, void *stream) {
+  if (P < 0 || cap <= 0) return S6D_EINVAL;
+  if (P == 0) return S6D_OK;
+  if (!center || !limit || !choose || !cloud || !n) return S6D_EINVAL;
+  hipLaunchKernelGGL(radius_filter_kernel, dim3((unsigned)P), dim3(kCmpThreads), 0, as_stream(stream), center, limit, cap,
+                     choose, cloud, (long *)n);
   return launch_status();
 }

@@ -311,6 +311,38 @@ def pem_sample_indices(keys, count, n_sample):
     return idx, overflow
 
 
+def pem_compact_cloud(m8, depth, box, ok8, fx, fy, cx, cy, cap):
+    """m8 (P,H,W) uint8, depth (H,W) f32, box (P,4) int64, ok8 (P,) uint8 -> (choose (P,cap) int32, cloud (P,cap,3) f32,
+    n (P,) int64): masked crop pixels in row-major crop order and their back-projections, one fixed-capacity slot each."""
+    _chk(m8, torch.uint8, "m8", 3)
+    _chk(depth, torch.float32, "depth", 2)
+    _chk(box, torch.int64, "box", 2)
+    _chk(ok8, torch.uint8, "ok8", 1)
+    P, H, W = m8.shape
+    if tuple(depth.shape) != (H, W) or tuple(box.shape) != (P, 4) or ok8.shape[0] != P:
+        raise RuntimeError("pem_compact_cloud: shape mismatch")
+    choose = torch.empty(P, cap, dtype=torch.int32, device=m8.device)
+    cloud = torch.empty(P, cap, 3, dtype=torch.float32, device=m8.device)
+    n = torch.zeros(P, dtype=torch.int64, device=m8.device)
+    _call("s6d_pem_compact_cloud_f32", _ptr(m8), _ptr(depth), _ptr(box), _ptr(ok8), P, H, W, ctypes.c_float(fx), ctypes.c_float(fy),
+          ctypes.c_float(cx), ctypes.c_float(cy), ctypes.c_long(cap), _ptr(choose), _ptr(cloud), _ptr(n), _stream())
+    return choose, cloud, n
+
+
+def pem_radius_filter(center, limit, choose, cloud, n):
+    """In place on (choose, cloud, n) of pem_compact_cloud: keep, in order, the points within limit[p] of center[p]."""
+    _chk(center, torch.float32, "center", 2)
+    _chk(limit, torch.float64, "limit", 1)
+    _chk(choose, torch.int32, "choose", 2)
+    _chk(cloud, torch.float32, "cloud", 3)
+    _chk(n, torch.int64, "n", 1)
+    P, cap = choose.shape
+    if tuple(center.shape) != (P, 3) or limit.shape[0] != P or tuple(cloud.shape) != (P, cap, 3) or n.shape[0] != P:
+        raise RuntimeError("pem_radius_filter: shape mismatch")
+    _call("s6d_pem_radius_filter_f32", _ptr(center), _ptr(limit), P, ctypes.c_long(cap), _ptr(choose), _ptr(cloud), _ptr(n), _stream())
+    return n
+
+
 def upsample_gather(up, choose, H, W, C):
     """up (B,196,16*C) f32, choose (B,n) int64 -> (B,n,C): bilinear x4 of the pixel-shuffled map at chosen pixels."""
     _chk(up, torch.float32, "up", 3)

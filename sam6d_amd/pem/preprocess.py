@@ -104,6 +104,26 @@ def observed_inputs(image_u8, depth, K, masks, radius, keys=None, n_sample=2048,
     cnt = m.flatten(1).sum(1)
     ok1 = cnt > min_points
     box = square_boxes(m | ~ok1[:, None, None])                                        # dummy full mask where empty
+    if os.environ.get("S6D_PEM_PRE") == "kernels":
+        # kernel path (csrc/s6d_pempre.hip + s6d_segment_seq_sum_f32): per-detection fixed-capacity lists instead of one
+        # frame-wide list, the reference's sequential centroid, no host round trip before the survivor list.  Opt-in until it
+        # has been through the device parity test.
+        from .. import ops
+        cap = min(H, W) ** 2                                                           # a square crop is at most this large
+        choose_l, cloud_l, n = ops.pem_compact_cloud(m.to(torch.uint8).contiguous(), depth.contiguous(), box.contiguous(),
+                                                     ok1.to(torch.uint8), fx, fy, cx, cy, cap)
+        start = torch.arange(P, device=dev) * cap
+        center = ops.segment_seq_sum(cloud_l.view(P * cap, 3), start, n) / n.clamp(min=1).float()[:, None]
+        if torch.is_tensor(radius) and radius.numel() > 1:
+            lim = (radius.to(dev).double() * radius_factor).contiguous()
+        else:
+            lim = torch.full((P,), float(radius) * radius_factor, dtype=torch.float64, device=dev)
+        ops.pem_radius_filter(center.contiguous(), lim, choose_l, cloud_l, n)
+        ok = ok1 & (n >= min_inliers)
+        idx = _numpy_choice_indices(n, ok, n_sample, rng).to(dev) if rng is not None else _keyed_indices(n, keys, n_sample)
+        kept = torch.nonzero(ok).squeeze(1)
+        g = (start[:, None] + idx)[kept]
+        return _finish(image_u8, m, box, kept, cloud_l.view(-1, 3)[g], choose_l.view(-1)[g].long(), img_size, rgb_mask_flag)
     y1, y2, x1, x2 = box.unbind(1)
     # ---- ragged pixel lists as one (detection, y, x) list, row-major inside each crop ---------------------------------
     pyx = torch.nonzero(m)                                                             # host round trip #1 (list length)
@@ -138,8 +158,12 @@ def observed_inputs(image_u8, depth, K, masks, radius, keys=None, n_sample=2048,
         idx = _keyed_indices(n, keys, n_sample)
     kept = torch.nonzero(ok).squeeze(1)
     g = (start[:, None] + idx)[kept].clamp(max=max(cloud.shape[0] - 1, 0))
-    pts = cloud[g]
-    ch = choose[g]
+    return _finish(image_u8, m, box, kept, cloud[g], choose[g], img_size, rgb_mask_flag)
+
+
+def _finish(image_u8, m, box, kept, pts, ch, img_size, rgb_mask_flag):
+    """Colour crops and the index of every sampled point in the resized crop, for the detections that survived."""
+    dev = image_u8.device
     bk = box[kept]
     rgb = _crops(image_u8, m[kept].float(), bk, img_size, rgb_mask_flag) if len(kept) else \
         torch.zeros(0, 3, img_size, img_size, device=dev)

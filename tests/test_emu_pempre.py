@@ -54,3 +54,46 @@ def test_full_frame_with_the_kernel_sampler_matches_the_oracle(emu, monkeypatch)
     assert out["kept"].tolist() == ref["kept"].tolist()
     np.testing.assert_array_equal(out["pts"].numpy(), ref["pts"])
     np.testing.assert_array_equal(out["rgb_choose"].numpy(), ref["rgb_choose"])
+
+
+def _frame(P=8, seed=3):
+    from sam6d_amd.utils import synth
+    inp = synth.pem_pre_inputs(P=P, seed=seed)
+    return inp, (torch.from_numpy(inp["image"]), inp["depth"], inp["K"], inp["masks"])
+
+
+def test_kernel_path_of_the_whole_preprocessing_matches_the_oracle(emu, monkeypatch):
+    """S6D_PEM_PRE=kernels: compaction + back-projection, sequential centroid, radius filter (and the sampler kernel) against
+    the oracle's per-detection loop -- bit-identical points, crops, indices and survivors, also at the radii whose sphere cuts
+    through dense points (where the default path's float64-accumulated centroid flips boundary points)."""
+    from oracle import pem_pre as opre
+    monkeypatch.setenv("S6D_PEM_PRE", "kernels")
+    monkeypatch.setenv("S6D_PEM_SAMPLER", "kernel")
+    inp, args = _frame()
+    kw = dict(n_sample=512, img_size=224, min_points=32, min_inliers=4, radius_factor=1.2)
+    for radius in (0.12, np.array([0.12, 0.03, 0.5, 0.12, 0.06, 0.2, 0.07, 0.01])):
+        ref = opre.preprocess_frame(inp["image"], inp["depth"].numpy(), inp["K"].numpy(), inp["masks"].numpy(), radius,
+                                    keys=inp["keys"].numpy(), **kw)
+        r = torch.from_numpy(radius) if isinstance(radius, np.ndarray) else radius
+        out = pre.observed_inputs(*args, r, keys=inp["keys"], **kw)
+        assert out["kept"].tolist() == ref["kept"].tolist() and len(ref["kept"]) >= 6
+        np.testing.assert_array_equal(out["bbox"].numpy(), ref["bbox"])
+        np.testing.assert_array_equal(out["pts"].numpy(), ref["pts"])
+        np.testing.assert_array_equal(out["rgb_choose"].numpy(), ref["rgb_choose"])
+        np.testing.assert_array_equal(out["rgb"].numpy(), ref["rgb"])
+    # numpy-compatible draws on the kernel path too
+    ref = opre.preprocess_frame(inp["image"], inp["depth"].numpy(), inp["K"].numpy(), inp["masks"].numpy(), 0.12,
+                                rng=np.random.RandomState(5), **kw)
+    out = pre.observed_inputs(*args, 0.12, rng=np.random.RandomState(5), **kw)
+    np.testing.assert_array_equal(out["pts"].numpy(), ref["pts"])
+
+
+def test_kernel_path_with_no_survivor_and_with_empty_masks(emu, monkeypatch):
+    monkeypatch.setenv("S6D_PEM_PRE", "kernels")
+    inp, args = _frame(P=3, seed=5)
+    out = pre.observed_inputs(args[0], args[1] * 0, args[2], args[3], 0.1, inp["keys"])
+    assert out["pts"].shape[0] == 0 and out["rgb"].shape == (0, 3, 224, 224) and out["kept"].numel() == 0
+    masks = args[3].clone()
+    masks[1] = False                                                 # one detection without a single pixel
+    out = pre.observed_inputs(args[0], args[1], args[2], masks, 0.3, inp["keys"], n_sample=256)
+    assert 1 not in out["kept"].tolist() and out["pts"].shape[1:] == (256, 3)

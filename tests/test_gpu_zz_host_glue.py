@@ -88,3 +88,34 @@ def test_sampler_kernel_equals_the_library_path_on_the_device(monkeypatch):
     idx, overflow = ops.pem_sample_indices(keys.cuda(), n.cuda(), ns)
     assert overflow.cpu().tolist() == [0] * len(n) and torch.equal(idx, want)
 
+
+@pytest.mark.skipif(os.environ.get("S6D_PEM_PRE") != "kernels", reason="opt-in path: set S6D_PEM_PRE=kernels")
+def test_kernel_path_of_the_preprocessing_on_the_device():
+    """S6D_PEM_PRE=kernels on cuda:0 against the oracle loop (boundary-cutting radii included) and timed at 64 detections."""
+    import time
+
+    import numpy as np
+
+    from oracle import pem_pre as opre
+    from sam6d_amd.pem import preprocess as pre
+    from sam6d_amd.utils import synth
+    inp = synth.pem_pre_inputs(P=8, seed=3)
+    kw = dict(n_sample=2048, img_size=224, min_points=32, min_inliers=4, radius_factor=1.2)
+    radius = np.array([0.12, 0.03, 0.5, 0.12, 0.06, 0.2, 0.07, 0.01])
+    ref = opre.preprocess_frame(inp["image"], inp["depth"].numpy(), inp["K"].numpy(), inp["masks"].numpy(), radius,
+                                keys=inp["keys"].numpy(), **kw)
+    out = pre.observed_inputs(torch.from_numpy(inp["image"]).cuda(), inp["depth"].cuda(), inp["K"], inp["masks"].cuda(),
+                              torch.from_numpy(radius).cuda(), keys=inp["keys"].cuda(), **kw)
+    assert out["kept"].cpu().tolist() == ref["kept"].tolist()
+    for k in ("bbox", "pts", "rgb_choose", "rgb"):
+        np.testing.assert_array_equal(out[k].cpu().numpy(), ref[k], err_msg=k)
+    big = synth.pem_pre_inputs(P=64, seed=9)
+    args = (torch.from_numpy(big["image"]).cuda(), big["depth"].cuda(), big["K"], big["masks"].cuda(), 0.15, big["keys"].cuda())
+    pre.observed_inputs(*args)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(3):
+        pre.observed_inputs(*args)
+    torch.cuda.synchronize()
+    print(f"PEM pre-processing, kernel path, 64 detections: {(time.time() - t0) / 3 * 1e3:.1f} ms")
+

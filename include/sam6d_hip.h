@@ -84,6 +84,13 @@ int s6d_segment_seq_sum_f32(const float *x, const int64_t *start, const int64_t 
 int s6d_pem_sample_indices_f32(const float *keys, long key_stride, const int64_t *count, int P, int n_sample,
                                int64_t *idx, int32_t *overflow, void *stream);
 
+/* m = mask AND depth > 0, its pixel count, ok = count > min_points, and the square crop box of get_bbox
+ * (Pose_Estimation_Model/utils/data_utils.py:126-160; run_inference_custom.py:204-208) per detection, in one pass.
+ * mask (P,H,W) u8 (non-zero = set), depth (H,W) f32 -> m (P,H,W) u8, cnt (P) i64, ok (P) u8, box (P,4) i64 [y1,y2,x1,x2]
+ * (the whole-frame box for a detection that is not ok). */
+int s6d_pem_mask_boxes_u8(const unsigned char *mask, const float *depth, int P, int H, int W, long min_points,
+                          unsigned char *m, int64_t *cnt, unsigned char *ok, int64_t *box, void *stream);
+
 /* Masked crop pixels of every detection, in row-major crop order, with their back-projected points
  * (run_inference_custom.py:209-213, utils/data_utils.py:92-110).  m (P,H,W) u8 = mask AND depth > 0, depth (H,W) f32,
  * box (P,4) i64 [y1,y2,x1,x2], ok (P) u8 (0: detection skipped, n = 0) -> choose (P,cap) i32 crop-flat indices,
@@ -95,6 +102,14 @@ int s6d_pem_compact_cloud_f32(const unsigned char *m, const float *depth, const 
  * center (P,3) f32, limit (P) f64, choose / cloud / n as above (n is updated). */
 int s6d_pem_radius_filter_f32(const float *center, const double *limit, int P, long cap, int32_t *choose, float *cloud,
                               int64_t *n, void *stream);
+
+/* Masked colour crops of the surviving detections, resized to S x S and normalised (run_inference_custom.py:231-236 in
+ * the defined form of sam6d_amd/pem/preprocess.py: float32 bilinear, rounded to a grey level, ToTensor + Normalize).
+ * image (H,W,3) u8 RGB, m (P,H,W) u8, kept (M) i64 detection indices, box (P,4) i64, mean / std: 3 floats each on the HOST
+ * -> out (M,3,S,S) f32 with channel c = image channel 2 - c (the reference's [:, :, ::-1]). */
+int s6d_pem_crops_f32(const unsigned char *image, const unsigned char *m, const int64_t *kept, const int64_t *box, int M,
+                      int H, int W, int S, int use_mask, const float *mean3_host, const float *std3_host, float *out,
+                      void *stream);
 
 /* ---------------------------------------------------------------- PEM pose solvers
  * Replace the library-op chains of Pose_Estimation_Model/utils/model_utils.py. */

@@ -47,6 +47,91 @@ __device__ __forceinline__ long block_rank(bool keep, long *base, unsigned *wave
   return keep ? off + rank : -1;
 }
 
+// mask (P,H,W) u8 (non-zero = set), depth (H,W) f32 -> m (P,H,W) u8 = mask AND depth > 0, cnt (P) i64, ok (P) u8 = cnt > min_points,
+// box (P,4) i64: get_bbox (utils/data_utils.py:126-160) of m -- of the whole frame for a detection that is not ok, like the
+// library path's dummy mask.  One workgroup per detection, one pass over its mask.
+__global__ __launch_bounds__(kCmpThreads) void mask_boxes_kernel(const unsigned char *__restrict__ mask,
+                                                                const float *__restrict__ depth, int H, int W, long min_points,
+                                                                unsigned char *__restrict__ m, long *__restrict__ cnt_out,
+                                                                unsigned char *__restrict__ ok_out, long *__restrict__ box) {
+  __shared__ int s_cnt[kCmpThreads / 64], s_y0[kCmpThreads / 64], s_y1[kCmpThreads / 64], s_x0[kCmpThreads / 64],
+      s_x1[kCmpThreads / 64];
+  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t off = (size_t)p * H * W;
+  int cnt = 0, y0 = H, y1 = -1, x0 = W, x1 = -1;
+  for (int i = tid; i < H * W; i += kCmpThreads) {
+    const bool v = mask[off + i] != 0 && depth[i] > 0.f;
+    m[off + i] = v ? 1 : 0;
+    if (v) {
+      const int y = i / W, x = i - y * W;
+      ++cnt;
+      y0 = min(y0, y);
+      y1 = max(y1, y);
+      x0 = min(x0, x);
+      x1 = max(x1, x);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    cnt += __shfl_xor(cnt, o);
+    y0 = min(y0, __shfl_xor(y0, o));
+    y1 = max(y1, __shfl_xor(y1, o));
+    x0 = min(x0, __shfl_xor(x0, o));
+    x1 = max(x1, __shfl_xor(x1, o));
+  }
+  if (lane == 0) {
+    s_cnt[wave] = cnt;
+    s_y0[wave] = y0;
+    s_y1[wave] = y1;
+    s_x0[wave] = x0;
+    s_x1[wave] = x1;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    long c = 0;
+    int ry0 = H, ry1 = -1, rx0 = W, rx1 = -1;
+    for (int w = 0; w < kCmpThreads / 64; ++w) {
+      c += s_cnt[w];
+      ry0 = min(ry0, s_y0[w]);
+      ry1 = max(ry1, s_y1[w]);
+      rx0 = min(rx0, s_x0[w]);
+      rx1 = max(rx1, s_x1[w]);
+    }
+    const bool ok = c > min_points;
+    long rmin = ok ? ry0 : 0, rmax = ok ? ry1 + 1 : H, cmin = ok ? rx0 : 0, cmax = ok ? rx1 + 1 : W;
+    const long rb = rmax - rmin, cb = cmax - cmin, lim = H < W ? H : W;
+    long b = rb > cb ? rb : cb;
+    b = b < lim ? b : lim;
+    const long cy = (rmin + rmax) / 2, cx = (cmin + cmax) / 2, half = b / 2;
+    rmin = cy - half;
+    rmax = cy + half;
+    cmin = cx - half;
+    cmax = cx + half;
+    if (rmin < 0) {
+      rmax -= rmin;
+      rmin = 0;
+    }
+    if (cmin < 0) {
+      cmax -= cmin;
+      cmin = 0;
+    }
+    if (rmax > H) {
+      rmin -= rmax - H;
+      rmax = H;
+    }
+    if (cmax > W) {
+      cmin -= cmax - W;
+      cmax = W;
+    }
+    cnt_out[p] = c;
+    ok_out[p] = ok ? 1 : 0;
+    box[p * 4 + 0] = rmin;
+    box[p * 4 + 1] = rmax;
+    box[p * 4 + 2] = cmin;
+    box[p * 4 + 3] = cmax;
+  }
+}
+
 // m (P,H,W) u8 = mask AND depth > 0; box (P,4) i64 [y1,y2,x1,x2]; ok (P) u8 -> choose (P,cap) i32, cloud (P,cap,3) f32, n (P) i64
 __global__ __launch_bounds__(kCmpThreads) void compact_cloud_kernel(const unsigned char *__restrict__ m,
                                                                    const float *__restrict__ depth,
@@ -201,6 +286,43 @@ __global__ __launch_bounds__(kSelThreads) void sample_indices_kernel(const float
   if (tid == 0) overflow[p] = 0;
 }
 
+// Masked colour crop of every surviving detection, resized to S x S and normalised (run_inference_custom.py:231-236 in the
+// DEFINED form of preprocess.py: bilinear with half-pixel centres in float32, rounded to a grey level, then ToTensor +
+// Normalize).  Same float32 operations, in the same order, as the library statement `_crops` (file-level contract(off)).
+// image (H,W,3) u8 RGB, m (P,H,W) u8, kept (M) i64, box (P,4) i64 -> out (M,3,S,S) f32, channel c = image channel 2 - c.
+__global__ void pem_crops_kernel(const unsigned char *__restrict__ image, const unsigned char *__restrict__ m,
+                                 const long *__restrict__ kept, const long *__restrict__ box, int M, int H, int W, int S,
+                                 int use_mask, float mean0, float mean1, float mean2, float std0, float std1, float std2,
+                                 float *__restrict__ out) {
+  const size_t total = (size_t)M * 3 * S * S;
+  const float Sf = (float)S;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % S), oy = (int)((i / S) % S), c = (int)((i / ((size_t)S * S)) % 3), k = (int)(i / ((size_t)3 * S * S));
+    const long p = kept[k];
+    const long y1 = box[p * 4 + 0], y2 = box[p * 4 + 1], x1 = box[p * 4 + 2], x2 = box[p * 4 + 3];
+    // taps along one axis: s = o * (n / S) - 0.5; i0 = floor(s); f = s - i0; indices clamped to the crop
+    const float sy = ((float)oy + 0.5f) * ((float)(y2 - y1) / Sf) - 0.5f, sx = ((float)ox + 0.5f) * ((float)(x2 - x1) / Sf) - 0.5f;
+    const float fy0 = floorf(sy), fx0 = floorf(sx);
+    const float fy = sy - fy0, fx = sx - fx0;
+    const long iy = (long)fy0, ix = (long)fx0, ly = y2 - y1 - 1, lx = x2 - x1 - 1;
+    const long ya = y1 + min(max(iy, 0L), ly), yb = y1 + min(max(iy + 1, 0L), ly);
+    const long xa = x1 + min(max(ix, 0L), lx), xb = x1 + min(max(ix + 1, 0L), lx);
+    const int ch = 2 - c;
+    const unsigned char *mp = m + (size_t)p * H * W;
+    auto px = [&](long yy, long xx) {
+      float v = (float)image[(yy * W + xx) * 3 + ch];
+      if (use_mask) v = v * (float)mp[yy * W + xx];
+      return v;
+    };
+    const float top = px(ya, xa) * (1.f - fx) + px(ya, xb) * fx;
+    const float bot = px(yb, xa) * (1.f - fx) + px(yb, xb) * fx;
+    float g = floorf(top * (1.f - fy) + bot * fy + 0.5f);
+    g = fminf(fmaxf(g, 0.f), 255.f);
+    const float mean = c == 0 ? mean0 : (c == 1 ? mean1 : mean2), sd = c == 0 ? std0 : (c == 1 ? std1 : std2);
+    out[i] = (g / 255.f - mean) / sd;
+  }
+}
+
 }  // namespace s6d
 
 using namespace s6d;
@@ -233,5 +355,30 @@ extern "C" int s6d_pem_radius_filter_f32(const float *center, const double *limi
   if (!center || !limit || !choose || !cloud || !n) return S6D_EINVAL;
   hipLaunchKernelGGL(radius_filter_kernel, dim3((unsigned)P), dim3(kCmpThreads), 0, as_stream(stream), center, limit, cap,
                      choose, cloud, (long *)n);
+  return launch_status();
+}
+
+extern "C" int s6d_pem_mask_boxes_u8(const unsigned char *mask, const float *depth, int P, int H, int W, long min_points,
+                                     unsigned char *m, int64_t *cnt, unsigned char *ok, int64_t *box, void *stream) {
+  if (P < 0 || H <= 0 || W <= 0 || (long)H * W > 0x7fffffffL) return S6D_EINVAL;
+  if (P == 0) return S6D_OK;
+  if (!mask || !depth || !m || !cnt || !ok || !box) return S6D_EINVAL;
+  hipLaunchKernelGGL(mask_boxes_kernel, dim3((unsigned)P), dim3(kCmpThreads), 0, as_stream(stream), mask, depth, H, W, min_points,
+                     m, (long *)cnt, ok, (long *)box);
+  return launch_status();
+}
+
+extern "C" int s6d_pem_crops_f32(const unsigned char *image, const unsigned char *m, const int64_t *kept, const int64_t *box,
+                                 int M, int H, int W, int S, int use_mask, const float *mean3_host, const float *std3_host,
+                                 float *out, void *stream) {
+  if (M < 0 || H <= 0 || W <= 0 || S <= 0) return S6D_EINVAL;
+  if (M == 0) return S6D_OK;
+  if (!image || !m || !kept || !box || !mean3_host || !std3_host || !out) return S6D_EINVAL;
+  const size_t total = (size_t)M * 3 * S * S;
+  size_t g = (total + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(pem_crops_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), image, m, (const long *)kept,
+                     (const long *)box, M, H, W, S, use_mask, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0],
+                     std3_host[1], std3_host[2], out);
   return launch_status();
 }

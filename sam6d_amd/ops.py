@@ -311,6 +311,40 @@ def pem_sample_indices(keys, count, n_sample):
     return idx, overflow
 
 
+def pem_mask_boxes(mask8, depth, min_points):
+    """mask8 (P,H,W) uint8 (non-zero = set), depth (H,W) f32 -> (m8 (P,H,W) uint8 = mask AND depth > 0, cnt (P,) int64,
+    ok8 (P,) uint8 = cnt > min_points, box (P,4) int64 [y1,y2,x1,x2] by the reference's get_bbox)."""
+    _chk(mask8, torch.uint8, "mask8", 3)
+    _chk(depth, torch.float32, "depth", 2)
+    P, H, W = mask8.shape
+    if tuple(depth.shape) != (H, W):
+        raise RuntimeError("pem_mask_boxes: depth must be (H,W)")
+    dev = mask8.device
+    m8 = torch.empty(P, H, W, dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(P, dtype=torch.int64, device=dev)
+    ok8 = torch.zeros(P, dtype=torch.uint8, device=dev)
+    box = torch.zeros(P, 4, dtype=torch.int64, device=dev)
+    _call("s6d_pem_mask_boxes_u8", _ptr(mask8), _ptr(depth), P, H, W, ctypes.c_long(int(min_points)), _ptr(m8), _ptr(cnt), _ptr(ok8),
+          _ptr(box), _stream())
+    return m8, cnt, ok8, box
+
+
+def pem_crops(image_u8, m8, kept, box, S, use_mask, mean, std):
+    """image (H,W,3) uint8, m8 (P,H,W) uint8, kept (M,) int64, box (P,4) int64 -> (M,3,S,S) f32 normalised masked crops."""
+    _chk(image_u8, torch.uint8, "image", 3)
+    _chk(m8, torch.uint8, "m8", 3)
+    _chk(kept, torch.int64, "kept", 1)
+    _chk(box, torch.int64, "box", 2)
+    P, H, W = m8.shape
+    if tuple(image_u8.shape) != (H, W, 3) or tuple(box.shape) != (P, 4):
+        raise RuntimeError("pem_crops: shape mismatch")
+    M = kept.shape[0]
+    out = torch.empty(M, 3, S, S, dtype=torch.float32, device=m8.device)
+    _call("s6d_pem_crops_f32", _ptr(image_u8), _ptr(m8), _ptr(kept), _ptr(box), M, H, W, int(S), int(bool(use_mask)),
+          (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std), _ptr(out), _stream())
+    return out
+
+
 def pem_compact_cloud(m8, depth, box, ok8, fx, fy, cx, cy, cap):
     """m8 (P,H,W) uint8, depth (H,W) f32, box (P,4) int64, ok8 (P,) uint8 -> (choose (P,cap) int32, cloud (P,cap,3) f32,
     n (P,) int64): masked crop pixels in row-major crop order and their back-projections, one fixed-capacity slot each."""

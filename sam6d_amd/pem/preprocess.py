@@ -100,18 +100,16 @@ def observed_inputs(image_u8, depth, K, masks, radius, keys=None, n_sample=2048,
     dev = depth.device
     P, H, W = masks.shape
     fx, fy, cx, cy = (float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]))
-    m = (masks > 0) & (depth > 0)[None]
-    cnt = m.flatten(1).sum(1)
-    ok1 = cnt > min_points
-    box = square_boxes(m | ~ok1[:, None, None])                                        # dummy full mask where empty
     if os.environ.get("S6D_PEM_PRE") == "kernels":
-        # kernel path (csrc/s6d_pempre.hip + s6d_segment_seq_sum_f32): per-detection fixed-capacity lists instead of one
-        # frame-wide list, the reference's sequential centroid, no host round trip before the survivor list.  Opt-in until it
-        # has been through the device parity test.
+        # kernel path (csrc/s6d_pempre.hip + s6d_segment_seq_sum_f32): one pass per detection for mask AND depth / count / box,
+        # per-detection fixed-capacity lists instead of one frame-wide list, the reference's sequential centroid, no host round
+        # trip before the survivor list.  Opt-in until it has been through the device parity test.
         from .. import ops
+        mb = masks if masks.dtype == torch.bool else masks > 0
+        m8, cnt, ok8, box = ops.pem_mask_boxes(mb.contiguous().view(torch.uint8), depth.contiguous(), min_points)
+        m, ok1 = None, ok8.bool()
         cap = min(H, W) ** 2                                                           # a square crop is at most this large
-        choose_l, cloud_l, n = ops.pem_compact_cloud(m.to(torch.uint8).contiguous(), depth.contiguous(), box.contiguous(),
-                                                     ok1.to(torch.uint8), fx, fy, cx, cy, cap)
+        choose_l, cloud_l, n = ops.pem_compact_cloud(m8, depth.contiguous(), box, ok8, fx, fy, cx, cy, cap)
         start = torch.arange(P, device=dev) * cap
         center = ops.segment_seq_sum(cloud_l.view(P * cap, 3), start, n) / n.clamp(min=1).float()[:, None]
         if torch.is_tensor(radius) and radius.numel() > 1:
@@ -123,7 +121,12 @@ def observed_inputs(image_u8, depth, K, masks, radius, keys=None, n_sample=2048,
         idx = _numpy_choice_indices(n, ok, n_sample, rng).to(dev) if rng is not None else _keyed_indices(n, keys, n_sample)
         kept = torch.nonzero(ok).squeeze(1)
         g = (start[:, None] + idx)[kept]
-        return _finish(image_u8, m, box, kept, cloud_l.view(-1, 3)[g], choose_l.view(-1)[g].long(), img_size, rgb_mask_flag)
+        rgb = ops.pem_crops(image_u8.contiguous(), m8, kept, box, img_size, rgb_mask_flag, MEAN, STD)
+        return _finish(image_u8, m, box, kept, cloud_l.view(-1, 3)[g], choose_l.view(-1)[g].long(), img_size, rgb_mask_flag, rgb)
+    m = (masks > 0) & (depth > 0)[None]
+    cnt = m.flatten(1).sum(1)
+    ok1 = cnt > min_points
+    box = square_boxes(m | ~ok1[:, None, None])                                        # dummy full mask where empty
     y1, y2, x1, x2 = box.unbind(1)
     # ---- ragged pixel lists as one (detection, y, x) list, row-major inside each crop ---------------------------------
     pyx = torch.nonzero(m)                                                             # host round trip #1 (list length)
@@ -161,12 +164,14 @@ def observed_inputs(image_u8, depth, K, masks, radius, keys=None, n_sample=2048,
     return _finish(image_u8, m, box, kept, cloud[g], choose[g], img_size, rgb_mask_flag)
 
 
-def _finish(image_u8, m, box, kept, pts, ch, img_size, rgb_mask_flag):
-    """Colour crops and the index of every sampled point in the resized crop, for the detections that survived."""
+def _finish(image_u8, m, box, kept, pts, ch, img_size, rgb_mask_flag, rgb=None):
+    """Colour crops (unless the kernel path already made them) and the index of every sampled point in the resized crop, for
+    the detections that survived."""
     dev = image_u8.device
     bk = box[kept]
-    rgb = _crops(image_u8, m[kept].float(), bk, img_size, rgb_mask_flag) if len(kept) else \
-        torch.zeros(0, 3, img_size, img_size, device=dev)
+    if rgb is None:
+        rgb = _crops(image_u8, m[kept].float(), bk, img_size, rgb_mask_flag) if len(kept) else \
+            torch.zeros(0, 3, img_size, img_size, device=dev)
     ch_h, ch_w = (bk[:, 1] - bk[:, 0]), (bk[:, 3] - bk[:, 2])
     row, col = ch // ch_w[:, None], ch % ch_w[:, None]
     rgb_choose = ((row.double() * (img_size / ch_h.double())[:, None]).floor() * img_size +

@@ -97,3 +97,36 @@ def test_kernel_path_with_no_survivor_and_with_empty_masks(emu, monkeypatch):
     masks[1] = False                                                 # one detection without a single pixel
     out = pre.observed_inputs(args[0], args[1], args[2], masks, 0.3, inp["keys"], n_sample=256)
     assert 1 not in out["kept"].tolist() and out["pts"].shape[1:] == (256, 3)
+
+
+def test_mask_boxes_kernel_equals_the_library_ops(emu):
+    """s6d_pem_mask_boxes_u8 against mask AND depth / count / square_boxes of the library path (itself pinned to the
+    reference's get_bbox), incl. empty masks, masks touching the frame edge and a detection below the point threshold."""
+    g = torch.Generator().manual_seed(4)
+    P, H, W = 9, 48, 64
+    masks = torch.zeros(P, H, W, dtype=torch.bool)
+    for i, (y1, y2, x1, x2) in enumerate([(0, 48, 0, 64), (0, 5, 0, 64), (10, 40, 60, 64), (47, 48, 0, 1), (5, 45, 3, 9), (20, 21, 10, 50),
+                                          (0, 0, 0, 0), (3, 44, 2, 63), (12, 30, 12, 30)]):
+        masks[i, y1:y2, x1:x2] = torch.rand(y2 - y1, x2 - x1, generator=g) > 0.3
+    depth = torch.rand(H, W, generator=g)
+    depth[depth < 0.2] = 0.0
+    m8, cnt, ok8, box = emu.pem_mask_boxes(masks.view(torch.uint8), depth, 32)
+    m = masks & (depth > 0)[None]
+    ok = m.flatten(1).sum(1) > 32
+    assert torch.equal(m8.bool(), m) and torch.equal(cnt, m.flatten(1).sum(1)) and torch.equal(ok8.bool(), ok)
+    assert 0 < int(ok.sum()) < P                                     # both kinds present
+    assert torch.equal(box, pre.square_boxes(m | ~ok[:, None, None]))
+
+
+def test_crops_kernel_equals_the_library_statement(emu):
+    """s6d_pem_crops_f32 against preprocess._crops, value for value (same float32 operations in the same order)."""
+    inp, (image, depth, K, masks) = _frame()
+    m = masks & (depth > 0)[None]
+    box = pre.square_boxes(m)
+    kept = torch.tensor([6, 0, 2, 5])
+    for flag in (True, False):
+        want = pre._crops(image, m[kept].float(), box[kept], 224, flag)
+        got = emu.pem_crops(image.contiguous(), m.to(torch.uint8), kept, box, 224, flag, pre.MEAN, pre.STD)
+        assert torch.equal(got, want), (got - want).abs().max()
+    want = pre._crops(image, m[kept].float(), box[kept], 56, True)
+    assert torch.equal(emu.pem_crops(image.contiguous(), m.to(torch.uint8), kept, box, 56, True, pre.MEAN, pre.STD), want)

@@ -182,7 +182,8 @@ def _finish(image_u8, m, box, kept, pts, ch, img_size, rgb_mask_flag, rgb=None):
 def _keyed_indices(n, keys, n_sample):
     """The defined sampler: (P,n_sample) in-list positions from one uniform per crop pixel."""
     dev = n.device
-    if os.environ.get("S6D_PEM_SAMPLER") == "kernel" and keys.dtype == torch.float32 and keys.is_contiguous() and n_sample <= 2048:
+    use_kernel = os.environ.get("S6D_PEM_SAMPLER") == "kernel" or os.environ.get("S6D_PEM_PRE") == "kernels"
+    if use_kernel and keys.dtype == torch.float32 and keys.is_contiguous() and n_sample <= 2048:
         # one workgroup per detection (s6d_pem_sample_indices_f32) instead of a top-k over a (P, L) table of 64-bit keys; no host
         # round trip for L.  Opt-in until it has been through the device parity test (DESIGN.md section 4b).
         from .. import ops

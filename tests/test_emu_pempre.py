@@ -8,6 +8,7 @@ from sam6d_amd.pem import preprocess as pre
 
 def _lib_path(n, keys, n_sample, monkeypatch):
     monkeypatch.delenv("S6D_PEM_SAMPLER", raising=False)
+    monkeypatch.delenv("S6D_PEM_PRE", raising=False)
     return pre._keyed_indices(n, keys, n_sample)
 
 
@@ -67,8 +68,10 @@ def test_kernel_path_of_the_whole_preprocessing_matches_the_oracle(emu, monkeypa
     the oracle's per-detection loop -- bit-identical points, crops, indices and survivors, also at the radii whose sphere cuts
     through dense points (where the default path's float64-accumulated centroid flips boundary points)."""
     from oracle import pem_pre as opre
-    monkeypatch.setenv("S6D_PEM_PRE", "kernels")
-    monkeypatch.setenv("S6D_PEM_SAMPLER", "kernel")
+    monkeypatch.setenv("S6D_PEM_PRE", "kernels")                     # implies the sampler kernel
+    called = []
+    real = emu.pem_sample_indices
+    monkeypatch.setattr(emu, "pem_sample_indices", lambda *a, **k: (called.append(1), real(*a, **k))[1])
     inp, args = _frame()
     kw = dict(n_sample=512, img_size=224, min_points=32, min_inliers=4, radius_factor=1.2)
     for radius in (0.12, np.array([0.12, 0.03, 0.5, 0.12, 0.06, 0.2, 0.07, 0.01])):
@@ -81,6 +84,7 @@ def test_kernel_path_of_the_whole_preprocessing_matches_the_oracle(emu, monkeypa
         np.testing.assert_array_equal(out["pts"].numpy(), ref["pts"])
         np.testing.assert_array_equal(out["rgb_choose"].numpy(), ref["rgb_choose"])
         np.testing.assert_array_equal(out["rgb"].numpy(), ref["rgb"])
+    assert len(called) == 2
     # numpy-compatible draws on the kernel path too
     ref = opre.preprocess_frame(inp["image"], inp["depth"].numpy(), inp["K"].numpy(), inp["masks"].numpy(), 0.12,
                                 rng=np.random.RandomState(5), **kw)

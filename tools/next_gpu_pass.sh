@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 timeout 600 python -m pytest tests/test_gpu_zz_host_glue.py tests/test_gpu_zz_pipeline.py -q 2>&1 | tail -5 > gpurun_out/n1_glue.txt
 S6D_PEM_SEQ_CENTROID=1 timeout 600 python -m pytest tests/test_gpu_zz_host_glue.py -q -k sequential 2>&1 | tail -5 > gpurun_out/n2_seq_centroid.txt
 S6D_PEM_SAMPLER=kernel timeout 600 python -m pytest tests/test_gpu_zz_host_glue.py tests/test_gpu_pem_pre.py -q -s 2>&1 | tail -8 > gpurun_out/n2_sampler_kernel.txt
-S6D_PEM_PRE=kernels S6D_PEM_SAMPLER=kernel timeout 600 python -m pytest tests/test_gpu_zz_host_glue.py tests/test_gpu_pem_pre.py tests/test_gpu_zz_pipeline.py -q -s 2>&1 | tail -10 > gpurun_out/n2_pem_pre_kernels.txt
+S6D_PEM_PRE=kernels timeout 600 python -m pytest tests/test_gpu_zz_host_glue.py tests/test_gpu_pem_pre.py tests/test_gpu_zz_pipeline.py -q -s 2>&1 | tail -10 > gpurun_out/n2_pem_pre_kernels.txt
 timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > gpurun_out/n3_gpu_suite.txt
 # 2. the segmentor plugin end to end (ViT-H, seeded weights) and the five-model frame chain
 timeout 600 python tools/segmentor_demo.py > gpurun_out/n4_segmentor_demo.txt 2>&1

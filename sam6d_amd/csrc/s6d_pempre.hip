@@ -147,21 +147,22 @@ __global__ __launch_bounds__(kCmpThreads) void compact_cloud_kernel(const unsign
   __syncthreads();
   if (ok[p]) {
     const long y1 = box[p * 4 + 0], y2 = box[p * 4 + 1], x1 = box[p * 4 + 2], x2 = box[p * 4 + 3];
-    const long bw = x2 - x1, area = (y2 - y1) * bw;
+    const int bw = (int)(x2 - x1), area = (int)(y2 - y1) * bw;    // a crop is at most min(H,W)^2 pixels: 32-bit index arithmetic
     const unsigned char *mp = m + (size_t)p * H * W;
-    for (long c0 = 0; c0 < area; c0 += kCmpThreads) {
-      const long j = c0 + tid;
+    for (int c0 = 0; c0 < area; c0 += kCmpThreads) {
+      const int j = c0 + tid;
       bool keep = false;
-      long y = 0, x = 0;
+      int y = 0, x = 0;
       if (j < area) {
-        y = y1 + j / bw;
-        x = x1 + j % bw;
+        const int r = j / bw;
+        y = (int)y1 + r;
+        x = (int)x1 + (j - r * bw);
         keep = mp[y * W + x] != 0;
       }
       const long pos = block_rank(keep, &base, wave_tot);
       if (keep) {
         const float z = depth[y * W + x];
-        choose[(size_t)p * cap + pos] = (int)j;
+        choose[(size_t)p * cap + pos] = j;
         float *c = cloud + ((size_t)p * cap + pos) * 3;
         c[0] = ((float)x - cx) * z / fx;
         c[1] = ((float)y - cy) * z / fy;

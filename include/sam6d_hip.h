@@ -165,6 +165,17 @@ long s6d_win_attention_scratch_bytes(int H, int window, int head_dim);
 int s6d_add_layernorm_bf16(const void *x, const void *delta, const float *gamma, const float *beta, float eps,
                            long rows, int C, void *x_out, void *y_out, void *stream);
 
+/* C = epilogue(A W^T + bias): the nn.Linear layers of the ViTs with the bias and the activation folded into the GEMM.
+ * A (M,K) bf16, row stride lda; W (N,K) bf16 = nn.Linear.weight, row stride ldw; bias (N) f32 or NULL; C (M,N) bf16, row
+ * stride ldc (strides in elements, multiples of 8; 16-byte aligned bases).  epilogue: 0 = none, 1 = exact (erf) GELU.
+ * N % 256 == 0, K % 64 == 0, any M.  max_blocks: workgroups to launch (<= 0: one persistent workgroup per CU, 256).
+ * fp32 accumulation on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16), one rounding to bf16 at the end.
+ * ref: segment_anything/modeling/common.py:13-28 (MLPBlock: lin1 -> GELU -> lin2), image_encoder.py:224-240 (qkv, proj),
+ * :90-104 (neck 1x1 conv); the same statements in timm's ViT-B (Pose_Estimation_Model/model/feature_extraction.py:17-35)
+ * and DINOv2 ViT-L (Instance_Segmentation_Model/model/layers/{attention,mlp}.py). */
+int s6d_gemm_bf16(const void *A, long lda, const void *W, long ldw, const float *bias, void *C, long ldc, int M, int N,
+                  int K, int epilogue, int max_blocks, void *stream);
+
 /* ---------------------------------------------------------------- ISM proposal-vs-template scoring */
 
 /* clamp(cosine(query_p, ref_r), 0, 1): query (P,C), ref (R = O*T, C) f32 -> out (P,R) f32; C % 16 == 0.

@@ -1,0 +1,440 @@
+// bf16 GEMM with fused epilogue for the Linear layers of the ViTs on the hot path (gfx950):  C = epi(A W^T + bias).
+//
+// Reference (the nn.Linear calls this replaces; the reference runs them through cuBLAS and a separate GELU kernel):
+//   segment_anything/modeling/common.py:13-28         MLPBlock  lin1 (1280 -> 5120) + exact GELU, lin2 (5120 -> 1280)
+//   segment_anything/modeling/image_encoder.py:224-240 Attention qkv (1280 -> 3840), proj (1280 -> 1280)
+//   segment_anything/modeling/image_encoder.py:90-104  neck 1x1 conv (= Linear 1280 -> 256 on channels-last tokens)
+//   Pose_Estimation_Model/model/feature_extraction.py:17-35 (timm ViT-B blocks), Instance_Segmentation_Model/model/layers/
+//   {attention,mlp}.py (DINOv2 ViT-L blocks) -- same Linear / GELU statements.
+// A (M,K) activations and W (N,K) nn.Linear weight are both K-contiguous, so both operands are read the same way.
+//
+// Structure (one 512-thread workgroup per CU, 256 x 256 output tile, K step 64, persistent over its share of the tiles):
+//   * operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4) in HALF-TILES of 128 rows x 64 k (16 KiB).  All of
+//     the CU's 160 KiB LDS is one ring of 10 half-tile slots; half-tiles are issued in stream order B0 B1 A0 A1 per K tile,
+//     one per phase, 6 phases (1.5 K tiles) ahead of the phase that first reads them, and the stream runs across output-tile
+//     boundaries, so the next tile's operands arrive while this tile's epilogue runs.  Waits are COUNTED (vmcnt(8) / (6)):
+//     the queue never drains inside the loop.
+//   * LDS image of a half-tile: [128 rows][8 chunks of 16 B], chunk position c' = c ^ ((row >> 1) & 7).  The DMA writes
+//     lane-linear, so the permutation is applied to each lane's SOURCE address (it stays inside one 128-byte line) and again
+//     on the fragment read: every ds_read_b128 lane group then covers 16 distinct 16-byte bank slots (conflict-free).
+//   * 8 waves = 2 (M) x 4 (N); a wave owns 128 x 64 of the tile as 4 x 2 MFMA tiles (v_mfma_f32_32x32x16_bf16).  The
+//     product is formed TRANSPOSED (W fragment as the A operand, activation fragment as B): a lane then holds one output
+//     row and 4 consecutive output columns per register quad, which makes the epilogue stores 16 B per lane.
+//   * a K tile is 4 phases (one 64 x 32 quadrant of the wave's tile over the whole K step each); the two wave groups
+//     (M halves) run one barrier apart, so on every SIMD one wave is in its matrix segment (8 MFMAs) while the other issues
+//     its fragment reads and DMA: phase = { ds_read, DMA issue, [counted wait], barrier, 8 x MFMA, barrier }.
+//   * epilogue in registers: bias is the accumulator's initial value (scalar loads), exact GELU as
+//     relu(x) - |x| * erfc(|x| / sqrt 2) / 2 with erfc from Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7), round to bf16,
+//     v_permlane32_swap pairs the two lane halves into 16-byte row segments.
+#include "s6d_common.h"
+#include <stdlib.h>
+
+namespace s6d {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef unsigned short u16;
+#define S6D_LDS(T) __attribute__((address_space(3))) T
+#define S6D_GLOBAL(T) __attribute__((address_space(1))) T
+
+#ifdef HIPEMU
+#define S6D_VMCNT(n) hipemu::vmcnt_wait(n)
+#define S6D_CONST(T) T
+#else
+#define S6D_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define S6D_CONST(T) __attribute__((address_space(4))) T   // uniform address + constant address space = s_load (lgkmcnt, not vmcnt)
+#endif
+// An MFMA is a pure register operation: neither s_barrier nor sched_barrier orders it at instruction-selection time (it has
+// no chain), so the matrix segment is tied down by data: an empty asm makes the operands opaque after the opening barrier
+// (no MFMA can be placed above it) and the accumulators opaque before the closing one (none can sink below it).
+#ifdef HIPEMU
+#define S6D_PIN(x)
+#else
+#define S6D_PIN(x) asm volatile("" : "+v"(x))
+#endif
+// hipcc treats s_barrier as a memory fence only: register-only MFMAs drift across it (and past s_setprio) unless pinned
+#define S6D_BARRIER()                     \
+  do {                                    \
+    __builtin_amdgcn_sched_barrier(0);    \
+    __builtin_amdgcn_s_barrier();         \
+    __builtin_amdgcn_sched_barrier(0);    \
+  } while (0)
+
+// Profiling switches, COMPILE-time (tools/gemm_variants.sh builds one library per setting; the product library has none):
+//   S6D_GEMM_ABLATE bit 1 = no LDS-DMA, 2 = no MFMA (fragment reads stay), 4 = no epilogue stores;  S6D_GEMM_NOPRIO = no s_setprio
+#ifndef S6D_GEMM_ABLATE
+#define S6D_GEMM_ABLATE 0
+#endif
+#ifdef S6D_GEMM_NOPRIO
+#define S6D_SETPRIO(n)
+#else
+#define S6D_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#endif
+
+struct GemmParams {
+  const u16 *A;       // (M,K) bf16, row stride lda
+  const u16 *W;       // (N,K) bf16, row stride ldw
+  const float *bias;  // (N) f32 or nullptr
+  u16 *C;             // (M,N) bf16, row stride ldc
+  unsigned lda2, ldw2;  // row strides in BYTES
+  long ldc;
+  int M, N, K;
+  int MT, NT, nk, ntiles;
+  int GM;             // m-tiles per group of the tile order
+};
+
+constexpr int kSlot = 16384;  // one half-tile: 128 rows x 64 k bf16
+constexpr int kRing = 10;     // slots: all 160 KiB of the CU
+
+extern __shared__ __attribute__((aligned(16))) char gemm_smem[];
+
+__device__ __forceinline__ int ring(int s) { return s >= kRing ? s - kRing : s; }
+
+// exact GELU, x Phi(x) = relu(x) - |x| * 0.5 erfc(|x| / sqrt 2); erfc(z) = t (a1 + t (a2 + ... t a5)) exp(-z^2),
+// t = 1 / (1 + p z)  (Abramowitz & Stegun 7.1.26, absolute error <= 1.5e-7); exp(-z^2) = exp2(-(z sqrt(log2 e))^2)
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float ax = fabsf(x);
+  const float zs = ax * 0.84932180028801904f;                           // |x| sqrt(log2(e) / 2)
+  const float e = __builtin_amdgcn_exp2f(-zs * zs);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.0f));
+  float poly = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+  poly = fmaf(t, poly, 0.5f * 1.421413741f);
+  poly = fmaf(t, poly, 0.5f * -0.284496736f);
+  poly = fmaf(t, poly, 0.5f * 0.254829592f);
+  const float h = poly * t * e;                                         // erfc(|x| / sqrt 2) / 2
+  return fmaf(-ax, h, fmaxf(x, 0.f));
+}
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+  union { __bf16 b; u16 u; } a, c;
+  a.b = (__bf16)lo;                                                     // round-to-nearest-even
+  c.b = (__bf16)hi;
+  return (unsigned)a.u | ((unsigned)c.u << 16);
+}
+
+template <int EPI, bool HAS_BIAS>
+__global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;       // M half / N quarter of the 256 x 256 tile
+
+  // ---- tile schedule.  Workgroup b runs on XCD b % 8 (observed dispatch rule; used for speed only): XCD x takes a
+  // contiguous range of the logical tile order, its workgroups walk that range with stride (workgroups per XCD), and
+  // the logical order goes down GM m-tiles before moving to the next n-tile, so the tiles one XCD works on at a time share
+  // A panels and W panels through its L2.
+  const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+  const int tq = p.ntiles >> 3, tr = p.ntiles & 7;
+  const int first = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+  const int cnt = tq + (xcd < tr ? 1 : 0);
+  if (bi >= cnt) return;
+  const int my_tiles = (cnt - bi + bpx - 1) / bpx;
+  const int G = my_tiles * p.nk;                 // K tiles this workgroup streams through
+
+  auto tile_mn = [&](int j, int &m0, int &n0) __attribute__((always_inline)) {
+    const int L = first + bi + j * bpx;
+    const int tpg = p.GM * p.NT;
+    const int grp = L / tpg, rem = L - grp * tpg;
+    const int mf = grp * p.GM;
+    const int gs = min(p.GM, p.MT - mf);
+    const int nn = rem / gs;
+    m0 = (mf + rem - nn * gs) * 256;
+    n0 = nn * 256;
+  };
+
+  // ---- staging geometry: wave w fills rows [16 w, 16 w + 16) of a half-tile in two 1-KiB pieces (8 rows x 128 B each);
+  // lane -> row (lane >> 3), chunk position (lane & 7); the chunk it fetches is position ^ ((row >> 1) & 7)
+  const int srow = wave * 16 + (lane >> 3);
+  const unsigned sc0 = (unsigned)(((lane & 7) ^ (lane >> 4)) << 4);     // piece 0; piece 1 (rows + 8): sc0 ^ 64
+  const unsigned sd1 = (sc0 ^ 64u) - sc0;
+  unsigned a_off[2][2], b_off = 0;
+  int ia_kt = 0, ia_tile = 0, ib_kt = 0, ib_tile = 0;                   // issue cursors (K tile within the output tile, tile)
+  auto set_a = [&](int tile) __attribute__((always_inline)) {
+    int m0, n0;
+    tile_mn(tile, m0, n0);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)                                       // rows past M re-read row M - 1 (never stored)
+        a_off[a][i] = (unsigned)min(m0 + a * 128 + srow + 8 * i, p.M - 1) * p.lda2 + (sc0 ^ (unsigned)(i * 64));
+  };
+  auto set_b = [&](int tile) __attribute__((always_inline)) {
+    int m0, n0;
+    tile_mn(tile, m0, n0);
+    b_off = (unsigned)(n0 + srow) * p.ldw2 + sc0;
+  };
+  auto dma = [&](const u16 *base, unsigned off, int slot, int piece) __attribute__((always_inline)) {
+    S6D_LDS(char) *dst = (S6D_LDS(char) *)gemm_smem + slot * kSlot + (wave * 2 + piece) * 1024;
+    if (S6D_GEMM_ABLATE & 1) return;
+    __builtin_amdgcn_global_load_lds((const S6D_GLOBAL(void) *)((const char *)base + off), dst, 16, 0, 0);
+  };
+  auto issue_b = [&](int half, int slot) __attribute__((always_inline)) {
+    const unsigned o = b_off + (unsigned)ib_kt * 128u + (unsigned)half * 128u * p.ldw2;
+    dma(p.W, o, slot, 0);
+    dma(p.W, o + 8u * p.ldw2 + sd1, slot, 1);
+    if (half == 1 && ++ib_kt == p.nk) {
+      ib_kt = 0;
+      if (++ib_tile < my_tiles) set_b(ib_tile);
+    }
+  };
+  auto issue_a = [&](int half, int slot) __attribute__((always_inline)) {
+    const unsigned k = (unsigned)ia_kt * 128u;
+    dma(p.A, a_off[half][0] + k, slot, 0);
+    dma(p.A, a_off[half][1] + k, slot, 1);
+    if (half == 1 && ++ia_kt == p.nk) {
+      ia_kt = 0;
+      if (++ia_tile < my_tiles) set_a(ia_tile);
+    }
+  };
+
+  // ---- fragment geometry (32x32x16: lane -> row lane & 31, 8 consecutive k at 8 (lane >> 5) of the 16-wide k step)
+  unsigned foff[4];
+  {
+    const int sw = (lane >> 1) & 7, hb = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) foff[ks] = (unsigned)((lane & 31) * 128 + ((((2 * ks) | hb) ^ sw) << 4));
+  }
+  const unsigned brow = (unsigned)((wc & 1) * 64 * 128);                // this wave's 64 W rows inside its B half-tile
+  auto frag = [&](int slot, unsigned rowbytes, int ks) __attribute__((always_inline)) -> bf16x8 {
+    return *reinterpret_cast<const bf16x8 *>(gemm_smem + slot * kSlot + rowbytes + foff[ks]);
+  };
+
+  f32x16 acc[4][2];                                                      // [m tile][n tile], transposed: lane -> m, regs -> n
+  bf16x8 xf[2][4], wf[2][4];                                             // activation rows (2 m tiles), W rows (2 n tiles) x 4 k steps
+  int ct = 0, ck = 0;                                                    // compute cursor
+  int cm0, cn0;
+  tile_mn(0, cm0, cn0);
+
+  auto init_acc = [&](int n0) __attribute__((always_inline)) {                                          // accumulators start at the bias (scalar loads)
+    const int nb = __builtin_amdgcn_readfirstlane(n0 + wc * 64);
+    const S6D_CONST(float) *bs = (const S6D_CONST(float) *)p.bias + nb;
+    const bool hi = (lane >> 5) != 0;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        float v[8];                                                      // bias of columns 32 nt + 8 qd + {0..7}
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = HAS_BIAS ? bs[nt * 32 + 8 * qd + e] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float b = hi ? v[4 + e] : v[e];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) acc[mt][nt][4 * qd + e] = b;
+        }
+      }
+  };
+
+  auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) {
+    const int hb = lane >> 5;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int m = m0 + wr * 128 + mt * 32 + (lane & 31);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        unsigned pk[4][2];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[mt][nt][4 * qd + e];
+            if (EPI == 1) v[e] = gelu_erf(v[e]);
+          }
+          pk[qd][0] = pack_bf16(v[0], v[1]);
+          pk[qd][1] = pack_bf16(v[2], v[3]);
+        }
+        // quad qd holds columns 8 qd + 4 hb + {0..3}: swapping the upper lane half of quad 2j with the lower lane half of
+        // quad 2j + 1 leaves each lane 8 consecutive columns 16 j + 8 hb + {0..7} of its row
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          uint4 o;
+          {
+            auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * j][0], pk[2 * j + 1][0], false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * j][1], pk[2 * j + 1][1], false, false);
+            o.x = s0[0];
+            o.y = s1[0];
+            o.z = s0[1];
+            o.w = s1[1];
+          }
+          if (S6D_GEMM_ABLATE & 4) {
+#ifndef HIPEMU
+            asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));   // keep the epilogue arithmetic alive
+#endif
+          } else if (m < p.M) {
+            u16 *dst = p.C + (size_t)m * p.ldc + (n0 + wc * 64 + nt * 32 + 16 * j + 8 * hb);
+            *reinterpret_cast<uint4 *>(dst) = o;
+          }
+        }
+      }
+    }
+  };
+
+#define S6D_MFMA(C, A, B)                                                              \
+  do {                                                                                 \
+    if (S6D_GEMM_ABLATE & 2) {                                                         \
+      S6D_PIN(B);                                                                      \
+    } else {                                                                           \
+      C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0);                   \
+    }                                                                                  \
+  } while (0)
+#define S6D_MSEG(QM, QN)                                                               \
+  do {                                                                                 \
+    S6D_SETPRIO(1);                                                                    \
+    S6D_PIN(wf[QN][0]);                                                                \
+    S6D_PIN(wf[QN][1]);                                                                \
+    S6D_PIN(wf[QN][2]);                                                                \
+    S6D_PIN(wf[QN][3]);                                                                \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                 \
+      S6D_MFMA(acc[2 * QM][QN], wf[QN][ks], xf[0][ks]);                                \
+      S6D_MFMA(acc[2 * QM + 1][QN], wf[QN][ks], xf[1][ks]);                            \
+    }                                                                                  \
+    S6D_PIN(acc[2 * QM][QN]);                                                          \
+    S6D_PIN(acc[2 * QM + 1][QN]);                                                      \
+    S6D_SETPRIO(0);                                                                    \
+  } while (0)
+
+  // ---- prologue: half-tiles 0..6 of the stream (K tile 0 whole; B0 B1 A0 of K tile 1)
+  set_b(0);
+  set_a(0);
+  issue_b(0, 0);
+  issue_b(1, 1);
+  issue_a(0, 2);
+  issue_a(1, 3);
+  if (G > 1) {
+    issue_b(0, 4);
+    issue_b(1, 5);
+    issue_a(0, 6);
+    S6D_VMCNT(6);
+  } else {
+    S6D_VMCNT(0);
+  }
+  init_acc(cn0);
+  S6D_BARRIER();
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) wf[0][ks] = frag(wc >> 1, brow, ks);      // B(0), n tile 0
+  if (wr == 1) S6D_BARRIER();                             // the M halves run one barrier apart from here on
+
+  int s0 = 0;                                                            // ring slot of B0 of K tile g: (4 g) % 10
+  for (int g = 0; g < G; ++g) {
+    const int sA = ring(s0 + 2 + wr);                                    // A[wr](g)
+    const int sB = s0 + (wc >> 1);                                       // B[wc >> 1](g)
+    const int sBn = ring(s0 + 4 + (wc >> 1));                            // B[wc >> 1](g + 1)
+    const bool more1 = g + 1 < G, more2 = g + 2 < G;
+
+    // phase 1: activation rows 0..63 of this wave -> quadrant (0,0)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) xf[i][ks] = frag(sA, (unsigned)(i * 4096), ks);
+    if (more1) issue_a(1, ring(s0 + 7));                                 // A1(g + 1)
+    S6D_BARRIER();
+    S6D_MSEG(0, 0);
+    S6D_BARRIER();
+
+    // phase 2: W rows 32..63 of this wave -> quadrant (0,1)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wf[1][ks] = frag(sB, brow + 4096u, ks);
+    if (more2) issue_b(0, ring(s0 + 8));                                 // B0(g + 2)
+    S6D_BARRIER();
+    S6D_MSEG(0, 1);
+    S6D_BARRIER();
+
+    // phase 3: activation rows 64..127 -> quadrant (1,0)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) xf[i][ks] = frag(sA, (unsigned)((2 + i) * 4096), ks);
+    if (more2) {
+      issue_b(1, ring(s0 + 9));                                          // B1(g + 2)
+      S6D_VMCNT(8);                                                      // B(g + 1) has landed (4 younger half-tiles in flight)
+    } else {
+      S6D_VMCNT(0);
+    }
+    S6D_BARRIER();
+    S6D_MSEG(1, 0);
+    S6D_BARRIER();
+
+    // phase 4: next K tile's W rows 0..31 (wf[0] is free after quadrant (1,0)) -> quadrant (1,1)
+    if (more1) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) wf[0][ks] = frag(sBn, brow, ks);
+    }
+    if (more2) {
+      issue_a(0, s0);                                                    // A0(g + 2) into the slot B0(g) just left
+      S6D_VMCNT(6);                                                      // A(g + 1) has landed (3 younger half-tiles in flight)
+    } else {
+      S6D_VMCNT(0);
+    }
+    S6D_BARRIER();
+    S6D_MSEG(1, 1);
+    S6D_BARRIER();
+
+    s0 = ring(s0 + 4);
+    if (++ck == p.nk) {                                                  // output tile complete
+      ck = 0;
+      // both M halves run the epilogue in the same interval (their VALU work shares the SIMDs either way; running it
+      // one after the other would leave one wave per SIMD): the leading half waits one barrier, the trailing half gives
+      // one back afterwards, which also restores the one-barrier stagger
+      if (wr == 0) S6D_BARRIER();
+      epilogue(cm0, cn0);
+      if (++ct < my_tiles) {
+        tile_mn(ct, cm0, cn0);
+        init_acc(cn0);
+      }
+      if (wr == 1) S6D_BARRIER();
+    }
+  }
+  if (wr == 0) S6D_BARRIER();                             // same barrier count for both halves
+#undef S6D_MSEG
+#undef S6D_MFMA
+}
+
+}  // namespace s6d
+
+using namespace s6d;
+
+extern "C" int s6d_gemm_bf16(const void *A, long lda, const void *W, long ldw, const float *bias, void *C, long ldc, int M,
+                             int N, int K, int epilogue, int max_blocks, void *stream) {
+  if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return S6D_EINVAL;
+  if (N % 256 != 0 || K % 64 != 0 || lda < K || ldw < K || ldc < N) return S6D_EINVAL;
+  if ((lda % 8) || (ldw % 8) || (ldc % 8)) return S6D_EINVAL;           // 16-byte rows
+  if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) return S6D_EINVAL;
+  if (epilogue != 0 && epilogue != 1) return S6D_EINVAL;
+  // staging addresses are 32-bit byte offsets from A / W
+  if ((double)M * (double)lda * 2.0 >= 2147483648.0 || (double)N * (double)ldw * 2.0 >= 2147483648.0) return S6D_EUNSUPPORTED;
+  GemmParams p;
+  p.A = (const u16 *)A;
+  p.W = (const u16 *)W;
+  p.bias = bias;
+  p.C = (u16 *)C;
+  p.lda2 = (unsigned)(lda * 2);
+  p.ldw2 = (unsigned)(ldw * 2);
+  p.ldc = ldc;
+  p.M = M;
+  p.N = N;
+  p.K = K;
+  p.MT = (M + 255) / 256;
+  p.NT = N / 256;
+  p.nk = K / 64;
+  p.ntiles = p.MT * p.NT;
+  const char *gm_env = getenv("S6D_GEMM_GM");                            // tile-order experiment knob
+  p.GM = (gm_env && atoi(gm_env) > 0) ? atoi(gm_env) : 8;
+  if (max_blocks <= 0) max_blocks = 256;                                 // one persistent workgroup per CU
+  int grid = p.ntiles < max_blocks ? p.ntiles : max_blocks;
+  grid = (grid + 7) & ~7;                                                // whole XCD rounds
+  const size_t lds = (size_t)kRing * kSlot;
+  hipStream_t st = as_stream(stream);
+#define S6D_GEMM_LAUNCH(E, HB)                                                                                          \
+  do {                                                                                                                  \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<E, HB>),                                 \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                    \
+    hipLaunchKernelGGL((gemm_bf16_kernel<E, HB>), dim3(grid), dim3(512), lds, st, p);                                   \
+  } while (0)
+  if (epilogue == 1) {
+    if (bias) S6D_GEMM_LAUNCH(1, true); else S6D_GEMM_LAUNCH(1, false);
+  } else {
+    if (bias) S6D_GEMM_LAUNCH(0, true); else S6D_GEMM_LAUNCH(0, false);
+  }
+#undef S6D_GEMM_LAUNCH
+  return launch_status();
+}

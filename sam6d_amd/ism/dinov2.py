@@ -28,6 +28,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from ..utils.linear import eligible, fused_linear
 
 descriptor_size = {"dinov2_vits14": 384, "dinov2_vitb14": 768, "dinov2_vitl14": 1024, "dinov2_vitg14": 1536}
 descriptor_map = {"dinov2_vits14": "vit_small", "dinov2_vitb14": "vit_base", "dinov2_vitl14": "vit_large",
@@ -114,7 +115,7 @@ class Block(nn.Module):
 
     # -- fused path helpers ---------------------------------------------------------------------------------------
     def _folded(self, dtype):
-        """(W_proj, b_proj, W_fc2, b_fc2) with the LayerScale gains folded in, cached per weight version."""
+        """(W_proj, b_proj, b_proj_f32, W_fc2, b_fc2, b_fc2_f32) with the LayerScale gains folded in, cached per weight version."""
         srcs = [self.attn.proj.weight, self.attn.proj.bias, self.mlp.fc2.weight, self.mlp.fc2.bias]
         g1 = self.ls1.gamma if isinstance(self.ls1, LayerScale) else None
         g2 = self.ls2.gamma if isinstance(self.ls2, LayerScale) else None
@@ -126,7 +127,7 @@ class Block(nn.Module):
                     w, b = w.detach().float(), b.detach().float()
                     if g is not None:
                         w, b = w * g.detach().float()[:, None], b * g.detach().float()
-                    return w.to(dtype).contiguous(), b.to(dtype).contiguous()
+                    return w.to(dtype).contiguous(), b.to(dtype).contiguous(), b.contiguous()
                 c = (key,) + fold(srcs[0], srcs[1], g1) + fold(srcs[2], srcs[3], g2)
             self._s6d_folded = c
         return c[1:]
@@ -204,13 +205,18 @@ class DinoVisionTransformer(nn.Module):
         delta = None
         scale = (self.embed_dim // self.num_heads) ** -0.5
         for blk in self.blocks:
-            wp, bp, w2, b2 = blk._folded(x.dtype)
+            wp, bp, bpf, w2, b2, b2f = blk._folded(x.dtype)
+            own = eligible(x, wp.shape[0], wp.shape[1]) and eligible(x, w2.shape[0], w2.shape[1])   # s6d_gemm_bf16
             g, b = _ln_f32(blk.norm1)
             x, h = ops.add_layernorm(x, delta, g, b, blk.norm1.eps)
-            a = F.linear(ops.seq_attention(blk.attn.qkv(h).contiguous(), blk.attn.num_heads, scale), wp, bp)
+            o = ops.seq_attention(fused_linear(blk.attn.qkv, h).contiguous(), blk.attn.num_heads, scale)
+            a = ops.gemm_bf16(o, wp, bpf) if own else F.linear(o, wp, bp)
             g, b = _ln_f32(blk.norm2)
             x, h = ops.add_layernorm(x, a, g, b, blk.norm2.eps)
-            delta = F.linear(blk.mlp.act(blk.mlp.fc1(h)), w2, b2)
+            if own and isinstance(blk.mlp.act, nn.GELU) and blk.mlp.act.approximate == "none":
+                delta = ops.gemm_bf16(fused_linear(blk.mlp.fc1, h, gelu=True), w2, b2f)
+            else:
+                delta = F.linear(blk.mlp.act(blk.mlp.fc1(h)), w2, b2)
         g, b = _ln_f32(self.norm)
         return ops.add_layernorm(x, delta, g, b, self.norm.eps)
 

@@ -427,6 +427,33 @@ def seq_attention(qkv, num_heads, scale):
     return out
 
 
+def gemm_bf16(a, w, bias=None, gelu=False, out=None, max_blocks=0):
+    """a (..., K) bf16 (rows may be strided), w (N, K) bf16 = nn.Linear.weight, bias (N) f32 or None ->
+    act(a @ w.T + bias) (..., N) bf16 with act = exact GELU or identity; N % 256 == 0, K % 64 == 0."""
+    if not a.is_cuda or not w.is_cuda:
+        raise RuntimeError("a and w must be CUDA tensors")
+    if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
+        raise RuntimeError("a and w must be bfloat16 tensors")
+    K = a.shape[-1]
+    N = w.shape[0]
+    a2 = a.reshape(-1, K)
+    if a2.stride(1) != 1 or a2.stride(0) % 8 or a2.data_ptr() % 16:
+        a2 = a2.contiguous()
+    if w.dim() != 2 or w.shape[1] != K or w.stride(1) != 1 or w.stride(0) % 8:
+        raise RuntimeError("w must be (N, K) with contiguous rows")
+    if bias is not None:
+        _chk(bias, torch.float32, "bias", 1)
+    M = a2.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    else:
+        _chk(out, torch.bfloat16, "out", 2)
+    _call("s6d_gemm_bf16", _ptr(a2), ctypes.c_long(a2.stride(0)), _ptr(w), ctypes.c_long(w.stride(0)),
+          _ptr(bias) if bias is not None else _vp(0), _ptr(out), ctypes.c_long(out.stride(0)), M, N, K, 1 if gelu else 0,
+          int(max_blocks), _stream())
+    return out.reshape(*a.shape[:-1], N)
+
+
 def add_layernorm(x, delta, gamma, beta, eps):
     """x (...,C) bf16, delta same shape or None, gamma/beta (C) f32 -> (x + delta, LN(x + delta)) bf16."""
     _chk(x, torch.bfloat16, "x")
@@ -613,7 +640,7 @@ def have(name):
     if name not in _FUSED:
         sym = {"rpe_attention": "s6d_rpe_attention_f32", "geo_embedding": "s6d_geo_embedding_f32",
                "fine_assign": "s6d_fine_assign_f32", "upsample_gather": "s6d_upsample_gather_f32",
-               "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "add_layernorm": "s6d_add_layernorm_bf16", "win_attention": "s6d_win_attention_bf16",
+               "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "add_layernorm": "s6d_add_layernorm_bf16", "gemm_bf16": "s6d_gemm_bf16", "win_attention": "s6d_win_attention_bf16",
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
                "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_f32",

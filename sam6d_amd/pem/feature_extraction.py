@@ -19,6 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from ..utils.linear import fused_linear
 
 
 def _vit_dtype():
@@ -47,7 +48,7 @@ class _Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden, dim)
 
     def forward(self, x):
-        return self.fc2(F.gelu(self.fc1(x)))
+        return fused_linear(self.fc2, fused_linear(self.fc1, x, gelu=True))
 
 
 class _Block(nn.Module):
@@ -125,8 +126,9 @@ def _vit_forward_fused(self, x, taps):
     for i, blk in enumerate(self.blocks):
         g, b = _ln_f32(blk.norm1)
         x, h = ops.add_layernorm(x, delta, g, b, blk.norm1.eps)
-        qkv = blk.attn.qkv(h)
-        a = blk.attn.proj(ops.seq_attention(qkv.contiguous(), blk.attn.num_heads, (x.shape[-1] // blk.attn.num_heads) ** -0.5))
+        qkv = fused_linear(blk.attn.qkv, h)
+        a = fused_linear(blk.attn.proj,
+                         ops.seq_attention(qkv.contiguous(), blk.attn.num_heads, (x.shape[-1] // blk.attn.num_heads) ** -0.5))
         g, b = _ln_f32(blk.norm2)
         x, h = ops.add_layernorm(x, a.contiguous(), g, b, blk.norm2.eps)
         delta = blk.mlp(h).contiguous()

@@ -23,6 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from ..utils.linear import fused_linear
 
 
 def _dtype():
@@ -39,6 +40,9 @@ class MLPBlock(nn.Module):
     def forward(self, x):
         rows = int(os.environ.get("S6D_SAM_MLP_ROWS", "0"))
         if rows <= 0 or x.numel() // x.shape[-1] <= rows:
+            if isinstance(self.act, nn.GELU) and self.act.approximate == "none":
+                # lin1 + bias + exact GELU in one GEMM epilogue, lin2 + bias in the other (common.py:13-28)
+                return fused_linear(self.lin2, fused_linear(self.lin1, x, gelu=True))
             return self.lin2(self.act(self.lin1(x)))
         # Experiment knob (off by default, not yet measured): run lin1 -> GELU -> lin2 over row chunks so that a chunk's
         # (rows, mlp_dim) intermediate -- 168 MB at 16384 rows of ViT-H in bf16 -- can stay in the 256 MB Infinity Cache
@@ -71,7 +75,7 @@ class PatchEmbed(nn.Module):
         B, C, H, W = x.shape
         p = self.proj.kernel_size[0]
         x = x.view(B, C, H // p, p, W // p, p).permute(0, 2, 4, 1, 3, 5).reshape(B, H // p, W // p, C * p * p)
-        return F.linear(x, self.proj.weight.flatten(1).to(x.dtype), self.proj.bias.to(x.dtype))
+        return fused_linear(self.proj, x, weight2d=self.proj.weight.flatten(1))
 
 
 def _rel_table(size, rel_pos):
@@ -102,7 +106,7 @@ class Attention(nn.Module):
     def forward(self, x, window_size=0):
         """x: (B,H,W,C) token map (already normed).  window_size 0 = global attention."""
         B, H, W, C = x.shape
-        qkv = self.qkv(x)                                            # (B,H,W,3C): real tokens only
+        qkv = fused_linear(self.qkv, x)                              # (B,H,W,3C): real tokens only
         if ops.have("win_attention") and x.is_cuda and x.dtype == torch.bfloat16 and self.use_rel_pos:
             S = window_size if window_size > 0 else H
             out = ops.window_attention(qkv.contiguous(), self.qkv.bias.to(qkv.dtype),
@@ -111,7 +115,7 @@ class Attention(nn.Module):
                                        self.num_heads, window_size, self.scale)
         else:
             out = self._attention_lib(qkv, B, H, W, C, window_size)
-        return self.proj(out)
+        return fused_linear(self.proj, out)
 
     def _attention_lib(self, qkv, B, H, W, C, ws):
         """Library-op statement of the same computation (device tensors; used when the fused
@@ -232,7 +236,7 @@ class ImageEncoderViT(nn.Module):
         c1, n1, c3, n2 = self.neck[0], self.neck[1], self.neck[2], self.neck[3]
         B, H, W, C = t.shape
         dt = t.dtype
-        y = F.linear(t, c1.weight.flatten(1).to(dt))
+        y = fused_linear(c1, t, weight2d=c1.weight.flatten(1))
         y = F.layer_norm(y.float(), (y.shape[-1],), n1.weight.float(), n1.bias.float(), n1.eps).to(dt)
         Co = y.shape[-1]
         yp = F.pad(y, (0, 0, 1, 1, 1, 1))                                   # zero pad H and W by 1

@@ -1,0 +1,38 @@
+"""nn.Linear (+ exact GELU) through the hand-written bf16 GEMM (csrc/s6d_gemm.hip) for the ViTs on the hot path.
+
+The modules keep their nn.Linear parameters (state_dict surface of the reference unchanged); this helper only decides
+how the statement  act(x @ W^T + b)  is executed: on a device bf16 activation with N % 256 == 0 and K % 64 == 0 it is one
+launch of s6d_gemm_bf16 (bias and GELU in the epilogue), otherwise the library statement.  `S6D_DISABLE_FUSED=gemm_bf16`
+turns the kernel off (A/B runs)."""
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+
+
+def _cached(lin, w2d):
+    """bf16 weight (N,K) + fp32 bias of a Linear / 1x1-or-patch Conv, cached until the parameters change."""
+    b = lin.bias
+    key = (lin.weight._version, lin.weight.data_ptr(), lin.weight.dtype, None if b is None else (b._version, b.data_ptr()))
+    c = getattr(lin, "_s6d_gemm", None)
+    if c is None or c[0] != key:
+        wb = w2d.detach().to(torch.bfloat16).contiguous()
+        bf = None if b is None else b.detach().float().contiguous()
+        c = (key, wb, bf)
+        lin._s6d_gemm = c
+    return c[1], c[2]
+
+
+def eligible(x, n_out, k_in):
+    return (x.is_cuda and x.dtype == torch.bfloat16 and n_out % 256 == 0 and k_in % 64 == 0 and ops.have("gemm_bf16"))
+
+
+def fused_linear(lin, x, gelu=False, weight2d=None):
+    """act(lin(x)); `weight2d` overrides lin.weight for conv weights viewed as (N, K)."""
+    w = lin.weight if weight2d is None else weight2d
+    N, K = w.shape
+    if eligible(x, N, K):
+        wb, bf = _cached(lin, w)
+        return ops.gemm_bf16(x, wb, bf, gelu=gelu)
+    y = F.linear(x, w.to(x.dtype), None if lin.bias is None else lin.bias.to(x.dtype))
+    return F.gelu(y) if gelu else y

@@ -67,11 +67,17 @@ static inline hipError_t hipFuncSetAttribute(F, int, int) { return hipSuccess; }
 
 namespace hipemu {
 
+struct PendingDma {                        // an LDS-DMA (global_load_lds) that has been issued but has not landed yet
+  const void *src;
+  void *dst;
+  int bytes;
+};
 struct Lane {
   void *sp = nullptr;                       // saved stack pointer while the lane is switched out
   std::vector<char> stack;
   dim3 tid;
   bool done = false;
+  std::vector<PendingDma> vm;               // in issue order (HIPEMU_GLDS=late only)
 };
 
 struct Block {
@@ -104,6 +110,12 @@ void yield();
 void block_barrier();
 void wave_barrier();
 void run_grid(dim3 grid, dim3 block, size_t shmem, std::function<void()> body);
+// LDS-DMA.  The hardware may land the data any time between the issue and the issuing wave's covering s_waitcnt vmcnt(N).
+// HIPEMU_GLDS=early (default) lands it at the issue -- exposes a slot that is restaged while somebody still has to read it;
+// HIPEMU_GLDS=late lands it only when a counted wait retires it -- exposes a read that is not covered by a wait + barrier.
+// A kernel that is correct on the GPU passes under both.
+void glds_issue(const void *src, void *dst_lane, int bytes);
+void vmcnt_wait(int n);
 inline unsigned char *slot(int lane) { return g_blk->xchg.data() + ((size_t)wave_of() * 64 + lane) * 64; }
 
 // every lane of the wave contributes `mine`; returns after all have, with a stable view of all 64 contributions until the
@@ -145,6 +157,7 @@ static inline void __threadfence_block() {}
 static inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_barrier(); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __builtin_amdgcn_s_barrier() { hipemu::block_barrier(); }
+static inline void __builtin_amdgcn_s_setprio(int) {}
 
 template <class T>
 static inline T __shfl_xor(T v, int mask, int width = 64) {
@@ -193,6 +206,43 @@ static inline unsigned __brev(unsigned v) {
   for (int i = 0; i < 32; ++i) r |= ((v >> i) & 1u) << (31 - i);
   return r;
 }
+
+// v_readfirstlane_b32: the value of the first ACTIVE lane of the wave (all alive lanes here: the lanes must meet)
+static inline int __builtin_amdgcn_readfirstlane(int v) {
+  hipemu::begin_exchange(v, 6);
+  int r = v;
+  for (int l = 0; l < 64; ++l)
+    if (l < hipemu::g_blk->w_alive[hipemu::wave_of()]) { r = hipemu::peek<int>(l); break; }
+  hipemu::end_exchange();
+  return r;
+}
+// v_permlane32_swap_b32 vdst, src0: lanes 32..63 of vdst <-> lanes 0..31 of src0; returns {vdst, src0}
+typedef __attribute__((ext_vector_type(2))) unsigned hipemu_u32x2;
+static inline hipemu_u32x2 __builtin_amdgcn_permlane32_swap(unsigned vdst, unsigned src0, bool, bool) {
+  struct P { unsigned a, b; } mine{vdst, src0};
+  hipemu::begin_exchange(mine, 7);
+  const int l = hipemu::lane_of();
+  hipemu_u32x2 r;
+  if (l < 32) { r[0] = vdst; r[1] = hipemu::peek<P>(l + 32).a; }
+  else { r[0] = hipemu::peek<P>(l - 32).b; r[1] = src0; }
+  hipemu::end_exchange();
+  return r;
+}
+// global_load_lds_dwordx4 (and narrower): LDS address = M0 (wave-uniform base) + lane * size; the global address is per lane
+template <class G, class L>
+static inline void hipemu_global_load_lds(G g, L l, int size) {
+  // the destination operand goes through M0: it must be the same in every lane of the wave
+  const unsigned long long base = (unsigned long long)(uintptr_t)(void *)l;
+  hipemu::begin_exchange(base, 8);
+  for (int k = 0; k < 64; ++k)
+    if (k < hipemu::g_blk->w_alive[hipemu::wave_of()] && hipemu::peek<unsigned long long>(k) != base) {
+      std::fprintf(stderr, "hipemu: global_load_lds with a lane-dependent LDS base\n");
+      std::abort();
+    }
+  hipemu::end_exchange();
+  hipemu::glds_issue((const void *)g, (char *)(void *)l + hipemu::lane_of() * size, size);
+}
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) hipemu_global_load_lds(g, l, size)
 
 // lanes are fibers of ONE OS thread and only switch at rendezvous points: plain read-modify-write is atomic here
 template <class T>
@@ -267,6 +317,32 @@ static inline VC hipemu_mfma_16x16x32_bf16(VA a, VA b, VC c) {
   return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) hipemu_mfma_16x16x32_bf16(a, b, c)
+
+// v_mfma_f32_32x32x16_bf16: A lane l = row l%32, k (l/32)*8..+7; B lane l = column l%32, same k; C/D lane l = column l%32,
+// rows (r&3) + 8 (r>>2) + 4 (l/32) for register r of 16
+template <class VA, class VC>
+static inline VC hipemu_mfma_32x32x16_bf16(VA a, VA b, VC c) {
+  struct AB {
+    hipemu_bf16x8 a, b;
+  } mine;
+  std::memcpy(&mine.a, &a, 16);
+  std::memcpy(&mine.b, &b, 16);
+  hipemu::begin_exchange(mine, 9);
+  const int l = hipemu::lane_of(), col = l & 31, hb = l >> 5;
+  VC d = c;
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * hb;
+    float acc = c[r];
+    for (int k = 0; k < 16; ++k) {
+      const AB ra = hipemu::peek<AB>(row + 32 * (k >> 3)), rbv = hipemu::peek<AB>(col + 32 * (k >> 3));
+      acc += hipemu_bf2f(ra.a[k & 7]) * hipemu_bf2f(rbv.b[k & 7]);
+    }
+    d[r] = acc;
+  }
+  hipemu::end_exchange();
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipemu_mfma_32x32x16_bf16(a, b, c)
 
 // v_mfma_f32_16x16x4_f32: A lane l = row l%16, k = l/16; B lane l = column l%16, k = l/16; C/D as above
 template <class VC>

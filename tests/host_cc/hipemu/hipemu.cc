@@ -73,6 +73,29 @@ void check_same_kind(int kind) {
   }
 }
 
+static bool glds_late() {
+  static const int mode = [] {
+    const char *e = std::getenv("HIPEMU_GLDS");
+    return (e && std::strcmp(e, "late") == 0) ? 1 : 0;
+  }();
+  return mode == 1;
+}
+void glds_issue(const void *src, void *dst_lane, int bytes) {
+  if (!glds_late()) {
+    std::memcpy(dst_lane, src, (size_t)bytes);
+    return;
+  }
+  self().vm.push_back({src, dst_lane, bytes});
+}
+// s_waitcnt vmcnt(n): the oldest operations complete until at most n are outstanding (loads return in order)
+void vmcnt_wait(int n) {
+  std::vector<PendingDma> &q = self().vm;
+  const int done = (int)q.size() - n;
+  if (done <= 0) return;
+  for (int i = 0; i < done; ++i) std::memcpy(q[i].dst, q[i].src, (size_t)q[i].bytes);
+  q.erase(q.begin(), q.begin() + done);
+}
+
 static void trampoline() {
   Block &b = *g_blk;
   b.body();
@@ -100,6 +123,7 @@ static void run_block(Block &b) {
     Lane &l = b.lanes[t];
     if (l.stack.size() != kStack) l.stack.resize(kStack);
     l.done = false;
+    l.vm.clear();
     l.tid = dim3(t % b.bdim.x, (t / b.bdim.x) % b.bdim.y, t / (b.bdim.x * b.bdim.y));
     // initial frame: six zeroed callee-saved registers, then the trampoline as the address `ret` jumps to; after that `ret`
     // the stack pointer is 8 below a 16-byte boundary, as at any function entry

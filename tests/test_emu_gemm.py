@@ -1,0 +1,73 @@
+"""bf16 GEMM kernel (csrc/s6d_gemm.hip) on the emulator: tile order, LDS ring / swizzle, counted waits, epilogue layout.
+Both completion models of the LDS-DMA are run (tests/host_cc/hipemu: early = lands at the issue, late = lands when a counted
+wait retires it); a schedule with a missing wait or an early restage fails one of them."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _ref(a, w, bias, gelu):
+    y = a.float() @ w.float().t()
+    if bias is not None:
+        y = y + bias
+    if gelu:
+        y = torch.nn.functional.gelu(y)
+    return y
+
+
+def _check(ops, M, N, K, bias, gelu, max_blocks, lda_pad=0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    a_full = torch.randn(M, K + lda_pad, generator=g).to(torch.bfloat16)
+    a = a_full[:, :K]
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, generator=g) if bias else None
+    out = ops.gemm_bf16(a, w, b, gelu=gelu, max_blocks=max_blocks)
+    ref = _ref(a, w, b, gelu)
+    err = (out.float() - ref).abs()
+    tol = 2.0 ** -8 * ref.abs() + 1e-5        # one bf16 rounding of an fp32-accumulated result
+    bad = (err > tol * 1.01).sum().item()
+    assert bad == 0, (bad, err.max().item())
+
+
+CASES = [
+    # M, N, K, bias, gelu, max_blocks, lda_pad
+    (256, 256, 64, False, False, 0, 0),        # one tile, one K tile (all guards of the short stream)
+    (256, 256, 128, True, False, 0, 0),        # two K tiles
+    (300, 256, 320, True, True, 0, 8),         # ragged M, strided A rows, ring wraps (5 K tiles), GELU epilogue
+    (700, 512, 192, True, False, 8, 0),        # 6 tiles on 8 workgroups
+    (1280, 768, 192, True, True, 8, 0),        # 15 tiles on 8 workgroups: persistent stream across output tiles
+]
+
+
+def _run_case(i):
+    from tests import hipemu  # noqa: F401
+    import ctypes
+
+    from sam6d_amd import _lib, ops
+    L = ctypes.CDLL(hipemu.build())
+    L.s6d_strerror.restype = ctypes.c_char_p
+    L.s6d_strerror.argtypes = [ctypes.c_int]
+    L.s6d_last_hip_error.restype = ctypes.c_char_p
+    _lib._lib = L
+    ops._stream = lambda: ctypes.c_void_p(0)
+    torch.Tensor.is_cuda = property(lambda self: True)
+    M, N, K, bias, gelu, mb, pad = CASES[i]
+    _check(ops, M, N, K, bias, gelu, mb, pad, seed=i)
+
+
+@pytest.mark.parametrize("mode", ["early", "late"])
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_gemm_on_the_emulator(case, mode):
+    if case == 4 and not os.environ.get("S6D_EMU_SLOW") and mode == "late":
+        pytest.skip("long case runs once by default (S6D_EMU_SLOW=1 for both completion models)")
+    # HIPEMU_GLDS is read once per process: each completion model gets its own interpreter
+    env = dict(os.environ, HIPEMU_GLDS=mode)
+    r = subprocess.run([sys.executable, "-c", f"import sys; sys.path.insert(0, {ROOT!r}); "
+                        f"from tests import test_emu_gemm as t; t._run_case({case})"], env=env, capture_output=True,
+                       text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

@@ -1,0 +1,113 @@
+"""GPU parity of s6d_gemm_bf16 (csrc/s6d_gemm.hip: the nn.Linear layers of the ViTs with bias / exact GELU in the epilogue)
+against the fp32 product of the SAME bf16-rounded operands (plain torch reference of the op: common.py:13-28,
+image_encoder.py:224-240).  Tolerance: one bf16 rounding of an fp32-accumulated result (2^-8 relative); the GELU is the erf
+form (torch.nn.functional.gelu, approximate='none')."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(a, w, bias, gelu):
+    y = a.float() @ w.float().t()
+    if bias is not None:
+        y = y + bias
+    return torch.nn.functional.gelu(y) if gelu else y
+
+
+def _check(out, ref, what):
+    err = (out.float() - ref).abs()
+    tol = 2.0 ** -8 * ref.abs() + 1e-5
+    bad = int((err > 1.01 * tol).sum().item())
+    assert bad == 0, f"{what}: {bad} of {ref.numel()} outside one bf16 rounding (max err {err.max().item():.3e})"
+
+
+@pytest.mark.parametrize("K,N,gelu", [(1280, 3840, False), (1280, 1280, False), (1280, 5120, True), (5120, 1280, False),
+                                      (1280, 256, False)])
+def test_vit_h_linear_shapes_at_16_frames(K, N, gelu):
+    """M = 16 frames x 4096 tokens = 65536 rows: the launch-group shapes of the benched SAM ViT-H stage."""
+    from sam6d_amd import ops
+    assert ops.have("gemm_bf16")
+    M = 65536
+    g = torch.Generator(device="cuda").manual_seed(K + N)
+    a = torch.randn(M, K, generator=g, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g, device="cuda") / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, generator=g, device="cuda")
+    out = ops.gemm_bf16(a, w, b, gelu=gelu)
+    for r0 in range(0, M, 8192):                       # fp32 reference in row blocks (keeps the fp32 product at 168 MB)
+        _check(out[r0:r0 + 8192], _ref(a[r0:r0 + 8192], w, b, gelu), f"rows {r0}")
+
+
+@pytest.mark.parametrize("M,K,N,gelu,bias,pad,blocks", [
+    (197 * 32, 768, 2304, False, True, 0, 0),          # PEM ViT-B qkv at the benched batch: ragged last m-tile
+    (197 * 32, 768, 3072, True, True, 0, 0),           # ... fc1 + GELU
+    (257 * 7, 1024, 4096, True, True, 0, 0),           # DINOv2 ViT-L fc1, 7 crops
+    (1000, 3072, 768, False, False, 0, 0),             # no bias
+    (777, 192, 256, False, True, 64, 0),               # strided activation rows, one n-tile, 3 K tiles
+    (255, 64, 256, True, True, 0, 0),                  # a single partial tile, one K tile
+    (4096, 1280, 1280, False, True, 0, 8),             # 80 tiles on 8 workgroups: 10 output tiles per persistent workgroup
+    (3000, 640, 512, True, True, 0, 16),
+])
+def test_shapes_edges_and_persistent_streams(M, K, N, gelu, bias, pad, blocks):
+    from sam6d_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + K + N)
+    a = torch.randn(M, K + pad, generator=g, device="cuda").to(torch.bfloat16)[:, :K]
+    w = (torch.randn(N, K, generator=g, device="cuda") / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, generator=g, device="cuda") if bias else None
+    out = ops.gemm_bf16(a, w, b, gelu=gelu, max_blocks=blocks)
+    _check(out, _ref(a, w, b, gelu), "whole matrix")
+
+
+def test_repeated_launches_are_bit_identical_and_rows_past_m_untouched():
+    """The counted-wait pipeline has no data-dependent path: 20 launches must agree bit for bit (a schedule that reads a
+    slot before its DMA has landed shows up as run-to-run differences); the output buffer behind row M is not written."""
+    from sam6d_amd import ops
+    M, K, N = 8192 + 100, 1280, 1280
+    g = torch.Generator(device="cuda").manual_seed(7)
+    a = torch.randn(M, K, generator=g, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g, device="cuda") / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, generator=g, device="cuda")
+    buf = torch.full((M + 256, N), 7.0, dtype=torch.bfloat16, device="cuda")
+    first = None
+    for i in range(20):
+        ops.gemm_bf16(a, w, b, gelu=True, out=buf[:M])
+        if first is None:
+            first = buf[:M].clone()
+        else:
+            assert torch.equal(first, buf[:M]), f"launch {i} differs from launch 0"
+    assert bool((buf[M:] == 7.0).all())
+    _check(first, _ref(a, w, b, True), "whole matrix")
+
+
+def test_gelu_epilogue_against_exact_gelu_over_the_whole_bf16_range():
+    """x W^T with W = identity blocks exposes the epilogue alone: every finite bf16 value in [-12, 12] through the fused GELU
+    equals bf16(gelu_fp32(x)) up to the rounding of a 1.5e-7-accurate erfc."""
+    from sam6d_amd import ops
+    vals = torch.arange(-2 ** 15, 2 ** 15, dtype=torch.int32).to(torch.int16).view(torch.bfloat16).float()
+    vals = vals[torch.isfinite(vals) & (vals.abs() <= 12)]
+    n = vals.numel()
+    M = (n + 255) // 256
+    x = torch.zeros(M * 256, dtype=torch.float32)
+    x[:n] = vals
+    a = x.view(M, 256).to(torch.bfloat16).cuda()              # 256 test values per row, passed through W = identity
+    w = torch.eye(256, dtype=torch.bfloat16, device="cuda")
+    out = ops.gemm_bf16(a, w, None, gelu=True).float().cpu().view(-1)[:n]
+    ref = torch.nn.functional.gelu(vals.double()).float()
+    err = (out - ref).abs()
+    tol = 2.0 ** -8 * ref.abs() + 3e-7
+    assert int((err > 1.01 * tol).sum()) == 0, err.max().item()
+
+
+def test_sam_block_with_the_kernel_equals_the_library_statement():
+    """One ViT-H block's Linear layers through fused_linear vs torch.nn.functional on the same bf16 tensors."""
+    from sam6d_amd.sam.image_encoder import MLPBlock
+    from sam6d_amd.utils import seeded
+    mlp = seeded.load_seeded(MLPBlock(1280, 5120).eval(), 5).cuda().to(torch.bfloat16)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(2, 64, 64, 1280, generator=g, device="cuda").to(torch.bfloat16)
+    with torch.no_grad():
+        y = mlp(x).float()
+        h = torch.nn.functional.gelu(x.float() @ mlp.lin1.weight.float().t() + mlp.lin1.bias.float()).to(torch.bfloat16)
+        ref = h.float() @ mlp.lin2.weight.float().t() + mlp.lin2.bias.float()
+    rel = (y - ref).norm() / ref.norm()
+    assert rel < 4e-3, rel.item()                                 # two bf16 roundings (h, y)

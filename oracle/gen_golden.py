@@ -31,6 +31,7 @@ PEM_CASE = dict(B=2, weight_seed=1, input_seed=1, rand_seed=7)
 SAM_MINI_CASE = dict(weight_seed=3, input_seed=5)
 SAM_H_CASE = dict(weight_seed=3, input_seed=5)
 ISM_CASE = dict(P=64, O=3, T=42, seed=11)
+ISM_CASE_BENCH = dict(P=128, O=1, T=42, seed=11)          # the shape bench.py scores per frame (BASELINE configs[1])
 SAMDEC_CASE = dict(weight_seed=2, input_seed=9, n_mini=9, n_full=4, mini_input_size=(96, 128), mini_orig=(60, 80),
                    post_B=3, post_seed=6, post_input_size=(768, 1024), post_orig=(480, 640))
 DINO_CASE = dict(P=8, input_seed=4, weight_seed=6, mini_target=56, n_full=2)
@@ -126,7 +127,11 @@ def gen_sam():
 
 def gen_ism():
     ns = rh.ism()
-    c = ISM_CASE
+    _gen_ism(ns, ISM_CASE, "ism_scoring.npz")
+    _gen_ism(ns, ISM_CASE_BENCH, "ism_scoring_p128.npz")
+
+
+def _gen_ism(ns, c, fname):
     inp = synth.ism_inputs(P=c["P"], O=c["O"], T=c["T"], seed=c["seed"])
     Det = ns.detector.Instance_Segmentation_Model
     fake = types.SimpleNamespace()
@@ -158,8 +163,8 @@ def gen_ism():
                    final=final.numpy(), iou2=iou2.numpy(), boxes2=boxes2.numpy(),
                    translation=fake.Calculate_the_query_translation(inp["masks"][sel].clone(), inp["depth"], inp["K"], 1.0).numpy())
     rec["case"] = np.array(str(c))
-    np.savez_compressed(os.path.join(OUT, "ism_scoring.npz"), **rec)
-    print("ism_scoring.npz", {k: (v.shape if hasattr(v, "shape") else v) for k, v in rec.items()})
+    np.savez_compressed(os.path.join(OUT, fname), **rec)
+    print(fname, {k: (v.shape if hasattr(v, "shape") else v) for k, v in rec.items()})
     print("selected", len(rec["sel"]), "iou", rec["iou"], "vr", rec["visible_ratio"][:5], "final", rec["final"][:5])
 
 

@@ -386,13 +386,16 @@ __global__ __launch_bounds__(256) void project_bbox_kernel(const float *__restri
   int mnu = 1 << 30, mnv = 1 << 30, mxu = -(1 << 30), mxv = -(1 << 30);
   for (int i = tid; i < N; i += 256) {
     const float x = pc[i * 3], y = pc[i * 3 + 1], z = pc[i * 3 + 2];
-    const float px = R[0] * x + R[1] * y + R[2] * z + tx;
-    const float py = R[4] * x + R[5] * y + R[6] * z + ty;
-    const float pz = R[8] * x + R[9] * y + R[10] * z + tz;
-    const float hx = K[0] * px + K[1] * py + K[2] * pz;
-    const float hy = K[3] * px + K[4] * py + K[5] * pz;
-    const float hz = K[6] * px + K[7] * py + K[8] * pz;
-    int u = (int)(hx / hz), v = (int)(hy / hz);             // .to(torch.int): truncation toward zero
+    // Operation order of the reference's statements on its pinned (CPU) run, spelled out so that the float -> int
+    // truncation sees the same bits: each 3-term product is a k-ascending fma chain (bmm, detector.py:218-221),
+    // the translation is a separate rounded add (:222), then the second product (:226), an IEEE division (:227), .to(int).
+    const float px = __fadd_rn(__fmaf_rn(R[2], z, __fmaf_rn(R[1], y, __fmul_rn(R[0], x))), tx);
+    const float py = __fadd_rn(__fmaf_rn(R[6], z, __fmaf_rn(R[5], y, __fmul_rn(R[4], x))), ty);
+    const float pz = __fadd_rn(__fmaf_rn(R[10], z, __fmaf_rn(R[9], y, __fmul_rn(R[8], x))), tz);
+    const float hx = __fmaf_rn(K[2], pz, __fmaf_rn(K[1], py, __fmul_rn(K[0], px)));
+    const float hy = __fmaf_rn(K[5], pz, __fmaf_rn(K[4], py, __fmul_rn(K[3], px)));
+    const float hz = __fmaf_rn(K[8], pz, __fmaf_rn(K[7], py, __fmul_rn(K[6], px)));
+    int u = (int)__fdiv_rn(hx, hz), v = (int)__fdiv_rn(hy, hz);   // .to(torch.int): truncation toward zero
     u = min(max(u, 0), W - 1);
     v = min(max(v, 0), H - 1);
     uv[((size_t)s * N + i) * 2] = u;

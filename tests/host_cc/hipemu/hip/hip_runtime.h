@@ -279,6 +279,7 @@ static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c);
 static inline float __fmul_rn(float a, float b) { return a * b; }
 static inline float __fadd_rn(float a, float b) { return a + b; }
 static inline float __fsub_rn(float a, float b) { return a - b; }
+static inline float __fdiv_rn(float a, float b) { return a / b; }
 using std::max;
 using std::min;
 

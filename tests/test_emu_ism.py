@@ -9,4 +9,9 @@ def test_ism_kernels_on_the_emulator(emu):
 
 
 def test_frame_scoring_chain_on_the_emulator(emu):
-    T.test_frame_scoring_vs_reference_golden()
+    T.test_frame_scoring_vs_reference_golden("ism_scoring.npz")
+
+
+def test_projection_bit_exact_on_the_emulator(emu):
+    T.test_projection_is_bit_exact_given_the_reference_translation("ism_scoring.npz")
+    T.test_projection_is_bit_exact_given_the_reference_translation("ism_scoring_p128.npz")

@@ -198,12 +198,13 @@ int s6d_patch_scores_f32(const float *query, const float *refstore, const int32_
                          float *ratio, void *stream);
 long s6d_patch_scores_workspace_floats(int S, int N1, int N2);
 
-/* Mean back-projected 3-D point of each mask: masks (S,H,W) f32, depth (H,W) f32 [mm] -> out (S,3) f32 [m].
+/* Mean back-projected 3-D point of each mask: masks (S,H,W) f32, depth (H,W) f32 -> out (S,3) f32 [m], with
+ * Z = depth * depth_scale / 1000 (the reference's contract: depth in millimetres at depth_scale 1).
+ * K: the 3x3 row-major float64 camera matrix IN DEVICE MEMORY (read by the kernel: no host copy per frame).
  * ref: Calculate_the_query_translation, model/detector.py:234-246 +
  * depth_image_to_pointcloud_translate_torch, utils/trimesh_utils.py:77-105 (float64 X/Y, float32 Z). */
 int s6d_masked_depth_mean_f32(const float *masks, const float *depth, int S, int H, int W, float depth_scale,
-                              double fx, double fy, double cx, double cy, void *workspace, float *out,
-                              void *stream);
+                              const double *K, void *workspace, float *out, void *stream);
 long s6d_masked_depth_mean_workspace_bytes(int S);   /* W % 4 == 0 */
 
 /* Template projection: uv[s,i] = clamp(trunc(K (R_tmpl[s] p_i + t_s))), bbox[s] = (min u, min v, max u, max v).

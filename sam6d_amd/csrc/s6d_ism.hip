@@ -311,12 +311,14 @@ constexpr int kDepthChunks = 16;       // workgroups per mask
 
 __global__ __launch_bounds__(256) void masked_depth_partial_kernel(const float *__restrict__ masks,
                                                                   const float *__restrict__ depth, int H, int W,
-                                                                  unsigned magicW, float depth_scale, double fx,
-                                                                  double fy, double cx, double cy,
+                                                                  unsigned magicW, float depth_scale,
+                                                                  const double *__restrict__ K,
                                                                   double *__restrict__ part) {
   __shared__ double sx[4], sy[4], sz[4];
   __shared__ int sn[4];
   const int s = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+  // the camera matrix is read on the device (3x3 row-major float64, the reference's dtype): no host copy, no cache
+  const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
   const int n4 = (H * W) / 4;                               // W % 4 == 0 (checked by the launcher)
   const int per = (n4 + kDepthChunks - 1) / kDepthChunks;
   const int i0 = ch * per, i1 = min(i0 + per, n4);
@@ -474,16 +476,15 @@ extern "C" long s6d_patch_scores_workspace_floats(int S, int N1, int N2) {
 extern "C" long s6d_masked_depth_mean_workspace_bytes(int S) { return (long)S * kDepthChunks * 4 * sizeof(double); }
 
 extern "C" int s6d_masked_depth_mean_f32(const float *masks, const float *depth, int S, int H, int W, float depth_scale,
-                                         double fx, double fy, double cx, double cy, void *workspace, float *out,
-                                         void *stream) {
+                                         const double *K, void *workspace, float *out, void *stream) {
   if (S < 0 || H <= 0 || W <= 0) return S6D_EINVAL;
   if ((W % 4) != 0) return S6D_EUNSUPPORTED;
   if (S == 0) return S6D_OK;
-  if (!masks || !depth || !out || !workspace) return S6D_EINVAL;
+  if (!masks || !depth || !out || !workspace || !K) return S6D_EINVAL;
   const unsigned magicW = (unsigned)(((1ull << 32) + (unsigned)W - 1) / (unsigned)W);
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(masked_depth_partial_kernel, dim3(kDepthChunks, S), dim3(256), 0, st, masks, depth, H, W, magicW,
-                     depth_scale, fx, fy, cx, cy, (double *)workspace);
+                     depth_scale, K, (double *)workspace);
   int rc = launch_status();
   if (rc) return rc;
   hipLaunchKernelGGL(masked_depth_final_kernel, dim3((S + 63) / 64), dim3(64), 0, st, (const double *)workspace, S, out);

@@ -43,8 +43,14 @@ class MaskedPatch_MatrixSimilarity(nn.Module):
 
     def both(self, query, reference, thred=0.5):
         """(appearance score (S), visible ratio (S)) from one similarity pass."""
-        if ops.have("patch_scores") and query.is_cuda and query.dtype == torch.float32:
-            return ops.patch_scores(query.contiguous(), reference.contiguous(), float(thred))
+        S, N2 = reference.shape[0], reference.shape[1]
+        if ops.have("patch_scores") and query.is_cuda and query.dtype == torch.float32 and reference.dtype == torch.float32 \
+                and N2 <= 256 and query.shape[-1] % 32 == 0:
+            # the kernel addresses a resident (O,T,N2,C) store by (object, template): a materialised (S,N2,C) reference
+            # is the store of ONE object whose "templates" are the S rows
+            obj = torch.zeros(S, dtype=torch.int32, device=query.device)
+            tmpl = torch.arange(S, dtype=torch.int32, device=query.device)
+            return ops.patch_scores(query.contiguous(), reference.contiguous()[None], obj, tmpl, float(thred))
         sim = query @ reference.transpose(1, 2)
         factor = torch.count_nonzero(query.sum(dim=-1), dim=-1) + 1e-6
         appe = (sim.max(dim=-1).values.sum(dim=-1) / factor).clamp(min=0.0, max=1.0)

@@ -171,7 +171,9 @@ class FrameScorer(ScoringMixin):
         self.visible_thred = visible_thred
 
     def score(self, qry_cls, qry_patch, masks, boxes, depth, K, depth_scale=1.0):
-        """Matching stage of run_inference_custom.py:168-200 for one frame."""
+        """Matching stage of run_inference_custom.py:168-200 for one frame.  ``depth`` follows the reference's contract:
+        Z [m] = depth * depth_scale / 1000, i.e. a MILLIMETRE map at depth_scale 1 (run_inference_custom.py reads the png as
+        int32 mm, trimesh_utils.py:87); a map in metres goes in with depth_scale=1000."""
         from types import SimpleNamespace
         sel, pobj, sem, bt = self.compute_semantic_score(qry_cls)
         qp = qry_patch[sel]

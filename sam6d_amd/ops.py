@@ -584,36 +584,22 @@ def patch_scores(query, refstore, obj, tmpl, thred):
 
 
 def masked_depth_mean(masks, depth, K, depth_scale):
-    """masks (S,H,W) f32, depth (H,W) f32, K 3x3 (host-readable) -> (S,3) f32."""
+    """masks (S,H,W) f32, depth (H,W) f32, K 3x3 (any float dtype, host or device) -> (S,3) f32.  The camera matrix goes to
+    the device as float64 (the reference's dtype) and is read there: no host copy of a device K and no cache keyed by
+    an address (a new frame's K may land on the old one's)."""
     _chk(masks, torch.float32, "masks", 3)
     _chk(depth, torch.float32, "depth", 2)
     S, H, W = masks.shape
-    fx, fy, cx, cy = _intrinsics(K)
+    if tuple(K.shape) != (3, 3):
+        raise ValueError(f"K must be 3x3, got {tuple(K.shape)}")
+    Kd = K.detach().to(device=masks.device, dtype=torch.float64).contiguous()
     out = torch.empty(S, 3, dtype=torch.float32, device=masks.device)
     fn = _lib.lib().s6d_masked_depth_mean_workspace_bytes
     fn.restype = ctypes.c_long
     ws = torch.empty(max(int(fn(S)), 8), dtype=torch.uint8, device=masks.device)
-    _call("s6d_masked_depth_mean_f32", _ptr(masks), _ptr(depth), S, H, W, ctypes.c_float(depth_scale),
-          ctypes.c_double(fx), ctypes.c_double(fy), ctypes.c_double(cx), ctypes.c_double(cy), _ptr(ws), _ptr(out),
-          _stream())
+    _call("s6d_masked_depth_mean_f32", _ptr(masks), _ptr(depth), S, H, W, ctypes.c_float(depth_scale), _ptr(Kd), _ptr(ws),
+          _ptr(out), _stream())
     return out
-
-
-_K_CACHE = {}
-
-
-def _intrinsics(K):
-    """(fx, fy, cx, cy) as python floats; device->host copy done once per distinct K tensor (the camera matrix
-    is constant over a sequence; re-reading it every frame would be a host sync per frame)."""
-    key = (K.data_ptr(), K._version, K.device)
-    hit = _K_CACHE.get(key)
-    if hit is None:
-        Kc = K.detach().double().cpu()
-        hit = (Kc[0, 0].item(), Kc[1, 1].item(), Kc[0, 2].item(), Kc[1, 2].item())
-        if len(_K_CACHE) > 64:
-            _K_CACHE.clear()
-        _K_CACHE[key] = hit
-    return hit
 
 
 def project_bbox(pointcloud, poses, obj, tmpl, trans, K, H, W):

@@ -46,6 +46,13 @@ class FramePipeline:
         self.nms_thresh, self.det_thresh = nms_per_object_thresh, det_score_thresh
         self.times = {}
 
+    def score_metres(self, cls, patch, masks, boxes, depth_m, K):
+        """The unit boundary between the two halves of the frame: this class takes depth in METRES (what the PEM
+        pre-processing needs); the ISM's query translation is Z = depth * depth_scale / 1000 on a millimetre map
+        (trimesh_utils.py:87 "depth metric is mm", run_inference_custom.py reads the png as int32 mm), so a map in metres
+        goes in with depth_scale 1000."""
+        return self.scorer.score(cls, patch, masks, boxes, depth_m, K, depth_scale=1000.0)
+
     def _tick(self, name, t0):
         torch.cuda.synchronize()
         self.times[name] = (time.perf_counter() - t0) * 1e3
@@ -57,6 +64,10 @@ class FramePipeline:
         (top_k, H*W) / coarse_rand_u (top_k, 18000): the injected random numbers of the two sampling steps.
         -> (Detections of the frame, dict(pred_R, pred_t, pred_pose_score, kept))."""
         H, W = image_u8.shape[:2]
+        n_keys = sample_keys.shape[0]
+        if self.top_k is not None and (n_keys < self.top_k or coarse_rand_u.shape[0] < self.top_k):
+            raise ValueError(f"sample_keys / coarse_rand_u need one row per detection handed to the PEM (top_k={self.top_k}); "
+                             f"got {n_keys} / {coarse_rand_u.shape[0]}")
         t0 = time.perf_counter()
         # ---- SAM image encoder ------------------------------------------------------------------------------------
         x = ResizeLongestSide(self.enc.img_size).apply_image(image_u8).permute(2, 0, 1)[None].float()
@@ -80,7 +91,7 @@ class FramePipeline:
         # ---- descriptors + scoring -----------------------------------------------------------------------------------
         cls, patch = self.desc(image_u8.cpu().numpy(), SimpleNamespace(masks=masks.float(), boxes=boxes))
         t0 = self._tick("descriptors", t0)
-        sc = self.scorer.score(cls, patch, masks.float(), boxes.float(), depth, K)
+        sc = self.score_metres(cls, patch, masks.float(), boxes.float(), depth, K)
         order = torch.argsort(sc["final"], descending=True)
         sel = sc["sel"][order]
         det = Detections(0, 0, masks[sel], boxes[sel], sc["final"][order], sc["pred_obj"][order])
@@ -100,6 +111,9 @@ class FramePipeline:
         radius = self.radius
         if torch.is_tensor(radius) and radius.numel() > 1:
             radius = radius.to(det.object_ids.device)[det.object_ids.long()]
+        if len(det) > sample_keys.shape[0] or len(det) > coarse_rand_u.shape[0]:
+            raise ValueError(f"{len(det)} detections go to the PEM but sample_keys / coarse_rand_u have "
+                             f"{sample_keys.shape[0]} / {coarse_rand_u.shape[0]} rows (top_k=None keeps every detection)")
         obs = pem_pre.observed_inputs(image_u8, depth, K, det.masks, radius, sample_keys[: det.masks.shape[0]])
         t0 = self._tick("pem_preprocessing", t0)
         M = obs["pts"].shape[0]

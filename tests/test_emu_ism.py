@@ -15,3 +15,28 @@ def test_frame_scoring_chain_on_the_emulator(emu):
 def test_projection_bit_exact_on_the_emulator(emu):
     T.test_projection_is_bit_exact_given_the_reference_translation("ism_scoring.npz")
     T.test_projection_is_bit_exact_given_the_reference_translation("ism_scoring_p128.npz")
+
+
+def test_masked_patch_similarity_methods_reach_the_kernel(emu):
+    """MaskedPatch_MatrixSimilarity.compute_straight / compute_visible_ratio (detector.py:305,312 call
+    them on a materialised (S,256,C) reference) go through patch_scores_kernel and agree with the oracle statements."""
+    import torch
+
+    from oracle import ism as oism
+    from sam6d_amd.ism.loss import MaskedPatch_MatrixSimilarity
+    from sam6d_amd.utils import synth
+    d = synth.ism_inputs(P=5, O=2, T=3, C=64, n_patch=40, H=120, W=160, seed=9)
+    q = d["qry_patch"]
+    ref = d["ref_patch"][d["gt_obj"], d["gt_tem"]].contiguous()
+    m = MaskedPatch_MatrixSimilarity(metric="cosine", chunk_size=64)
+    calls = []
+    orig = emu.patch_scores
+    emu.patch_scores = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        appe = m.compute_straight(q, ref)
+        ratio = m.compute_visible_ratio(q, ref, 0.5)
+    finally:
+        emu.patch_scores = orig
+    assert len(calls) == 2
+    assert torch.allclose(appe, oism.appearance_score(q, d['ref_patch'], d['gt_obj'], d['gt_tem'])[0], atol=1e-5)
+    assert torch.allclose(ratio, oism.visible_ratio(q, ref, 0.5), atol=1e-5)

@@ -50,7 +50,8 @@ def test_glue_between_the_stages(monkeypatch):
             return torch.zeros(n, 4), torch.zeros(n, 16, 4)
 
     class Scorer:
-        def score(self, cls, patch, m, b, d, k):
+        def score(self, cls, patch, m, b, d, k, depth_scale=1.0):
+            seen["depth_scale"] = depth_scale
             n = m.shape[0]
             final = torch.linspace(0.2, 0.9, n)                                # best = last surviving proposal
             return dict(final=final, sel=torch.arange(n), pred_obj=torch.zeros(n, dtype=torch.long))
@@ -100,10 +101,11 @@ def test_glue_between_the_stages(monkeypatch):
     pipe.det_thresh = 0.95
     det, poses = pipe(img, depth, K, torch.rand(4, H * W, generator=g), torch.rand(4, 18000, generator=g))
     assert len(det) == 0 and poses is None
+    assert seen["depth_scale"] == 1000.0                  # metres in, the ISM's millimetre contract out
     # ---- several objects: template rows and radius follow the predicted object id ------------------------------------------
     class Scorer2(Scorer):
-        def score(self, cls, patch, m, b, d, k):
-            r = super().score(cls, patch, m, b, d, k)
+        def score(self, cls, patch, m, b, d, k, depth_scale=1.0):
+            r = super().score(cls, patch, m, b, d, k, depth_scale)
             r["pred_obj"] = torch.tensor([2, 0, 1, 2])[: m.shape[0]]
             return r
     tpl3 = dict(model=torch.arange(3.0)[:, None, None].expand(3, 64, 3).clone(), dense_po=torch.arange(3.0)[:, None, None].expand(3, 32, 3).clone(),
@@ -122,3 +124,51 @@ def test_glue_between_the_stages(monkeypatch):
     out = pipeline.frame_results(det, poses, "ycbv", 0.0)
     assert [r["category_id"] for r in out["pem_records"]] == [3, 2, 1, 3] and [l.split(",")[2] for l in out["csv_lines"]] == ["3", "2", "1", "3"]
 
+
+
+def _known_answer_scene():
+    """One object (a 4 cm ball of model points, identity template pose) seen at 0.8 m in the middle of a box mask."""
+    H, W = 120, 160
+    g = torch.Generator().manual_seed(3)
+    K = torch.tensor([[143.0, 0, 80.0], [0, 143.0, 60.0], [0, 0, 1]], dtype=torch.float64)
+    pc = torch.nn.functional.normalize(torch.randn(1, 512, 3, generator=g), dim=-1) * 0.04
+    poses = torch.eye(4)[None]
+    C = 32
+    ref_cls = torch.randn(1, 1, C, generator=g)
+    ref_patch = torch.nn.functional.normalize(torch.randn(1, 1, 16, C, generator=g), dim=-1)
+    masks = torch.zeros(1, H, W)
+    masks[0, 50:71, 70:91] = 1.0                                    # 21 x 21 px around the principal point
+    boxes = torch.tensor([[70.0, 50.0, 90.0, 70.0]])
+    depth_m = torch.full((H, W), 0.8)
+    return H, W, K, pc, poses, ref_cls, ref_patch, masks, boxes, depth_m
+
+
+def test_depth_unit_boundary_known_answer():
+    """the pipeline takes depth in metres, the ISM translation works on millimetres x depth_scale / 1000.
+    A known-answer object: the query translation must be the mask's depth (0.8 m, not 0.0008) and the projected template
+    box must overlap the proposal box."""
+    from sam6d_amd.ism.scoring import FrameScorer
+    H, W, K, pc, poses, ref_cls, ref_patch, masks, boxes, depth_m = _known_answer_scene()
+    scorer = FrameScorer(ref_cls, ref_patch, poses, pc, confidence_thresh=-1.0, aggregation_function="max")
+    pipe = pipeline.FramePipeline.__new__(pipeline.FramePipeline)
+    pipe.scorer = scorer
+    sc = pipe.score_metres(ref_cls[0], ref_patch[0], masks, boxes, depth_m, K)
+    t = scorer.Calculate_the_query_translation(masks.clone(), depth_m, K, 1000.0)
+    assert abs(t[0, 2].item() - 0.8) < 1e-6 and abs(t[0, 0].item()) < 5e-3 and abs(t[0, 1].item()) < 5e-3
+    uv = sc["image_uv"][0]
+    # a 4 cm ball at 0.8 m spans 143 * 0.04 / 0.8 = 7 px either side of the principal point
+    assert 70 <= uv[:, 0].min() <= 76 and 84 <= uv[:, 0].max() <= 90 and 50 <= uv[:, 1].min() <= 56
+    assert torch.is_tensor(sc["iou"]) and sc["iou"][0] > 0.3
+    # the same frame in the reference's own unit gives the same answer
+    sc_mm = scorer.score(ref_cls[0], ref_patch[0], masks, boxes, depth_m * 1000.0, K, depth_scale=1.0)
+    assert torch.equal(sc_mm["image_uv"], sc["image_uv"])
+    # and the old call (metres with depth_scale 1) is the failure the advisor described: every point lands on one pixel
+    bad = scorer.score(ref_cls[0], ref_patch[0], masks, boxes, depth_m, K, depth_scale=1.0)
+    assert not torch.is_tensor(bad["iou"]) or bad["iou"][0] < 0.05
+
+
+def test_pipeline_rejects_too_few_random_rows():
+    import pytest
+    pipe = pipeline.FramePipeline(None, None, None, None, None, None, {}, 1.0, top_k=4)
+    with pytest.raises(ValueError, match="one row per detection"):
+        pipe(torch.zeros(8, 8, 3, dtype=torch.uint8), torch.zeros(8, 8), torch.eye(3), torch.zeros(2, 64), torch.zeros(4, 18000))

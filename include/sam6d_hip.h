@@ -233,6 +233,17 @@ int s6d_fine_assign_f32(const float *atten, const float *pts2, int B, int M1, in
                         float *wsum, float *w1, void *stream);
 long s6d_fine_assign_workspace_bytes(int B, int M1, int M2);
 
+/* Fine point matching, similarity + soft assignment fused: the (B, M1, M2) similarity matrix is never written.
+ * f1 (B,M1,C), f2 (B,M2,C) f32 = out_proj features INCLUDING the background token at row 0 (un-normalised);
+ * pts2 (B,M2-1,3) f32; inv_temp = 1 / temp.  -> pred (B,M1-1,3), wsum (B,M1-1), w1 (B,M1-1) f32 as s6d_fine_assign_f32.
+ * C = 256.  Tiles of the matrix are recomputed on the bf16 matrix cores with a hi/lo split of the normalised rows
+ * (fp32-class similarities) in three sweeps: row sums, column sums + column labels, row labels + assignment.
+ * ref: compute_feature_similarity, utils/model_utils.py:114-136 (called at model/fine_point_matching.py:75-80) +
+ * compute_fine_Rt, utils/model_utils.py:250-270. */
+int s6d_fine_match_f32(const float *f1, const float *f2, const float *pts2, int B, int M1, int M2, int C, float inv_temp,
+                       void *workspace, float *pred, float *wsum, float *w1, void *stream);
+long s6d_fine_match_workspace_bytes(int B, int M1, int M2);
+
 /* Plain multi-head self-attention over a token sequence (no positional bias): qkv (B,N,3,nh,hd) bf16 ->
  * out (B,N,nh*hd) bf16, softmax(scale q.k) v; all N key slots LDS-resident (N <= ~500 at hd 64).  hd in {64, 80}.
  * ref: the timm ViT attention used by Pose_Estimation_Model/model/feature_extraction.py:17-35 (N = 197, hd = 64). */

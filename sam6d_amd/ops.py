@@ -501,6 +501,27 @@ def fine_assign(atten, pts2):
     return pred, wsum, w1
 
 
+def fine_match(f1, f2, pts2, temp):
+    """f1 (B,M1,256), f2 (B,M2,256) f32 (background token at row 0), pts2 (B,M2-1,3) -> pred (B,M1-1,3), wsum, w1 (B,M1-1):
+    feature similarity + dual softmax + labels + normalised assignment without the (B,M1,M2) matrix."""
+    for t, nm in ((f1, "f1"), (f2, "f2"), (pts2, "pts2")):
+        _chk(t, torch.float32, nm, 3)
+    B, M1, C = f1.shape
+    M2 = f2.shape[1]
+    if f2.shape[0] != B or f2.shape[2] != C or tuple(pts2.shape) != (B, M2 - 1, 3):
+        raise ValueError(f"fine_match: shapes {tuple(f1.shape)}, {tuple(f2.shape)}, {tuple(pts2.shape)}")
+    dev = f1.device
+    fn = _lib.lib().s6d_fine_match_workspace_bytes
+    fn.restype = ctypes.c_long
+    ws = torch.empty(int(fn(B, M1, M2)), dtype=torch.uint8, device=dev)
+    pred = torch.empty(B, M1 - 1, 3, dtype=torch.float32, device=dev)
+    wsum = torch.empty(B, M1 - 1, dtype=torch.float32, device=dev)
+    w1 = torch.empty(B, M1 - 1, dtype=torch.float32, device=dev)
+    _call("s6d_fine_match_f32", _ptr(f1), _ptr(f2), _ptr(pts2), B, M1, M2, C, ctypes.c_float(1.0 / temp), _ptr(ws),
+          _ptr(pred), _ptr(wsum), _ptr(w1), _stream())
+    return pred, wsum, w1
+
+
 def pe_group_mlp(pts, idx, W0, b0, W1, b1, W2, b2):
     """pts (B,N,3) f32, idx (B,N,ns) i32, folded MLP weights -> (B,N,128) f32 (max over neighbours)."""
     _chk(pts, torch.float32, "pts", 3)
@@ -625,7 +646,7 @@ _FUSED = {}
 def have(name):
     if name not in _FUSED:
         sym = {"rpe_attention": "s6d_rpe_attention_f32", "geo_embedding": "s6d_geo_embedding_f32",
-               "fine_assign": "s6d_fine_assign_f32", "upsample_gather": "s6d_upsample_gather_f32",
+               "fine_assign": "s6d_fine_assign_f32", "fine_match": "s6d_fine_match_f32", "upsample_gather": "s6d_upsample_gather_f32",
                "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "add_layernorm": "s6d_add_layernorm_bf16", "gemm_bf16": "s6d_gemm_bf16", "win_attention": "s6d_win_attention_bf16",
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",

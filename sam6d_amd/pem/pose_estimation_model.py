@@ -153,9 +153,13 @@ class FinePointMatching(nn.Module):
         f2 = torch.cat([bg, self.in_proj(f2) + self.PE(p2)], dim=1)
         for blk in self.transformers:
             f1, f2 = blk(f1, geo1, fps_idx1, f2, geo2, fps_idx2)
-        atten = feature_similarity(self.out_proj(f1), self.out_proj(f2), self.cfg.temp)
+        o1, o2 = self.out_proj(f1), self.out_proj(f2)
         model = end_points["model"] / (radius.reshape(-1, 1, 1) + 1e-6)
-        R, t, score = fine_Rt(atten, p1, p2, model)
+        if ops.have("fine_match") and o1.is_cuda and o1.dtype == torch.float32 and o1.shape[2] == 256:
+            # similarity tiles are formed inside the assignment kernel: the (B,2049,2049) matrix is never written
+            R, t, score = fine_Rt(None, p1, p2, model, feats=(o1, o2, self.cfg.temp))
+        else:
+            R, t, score = fine_Rt(feature_similarity(o1, o2, self.cfg.temp), p1, p2, model)
         end_points["pred_R"] = R
         end_points["pred_t"] = t * (radius.reshape(-1, 1) + 1e-6)
         end_points["pred_pose_score"] = score

@@ -85,9 +85,15 @@ def coarse_Rt(atten, pts1, pts2, model_pts, rand_u, n1=6000, n2=300):
     return Rs[ar, best], ts[ar, best]
 
 
-def fine_Rt(atten, pts1, pts2, model_pts, dis_thres=0.15):
-    """compute_fine_Rt."""
-    if ops.have("fine_assign") and atten.is_cuda and atten.shape[2] <= 2112 and pts2.shape[1] == atten.shape[2] - 1:
+def fine_Rt(atten, pts1, pts2, model_pts, dis_thres=0.15, feats=None):
+    """compute_fine_Rt.  feats = (f1, f2, temp): the out_proj features the similarity is made of -- with them the fused kernel
+    forms similarity tiles on the fly and ``atten`` (the (B,2049,2049) matrix) may be None."""
+    if feats is not None and ops.have("fine_match") and feats[0].is_cuda and feats[0].shape[2] == 256 \
+            and feats[0].dtype == torch.float32:
+        pred, wsum, w1 = ops.fine_match(feats[0].contiguous(), feats[1].contiguous(), pts2.contiguous(), float(feats[2]))
+    elif atten is None:
+        raise ValueError("fine_Rt needs the similarity matrix when the fused similarity kernel is not available")
+    elif ops.have("fine_assign") and atten.is_cuda and atten.shape[2] <= 2112 and pts2.shape[1] == atten.shape[2] - 1:
         pred, wsum, w1 = ops.fine_assign(atten.contiguous(), pts2.contiguous())
     else:
         amat, w1, _ = soft_assignment(atten)

@@ -14,7 +14,7 @@ EMU = os.path.join(HERE, "host_cc", "hipemu")
 OUT = os.path.join(HERE, "host_cc", "_build")
 SO = os.path.join(OUT, "libsam6d_emu.so")
 CXX = os.environ.get("HIPEMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
-DYN_NAMES = ("smem", "ps_smem", "sd_smem", "t2i_smem", "gemm_smem")
+DYN_NAMES = ("smem", "ps_smem", "sd_smem", "t2i_smem", "gemm_smem", "fm_smem")
 
 _lib = None
 

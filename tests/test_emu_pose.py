@@ -26,6 +26,13 @@ def test_fine_assign_on_the_emulator(emu, B, M):
     T.test_fine_assign_vs_oracle(emu, B, M)
 
 
+@pytest.mark.parametrize("B,M1,M2", [(1, 65, 65), (2, 40, 34), (1, 300, 270)])
+def test_fine_match_on_the_emulator(emu, B, M1, M2):
+    """Fused similarity + assignment (LDS-DMA staged split-bf16 tiles, three sweeps): single tile, ragged sides, several owner
+    blocks / odd and even tile counts."""
+    T._check_fine_match(emu, B, M1, M2)
+
+
 def test_positional_encoding_on_the_emulator(emu):
     """Same comparison as T.test_positional_encoding_fused_vs_oracle on a smaller cloud (the emulator is ~1e5 x slower than
     the GPU; the full-size body runs with S6D_EMU_SLOW=1)."""

@@ -124,6 +124,34 @@ def test_fine_assign_vs_oracle(ops, B, M):
     assert (p - pred).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("B,M", [(2, 2049), (1, 300), (3, 65), (1, 258)])
+def test_fine_match_vs_oracle(ops, B, M):
+    """Similarity + assignment fused (s6d_fine_match_f32: split-bf16 MFMA tiles, three sweeps, no (B,M,M) matrix) against the
+    reference chain compute_feature_similarity -> compute_fine_Rt head.  Tolerances: labels exact, weights and assigned points
+    2e-5 (the tiles are fp32-class: the dropped lo.lo term is below 2^-16 of a product)."""
+    _check_fine_match(ops, B, M, M)
+
+
+def test_fine_match_ragged_sides(ops):
+    _check_fine_match(ops, 2, 131, 97)
+
+
+def _check_fine_match(ops, B, M1, M2):
+    g = torch.Generator().manual_seed(M1 + 7 * M2)
+    f1 = torch.randn(B, M1, 256, generator=g) * (0.5 + torch.rand(B, M1, 1, generator=g))     # un-normalised out_proj rows
+    perm = torch.randint(0, M1, (M2,), generator=g)
+    f2 = f1[:, perm] + 0.4 * torch.randn(B, M2, 256, generator=g)
+    pts2 = torch.randn(B, M2 - 1, 3, generator=g)
+    atten = opem.feature_similarity(f1, f2, 0.1)
+    amat, w1, _ = opem.soft_assignment(atten)
+    wsum = amat.sum(2)
+    pred = (amat / (wsum.unsqueeze(2) + 1e-6)) @ pts2
+    p, ws, w = (t.cpu() for t in ops.fine_match(f1.cuda(), f2.cuda(), pts2.cuda(), 0.1))
+    assert torch.equal(w, w1), (w != w1).sum()
+    assert (ws - wsum).abs().max() < 2e-5 * max(1.0, wsum.abs().max().item()), (ws - wsum).abs().max()
+    assert (p - pred).abs().max() < 2e-5, (p - pred).abs().max()
+
+
 def test_positional_encoding_fused_vs_oracle(ops):
     """Fused ball-query-group + SharedMLP + max kernel (exact-f32 MFMA chain) vs the reference PositionalEncoding."""
     from sam6d_amd.pem.pose_estimation_model import PositionalEncoding

@@ -89,6 +89,7 @@ constexpr int kRing = 10;     // slots: all 160 KiB of the CU
 extern __shared__ __attribute__((aligned(16))) char gemm_smem[];
 
 __device__ __forceinline__ int ring(int s) { return s >= kRing ? s - kRing : s; }
+__device__ __forceinline__ int ring5(int s) { return s >= 5 ? s - 5 : s; }
 
 // exact GELU, x Phi(x) = relu(x) - |x| * 0.5 erfc(|x| / sqrt 2); erfc(z) = t (a1 + t (a2 + ... t a5)) exp(-z^2),
 // t = 1 / (1 + p z)  (Abramowitz & Stegun 7.1.26, absolute error <= 1.5e-7); exp(-z^2) = exp2(-(z sqrt(log2 e))^2)
@@ -389,19 +390,241 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
 #undef S6D_MFMA
 }
 
+
+// =====================================================================================================================================
+// Version 2: two INDEPENDENT 256-thread workgroups per CU, 256 x 128 output tiles.
+//
+// What the measurements of version 1 said (profiles/r02_gemm_v1_time.json, 65536 x 1280 -> 5120): the whole kernel 0.76 ms, without
+// the epilogue stores 0.65, without the LDS-DMA 0.62, matrix work + fragment reads alone 0.55 -- and everything EXCEPT the matrix work
+// alone 0.58.  The eight waves of that kernel are one lock-step machine: nothing runs beside the epilogue of a tile (14 %), and every
+// 256-cycle matrix segment is bracketed by workgroup barriers.  Here the CU holds two workgroups that know nothing of each other
+// (80 KiB of LDS each, <= 256 VGPRs): on every SIMD one wave of each; whenever one waits -- barrier, DMA landing, fragment reads,
+// its GELU / store epilogue -- the other one has the matrix pipe.  Price: a 256 x 128 tile moves 1.5x the operand bytes per FLOP.
+//
+//   * waves 2 (M) x 2 (N), the same 128 x 64 wave tile, fragment layout, transposed product and epilogue as version 1;
+//   * LDS = ring of 5 slots of 16 KiB (128 rows x 64 k, the version-1 image and swizzle); the operand stream is W, A0, A1 per K
+//     tile (A0 / A1 = rows 0-127 / 128-255 of the tile) and runs across output tiles;
+//   * per K tile: [counted wait + barrier: the K tile has landed] -> ALL fragments of the K tile into registers (24 ds_read_b128,
+//     96 VGPRs) -> [barrier: its three slots are free] -> the next three stream elements are issued (12 pieces per wave, between
+//     the MFMAs) -> 32 MFMAs from registers.  The stream therefore stays 5 slots = 1.67 K tiles ahead of the matrix work.
+template <int EPI, bool HAS_BIAS>
+__global__ void __launch_bounds__(256, 2) gemm2_bf16_kernel(GemmParams p) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;       // M half / N half of the 256 x 128 tile
+
+  // tile schedule: as version 1 (XCD x takes a contiguous range of the logical order, GM m-tiles per n-tile group)
+  const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+  const int tq = p.ntiles >> 3, tr = p.ntiles & 7;
+  const int first = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+  const int cnt = tq + (xcd < tr ? 1 : 0);
+  if (bi >= cnt) return;
+  const int my_tiles = (cnt - bi + bpx - 1) / bpx;
+  const int G = my_tiles * p.nk;
+  auto tile_mn = [&](int j, int &m0, int &n0) __attribute__((always_inline)) {
+    const int L = first + bi + j * bpx;
+    const int tpg = p.GM * p.NT;
+    const int grp = L / tpg, rem = L - grp * tpg;
+    const int mf = grp * p.GM;
+    const int gs = min(p.GM, p.MT - mf);
+    const int nn = rem / gs;
+    m0 = (mf + rem - nn * gs) * 256;
+    n0 = nn * 128;
+  };
+
+  // staging: wave w fills rows [32 w, 32 w + 32) of a slot in four 1-KiB pieces (8 rows x 128 B); lane -> row (lane >> 3),
+  // chunk position (lane & 7), fetched chunk = position ^ ((row >> 1) & 7)
+  const int srow = wave * 32 + (lane >> 3);
+  unsigned sc[4];                                                       // chunk byte offset of piece i (rows + 8 i)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sc[i] = (unsigned)(((lane & 7) ^ (((lane >> 3) + 8 * i) >> 1 & 7)) << 4);
+  // issue cursor = the K tile whose W / A0 go out next (K tile in the output tile, tile); its A1 addresses are parked in
+  // a1_pend and go out one iteration later (the stream order is W, A0, A1 per K tile, 5 elements ahead of the matrix work)
+  unsigned w_off = 0, a_off[2][4], a1_pend[4] = {0u, 0u, 0u, 0u};
+  int is_kt = 0, is_tile = 0;
+  auto set_tile = [&](int tile) __attribute__((always_inline)) {
+    int m0, n0;
+    tile_mn(tile, m0, n0);
+    w_off = (unsigned)(n0 + srow) * p.ldw2;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a_off[a][i] = (unsigned)min(m0 + a * 128 + srow + 8 * i, p.M - 1) * p.lda2 + sc[i];
+  };
+  auto dma = [&](const u16 *base, unsigned off, int slot, int piece) __attribute__((always_inline)) {
+    S6D_LDS(char) *dst = (S6D_LDS(char) *)gemm_smem + slot * kSlot + (wave * 4 + piece) * 1024;
+    __builtin_amdgcn_global_load_lds((const S6D_GLOBAL(void) *)((const char *)base + off), dst, 16, 0, 0);
+  };
+  auto issue_w = [&](int slot) __attribute__((always_inline)) {        // W of the cursor's K tile
+    const unsigned k = (unsigned)is_kt * 128u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma(p.W, w_off + (unsigned)(8 * i) * p.ldw2 + sc[i] + k, slot, i);
+  };
+  auto issue_a0 = [&](int slot) __attribute__((always_inline)) {       // A0 of the cursor's K tile; parks its A1; advances the cursor
+    const unsigned k = (unsigned)is_kt * 128u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dma(p.A, a_off[0][i] + k, slot, i);
+      a1_pend[i] = a_off[1][i] + k;
+    }
+    if (++is_kt == p.nk) {
+      is_kt = 0;
+      if (++is_tile < my_tiles) set_tile(is_tile);
+    }
+  };
+  auto issue_a1 = [&](int slot) __attribute__((always_inline)) {       // the parked A1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma(p.A, a1_pend[i], slot, i);
+  };
+
+  unsigned foff[4];
+  {
+    const int sw = (lane >> 1) & 7, hb = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) foff[ks] = (unsigned)((lane & 31) * 128 + ((((2 * ks) | hb) ^ sw) << 4));
+  }
+  auto frag = [&](int slot, unsigned rowbytes, int ks) __attribute__((always_inline)) -> bf16x8 {
+    return *reinterpret_cast<const bf16x8 *>(gemm_smem + slot * kSlot + rowbytes + foff[ks]);
+  };
+
+  f32x16 acc[4][2];
+  int ct = 0, ck = 0, cm0, cn0;
+  tile_mn(0, cm0, cn0);
+
+  auto init_acc = [&](int n0) __attribute__((always_inline)) {
+    const int nb = __builtin_amdgcn_readfirstlane(n0 + wc * 64);
+    const S6D_CONST(float) *bs = (const S6D_CONST(float) *)p.bias + nb;
+    const bool hi = (lane >> 5) != 0;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = HAS_BIAS ? bs[nt * 32 + 8 * qd + e] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float b = hi ? v[4 + e] : v[e];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) acc[mt][nt][4 * qd + e] = b;
+        }
+      }
+  };
+  auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) {
+    const int hb = lane >> 5;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int m = m0 + wr * 128 + mt * 32 + (lane & 31);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        unsigned pk[4][2];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[mt][nt][4 * qd + e];
+            if (EPI == 1) v[e] = gelu_erf(v[e]);
+          }
+          pk[qd][0] = pack_bf16(v[0], v[1]);
+          pk[qd][1] = pack_bf16(v[2], v[3]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          uint4 o;
+          auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * j][0], pk[2 * j + 1][0], false, false);
+          auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * j][1], pk[2 * j + 1][1], false, false);
+          o.x = s0[0];
+          o.y = s1[0];
+          o.z = s0[1];
+          o.w = s1[1];
+          if (m < p.M) {
+            u16 *dst = p.C + (size_t)m * p.ldc + (n0 + wc * 64 + nt * 32 + 16 * j + 8 * hb);
+            *reinterpret_cast<uint4 *>(dst) = o;
+          }
+        }
+      }
+    }
+  };
+
+  // ---- prologue: the first 5 stream elements (K tile 0 whole; W, A0 of K tile 1)
+  set_tile(0);
+  issue_w(0);
+  issue_a0(1);
+  issue_a1(2);
+  if (G > 1) {
+    issue_w(3);
+    issue_a0(4);
+  }
+  init_acc(cn0);
+
+  int s0 = 0;                                                            // ring slot of W of K tile g: (3 g) % 5
+  for (int g = 0; g < G; ++g) {
+    // the K tile has landed: mine by the counted wait (two younger elements = 8 pieces stay in flight), everybody's by the barrier
+    if (g + 1 < G) S6D_VMCNT(8); else S6D_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+    const int sW = s0, sA = ring5(s0 + 1 + wr);
+    bf16x8 wf[2][4], xf[4][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) wf[nt][ks] = frag(sW, (unsigned)((wc * 64 + nt * 32) * 128), ks);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) xf[mt][ks] = frag(sA, (unsigned)(mt * 32 * 128), ks);
+#ifndef HIPEMU
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // the fragments are in registers ...
+#endif
+    __builtin_amdgcn_s_barrier();                                        // ... everybody's: the three slots of this K tile are free
+    // the next three stream elements go out between the matrix instructions of the four k steps
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks == 0 && g + 1 < G) issue_a1(s0);                            // A1(g + 1) into the slot W(g) left
+      if (ks == 1 && g + 2 < G) issue_w(ring5(s0 + 1));                  // W(g + 2) into A0(g)'s
+      if (ks == 2 && g + 2 < G) issue_a0(ring5(s0 + 2));                 // A0(g + 2) into A1(g)'s
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt][ks], xf[mt][ks], acc[mt][nt], 0, 0, 0);
+    }
+    s0 = ring5(s0 + 3);
+    if (++ck == p.nk) {
+      ck = 0;
+      epilogue(cm0, cn0);
+      if (++ct < my_tiles) {
+        tile_mn(ct, cm0, cn0);
+        init_acc(cn0);
+      }
+    }
+  }
+}
+
 }  // namespace s6d
 
 using namespace s6d;
 
+// Which kernel: 2 = two independent 256 x 128 workgroups per CU (N % 128 == 0), 1 = the eight-wave 256 x 256 machine (N % 256 == 0).
+static int gemm_impl() {
+  static int impl = -1;
+  if (impl < 0) {
+    const char *e = getenv("S6D_GEMM_IMPL");
+    impl = (e && atoi(e) == 1) ? 1 : 2;
+  }
+  return impl;
+}
+
 extern "C" int s6d_gemm_bf16(const void *A, long lda, const void *W, long ldw, const float *bias, void *C, long ldc, int M,
                              int N, int K, int epilogue, int max_blocks, void *stream) {
   if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return S6D_EINVAL;
-  if (N % 256 != 0 || K % 64 != 0 || lda < K || ldw < K || ldc < N) return S6D_EINVAL;
+  if (N % 128 != 0 || K % 64 != 0 || lda < K || ldw < K || ldc < N) return S6D_EINVAL;
   if ((lda % 8) || (ldw % 8) || (ldc % 8)) return S6D_EINVAL;           // 16-byte rows
   if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) return S6D_EINVAL;
   if (epilogue != 0 && epilogue != 1) return S6D_EINVAL;
   // staging addresses are 32-bit byte offsets from A / W
   if ((double)M * (double)lda * 2.0 >= 2147483648.0 || (double)N * (double)ldw * 2.0 >= 2147483648.0) return S6D_EUNSUPPORTED;
+  const int impl = (N % 256 != 0) ? 2 : gemm_impl();
   GemmParams p;
   p.A = (const u16 *)A;
   p.W = (const u16 *)W;
@@ -414,16 +637,35 @@ extern "C" int s6d_gemm_bf16(const void *A, long lda, const void *W, long ldw, c
   p.N = N;
   p.K = K;
   p.MT = (M + 255) / 256;
-  p.NT = N / 256;
+  p.NT = N / (impl == 2 ? 128 : 256);
   p.nk = K / 64;
   p.ntiles = p.MT * p.NT;
   const char *gm_env = getenv("S6D_GEMM_GM");                            // tile-order experiment knob
   p.GM = (gm_env && atoi(gm_env) > 0) ? atoi(gm_env) : 8;
+  hipStream_t st = as_stream(stream);
+  if (impl == 2) {
+    if (max_blocks <= 0) max_blocks = 512;                               // two persistent workgroups per CU
+    int grid = p.ntiles < max_blocks ? p.ntiles : max_blocks;
+    grid = (grid + 7) & ~7;
+    const size_t lds = (size_t)5 * kSlot;
+#define S6D_GEMM2_LAUNCH(E, HB)                                                                                         \
+  do {                                                                                                                  \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm2_bf16_kernel<E, HB>),                                \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                    \
+    hipLaunchKernelGGL((gemm2_bf16_kernel<E, HB>), dim3(grid), dim3(256), lds, st, p);                                  \
+  } while (0)
+    if (epilogue == 1) {
+      if (bias) S6D_GEMM2_LAUNCH(1, true); else S6D_GEMM2_LAUNCH(1, false);
+    } else {
+      if (bias) S6D_GEMM2_LAUNCH(0, true); else S6D_GEMM2_LAUNCH(0, false);
+    }
+#undef S6D_GEMM2_LAUNCH
+    return launch_status();
+  }
   if (max_blocks <= 0) max_blocks = 256;                                 // one persistent workgroup per CU
   int grid = p.ntiles < max_blocks ? p.ntiles : max_blocks;
   grid = (grid + 7) & ~7;                                                // whole XCD rounds
   const size_t lds = (size_t)kRing * kSlot;
-  hipStream_t st = as_stream(stream);
 #define S6D_GEMM_LAUNCH(E, HB)                                                                                          \
   do {                                                                                                                  \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<E, HB>),                                 \

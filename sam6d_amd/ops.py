@@ -429,7 +429,7 @@ def seq_attention(qkv, num_heads, scale):
 
 def gemm_bf16(a, w, bias=None, gelu=False, out=None, max_blocks=0):
     """a (..., K) bf16 (rows may be strided), w (N, K) bf16 = nn.Linear.weight, bias (N) f32 or None ->
-    act(a @ w.T + bias) (..., N) bf16 with act = exact GELU or identity; N % 256 == 0, K % 64 == 0."""
+    act(a @ w.T + bias) (..., N) bf16 with act = exact GELU or identity; N % 128 == 0, K % 64 == 0."""
     if not a.is_cuda or not w.is_cuda:
         raise RuntimeError("a and w must be CUDA tensors")
     if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:

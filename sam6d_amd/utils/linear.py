@@ -1,7 +1,7 @@
 """nn.Linear (+ exact GELU) through the hand-written bf16 GEMM (csrc/s6d_gemm.hip) for the ViTs on the hot path.
 
 The modules keep their nn.Linear parameters (state_dict surface of the reference unchanged); this helper only decides
-how the statement  act(x @ W^T + b)  is executed: on a device bf16 activation with N % 256 == 0 and K % 64 == 0 it is one
+how the statement  act(x @ W^T + b)  is executed: on a device bf16 activation with N % 128 == 0 and K % 64 == 0 it is one
 launch of s6d_gemm_bf16 (bias and GELU in the epilogue), otherwise the library statement.  `S6D_DISABLE_FUSED=gemm_bf16`
 turns the kernel off (A/B runs)."""
 import torch
@@ -24,7 +24,7 @@ def _cached(lin, w2d):
 
 
 def eligible(x, n_out, k_in):
-    return (x.is_cuda and x.dtype == torch.bfloat16 and n_out % 256 == 0 and k_in % 64 == 0 and ops.have("gemm_bf16"))
+    return (x.is_cuda and x.dtype == torch.bfloat16 and n_out % 128 == 0 and k_in % 64 == 0 and ops.have("gemm_bf16"))
 
 
 def fused_linear(lin, x, gelu=False, weight2d=None):

@@ -41,6 +41,7 @@ CASES = [
     (300, 256, 320, True, True, 0, 8),         # ragged M, strided A rows, ring wraps (5 K tiles), GELU epilogue
     (700, 512, 192, True, False, 8, 0),        # 6 tiles on 8 workgroups
     (1280, 768, 192, True, True, 8, 0),        # 15 tiles on 8 workgroups: persistent stream across output tiles
+    (520, 384, 256, True, True, 8, 0),         # N % 256 != 0 (256 x 128 tiles only), ragged M, 9 tiles on 8 workgroups
 ]
 
 
@@ -60,13 +61,17 @@ def _run_case(i):
     _check(ops, M, N, K, bias, gelu, mb, pad, seed=i)
 
 
+@pytest.mark.parametrize("impl", [2, 1])
 @pytest.mark.parametrize("mode", ["early", "late"])
 @pytest.mark.parametrize("case", range(len(CASES)))
-def test_gemm_on_the_emulator(case, mode):
-    if case == 4 and not os.environ.get("S6D_EMU_SLOW") and mode == "late":
-        pytest.skip("long case runs once by default (S6D_EMU_SLOW=1 for both completion models)")
-    # HIPEMU_GLDS is read once per process: each completion model gets its own interpreter
-    env = dict(os.environ, HIPEMU_GLDS=mode)
+def test_gemm_on_the_emulator(case, mode, impl):
+    """impl 2 = two independent 256 x 128 workgroups per CU (the default), 1 = the eight-wave 256 x 256 kernel (S6D_GEMM_IMPL=1)."""
+    if case == 4 and not os.environ.get("S6D_EMU_SLOW") and (mode == "late" or impl == 1):
+        pytest.skip("long case runs once by default (S6D_EMU_SLOW=1 for every combination)")
+    if impl == 1 and CASES[case][1] % 256:
+        pytest.skip("the 256 x 256 kernel needs N % 256 == 0 (the launcher routes other N to the 256 x 128 kernel)")
+    # HIPEMU_GLDS / S6D_GEMM_IMPL are read once per process: each combination gets its own interpreter
+    env = dict(os.environ, HIPEMU_GLDS=mode, S6D_GEMM_IMPL=str(impl))
     r = subprocess.run([sys.executable, "-c", f"import sys; sys.path.insert(0, {ROOT!r}); "
                         f"from tests import test_emu_gemm as t; t._run_case({case})"], env=env, capture_output=True,
                        text=True, timeout=1500)

@@ -1,6 +1,6 @@
 """Time s6d_gemm_bf16 (csrc/s6d_gemm.hip) against the library GEMM (hipBLASLt through torch) at the Linear shapes of the
 three ViTs on the path, check it against an fp32 product of the same bf16 operands, and run the profiling variants built by
-tools/gemm_variants.sh.  Usage: python tools/gemm_time.py [quick|full|pmc]   (writes gpurun_out/gemm_time.json)"""
+tools/gemm_variants.sh.  Usage: python tools/gemm_time.py [quick|full|shapes|pmc]   (writes gpurun_out/gemm_time.json)"""
 import ctypes
 import json
 import os
@@ -75,7 +75,7 @@ def main():
             call(L, a, w, b, out, True)
         torch.cuda.synchronize()
         return
-    shapes = SHAPES if mode == "full" else SHAPES[:4]
+    shapes = SHAPES[:4] if mode == "quick" else SHAPES
     for name, M, K, N, gelu in shapes:
         a, w, b = make(M, N, K)
         out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
@@ -94,6 +94,11 @@ def main():
                "speedup_vs_lib_total": round((ms_lib + ms_gelu) / ms, 3), "mismatches": bad, "max_err": emax}
         res["shapes"].append(row)
         print(row, flush=True)
+    if mode == "shapes":                    # the shape table only (one run per S6D_GEMM_IMPL)
+        tag = os.environ.get("S6D_GEMM_IMPL", "2")
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        json.dump(res, open(os.path.join(ROOT, "gpurun_out", f"gemm_time_impl{tag}.json"), "w"), indent=1)
+        return
     # profiling variants, grid sizes and tile orders on the dominant shape
     a, w, b = make(65536, 5120, 1280)
     out = torch.empty(65536, 5120, dtype=torch.bfloat16, device="cuda")

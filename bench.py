@@ -265,8 +265,11 @@ def _pmc_traffic(kernel_name):
 
 
 def cpu_baseline():
-    """CPU restatement (oracle = 'port' of the reference algorithm) timed on the host cores on a
-    bounded sample: 1 SAM ViT-H frame + 1 ISM frame + a PEM batch of 2 instances."""
+    """CPU restatement (oracle = 'port' of the reference algorithm) timed on the host cores on a bounded sample of the same
+    workload: 1 SAM ViT-H frame + 1 ISM frame (P = 128) + a PEM batch of 2 instances; per SURVEY 8(d) each leg is 1 warm-up
+    run + the MEDIAN of 3 timed runs, and the core count used is stated next to ``nproc``."""
+    import statistics
+
     from oracle import ism as oism
     from oracle import pem as opem
     from oracle import sam as osam
@@ -274,29 +277,37 @@ def cpu_baseline():
     from sam6d_amd.sam.image_encoder import build_vit_h
     from sam6d_amd.utils import seeded, synth
 
-    cores = min(os.cpu_count(), 32)          # torch CPU kernels stop scaling (and regress) beyond ~32 threads
+    nproc = os.cpu_count()
+    cores = min(nproc, 32)          # torch CPU kernels stop scaling (and regress) beyond ~32 threads
     torch.set_num_threads(cores)
+
+    def med3(fn):
+        fn()                        # warm-up (thread pool, allocator, first-touch of the weights)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts), ts
+
     with torch.no_grad():
         Wp = {k: v for k, v in seeded.load_seeded(pm.Net(pm.default_cfg()), 1).state_dict().items()}
         inp = synth.pem_inputs(2, seed=1)
         ep = {k: inp[k] for k in ("pts", "rgb", "rgb_choose", "model", "dense_po", "dense_fo")}
-        t0 = time.time()
-        opem.net_forward(Wp, ep, synth.coarse_uniforms(2, 2))
-        t_pem = (time.time() - t0) / 2
+        ru = synth.coarse_uniforms(2, 2)
+        t_pem, pem_runs = med3(lambda: opem.net_forward(Wp, ep, ru))
+        t_pem /= 2
         ii = synth.ism_inputs(P=P_PROPOSALS, O=1, T=42, seed=11)
-        t0 = time.time()
-        oism.score_frame(ii)
-        t_ism = time.time() - t0
+        t_ism, _ = med3(lambda: oism.score_frame(ii))
         with torch.device("cpu"):
             Ws = {k: v for k, v in seeded.load_seeded(build_vit_h(), 3).state_dict().items()}
         x = synth.sam_input(1, 5, 1024)
-        t0 = time.time()
-        osam.encoder_forward(Ws, x, osam.VIT_H)
-        t_sam = time.time() - t0
+        t_sam, sam_runs = med3(lambda: osam.encoder_forward(Ws, x, osam.VIT_H))
     per_frame = t_sam + t_ism + t_pem
-    return {"value": 1.0 / per_frame, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"1 SAM ViT-H frame ({t_sam:.2f}s) + 1 ISM frame P=128 ({t_ism:.3f}s) + PEM batch of 2 "
-                      f"({t_pem:.2f}s/instance), fp32 torch CPU oracle"}
+    return {"value": 1.0 / per_frame, "unit": "frames/s", "cores": cores, "nproc": nproc, "kind": "port",
+            "sample": f"1 warm-up + median of 3 per leg: 1 SAM ViT-H frame ({t_sam:.2f}s; runs "
+                      f"{'/'.join(f'{t:.2f}' for t in sam_runs)}) + 1 ISM frame P=128 ({t_ism:.3f}s) + PEM batch of 2 "
+                      f"({t_pem:.2f}s/instance; runs {'/'.join(f'{t / 2:.2f}' for t in pem_runs)}), fp32 torch CPU oracle"}
 
 
 def main():

@@ -71,6 +71,19 @@ typedef unsigned short u16;
 #define S6D_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 #endif
 
+// Epilogue layout.  Measured on the ViT-H shapes (profiles/r02_gemm_variants.json): the same kernel without its stores runs
+// qkv / proj 25 % faster -- the stores, not the matrix work, are the largest loss at K = 1280.  In the accumulator layout a lane
+// owns ONE output row, so a 16-byte-per-lane store instruction touches 64 different rows: 64 write requests of 16 B.  With
+// S6D_GEMM_QT (default) the four lanes of a quad exchange their four 16-byte chunks (a 4 x 4 transpose by DPP quad_perm) so
+// that a quad holds 64 contiguous bytes of one row: 16 requests of 64 B per instruction.  Two things make that possible without
+// a second exchange: the W rows are fed to the matrix instruction in a permuted order (lane half hb owns columns 32 hb ..
+// 32 hb + 31 of the wave's 64, tile nt the 16-column group nt of each half), which also removes the permlane32 swaps.
+// Tried and dropped (same file): the epilogue rolled quadrant by quadrant into the next tile's first K tile (-3 %: its VALU work
+// lengthens the load segments) and start-time staggering of the workgroups (-4 %).
+#ifndef S6D_GEMM_QT
+#define S6D_GEMM_QT 1
+#endif
+
 struct GemmParams {
   const u16 *A;       // (M,K) bf16, row stride lda
   const u16 *W;       // (N,K) bf16, row stride ldw
@@ -198,6 +211,21 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
   auto frag = [&](int slot, unsigned rowbytes, int ks) __attribute__((always_inline)) -> bf16x8 {
     return *reinterpret_cast<const bf16x8 *>(gemm_smem + slot * kSlot + rowbytes + foff[ks]);
   };
+  // W fragment of n tile nt.  S6D_GEMM_QT: matrix row a (= A-operand lane, a = 4 h + 8 qd + e with h = (a >> 2) & 1) is fed W row
+  // 32 h + 16 nt + 4 qd + e of the wave's 64, so that in the accumulators lane half h owns columns 32 h + 16 nt + {0..15}.
+  // (rows mod 16 stay distinct inside every ds_read_b128 lane group: the swizzle stays conflict-free)
+  unsigned wfo[2][4];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int a = lane & 31;
+    const int row = S6D_GEMM_QT ? 32 * ((a >> 2) & 1) + 16 * nt + 4 * (a >> 3) + (a & 3) : 32 * nt + a;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      wfo[nt][ks] = brow + (unsigned)(row * 128 + ((((2 * ks) | (lane >> 5)) ^ ((row >> 1) & 7)) << 4));
+  }
+  auto wfrag = [&](int slot, int nt, int ks) __attribute__((always_inline)) -> bf16x8 {
+    return *reinterpret_cast<const bf16x8 *>(gemm_smem + slot * kSlot + wfo[nt][ks]);
+  };
 
   f32x16 acc[4][2];                                                      // [m tile][n tile], transposed: lane -> m, regs -> n
   bf16x8 xf[2][4], wf[2][4];                                             // activation rows (2 m tiles), W rows (2 n tiles) x 4 k steps
@@ -205,7 +233,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
   int cm0, cn0;
   tile_mn(0, cm0, cn0);
 
-  auto init_acc = [&](int n0) __attribute__((always_inline)) {                                          // accumulators start at the bias (scalar loads)
+  auto init_acc = [&](int n0) __attribute__((always_inline)) {          // accumulators start at the bias (scalar loads)
     const int nb = __builtin_amdgcn_readfirstlane(n0 + wc * 64);
     const S6D_CONST(float) *bs = (const S6D_CONST(float) *)p.bias + nb;
     const bool hi = (lane >> 5) != 0;
@@ -213,63 +241,117 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
-        float v[8];                                                      // bias of columns 32 nt + 8 qd + {0..7}
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = HAS_BIAS ? bs[nt * 32 + 8 * qd + e] : 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float b = hi ? v[4 + e] : v[e];
+          // register 4 qd + e of lane half h: column 32 h + 16 nt + 4 qd + e (QT) / 32 nt + 8 qd + 4 h + e
+          const int c0 = S6D_GEMM_QT ? 16 * nt + 4 * qd + e : 32 * nt + 8 * qd + e;
+          const int c1 = S6D_GEMM_QT ? c0 + 32 : c0 + 4;
+          const float b = HAS_BIAS ? (hi ? bs[c1] : bs[c0]) : 0.f;
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) acc[mt][nt][4 * qd + e] = b;
         }
       }
   };
 
-  auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) {
+  auto epilogue_one = [&](int mt, int nt, int m0, int n0) __attribute__((always_inline)) {   // one 32 x 32 accumulator tile
     const int hb = lane >> 5;
+    const int m = m0 + wr * 128 + mt * 32 + (lane & 31);
+    unsigned pk[4][2];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const int m = m0 + wr * 128 + mt * 32 + (lane & 31);
+    for (int qd = 0; qd < 4; ++qd) {
+      float v[4];
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        unsigned pk[4][2];
+      for (int e = 0; e < 4; ++e) {
+        v[e] = acc[mt][nt][4 * qd + e];
+        if (EPI == 1) v[e] = gelu_erf(v[e]);
+      }
+      pk[qd][0] = pack_bf16(v[0], v[1]);
+      pk[qd][1] = pack_bf16(v[2], v[3]);
+    }
+    // quad qd holds columns 8 qd + 4 hb + {0..3}: swapping the upper lane half of quad 2j with the lower lane half of
+    // quad 2j + 1 leaves each lane 8 consecutive columns 16 j + 8 hb + {0..7} of its row
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = acc[mt][nt][4 * qd + e];
-            if (EPI == 1) v[e] = gelu_erf(v[e]);
-          }
-          pk[qd][0] = pack_bf16(v[0], v[1]);
-          pk[qd][1] = pack_bf16(v[2], v[3]);
-        }
-        // quad qd holds columns 8 qd + 4 hb + {0..3}: swapping the upper lane half of quad 2j with the lower lane half of
-        // quad 2j + 1 leaves each lane 8 consecutive columns 16 j + 8 hb + {0..7} of its row
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          uint4 o;
-          {
-            auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * j][0], pk[2 * j + 1][0], false, false);
-            auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * j][1], pk[2 * j + 1][1], false, false);
-            o.x = s0[0];
-            o.y = s1[0];
-            o.z = s0[1];
-            o.w = s1[1];
-          }
-          if (S6D_GEMM_ABLATE & 4) {
+    for (int j = 0; j < 2; ++j) {
+      uint4 o;
+      {
+        auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * j][0], pk[2 * j + 1][0], false, false);
+        auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * j][1], pk[2 * j + 1][1], false, false);
+        o.x = s0[0];
+        o.y = s1[0];
+        o.z = s0[1];
+        o.w = s1[1];
+      }
+      if (S6D_GEMM_ABLATE & 4) {
 #ifndef HIPEMU
-            asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));   // keep the epilogue arithmetic alive
+        asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));   // keep the epilogue arithmetic alive
 #endif
-          } else if (m < p.M) {
-            u16 *dst = p.C + (size_t)m * p.ldc + (n0 + wc * 64 + nt * 32 + 16 * j + 8 * hb);
-            *reinterpret_cast<uint4 *>(dst) = o;
-          }
-        }
+      } else if (m < p.M) {
+        u16 *dst = p.C + (size_t)m * p.ldc + (n0 + wc * 64 + nt * 32 + 16 * j + 8 * hb);
+        *reinterpret_cast<uint4 *>(dst) = o;
       }
     }
   };
-
+  // S6D_GEMM_QT: the 32 x 64 strip of m tile mt.  A lane holds 4 chunks of 8 consecutive columns of its row (chunk 2 nt + k =
+  // columns 32 h + 16 nt + 8 k ..); the 4 x 4 transpose inside each lane quad turns that into chunk (lane & 3) of the four rows
+  // of the quad, i.e. a quad writes 64 contiguous bytes per instruction
+  auto epilogue_qt = [&](int mt, int m0, int n0) __attribute__((always_inline)) {
+    unsigned X[4][4];                                                    // [chunk][dword]
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          float v0 = acc[mt][nt][8 * k + 2 * d], v1 = acc[mt][nt][8 * k + 2 * d + 1];
+          if (EPI == 1) {
+            v0 = gelu_erf(v0);
+            v1 = gelu_erf(v1);
+          }
+          X[2 * nt + k][d] = pack_bf16(v0, v1);
+        }
+    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      // bit 0 of (chunk index, lane): pairs (0,1), (2,3) with the neighbour lane ^ 1; then bit 1: pairs (0,2), (1,3) with lane ^ 2
+#pragma unroll
+      for (int q = 0; q < 4; q += 2) {
+        const unsigned send = b0 ? X[q][d] : X[q + 1][d];
+        const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+        X[q][d] = b0 ? recv : X[q][d];
+        X[q + 1][d] = b0 ? X[q + 1][d] : recv;
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const unsigned send = b1 ? X[q][d] : X[q + 2][d];
+        const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+        X[q][d] = b1 ? recv : X[q][d];
+        X[q + 2][d] = b1 ? X[q + 2][d] : recv;
+      }
+    }
+    const int mq = m0 + wr * 128 + mt * 32 + (lane & 28);                // first row of this lane's quad
+    const int col = n0 + wc * 64 + 32 * (lane >> 5) + 8 * (lane & 3);
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      if (S6D_GEMM_ABLATE & 4) {
+#ifndef HIPEMU
+        asm volatile("" ::"v"(X[y][0]), "v"(X[y][1]), "v"(X[y][2]), "v"(X[y][3]));
+#endif
+      } else if (mq + y < p.M) {
+        *reinterpret_cast<uint4 *>(p.C + (size_t)(mq + y) * p.ldc + col) = make_uint4(X[y][0], X[y][1], X[y][2], X[y][3]);
+      }
+    }
+  };
+  auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      if (S6D_GEMM_QT) {
+        epilogue_qt(mt, m0, n0);
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) epilogue_one(mt, nt, m0, n0);
+      }
+    }
+  };
 #define S6D_MFMA(C, A, B)                                                              \
   do {                                                                                 \
     if (S6D_GEMM_ABLATE & 2) {                                                         \
@@ -312,7 +394,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
   init_acc(cn0);
   S6D_BARRIER();
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) wf[0][ks] = frag(wc >> 1, brow, ks);      // B(0), n tile 0
+  for (int ks = 0; ks < 4; ++ks) wf[0][ks] = wfrag(wc >> 1, 0, ks);        // B(0), n tile 0
   if (wr == 1) S6D_BARRIER();                             // the M halves run one barrier apart from here on
 
   int s0 = 0;                                                            // ring slot of B0 of K tile g: (4 g) % 10
@@ -334,7 +416,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
 
     // phase 2: W rows 32..63 of this wave -> quadrant (0,1)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) wf[1][ks] = frag(sB, brow + 4096u, ks);
+    for (int ks = 0; ks < 4; ++ks) wf[1][ks] = wfrag(sB, 1, ks);
     if (more2) issue_b(0, ring(s0 + 8));                                 // B0(g + 2)
     S6D_BARRIER();
     S6D_MSEG(0, 1);
@@ -358,7 +440,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
     // phase 4: next K tile's W rows 0..31 (wf[0] is free after quadrant (1,0)) -> quadrant (1,1)
     if (more1) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) wf[0][ks] = frag(sBn, brow, ks);
+      for (int ks = 0; ks < 4; ++ks) wf[0][ks] = wfrag(sBn, 0, ks);
     }
     if (more2) {
       issue_a(0, s0);                                                    // A0(g + 2) into the slot B0(g) just left
@@ -606,11 +688,14 @@ __global__ void __launch_bounds__(256, 2) gemm2_bf16_kernel(GemmParams p) {
 using namespace s6d;
 
 // Which kernel: 2 = two independent 256 x 128 workgroups per CU (N % 128 == 0), 1 = the eight-wave 256 x 256 machine (N % 256 == 0).
+#ifndef S6D_GEMM_DEFAULT_IMPL
+#define S6D_GEMM_DEFAULT_IMPL 1     // measured (profiles/r02_gemm_v2_vs_v1.json): version 1 is ahead on every ViT-H shape
+#endif
 static int gemm_impl() {
   static int impl = -1;
   if (impl < 0) {
     const char *e = getenv("S6D_GEMM_IMPL");
-    impl = (e && atoi(e) == 1) ? 1 : 2;
+    impl = (e && (atoi(e) == 1 || atoi(e) == 2)) ? atoi(e) : S6D_GEMM_DEFAULT_IMPL;
   }
   return impl;
 }

@@ -12,7 +12,9 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(REPO, "sam6d_amd", "csrc")
 EMU = os.path.join(HERE, "host_cc", "hipemu")
 OUT = os.path.join(HERE, "host_cc", "_build")
-SO = os.path.join(OUT, "libsam6d_emu.so")
+# HIPEMU_EXTRA: extra compiler flags (e.g. "-DS6D_GEMM_ROLL=1" for a kernel variant); each setting gets its own library file
+EXTRA = os.environ.get("HIPEMU_EXTRA", "").split()
+SO = os.path.join(OUT, "libsam6d_emu" + ("_" + re.sub(r"[^A-Za-z0-9]+", "_", "".join(EXTRA)) if EXTRA else "") + ".so")
 CXX = os.environ.get("HIPEMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 DYN_NAMES = ("smem", "ps_smem", "sd_smem", "t2i_smem", "gemm_smem", "fm_smem")
 
@@ -48,7 +50,7 @@ def build(force=False, files=None):
     dyn = os.path.join(OUT, "_dyn_shared.cc")
     with open(dyn, "w") as g:
         g.write("namespace s6d {\n" + "".join(f"alignas(64) char {n}[160 * 1024];\n" for n in DYN_NAMES) + "}\n")
-    cmd = [CXX, "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-ffp-contract=off", "-I", EMU, "-I", CSRC, "-I",
+    cmd = [CXX, "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-ffp-contract=off"] + EXTRA + ["-I", EMU, "-I", CSRC, "-I",
            os.path.join(REPO, "include"), "-o", SO, os.path.join(EMU, "hipemu.cc"), dyn] + srcs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode:

@@ -228,6 +228,18 @@ static inline hipemu_u32x2 __builtin_amdgcn_permlane32_swap(unsigned vdst, unsig
   hipemu::end_exchange();
   return r;
 }
+// v_mov_b32_dpp with a quad_perm control (dpp_ctrl < 0x100): lane l reads lane (l & ~3) + ((ctrl >> 2 (l & 3)) & 3)
+static inline int __builtin_amdgcn_mov_dpp(int src, int dpp_ctrl, int, int, bool) {
+  if (dpp_ctrl >= 0x100) {
+    std::fprintf(stderr, "hipemu: only quad_perm DPP controls are emulated (got 0x%x)\n", dpp_ctrl);
+    std::abort();
+  }
+  hipemu::begin_exchange(src, 10);
+  const int l = hipemu::lane_of();
+  const int r = hipemu::peek<int>((l & ~3) + ((dpp_ctrl >> (2 * (l & 3))) & 3));
+  hipemu::end_exchange();
+  return r;
+}
 // global_load_lds_dwordx4 (and narrower): LDS address = M0 (wave-uniform base) + lane * size; the global address is per lane
 template <class G, class L>
 static inline void hipemu_global_load_lds(G g, L l, int size) {

@@ -128,7 +128,7 @@ def test_fine_assign_vs_oracle(ops, B, M):
 def test_fine_match_vs_oracle(ops, B, M):
     """Similarity + assignment fused (s6d_fine_match_f32: split-bf16 MFMA tiles, three sweeps, no (B,M,M) matrix) against the
     reference chain compute_feature_similarity -> compute_fine_Rt head.  Tolerances: labels exact, weights and assigned points
-    2e-5 (the tiles are fp32-class: the dropped lo.lo term is below 2^-16 of a product)."""
+    weights 2e-5 relative, assigned points 5e-5 absolute on |pts| <= 4.5 (the split drops lo.lo and the rounding of lo: <= 3 x 2^-18 of a product, times log2(e) / temp = 14.4 in the exponent; measured 1.7e-5 relative on the weights at B = 32)."""
     _check_fine_match(ops, B, M, M)
 
 
@@ -149,7 +149,7 @@ def _check_fine_match(ops, B, M1, M2):
     p, ws, w = (t.cpu() for t in ops.fine_match(f1.cuda(), f2.cuda(), pts2.cuda(), 0.1))
     assert torch.equal(w, w1), (w != w1).sum()
     assert (ws - wsum).abs().max() < 2e-5 * max(1.0, wsum.abs().max().item()), (ws - wsum).abs().max()
-    assert (p - pred).abs().max() < 2e-5, (p - pred).abs().max()
+    assert (p - pred).abs().max() < 5e-5, (p - pred).abs().max()
 
 
 def test_positional_encoding_fused_vs_oracle(ops):

@@ -75,7 +75,7 @@ def main():
             call(L, a, w, b, out, True)
         torch.cuda.synchronize()
         return
-    shapes = SHAPES[:4] if mode == "quick" else SHAPES
+    shapes = [] if mode == "variants" else SHAPES[:4] if mode == "quick" else SHAPES
     for name, M, K, N, gelu in shapes:
         a, w, b = make(M, N, K)
         out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
@@ -94,6 +94,24 @@ def main():
                "speedup_vs_lib_total": round((ms_lib + ms_gelu) / ms, 3), "mismatches": bad, "max_err": emax}
         res["shapes"].append(row)
         print(row, flush=True)
+    if mode == "variants":                  # every library of tools/gemm_variants on the four ViT-H shapes
+        import glob
+        out = {}
+        data = {name: (make(M, N, K), torch.empty(M, N, dtype=torch.bfloat16, device="cuda"), gelu, 2.0 * M * N * K)
+                for name, M, K, N, gelu in SHAPES[:4]}
+        libs = sorted(glob.glob(os.path.join(ROOT, "tools", "gemm_variants", "libgemm_*.so")))
+        for rep in range(2):                # two interleaved rounds: run-to-run spread next to the differences
+            for path in libs:
+                v = os.path.basename(path)[8:-3]
+                Lv = ctypes.CDLL(path)
+                for name, ((a, w, b), o, gelu, fl) in data.items():
+                    ms = event_ms(lambda: call(Lv, a, w, b, o, gelu), n=20, warm=3)
+                    out.setdefault(v, {}).setdefault(name, []).append(round(fl / ms / 1e9, 1))
+        for v, d in out.items():
+            print(v.ljust(12), {k: x for k, x in d.items()}, flush=True)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        json.dump(out, open(os.path.join(ROOT, "gpurun_out", "gemm_variants.json"), "w"), indent=1)
+        return
     if mode == "shapes":                    # the shape table only (one run per S6D_GEMM_IMPL)
         tag = os.environ.get("S6D_GEMM_IMPL", "2")
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

@@ -8,10 +8,8 @@ mkdir -p $OUT
 FLAGS="-O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form -Wno-unused-function"
 build() { /opt/rocm/bin/hipcc $FLAGS $2 -o $OUT/libgemm_$1.so sam6d_amd/csrc/s6d_gemm.hip sam6d_amd/csrc/s6d_capi.hip & }
 build base ""
-build noprio "-DS6D_GEMM_NOPRIO"
-build nodma "-DS6D_GEMM_ABLATE=1"
-build nomfma "-DS6D_GEMM_ABLATE=2"
+build noqt "-DS6D_GEMM_QT=0"
 build nostore "-DS6D_GEMM_ABLATE=4"
-build mfmaonly "-DS6D_GEMM_ABLATE=5"
+build v2 "-DS6D_GEMM_DEFAULT_IMPL=2"
 wait
 ls -la $OUT

@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--sam-chunk", type=int, default=int(os.environ.get("S6D_SAM_CHUNK", str(SAM_CHUNK))))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the whole-frame `pipeline` block (all five models)")
     return ap.parse_args()
 
 
@@ -240,27 +241,47 @@ def kernel_rooflines(dev, sam_chunk, frames):
                 "unit": "TFLOP/s (bf16 MFMA executed = 3x the algorithmic fp32 FLOP)",
                 "frac": round(3 * flop / ms / 1e9 / 2500.0, 4), "avg_ms": round(ms, 4), "launches_per_step": 2,
                 "algorithmic_fp32_tflops": round(flop / ms / 1e9, 1)})
-    # the library GEMM that dominates the SAM stage, for context (hipBLASLt through torch): MLP lin1 shape
-    x = torch.randn(sam_chunk * 4096, 1280, generator=g).to(dev).to(torch.bfloat16)
+    # the Linear layers of the ViT-H blocks: the hand-written bf16 GEMM (csrc/s6d_gemm.hip) at the four shapes of a block, and the
+    # library GEMM (hipBLASLt through torch) at the largest of them for context.  Algorithmic work 2 M N K FLOP.
+    M = sam_chunk * 4096
+    groups = frames // sam_chunk
+    for nm, K, N, gelu in (("qkv", 1280, 3840, False), ("proj", 1280, 1280, False), ("lin1+gelu", 1280, 5120, True),
+                           ("lin2", 5120, 1280, False)):
+        x = torch.randn(M, K, generator=g).to(dev).to(torch.bfloat16)
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).to(torch.bfloat16)
+        b = torch.randn(N, generator=g).to(dev)
+        if not ops.have("gemm_bf16"):
+            break
+        ms = _event_ms(lambda: ops.gemm_bf16(x, w, b, gelu=gelu), 10)
+        flop = 2.0 * M * N * K
+        out.append({"kernel": f"gemm_bf16_kernel ({nm}, M={M} K={K} N={N})", "bound": "mfma", "achieved": round(flop / ms / 1e9, 1),
+                    "peak": 2500.0, "unit": "TFLOP/s", "frac": round(flop / ms / 1e9 / 2500.0, 4), "avg_ms": round(ms, 4),
+                    "launches_per_step": 32 * groups, "algorithmic_bytes": 2.0 * (M * K + N * K + M * N)})
+    x = torch.randn(M, 1280, generator=g).to(dev).to(torch.bfloat16)
     w = torch.randn(5120, 1280, generator=g).to(dev).to(torch.bfloat16)
     bb = torch.randn(5120, generator=g).to(dev).to(torch.bfloat16)
     ms = _event_ms(lambda: torch.nn.functional.linear(x, w, bb), 10)
-    flop = 2.0 * x.shape[0] * 1280 * 5120
-    out.append({"kernel": "library GEMM (hipBLASLt) mlp.lin1 M=%d" % x.shape[0], "bound": "mfma",
+    ms_g = _event_ms(lambda: torch.nn.functional.gelu(torch.nn.functional.linear(x, w, bb)), 10)
+    flop = 2.0 * M * 1280 * 5120
+    out.append({"kernel": "library GEMM (hipBLASLt) mlp.lin1 M=%d" % M, "bound": "mfma",
                 "achieved": round(flop / ms / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                "frac": round(flop / ms / 1e9 / 2500.0, 4), "avg_ms": round(ms, 4), "launches_per_step": 32 * (frames // sam_chunk)})
+                "frac": round(flop / ms / 1e9 / 2500.0, 4), "avg_ms": round(ms, 4), "with_gelu_pass_ms": round(ms_g, 4),
+                "launches_per_step": 0})
     return out
 
 
 def _pmc_traffic(kernel_name):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_summary.json), if present."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-        for k, v in d.items():
-            if kernel_name.split("<")[0] == k.split("<")[0]:
-                return v.get("hbm_bytes_per_launch")
-    except Exception:
-        pass
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r02_pmc_summary.json, else the round-1 file),
+    if present: FETCH_SIZE (doubled: gfx950 half-count of wide coalesced reads, MI355X_MICROARCH.md) + WRITE_SIZE."""
+    for f in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", f)))
+            for k, v in d.items():
+                if kernel_name.split("<")[0].split(" (")[0] == k.split("<")[0].split(" (")[0] and \
+                        (" (" not in k or k.split(" (")[1][:4] == kernel_name.split(" (")[1][:4]):
+                    return v.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
     return None
 
 
@@ -370,8 +391,8 @@ def main():
         kr = kernel_rooflines(dev, args.sam_chunk, args.frames)
         dom = max((k for k in kr if not k["kernel"].startswith("library")),
                   key=lambda k: k["avg_ms"] * k["launches_per_step"])
-        # dominant HAND-WRITTEN kernel (largest avg duration x launches per step); library GEMMs, which take more
-        # time than any of them, are listed in `kernels` for context
+        # the dominant kernel of the step (largest avg duration x launches per step) -- since round 2 the hand-written bf16 GEMM;
+        # the library GEMM is listed in `kernels` for comparison only (it is not on the path)
         extra["roofline"] = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"],
                              "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
                              "avg_launch_ms": dom["avg_ms"], "traffic": _pmc_traffic(dom["kernel"])}
@@ -379,6 +400,17 @@ def main():
         extra["stage_roofline"] = {"stage": f"SAM ViT-H encoder, {args.frames} frames (bf16 GEMMs + fused attention)",
                                    "bound": "mfma", "achieved": round(achieved / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12,
                                    "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK, 4)}
+        if world == 1 and not args.no_pipeline:
+            # what a whole frame costs: every stage of the chain incl. mask decoding, DINOv2 descriptors and the PEM
+            # pre-processing, K = 10 instances per frame; outside the timed region, reported next to the headline
+            try:
+                del hp
+                torch.cuda.empty_cache()
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import frame_demo
+                extra["pipeline"] = frame_demo.measure(dev)
+            except Exception as e:  # noqa: BLE001
+                extra["pipeline"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             extra["cpu_baseline"] = cpu_baseline()
 

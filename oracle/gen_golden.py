@@ -90,6 +90,39 @@ def gen_pem():
     print("KAT |dR|_F", dR, "score", rec["kat_pred_pose_score"], "t", rec["kat_pred_t"])
 
 
+def gen_pem_b32():
+    """The matching path (coarse + fine point matching, pose solvers) of the reference Net at the BENCHED batch (B = 32): the
+    reference sub-modules in Net.forward's order on the known-answer inputs, outputs only (tests/golden/pem_b32.npz)."""
+    ns = rh.pem()
+    cfg = rh.pem_cfg()
+    net = ns.pose_estimation_model.Net(cfg.model).eval()
+    seeded.load_seeded(net, PEM_CASE["weight_seed"])
+    case = dict(B=32, input_seed=41, rand_seed=42, weight_seed=PEM_CASE["weight_seed"])
+    B = case["B"]
+    inp = synth.pem_inputs(B, seed=case["input_seed"], with_rgb=False)
+    rec = {}
+    with torch.no_grad():
+        radius = torch.norm(inp["dense_po"], dim=2).max(1)[0]
+        s = radius.reshape(-1, 1, 1) + 1e-6
+        dense_pm, dense_po, dense_fm, dense_fo = inp["pts"] / s, inp["dense_po"] / s, inp["dense_fm_kat"], inp["dense_fo"]
+        bg = torch.ones(B, 1, 3) * 100
+        sp_m, sf_m, idx_m = ns.model_utils.sample_pts_feats(dense_pm, dense_fm, 196, return_index=True)
+        geo_m = net.geo_embedding(torch.cat([bg, sp_m], 1))
+        sp_o, sf_o, idx_o = ns.model_utils.sample_pts_feats(dense_po, dense_fo, 196, return_index=True)
+        geo_o = net.geo_embedding(torch.cat([bg, sp_o], 1))
+        e = {"model": inp["model"]}
+        torch.manual_seed(case["rand_seed"])  # the reference draws torch.rand(B, 18000) from this (= synth.coarse_uniforms)
+        e = net.coarse_point_matching(sp_m, sf_m, geo_m, sp_o, sf_o, geo_o, radius, e)
+        e = net.fine_point_matching(dense_pm, dense_fm, geo_m, idx_m, dense_po, dense_fo, geo_o, idx_o, radius, e)
+        for k in ("init_R", "init_t", "pred_R", "pred_t", "pred_pose_score"):
+            rec["kat_" + k] = e[k].numpy()
+        rec["kat_gt_R"], rec["kat_gt_t"] = inp["gt_R"].numpy(), inp["gt_t"].numpy()
+    rec["case"] = np.array(str(case))
+    np.savez_compressed(os.path.join(OUT, "pem_b32.npz"), **rec)
+    dR = np.linalg.norm(rec["kat_pred_R"] - rec["kat_gt_R"], axis=(1, 2))
+    print("pem_b32.npz KAT |dR|_F max", dR.max(), "score min", rec["kat_pred_pose_score"].min())
+
+
 def _sam_ref(cfg, weight_seed):
     enc = rh.sam_encoder()
     from functools import partial
@@ -513,4 +546,4 @@ def gen_dinov2():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    {"pem": gen_pem, "sam": gen_sam, "ism": gen_ism, "dinov2": gen_dinov2, "sam_decoder": gen_sam_decoder, "handoff": gen_handoff, "pem_pre": gen_pem_pre, "pem_results": gen_pem_results, "detections_ops": gen_detections_ops, "sam_transforms": gen_sam_transforms, "sam_state_dict": gen_sam_state_dict}[sys.argv[1]]()
+    {"pem": gen_pem, "pem_b32": gen_pem_b32, "sam": gen_sam, "ism": gen_ism, "dinov2": gen_dinov2, "sam_decoder": gen_sam_decoder, "handoff": gen_handoff, "pem_pre": gen_pem_pre, "pem_results": gen_pem_results, "detections_ops": gen_detections_ops, "sam_transforms": gen_sam_transforms, "sam_state_dict": gen_sam_state_dict}[sys.argv[1]]()

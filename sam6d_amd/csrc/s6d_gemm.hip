@@ -83,6 +83,9 @@ typedef unsigned short u16;
 #ifndef S6D_GEMM_QT
 #define S6D_GEMM_QT 1
 #endif
+// Also tried and dropped: draining the ring (vmcnt(0)) before the stores so that no counted wait sits behind them for 7 phases --
+// the single vector-memory counter makes a counted wait behind 16 stores wait for their acknowledgement -- measured -8 % (the drain
+// itself exposes a load latency per tile and the store cost did not move: profiles/r02_gemm_variants_qt_drain.json).
 
 struct GemmParams {
   const u16 *A;       // (M,K) bf16, row stride lda

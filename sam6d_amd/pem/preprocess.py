@@ -15,7 +15,11 @@ Defined differently from the reference, on purpose (oracle/pem_pre.py explains a
     reference's own draws -- ``np.random.choice`` once per surviving detection, in detection order, :224-227 -- for runs that
     must reproduce a seeded reference run point for point; it costs one more device->host copy of P counts);
   * the colour crop is bilinear with half-pixel centres in float32, rounded to uint8 (the reference calls cv2.resize,
-    whose fixed-point arithmetic can differ by one grey level).
+    whose fixed-point arithmetic can differ by one grey level);
+  * the radius test ``|p - centre| < radius * 1.2`` compares the float32 distance against the float64 product (what numpy does
+    for a float64 ``radius``; for a Python-float radius numpy >= 2 (NEP 50, the version the goldens were made with: 2.2) rounds
+    the product to float32 first, and numpy 1.x did so by value-based casting -- a point would have to lie within one float32
+    ulp of the sphere to tell the three apart).
 """
 import os
 
@@ -100,15 +104,27 @@ def observed_inputs(image_u8, depth, K, masks, radius, keys=None, n_sample=2048,
     dev = depth.device
     P, H, W = masks.shape
     fx, fy, cx, cy = (float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]))
-    if os.environ.get("S6D_PEM_PRE") == "kernels":
-        # kernel path (csrc/s6d_pempre.hip + s6d_segment_seq_sum_f32): one pass per detection for mask AND depth / count / box,
-        # per-detection fixed-capacity lists instead of one frame-wide list, the reference's sequential centroid, no host round
-        # trip before the survivor list.  Opt-in until it has been through the device parity test.
+    if _use_kernels(depth):
+        # kernel path (csrc/s6d_pempre.hip + s6d_segment_seq_sum_f32), the default on the device since its parity tests ran on an
+        # MI355X (round 2): one pass per detection for mask AND depth / count / box, per-detection fixed-capacity lists instead of
+        # one frame-wide list, the reference's sequential centroid, no host round trip before the survivor list.  A slot holds a
+        # whole square crop (cap = min(H,W)^2 points, 16 B each): detections go through in chunks of at most _SLOT_BYTES of slots,
+        # so a frame with hundreds of detections (BOP flow, top_k=None) or a 1080p frame stays bounded.
+        cap = min(H, W) ** 2
+        step = max(1, _SLOT_BYTES // (16 * cap))
+        if P > step:
+            outs = []
+            for i in range(0, P, step):
+                r = radius[i:i + step] if (torch.is_tensor(radius) and radius.numel() > 1) else radius
+                o = observed_inputs(image_u8, depth, K, masks[i:i + step], r, None if keys is None else keys[i:i + step], n_sample,
+                                    img_size, min_points, min_inliers, radius_factor, rgb_mask_flag, rng)
+                o["kept"] = o["kept"] + i
+                outs.append(o)
+            return {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
         from .. import ops
         mb = masks if masks.dtype == torch.bool else masks > 0
         m8, cnt, ok8, box = ops.pem_mask_boxes(mb.contiguous().view(torch.uint8), depth.contiguous(), min_points)
         m, ok1 = None, ok8.bool()
-        cap = min(H, W) ** 2                                                           # a square crop is at most this large
         choose_l, cloud_l, n = ops.pem_compact_cloud(m8, depth.contiguous(), box, ok8, fx, fy, cx, cy, cap)
         start = torch.arange(P, device=dev) * cap
         center = ops.segment_seq_sum(cloud_l.view(P * cap, 3), start, n) / n.clamp(min=1).float()[:, None]
@@ -123,6 +139,7 @@ def observed_inputs(image_u8, depth, K, masks, radius, keys=None, n_sample=2048,
         g = (start[:, None] + idx)[kept]
         rgb = ops.pem_crops(image_u8.contiguous(), m8, kept, box, img_size, rgb_mask_flag, MEAN, STD)
         return _finish(image_u8, m, box, kept, cloud_l.view(-1, 3)[g], choose_l.view(-1)[g].long(), img_size, rgb_mask_flag, rgb)
+    # library-op path (S6D_PEM_PRE=library, and host tensors): the same quantities as batched tensor ops
     m = (masks > 0) & (depth > 0)[None]
     cnt = m.flatten(1).sum(1)
     ok1 = cnt > min_points
@@ -138,14 +155,9 @@ def observed_inputs(image_u8, depth, K, masks, radius, keys=None, n_sample=2048,
     fx_t, fy_t = torch.tensor(fx, device=dev), torch.tensor(fy, device=dev)            # tensor divisors: true division
     cloud = torch.stack([(x_.float() - cx) * z / fx_t, (y_.float() - cy) * z / fy_t, z], 1)  # float32, reference order
     n0 = torch.bincount(p_, minlength=P)
-    if os.environ.get("S6D_PEM_SEQ_CENTROID") == "1":
-        # the reference's np.mean(cloud, axis=0): rows added in order into a float32 accumulator, then one float32 division
-        # (s6d_segment_seq_sum_f32).  Opt-in until it has been through the device parity test.
-        center = _segment_seq_sum(cloud.contiguous(), (torch.cumsum(n0, 0) - n0).contiguous(), n0.contiguous()) \
-            / n0.clamp(min=1).float()[:, None]
-    else:
-        center = (torch.zeros(P, 3, dtype=torch.float64, device=dev).index_add_(0, p_, cloud.double())
-                  / n0.clamp(min=1)[:, None]).float()
+    # the reference's np.mean(cloud, axis=0): rows added in order into a float32 accumulator, then one float32 division
+    center = _segment_seq_sum(cloud.contiguous(), (torch.cumsum(n0, 0) - n0).contiguous(), n0.contiguous()) \
+        / n0.clamp(min=1).float()[:, None]
     dist = torch.linalg.norm(cloud - center[p_], dim=1)
     if torch.is_tensor(radius) and radius.numel() > 1:                                 # one radius per detection (multi-object frames)
         flag = dist.double() < (radius.to(dev).double() * radius_factor)[p_]
@@ -182,10 +194,10 @@ def _finish(image_u8, m, box, kept, pts, ch, img_size, rgb_mask_flag, rgb=None):
 def _keyed_indices(n, keys, n_sample):
     """The defined sampler: (P,n_sample) in-list positions from one uniform per crop pixel."""
     dev = n.device
-    use_kernel = os.environ.get("S6D_PEM_SAMPLER") == "kernel" or os.environ.get("S6D_PEM_PRE") == "kernels"
+    use_kernel = _use_kernels(n) and os.environ.get("S6D_PEM_SAMPLER") != "library"
     if use_kernel and keys.dtype == torch.float32 and keys.is_contiguous() and n_sample <= 2048:
         # one workgroup per detection (s6d_pem_sample_indices_f32) instead of a top-k over a (P, L) table of 64-bit keys; no host
-        # round trip for L.  Opt-in until it has been through the device parity test (DESIGN.md section 4b).
+        # round trip for L
         from .. import ops
         idx, overflow = ops.pem_sample_indices(keys, n.contiguous(), n_sample)
         if not bool(overflow.any()):                                # heavily duplicated keys: the library path below
@@ -220,8 +232,26 @@ def _numpy_choice_indices(n, ok, n_sample, rng):
     return torch.from_numpy(idx)
 
 
-def _segment_seq_sum(x, start, count):
-    """Row-order float32 segment sums on the device (raises on host tensors: there is no CPU implementation in the product)."""
+_SLOT_BYTES = 1 << 30          # bound on the fixed-capacity point slots of one kernel-path call
+
+
+def _use_kernels(t):
+    """The csrc/s6d_pempre.hip path: device tensors, library present, not switched off (S6D_PEM_PRE=library)."""
     from .. import ops
-    return ops.segment_seq_sum(x, start, count)
+    return t.is_cuda and os.environ.get("S6D_PEM_PRE") != "library" and ops.have("pem_pre")
+
+
+def _segment_seq_sum(x, start, count):
+    """Row-order float32 segment sums: the device kernel, or -- for host tensors only (CPU tests of this module's tensor logic;
+    the product path is the device) -- the same sequential float32 accumulation as a loop."""
+    if x.is_cuda:
+        from .. import ops
+        return ops.segment_seq_sum(x, start, count)
+    import numpy as np
+    out = torch.zeros(start.shape[0], x.shape[1], dtype=torch.float32)
+    xn = x.numpy()
+    for i, (s0, c) in enumerate(zip(start.tolist(), count.tolist())):
+        if c:                                                           # add.accumulate is strictly sequential: last row = the running sum
+            out[i] = torch.from_numpy(np.add.accumulate(xn[s0:s0 + c], axis=0, dtype=np.float32)[-1].copy())
+    return out
 

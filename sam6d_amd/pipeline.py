@@ -30,14 +30,16 @@ from .sam.transforms import ResizeLongestSide
 class FramePipeline:
     def __init__(self, sam_encoder, prompt_encoder, mask_decoder, descriptor_model, scorer, pem_net, pem_templates,
                  object_radius, top_k=10, points_per_batch=1024, min_box_size=0.05 ** 2, min_mask_size=3e-4,
-                 segmentor=None, nms_per_object_thresh=None, det_score_thresh=None):
+                 segmentor=None, nms_per_object_thresh=None, det_score_thresh=None, sync_stages=True):
         """descriptor_model: sam6d_amd.ism.dinov2.CustomDINOv2; scorer: sam6d_amd.ism.scoring.FrameScorer (holds the
         template descriptors); pem_templates: dict(dense_po (O,n,3), dense_fo (O,n,C), model (O,m,3)) of the O objects (O = 1: every detection
         is that object; O > 1: rows are picked by the ISM's predicted object id); object_radius: a number or an (O,) tensor;
         segmentor: keyword overrides of amg.generate_proposals (thresholds).  nms_per_object_thresh: the BOP flow's
         ``apply_nms_per_object_id`` after scoring (detector.py:388-390; 0.25 in configs/model/ISM_sam.yaml; the custom
         demo flow has none).  det_score_thresh: only detections scoring above it go to the PEM
-        (run_inference_custom.py:165-171, default 0.2 there); top_k=None keeps every detection."""
+        (run_inference_custom.py:165-171, default 0.2 there); top_k=None keeps every detection.  sync_stages=False: no
+        device synchronisation between the stages (``times`` stays empty): frames issued back to back keep the device queue
+        full across stage and frame boundaries (throughput runs)."""
         self.enc, self.pe, self.md, self.desc, self.scorer, self.pem = (sam_encoder, prompt_encoder, mask_decoder,
                                                                        descriptor_model, scorer, pem_net)
         self.tpl, self.radius, self.top_k, self.ppb = pem_templates, object_radius, top_k, points_per_batch
@@ -45,6 +47,7 @@ class FramePipeline:
         self.seg_kw = segmentor or {}
         self.nms_thresh, self.det_thresh = nms_per_object_thresh, det_score_thresh
         self.times = {}
+        self.sync_stages = sync_stages
 
     def score_metres(self, cls, patch, masks, boxes, depth_m, K):
         """The unit boundary between the two halves of the frame: this class takes depth in METRES (what the PEM
@@ -54,6 +57,8 @@ class FramePipeline:
         return self.scorer.score(cls, patch, masks, boxes, depth_m, K, depth_scale=1000.0)
 
     def _tick(self, name, t0):
+        if not self.sync_stages:
+            return t0
         torch.cuda.synchronize()
         self.times[name] = (time.perf_counter() - t0) * 1e3
         return time.perf_counter()

@@ -42,6 +42,8 @@ CASES = [
     (700, 512, 192, True, False, 8, 0),        # 6 tiles on 8 workgroups
     (1280, 768, 192, True, True, 8, 0),        # 15 tiles on 8 workgroups: persistent stream across output tiles
     (520, 384, 256, True, True, 8, 0),         # N % 256 != 0 (256 x 128 tiles only), ragged M, 9 tiles on 8 workgroups
+    (1280, 768, 64, True, False, 8, 0),        # one K tile per output tile, 15 tiles on 8 workgroups: every K tile is first AND last
+    (1100, 512, 128, False, True, 8, 0),       # two K tiles per output tile, 10 tiles on 8 workgroups (drain / no-wait K tiles adjacent)
 ]
 
 

@@ -7,9 +7,11 @@ from sam6d_amd.pem import preprocess as pre
 
 
 def _lib_path(n, keys, n_sample, monkeypatch):
-    monkeypatch.delenv("S6D_PEM_SAMPLER", raising=False)
-    monkeypatch.delenv("S6D_PEM_PRE", raising=False)
-    return pre._keyed_indices(n, keys, n_sample)
+    monkeypatch.setenv("S6D_PEM_SAMPLER", "library")                 # the top-k formulation (the kernel is the default on the device)
+    try:
+        return pre._keyed_indices(n, keys, n_sample)
+    finally:
+        monkeypatch.delenv("S6D_PEM_SAMPLER")
 
 
 def test_sampler_kernel_equals_the_library_path(emu, monkeypatch):

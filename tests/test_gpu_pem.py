@@ -61,6 +61,30 @@ def test_known_answer_vs_reference_golden_and_truth(net):
     np.testing.assert_allclose(out["pred_pose_score"].cpu().numpy(), g["kat_pred_pose_score"], atol=2e-3)
 
 
+def test_known_answer_at_the_benched_batch_vs_reference_golden(net):
+    """B = 32 (BASELINE configs[1], the batch bench.py runs): the matching path against tests/golden/pem_b32.npz, produced by
+    the reference's own sub-modules (oracle/gen_golden.py pem_b32).  |R - R_ref|_F <= 1e-3, |t - t_ref| <= 1e-3 mm, identical ADD recall."""
+    from sam6d_amd.utils import metrics
+    g = util.golden("pem_b32.npz")
+    case = ast.literal_eval(str(g["case"]))
+    B = case["B"]
+    inp = synth.pem_inputs(B, seed=case["input_seed"], with_rgb=False)
+    radius = torch.norm(inp["dense_po"], dim=2).max(1)[0]
+    s = radius.reshape(-1, 1, 1) + 1e-6
+    ep = _to(dict(model=inp["model"], coarse_rand_u=synth.coarse_uniforms(B, case["rand_seed"])), "cuda")
+    with torch.no_grad():
+        out = net.match((inp["pts"] / s).cuda(), inp["dense_fm_kat"].cuda(), (inp["dense_po"] / s).cuda(),
+                        inp["dense_fo"].cuda(), radius.cuda(), ep)
+    R, t = out["pred_R"].cpu(), out["pred_t"].cpu()
+    dR = np.linalg.norm(R.numpy() - g["kat_pred_R"], axis=(1, 2))
+    dt = np.abs(t.numpy() - g["kat_pred_t"]).max()
+    assert dR.max() <= R_TOL and dt <= T_TOL_M, (dR.max(), dt)
+    np.testing.assert_allclose(out["pred_pose_score"].cpu().numpy(), g["kat_pred_pose_score"], atol=2e-3)
+    a = metrics.add_recall(R, t, inp["gt_R"], inp["gt_t"], inp["model"], 0.2)
+    b = metrics.add_recall(torch.from_numpy(g["kat_pred_R"]), torch.from_numpy(g["kat_pred_t"]), inp["gt_R"], inp["gt_t"], inp["model"], 0.2)
+    assert torch.equal(a[1], b[1]) and a[0] == b[0]
+
+
 @pytest.mark.parametrize("B,seed", [(4, 21), (16, 33)])
 def test_known_answer_vs_oracle_other_seeds(net, B, seed):
     """Same seeded inputs through the CPU oracle and the MI355X path."""

@@ -43,7 +43,6 @@ def test_frame_resize_on_the_device_is_pillow_exact():
         np.testing.assert_array_equal(out.cpu().numpy(), g[tag + "_out"])
 
 
-@pytest.mark.skipif(os.environ.get("S6D_PEM_SEQ_CENTROID") != "1", reason="opt-in path: set S6D_PEM_SEQ_CENTROID=1")
 def test_sequential_centroid_matches_numpy_row_order():
     """s6d_segment_seq_sum_f32 == numpy's add.reduce over axis 0, bit for bit, and with it the pre-processing agrees with the
     oracle at radii whose sphere cuts through dense points (where the float64-accumulated centroid does not)."""
@@ -73,7 +72,6 @@ def test_sequential_centroid_matches_numpy_row_order():
     np.testing.assert_array_equal(out["rgb_choose"].cpu().numpy(), ref["rgb_choose"])
 
 
-@pytest.mark.skipif(os.environ.get("S6D_PEM_SAMPLER") != "kernel", reason="opt-in path: set S6D_PEM_SAMPLER=kernel")
 def test_sampler_kernel_equals_the_library_path_on_the_device(monkeypatch):
     """s6d_pem_sample_indices_f32 against the composite-key top-k it replaces, at frame sizes (480 x 640 keys per detection)."""
     from sam6d_amd import ops
@@ -83,15 +81,16 @@ def test_sampler_kernel_equals_the_library_path_on_the_device(monkeypatch):
     n = torch.tensor([0, 1, 100, 2048, 2049, 3000, 10000, 100000, 307200, 5000])
     keys = torch.rand(len(n), L, generator=g)
     keys[5] = (keys[5] * 3000).floor() / 3000                       # ties: the position decides
-    monkeypatch.delenv("S6D_PEM_SAMPLER")
+    monkeypatch.setenv("S6D_PEM_SAMPLER", "library")
     want = pre._keyed_indices(n.cuda(), keys.cuda(), ns)
     idx, overflow = ops.pem_sample_indices(keys.cuda(), n.cuda(), ns)
     assert overflow.cpu().tolist() == [0] * len(n) and torch.equal(idx, want)
 
 
-@pytest.mark.skipif(os.environ.get("S6D_PEM_PRE") != "kernels", reason="opt-in path: set S6D_PEM_PRE=kernels")
-def test_kernel_path_of_the_preprocessing_on_the_device():
-    """S6D_PEM_PRE=kernels on cuda:0 against the oracle loop (boundary-cutting radii included) and timed at 64 detections."""
+def test_kernel_path_of_the_preprocessing_on_the_device(monkeypatch):
+    """The kernel path (the default on the device) on cuda:0 against the oracle loop (boundary-cutting radii included), the
+    library-op path (S6D_PEM_PRE=library) against the same oracle, the chunked form of a many-detection frame, timing at 64
+    detections."""
     import time
 
     import numpy as np
@@ -109,9 +108,20 @@ def test_kernel_path_of_the_preprocessing_on_the_device():
     assert out["kept"].cpu().tolist() == ref["kept"].tolist()
     for k in ("bbox", "pts", "rgb_choose", "rgb"):
         np.testing.assert_array_equal(out[k].cpu().numpy(), ref[k], err_msg=k)
+    monkeypatch.setenv("S6D_PEM_PRE", "library")
+    lib = pre.observed_inputs(torch.from_numpy(inp["image"]).cuda(), inp["depth"].cuda(), inp["K"], inp["masks"].cuda(),
+                              torch.from_numpy(radius).cuda(), keys=inp["keys"].cuda(), **kw)
+    monkeypatch.delenv("S6D_PEM_PRE")
+    for k in ("kept", "bbox", "pts", "rgb_choose"):
+        np.testing.assert_array_equal(lib[k].cpu().numpy(), ref[k], err_msg="library path: " + k)
     big = synth.pem_pre_inputs(P=64, seed=9)
     args = (torch.from_numpy(big["image"]).cuda(), big["depth"].cuda(), big["K"], big["masks"].cuda(), 0.15, big["keys"].cuda())
-    pre.observed_inputs(*args)
+    whole = pre.observed_inputs(*args)
+    monkeypatch.setattr(pre, "_SLOT_BYTES", 16 * 480 * 480 * 10)     # 10 detections per chunk
+    parts = pre.observed_inputs(*args)
+    monkeypatch.undo()
+    for k in whole:
+        assert torch.equal(whole[k], parts[k]), "chunked call: " + k
     torch.cuda.synchronize()
     t0 = time.time()
     for _ in range(3):

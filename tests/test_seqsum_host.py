@@ -49,8 +49,9 @@ def test_kernel_source_equals_numpy_row_order(tmp_path):
 
 
 def test_preprocessing_with_the_sequential_centroid_matches_the_oracle(tmp_path, monkeypatch):
-    """observed_inputs with its centroid replaced by the kernel's arithmetic (through the host build) == oracle loop at the
-    radii where the default float64-accumulated centroid flips boundary points."""
+    """observed_inputs == oracle loop at the radii where a float64-accumulated centroid (round 1's default, deleted in round 2)
+    flipped boundary points: with the module's own sequential float32 centroid, and with the centroid kernel's arithmetic
+    (through the host build) in its place."""
     from oracle import pem_pre as opre
     from sam6d_amd.pem import preprocess as pre
     from sam6d_amd.utils import synth
@@ -62,12 +63,11 @@ def test_preprocessing_with_the_sequential_centroid_matches_the_oracle(tmp_path,
                                 keys=inp["keys"].numpy(), **kw)
     args = (torch.from_numpy(inp["image"]), inp["depth"], inp["K"], inp["masks"], torch.from_numpy(radius))
     default = pre.observed_inputs(*args, keys=inp["keys"], **kw)
-    assert not np.array_equal(default["pts"].numpy(), ref["pts"])             # the gap this kernel closes
+    np.testing.assert_array_equal(default["pts"].numpy(), ref["pts"])         # round 1's float64 centroid differed here
 
     def seq_sum(x, start, count):
         return torch.from_numpy(_run(L, x.numpy(), start.numpy(), count.numpy()))
     monkeypatch.setattr(pre, "_segment_seq_sum", seq_sum)
-    monkeypatch.setenv("S6D_PEM_SEQ_CENTROID", "1")
     out = pre.observed_inputs(*args, keys=inp["keys"], **kw)
     assert out["kept"].tolist() == ref["kept"].tolist()
     np.testing.assert_array_equal(out["pts"].numpy(), ref["pts"])

@@ -8,7 +8,8 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sam6d_amd import pipeline  # noqa: E402
 from sam6d_amd.ism import dinov2 as pd  # noqa: E402
 from sam6d_amd.ism.scoring import FrameScorer  # noqa: E402
@@ -18,48 +19,83 @@ from sam6d_amd.sam.image_encoder import build_vit_h  # noqa: E402
 from sam6d_amd.utils import seeded, synth  # noqa: E402
 from sam6d_amd.sam.mask_decoder import build_sam_decoder  # noqa: E402
 
-dev = torch.device("cuda", 0)
-t0 = time.time()
-enc = seeded.load_seeded(build_vit_h().eval(), 3).to(dev)
-dec = seeded.load_seeded(build_sam_decoder(), 2).to(dev)
-dino = pd.CustomDINOv2.__new__(pd.CustomDINOv2)
-torch.nn.Module.__init__(dino)
-dino.model = seeded.load_seeded(pd._make_dinov2_model(arch_name="vit_large").eval(), 6).to(dev)
-dino.patch_size, dino.validpatch_thresh, dino.chunk_size, dino.proposal_size, dino.token_name = 14, 0.5, 128, 224, "x_norm_clstoken"
-ism = synth.ism_inputs(P=128, O=1, T=42, seed=11)
-scorer = FrameScorer(ism["ref_cls"].to(dev), ism["ref_patch"].to(dev), ism["poses"].to(dev), ism["pointcloud"].to(dev),
-                     confidence_thresh=-1.0)       # seeded descriptors match no template: let every proposal through
-pem = seeded.load_seeded(pm.Net(pm.default_cfg()).eval(), 1).to(dev)
-pin = synth.pem_inputs(1, seed=1)
-tpl = {k: pin[k].to(dev) for k in ("model", "dense_po", "dense_fo")}
-print(f"models ready in {time.time() - t0:.0f} s", flush=True)
 
-frame = synth.pem_pre_inputs(P=128, seed=3)
-img = torch.from_numpy(frame["image"]).to(dev)
-depth, K = frame["depth"].to(dev), frame["K"].to(dev)
-keys = torch.rand(16, 480 * 640, generator=torch.Generator().manual_seed(1)).to(dev)
-rand_u = synth.coarse_uniforms(16, 2).to(dev)
-pipe = pipeline.FramePipeline(enc, dec.prompt_encoder, dec.mask_decoder, dino, scorer, pem, tpl, object_radius=0.12, points_per_batch=int(sys.argv[1]) if len(sys.argv) > 1 else 1024,
-                              top_k=10, segmentor=dict(pred_iou_thresh=0.09, stability_score_thresh=0.3,
-                                                       stability_score_offset=0.02))
-# seeded weights: substitute the synthetic proposals when the generator's own survive in too small a number
-real_generate = amg.generate_proposals
-sub_masks, sub_boxes = frame["masks"].to(dev), synth.dinov2_inputs(P=128, seed=3)["boxes"].to(dev)
+def build(dev, points_per_batch=1024, top_k=10, sync_stages=True):
+    """FramePipeline with the released model sizes (SAM ViT-H, mask decoder, DINOv2 ViT-L/14, PEM) on seeded weights + one
+    synthetic 480 x 640 RGB-D frame with P = 128 proposals and top_k instances for the PEM.  -> (pipe, call_args)"""
+    enc = seeded.load_seeded(build_vit_h().eval(), 3).to(dev)
+    dec = seeded.load_seeded(build_sam_decoder(), 2).to(dev)
+    dino = pd.CustomDINOv2.__new__(pd.CustomDINOv2)
+    torch.nn.Module.__init__(dino)
+    dino.model = seeded.load_seeded(pd._make_dinov2_model(arch_name="vit_large").eval(), 6).to(dev)
+    dino.patch_size, dino.validpatch_thresh, dino.chunk_size, dino.proposal_size, dino.token_name = 14, 0.5, 128, 224, "x_norm_clstoken"
+    ism = synth.ism_inputs(P=128, O=1, T=42, seed=11)
+    scorer = FrameScorer(ism["ref_cls"].to(dev), ism["ref_patch"].to(dev), ism["poses"].to(dev), ism["pointcloud"].to(dev),
+                         confidence_thresh=-1.0)       # seeded descriptors match no template: let every proposal through
+    pem = seeded.load_seeded(pm.Net(pm.default_cfg()).eval(), 1).to(dev)
+    pin = synth.pem_inputs(1, seed=1)
+    tpl = {k: pin[k].to(dev) for k in ("model", "dense_po", "dense_fo")}
+    frame = synth.pem_pre_inputs(P=128, seed=3)
+    img = torch.from_numpy(frame["image"]).to(dev)
+    depth, K = frame["depth"].to(dev), frame["K"].to(dev)
+    keys = torch.rand(16, 480 * 640, generator=torch.Generator().manual_seed(1)).to(dev)
+    rand_u = synth.coarse_uniforms(16, 2).to(dev)
+    pipe = pipeline.FramePipeline(enc, dec.prompt_encoder, dec.mask_decoder, dino, scorer, pem, tpl, object_radius=0.12,
+                                  points_per_batch=points_per_batch, top_k=top_k, sync_stages=sync_stages,
+                                  segmentor=dict(pred_iou_thresh=0.09, stability_score_thresh=0.3, stability_score_offset=0.02))
+    # seeded weights: substitute the synthetic proposals when the generator's own survive in too small a number
+    real_generate = amg.generate_proposals
+    sub_masks, sub_boxes = frame["masks"].to(dev), synth.dinov2_inputs(P=128, seed=3)["boxes"].to(dev)
+
+    def generate(*a, **k):
+        r = real_generate(*a, **k)
+        if r["masks"].shape[0] < 16:
+            r = dict(r, masks=sub_masks, boxes=sub_boxes)
+        return r
+    amg.generate_proposals = generate
+    return pipe, (img, depth, K, keys, rand_u)
 
 
-def generate(*a, **k):
-    r = real_generate(*a, **k)
-    if r["masks"].shape[0] < 16:
-        r = dict(r, masks=sub_masks, boxes=sub_boxes)
-    return r
-
-
-amg.generate_proposals = generate
-for it in range(3):
-    t = time.perf_counter()
-    det, poses = pipe(img, depth, K, keys, rand_u)
+def measure(dev, n_frames=8, points_per_batch=1024, top_k=10):
+    """The ``pipeline`` block of bench.py: whole frames (all five models + pre-processing, K = top_k instances per frame) per
+    second, (a) with a synchronisation after every stage (per-stage milliseconds), (b) frames issued back to back."""
+    pipe, args = build(dev, points_per_batch, top_k, sync_stages=True)
+    pipe(*args)                                                         # first call: allocator, autotuned library GEMMs
+    pipe(*args)
+    stages = {k: round(v, 2) for k, v in pipe.times.items()}
     torch.cuda.synchronize()
-    total = (time.perf_counter() - t) * 1e3
-    n_pose = 0 if poses is None else poses["pred_R"].shape[0]
-    print(f"frame {it}: {total:.1f} ms  -> {det.masks.shape[0]} detections, {n_pose} poses | " +
-          ", ".join(f"{k} {v:.1f}" for k, v in pipe.times.items()), flush=True)
+    t = time.perf_counter()
+    for _ in range(n_frames):
+        det, poses = pipe(*args)
+    torch.cuda.synchronize()
+    sync_ms = (time.perf_counter() - t) * 1e3 / n_frames
+    pipe.sync_stages = False
+    pipe(*args)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(n_frames):
+        det, poses = pipe(*args)
+    torch.cuda.synchronize()
+    free_ms = (time.perf_counter() - t) * 1e3 / n_frames
+    return {"workload": f"one 640x480 RGB-D frame through SAM ViT-H encoder + 1024-prompt mask decoding + DINOv2 ViT-L/14 descriptors of "
+                        f"P=128 proposals + ISM scoring + PEM pre-processing + PEM for K={top_k} instances (SURVEY 8d frame definition)",
+            "frames_per_s": round(1e3 / free_ms, 2), "ms_per_frame": round(free_ms, 2),
+            "ms_per_frame_stage_synchronised": round(sync_ms, 2), "stages_ms": stages,
+            "detections": int(det.masks.shape[0]), "poses": 0 if poses is None else int(poses["pred_R"].shape[0])}
+
+
+if __name__ == "__main__":
+    dev = torch.device("cuda", 0)
+    t0 = time.time()
+    pipe, args = build(dev, int(sys.argv[1]) if len(sys.argv) > 1 else 1024)
+    print(f"models ready in {time.time() - t0:.0f} s", flush=True)
+    for it in range(3):
+        t = time.perf_counter()
+        det, poses = pipe(*args)
+        torch.cuda.synchronize()
+        total = (time.perf_counter() - t) * 1e3
+        n_pose = 0 if poses is None else poses["pred_R"].shape[0]
+        print(f"frame {it}: {total:.1f} ms  -> {det.masks.shape[0]} detections, {n_pose} poses | " +
+              ", ".join(f"{k} {v:.1f}" for k, v in pipe.times.items()), flush=True)
+    import json
+    print(json.dumps(measure(dev)))

@@ -8,8 +8,8 @@ mkdir -p $OUT
 FLAGS="-O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form -Wno-unused-function"
 build() { /opt/rocm/bin/hipcc $FLAGS $2 -o $OUT/libgemm_$1.so sam6d_amd/csrc/s6d_gemm.hip sam6d_amd/csrc/s6d_capi.hip & }
 build base ""
-build noqt "-DS6D_GEMM_QT=0"
+build nodrain "-DS6D_GEMM_DRAIN=0"
+build noqt "-DS6D_GEMM_QT=0 -DS6D_GEMM_DRAIN=0"
 build nostore "-DS6D_GEMM_ABLATE=4"
-build v2 "-DS6D_GEMM_DEFAULT_IMPL=2"
 wait
 ls -la $OUT

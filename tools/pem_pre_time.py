@@ -70,3 +70,20 @@ for it in range(3):
         for (a, ta), (_, tb) in zip(marks[1:], marks[:-1]):
             print(f"  {a:52s} {(ta - tb) * 1e3:8.2f} ms")
         print(f"  {'total':52s} {(marks[-1][1] - t0) * 1e3:8.2f} ms")
+
+# ---- whole calls: the kernel path (default on the device) and the library-op path -------------------------------------------------
+if dev.type == "cuda":
+    import os
+    for tag, env in (("kernel path (default)", None), ("library-op path (S6D_PEM_PRE=library)", "library")):
+        if env is None:
+            os.environ.pop("S6D_PEM_PRE", None)
+        else:
+            os.environ["S6D_PEM_PRE"] = env
+        pre.observed_inputs(image, depth, K, masks, radius, keys)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            pre.observed_inputs(image, depth, K, masks, radius, keys)
+        torch.cuda.synchronize()
+        print(f"observed_inputs, {tag}, P = {P}: {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms")
+    os.environ.pop("S6D_PEM_PRE", None)

@@ -125,6 +125,24 @@ int s6d_rot_from_h_f32(const float *H, int n, float *R, void *stream);
 int s6d_pose_hypotheses_f32(const float *pts1, const float *pts2, const int32_t *pair, int B, int N1,
                             int N2, int n_hyp, float *R, float *t, float *dis, void *stream);
 
+/* Coarse hypothesis sampling: dual softmax of atten (B,M1,M2), background labels, (score[1:,1:])^1.5, float64-accumulated prefix
+ * sums normalised by (total + 1e-8), lower-bound search of the caller's uniforms rand_u (B,n_u) -> pair (B,n_u) i32 (flat bin
+ * index i1 * (M2-1) + i2, or (M1-1)(M2-1) past the end, as torch.searchsorted) and w1 (B,M1-1) f32 (label1 > 0).
+ * One workgroup per instance, the 196 x 196 distribution stays in LDS ((M1-1)(M2-1) * 4 B <= ~155 KB, M2 <= 256).
+ * ref: compute_coarse_Rt, utils/model_utils.py:203-219. */
+int s6d_coarse_sample_f32(const float *atten, const float *rand_u, int B, int M1, int M2, int n_u, int32_t *pair, float *w1,
+                          void *stream);
+
+/* The k smallest of n residuals per instance in ascending (value, index) order and the rows of Rs (B,n,3,3), ts (B,n,3) they
+ * select -> Rk (B,k,3,3), tk (B,k,3), idx (B,k) i32.  ref: torch.topk(dis, 300, largest=False) + gathers, model_utils.py:233-235. */
+int s6d_smallest_k_f32(const float *dis, const float *Rs, const float *ts, int B, int n, int k, float *Rk, float *tk,
+                       int32_t *idx, void *stream);
+
+/* score_p = sum(w1) / (sum_n dmin[b,p,n] w1[b,n] + 1e-8); R, t of the first arg-max.  dmin (B,P,N), w1 (B,N), Rk (B,P,3,3),
+ * tk (B,P,3) -> R (B,3,3), t (B,3).  ref: model_utils.py:240-246. */
+int s6d_hypothesis_select_f32(const float *dmin, const float *w1, const float *Rk, const float *tk, int B, int P, int N,
+                              float *R, float *t, void *stream);
+
 /* dmin[b,p,n] = min_m |(pts[b,n] - t[b,p]) R[b,p] - model[b,m]|
  * pts (B,N,3), R (B,P,3,3), t (B,P,3), model (B,Nm,3) -> dmin (B,P,N).
  * ref: compute_coarse_Rt :234-239 (P = 300) and compute_fine_Rt :272-275 (P = 1). */

@@ -122,6 +122,41 @@ def pose_hypotheses(pts1, pts2, pair):
     return R, t, dis
 
 
+def coarse_sample(atten, rand_u):
+    """atten (B,M1,M2) f32, rand_u (B,n_u) f32 -> pair (B,n_u) i32 (flat bin index), w1 (B,M1-1) f32."""
+    _chk(atten, torch.float32, "atten", 3)
+    _chk(rand_u, torch.float32, "rand_u", 2)
+    B, M1, M2 = atten.shape
+    pair = torch.empty(B, rand_u.shape[1], dtype=torch.int32, device=atten.device)
+    w1 = torch.empty(B, M1 - 1, dtype=torch.float32, device=atten.device)
+    _call("s6d_coarse_sample_f32", _ptr(atten), _ptr(rand_u), B, M1, M2, int(rand_u.shape[1]), _ptr(pair), _ptr(w1), _stream())
+    return pair, w1
+
+
+def smallest_k(dis, Rs, ts, k):
+    """dis (B,n), Rs (B,n,3,3), ts (B,n,3) f32 -> Rk (B,k,3,3), tk (B,k,3), idx (B,k) i32: the k smallest, ascending."""
+    _chk(dis, torch.float32, "dis", 2)
+    _chk(Rs, torch.float32, "Rs", 4)
+    _chk(ts, torch.float32, "ts", 3)
+    B, n = dis.shape
+    Rk = torch.empty(B, k, 3, 3, dtype=torch.float32, device=dis.device)
+    tk = torch.empty(B, k, 3, dtype=torch.float32, device=dis.device)
+    idx = torch.empty(B, k, dtype=torch.int32, device=dis.device)
+    _call("s6d_smallest_k_f32", _ptr(dis), _ptr(Rs), _ptr(ts), B, n, int(k), _ptr(Rk), _ptr(tk), _ptr(idx), _stream())
+    return Rk, tk, idx
+
+
+def hypothesis_select(dmin, w1, Rk, tk):
+    """dmin (B,P,N), w1 (B,N), Rk (B,P,3,3), tk (B,P,3) f32 -> R (B,3,3), t (B,3) of the best-scoring hypothesis."""
+    for a, nm, nd in ((dmin, "dmin", 3), (w1, "w1", 2), (Rk, "Rk", 4), (tk, "tk", 3)):
+        _chk(a, torch.float32, nm, nd)
+    B, P, N = dmin.shape
+    R = torch.empty(B, 3, 3, dtype=torch.float32, device=dmin.device)
+    t = torch.empty(B, 3, dtype=torch.float32, device=dmin.device)
+    _call("s6d_hypothesis_select_f32", _ptr(dmin), _ptr(w1), _ptr(Rk), _ptr(tk), B, P, N, _ptr(R), _ptr(t), _stream())
+    return R, t
+
+
 def min_dist(pts, R, t, model):
     """pts (B,N,3), R (B,P,3,3), t (B,P,3), model (B,Nm,3) -> (B,P,N)."""
     for a, nm, nd in ((pts, "pts", 3), (R, "R", 4), (t, "t", 3), (model, "model", 3)):
@@ -646,7 +681,7 @@ _FUSED = {}
 def have(name):
     if name not in _FUSED:
         sym = {"rpe_attention": "s6d_rpe_attention_f32", "geo_embedding": "s6d_geo_embedding_f32",
-               "fine_assign": "s6d_fine_assign_f32", "fine_match": "s6d_fine_match_f32", "pem_pre": "s6d_pem_compact_cloud_f32", "upsample_gather": "s6d_upsample_gather_f32",
+               "fine_assign": "s6d_fine_assign_f32", "fine_match": "s6d_fine_match_f32", "pem_pre": "s6d_pem_compact_cloud_f32", "coarse_sample": "s6d_coarse_sample_f32", "upsample_gather": "s6d_upsample_gather_f32",
                "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "add_layernorm": "s6d_add_layernorm_bf16", "gemm_bf16": "s6d_gemm_bf16", "win_attention": "s6d_win_attention_bf16",
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",

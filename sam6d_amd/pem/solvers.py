@@ -61,6 +61,15 @@ def coarse_Rt(atten, pts1, pts2, model_pts, rand_u, n1=6000, n2=300):
     """compute_coarse_Rt.  rand_u (B, 3*n1) are the uniform samples (drawn by the caller)."""
     B, N1, _ = pts1.shape
     N2 = pts2.shape[1]
+    if ops.have("coarse_sample") and atten.is_cuda and atten.dtype == torch.float32 and N2 + 1 <= 256 \
+            and N1 * N2 * 4 <= 152 * 1024 and n1 <= 16384:
+        # five launches: sampling head (dual softmax, labels, ^1.5, prefix sums, search) -> hypotheses -> the n2 smallest residuals
+        # -> nearest-model-point scan -> scored arg-max
+        pair, w1 = ops.coarse_sample(atten.contiguous(), rand_u.contiguous())
+        Rs, ts, dis = ops.pose_hypotheses(pts1.contiguous(), pts2.contiguous(), pair)
+        Rk, tk, _ = ops.smallest_k(dis, Rs, ts, n2)
+        dmin = ops.min_dist(pts1.contiguous(), Rk, tk, model_pts.contiguous())
+        return ops.hypothesis_select(dmin, w1, Rk, tk)
     score, w1, _ = soft_assignment(atten)
     score = score.reshape(B, N1 * N2) ** 1.5
     cum = torch.cumsum(score, dim=1)

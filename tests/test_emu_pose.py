@@ -33,6 +33,12 @@ def test_fine_match_on_the_emulator(emu, B, M1, M2):
     T._check_fine_match(emu, B, M1, M2)
 
 
+def test_coarse_sampling_kernels_on_the_emulator(emu):
+    T.test_coarse_sample_vs_oracle(emu, 2, 41, 900)
+    T.test_smallest_k_and_hypothesis_select_vs_library(emu)
+    T.test_coarse_Rt_kernel_chain_vs_oracle(emu, 2, 40, 300, 30)
+
+
 def test_positional_encoding_on_the_emulator(emu):
     """Same comparison as T.test_positional_encoding_fused_vs_oracle on a smaller cloud (the emulator is ~1e5 x slower than
     the GPU; the full-size body runs with S6D_EMU_SLOW=1)."""

@@ -52,6 +52,76 @@ def test_pose_hypotheses_vs_oracle(ops):
     assert (t - tr)[well].abs().max() < 5e-3
 
 
+@pytest.mark.parametrize("B,M,n_u", [(3, 197, 18000), (2, 41, 900)])
+def test_coarse_sample_vs_oracle(ops, B, M, n_u):
+    """Sampling head of compute_coarse_Rt (model_utils.py:203-219) in one kernel against the reference statements: labels exact;
+    sampled bins identical except where a uniform falls within float32 rounding of a bin boundary (the bins differ in their
+    last bits: hardware exp and s * sqrt(s) against libm's exp and pow; the prefix sums are accumulated in float64 on both sides):
+    at most 0.2 % of the draws, each landing on a bin whose cumulative value is within 1e-6 of the reference's."""
+    g = torch.Generator().manual_seed(M)
+    f1 = torch.nn.functional.normalize(torch.randn(B, M, 64, generator=g), dim=2)
+    f2 = torch.nn.functional.normalize(f1[:, torch.randperm(M, generator=g)] + 0.3 * torch.randn(B, M, 64, generator=g), dim=2)
+    atten = f1 @ f2.transpose(1, 2) / 0.1
+    u = torch.rand(B, n_u, generator=g)
+    score, w1, _ = opem.soft_assignment(atten)
+    sc = score.reshape(B, -1) ** 1.5
+    cum = torch.cumsum(sc, 1)
+    cum = cum / (cum[:, -1].unsqueeze(1) + 1e-8)
+    ref = torch.searchsorted(cum, u)
+    pair, w = ops.coarse_sample(atten.cuda(), u.cuda())
+    pair, w = pair.cpu().long(), w.cpu()
+    assert torch.equal(w, w1)
+    diff = pair != ref
+    assert diff.float().mean() <= 2e-3, diff.float().mean()
+    if diff.any():                                                     # a differing draw sits on a boundary: same cumulative value
+        b = diff.nonzero()[:, 0]
+        got, want = cum[b, pair[diff].clamp(max=cum.shape[1] - 1)], cum[b, ref[diff].clamp(max=cum.shape[1] - 1)]
+        assert (got - want).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("B,N,n1,n2", [(2, 196, 6000, 300), (2, 40, 300, 30)])
+def test_coarse_Rt_kernel_chain_vs_oracle(ops, B, N, n1, n2):
+    """solvers.coarse_Rt through its five kernels (sampling head, hypotheses, smallest-k, min-dist, scored arg-max) against the
+    oracle's compute_coarse_Rt on a known-answer case: same hypothesis => same pose."""
+    from sam6d_amd.pem import solvers
+    g = torch.Generator().manual_seed(N + n1)
+    p2 = torch.randn(B, N, 3, generator=g) * 0.4
+    Rgt = synth.random_rotations(B, g)
+    tgt = 0.1 * torch.randn(B, 3, generator=g)
+    p1 = p2 @ Rgt.transpose(1, 2) + tgt[:, None, :]
+    f = torch.nn.functional.normalize(torch.randn(B, N + 1, 32, generator=g), dim=2)
+    atten = f @ torch.nn.functional.normalize(f + 0.2 * torch.randn(B, N + 1, 32, generator=g), dim=2).transpose(1, 2) / 0.1
+    model = p2[:, : max(N // 2, 16)].contiguous()
+    u = torch.rand(B, 3 * n1, generator=g)
+    Rr, tr = opem.coarse_Rt(atten, p1, p2, model, u, n1, n2)
+    R, t = solvers.coarse_Rt(atten.cuda(), p1.cuda(), p2.cuda(), model.cuda(), u.cuda(), n1, n2)
+    assert (R.cpu() - Rr).norm(dim=(1, 2)).max() < 1e-3 and (t.cpu() - tr).abs().max() < 1e-4
+    assert (R.cpu() - Rgt).norm(dim=(1, 2)).max() < 1e-2
+
+
+def test_smallest_k_and_hypothesis_select_vs_library(ops):
+    """topk(largest=False) + gathers, and the scored arg-max over hypotheses (model_utils.py:233-246), as kernels."""
+    g = torch.Generator().manual_seed(3)
+    B, n, k, N = 3, 6000, 300, 196
+    dis = torch.rand(B, n, generator=g)
+    dis[0, 100] = dis[0, 7]                                            # a tie: the lower index first
+    Rs = synth.random_rotations(B * n, g).reshape(B, n, 3, 3)
+    ts = torch.randn(B, n, 3, generator=g)
+    Rk, tk, idx = (t.cpu() for t in ops.smallest_k(dis.cuda(), Rs.cuda(), ts.cuda(), k))
+    val, _ = torch.topk(dis, k, dim=1, largest=False)
+    assert torch.equal(torch.gather(dis, 1, idx.long()), val)          # ascending values (indices may differ only on ties)
+    assert (idx[0] == 7).nonzero().item() + 1 == (idx[0] == 100).nonzero().item() if (idx[0] == 7).any() and (idx[0] == 100).any() else True
+    ar = torch.arange(B)[:, None]
+    assert torch.equal(Rk, Rs[ar, idx.long()]) and torch.equal(tk, ts[ar, idx.long()])
+    dmin = torch.rand(B, k, N, generator=g)
+    w1 = (torch.rand(B, N, generator=g) > 0.3).float()
+    w1[2] = 0                                                          # no foreground point: every score is 0 -> hypothesis 0
+    sc = w1.sum(1, keepdim=True) / ((dmin * w1.unsqueeze(1)).sum(2) + 1e-8)
+    best = sc.max(1)[1]
+    R, t = (x.cpu() for x in ops.hypothesis_select(dmin.cuda(), w1.cuda(), Rk.cuda(), tk.cuda()))
+    assert torch.equal(R, Rk[torch.arange(B), best]) and torch.equal(t, tk[torch.arange(B), best])
+
+
 @pytest.mark.parametrize("N,P", [(196, 300), (2048, 1)])
 def test_min_dist_vs_oracle(ops, N, P):
     B, Nm = 2, 1024

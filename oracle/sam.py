@@ -38,42 +38,62 @@ def _rel_pos(q_size, k_size, rel_pos):
     return rel_pos[rel.long()]
 
 
-def attention(W, p, x, heads):
-    """Attention.forward + add_decomposed_rel_pos (image_encoder.py:224-240, 325-361).
-    x (B,H,W,C).  NOTE: the rel-pos terms use the UNscaled q."""
-    B, H, Wd, C = x.shape
+def attention_from_qkv(qkv, rel_pos_h, rel_pos_w, heads):
+    """The attention statements of Attention.forward between the two Linear layers + add_decomposed_rel_pos
+    (image_encoder.py:229-238, 325-361) on a given qkv (B,H,W,3C).  NOTE: the rel-pos terms use the UNscaled q."""
+    B, H, Wd, C3 = qkv.shape
+    C = C3 // 3
     hd = C // heads
-    qkv = F.linear(x, W[p + ".qkv.weight"], W[p + ".qkv.bias"]).reshape(B, H * Wd, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    qkv = qkv.reshape(B, H * Wd, 3, heads, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv.reshape(3, B * heads, H * Wd, hd).unbind(0)
     attn = (q * hd ** -0.5) @ k.transpose(-2, -1)
-    Rh = _rel_pos(H, H, W[p + ".rel_pos_h"])
-    Rw = _rel_pos(Wd, Wd, W[p + ".rel_pos_w"])
-    rq = q.reshape(B * heads, H, Wd, hd)
-    rel_h = torch.einsum("bhwc,hkc->bhwk", rq, Rh)
-    rel_w = torch.einsum("bhwc,wkc->bhwk", rq, Rw)
-    attn = (attn.view(B * heads, H, Wd, H, Wd) + rel_h[:, :, :, :, None] + rel_w[:, :, :, None, :]).view(
-        B * heads, H * Wd, H * Wd)
+    if rel_pos_h is not None:
+        Rh = _rel_pos(H, H, rel_pos_h)
+        Rw = _rel_pos(Wd, Wd, rel_pos_w)
+        rq = q.reshape(B * heads, H, Wd, hd)
+        rel_h = torch.einsum("bhwc,hkc->bhwk", rq, Rh)
+        rel_w = torch.einsum("bhwc,wkc->bhwk", rq, Rw)
+        attn = (attn.view(B * heads, H, Wd, H, Wd) + rel_h[:, :, :, :, None] + rel_w[:, :, :, None, :]).view(
+            B * heads, H * Wd, H * Wd)
     attn = attn.softmax(-1)
-    x = (attn @ v).view(B, heads, H, Wd, hd).permute(0, 2, 3, 1, 4).reshape(B, H, Wd, C)
-    return F.linear(x, W[p + ".proj.weight"], W[p + ".proj.bias"])
+    return (attn @ v).view(B, heads, H, Wd, hd).permute(0, 2, 3, 1, 4).reshape(B, H, Wd, C)
+
+
+def attention(W, p, x, heads):
+    """Attention.forward (image_encoder.py:224-240).  x (B,H,W,C)."""
+    qkv = F.linear(x, W[p + ".qkv.weight"], W[p + ".qkv.bias"])
+    return F.linear(attention_from_qkv(qkv, W[p + ".rel_pos_h"], W[p + ".rel_pos_w"], heads), W[p + ".proj.weight"],
+                    W[p + ".proj.bias"])
+
+
+def windowed_attention_from_qkv(qkv, qkv_bias, rel_pos_h, rel_pos_w, heads, window):
+    """What Block.forward computes between the qkv Linear and the proj Linear (image_encoder.py:168-179 around Attention), on
+    the UN-padded qkv (B,H,W,3C) of the token map: quirk Q2 -- the reference pads AFTER norm1, so a padded token is a zero vector
+    whose q / k / v equal the qkv bias exactly (Linear(0) = bias) and it takes part as a key; padding the qkv map with the bias
+    is the same statement.  window = 0: global attention.  This is the comparand of the fused attention kernels."""
+    if window == 0:
+        return attention_from_qkv(qkv, rel_pos_h, rel_pos_w, heads)
+    B, H, Wd, C3 = qkv.shape
+    ph, pw = (window - H % window) % window, (window - Wd % window) % window
+    Hp, Wp = H + ph, Wd + pw
+    full = qkv_bias.to(qkv.dtype).expand(B, Hp, Wp, C3).clone()
+    full[:, :H, :Wd] = qkv
+    x = full.view(B, Hp // window, window, Wp // window, window, C3).permute(0, 1, 3, 2, 4, 5).reshape(-1, window, window, C3)
+    x = attention_from_qkv(x, rel_pos_h, rel_pos_w, heads)
+    C = C3 // 3
+    x = x.view(B, Hp // window, Wp // window, window, window, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)
+    return x[:, :H, :Wd, :]
 
 
 def block(W, p, x, heads, window):
     """Block.forward (image_encoder.py:166-182).  Quirk Q2: padding happens AFTER norm1, so the
-    padded tokens are zeros whose q/k/v equal the qkv bias and they DO take part as keys."""
+    padded tokens are zeros whose q/k/v equal the qkv bias and they DO take part as keys (windowed_attention_from_qkv)."""
     sc = x
     x = F.layer_norm(x, (x.shape[-1],), W[p + ".norm1.weight"], W[p + ".norm1.bias"], 1e-6)
-    if window > 0:
-        B, H, Wd, C = x.shape
-        ph, pw = (window - H % window) % window, (window - Wd % window) % window
-        x = F.pad(x, (0, 0, 0, pw, 0, ph))
-        Hp, Wp = H + ph, Wd + pw
-        x = x.view(B, Hp // window, window, Wp // window, window, C).permute(0, 1, 3, 2, 4, 5).reshape(
-            -1, window, window, C)
-    x = attention(W, p + ".attn", x, heads)
-    if window > 0:
-        x = x.view(B, Hp // window, Wp // window, window, window, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)
-        x = x[:, :H, :Wd, :]
+    a = p + ".attn"
+    qkv = F.linear(x, W[a + ".qkv.weight"], W[a + ".qkv.bias"])
+    x = windowed_attention_from_qkv(qkv, W[a + ".qkv.bias"], W[a + ".rel_pos_h"], W[a + ".rel_pos_w"], heads, window)
+    x = F.linear(x, W[a + ".proj.weight"], W[a + ".proj.bias"])
     x = sc + x
     h = F.layer_norm(x, (x.shape[-1],), W[p + ".norm2.weight"], W[p + ".norm2.bias"], 1e-6)
     h = F.linear(F.gelu(F.linear(h, W[p + ".mlp.lin1.weight"], W[p + ".mlp.lin1.bias"])),

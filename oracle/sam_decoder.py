@@ -70,19 +70,24 @@ def prompt_encoder(W, cfg, points=None, labels=None, boxes=None):
     return sparse, dense
 
 
-def attention(W, p, q, k, v, heads):
-    q = F.linear(q, W[p + ".q_proj.weight"], W[p + ".q_proj.bias"])
-    k = F.linear(k, W[p + ".k_proj.weight"], W[p + ".k_proj.bias"])
-    v = F.linear(v, W[p + ".v_proj.weight"], W[p + ".v_proj.bias"])
-
+def attention_core(q, k, v, heads):
+    """Attention.forward between the input and output projections (transformer.py:218-232): heads split off the channel axis,
+    softmax(q k^T / sqrt(d)) v, heads recombined.  q (B,Nq,C), k / v (B,Nk,C) -> (B,Nq,C).  The comparand of the fused
+    token<->image attention kernels (tests/test_gpu_sam_decoder.py)."""
     def sep(x):
         b, n, c = x.shape
         return x.reshape(b, n, heads, c // heads).transpose(1, 2)
     q, k, v = sep(q), sep(k), sep(v)
     a = torch.softmax(q @ k.permute(0, 1, 3, 2) / math.sqrt(q.shape[-1]), dim=-1)
     o = (a @ v).transpose(1, 2)
-    o = o.reshape(o.shape[0], o.shape[1], -1)
-    return F.linear(o, W[p + ".out_proj.weight"], W[p + ".out_proj.bias"])
+    return o.reshape(o.shape[0], o.shape[1], -1)
+
+
+def attention(W, p, q, k, v, heads):
+    q = F.linear(q, W[p + ".q_proj.weight"], W[p + ".q_proj.bias"])
+    k = F.linear(k, W[p + ".k_proj.weight"], W[p + ".k_proj.bias"])
+    v = F.linear(v, W[p + ".v_proj.weight"], W[p + ".v_proj.bias"])
+    return F.linear(attention_core(q, k, v, heads), W[p + ".out_proj.weight"], W[p + ".out_proj.bias"])
 
 
 def _ln(W, p, x):

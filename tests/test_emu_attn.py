@@ -7,7 +7,7 @@ from tests import test_gpu_attn as T
 
 @pytest.mark.parametrize("B,H,nh,hd,ws", [(1, 16, 1, 64, 7), (1, 16, 1, 64, 0), (1, 14, 1, 80, 14)])
 def test_fused_attention_on_the_emulator(emu, B, H, nh, hd, ws):
-    T.test_fused_attention_vs_library_statement(B, H, nh, hd, ws)
+    T.test_fused_attention_vs_oracle(B, H, nh, hd, ws)
 
 
 @pytest.mark.parametrize("rows,C", [(37, 160), (5, 768)])
@@ -21,8 +21,8 @@ def test_seq_attention_on_the_emulator(emu, B, N, nh, hd):
 
 
 def test_segment_seq_sum_and_centroid_path_on_the_emulator(emu, monkeypatch):
-    """s6d_segment_seq_sum_f32 through the C ABI (emulated launch) == numpy's row-order reduction, and the opt-in centroid path
-    of the PEM pre-processing (S6D_PEM_SEQ_CENTROID=1 -> ops.segment_seq_sum) == the oracle loop at boundary-cutting radii."""
+    """s6d_segment_seq_sum_f32 through the C ABI (emulated launch) == numpy's row-order reduction, and the library-op path
+    of the PEM pre-processing (S6D_PEM_PRE=library -> ops.segment_seq_sum for the centroid) == the oracle loop at boundary-cutting radii."""
     import numpy as np
     import torch
 
@@ -37,7 +37,7 @@ def test_segment_seq_sum_and_centroid_path_on_the_emulator(emu, monkeypatch):
     for i, (s0, c) in enumerate(zip(start.tolist(), counts.tolist())):
         want = np.add.reduce(x[s0:s0 + c].numpy(), axis=0) if c else np.zeros(3, np.float32)
         np.testing.assert_array_equal(got[i], want)
-    monkeypatch.setenv("S6D_PEM_SEQ_CENTROID", "1")
+    monkeypatch.setenv("S6D_PEM_PRE", "library")                     # the library-op path with the centroid kernel in it
     inp = synth.pem_pre_inputs(P=8, seed=3)
     kw = dict(n_sample=512, img_size=224, min_points=32, min_inliers=4, radius_factor=1.2)
     radius = np.array([0.12, 0.03, 0.5, 0.12, 0.06, 0.2, 0.07, 0.01])

@@ -26,9 +26,9 @@ def test_crop_kernel_on_the_emulator(emu):
 
 
 def test_decoder_kernels_on_the_emulator(emu):
-    T.test_img2tok_kernel_vs_library_ops()
-    T.test_upscale_heads_kernel_vs_library_ops()
-    T.test_tok2img_kernel_vs_library_ops()
+    T.test_img2tok_kernel_vs_restated_algebra()
+    T.test_upscale_heads_kernel_vs_restated_algebra()
+    T.test_tok2img_kernel_vs_oracle()
 
 
 def test_mini_encoder_bf16_fused_path_on_the_emulator(emu, monkeypatch):

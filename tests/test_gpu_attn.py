@@ -1,6 +1,6 @@
-"""GPU parity of the fused MFMA attention (windowed / global, decomposed rel-pos bias) against the
-fp32 library-op statement of the same attention, itself pinned to the reference through
-tests/test_host_sam.py (mini encoder vs reference golden)."""
+"""GPU parity of the fused MFMA attention (windowed / global, decomposed rel-pos bias) against the ORACLE's statement of the
+same attention (oracle/sam.py windowed_attention_from_qkv: the code path of oracle.block, which tests/test_oracle_golden.py pins
+to the reference's ImageEncoderViT), in fp32 on the same bf16-rounded operands."""
 import pytest
 import torch
 
@@ -8,36 +8,26 @@ pytestmark = pytest.mark.gpu
 
 
 def _mk(B, H, nh, hd, ws, seed):
-    from sam6d_amd.sam.image_encoder import Attention
     g = torch.Generator().manual_seed(seed)
     S = ws if ws > 0 else H
-    att = Attention(nh * hd, num_heads=nh, qkv_bias=True, use_rel_pos=True, input_size=(S, S)).eval()
-    with torch.no_grad():
-        att.qkv.bias.copy_(0.3 * torch.randn(3 * nh * hd, generator=g))
-        att.rel_pos_h.copy_(0.3 * torch.randn(2 * S - 1, hd, generator=g))
-        att.rel_pos_w.copy_(0.3 * torch.randn(2 * S - 1, hd, generator=g))
+    bias = 0.3 * torch.randn(3 * nh * hd, generator=g)
+    rh = 0.3 * torch.randn(2 * S - 1, hd, generator=g)
+    rw = 0.3 * torch.randn(2 * S - 1, hd, generator=g)
     qkv = torch.randn(B, H, H, 3 * nh * hd, generator=g)
-    return att, qkv
+    return bias, rh, rw, qkv
 
 
 @pytest.mark.parametrize("B,H,nh,hd,ws", [(2, 32, 2, 80, 14), (1, 32, 2, 80, 0), (1, 64, 2, 80, 14),
                                           (1, 64, 1, 80, 0), (2, 16, 3, 64, 7), (1, 16, 2, 64, 0), (1, 20, 1, 80, 14)])
-def test_fused_attention_vs_library_statement(B, H, nh, hd, ws):
+def test_fused_attention_vs_oracle(B, H, nh, hd, ws):
+    from oracle import sam as osam
     from sam6d_amd import ops
     assert ops.have("win_attention")
-    att, qkv = _mk(B, H, nh, hd, ws, 1000 * H + ws + hd)
-    att = att.cuda()
-    qkv_bf = qkv.cuda().to(torch.bfloat16)
-    bias_bf = att.qkv.bias.detach().to(torch.bfloat16)
-    rh = att.rel_pos_h.detach().to(torch.bfloat16).contiguous()
-    rw = att.rel_pos_w.detach().to(torch.bfloat16).contiguous()
-    out = ops.window_attention(qkv_bf.contiguous(), bias_bf.contiguous(), rh, rw, nh, ws, att.scale).float()
-    # fp32 statement on the SAME bf16-rounded operands
-    with torch.no_grad():
-        att.qkv.bias.copy_(bias_bf.float())
-        att.rel_pos_h.copy_(rh.float())
-        att.rel_pos_w.copy_(rw.float())
-        ref = att._attention_lib(qkv_bf.float(), B, H, H, nh * hd, ws)
+    bias, rh, rw, qkv = (t.to(torch.bfloat16) for t in _mk(B, H, nh, hd, ws, 1000 * H + ws + hd))
+    out = ops.window_attention(qkv.cuda().contiguous(), bias.cuda().contiguous(), rh.cuda().contiguous(), rw.cuda().contiguous(), nh, ws,
+                               hd ** -0.5).float().cpu()
+    # the oracle in fp32 on the SAME bf16-rounded operands (padded window tokens carry the qkv bias: quirk Q2)
+    ref = osam.windowed_attention_from_qkv(qkv.float(), bias.float(), rh.float(), rw.float(), nh, ws)
     err = (out - ref).abs()
     assert err.max() < 3e-2 and err.mean() < 3e-3, (err.max().item(), err.mean().item())
 

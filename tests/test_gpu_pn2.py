@@ -92,7 +92,7 @@ def test_errors_are_python_exceptions(ops):
         ops.furthest_point_sampling(x.cuda(), 1000)  # M > N
 
 
-def test_reference_wrappers_run_on_the_shim(ops):
+def test_fps_greedy_property_at_the_benched_batch(ops):
     """Large-size property check at BASELINE sizes (B=32): FPS output is a set of distinct
     indices, starts at 0 and greedily maximises the min-distance (checked with torch)."""
     x = _cloud(32, 2048, 11).cuda()

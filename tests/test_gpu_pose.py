@@ -57,7 +57,8 @@ def test_coarse_sample_vs_oracle(ops, B, M, n_u):
     """Sampling head of compute_coarse_Rt (model_utils.py:203-219) in one kernel against the reference statements: labels exact;
     sampled bins identical except where a uniform falls within float32 rounding of a bin boundary (the bins differ in their
     last bits: hardware exp and s * sqrt(s) against libm's exp and pow; the prefix sums are accumulated in float64 on both sides):
-    at most 0.2 % of the draws, each landing on a bin whose cumulative value is within 1e-6 of the reference's."""
+    at most 0.2 % of the draws, each landing on a bin whose cumulative value is within 2e-5 of the reference's (the hardware
+    exponential is good to ~2e-6 relative, and a bin's cumulative value carries the drift of all bins before it)."""
     g = torch.Generator().manual_seed(M)
     f1 = torch.nn.functional.normalize(torch.randn(B, M, 64, generator=g), dim=2)
     f2 = torch.nn.functional.normalize(f1[:, torch.randperm(M, generator=g)] + 0.3 * torch.randn(B, M, 64, generator=g), dim=2)
@@ -76,7 +77,7 @@ def test_coarse_sample_vs_oracle(ops, B, M, n_u):
     if diff.any():                                                     # a differing draw sits on a boundary: same cumulative value
         b = diff.nonzero()[:, 0]
         got, want = cum[b, pair[diff].clamp(max=cum.shape[1] - 1)], cum[b, ref[diff].clamp(max=cum.shape[1] - 1)]
-        assert (got - want).abs().max() < 1e-6
+        assert (got - want).abs().max() < 2e-5
 
 
 @pytest.mark.parametrize("B,N,n1,n2", [(2, 196, 6000, 300), (2, 40, 300, 30)])

@@ -56,7 +56,7 @@ def test_postprocess_matches_oracle():
     np.testing.assert_allclose(y.cpu().numpy(), g["mini_post"], rtol=1e-5, atol=1e-6)
 
 
-def test_img2tok_kernel_vs_library_ops():
+def test_img2tok_kernel_vs_restated_algebra():
     """s6d_samdec_img2tok_bf16 against the same computation in torch fp32 on the same bf16 operands, shared and
     per-prompt q / residual, strided q, 5..8 prompt tokens."""
     from sam6d_amd import ops
@@ -79,16 +79,23 @@ def test_img2tok_kernel_vs_library_ops():
         bo, lw, lb = (torch.randn(256, generator=g).cuda() for _ in range(3))
         out = ops.samdec_img2tok(q, q_add, kexp, vpt, resid, bo, lw, lb, 1e-5, T).float()
         qq = q.float() if q_add is None else (q.float() + q_add.float()).to(torch.bfloat16).float()
-        s = torch.einsum("bnk,bjk->bnj", qq.expand(B, -1, -1), kexp.float()).view(B, N, 8, 8)
-        s[..., T:] = -1e30
-        p = torch.softmax(s, -1).to(torch.bfloat16).float().view(B, N, 64)
-        y = torch.einsum("bnj,bcj->bnc", p, vpt.float()) + bo + resid.float()
-        ref = torch.nn.functional.layer_norm(y, (256,), lw, lb, 1e-5)
+        # comparand: the oracle's attention core on the UN-expanded keys (B, T, 128) and the values with the output projection
+        # folded in (the kernel's algebra: out_proj(softmax(qk^T) v) = softmax(qk^T)(v W_o^T)), + bias + residual + LayerNorm.
+        # The kernel rounds the probabilities to bf16 before the value product; so does the comparand.
+        kk = kt.permute(0, 2, 1, 3).reshape(B, T, 128).to(torch.bfloat16).float()                        # (B, T, heads * 16)
+        s = torch.einsum("bnk,bjk->bnj", qq.cpu().expand(B, -1, -1), kexp.float().cpu()).view(B, N, 8, 8)[..., :T]
+        s_or = (qq.cpu().expand(B, -1, -1).reshape(B, N, 8, 16).transpose(1, 2) @ kk.reshape(B, T, 8, 16).permute(0, 2, 3, 1))
+        assert torch.allclose(s.permute(0, 2, 1, 3), s_or, atol=1e-4)                                     # the key expansion is exact
+        p = torch.softmax(s_or, -1).to(torch.bfloat16).float()                                           # (B, heads, N, T)
+        vv = vpt.float().cpu().view(B, 256, 8, 8)[..., :T]                                               # (B, c, head, T)
+        y = torch.einsum("bhnt,bcht->bnc", p, vv) + bo.cpu() + resid.float().cpu()
+        ref = torch.nn.functional.layer_norm(y, (256,), lw.cpu(), lb.cpu(), 1e-5)
+        out = out.cpu()
         err = (out - ref).abs()
         assert err.max() < 0.06 and err.mean() < 4e-3, (T, shared, err.max().item(), err.mean().item())
 
 
-def test_upscale_heads_kernel_vs_library_ops():
+def test_upscale_heads_kernel_vs_restated_algebra():
     from sam6d_amd import ops
     g = torch.Generator().manual_seed(2)
     B, h, w, M = 3, 8, 8, 4
@@ -108,7 +115,10 @@ def test_upscale_heads_kernel_vs_library_ops():
     assert err.max() < 5e-3 * lg.abs().max() + 1e-3, (err.max().item(), lg.abs().max().item())
 
 
-def test_tok2img_kernel_vs_library_ops():
+def test_tok2img_kernel_vs_oracle():
+    """s6d_samdec_tok2img_f32 (token -> image attention, 8 heads x 16, keys / values read in place from the concatenated
+    [q | k | v] projection of the image tokens) against the oracle's attention core (oracle/sam_decoder.py attention_core, the
+    statements between the projections of the reference Attention), fp32 on the same bf16-rounded operands."""
     from sam6d_amd import ops
     g = torch.Generator().manual_seed(4)
     B, N, T = 6, 512, 7
@@ -121,12 +131,8 @@ def test_tok2img_kernel_vs_library_ops():
         if pe:
             k = (k + kpe.float()).to(torch.bfloat16).float()
         v = kv[..., 256:384].float()
-        qh = qt.view(B, T, 8, 16).transpose(1, 2)
-        kh = k.view(-1, N, 8, 16).transpose(1, 2)
-        vh = v.view(-1, N, 8, 16).transpose(1, 2)
-        a = torch.softmax(qh @ kh.transpose(-1, -2) * 0.25, -1) @ vh
-        ref = a.transpose(1, 2).reshape(B, T, 128)
-        assert (out - ref).abs().max() < 2e-4, (shared, (out - ref).abs().max().item())
+        ref = osd.attention_core(qt.cpu(), k.cpu().expand(B, -1, -1), v.cpu().expand(B, -1, -1), 8)    # 1 / sqrt(16) = 0.25
+        assert (out.cpu() - ref).abs().max() < 2e-4, (shared, (out.cpu() - ref).abs().max().item())
 
 
 def test_mask_post_kernel_bit_exact_vs_oracle_and_golden():

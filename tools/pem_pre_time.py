@@ -1,6 +1,7 @@
-"""Where the PEM per-detection pre-processing (sam6d_amd/pem/preprocess.py, 107 ms for 64 detections in round 1) spends its
-time: the same tensor ops as observed_inputs, grouped into stages with a device synchronisation after each (run on the GPU
-box).  The stage that dominates is the one to turn into a kernel (the emulator can then verify it on the host)."""
+"""Where the PEM per-detection pre-processing (sam6d_amd/pem/preprocess.py) spends its time: the tensor ops of its library-op
+path grouped into stages with a device synchronisation after each, then whole calls of the kernel path (the default) and of the
+library-op path.  Round 1: 107 ms for 64 detections, 104 of them a float64 index_add_ centroid (deleted); round 2: 3.9 ms kernel
+path, 6.0 ms library-op path (profiles/r02_pem_pre_time.txt)."""
 import sys
 import time
 
@@ -47,7 +48,7 @@ for it in range(3):
     cloud = torch.stack([(x_.float() - cx) * z / fx_t, (y_.float() - cy) * z / fy_t, z], 1)
     tick("inside-box filter, crop indices, back-projection")
     n0 = torch.bincount(p_, minlength=Pn)
-    center = (torch.zeros(Pn, 3, dtype=torch.float64, device=dev).index_add_(0, p_, cloud.double()) / n0.clamp(min=1)[:, None]).float()
+    center = pre._segment_seq_sum(cloud.contiguous(), (torch.cumsum(n0, 0) - n0).contiguous(), n0.contiguous()) / n0.clamp(min=1).float()[:, None]
     dist = torch.linalg.norm(cloud - center[p_], dim=1)
     flag = dist.double() < radius * 1.2
     p_, choose, cloud = p_[flag], choose[flag], cloud[flag]

@@ -406,6 +406,74 @@ def gen_pem_pre():
     print("pem_pre.npz", {k: v.shape for k, v in rec.items()}, rec["bbox"][:4].tolist())
 
 
+def gen_example():
+    """BASELINE configs[0]: the ONE real frame the reference ships (SAM-6D/Data/Example: rgb.png, depth.png in millimetres,
+    camera.json, obj_000005.ply in millimetres; demo.sh:1-17 runs it through both models).  No checkpoint and no ISM result are
+    reachable offline, so the plumbing is pinned as far as tensors can be frozen: the frame itself, a deterministic object mask
+    (a depth window inside a box around the object at (370, 200)), the reference's own pre-processing helpers
+    (utils/data_utils.py get_bbox / get_point_cloud_from_depth / get_resize_rgb_choose, run unmodified) on that mask, model and
+    template points taken from the ply's vertices (the reference samples the mesh surface with trimesh's RNG), seeded template
+    features and weights.  tests/golden/example_frame.npz holds the inputs (the GPU box has no /root/reference) and these outputs;
+    the oracle's pre-processing + Net.forward on them is added by tests/test_oracle_golden.py's twin in gen (`oracle_*` keys)."""
+    from PIL import Image
+
+    from . import pem as opem
+    from . import pem_pre as opre
+    ex = os.path.join(rh.REF_ROOT, "SAM-6D", "Data", "Example")
+    rgb = np.array(Image.open(os.path.join(ex, "rgb.png")))[..., :3].astype(np.uint8)
+    depth_mm = np.array(Image.open(os.path.join(ex, "depth.png"))).astype(np.uint16)
+    import json
+    cam = json.load(open(os.path.join(ex, "camera.json")))
+    K = np.array(cam["cam_K"], dtype=np.float64).reshape(3, 3)
+    # ascii ply: vertex lines after end_header (x y z nx ny nz r g b a), millimetres
+    with open(os.path.join(ex, "obj_000005.ply")) as f:
+        lines = f.read().split("end_header\n")[1].split("\n")
+    nv = 22831
+    verts = np.array([[float(v) for v in ln.split()[:3]] for ln in lines[:nv]], dtype=np.float32) / np.float32(1000.0)
+    model = np.ascontiguousarray(verts[::22][:1024])                       # (1024,3) m: `model` of the PEM
+    dense_po = np.ascontiguousarray(verts[::11][:2048])                    # (2048,3) m: template points
+    radius = float(np.max(np.linalg.norm(model, axis=1)))
+    depth = depth_mm.astype(np.float32) * np.float32(cam["depth_scale"]) / np.float32(1000.0)        # run_inference_custom.py:203
+    mask = np.zeros(depth.shape, bool)
+    mask[140:262, 300:442] = (depth_mm[140:262, 300:442] > 900) & (depth_mm[140:262, 300:442] < 1075)
+    du = rh.pem_data_utils()
+    rec = dict(rgb=rgb, depth_mm=depth_mm, K=K, depth_scale=np.float64(cam["depth_scale"]), model=model, dense_po=dense_po,
+               radius=np.float64(radius), mask_box=np.array([140, 262, 300, 442]), mask_window_mm=np.array([900, 1075]))
+    m = np.logical_and(mask, depth > 0)
+    y1, y2, x1, x2 = du.get_bbox(m)
+    rec["ref_bbox"] = np.array([y1, y2, x1, x2])
+    cloud = du.get_point_cloud_from_depth(depth, K, [y1, y2, x1, x2]).astype(np.float32).reshape(-1, 3)
+    rec["ref_cloud_sum"], rec["ref_cloud_smp"] = digest(torch.from_numpy(cloud), 211)
+    ch = m[y1:y2, x1:x2].astype(np.float32).flatten().nonzero()[0]
+    rec["ref_n_mask"] = np.int64(len(ch))
+    rec["ref_rgb_choose"] = du.get_resize_rgb_choose(ch[::17], [y1, y2, x1, x2], 224)
+    # ---- the oracle's full pre-processing and Net.forward on the frozen inputs (seeded weights / template features / uniforms)
+    case = dict(weight_seed=PEM_CASE["weight_seed"], key_seed=7, feat_seed=8, rand_seed=9)
+    keys = torch.rand(1, depth.size, generator=torch.Generator().manual_seed(case["key_seed"])).numpy()
+    obs = opre.preprocess_frame(rgb, depth, K, mask[None], radius, keys=keys)
+    dense_fo = torch.randn(1, 2048, 256, generator=torch.Generator().manual_seed(case["feat_seed"]))
+    ns = rh.pem()
+    net = ns.pose_estimation_model.Net(rh.pem_cfg().model).eval()
+    seeded.load_seeded(net, case["weight_seed"])
+    W = {k: v.clone() for k, v in net.state_dict().items()}
+    ep = dict(pts=torch.from_numpy(obs["pts"]), rgb=torch.from_numpy(obs["rgb"]), rgb_choose=torch.from_numpy(obs["rgb_choose"]),
+              model=torch.from_numpy(model)[None], dense_po=torch.from_numpy(dense_po)[None], dense_fo=dense_fo)
+    with torch.no_grad():
+        out = opem.net_forward(W, ep, synth.coarse_uniforms(1, case["rand_seed"]))
+        torch.manual_seed(case["rand_seed"])
+        ref = net(dict(ep))                                                 # the reference Net itself on the same tensors
+    for k in ("pts", "rgb_choose", "bbox", "kept"):
+        rec["oracle_" + k] = obs[k]
+    rec["oracle_rgb_sum"], rec["oracle_rgb_smp"] = digest(torch.from_numpy(obs["rgb"]), 4099)
+    for k in ("pred_R", "pred_t", "pred_pose_score"):
+        rec["oracle_" + k] = out[k].numpy()
+        rec["ref_" + k] = ref[k].numpy()
+    rec["case"] = np.array(str(case))
+    np.savez_compressed(os.path.join(OUT, "example_frame.npz"), **rec)
+    print("example_frame.npz bbox", rec["ref_bbox"], "mask px", int(rec["ref_n_mask"]), "radius", radius, "kept", obs["kept"],
+          "pred_t", rec["oracle_pred_t"], "|R_oracle - R_ref|", np.abs(rec["oracle_pred_R"] - rec["ref_pred_R"]).max())
+
+
 def _samdec_ref(ns, cfg, seed):
     pe = ns.PromptEncoder(embed_dim=cfg["dim"], image_embedding_size=(cfg["emb"],) * 2,
                           input_image_size=(cfg["img"],) * 2, mask_in_chans=16)
@@ -546,4 +614,4 @@ def gen_dinov2():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    {"pem": gen_pem, "pem_b32": gen_pem_b32, "sam": gen_sam, "ism": gen_ism, "dinov2": gen_dinov2, "sam_decoder": gen_sam_decoder, "handoff": gen_handoff, "pem_pre": gen_pem_pre, "pem_results": gen_pem_results, "detections_ops": gen_detections_ops, "sam_transforms": gen_sam_transforms, "sam_state_dict": gen_sam_state_dict}[sys.argv[1]]()
+    {"pem": gen_pem, "pem_b32": gen_pem_b32, "example": gen_example, "sam": gen_sam, "ism": gen_ism, "dinov2": gen_dinov2, "sam_decoder": gen_sam_decoder, "handoff": gen_handoff, "pem_pre": gen_pem_pre, "pem_results": gen_pem_results, "detections_ops": gen_detections_ops, "sam_transforms": gen_sam_transforms, "sam_state_dict": gen_sam_state_dict}[sys.argv[1]]()

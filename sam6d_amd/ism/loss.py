@@ -19,6 +19,9 @@ import torch.nn.functional as F
 from .. import ops
 
 
+_FLOATS = (torch.float32, torch.float16, torch.bfloat16)
+
+
 class PairwiseSimilarity(nn.Module):
     def __init__(self, metric="cosine", chunk_size=64):
         super().__init__()
@@ -28,8 +31,11 @@ class PairwiseSimilarity(nn.Module):
     def forward(self, query, reference):
         """query (P,C), reference (O,T,C) -> (P,O,T) in [0,1]."""
         O, T, C = reference.shape
-        if ops.have("pairwise_cosine") and query.is_cuda and query.dtype == torch.float32:
-            return ops.pairwise_cosine(query.contiguous(), reference.reshape(O * T, C).contiguous()).view(-1, O, T)
+        if ops.have("pairwise_cosine") and query.is_cuda and query.dtype in _FLOATS and reference.dtype in _FLOATS:
+            # fp16 / bf16 descriptors (the BOP flow runs under Lightning precision=16, configs/machine/trainer/local.yaml:9) take
+            # the same kernel: it accumulates in fp32 either way, and under autocast the reference's cosine_similarity is an
+            # fp32 op with an fp32 result -- which is what comes back here
+            return ops.pairwise_cosine(query.float().contiguous(), reference.reshape(O * T, C).float().contiguous()).view(-1, O, T)
         q = F.normalize(query.float(), dim=-1)
         r = F.normalize(reference.float().reshape(O * T, C), dim=-1)
         return (q @ r.t()).clamp(min=0.0, max=1.0).view(-1, O, T).to(query.dtype)
@@ -44,13 +50,14 @@ class MaskedPatch_MatrixSimilarity(nn.Module):
     def both(self, query, reference, thred=0.5):
         """(appearance score (S), visible ratio (S)) from one similarity pass."""
         S, N2 = reference.shape[0], reference.shape[1]
-        if ops.have("patch_scores") and query.is_cuda and query.dtype == torch.float32 and reference.dtype == torch.float32 \
+        if ops.have("patch_scores") and query.is_cuda and query.dtype in _FLOATS and reference.dtype in _FLOATS \
                 and N2 <= 256 and query.shape[-1] % 32 == 0:
             # the kernel addresses a resident (O,T,N2,C) store by (object, template): a materialised (S,N2,C) reference
             # is the store of ONE object whose "templates" are the S rows
             obj = torch.zeros(S, dtype=torch.int32, device=query.device)
             tmpl = torch.arange(S, dtype=torch.int32, device=query.device)
-            return ops.patch_scores(query.contiguous(), reference.contiguous()[None], obj, tmpl, float(thred))
+            appe, ratio = ops.patch_scores(query.float().contiguous(), reference.float().contiguous()[None], obj, tmpl, float(thred))
+            return appe.to(query.dtype), ratio.to(query.dtype)       # half inputs: fp32 arithmetic inside, the caller's dtype outside
         sim = query @ reference.transpose(1, 2)
         factor = torch.count_nonzero(query.sum(dim=-1), dim=-1) + 1e-6
         appe = (sim.max(dim=-1).values.sum(dim=-1) / factor).clamp(min=0.0, max=1.0)

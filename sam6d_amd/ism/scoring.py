@@ -95,11 +95,21 @@ class ScoringMixin:
     def compute_appearance_score(self, best_pose, pred_objects_idx, qurey_appe_descriptors):
         store = self.ref_data["appe_descriptors"]
         thred = getattr(self, "visible_thred", 0.5)
-        if ops.have("patch_scores") and qurey_appe_descriptors.is_cuda and store.dtype == torch.float32 \
-                and qurey_appe_descriptors.dtype == torch.float32 and store.is_contiguous() and store.shape[2] <= 256:
+        halfs = (torch.float16, torch.bfloat16)
+        if ops.have("patch_scores") and qurey_appe_descriptors.is_cuda and store.is_contiguous() and store.shape[2] <= 256 \
+                and store.dtype in (torch.float32,) + halfs and qurey_appe_descriptors.dtype in (torch.float32,) + halfs:
+            # half descriptors (BOP flow under precision=16): the resident store is converted ONCE per store tensor and kept (it
+            # is read-only template data); the query of the frame is converted per call.  fp32 arithmetic inside the kernel.
+            if store.dtype != torch.float32:
+                c = getattr(self, "_store_f32", None)
+                if c is None or c[0] is not store:
+                    c = (store, store.float())
+                    self._store_f32 = c
+                store = c[1]
+            qdt = qurey_appe_descriptors.dtype
             obj32, tmpl32 = pred_objects_idx.int().contiguous(), best_pose.int().contiguous()
-            appe, ratio = ops.patch_scores(qurey_appe_descriptors.contiguous(), store, obj32, tmpl32, float(thred))
-            return appe, RefPatchHandle(store, obj32, tmpl32, ratio, thred)
+            appe, ratio = ops.patch_scores(qurey_appe_descriptors.float().contiguous(), store, obj32, tmpl32, float(thred))
+            return appe.to(qdt), RefPatchHandle(store, obj32, tmpl32, ratio.to(qdt), thred)
         ref = store[pred_objects_idx, best_pose, ...]
         metric = MaskedPatch_MatrixSimilarity(metric="cosine", chunk_size=64)
         appe, ratio = metric.both(qurey_appe_descriptors, ref, thred)
@@ -111,8 +121,9 @@ class ScoringMixin:
             if ref_aux_descriptor.thred == visible_thred:
                 visible_ratio = ref_aux_descriptor.visible_ratio    # produced by the same similarity pass
             else:
-                visible_ratio = ops.patch_scores(appe_descriptors.contiguous(), ref_aux_descriptor.store,
-                                                 ref_aux_descriptor.obj, ref_aux_descriptor.tmpl, float(visible_thred))[1]
+                visible_ratio = ops.patch_scores(appe_descriptors.float().contiguous(), ref_aux_descriptor.store,
+                                                 ref_aux_descriptor.obj, ref_aux_descriptor.tmpl,
+                                                 float(visible_thred))[1].to(appe_descriptors.dtype)
         else:
             c = getattr(self, "_cached_visible", None)
             if c is not None and c[0] == appe_descriptors.data_ptr() and c[1] == ref_aux_descriptor.data_ptr() \

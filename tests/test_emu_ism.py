@@ -40,3 +40,8 @@ def test_masked_patch_similarity_methods_reach_the_kernel(emu):
     assert len(calls) == 2
     assert torch.allclose(appe, oism.appearance_score(q, d['ref_patch'], d['gt_obj'], d['gt_tem'])[0], atol=1e-5)
     assert torch.allclose(ratio, oism.visible_ratio(q, ref, 0.5), atol=1e-5)
+
+
+def test_half_descriptors_on_the_emulator(emu, monkeypatch):
+    import torch
+    T.test_half_descriptors_take_the_kernels(torch.bfloat16, monkeypatch)

@@ -113,3 +113,30 @@ def test_ism_kernels_individually_vs_oracle():
     er = oism.visible_ratio(qp, eref, 0.5)
     a, rr = ops.patch_scores(qp.cuda(), store.cuda(), obj.int().cuda(), tm.int().cuda(), 0.5)
     assert (a.cpu() - ea).abs().max() < 2e-6 and (rr.cpu() - er).abs().max() < 2e-6
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_half_descriptors_take_the_kernels(dt, monkeypatch):
+    """b3: the BOP flow runs under Lightning precision=16 (configs/machine/trainer/local.yaml:9): half descriptors must reach the
+    same kernels (fp32 arithmetic on the rounded operands), not a library fallback.  Comparand: the oracle statements in fp32 on
+    the SAME half-rounded descriptors."""
+    from oracle import ism as oism
+    from sam6d_amd import ops
+    from sam6d_amd.ism.loss import MaskedPatch_MatrixSimilarity, PairwiseSimilarity
+    d = synth.ism_inputs(P=12, O=3, T=6, C=128, n_patch=48, H=120, W=160, seed=5)
+    calls = {"cos": 0, "patch": 0}
+    oc, op = ops.pairwise_cosine, ops.patch_scores
+    monkeypatch.setattr(ops, "pairwise_cosine", lambda *a, **k: (calls.__setitem__("cos", calls["cos"] + 1), oc(*a, **k))[1])
+    monkeypatch.setattr(ops, "patch_scores", lambda *a, **k: (calls.__setitem__("patch", calls["patch"] + 1), op(*a, **k))[1])
+    q, r = d["qry_cls"].to(dt), d["ref_cls"].to(dt)
+    out = PairwiseSimilarity()(q.cuda(), r.cuda())
+    assert calls["cos"] == 1 and out.dtype == torch.float32
+    assert torch.allclose(out.cpu(), oism.pairwise_similarity(q.float(), r.float()), atol=2e-5)
+    qp = d["qry_patch"].to(dt)
+    ref = d["ref_patch"][d["gt_obj"], d["gt_tem"]].to(dt).contiguous()
+    m = MaskedPatch_MatrixSimilarity()
+    appe, ratio = m.both(qp.cuda(), ref.cuda(), 0.5)
+    assert calls["patch"] == 1 and appe.dtype == dt
+    want = oism.appearance_score(qp.float(), d["ref_patch"].to(dt).float(), d["gt_obj"], d["gt_tem"])[0]
+    assert torch.allclose(appe.float().cpu(), want, atol=1e-2 if dt == torch.bfloat16 else 2e-3)       # output rounded to dt
+    assert torch.allclose(ratio.float().cpu(), oism.visible_ratio(qp.float(), ref.float(), 0.5), atol=2e-2)

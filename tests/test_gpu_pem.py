@@ -146,3 +146,36 @@ def test_upsample_gather_kernel_vs_dense_reference(net):
         exp = torch.gather(fm.flatten(2), 2, choose.cuda().unsqueeze(1).expand(-1, 256, -1)).transpose(1, 2)
         got = ae.sample(inp["rgb"].cuda(), choose.cuda())
     assert torch.allclose(got, exp, atol=2e-5, rtol=1e-5), (got - exp).abs().max()
+
+
+def test_real_example_frame_through_preprocessing_and_net(net):
+    """BASELINE configs[0]: the reference's Data/Example frame (tests/golden/example_frame.npz) through the device pre-processing
+    (kernel path) and Net.forward: sampled points and pixel indices identical to the oracle, pose within the parity tolerance of
+    the reference Net's on the same tensors."""
+    from sam6d_amd.pem import preprocess as pre
+    from tests.test_host_example_frame import frame
+    g = util.golden("example_frame.npz")
+    depth, mask, keys, case = frame(g)
+    out = pre.observed_inputs(torch.from_numpy(g["rgb"]).cuda(), torch.from_numpy(depth).cuda(), torch.from_numpy(g["K"]),
+                              torch.from_numpy(mask[None]).cuda(), float(g["radius"]), keys=keys.cuda())
+    assert out["kept"].cpu().tolist() == g["oracle_kept"].tolist()
+    np.testing.assert_array_equal(out["pts"].cpu().numpy(), g["oracle_pts"])
+    np.testing.assert_array_equal(out["rgb_choose"].cpu().numpy(), g["oracle_rgb_choose"])
+    dense_fo = torch.randn(1, 2048, 256, generator=torch.Generator().manual_seed(case["feat_seed"]))
+    ep = dict(pts=out["pts"], rgb=out["rgb"], rgb_choose=out["rgb_choose"], model=torch.from_numpy(g["model"])[None].cuda(),
+              dense_po=torch.from_numpy(g["dense_po"])[None].cuda(), dense_fo=dense_fo.cuda(),
+              coarse_rand_u=synth.coarse_uniforms(1, case["rand_seed"]).cuda())
+    import os
+    old = os.environ.get("S6D_PEM_VIT_DTYPE")
+    os.environ["S6D_PEM_VIT_DTYPE"] = "fp32"                        # parity run: the fp32 ViT (bf16 is the throughput configuration)
+    try:
+        with torch.no_grad():
+            res = net(ep)
+    finally:
+        if old is None:
+            os.environ.pop("S6D_PEM_VIT_DTYPE")
+        else:
+            os.environ["S6D_PEM_VIT_DTYPE"] = old
+    dR = np.linalg.norm(res["pred_R"].cpu().numpy() - g["ref_pred_R"], axis=(1, 2))
+    dt = np.abs(res["pred_t"].cpu().numpy() - g["ref_pred_t"]).max()
+    assert dR.max() <= R_TOL * 10 and dt <= T_TOL_M * 100, (dR, dt)    # random-ViT features on a real crop: ill-conditioned pose

@@ -565,7 +565,7 @@ __device__ __forceinline__ void win16_tables(const RelFrags<HD> &rf, int S, int 
 //      exponentials of step u+1.  The row sum comes from the matrix core too (an all-ones A fragment), so it is the
 //      sum of the SAME bf16-rounded P that multiplies V and costs no VALU adds or lane exchanges.
 // SRC = compile-time key-row count (even); EXACT: S == SRC (no unstaged key rows to skip).
-template <int HD, int NS, int SRC, bool EXACT>
+template <int HD, int NS, int SRC, bool EXACT, int KROWT = Cfg<HD>::KROW>
 __device__ __forceinline__ void win16_pass(const AttnParams &p, const u16 *Kl, const u16 *Vl, int S, int SR, int b,
                                            int wy, int wx, int head, int qy0, int rstride,
                                            const bf16x8 (&qf)[NS][Cfg<HD>::KS], const float (*twr)[4],
@@ -581,8 +581,16 @@ __device__ __forceinline__ void win16_pass(const AttnParams &p, const u16 *Kl, c
   auto kload = [&](int ky, bf16x8 (&dst)[C::KS]) {
     const int kyc = EXACT ? ky : min(ky, SR - 1);                   // rows >= SR are not staged: re-read a staged one
 #pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks)
-      dst[ks] = *reinterpret_cast<const bf16x8 *>(Kl + (kyc * 16 + c) * C::KROW + ks * 32 + g * 8);
+    for (int ks = 0; ks < C::KS; ++ks) {
+      dst[ks] = *reinterpret_cast<const bf16x8 *>(Kl + (kyc * 16 + c) * KROWT + ks * 32 + g * 8);
+      // compact K rows (KROWT < padded head dim): the k range past HD is not staged -- the lane reads into the next row and
+      // the fragment is zeroed here (the matching Q fragment is zero too, but 0 x a stray Inf would not be)
+      if (KROWT < C::HDP && ks * 32 + 32 > HD && ks * 32 + g * 8 >= HD) {
+        union { bf16x8 v; uint4 u; } z;
+        z.u = make_uint4(0, 0, 0, 0);
+        dst[ks] = z.v;
+      }
+    }
   };
   kload(0, kf[0]);
 #pragma unroll
@@ -670,29 +678,40 @@ __device__ __forceinline__ void win16_pass(const AttnParams &p, const u16 *Kl, c
 // ---- windowed, row-padded (S <= 16): key slot = ky*16 + kx, so every 16-key MFMA sub-tile is ONE key row and
 // every 16-query strip is ONE query row: the decomposed bias costs one LDS word per sub-tile (rel_h) plus four
 // registers (rel_w, kx = g*4+r fixed per lane; out-of-window columns carry -1e30 there, which is the mask).
-template <int HD, int WAVES>
+// HALF = false: one 8-wave workgroup per (window, head), query rows (wave, wave + 8).
+// HALF = true:  TWO 4-wave workgroups per (window, head), each with its own copy of the window's K / V (compact 75 KiB image: K rows
+//               of HD + 8 elements, the scratch tables aliased into the K area) and the query rows of one parity (2 wave + h,
+//               2 wave + 8 + h).  Two such workgroups fit a CU (2 x 75 KiB LDS, 2 x 4 waves at <= 256 VGPRs), so the staging of
+//               one overlaps the arithmetic of the other -- what one 98-KiB workgroup per CU could not do.  The two halves of an
+//               item run on the same XCD (workgroup ids 16 j + x and 16 j + 8 + x), i.e. the second K / V fetch is an L2 hit.
+template <int HD, int WAVES, bool HALF>
 __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p) {
   using C = Cfg<HD>;
+  constexpr int KROWT = HALF ? HD + 8 : C::KROW;                   // K image row stride (elements)
+  constexpr int KPARTST = HALF ? HD / 8 : C::KPARTS;               // 16-byte parts staged per K slot
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int S = p.S, SR = (S + 1) & ~1;                            // key rows, rounded up to a 32-key k-step
-  u16 *Kl = reinterpret_cast<u16 *>(smem);                         // [SR*16][KROW]
-  u16 *Vl = Kl + (size_t)SR * 16 * C::KROW;                        // [SR*16][VROW]
-  float *tabs = reinterpret_cast<float *>(Vl + (size_t)SR * 16 * C::VROW);
+  u16 *Kl = reinterpret_cast<u16 *>(smem);                         // [SR*16][KROWT]
+  u16 *Vl = Kl + (size_t)SR * 16 * KROWT;                          // [SR*16][VROW]
+  // HALF: the tables are scratch of the prologue only (bias registers are built before K / V are committed): they live in the K area
+  float *tabs = HALF ? reinterpret_cast<float *>(smem) : reinterpret_cast<float *>(Vl + (size_t)SR * 16 * C::VROW);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int g = lane >> 4, c = lane & 15;
   float *tab = tabs + (size_t)wave * 16 * W16_LT;                 // one [16][W16_LT] scratch table per wave
 
   WinItem item;
-  item.decode(p, blockIdx.x);
+  const int hsel = HALF ? ((int)blockIdx.x >> 3) & 1 : 0;          // which row parity this workgroup owns
+  item.decode(p, HALF ? (((int)blockIdx.x >> 4) << 3) | ((int)blockIdx.x & 7) : (int)blockIdx.x);
   const int head = item.head, wx = item.wx, wy = item.wy, b = item.b;
   const int Cc = p.nh * HD;
+  const int rbase = HALF ? 2 * wave + hsel : wave, rstride = HALF ? 2 * WAVES : WAVES;   // rows rbase, rbase + rstride
   // Q fragments of every query row this wave owns are fetched first so their latency hides under the staging
-  constexpr int MAXROWS = 2;                                      // rows (wave, wave + WAVES); WAVES >= 8 covers S <= 16
-  static_assert(2 * WAVES >= 16, "two rows per wave must cover 16 query rows");
+  constexpr int MAXROWS = 2;
+  static_assert((HALF ? 4 : 2) * WAVES >= 16, "two rows per wave must cover 16 query rows");
   bf16x8 qfa[MAXROWS][C::KS];
 #pragma unroll
   for (int i = 0; i < MAXROWS; ++i) {
-    const int qy = wave + i * WAVES;
+    const int qy = rbase + i * rstride;
     const int y = wy * p.ws + qy, x = wx * p.ws + c;
     const bool qwin = c < S && qy < S, qimg = qwin && (y < p.H) && (x < p.W);
 #pragma unroll
@@ -713,7 +732,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
   // independent 16-byte loads per thread are in flight before any is written to LDS, and the first batch
   // flies under the bias-table MFMAs (which need only Q and the position tables).
   constexpr int UN = 10;
-  const int total = SR * 16 * (C::KPARTS + C::VPARTS);
+  const int total = SR * 16 * (KPARTST + C::VPARTS);
   uint4 sv[UN];
   u16 *sdst[UN];
   auto issue = [&](int i0) {
@@ -721,13 +740,13 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
     for (int n = 0; n < UN; ++n) {
       const int i = i0 + n * WAVES * 64;
       const int iq = min(i, total - 1);
-      const bool isv = iq >= SR * 16 * C::KPARTS;
-      const int ii = isv ? iq - SR * 16 * C::KPARTS : iq;
-      const int parts = isv ? C::VPARTS : C::KPARTS;
+      const bool isv = iq >= SR * 16 * KPARTST;
+      const int ii = isv ? iq - SR * 16 * KPARTST : iq;
+      const int parts = isv ? C::VPARTS : KPARTST;
       const int slot = ii / parts, part = ii - slot * parts;
       const int ky = slot >> 4, kx = slot & 15;
       const int y = wy * p.ws + ky, x = wx * p.ws + kx;
-      sdst[n] = (i < total) ? (isv ? Vl + slot * C::VROW + part * 8 : Kl + slot * C::KROW + part * 8) : nullptr;
+      sdst[n] = (i < total) ? (isv ? Vl + slot * C::VROW + part * 8 : Kl + slot * KROWT + part * 8) : nullptr;
       const bool img = (y < p.H) && (x < p.W);
       const int dc = part * 8 < HD ? part * 8 : HD - 8;
       const size_t tokc = (size_t)(b * p.H + min(y, p.H - 1)) * p.W + min(x, p.W - 1);
@@ -746,16 +765,18 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
   if (stage) issue(tid);
   // bias registers; tables are instantiated for the key-row count the pass will use
   float twr[MAXROWS][4], thv[MAXROWS][16];
+  const bool two_rows = HALF ? S > 2 * WAVES : S > WAVES;           // otherwise one query row per wave covers the window
   if (!(kAbl & 2)) {
-    if (S > WAVES) {
+    if (two_rows) {
       if (S == 14)
-        win16_tables<HD, 2, 14>(rf, S, wave, WAVES, qfa, tab, twr, thv, lane);
+        win16_tables<HD, 2, 14>(rf, S, rbase, rstride, qfa, tab, twr, thv, lane);
       else
-        win16_tables<HD, 2, 16>(rf, S, wave, WAVES, qfa, tab, twr, thv, lane);
-    } else if (wave < S) {
-      win16_tables<HD, 1, 8>(rf, S, wave, WAVES, qfa, tab, twr, thv, lane);
+        win16_tables<HD, 2, 16>(rf, S, rbase, rstride, qfa, tab, twr, thv, lane);
+    } else if (rbase < S) {
+      win16_tables<HD, 1, 8>(rf, S, rbase, rstride, qfa, tab, twr, thv, lane);
     }
   }
+  if (HALF) __syncthreads();                                       // every wave is done with its scratch table: K may overwrite it
   if (stage) {
     commit();
     for (int i0 = tid + UN * WAVES * 64; i0 < total; i0 += UN * WAVES * 64) {
@@ -765,20 +786,18 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
   }
   __syncthreads();
 
-  // S <= WAVES: one query row per wave; otherwise two rows per wave share every K / V fragment read:
-  // rows (wave, wave + WAVES).
-  if (S <= WAVES) {
-    if (wave < S && !(kAbl & 2)) {
+  // one query row per wave when that covers the window; otherwise two rows per wave share every K / V fragment read
+  if (!two_rows) {
+    if (rbase < S && !(kAbl & 2)) {
       const bf16x8 (&q1)[1][C::KS] = reinterpret_cast<const bf16x8 (&)[1][C::KS]>(qfa[0]);
-      win16_pass<HD, 1, 8, false>(p, Kl, Vl, S, SR, b, wy, wx, head, wave, WAVES, q1, twr, thv, lane);
+      win16_pass<HD, 1, 8, false, KROWT>(p, Kl, Vl, S, SR, b, wy, wx, head, rbase, rstride, q1, twr, thv, lane);
     }
   } else if (!(kAbl & 2)) {
-    static_assert(MAXROWS >= 2 || WAVES >= 16, "row bookkeeping");
     const bf16x8 (&q2)[2][C::KS] = reinterpret_cast<const bf16x8 (&)[2][C::KS]>(qfa[0]);
     if (S == 14) {
-      win16_pass<HD, 2, 14, true>(p, Kl, Vl, S, SR, b, wy, wx, head, wave, WAVES, q2, twr, thv, lane);
+      win16_pass<HD, 2, 14, true, KROWT>(p, Kl, Vl, S, SR, b, wy, wx, head, rbase, rstride, q2, twr, thv, lane);
     } else
-      win16_pass<HD, 2, 16, false>(p, Kl, Vl, S, SR, b, wy, wx, head, wave, WAVES, q2, twr, thv, lane);
+      win16_pass<HD, 2, 16, false, KROWT>(p, Kl, Vl, S, SR, b, wy, wx, head, rbase, rstride, q2, twr, thv, lane);
   }
 }
 
@@ -891,15 +910,27 @@ static int launch_attn(AttnParams p, hipStream_t st) {
   using C = Cfg<HD>;
   const bool bias = p.rel_h != nullptr;
   if (p.ws > 0 && bias && p.S <= 16) {
-    constexpr int WAVES = 8;                                      // rows (wave, wave + 8): two query rows per wave share every
-                                                                  // K / V fragment read (measured: 8x2 rows 0.23 ms vs 14x1 rows 0.25 ms per 8 frames)
     const int SR = (p.S + 1) & ~1;
-    const size_t lds = (size_t)SR * 16 * (C::KROW + C::VROW) * 2 + (size_t)WAVES * 16 * W16_LT * 4;
-    if (lds > 160 * 1024) return S6D_EUNSUPPORTED;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_window16_kernel<HD, WAVES>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const unsigned grid = (unsigned)(p.B * p.nwy * p.nwx * p.nh);
-    hipLaunchKernelGGL((attn_window16_kernel<HD, WAVES>), dim3(grid), dim3(WAVES * 64), lds, st, p);
+    const unsigned items = (unsigned)(p.B * p.nwy * p.nwx * p.nh);
+    static int impl = -1;                                         // S6D_WIN16_IMPL=1: the one-workgroup-per-item kernel
+    if (impl < 0) {
+      const char *e = getenv("S6D_WIN16_IMPL");
+      impl = (e && atoi(e) == 1) ? 1 : 2;
+    }
+    const size_t lds_half = (size_t)SR * 16 * (HD + 8 + C::VROW) * 2;
+    if (impl == 2 && (items & 7) == 0 && lds_half <= 80 * 1024 && (size_t)4 * 16 * W16_LT * 4 <= (size_t)SR * 16 * (HD + 8) * 2) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_window16_kernel<HD, 4, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_half);
+      hipLaunchKernelGGL((attn_window16_kernel<HD, 4, true>), dim3(2 * items), dim3(256), lds_half, st, p);
+    } else {
+      constexpr int WAVES = 8;                                    // rows (wave, wave + 8): two query rows per wave share every
+                                                                  // K / V fragment read (measured: 8x2 rows 0.23 ms vs 14x1 rows 0.25 ms per 8 frames)
+      const size_t lds = (size_t)SR * 16 * (C::KROW + C::VROW) * 2 + (size_t)WAVES * 16 * W16_LT * 4;
+      if (lds > 160 * 1024) return S6D_EUNSUPPORTED;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_window16_kernel<HD, WAVES, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((attn_window16_kernel<HD, WAVES, false>), dim3(items), dim3(WAVES * 64), lds, st, p);
+    }
   } else if (p.ws > 0) {
     constexpr int WAVES = 8;
     const int ntile = (p.T + 63) / 64;

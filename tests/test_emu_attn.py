@@ -5,7 +5,9 @@ import pytest
 from tests import test_gpu_attn as T
 
 
-@pytest.mark.parametrize("B,H,nh,hd,ws", [(1, 16, 1, 64, 7), (1, 16, 1, 64, 0), (1, 14, 1, 80, 14)])
+@pytest.mark.parametrize("B,H,nh,hd,ws", [(1, 16, 1, 64, 7), (1, 16, 1, 64, 0), (1, 14, 1, 80, 14),
+                                          # item counts that are multiples of 8 take the two-workgroups-per-item kernel:
+                                          (1, 28, 2, 80, 14), (1, 14, 2, 64, 7), (2, 20, 4, 80, 14)])
 def test_fused_attention_on_the_emulator(emu, B, H, nh, hd, ws):
     T.test_fused_attention_vs_oracle(B, H, nh, hd, ws)
 

@@ -241,6 +241,19 @@ def kernel_rooflines(dev, sam_chunk, frames):
                 "unit": "TFLOP/s (bf16 MFMA executed = 3x the algorithmic fp32 FLOP)",
                 "frac": round(3 * flop / ms / 1e9 / 2500.0, 4), "avg_ms": round(ms, 4), "launches_per_step": 2,
                 "algorithmic_fp32_tflops": round(flop / ms / 1e9, 1)})
+    # fine matching head: similarity + assignment fused (csrc/s6d_fine.hip); executed matrix work = 3 sweeps x 3 bf16 terms per
+    # algorithmic fp32 product over the (2080 x 2048 x 256) padded tile space; algorithmic HBM bytes = the two feature sets + outputs
+    if ops.have("fine_match"):
+        f1 = torch.randn(B, 2049, 256, generator=g).to(dev)
+        f2 = torch.randn(B, 2049, 256, generator=g).to(dev)
+        p2 = torch.randn(B, 2048, 3, generator=g).to(dev)
+        ms = _event_ms(lambda: ops.fine_match(f1, f2, p2, 0.1), 10)
+        flop = 9 * 2.0 * B * 2080 * 2048 * 256
+        out.append({"kernel": "fine_match (split + 3 x fine_sweep_kernel)", "bound": "mfma", "achieved": round(flop / ms / 1e9, 1),
+                    "peak": 2500.0, "unit": "TFLOP/s (bf16 MFMA executed = 9x the algorithmic fp32 similarity FLOP)",
+                    "frac": round(flop / ms / 1e9 / 2500.0, 4), "avg_ms": round(ms, 4), "launches_per_step": 1,
+                    "algorithmic_bytes": float(B) * (2 * 2049 * 256 * 4 + 2048 * 5 * 4),
+                    "matrix_bytes_not_written": float(B) * 2049 * 2049 * 4, "pmc_key": "fine_sweep_kernel<2>"})
     # the Linear layers of the ViT-H blocks: the hand-written bf16 GEMM (csrc/s6d_gemm.hip) at the four shapes of a block, and the
     # library GEMM (hipBLASLt through torch) at the largest of them for context.  Algorithmic work 2 M N K FLOP.
     M = sam_chunk * 4096
@@ -256,7 +269,9 @@ def kernel_rooflines(dev, sam_chunk, frames):
         flop = 2.0 * M * N * K
         out.append({"kernel": f"gemm_bf16_kernel ({nm}, M={M} K={K} N={N})", "bound": "mfma", "achieved": round(flop / ms / 1e9, 1),
                     "peak": 2500.0, "unit": "TFLOP/s", "frac": round(flop / ms / 1e9 / 2500.0, 4), "avg_ms": round(ms, 4),
-                    "launches_per_step": 32 * groups, "algorithmic_bytes": 2.0 * (M * K + N * K + M * N)})
+                    "launches_per_step": 32 * groups, "algorithmic_bytes": 2.0 * (M * K + N * K + M * N),
+                    # the GELU instance runs at this one shape only; qkv / proj / lin2 share an instance (no per-shape counters)
+                    "pmc_key": "gemm_bf16_kernel<1, true>" if gelu else "-"})
     x = torch.randn(M, 1280, generator=g).to(dev).to(torch.bfloat16)
     w = torch.randn(5120, 1280, generator=g).to(dev).to(torch.bfloat16)
     bb = torch.randn(5120, generator=g).to(dev).to(torch.bfloat16)
@@ -270,18 +285,20 @@ def kernel_rooflines(dev, sam_chunk, frames):
     return out
 
 
-def _pmc_traffic(kernel_name):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r02_pmc_summary.json, else the round-1 file),
-    if present: FETCH_SIZE (doubled: gfx950 half-count of wide coalesced reads, MI355X_MICROARCH.md) + WRITE_SIZE."""
+def _pmc_traffic(row):
+    """HBM bytes per launch of a `kernels` row from the committed rocprofv3 --pmc passes (profiles/r02_pmc_summary.json, else the
+    round-1 file), if present: FETCH_SIZE (doubled: gfx950 half-count of wide coalesced reads, MI355X_MICROARCH.md) + WRITE_SIZE.
+    Rows name their counter key (`pmc_key` = the kernel's template instance as rocprofv3 prints it); a template instance that runs
+    at several shapes in the counter pass (its average would mix them) has none."""
+    key = row.get("pmc_key", row["kernel"])
     for f in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", f)))
-            for k, v in d.items():
-                if kernel_name.split("<")[0].split(" (")[0] == k.split("<")[0].split(" (")[0] and \
-                        (" (" not in k or k.split(" (")[1][:4] == kernel_name.split(" (")[1][:4]):
-                    return v.get("hbm_bytes_per_launch")
-        except Exception:
-            pass
+        except Exception:  # noqa: BLE001
+            continue
+        for k, v in d.items():
+            if k.replace(" ", "") == key.replace(" ", ""):
+                return v.get("hbm_bytes_per_launch")
     return None
 
 
@@ -395,7 +412,9 @@ def main():
         # the library GEMM is listed in `kernels` for comparison only (it is not on the path)
         extra["roofline"] = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"],
                              "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
-                             "avg_launch_ms": dom["avg_ms"], "traffic": _pmc_traffic(dom["kernel"])}
+                             "avg_launch_ms": dom["avg_ms"], "traffic": _pmc_traffic(dom)}
+        if "algorithmic_bytes" in dom:
+            extra["roofline"]["algorithmic_bytes"] = dom["algorithmic_bytes"]
         extra["kernels"] = kr
         extra["stage_roofline"] = {"stage": f"SAM ViT-H encoder, {args.frames} frames (bf16 GEMMs + fused attention)",
                                    "bound": "mfma", "achieved": round(achieved / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12,

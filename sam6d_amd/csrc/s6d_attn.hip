@@ -565,11 +565,16 @@ __device__ __forceinline__ void win16_tables(const RelFrags<HD> &rf, int S, int 
 //      exponentials of step u+1.  The row sum comes from the matrix core too (an all-ones A fragment), so it is the
 //      sum of the SAME bf16-rounded P that multiplies V and costs no VALU adds or lane exchanges.
 // SRC = compile-time key-row count (even); EXACT: S == SRC (no unstaged key rows to skip).
-template <int HD, int NS, int SRC, bool EXACT, int KROWT = Cfg<HD>::KROW>
+struct Win16NoMid {
+  __device__ __forceinline__ void operator()() const {}
+};
+// KROWT: K image row stride (elements); MID: called half way through the PV pass (the Q fragments are dead since the score pass,
+// and by then half of the score registers are free).
+template <int HD, int NS, int SRC, bool EXACT, int KROWT = Cfg<HD>::KROW, class MID = Win16NoMid>
 __device__ __forceinline__ void win16_pass(const AttnParams &p, const u16 *Kl, const u16 *Vl, int S, int SR, int b,
                                            int wy, int wx, int head, int qy0, int rstride,
                                            const bf16x8 (&qf)[NS][Cfg<HD>::KS], const float (*twr)[4],
-                                           const float (*thv)[16], int lane) {
+                                           const float (*thv)[16], int lane, MID mid = MID()) {
   using C = Cfg<HD>;
   const int g = lane >> 4, c = lane & 15;
   const int Cc = p.nh * HD;
@@ -631,6 +636,12 @@ __device__ __forceinline__ void win16_pass(const AttnParams &p, const u16 *Kl, c
   for (int i = 0; i < 8; ++i) ones.hh[i] = 0x3F80;                // bf16 1.0
 #pragma unroll
   for (int u = 0; u < SRC; u += 2) {
+    // half of the score registers have been consumed: room for what `mid` brings in (the next item's Q fragments)
+    if (u == ((SRC / 2 + 1) & ~1)) {
+      __builtin_amdgcn_sched_barrier(0);                              // keep the loads `mid` issues from being hoisted into the first half
+      mid();
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (EXACT || u < SR) {                                          // wave-uniform; K / V rows >= SR are not staged
       union { bf16x8 v; s16x4 q[2]; } va[C::DT];
       const u16 *vrow = Vl + (u * 16 + g * 4 + (c >> 2)) * C::VROW + (c & 3) * 4;
@@ -678,40 +689,29 @@ __device__ __forceinline__ void win16_pass(const AttnParams &p, const u16 *Kl, c
 // ---- windowed, row-padded (S <= 16): key slot = ky*16 + kx, so every 16-key MFMA sub-tile is ONE key row and
 // every 16-query strip is ONE query row: the decomposed bias costs one LDS word per sub-tile (rel_h) plus four
 // registers (rel_w, kx = g*4+r fixed per lane; out-of-window columns carry -1e30 there, which is the mask).
-// HALF = false: one 8-wave workgroup per (window, head), query rows (wave, wave + 8).
-// HALF = true:  TWO 4-wave workgroups per (window, head), each with its own copy of the window's K / V (compact 75 KiB image: K rows
-//               of HD + 8 elements, the scratch tables aliased into the K area) and the query rows of one parity (2 wave + h,
-//               2 wave + 8 + h).  Two such workgroups fit a CU (2 x 75 KiB LDS, 2 x 4 waves at <= 256 VGPRs), so the staging of
-//               one overlaps the arithmetic of the other -- what one 98-KiB workgroup per CU could not do.  The two halves of an
-//               item run on the same XCD (workgroup ids 16 j + x and 16 j + 8 + x), i.e. the second K / V fetch is an L2 hit.
-template <int HD, int WAVES, bool HALF>
+template <int HD, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p) {
   using C = Cfg<HD>;
-  constexpr int KROWT = HALF ? HD + 8 : C::KROW;                   // K image row stride (elements)
-  constexpr int KPARTST = HALF ? HD / 8 : C::KPARTS;               // 16-byte parts staged per K slot
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int S = p.S, SR = (S + 1) & ~1;                            // key rows, rounded up to a 32-key k-step
-  u16 *Kl = reinterpret_cast<u16 *>(smem);                         // [SR*16][KROWT]
-  u16 *Vl = Kl + (size_t)SR * 16 * KROWT;                          // [SR*16][VROW]
-  // HALF: the tables are scratch of the prologue only (bias registers are built before K / V are committed): they live in the K area
-  float *tabs = HALF ? reinterpret_cast<float *>(smem) : reinterpret_cast<float *>(Vl + (size_t)SR * 16 * C::VROW);
+  u16 *Kl = reinterpret_cast<u16 *>(smem);                         // [SR*16][KROW]
+  u16 *Vl = Kl + (size_t)SR * 16 * C::KROW;                        // [SR*16][VROW]
+  float *tabs = reinterpret_cast<float *>(Vl + (size_t)SR * 16 * C::VROW);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int g = lane >> 4, c = lane & 15;
   float *tab = tabs + (size_t)wave * 16 * W16_LT;                 // one [16][W16_LT] scratch table per wave
 
   WinItem item;
-  const int hsel = HALF ? ((int)blockIdx.x >> 3) & 1 : 0;          // which row parity this workgroup owns
-  item.decode(p, HALF ? (((int)blockIdx.x >> 4) << 3) | ((int)blockIdx.x & 7) : (int)blockIdx.x);
+  item.decode(p, blockIdx.x);
   const int head = item.head, wx = item.wx, wy = item.wy, b = item.b;
   const int Cc = p.nh * HD;
-  const int rbase = HALF ? 2 * wave + hsel : wave, rstride = HALF ? 2 * WAVES : WAVES;   // rows rbase, rbase + rstride
   // Q fragments of every query row this wave owns are fetched first so their latency hides under the staging
-  constexpr int MAXROWS = 2;
-  static_assert((HALF ? 4 : 2) * WAVES >= 16, "two rows per wave must cover 16 query rows");
+  constexpr int MAXROWS = 2;                                      // rows (wave, wave + WAVES); WAVES >= 8 covers S <= 16
+  static_assert(2 * WAVES >= 16, "two rows per wave must cover 16 query rows");
   bf16x8 qfa[MAXROWS][C::KS];
 #pragma unroll
   for (int i = 0; i < MAXROWS; ++i) {
-    const int qy = rbase + i * rstride;
+    const int qy = wave + i * WAVES;
     const int y = wy * p.ws + qy, x = wx * p.ws + c;
     const bool qwin = c < S && qy < S, qimg = qwin && (y < p.H) && (x < p.W);
 #pragma unroll
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
   // independent 16-byte loads per thread are in flight before any is written to LDS, and the first batch
   // flies under the bias-table MFMAs (which need only Q and the position tables).
   constexpr int UN = 10;
-  const int total = SR * 16 * (KPARTST + C::VPARTS);
+  const int total = SR * 16 * (C::KPARTS + C::VPARTS);
   uint4 sv[UN];
   u16 *sdst[UN];
   auto issue = [&](int i0) {
@@ -740,13 +740,13 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
     for (int n = 0; n < UN; ++n) {
       const int i = i0 + n * WAVES * 64;
       const int iq = min(i, total - 1);
-      const bool isv = iq >= SR * 16 * KPARTST;
-      const int ii = isv ? iq - SR * 16 * KPARTST : iq;
-      const int parts = isv ? C::VPARTS : KPARTST;
+      const bool isv = iq >= SR * 16 * C::KPARTS;
+      const int ii = isv ? iq - SR * 16 * C::KPARTS : iq;
+      const int parts = isv ? C::VPARTS : C::KPARTS;
       const int slot = ii / parts, part = ii - slot * parts;
       const int ky = slot >> 4, kx = slot & 15;
       const int y = wy * p.ws + ky, x = wx * p.ws + kx;
-      sdst[n] = (i < total) ? (isv ? Vl + slot * C::VROW + part * 8 : Kl + slot * KROWT + part * 8) : nullptr;
+      sdst[n] = (i < total) ? (isv ? Vl + slot * C::VROW + part * 8 : Kl + slot * C::KROW + part * 8) : nullptr;
       const bool img = (y < p.H) && (x < p.W);
       const int dc = part * 8 < HD ? part * 8 : HD - 8;
       const size_t tokc = (size_t)(b * p.H + min(y, p.H - 1)) * p.W + min(x, p.W - 1);
@@ -765,18 +765,16 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
   if (stage) issue(tid);
   // bias registers; tables are instantiated for the key-row count the pass will use
   float twr[MAXROWS][4], thv[MAXROWS][16];
-  const bool two_rows = HALF ? S > 2 * WAVES : S > WAVES;           // otherwise one query row per wave covers the window
   if (!(kAbl & 2)) {
-    if (two_rows) {
+    if (S > WAVES) {
       if (S == 14)
-        win16_tables<HD, 2, 14>(rf, S, rbase, rstride, qfa, tab, twr, thv, lane);
+        win16_tables<HD, 2, 14>(rf, S, wave, WAVES, qfa, tab, twr, thv, lane);
       else
-        win16_tables<HD, 2, 16>(rf, S, rbase, rstride, qfa, tab, twr, thv, lane);
-    } else if (rbase < S) {
-      win16_tables<HD, 1, 8>(rf, S, rbase, rstride, qfa, tab, twr, thv, lane);
+        win16_tables<HD, 2, 16>(rf, S, wave, WAVES, qfa, tab, twr, thv, lane);
+    } else if (wave < S) {
+      win16_tables<HD, 1, 8>(rf, S, wave, WAVES, qfa, tab, twr, thv, lane);
     }
   }
-  if (HALF) __syncthreads();                                       // every wave is done with its scratch table: K may overwrite it
   if (stage) {
     commit();
     for (int i0 = tid + UN * WAVES * 64; i0 < total; i0 += UN * WAVES * 64) {
@@ -786,18 +784,156 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
   }
   __syncthreads();
 
-  // one query row per wave when that covers the window; otherwise two rows per wave share every K / V fragment read
-  if (!two_rows) {
-    if (rbase < S && !(kAbl & 2)) {
+  // S <= WAVES: one query row per wave; otherwise two rows per wave share every K / V fragment read:
+  // rows (wave, wave + WAVES).
+  if (S <= WAVES) {
+    if (wave < S && !(kAbl & 2)) {
       const bf16x8 (&q1)[1][C::KS] = reinterpret_cast<const bf16x8 (&)[1][C::KS]>(qfa[0]);
-      win16_pass<HD, 1, 8, false, KROWT>(p, Kl, Vl, S, SR, b, wy, wx, head, rbase, rstride, q1, twr, thv, lane);
+      win16_pass<HD, 1, 8, false>(p, Kl, Vl, S, SR, b, wy, wx, head, wave, WAVES, q1, twr, thv, lane);
     }
   } else if (!(kAbl & 2)) {
+    static_assert(MAXROWS >= 2 || WAVES >= 16, "row bookkeeping");
     const bf16x8 (&q2)[2][C::KS] = reinterpret_cast<const bf16x8 (&)[2][C::KS]>(qfa[0]);
     if (S == 14) {
-      win16_pass<HD, 2, 14, true, KROWT>(p, Kl, Vl, S, SR, b, wy, wx, head, rbase, rstride, q2, twr, thv, lane);
+      win16_pass<HD, 2, 14, true>(p, Kl, Vl, S, SR, b, wy, wx, head, wave, WAVES, q2, twr, thv, lane);
     } else
-      win16_pass<HD, 2, 16, false, KROWT>(p, Kl, Vl, S, SR, b, wy, wx, head, rbase, rstride, q2, twr, thv, lane);
+      win16_pass<HD, 2, 16, false>(p, Kl, Vl, S, SR, b, wy, wx, head, wave, WAVES, q2, twr, thv, lane);
+  }
+}
+
+// ---- windowed, row-padded, PERSISTENT: one 8-wave workgroup per CU walks its share of the (window, head) items; the K / V
+// images of item i + 1 arrive by LDS-DMA into the second half of LDS while item i is computed from the first.
+//
+// Why: the one-item-per-workgroup kernel above spends an item as [fetch 107 KB | arithmetic | store]: with one 98-KiB workgroup
+// per CU nothing overlaps, and the CU's fetch path (~10 B/clk/CU from HBM, MI355X_MICROARCH.md) is idle for half of the item.
+// Two smaller workgroups per CU did not help (each needs its own copy of the window: 0.375 vs 0.358 ms per 16 frames); keeping
+// the fetch path busy does -- a register-free prefetch of the NEXT item, which LDS-DMA provides.
+//   * LDS (all 160 KiB): 2 x [K image 224 slots x 11 chunks (10 data + 1 pad: 176-B rows are bank-conflict free for the fragment
+//     reads) padded to 39 KiB | V image 224 x 10 chunks = 35 KiB] + the two padded rel-pos tables (12 KiB, read as A fragments per
+//     item instead of being held in 48 VGPRs across the loop).  The per-wave scratch tables of win16_tables live in the V area
+//     of the buffer that is being FILLED: the K image of the next item goes out first, the V image after the tables are done.
+//   * an image is lane-linear for the DMA (64 consecutive 16-byte chunks per instruction); the lane works out which (slot, part)
+//     its chunk is: in-window in-image -> the token's k / v run, out-of-image -> the qkv bias (quirk Q2 of SURVEY: padded tokens
+//     carry the bias), outside the 14 x 14 window or the pad chunk -> a 16-byte zero in global memory.
+//   * Q fragments of item i + 1 are loaded into the registers of item i's Q fragments as soon as item i's score pass is done (they
+//     are dead during the PV pass): the global-load latency hides under the PV pass.
+__device__ const uint4 g_win16_zero = {0u, 0u, 0u, 0u};
+
+#ifdef HIPEMU
+#define S6D_ATTN_VMCNT0() hipemu::vmcnt_wait(0)
+#else
+#define S6D_ATTN_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+#define S6D_ATTN_GLOBAL(T) __attribute__((address_space(1))) T
+
+template <int HD>
+__global__ __launch_bounds__(512) void attn_window16p_kernel(AttnParams p, int nitems) {
+  using C = Cfg<HD>;
+  constexpr int WAVES = 8;
+  constexpr int KROWT = HD + 8, KCH = KROWT / 8, VCH = C::VROW / 8;   // chunks (16 B) per K / V row
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int S = p.S, SR = (S + 1) & ~1;
+  const int kchunks = SR * 16 * KCH, vchunks = SR * 16 * VCH;
+  const int kinstr = (kchunks + 63) >> 6, vinstr = (vchunks + 63) >> 6;
+  const int kbytes = kinstr << 10, bufbytes = kbytes + (vinstr << 10);
+  u16 *relh = reinterpret_cast<u16 *>(smem + 2 * bufbytes);        // [32][HDP] padded rel_pos_h, then rel_pos_w
+  u16 *relw = relh + 32 * C::HDP;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int g = lane >> 4, c = lane & 15;
+  const int Cc = p.nh * HD;
+  for (int i = tid; i < 2 * 32 * C::HDP / 8; i += 512) {             // rel tables -> LDS, once
+    const bool w = i >= 32 * C::HDP / 8;
+    const int ii = w ? i - 32 * C::HDP / 8 : i;
+    reinterpret_cast<uint4 *>(w ? relw : relh)[ii] = reinterpret_cast<const uint4 *>(w ? p.rel_w : p.rel_h)[ii];
+  }
+
+  // ---- DMA of one image: `which` 1 = K (row KCH chunks, the last one padding), 2 = V
+  auto stage_image = [&](const WinItem &it, int which, char *dst_base) __attribute__((always_inline)) {
+    const int rowch = which == 1 ? KCH : VCH, ninstr = which == 1 ? kinstr : vinstr, nch = which == 1 ? kchunks : vchunks;
+    for (int k = wave; k < ninstr; k += WAVES) {
+      const int j = min((k << 6) + lane, nch - 1);                  // chunk of the image (tail lanes repeat the last chunk's source)
+      const int slot = j / rowch, part = j - slot * rowch;
+      const int ky = slot >> 4, kx = slot & 15;
+      const int y = it.wy * p.ws + ky, x = it.wx * p.ws + kx;
+      const bool inwin = ky < S && kx < S && part * 8 < HD, img = (y < p.H) && (x < p.W);
+      const size_t tokc = (size_t)(it.b * p.H + min(y, p.H - 1)) * p.W + min(x, p.W - 1);
+      const int sel = which * Cc + it.head * HD + min(part * 8, HD - 8);
+      const u16 *src = img ? p.qkv + tokc * (size_t)(3 * Cc) + sel : p.qkv_bias + sel;
+      const void *sp = inwin ? (const void *)src : (const void *)&g_win16_zero;
+      S6D_LDS(char) *dst = (S6D_LDS(char) *)dst_base + (k << 10);
+      __builtin_amdgcn_global_load_lds((const S6D_ATTN_GLOBAL(void) *)sp, dst, 16, 0, 0);
+    }
+  };
+  constexpr int MAXROWS = 2;
+  bf16x8 qfa[MAXROWS][C::KS];
+  auto load_q = [&](const WinItem &it) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < MAXROWS; ++i) {
+      const int qy = wave + i * WAVES;
+      const int y = it.wy * p.ws + qy, x = it.wx * p.ws + c;
+      const bool qwin = c < S && qy < S, qimg = qwin && (y < p.H) && (x < p.W);
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        union { uint4 u; bf16x8 v; } t;
+        const int d0 = ks * 32 + g * 8;
+        const int dc = d0 < HD ? d0 : HD - 8;
+        const size_t tokc = (size_t)(it.b * p.H + min(y, p.H - 1)) * p.W + min(x, p.W - 1);
+        const u16 *src = qimg ? p.qkv + tokc * (size_t)(3 * Cc) + it.head * HD + dc : p.qkv_bias + it.head * HD + dc;
+        t.u = *reinterpret_cast<const uint4 *>(src);
+        if (!(qwin && d0 < HD)) t.u = make_uint4(0, 0, 0, 0);
+        qfa[i][ks] = t.v;
+      }
+    }
+  };
+
+  WinItem cur, nxt;
+  int id = blockIdx.x;
+  cur.decode(p, id);
+  load_q(cur);
+  stage_image(cur, 1, smem);
+  stage_image(cur, 2, smem + kbytes);
+  S6D_ATTN_VMCNT0();
+  __syncthreads();
+  int buf = 0;
+  for (; id < nitems; id += gridDim.x) {
+    char *cb = smem + buf * bufbytes, *nb = smem + (buf ^ 1) * bufbytes;
+    const bool more = id + (int)gridDim.x < nitems;
+    if (more) {
+      nxt.decode(p, id + gridDim.x);
+      stage_image(nxt, 1, nb);                                       // K image of the next item; its V area is this item's scratch
+    }
+    // bias registers of this item (rel-pos tables as A fragments from LDS; scratch tables in the V area of the other buffer)
+    float twr[MAXROWS][4], thv[MAXROWS][16];
+    {
+      RelFrags<HD> rf;
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+          rf.rh[jt][ks].u = *reinterpret_cast<const uint4 *>(relh + (jt * 16 + c) * C::HDP + ks * 32 + g * 8);
+          rf.rw[jt][ks].u = *reinterpret_cast<const uint4 *>(relw + (jt * 16 + c) * C::HDP + ks * 32 + g * 8);
+        }
+      float *tab = reinterpret_cast<float *>(nb + kbytes) + (size_t)wave * 16 * W16_LT;
+      if (S == 14)
+        win16_tables<HD, 2, 14>(rf, S, wave, WAVES, qfa, tab, twr, thv, lane);
+      else
+        win16_tables<HD, 2, 16>(rf, S, wave, WAVES, qfa, tab, twr, thv, lane);
+    }
+    __builtin_amdgcn_s_barrier();                                    // every wave is done with its scratch table (raw: the K DMA stays in flight)
+    if (more) stage_image(nxt, 2, nb + kbytes);
+    const u16 *Kl = reinterpret_cast<const u16 *>(cb), *Vl = reinterpret_cast<const u16 *>(cb + kbytes);
+    auto mid = [&]() __attribute__((always_inline)) {                // half way through the PV pass: this item's Q fragments are long dead
+      if (more) load_q(nxt);
+    };
+    const bf16x8 (&q2)[2][C::KS] = reinterpret_cast<const bf16x8 (&)[2][C::KS]>(qfa[0]);
+    if (S == 14)
+      win16_pass<HD, 2, 14, true, KROWT>(p, Kl, Vl, S, SR, cur.b, cur.wy, cur.wx, cur.head, wave, WAVES, q2, twr, thv, lane, mid);
+    else
+      win16_pass<HD, 2, 16, false, KROWT>(p, Kl, Vl, S, SR, cur.b, cur.wy, cur.wx, cur.head, wave, WAVES, q2, twr, thv, lane, mid);
+    S6D_ATTN_VMCNT0();                                               // next item's images and Q have landed (and this item's stores)
+    __syncthreads();
+    cur = nxt;
+    buf ^= 1;
   }
 }
 
@@ -910,27 +1046,36 @@ static int launch_attn(AttnParams p, hipStream_t st) {
   using C = Cfg<HD>;
   const bool bias = p.rel_h != nullptr;
   if (p.ws > 0 && bias && p.S <= 16) {
+    constexpr int WAVES = 8;                                      // rows (wave, wave + 8): two query rows per wave share every
+                                                                  // K / V fragment read (measured: 8x2 rows 0.23 ms vs 14x1 rows 0.25 ms per 8 frames)
     const int SR = (p.S + 1) & ~1;
-    const unsigned items = (unsigned)(p.B * p.nwy * p.nwx * p.nh);
-    static int impl = -1;                                         // S6D_WIN16_IMPL=1: the one-workgroup-per-item kernel
+    // persistent, LDS-DMA double-buffered kernel: two query rows per wave (S > 8), both images + the rel tables inside 160 KiB.  S6D_WIN16_IMPL=1 selects the one-item kernel.
+    static int impl = -1;
     if (impl < 0) {
       const char *e = getenv("S6D_WIN16_IMPL");
       impl = (e && atoi(e) == 1) ? 1 : 2;
     }
-    const size_t lds_half = (size_t)SR * 16 * (HD + 8 + C::VROW) * 2;
-    if (impl == 2 && (items & 7) == 0 && lds_half <= 80 * 1024 && (size_t)4 * 16 * W16_LT * 4 <= (size_t)SR * 16 * (HD + 8) * 2) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_window16_kernel<HD, 4, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_half);
-      hipLaunchKernelGGL((attn_window16_kernel<HD, 4, true>), dim3(2 * items), dim3(256), lds_half, st, p);
-    } else {
-      constexpr int WAVES = 8;                                    // rows (wave, wave + 8): two query rows per wave share every
-                                                                  // K / V fragment read (measured: 8x2 rows 0.23 ms vs 14x1 rows 0.25 ms per 8 frames)
-      const size_t lds = (size_t)SR * 16 * (C::KROW + C::VROW) * 2 + (size_t)WAVES * 16 * W16_LT * 4;
-      if (lds > 160 * 1024) return S6D_EUNSUPPORTED;
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_window16_kernel<HD, WAVES, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((attn_window16_kernel<HD, WAVES, false>), dim3(items), dim3(WAVES * 64), lds, st, p);
+    if (impl == 2 && p.S > WAVES) {
+      const int kin = (SR * 16 * (HD + 8) / 8 + 63) / 64, vin = (SR * 16 * C::VROW / 8 + 63) / 64;
+      const size_t lds = (size_t)2 * (kin + vin) * 1024 + (size_t)2 * 32 * C::HDP * 2;
+      const int nitems = p.B * p.nwy * p.nwx * p.nh;
+      if (lds <= 160 * 1024 && (size_t)WAVES * 16 * W16_LT * 4 <= (size_t)vin * 1024) {
+        int grid = nitems < 256 ? nitems : 256;                   // one persistent workgroup per CU
+        const char *ge = getenv("S6D_WIN16_GRID");                // tests: fewer workgroups than items without a big problem
+        if (ge && atoi(ge) > 0 && atoi(ge) < grid) grid = atoi(ge);
+        if (grid >= 8) grid &= ~7;                                // whole XCD rounds: workgroup j keeps to XCD j % 8, like its items
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_window16p_kernel<HD>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((attn_window16p_kernel<HD>), dim3(grid), dim3(512), lds, st, p, nitems);
+        return launch_status();
+      }
     }
+    const size_t lds = (size_t)SR * 16 * (C::KROW + C::VROW) * 2 + (size_t)WAVES * 16 * W16_LT * 4;
+    if (lds > 160 * 1024) return S6D_EUNSUPPORTED;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_window16_kernel<HD, WAVES>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const unsigned grid = (unsigned)(p.B * p.nwy * p.nwx * p.nh);
+    hipLaunchKernelGGL((attn_window16_kernel<HD, WAVES>), dim3(grid), dim3(WAVES * 64), lds, st, p);
   } else if (p.ws > 0) {
     constexpr int WAVES = 8;
     const int ntile = (p.T + 63) / 64;

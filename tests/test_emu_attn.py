@@ -12,6 +12,16 @@ def test_fused_attention_on_the_emulator(emu, B, H, nh, hd, ws):
     T.test_fused_attention_vs_oracle(B, H, nh, hd, ws)
 
 
+@pytest.mark.parametrize("grid", [8, 3])
+def test_persistent_window_kernel_walks_several_items(emu, monkeypatch, grid):
+    """attn_window16p_kernel with fewer workgroups than items (S6D_WIN16_GRID): the LDS-DMA prefetch of the next item's K / V
+    images into the other half of LDS, the Q prefetch in the PV pass, scratch tables inside the buffer being filled; 32 items
+    (out-of-image window slots included) on 8 and on 3 workgroups (uneven shares, odd and even item counts per workgroup)."""
+    monkeypatch.setenv("S6D_WIN16_GRID", str(grid))
+    T.test_fused_attention_vs_oracle(2, 20, 4, 80, 14)
+    T.test_fused_attention_vs_oracle(1, 28, 2, 64, 14)
+
+
 @pytest.mark.parametrize("rows,C", [(37, 160), (5, 768)])
 def test_add_layernorm_on_the_emulator(emu, rows, C):
     T.test_add_layernorm_bf16(rows, C)

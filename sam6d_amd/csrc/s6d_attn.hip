@@ -815,8 +815,12 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
 //   * an image is lane-linear for the DMA (64 consecutive 16-byte chunks per instruction); the lane works out which (slot, part)
 //     its chunk is: in-window in-image -> the token's k / v run, out-of-image -> the qkv bias (quirk Q2 of SURVEY: padded tokens
 //     carry the bias), outside the 14 x 14 window or the pad chunk -> a 16-byte zero in global memory.
-//   * Q fragments of item i + 1 are loaded into the registers of item i's Q fragments as soon as item i's score pass is done (they
-//     are dead during the PV pass): the global-load latency hides under the PV pass.
+//   * Q fragments of item i + 1 are loaded into the registers of item i's Q fragments half way through item i's PV pass (they are
+//     dead since the score pass, and half of the score registers are free by then).
+// Measured (16 frames, 6400 items): 0.305 ms against 0.350 ms for the one-item kernel (profiles/r02_win16_variants.txt).  Tried on
+// top and dropped, both slower: keeping the packed output rows in registers and storing them after the end-of-item wait (so that the
+// wait does not cover the stores): 0.396 ms; that plus folding the row bias into the scores to free 28 registers in the PV pass:
+// 0.431 ms (the kernel sits at the 256-VGPR limit: every extra live value in the PV pass became scratch traffic in the hot loop).
 __device__ const uint4 g_win16_zero = {0u, 0u, 0u, 0u};
 
 #ifdef HIPEMU

@@ -119,10 +119,26 @@ class HotPath:
 
     @torch.no_grad()
     def ism_stage(self):
+        """Scoring of the step's frames in launch groups of S6D_ISM_CHUNK frames (default 8; FrameScorer.score_frames: the frames of a
+        group go through one set of launches with a per-proposal frame index -- like the SAM encoder's groups of 16 frames and the
+        PEM's batch of 32 instances; results identical to frame-by-frame scoring, tests/test_gpu_ism.py).  S6D_ISM_CHUNK=0: one
+        ``score`` call per frame (round 1)."""
         i = self.ism_in
+        c = int(os.environ.get("S6D_ISM_CHUNK", "8"))
         out = None
-        for _ in range(self.F):
-            out = self.scorer.score(i["qry_cls"], i["qry_patch"], i["masks"], i["boxes"], i["depth"], i["K"])
+        if c <= 0:
+            for _ in range(self.F):
+                out = self.scorer.score(i["qry_cls"], i["qry_patch"], i["masks"], i["boxes"], i["depth"], i["K"])
+            return out
+        if getattr(self, "_ism_group", None) is None or self._ism_group[0] != c:
+            # every frame of a group has its own tensors in HBM (here: copies of the one synthetic frame)
+            rep = lambda t: t[None].expand(c, *t.shape).contiguous()
+            self._ism_group = (c, {k: rep(i[k]) for k in ("qry_cls", "qry_patch", "masks", "boxes", "depth")},
+                               i["K"].to(self.dev)[None].expand(c, 3, 3).contiguous())
+        _, g, K = self._ism_group
+        for f0 in range(0, self.F, c):
+            n = min(c, self.F - f0)
+            out = self.scorer.score_frames(g["qry_cls"][:n], g["qry_patch"][:n], g["masks"][:n], g["boxes"][:n], g["depth"][:n], K[:n])
         return out
 
     @torch.no_grad()
@@ -440,7 +456,7 @@ def main():
                 "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (SAM ViT-H, PEM ViT-B) + f32 (ISM scoring, PEM point transformer and pose solvers)",
                 "data": "synthetic",
                 "config": {"workload": "LM-O single object: 32 frames/step/GPU, 640x480 RGB-D -> 1024^2 SAM input, "
-                                       "P=128 proposals x 42 templates, 1 instance/frame, 2048 pts (PEM batch 32)",
+                                       "P=128 proposals x 42 templates (scored in groups of 8 frames), 1 instance/frame, 2048 pts (PEM batch 32)",
                            "frames_per_step_per_gpu": args.frames, "sam_frames_per_launch_group": args.sam_chunk,
                            "sharding": f"frames over {world} rank(s)"}}
         line.update(extra)

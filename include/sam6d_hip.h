@@ -224,6 +224,9 @@ long s6d_patch_scores_workspace_floats(int S, int N1, int N2);
 int s6d_masked_depth_mean_f32(const float *masks, const float *depth, int S, int H, int W, float depth_scale,
                               const double *K, void *workspace, float *out, void *stream);
 long s6d_masked_depth_mean_workspace_bytes(int S);   /* W % 4 == 0 */
+/* Several frames in one launch: depth (F,H,W), K (F,3,3) f64, frame (S) i32 = the frame of every mask (NULL: one frame). */
+int s6d_masked_depth_mean_frames_f32(const float *masks, const float *depth, const int32_t *frame, int S, int H, int W,
+                                     float depth_scale, const double *K, void *workspace, float *out, void *stream);
 
 /* Template projection: uv[s,i] = clamp(trunc(K (R_tmpl[s] p_i + t_s))), bbox[s] = (min u, min v, max u, max v).
  * pointcloud (O,N,3), poses (T,4,4), trans (S,3), K (3,3) f32; obj/tmpl (S) i32 -> uv (S,N,2) i32, bbox (S,4) i32.
@@ -231,6 +234,10 @@ long s6d_masked_depth_mean_workspace_bytes(int S);   /* W % 4 == 0 */
 int s6d_project_bbox_f32(const float *pointcloud, const float *poses, const int32_t *obj, const int32_t *tmpl,
                          const float *trans, const float *K, int S, int N, int H, int W, int32_t *uv,
                          int32_t *bbox, void *stream);
+/* Several frames in one launch: K (F,3,3) f32, frame (S) i32 = the frame of every proposal (NULL: one K). */
+int s6d_project_bbox_frames_f32(const float *pointcloud, const float *poses, const int32_t *obj, const int32_t *tmpl,
+                                const float *trans, const float *K, const int32_t *frame, int S, int N, int H, int W,
+                                int32_t *uv, int32_t *bbox, void *stream);
 
 /* Geometric structure embedding, fused: out[p,:] = W_d s(idx4[p,0]) + b_d + max_k (W_a s(idx4[p,1+k]) + b_a)
  * with s(x) the interleaved sinusoidal embedding [sin(x w_i), cos(x w_i)] (w = div_term (C/2)).

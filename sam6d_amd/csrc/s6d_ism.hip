@@ -313,10 +313,15 @@ __global__ __launch_bounds__(256) void masked_depth_partial_kernel(const float *
                                                                   const float *__restrict__ depth, int H, int W,
                                                                   unsigned magicW, float depth_scale,
                                                                   const double *__restrict__ K,
+                                                                  const int *__restrict__ frame,
                                                                   double *__restrict__ part) {
   __shared__ double sx[4], sy[4], sz[4];
   __shared__ int sn[4];
   const int s = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+  // several frames in one launch: mask s belongs to frame[s], which selects its depth map and camera matrix
+  const int fr = frame ? frame[s] : 0;
+  depth += (size_t)fr * H * W;
+  K += (size_t)fr * 9;
   // the camera matrix is read on the device (3x3 row-major float64, the reference's dtype): no host copy, no cache
   const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
   const int n4 = (H * W) / 4;                               // W % 4 == 0 (checked by the launcher)
@@ -379,9 +384,11 @@ __global__ void masked_depth_final_kernel(const double *__restrict__ part, int S
 __global__ __launch_bounds__(256) void project_bbox_kernel(const float *__restrict__ pointcloud, const float *__restrict__ poses,
                                                           const int *__restrict__ obj, const int *__restrict__ tmpl,
                                                           const float *__restrict__ trans, const float *__restrict__ K,
-                                                          int N, int H, int W, int *__restrict__ uv, int *__restrict__ bbox) {
+                                                          const int *__restrict__ frame, int N, int H, int W,
+                                                          int *__restrict__ uv, int *__restrict__ bbox) {
   __shared__ int red[4][4];
   const int s = blockIdx.x, tid = threadIdx.x;
+  if (frame) K += (size_t)frame[s] * 9;                      // several frames in one launch: one camera matrix per frame
   const float *R = poses + (size_t)tmpl[s] * 16;            // 4x4 row-major, rotation in [0:3,0:3]
   const float *pc = pointcloud + (size_t)obj[s] * N * 3;
   const float tx = trans[s * 3], ty = trans[s * 3 + 1], tz = trans[s * 3 + 2];
@@ -475,8 +482,16 @@ extern "C" long s6d_patch_scores_workspace_floats(int S, int N1, int N2) {
 
 extern "C" long s6d_masked_depth_mean_workspace_bytes(int S) { return (long)S * kDepthChunks * 4 * sizeof(double); }
 
+extern "C" int s6d_masked_depth_mean_frames_f32(const float *masks, const float *depth, const int32_t *frame, int S, int H, int W,
+                                                float depth_scale, const double *K, void *workspace, float *out, void *stream);
+
 extern "C" int s6d_masked_depth_mean_f32(const float *masks, const float *depth, int S, int H, int W, float depth_scale,
                                          const double *K, void *workspace, float *out, void *stream) {
+  return s6d_masked_depth_mean_frames_f32(masks, depth, nullptr, S, H, W, depth_scale, K, workspace, out, stream);
+}
+
+extern "C" int s6d_masked_depth_mean_frames_f32(const float *masks, const float *depth, const int32_t *frame, int S, int H, int W,
+                                                float depth_scale, const double *K, void *workspace, float *out, void *stream) {
   if (S < 0 || H <= 0 || W <= 0) return S6D_EINVAL;
   if ((W % 4) != 0) return S6D_EUNSUPPORTED;
   if (S == 0) return S6D_OK;
@@ -484,20 +499,30 @@ extern "C" int s6d_masked_depth_mean_f32(const float *masks, const float *depth,
   const unsigned magicW = (unsigned)(((1ull << 32) + (unsigned)W - 1) / (unsigned)W);
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(masked_depth_partial_kernel, dim3(kDepthChunks, S), dim3(256), 0, st, masks, depth, H, W, magicW,
-                     depth_scale, K, (double *)workspace);
+                     depth_scale, K, frame, (double *)workspace);
   int rc = launch_status();
   if (rc) return rc;
   hipLaunchKernelGGL(masked_depth_final_kernel, dim3((S + 63) / 64), dim3(64), 0, st, (const double *)workspace, S, out);
   return launch_status();
 }
 
+extern "C" int s6d_project_bbox_frames_f32(const float *pointcloud, const float *poses, const int32_t *obj, const int32_t *tmpl,
+                                           const float *trans, const float *K, const int32_t *frame, int S, int N, int H, int W,
+                                           int32_t *uv, int32_t *bbox, void *stream);
+
 extern "C" int s6d_project_bbox_f32(const float *pointcloud, const float *poses, const int32_t *obj, const int32_t *tmpl,
                                     const float *trans, const float *K, int S, int N, int H, int W, int32_t *uv,
                                     int32_t *bbox, void *stream) {
+  return s6d_project_bbox_frames_f32(pointcloud, poses, obj, tmpl, trans, K, nullptr, S, N, H, W, uv, bbox, stream);
+}
+
+extern "C" int s6d_project_bbox_frames_f32(const float *pointcloud, const float *poses, const int32_t *obj, const int32_t *tmpl,
+                                           const float *trans, const float *K, const int32_t *frame, int S, int N, int H, int W,
+                                           int32_t *uv, int32_t *bbox, void *stream) {
   if (S < 0 || N <= 0 || H <= 0 || W <= 0) return S6D_EINVAL;
   if (S == 0) return S6D_OK;
   if (!pointcloud || !poses || !obj || !tmpl || !trans || !K || !uv || !bbox) return S6D_EINVAL;
-  hipLaunchKernelGGL(project_bbox_kernel, dim3(S), dim3(256), 0, as_stream(stream), pointcloud, poses, obj, tmpl, trans, K, N,
-                     H, W, uv, bbox);
+  hipLaunchKernelGGL(project_bbox_kernel, dim3(S), dim3(256), 0, as_stream(stream), pointcloud, poses, obj, tmpl, trans, K, frame,
+                     N, H, W, uv, bbox);
   return launch_status();
 }

@@ -195,3 +195,42 @@ class FrameScorer(ScoringMixin):
         final = (sem + appe + geo * vr) / (1 + 1 + vr)
         return dict(sel=sel, pred_obj=pobj, semantic=sem, best_template=bt, appearance=appe, iou=geo,
                     visible_ratio=vr, final=final, image_uv=uv)
+
+    def score_frames(self, qry_cls, qry_patch, masks, boxes, depth, K, depth_scale=1.0):
+        """The matching stage for F frames in ONE set of launches (frames are independent: SURVEY 8e; the reference loops over
+        them, one Lightning step per frame).  qry_cls (F,P,C), qry_patch (F,P,N,C), masks (F,P,H,W), boxes (F,P,4), depth (F,H,W),
+        K (F,3,3) or (3,3).  Every per-frame rule of ``score`` holds per frame: a proposal's scores depend on its own frame's depth
+        map and camera only, and quirk Q3 of compute_iou (one empty intersection zeroes the IoU of ALL proposals) applies per
+        frame.  -> dict of flat tensors over the selected proposals of all frames, in (frame, proposal) order, with ``frame`` (the
+        frame of each) and ``sel`` (the proposal index inside its frame): the rows of frame f equal ``score(... frame f ...)``."""
+        F_, P = qry_cls.shape[0], qry_cls.shape[1]
+        dev = qry_cls.device
+        sel, pobj, sem, bt = self.compute_semantic_score(qry_cls.reshape(F_ * P, -1))
+        frame = torch.div(sel, P, rounding_mode="floor")
+        qp = qry_patch.reshape(F_ * P, *qry_patch.shape[2:])[sel]
+        appe, ref = self.compute_appearance_score(bt, pobj, qp)
+        Kf = K if K.dim() == 3 else K[None].expand(F_, 3, 3)
+        H, W = depth.shape[-2:]
+        msel = masks.reshape(F_ * P, H, W)[sel].to(torch.float32).contiguous()
+        f32 = frame.int().contiguous()
+        poses, pcs = self.ref_data["poses"], self.ref_data["pointcloud"]
+        if not (ops.have("masked_depth_mean") and ops.have("project_bbox") and msel.is_cuda and isinstance(ref, RefPatchHandle)):
+            raise RuntimeError("score_frames is the batched device path (fp32 / half descriptors on the GPU); use score() per frame")
+        t = ops.masked_depth_mean(msel, depth.to(torch.float32).contiguous(), Kf, float(depth_scale), frame=f32)
+        uv, bbox = ops.project_bbox(pcs.contiguous(), poses.contiguous(), pobj.int().contiguous(), bt.int().contiguous(), t.contiguous(),
+                                    Kf.to(device=dev, dtype=torch.float32).contiguous(), H, W, frame=f32)
+        vr = ref.visible_ratio if ref.thred == self.visible_thred else ops.patch_scores(
+            qp.float().contiguous(), ref.store, ref.obj, ref.tmpl, float(self.visible_thred))[1].to(qp.dtype)
+        # compute_iou per proposal, then quirk Q3 per frame: a frame with any empty intersection reports 0.0 for all its proposals
+        bb_a, bb_b = bbox.to(boxes.dtype), boxes.reshape(F_ * P, 4)[sel]
+        tl = torch.max(bb_a[:, 0:2], bb_b[:, 0:2])
+        br = torch.min(bb_a[:, 2:4], bb_b[:, 2:4])
+        wh_a, wh_b, wh_i = bb_a[:, 2:4] - bb_a[:, 0:2], bb_b[:, 2:4] - bb_b[:, 0:2], br - tl
+        ai = wh_i[:, 0] * wh_i[:, 1]
+        iou = ai / (wh_a[:, 0] * wh_a[:, 1] + wh_b[:, 0] * wh_b[:, 1] - ai)
+        bad = torch.zeros(F_, dtype=torch.bool, device=dev).index_put_((frame,), ~(wh_i > 0).all(dim=1), accumulate=True)
+        geo = torch.where(bad[frame], torch.zeros_like(iou), iou)
+        final = (sem + appe + geo * vr) / (1 + 1 + vr)
+        return dict(frame=frame, sel=sel - frame * P, pred_obj=pobj, semantic=sem, best_template=bt, appearance=appe, iou=geo,
+                    visible_ratio=vr, final=final, image_uv=uv)
+

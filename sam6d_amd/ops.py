@@ -639,36 +639,45 @@ def patch_scores(query, refstore, obj, tmpl, thred):
     return appe, ratio
 
 
-def masked_depth_mean(masks, depth, K, depth_scale):
+def masked_depth_mean(masks, depth, K, depth_scale, frame=None):
     """masks (S,H,W) f32, depth (H,W) f32, K 3x3 (any float dtype, host or device) -> (S,3) f32.  The camera matrix goes to
     the device as float64 (the reference's dtype) and is read there: no host copy of a device K and no cache keyed by
-    an address (a new frame's K may land on the old one's)."""
+    an address (a new frame's K may land on the old one's).  Several frames in one launch: depth (F,H,W), K (F,3,3),
+    frame (S) i32 = the frame of every mask."""
     _chk(masks, torch.float32, "masks", 3)
-    _chk(depth, torch.float32, "depth", 2)
     S, H, W = masks.shape
-    if tuple(K.shape) != (3, 3):
-        raise ValueError(f"K must be 3x3, got {tuple(K.shape)}")
+    if frame is None:
+        _chk(depth, torch.float32, "depth", 2)
+        if tuple(K.shape) != (3, 3):
+            raise ValueError(f"K must be 3x3, got {tuple(K.shape)}")
+    else:
+        _chk(depth, torch.float32, "depth", 3)
+        _chk(frame, torch.int32, "frame", 1)
+        if K.dim() != 3 or tuple(K.shape[1:]) != (3, 3) or K.shape[0] != depth.shape[0] or frame.shape[0] != S:
+            raise ValueError(f"batched call: depth (F,H,W), K (F,3,3), frame (S); got {tuple(depth.shape)}, {tuple(K.shape)}, {tuple(frame.shape)}")
     Kd = K.detach().to(device=masks.device, dtype=torch.float64).contiguous()
     out = torch.empty(S, 3, dtype=torch.float32, device=masks.device)
     fn = _lib.lib().s6d_masked_depth_mean_workspace_bytes
     fn.restype = ctypes.c_long
     ws = torch.empty(max(int(fn(S)), 8), dtype=torch.uint8, device=masks.device)
-    _call("s6d_masked_depth_mean_f32", _ptr(masks), _ptr(depth), S, H, W, ctypes.c_float(depth_scale), _ptr(Kd), _ptr(ws),
-          _ptr(out), _stream())
+    _call("s6d_masked_depth_mean_frames_f32", _ptr(masks), _ptr(depth), _ptr(frame) if frame is not None else _vp(0), S, H, W,
+          ctypes.c_float(depth_scale), _ptr(Kd), _ptr(ws), _ptr(out), _stream())
     return out
 
 
-def project_bbox(pointcloud, poses, obj, tmpl, trans, K, H, W):
-    """-> uv (S,N,2) i32, bbox (S,4) i32 = (min u, min v, max u, max v)."""
-    for a, nm, nd in ((pointcloud, "pointcloud", 3), (poses, "poses", 3), (trans, "trans", 2), (K, "K", 2)):
+def project_bbox(pointcloud, poses, obj, tmpl, trans, K, H, W, frame=None):
+    """-> uv (S,N,2) i32, bbox (S,4) i32 = (min u, min v, max u, max v).  K (3,3) f32, or (F,3,3) with frame (S) i32."""
+    for a, nm, nd in ((pointcloud, "pointcloud", 3), (poses, "poses", 3), (trans, "trans", 2), (K, "K", 2 if frame is None else 3)):
         _chk(a, torch.float32, nm, nd)
     _chk(obj, torch.int32, "obj", 1)
     _chk(tmpl, torch.int32, "tmpl", 1)
+    if frame is not None:
+        _chk(frame, torch.int32, "frame", 1)
     S, N = obj.shape[0], pointcloud.shape[1]
     uv = torch.empty(S, N, 2, dtype=torch.int32, device=trans.device)
     bbox = torch.empty(S, 4, dtype=torch.int32, device=trans.device)
-    _call("s6d_project_bbox_f32", _ptr(pointcloud), _ptr(poses), _ptr(obj), _ptr(tmpl), _ptr(trans), _ptr(K), S, N,
-          int(H), int(W), _ptr(uv), _ptr(bbox), _stream())
+    _call("s6d_project_bbox_frames_f32", _ptr(pointcloud), _ptr(poses), _ptr(obj), _ptr(tmpl), _ptr(trans), _ptr(K),
+          _ptr(frame) if frame is not None else _vp(0), S, N, int(H), int(W), _ptr(uv), _ptr(bbox), _stream())
     return uv, bbox
 
 

@@ -45,3 +45,7 @@ def test_masked_patch_similarity_methods_reach_the_kernel(emu):
 def test_half_descriptors_on_the_emulator(emu, monkeypatch):
     import torch
     T.test_half_descriptors_take_the_kernels(torch.bfloat16, monkeypatch)
+
+
+def test_batched_frames_on_the_emulator(emu):
+    T.test_batched_frames_equal_the_per_frame_loop()

@@ -140,3 +140,42 @@ def test_half_descriptors_take_the_kernels(dt, monkeypatch):
     want = oism.appearance_score(qp.float(), d["ref_patch"].to(dt).float(), d["gt_obj"], d["gt_tem"])[0]
     assert torch.allclose(appe.float().cpu(), want, atol=1e-2 if dt == torch.bfloat16 else 2e-3)       # output rounded to dt
     assert torch.allclose(ratio.float().cpu(), oism.visible_ratio(qp.float(), ref.float(), 0.5), atol=2e-2)
+
+
+def test_batched_frames_equal_the_per_frame_loop():
+    """FrameScorer.score_frames (F frames in one set of launches, per-mask frame index for the depth map / camera matrix, quirk
+    Q3 applied per frame) == FrameScorer.score frame by frame, bit for bit."""
+    from sam6d_amd.ism.scoring import FrameScorer
+    F_, P = 3, 24
+    frames = [synth.ism_inputs(P=P, O=2, T=6, C=128, n_patch=48, H=120, W=160, seed=20 + f) for f in range(F_)]
+    frames[2]["K"] = frames[2]["K"].clone()
+    frames[2]["K"][0, 0] *= 1.1                                          # a camera of its own
+    base = frames[0]
+    sc = FrameScorer(base["ref_cls"].cuda(), base["ref_patch"].cuda(), base["poses"].cuda(), base["pointcloud"].cuda(),
+                     confidence_thresh=0.1)
+    def one(fr):
+        return sc.score(fr["qry_cls"].cuda(), fr["qry_patch"].cuda(), fr["masks"].cuda(), fr["boxes"].cuda(), fr["depth"].cuda(), fr["K"])
+    # random boxes rarely all overlap their projections (quirk Q3 then zeroes the frame): give frames 0 and 2 boxes that do
+    for f in (0, 2):
+        r = one(frames[f])
+        uv = r["image_uv"].cpu().float()
+        bb = torch.cat((uv.min(1).values - 2, uv.max(1).values + 3), -1)
+        frames[f]["boxes"] = frames[f]["boxes"].clone()
+        frames[f]["boxes"][r["sel"].cpu()] = bb
+    # frame 1: a far scene (small projections) and one selected proposal whose box sits in a corner: an empty intersection,
+    # i.e. quirk Q3 zeroes the IoU of the whole frame
+    frames[1]["depth"] = frames[1]["depth"] * 20
+    r = one(frames[1])
+    frames[1]["boxes"] = frames[1]["boxes"].clone()
+    frames[1]["boxes"][r["sel"][0].item()] = torch.tensor([0.0, 0.0, 1.0, 1.0])
+    per = [one(fr) for fr in frames]
+    st = lambda k: torch.stack([fr[k] for fr in frames]).cuda()
+    out = sc.score_frames(st("qry_cls"), st("qry_patch"), st("masks"), st("boxes"), st("depth"), st("K"))
+    assert any(not torch.is_tensor(p_["iou"]) for p_ in per) and any(torch.is_tensor(p_["iou"]) for p_ in per)   # both Q3 branches
+    for f, ref in enumerate(per):
+        rows = out["frame"] == f
+        assert torch.equal(out["sel"][rows], ref["sel"])
+        for k in ("pred_obj", "semantic", "best_template", "appearance", "visible_ratio", "final", "image_uv"):
+            assert torch.equal(out[k][rows], ref[k]), (f, k)
+        iou = ref["iou"] if torch.is_tensor(ref["iou"]) else torch.zeros_like(ref["final"])
+        assert torch.equal(out["iou"][rows], iou)

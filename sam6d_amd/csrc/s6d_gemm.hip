@@ -83,6 +83,13 @@ typedef unsigned short u16;
 #ifndef S6D_GEMM_QT
 #define S6D_GEMM_QT 1
 #endif
+// Main loop.  S6D_GEMM_PH2 = 1: TWO phases per K tile (16-MFMA segments: half the workgroup barriers per MFMA; a phase's load segment
+// = 16 / 8 fragment reads + 4 LDS-DMA pieces against 512 cycles of the partner's matrix segment) instead of the four 8-MFMA phases of
+// the template (S6D_GEMM_PH2 = 0).  Measured in one process, two interleaved rounds (profiles/r02_gemm_variants_ph2.json): +3..4 % on
+// all four ViT-H shapes (qkv 1161 -> 1202, proj 1115 -> 1140, lin1 + GELU 1025 -> 1047, lin2 1247 -> 1285 TFLOP/s): the default.
+#ifndef S6D_GEMM_PH2
+#define S6D_GEMM_PH2 1
+#endif
 // Also tried and dropped: draining the ring (vmcnt(0)) before the stores so that no counted wait sits behind them for 7 phases --
 // the single vector-memory counter makes a counted wait behind 16 stores wait for their acknowledgement -- measured -8 % (the drain
 // itself exposes a load latency per tile and the store cost did not move: profiles/r02_gemm_variants_qt_drain.json).
@@ -379,6 +386,108 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
     S6D_SETPRIO(0);                                                                    \
   } while (0)
 
+  if (S6D_GEMM_PH2) {
+    // =============================== two phases per K tile ===============================
+    // stream order B0 B1 A0 A1 per K tile, element e in slot e % 10; K tile g: s0 = (4 g) % 10.
+    //   phase A(g): reads W rows (both n tiles) of B[wc >> 1](g) and activation rows 0..63 of A[wr](g); issues B0, B1 of K tile g + 2
+    //               into the slots A(g - 1) left one phase ago; 16 MFMAs: m tiles 0, 1 x n tiles 0, 1
+    //   phase B(g): reads activation rows 64..127; issues A0, A1 of K tile g + 2 into the slots B(g) left one phase ago; counted wait
+    //               "K tile g + 1 has landed" (the 4 half-tiles of K tile g + 2 stay in flight); 16 MFMAs: m tiles 2, 3
+    // A slot is restaged one phase after its last fragment read; that is safe because every load segment ends with lgkmcnt(0)
+    // BEFORE its barrier (the reads are retired when the other wave group, one barrier apart, starts issuing into the slot), and
+    // a landed K tile is read one phase (two barriers) after the wait that retired it.
+#define S6D_MSEG2(QM)                                                                  \
+  do {                                                                                 \
+    S6D_SETPRIO(1);                                                                    \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) S6D_PIN(wf[nt][ks]); \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                 \
+      S6D_MFMA(acc[2 * QM][0], wf[0][ks], xf[0][ks]);                                  \
+      S6D_MFMA(acc[2 * QM + 1][0], wf[0][ks], xf[1][ks]);                              \
+      S6D_MFMA(acc[2 * QM][1], wf[1][ks], xf[0][ks]);                                  \
+      S6D_MFMA(acc[2 * QM + 1][1], wf[1][ks], xf[1][ks]);                              \
+    }                                                                                  \
+    S6D_PIN(acc[2 * QM][0]);                                                           \
+    S6D_PIN(acc[2 * QM + 1][0]);                                                       \
+    S6D_PIN(acc[2 * QM][1]);                                                           \
+    S6D_PIN(acc[2 * QM + 1][1]);                                                       \
+    S6D_SETPRIO(0);                                                                    \
+  } while (0)
+#ifdef HIPEMU
+#define S6D_LGKM0()
+#else
+#define S6D_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
+    set_b(0);
+    set_a(0);
+    issue_b(0, 0);
+    issue_b(1, 1);
+    issue_a(0, 2);
+    issue_a(1, 3);
+    if (G > 1) {
+      issue_b(0, 4);
+      issue_b(1, 5);
+      issue_a(0, 6);
+      issue_a(1, 7);
+      S6D_VMCNT(8);                                                      // K tile 0 has landed, K tile 1 in flight
+    } else {
+      S6D_VMCNT(0);
+    }
+    init_acc(cn0);
+    S6D_BARRIER();
+    if (wr == 1) S6D_BARRIER();                                          // the M halves run one barrier apart from here on
+    int s0 = 0;
+    for (int g = 0; g < G; ++g) {
+      const int sA = ring(s0 + 2 + wr), sB = s0 + (wc >> 1);
+      const bool more2 = g + 2 < G;
+      // ---- phase A
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wf[nt][ks] = wfrag(sB, nt, ks);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) xf[i][ks] = frag(sA, (unsigned)(i * 4096), ks);
+      if (more2) {
+        issue_b(0, ring(s0 + 8));                                        // B0, B1 of K tile g + 2 -> slots of A0, A1 (g - 1)
+        issue_b(1, ring(s0 + 9));
+      }
+      S6D_LGKM0();
+      S6D_BARRIER();
+      S6D_MSEG2(0);
+      S6D_BARRIER();
+      // ---- phase B
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) xf[i][ks] = frag(sA, (unsigned)((2 + i) * 4096), ks);
+      if (more2) {
+        issue_a(0, s0);                                                  // A0, A1 of K tile g + 2 -> slots of B0, B1 (g)
+        issue_a(1, s0 + 1);
+        S6D_VMCNT(8);                                                    // K tile g + 1 has landed (K tile g + 2: 4 half-tiles in flight)
+      } else {
+        S6D_VMCNT(0);
+      }
+      S6D_LGKM0();
+      S6D_BARRIER();
+      S6D_MSEG2(1);
+      S6D_BARRIER();
+      s0 = ring(s0 + 4);
+      if (++ck == p.nk) {
+        ck = 0;
+        if (wr == 0) S6D_BARRIER();
+        epilogue(cm0, cn0);
+        if (++ct < my_tiles) {
+          tile_mn(ct, cm0, cn0);
+          init_acc(cn0);
+        }
+        if (wr == 1) S6D_BARRIER();
+      }
+    }
+    if (wr == 0) S6D_BARRIER();
+#undef S6D_MSEG2
+    return;
+  }
   // ---- prologue: half-tiles 0..6 of the stream (K tile 0 whole; B0 B1 A0 of K tile 1)
   set_b(0);
   set_a(0);

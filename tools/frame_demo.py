@@ -77,9 +77,21 @@ def measure(dev, n_frames=8, points_per_batch=1024, top_k=10):
         det, poses = pipe(*args)
     torch.cuda.synchronize()
     free_ms = (time.perf_counter() - t) * 1e3 / n_frames
+    # (c) frames issued round-robin on several HIP streams: the launch-bound stages of different frames overlap on the device
+    # (the host thread still issues every launch and blocks on the chain's few device->host reads)
+    nstream = 4
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nstream)]
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for i in range(2 * n_frames):
+        with torch.cuda.stream(streams[i % nstream]):
+            pipe(*args)
+    torch.cuda.synchronize()
+    multi_ms = (time.perf_counter() - t) * 1e3 / (2 * n_frames)
     return {"workload": f"one 640x480 RGB-D frame through SAM ViT-H encoder + 1024-prompt mask decoding + DINOv2 ViT-L/14 descriptors of "
                         f"P=128 proposals + ISM scoring + PEM pre-processing + PEM for K={top_k} instances (SURVEY 8d frame definition)",
-            "frames_per_s": round(1e3 / free_ms, 2), "ms_per_frame": round(free_ms, 2),
+            "frames_per_s": round(1e3 / min(free_ms, multi_ms), 2), "ms_per_frame": round(free_ms, 2),
+            "ms_per_frame_on_4_streams": round(multi_ms, 2),
             "ms_per_frame_stage_synchronised": round(sync_ms, 2), "stages_ms": stages,
             "detections": int(det.masks.shape[0]), "poses": 0 if poses is None else int(poses["pred_R"].shape[0])}
 

@@ -57,6 +57,18 @@ def main():
     flop = 2.0 * M * N * K
     arm("s6d_gemm_bf16", lambda: ops.gemm_bf16(a, w, b, out=out), flop)
     arm("hipBLASLt", lambda: torch.nn.functional.linear(a, w, bb), flop)
+    # profiling variants (tools/gemm_variants.sh): which part of the kernel the power goes to
+    import ctypes
+    import glob
+    vp = ctypes.c_void_p
+    for path in sorted(glob.glob(os.path.join(ROOT, "tools", "gemm_variants", "libgemm_*.so"))):
+        Lv = ctypes.CDLL(path)
+
+        def call(Lv=Lv):
+            rc = Lv.s6d_gemm_bf16(vp(a.data_ptr()), ctypes.c_long(a.stride(0)), vp(w.data_ptr()), ctypes.c_long(w.stride(0)), vp(b.data_ptr()),
+                                  vp(out.data_ptr()), ctypes.c_long(out.stride(0)), M, N, K, 0, 0, vp(torch.cuda.current_stream().cuda_stream))
+            assert rc == 0
+        arm("variant " + os.path.basename(path)[8:-3], call, flop, 2.5)
     time.sleep(2)
     arm("idle-ish (1 launch / 10 ms)", lambda: (ops.gemm_bf16(a[:256], w, b), time.sleep(0.01)), 2.0 * 256 * N * K, 2.0)
 

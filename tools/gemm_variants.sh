@@ -8,9 +8,10 @@ mkdir -p $OUT
 FLAGS="-O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form -Wno-unused-function"
 build() { /opt/rocm/bin/hipcc $FLAGS $2 -o $OUT/libgemm_$1.so sam6d_amd/csrc/s6d_gemm.hip sam6d_amd/csrc/s6d_capi.hip & }
 build base ""
-build ph2 "-DS6D_GEMM_PH2=1"
-build ph2noprio "-DS6D_GEMM_PH2=1 -DS6D_GEMM_NOPRIO"
-build nostore "-DS6D_GEMM_ABLATE=4"
-build ph2nostore "-DS6D_GEMM_PH2=1 -DS6D_GEMM_ABLATE=4"
+build nomfma "-DS6D_GEMM_ABLATE=2"
+build lds_stores "-DS6D_GEMM_ABLATE=3"
+build dma_lds "-DS6D_GEMM_ABLATE=6"
+build ldsonly "-DS6D_GEMM_ABLATE=7"
+build mfmaonly "-DS6D_GEMM_ABLATE=5"
 wait
 ls -la $OUT

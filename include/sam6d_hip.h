@@ -174,6 +174,11 @@ int s6d_rpe_attention_f32(const float *q, const float *k, const float *v, const 
 int s6d_win_attention_bf16(const void *qkv, const void *qkv_bias, const void *rel_h, const void *rel_w, int B,
                            int H, int W, int num_heads, int head_dim, int window, float scale, void *rel_scratch,
                            void *out, void *stream);
+/* The same attention on a head-major q/k/v tensor (head_major = 1: qkv is (3, num_heads, B*H*W, head_dim), the column-block output of
+ * s6d_gemm_bf16_cblk; head_major = 0: the raw Linear output (B,H,W,3,num_heads,head_dim) as above). */
+int s6d_win_attention_layout_bf16(const void *qkv, int head_major, const void *qkv_bias, const void *rel_h, const void *rel_w,
+                                  int B, int H, int W, int num_heads, int head_dim, int window, float scale,
+                                  void *rel_scratch, void *out, void *stream);
 /* bytes of `rel_scratch` (zero-padded copies of the two tables; may be NULL when rel_h == NULL) */
 long s6d_win_attention_scratch_bytes(int H, int window, int head_dim);
 
@@ -193,6 +198,11 @@ int s6d_add_layernorm_bf16(const void *x, const void *delta, const float *gamma,
  * and DINOv2 ViT-L (Instance_Segmentation_Model/model/layers/{attention,mlp}.py). */
 int s6d_gemm_bf16(const void *A, long lda, const void *W, long ldw, const float *bias, void *C, long ldc, int M, int N,
                   int K, int epilogue, int max_blocks, void *stream);
+/* The same product with the output in COLUMN BLOCKS: block j (columns [j col_block, (j+1) col_block)) is a contiguous (M, col_block)
+ * matrix at C + j * M * col_block (ldc unused).  col_block % 8 == 0, N % col_block == 0, N % 256 == 0.  The qkv projection of a ViT
+ * block writes q / k / v head-major this way (col_block = head_dim) for s6d_win_attention_layout_bf16(head_major = 1). */
+int s6d_gemm_bf16_cblk(const void *A, long lda, const void *W, long ldw, const float *bias, void *C, long ldc, int M, int N, int K,
+                       int epilogue, int col_block, int max_blocks, void *stream);
 
 /* ---------------------------------------------------------------- ISM proposal-vs-template scoring */
 

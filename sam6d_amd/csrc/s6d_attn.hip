@@ -48,7 +48,16 @@ struct AttnParams {
   int LT;              // padded table length (multiple of 16, >= 2S-1)
   unsigned magicS;     // ceil(2^32 / S): n / S == umulhi(n, magicS) for n < 2^32 / S
   float scale_log2;    // softmax scale * log2(e): scores live in the exp2 domain
+  // q/k/v element (token, which, head, d) sits at qkv + token * tok_stride + which * which_stride + head * head_stride + d.
+  //   token-major (the raw Linear output (B,H,W,3,nh,HD)): tok_stride = 3 nh HD, which_stride = nh HD, head_stride = HD
+  //   head-major  ((3, nh, B H W, HD), written by the qkv GEMM's column-block epilogue): tok_stride = HD, head_stride = B H W HD,
+  //               which_stride = nh B H W HD -- a head's rows of one window row / key tile are contiguous whole lines
+  long tok_stride, which_stride, head_stride;
 };
+
+__device__ __forceinline__ const u16 *qkv_at(const AttnParams &p, size_t tok, int which, int head) {
+  return p.qkv + tok * (size_t)p.tok_stride + (size_t)which * (size_t)p.which_stride + (size_t)head * (size_t)p.head_stride;
+}
 
 // Ablation switches for profiling are COMPILE-time (-DS6D_ATTN_ABLATE=mask through S6D_EXTRA_HIPCC_FLAGS): 1 = no K/V
 // loads, 2 = no tile math, 4 = no softmax arithmetic, 8 = no PV, 16 = no QK^T.  As run-time branches they cut the
@@ -100,7 +109,7 @@ template <int HD>
 __device__ __forceinline__ uint4 load_chunk(const AttnParams &p, int which, int head, bool valid, size_t tok, int d0) {
   const int C = p.nh * HD;
   const int dc = d0 < HD ? d0 : HD - 8;
-  const u16 *a = p.qkv + tok * (size_t)(3 * C) + (size_t)which * C + head * HD + dc;
+  const u16 *a = qkv_at(p, tok, which, head) + dc;
   const u16 *bsrc = p.qkv_bias + (size_t)which * C + head * HD + dc;
   const uint4 v = *reinterpret_cast<const uint4 *>(valid ? a : bsrc);
   return d0 < HD ? v : make_uint4(0, 0, 0, 0);
@@ -299,20 +308,19 @@ struct StagerLinear {
   static_assert(Cfg<HD>::KROW - Cfg<HD>::HDP == 8, "K rows end in a 16-byte pad");
 
   __device__ __forceinline__ void init(const AttnParams &p, int b, int head, int tid) {
-    const int Cc = p.nh * HD;
 #pragma unroll
     for (int n = 0; n < NK; ++n) {
       const int i = tid + n * THREADS, ic = min(i, 64 * C::KPARTS - 1);
       const int key = ic / C::KPARTS, part = ic - key * C::KPARTS;
       kz[n] = part * 8 >= HD;
-      kp[n] = p.qkv + ((size_t)b * p.T + key) * (size_t)(3 * Cc) + Cc + head * HD + (kz[n] ? HD - 8 : part * 8);
+      kp[n] = qkv_at(p, (size_t)b * p.T + key, 1, head) + (kz[n] ? HD - 8 : part * 8);
       ko[n] = i < 64 * C::KPARTS ? key * C::KROW + part * 8 : (tid & 63) * C::KROW + C::HDP;
     }
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
       const int i = tid + n * THREADS, ic = min(i, 64 * C::VPARTS - 1);
       const int key = ic / C::VPARTS, part = ic - key * C::VPARTS;
-      vp[n] = p.qkv + ((size_t)b * p.T + key) * (size_t)(3 * Cc) + 2 * Cc + head * HD + part * 8;
+      vp[n] = qkv_at(p, (size_t)b * p.T + key, 2, head) + part * 8;
       vo[n] = i < 64 * C::VPARTS ? 64 * C::KROW + key * C::VROW + part * 8 : (tid & 63) * C::KROW + C::HDP;
     }
   }
@@ -720,7 +728,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
       const int d0 = ks * 32 + g * 8;
       const int dc = d0 < HD ? d0 : HD - 8;
       const size_t tokc = (size_t)(b * p.H + min(y, p.H - 1)) * p.W + min(x, p.W - 1);
-      const u16 *src = qimg ? p.qkv + tokc * (size_t)(3 * Cc) + head * HD + dc : p.qkv_bias + head * HD + dc;
+      const u16 *src = qimg ? qkv_at(p, tokc, 0, head) + dc : p.qkv_bias + head * HD + dc;
       t.u = *reinterpret_cast<const uint4 *>(src);
       if (!(qwin && d0 < HD)) t.u = make_uint4(0, 0, 0, 0);
       qfa[i][ks] = t.v;
@@ -751,7 +759,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window16_kernel(AttnParams p)
       const int dc = part * 8 < HD ? part * 8 : HD - 8;
       const size_t tokc = (size_t)(b * p.H + min(y, p.H - 1)) * p.W + min(x, p.W - 1);
       const int sel = (isv ? 2 : 1) * Cc + head * HD + dc;
-      const u16 *src = img ? p.qkv + tokc * (size_t)(3 * Cc) + sel : p.qkv_bias + sel;
+      const u16 *src = img ? qkv_at(p, tokc, isv ? 2 : 1, head) + dc : p.qkv_bias + sel;
       sv[n] = *reinterpret_cast<const uint4 *>(src);
       if (!(ky < S && kx < S && part * 8 < HD)) sv[n] = make_uint4(0, 0, 0, 0);
     }
@@ -862,7 +870,7 @@ __global__ __launch_bounds__(512) void attn_window16p_kernel(AttnParams p, int n
       const bool inwin = ky < S && kx < S && part * 8 < HD, img = (y < p.H) && (x < p.W);
       const size_t tokc = (size_t)(it.b * p.H + min(y, p.H - 1)) * p.W + min(x, p.W - 1);
       const int sel = which * Cc + it.head * HD + min(part * 8, HD - 8);
-      const u16 *src = img ? p.qkv + tokc * (size_t)(3 * Cc) + sel : p.qkv_bias + sel;
+      const u16 *src = img ? qkv_at(p, tokc, which, it.head) + min(part * 8, HD - 8) : p.qkv_bias + sel;
       const void *sp = inwin ? (const void *)src : (const void *)&g_win16_zero;
       S6D_LDS(char) *dst = (S6D_LDS(char) *)dst_base + (k << 10);
       __builtin_amdgcn_global_load_lds((const S6D_ATTN_GLOBAL(void) *)sp, dst, 16, 0, 0);
@@ -882,7 +890,7 @@ __global__ __launch_bounds__(512) void attn_window16p_kernel(AttnParams p, int n
         const int d0 = ks * 32 + g * 8;
         const int dc = d0 < HD ? d0 : HD - 8;
         const size_t tokc = (size_t)(it.b * p.H + min(y, p.H - 1)) * p.W + min(x, p.W - 1);
-        const u16 *src = qimg ? p.qkv + tokc * (size_t)(3 * Cc) + it.head * HD + dc : p.qkv_bias + it.head * HD + dc;
+        const u16 *src = qimg ? qkv_at(p, tokc, 0, it.head) + dc : p.qkv_bias + it.head * HD + dc;
         t.u = *reinterpret_cast<const uint4 *>(src);
         if (!(qwin && d0 < HD)) t.u = make_uint4(0, 0, 0, 0);
         qfa[i][ks] = t.v;
@@ -1023,7 +1031,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_global_kernel(AttnParams p) {
   const int ntile = p.T / 64;                       // launcher guarantees T % 64 == 0 for this kernel
   StagerLinear<HD, WAVES * 64> sg;
   sg.init(p, b, head, tid);
-  const size_t tstride = (size_t)64 * 3 * p.nh * HD;
+  const size_t tstride = (size_t)64 * (size_t)p.tok_stride;
   sg.load(tstride, 0);
   __syncthreads();                                  // table scratch (aliasing the ring) fully consumed
   sg.store(Kbuf(0));
@@ -1131,9 +1139,20 @@ extern "C" long s6d_win_attention_scratch_bytes(int H, int window, int head_dim)
   return 2L * (LT + 16) * HDP * 2;
 }
 
+extern "C" int s6d_win_attention_layout_bf16(const void *qkv, int head_major, const void *qkv_bias, const void *rel_h, const void *rel_w,
+                                             int B, int H, int W, int num_heads, int head_dim, int window, float scale,
+                                             void *rel_scratch, void *out, void *stream);
+
 extern "C" int s6d_win_attention_bf16(const void *qkv, const void *qkv_bias, const void *rel_h, const void *rel_w,
                                       int B, int H, int W, int num_heads, int head_dim, int window, float scale,
                                       void *rel_scratch, void *out, void *stream) {
+  return s6d_win_attention_layout_bf16(qkv, 0, qkv_bias, rel_h, rel_w, B, H, W, num_heads, head_dim, window, scale, rel_scratch, out,
+                                       stream);
+}
+
+extern "C" int s6d_win_attention_layout_bf16(const void *qkv, int head_major, const void *qkv_bias, const void *rel_h, const void *rel_w,
+                                             int B, int H, int W, int num_heads, int head_dim, int window, float scale,
+                                             void *rel_scratch, void *out, void *stream) {
   if (B < 0 || H <= 0 || W <= 0 || num_heads <= 0 || window < 0) return S6D_EINVAL;
   if (B == 0) return S6D_OK;
   if (!qkv || !qkv_bias || !out || ((rel_h == nullptr) != (rel_w == nullptr))) return S6D_EINVAL;
@@ -1149,6 +1168,12 @@ extern "C" int s6d_win_attention_bf16(const void *qkv, const void *qkv_bias, con
   p.LT = ((2 * p.S - 1) + 15) / 16 * 16;
   p.magicS = (unsigned)(((1ull << 32) + (unsigned)p.S - 1) / (unsigned)p.S);
   p.scale_log2 = scale * kLog2e;
+  if (head_major) {                              // (3, nh, B H W, hd): the qkv GEMM's column-block output
+    const long plane = (long)B * H * W * head_dim;
+    p.tok_stride = head_dim; p.head_stride = plane; p.which_stride = (long)num_heads * plane;
+  } else {                                       // (B, H, W, 3, nh, hd): the raw Linear output
+    p.tok_stride = 3L * num_heads * head_dim; p.which_stride = (long)num_heads * head_dim; p.head_stride = head_dim;
+  }
   hipStream_t st = as_stream(stream);
   if (rel_h) {                                   // zero-padded table copies: unconditional loads in the kernels
     if (!rel_scratch) return S6D_EINVAL;
@@ -1178,6 +1203,7 @@ extern "C" int s6d_seq_attention_bf16(const void *qkv, int B, int N, int num_hea
   p.S = N; p.T = N; p.nwx = 1; p.nwy = 1; p.LT = 16;
   p.magicS = (unsigned)(((1ull << 32) + (unsigned)N - 1) / (unsigned)N);
   p.scale_log2 = scale * kLog2e;
+  p.tok_stride = 3L * num_heads * head_dim; p.which_stride = (long)num_heads * head_dim; p.head_stride = head_dim;
   hipStream_t st = as_stream(stream);
   switch (head_dim) {
     case 80: return launch_attn<80>(p, st);

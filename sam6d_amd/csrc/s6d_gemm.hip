@@ -104,6 +104,9 @@ struct GemmParams {
   int M, N, K;
   int MT, NT, nk, ntiles;
   int GM;             // m-tiles per group of the tile order
+  int cblk;           // 0: C is (M, N) with row stride ldc.  > 0 (multiple of 8): column blocks of this width are stored as
+                      // separate (M, cblk) matrices one after the other -- element (m, n) at C + (n / cblk) M cblk + m cblk + n % cblk
+                      // (the qkv projection writes q / k / v head-major for the attention kernels: every head's rows contiguous)
 };
 
 constexpr int kSlot = 16384;  // one half-tile: 128 rows x 64 k bf16
@@ -347,7 +350,14 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
         asm volatile("" ::"v"(X[y][0]), "v"(X[y][1]), "v"(X[y][2]), "v"(X[y][3]));
 #endif
       } else if (mq + y < p.M) {
-        *reinterpret_cast<uint4 *>(p.C + (size_t)(mq + y) * p.ldc + col) = make_uint4(X[y][0], X[y][1], X[y][2], X[y][3]);
+        u16 *dst;
+        if (p.cblk > 0) {
+          const int blk = col / p.cblk;
+          dst = p.C + ((size_t)blk * p.M + (size_t)(mq + y)) * p.cblk + (col - blk * p.cblk);
+        } else {
+          dst = p.C + (size_t)(mq + y) * p.ldc + col;
+        }
+        *reinterpret_cast<uint4 *>(dst) = make_uint4(X[y][0], X[y][1], X[y][2], X[y][3]);
       }
     }
   };
@@ -812,16 +822,26 @@ static int gemm_impl() {
   return impl;
 }
 
+extern "C" int s6d_gemm_bf16_cblk(const void *A, long lda, const void *W, long ldw, const float *bias, void *C, long ldc, int M,
+                                  int N, int K, int epilogue, int col_block, int max_blocks, void *stream);
+
 extern "C" int s6d_gemm_bf16(const void *A, long lda, const void *W, long ldw, const float *bias, void *C, long ldc, int M,
                              int N, int K, int epilogue, int max_blocks, void *stream) {
+  return s6d_gemm_bf16_cblk(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, 0, max_blocks, stream);
+}
+
+extern "C" int s6d_gemm_bf16_cblk(const void *A, long lda, const void *W, long ldw, const float *bias, void *C, long ldc, int M,
+                                  int N, int K, int epilogue, int col_block, int max_blocks, void *stream) {
   if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return S6D_EINVAL;
+  if (col_block < 0 || (col_block % 8) != 0 || (col_block > 0 && N % col_block != 0)) return S6D_EINVAL;
+  if (col_block > 0 && (N % 256 != 0 || !S6D_GEMM_QT)) return S6D_EUNSUPPORTED;   // the quad-transposed epilogue of the 256 x 256 kernel
   if (N % 128 != 0 || K % 64 != 0 || lda < K || ldw < K || ldc < N) return S6D_EINVAL;
   if ((lda % 8) || (ldw % 8) || (ldc % 8)) return S6D_EINVAL;           // 16-byte rows
   if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) return S6D_EINVAL;
   if (epilogue != 0 && epilogue != 1) return S6D_EINVAL;
   // staging addresses are 32-bit byte offsets from A / W
   if ((double)M * (double)lda * 2.0 >= 2147483648.0 || (double)N * (double)ldw * 2.0 >= 2147483648.0) return S6D_EUNSUPPORTED;
-  const int impl = (N % 256 != 0) ? 2 : gemm_impl();
+  const int impl = (N % 256 != 0) ? 2 : (col_block > 0 ? 1 : gemm_impl());
   GemmParams p;
   p.A = (const u16 *)A;
   p.W = (const u16 *)W;
@@ -839,6 +859,7 @@ extern "C" int s6d_gemm_bf16(const void *A, long lda, const void *W, long ldw, c
   p.ntiles = p.MT * p.NT;
   const char *gm_env = getenv("S6D_GEMM_GM");                            // tile-order experiment knob
   p.GM = (gm_env && atoi(gm_env) > 0) ? atoi(gm_env) : 8;
+  p.cblk = col_block;
   hipStream_t st = as_stream(stream);
   if (impl == 2) {
     if (max_blocks <= 0) max_blocks = 512;                               // two persistent workgroups per CU

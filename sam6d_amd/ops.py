@@ -426,13 +426,22 @@ def upsample_gather(up, choose, H, W, C):
 
 
 # ------------------------------------------------------------------ SAM image encoder
-def window_attention(qkv, qkv_bias, rel_h, rel_w, num_heads, window, scale):
-    """qkv (B,H,W,3C) bf16, qkv_bias (3C) bf16, rel_h/rel_w (2S-1,hd) bf16 or None -> (B,H,W,C) bf16."""
-    _chk(qkv, torch.bfloat16, "qkv", 4)
+def window_attention(qkv, qkv_bias, rel_h, rel_w, num_heads, window, scale, head_major_shape=None):
+    """qkv (B,H,W,3C) bf16, qkv_bias (3C) bf16, rel_h/rel_w (2S-1,hd) bf16 or None -> (B,H,W,C) bf16.
+    head_major_shape=(B,H,W): qkv is the head-major tensor (3*num_heads, B*H*W, hd) that gemm_bf16(..., col_block=hd) writes."""
     _chk(qkv_bias, torch.bfloat16, "qkv_bias", 1)
-    B, H, W, C3 = qkv.shape
-    C = C3 // 3
-    hd = C // num_heads
+    if head_major_shape is None:
+        _chk(qkv, torch.bfloat16, "qkv", 4)
+        B, H, W, C3 = qkv.shape
+        C = C3 // 3
+        hd = C // num_heads
+    else:
+        _chk(qkv, torch.bfloat16, "qkv", 3)
+        B, H, W = head_major_shape
+        hd = qkv.shape[2]
+        C = num_heads * hd
+        if tuple(qkv.shape) != (3 * num_heads, B * H * W, hd):
+            raise RuntimeError(f"head-major qkv must be (3*heads, B*H*W, hd); got {tuple(qkv.shape)} for B,H,W={head_major_shape}")
     if rel_h is not None:
         _chk(rel_h, torch.bfloat16, "rel_h", 2)
         _chk(rel_w, torch.bfloat16, "rel_w", 2)
@@ -445,9 +454,9 @@ def window_attention(qkv, qkv_bias, rel_h, rel_w, num_heads, window, scale):
         fn = _lib.lib().s6d_win_attention_scratch_bytes
         fn.restype = ctypes.c_long
         scratch = torch.empty(int(fn(H, int(window), int(hd))), dtype=torch.uint8, device=qkv.device)
-    _call("s6d_win_attention_bf16", _ptr(qkv), _ptr(qkv_bias), _ptr(rel_h) if rel_h is not None else _vp(0),
-          _ptr(rel_w) if rel_w is not None else _vp(0), B, H, W, int(num_heads), int(hd), int(window),
-          ctypes.c_float(scale), _ptr(scratch) if scratch is not None else _vp(0), _ptr(out), _stream())
+    _call("s6d_win_attention_layout_bf16", _ptr(qkv), 0 if head_major_shape is None else 1, _ptr(qkv_bias),
+          _ptr(rel_h) if rel_h is not None else _vp(0), _ptr(rel_w) if rel_w is not None else _vp(0), B, H, W, int(num_heads), int(hd),
+          int(window), ctypes.c_float(scale), _ptr(scratch) if scratch is not None else _vp(0), _ptr(out), _stream())
     return out
 
 
@@ -462,9 +471,10 @@ def seq_attention(qkv, num_heads, scale):
     return out
 
 
-def gemm_bf16(a, w, bias=None, gelu=False, out=None, max_blocks=0):
+def gemm_bf16(a, w, bias=None, gelu=False, out=None, max_blocks=0, col_block=0):
     """a (..., K) bf16 (rows may be strided), w (N, K) bf16 = nn.Linear.weight, bias (N) f32 or None ->
-    act(a @ w.T + bias) (..., N) bf16 with act = exact GELU or identity; N % 128 == 0, K % 64 == 0."""
+    act(a @ w.T + bias) (..., N) bf16 with act = exact GELU or identity; N % 128 == 0, K % 64 == 0.
+    col_block > 0: the output comes back as (N / col_block, M, col_block) -- column blocks as separate matrices (N % 256 == 0)."""
     if not a.is_cuda or not w.is_cuda:
         raise RuntimeError("a and w must be CUDA tensors")
     if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
@@ -479,6 +489,14 @@ def gemm_bf16(a, w, bias=None, gelu=False, out=None, max_blocks=0):
     if bias is not None:
         _chk(bias, torch.float32, "bias", 1)
     M = a2.shape[0]
+    if col_block:
+        if out is not None:
+            raise RuntimeError("col_block output is allocated by the call")
+        out = torch.empty(N // col_block, M, col_block, dtype=torch.bfloat16, device=a.device)
+        _call("s6d_gemm_bf16_cblk", _ptr(a2), ctypes.c_long(a2.stride(0)), _ptr(w), ctypes.c_long(w.stride(0)),
+              _ptr(bias) if bias is not None else _vp(0), _ptr(out), ctypes.c_long(N), M, N, K, 1 if gelu else 0, int(col_block),
+              int(max_blocks), _stream())
+        return out
     if out is None:
         out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
     else:

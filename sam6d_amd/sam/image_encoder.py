@@ -106,8 +106,19 @@ class Attention(nn.Module):
     def forward(self, x, window_size=0):
         """x: (B,H,W,C) token map (already normed).  window_size 0 = global attention."""
         B, H, W, C = x.shape
+        fused = ops.have("win_attention") and x.is_cuda and x.dtype == torch.bfloat16 and self.use_rel_pos
+        if fused:
+            # q / k / v head-major straight out of the GEMM's epilogue ((3 heads, B H W, hd): a head's rows of a window row or of a
+            # key tile are contiguous whole lines for the attention kernels' fetches); S6D_QKV_LAYOUT=token keeps the Linear layout
+            hm = fused_linear(self.qkv, x, col_block=C // self.num_heads)
+            if hm is not None:
+                S = window_size if window_size > 0 else H
+                out = ops.window_attention(hm, self.qkv.bias.to(hm.dtype), _rel_table(S, self.rel_pos_h).to(hm.dtype).contiguous(),
+                                           _rel_table(S, self.rel_pos_w).to(hm.dtype).contiguous(), self.num_heads, window_size,
+                                           self.scale, head_major_shape=(B, H, W))
+                return fused_linear(self.proj, out)
         qkv = fused_linear(self.qkv, x)                              # (B,H,W,3C): real tokens only
-        if ops.have("win_attention") and x.is_cuda and x.dtype == torch.bfloat16 and self.use_rel_pos:
+        if fused:
             S = window_size if window_size > 0 else H
             out = ops.window_attention(qkv.contiguous(), self.qkv.bias.to(qkv.dtype),
                                        _rel_table(S, self.rel_pos_h).to(qkv.dtype).contiguous(),

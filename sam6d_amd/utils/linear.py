@@ -4,6 +4,8 @@ The modules keep their nn.Linear parameters (state_dict surface of the reference
 how the statement  act(x @ W^T + b)  is executed: on a device bf16 activation with N % 128 == 0 and K % 64 == 0 it is one
 launch of s6d_gemm_bf16 (bias and GELU in the epilogue), otherwise the library statement.  `S6D_DISABLE_FUSED=gemm_bf16`
 turns the kernel off (A/B runs)."""
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -27,10 +29,17 @@ def eligible(x, n_out, k_in):
     return (x.is_cuda and x.dtype == torch.bfloat16 and n_out % 128 == 0 and k_in % 64 == 0 and ops.have("gemm_bf16"))
 
 
-def fused_linear(lin, x, gelu=False, weight2d=None):
-    """act(lin(x)); `weight2d` overrides lin.weight for conv weights viewed as (N, K)."""
+def fused_linear(lin, x, gelu=False, weight2d=None, col_block=0):
+    """act(lin(x)); `weight2d` overrides lin.weight for conv weights viewed as (N, K).  col_block > 0 (kernel path only, N % 256
+    == 0): the result comes back as (N / col_block, M, col_block) -- the head-major q/k/v layout of the attention kernels -- or None
+    when the kernel path does not apply (the caller then takes the plain form)."""
     w = lin.weight if weight2d is None else weight2d
     N, K = w.shape
+    if col_block:
+        if eligible(x, N, K) and N % 256 == 0 and os.environ.get("S6D_QKV_LAYOUT", "head") == "head":
+            wb, bf = _cached(lin, w)
+            return ops.gemm_bf16(x, wb, bf, gelu=gelu, col_block=col_block)
+        return None
     if eligible(x, N, K):
         wb, bf = _cached(lin, w)
         return ops.gemm_bf16(x, wb, bf, gelu=gelu)

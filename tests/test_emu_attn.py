@@ -12,6 +12,11 @@ def test_fused_attention_on_the_emulator(emu, B, H, nh, hd, ws):
     T.test_fused_attention_vs_oracle(B, H, nh, hd, ws)
 
 
+@pytest.mark.parametrize("B,H,nh,hd,ws", [(1, 28, 2, 80, 14), (1, 16, 1, 64, 0), (1, 14, 2, 64, 7)])
+def test_head_major_layout_on_the_emulator(emu, B, H, nh, hd, ws):
+    T.test_head_major_layout_equals_token_major(B, H, nh, hd, ws)
+
+
 @pytest.mark.parametrize("grid", [8, 3])
 def test_persistent_window_kernel_walks_several_items(emu, monkeypatch, grid):
     """attn_window16p_kernel with fewer workgroups than items (S6D_WIN16_GRID): the LDS-DMA prefetch of the next item's K / V

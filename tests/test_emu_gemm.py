@@ -78,3 +78,29 @@ def test_gemm_on_the_emulator(case, mode, impl):
                         f"from tests import test_emu_gemm as t; t._run_case({case})"], env=env, capture_output=True,
                        text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def _run_cblk():
+    from tests import hipemu  # noqa: F401
+    import ctypes
+
+    from sam6d_amd import _lib, ops
+    from tests import test_gpu_gemm as T
+    L = ctypes.CDLL(hipemu.build())
+    L.s6d_strerror.restype = ctypes.c_char_p
+    L.s6d_strerror.argtypes = [ctypes.c_int]
+    L.s6d_last_hip_error.restype = ctypes.c_char_p
+    _lib._lib = L
+    ops._stream = lambda: ctypes.c_void_p(0)
+    torch.Tensor.is_cuda = property(lambda self: True)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    T.test_column_block_output_equals_the_plain_product(700, 768, 192, 64)
+    T.test_column_block_output_equals_the_plain_product(300, 256, 64, 32)
+
+
+def test_column_block_output_on_the_emulator():
+    """s6d_gemm_bf16_cblk (head-major q/k/v out of the qkv GEMM) through the quad-transposed epilogue, ragged M included."""
+    r = subprocess.run([sys.executable, "-c", f"import sys; sys.path.insert(0, {ROOT!r}); "
+                        f"from tests import test_emu_gemm as t; t._run_cblk()"], env=dict(os.environ, HIPEMU_GLDS="late"),
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

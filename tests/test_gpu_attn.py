@@ -32,6 +32,18 @@ def test_fused_attention_vs_oracle(B, H, nh, hd, ws):
     assert err.max() < 3e-2 and err.mean() < 3e-3, (err.max().item(), err.mean().item())
 
 
+@pytest.mark.parametrize("B,H,nh,hd,ws", [(1, 28, 2, 80, 14), (1, 32, 2, 80, 0), (2, 20, 4, 80, 14), (1, 16, 2, 64, 7)])
+def test_head_major_layout_equals_token_major(B, H, nh, hd, ws):
+    """The attention kernels on the head-major q/k/v tensor (3 heads, B H W, hd) -- what the qkv GEMM's column-block epilogue
+    writes -- give bit for bit what they give on the Linear layout (B,H,W,3,heads,hd): only addresses differ."""
+    from sam6d_amd import ops
+    bias, rh, rw, qkv = (t.to(torch.bfloat16).cuda() for t in _mk(B, H, nh, hd, ws, 7 * H + ws + hd))
+    tok = ops.window_attention(qkv.contiguous(), bias, rh.contiguous(), rw.contiguous(), nh, ws, hd ** -0.5)
+    hm = qkv.view(B * H * H, 3 * nh, hd).permute(1, 0, 2).contiguous()
+    out = ops.window_attention(hm, bias, rh.contiguous(), rw.contiguous(), nh, ws, hd ** -0.5, head_major_shape=(B, H, H))
+    assert torch.equal(out, tok)
+
+
 def test_no_bias_variant_matches_sdpa():
     from sam6d_amd import ops
     g = torch.Generator().manual_seed(5)

@@ -111,3 +111,18 @@ def test_sam_block_with_the_kernel_equals_the_library_statement():
         ref = h.float() @ mlp.lin2.weight.float().t() + mlp.lin2.bias.float()
     rel = (y - ref).norm() / ref.norm()
     assert rel < 4e-3, rel.item()                                 # two bf16 roundings (h, y)
+
+
+@pytest.mark.parametrize("M,N,K,cb", [(65536, 3840, 1280, 80), (700, 768, 192, 64), (300, 256, 64, 32)])
+def test_column_block_output_equals_the_plain_product(M, N, K, cb):
+    """s6d_gemm_bf16_cblk: column blocks stored as separate (M, col_block) matrices (the head-major q/k/v of the attention kernels) ==
+    the plain (M, N) output of the same launch, rearranged -- bit for bit (only store addresses differ)."""
+    from sam6d_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    plain = ops.gemm_bf16(a, w, b)
+    blk = ops.gemm_bf16(a, w, b, col_block=cb)
+    assert blk.shape == (N // cb, M, cb)
+    assert torch.equal(blk, plain.view(M, N // cb, cb).permute(1, 0, 2))

@@ -346,7 +346,14 @@ class CustomDINOv2(nn.Module):
         if m.dim() == 4:
             m = m.squeeze(1)
         params = torch.from_numpy(crop_params(boxes.detach().cpu().numpy(), self.proposal_size)).to(m.device)
-        img = torch.as_tensor(np.ascontiguousarray(image_np)).to(m.device) if rgb else None
+        # image_np: the reference's numpy frame (H,W,3) uint8 -- or the same frame as a device tensor (FramePipeline hands it over
+        # without the device -> host -> device round trip)
+        if not rgb:
+            img = None
+        elif torch.is_tensor(image_np):
+            img = image_np.to(device=m.device, dtype=torch.uint8).contiguous()
+        else:
+            img = torch.as_tensor(np.ascontiguousarray(image_np)).to(m.device)
         return ops.crop_resize_pad(img, m.contiguous(), params, self.proposal_size, RGB_MEAN, RGB_STD, rgb=rgb, mask=mask)
 
     def process_rgb_proposals(self, image_np, masks, boxes):

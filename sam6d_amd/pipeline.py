@@ -94,7 +94,7 @@ class FramePipeline:
         if masks.shape[0] == 0:
             return Detections(0, 0, masks, boxes, boxes.new_zeros(0), boxes.new_zeros(0)), None
         # ---- descriptors + scoring -----------------------------------------------------------------------------------
-        cls, patch = self.desc(image_u8.cpu().numpy(), SimpleNamespace(masks=masks.float(), boxes=boxes))
+        cls, patch = self.desc(image_u8, SimpleNamespace(masks=masks.float(), boxes=boxes))      # device frame: no host round trip
         t0 = self._tick("descriptors", t0)
         sc = self.score_metres(cls, patch, masks.float(), boxes.float(), depth, K)
         order = torch.argsort(sc["final"], descending=True)

@@ -108,8 +108,9 @@ class Attention(nn.Module):
         B, H, W, C = x.shape
         fused = ops.have("win_attention") and x.is_cuda and x.dtype == torch.bfloat16 and self.use_rel_pos
         if fused:
-            # q / k / v head-major straight out of the GEMM's epilogue ((3 heads, B H W, hd): a head's rows of a window row or of a
-            # key tile are contiguous whole lines for the attention kernels' fetches); S6D_QKV_LAYOUT=token keeps the Linear layout
+            # S6D_QKV_LAYOUT=head: q / k / v head-major straight out of the GEMM's epilogue ((3 heads, B H W, hd): a head's rows of a
+            # window row or of a key tile are contiguous whole lines for the attention kernels' fetches).  Measured neutral on the
+            # step, so the default stays the Linear layout (fused_linear returns None)
             hm = fused_linear(self.qkv, x, col_block=C // self.num_heads)
             if hm is not None:
                 S = window_size if window_size > 0 else H

@@ -45,7 +45,7 @@ def test_glue_between_the_stages(monkeypatch):
 
         def __call__(self, image_np, prop):
             seen["desc_n"] = prop.masks.shape[0]
-            assert isinstance(image_np, np.ndarray) and image_np.shape == (H, W, 3)
+            assert torch.is_tensor(image_np) and tuple(image_np.shape) == (H, W, 3) and image_np.dtype == torch.uint8   # the device frame itself
             n = prop.masks.shape[0]
             return torch.zeros(n, 4), torch.zeros(n, 16, 4)
 

@@ -49,8 +49,12 @@ class MLPBlock(nn.Module):
         # between the three kernels instead of making two HBM round trips.
         flat = x.reshape(-1, x.shape[-1])
         out = torch.empty(flat.shape[0], self.lin2.out_features, dtype=flat.dtype, device=flat.device)
+        exact = isinstance(self.act, nn.GELU) and self.act.approximate == "none"
         for a in range(0, flat.shape[0], rows):
-            out[a:a + rows] = self.lin2(self.act(self.lin1(flat[a:a + rows])))
+            if exact:
+                out[a:a + rows] = fused_linear(self.lin2, fused_linear(self.lin1, flat[a:a + rows], gelu=True))
+            else:
+                out[a:a + rows] = self.lin2(self.act(self.lin1(flat[a:a + rows])))
         return out.reshape(*x.shape[:-1], self.lin2.out_features)
 
 

@@ -91,8 +91,7 @@ class ViT(nn.Module):
         # 16x16/16 conv == GEMM on unfolded patches
         h = x.shape[2] // p
         x = x.view(B, 3, h, p, h, p).permute(0, 2, 4, 1, 3, 5).reshape(B, h * h, 3 * p * p)
-        x = F.linear(x, self.patch_embed.proj.weight.view(self.patch_embed.proj.weight.shape[0], -1),
-                     self.patch_embed.proj.bias)
+        x = fused_linear(self.patch_embed.proj, x, weight2d=self.patch_embed.proj.weight.view(self.patch_embed.proj.weight.shape[0], -1))
         x = torch.cat([self.cls_token.expand(B, -1, -1), x], dim=1) + self.pos_embed
         d = len(self.blocks)
         n = d // 4
@@ -158,7 +157,7 @@ class ViT_AE(nn.Module):
         if dt != torch.float32:
             with torch.autocast(device_type=x.device.type, dtype=dt):
                 taps = self.vit(x.to(dt))
-                return self.output_upscaling(torch.cat([t[:, 1:] for t in taps], dim=2)).float()
+                return fused_linear(self.output_upscaling, torch.cat([t[:, 1:] for t in taps], dim=2)).float()
         taps = self.vit(x)
         return self.output_upscaling(torch.cat([t[:, 1:] for t in taps], dim=2))
 

@@ -256,12 +256,20 @@ class ImageEncoderViT(nn.Module):
         y = F.layer_norm(y.float(), (y.shape[-1],), n1.weight.float(), n1.bias.float(), n1.eps).to(dt)
         Co = y.shape[-1]
         yp = F.pad(y, (0, 0, 1, 1, 1, 1))                                   # zero pad H and W by 1
-        w = c3.weight.to(dt)                                                # (Co, Ci, 3, 3)
-        acc = None
-        for dy in range(3):
-            for dx in range(3):
-                part = F.linear(yp[:, dy:dy + H, dx:dx + W, :], w[:, :, dy, dx])
-                acc = part.float() if acc is None else acc + part.float()
+        if y.is_cuda and dt == torch.bfloat16 and ops.have("gemm_bf16") and (9 * Co) % 64 == 0 and c3.weight.shape[0] % 128 == 0:
+            # the 3x3 convolution as ONE GEMM over K = 9 Ci (the nine shifted views side by side, weight in (dy, dx, ci) order):
+            # fp32 accumulation over all taps inside the kernel instead of nine bf16 partial products summed in fp32 passes
+            cols = torch.cat([yp[:, dy:dy + H, dx:dx + W, :] for dy in range(3) for dx in range(3)], dim=-1)
+            acc = fused_linear(c3, cols, weight2d=c3.weight.permute(0, 2, 3, 1).reshape(c3.weight.shape[0], -1)).float()
+        else:
+            w = c3.weight.to(dt)                                            # (Co, Ci, 3, 3)
+            acc = None
+            for dy in range(3):
+                for dx in range(3):
+                    part = F.linear(yp[:, dy:dy + H, dx:dx + W, :], w[:, :, dy, dx])
+                    acc = part.float() if acc is None else acc + part.float()
+            if c3.bias is not None:
+                acc = acc + c3.bias.float()
         z = F.layer_norm(acc, (Co,), n2.weight.float(), n2.bias.float(), n2.eps)
         return z.permute(0, 3, 1, 2)
 

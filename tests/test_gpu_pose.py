@@ -259,3 +259,29 @@ def test_cross_attention_and_linear_attention_vs_oracle(ops):
         ref = opem.linear_layer(W, "l", xd, ms)
         out = ll.cuda()(xd.cuda(), ms.cuda()).cpu()
     assert (out - ref).abs().max() < 5e-5, (out - ref).abs().max()
+
+
+def test_fine_match_properties_at_the_benched_size(ops):
+    """B = 32, 2049 x 2049 (BASELINE configs[1]; too large for the CPU oracle in seconds): (1) against the other device
+    formulation (library bmm -> s6d_fine_assign_f32, itself oracle-checked at small sizes): identical labels, weights 5e-5
+    relative; (2) equivariance: permuting the observed rows (background row kept) permutes the outputs and nothing else -- every
+    owner row is reduced on its own; (3) weights are probabilities mass: 0 <= wsum <= 1 + 1e-5, and rows labelled background
+    carry exactly zero weight and a zero point."""
+    g = torch.Generator().manual_seed(11)
+    B, M = 32, 2049
+    f1 = torch.randn(B, M, 256, generator=g).cuda()
+    perm = torch.randperm(M, generator=g).cuda()
+    f2 = f1[:, perm] + 0.4 * torch.randn(B, M, 256, generator=g).cuda()
+    pts2 = torch.randn(B, M - 1, 3, generator=g).cuda()
+    F = torch.nn.functional
+    pred, wsum, w1 = ops.fine_match(f1, f2, pts2, 0.1)
+    atten = F.normalize(f1, dim=2) @ F.normalize(f2, dim=2).transpose(1, 2) / 0.1
+    p0, ws0, l0 = ops.fine_assign(atten, pts2)
+    assert torch.equal(w1, l0)
+    assert ((wsum - ws0).abs() <= 5e-5 * ws0.abs().clamp(min=1e-3)).all() and (pred - p0).abs().max() < 1e-4
+    rp = torch.cat([torch.zeros(1, dtype=torch.long), 1 + torch.randperm(M - 1, generator=g)]).cuda()
+    pred2, wsum2, w12 = ops.fine_match(f1[:, rp].contiguous(), f2, pts2, 0.1)
+    assert torch.equal(w12, w1[:, rp[1:] - 1]) and torch.equal(wsum2, wsum[:, rp[1:] - 1]) and torch.equal(pred2, pred[:, rp[1:] - 1])
+    assert (wsum >= 0).all() and (wsum <= 1 + 1e-5).all()
+    off = w1 == 0
+    assert (wsum[off] == 0).all() and (pred[off] == 0).all()

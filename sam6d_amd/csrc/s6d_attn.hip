@@ -60,12 +60,50 @@ __device__ __forceinline__ const u16 *qkv_at(const AttnParams &p, size_t tok, in
 }
 
 // Ablation switches for profiling are COMPILE-time (-DS6D_ATTN_ABLATE=mask through S6D_EXTRA_HIPCC_FLAGS): 1 = no K/V
-// loads, 2 = no tile math, 4 = no softmax arithmetic, 8 = no PV, 16 = no QK^T.  As run-time branches they cut the
+// loads, 2 = no tile math, 4 = no softmax arithmetic, 8 = no PV, 16 = no QK^T, 32 = no LDS stores of the staged tile.  As run-time branches they cut the
 // tile loop into a dozen basic blocks and kept the scheduler from placing MFMAs beside the softmax VALU work.
 #ifndef S6D_ATTN_ABLATE
 #define S6D_ATTN_ABLATE 0
 #endif
 constexpr int kAbl = S6D_ATTN_ABLATE;
+// Global-attention layout / schedule switches (defaults = what is measured fastest; tools/attn_variants.sh builds the others):
+//   S6D_GLB_KSWZ  K image rows whose (row >> 2 ^ row >> 3) & 1 is set keep their 16-byte chunks pairwise swapped: with an odd row
+//                 stride (13 chunks) the two row sets of a ds_read_b128 lane group ({0-3,12-15} reading chunk g, {4-11} reading
+//                 chunk g + 1) otherwise meet on 5 of 16 bank slots (2-way conflict on every K fragment read)
+//   S6D_GLB_THLD  row stride (floats) of the per-query th tables: at 64 the 16 queries of a lane group read ONE bank
+//   S6D_GLB_PRIO  s_setprio 1 around the MFMA phases of a tile (the wave in its MFMA phase wins issue over the one in softmax)
+//   S6D_GLB_WAVES waves per workgroup (4: two workgroups per CU; 8: one, each staged K/V tile shared by twice the queries)
+#ifndef S6D_GLB_KSWZ
+#define S6D_GLB_KSWZ 1
+#endif
+#ifndef S6D_GLB_THLD
+#define S6D_GLB_THLD 65
+#endif
+#ifndef S6D_GLB_PRIO
+#define S6D_GLB_PRIO 1
+#endif
+#ifndef S6D_GLB64_DEFAULT_IMPL
+#define S6D_GLB64_DEFAULT_IMPL 2     // 64 x 64 grid: 2 = attn_global64_kernel (LDS-DMA ring), 1 = attn_global_kernel (register staged)
+#endif
+#ifndef S6D_GLB_WAVES
+#define S6D_GLB_WAVES 4
+#endif
+__device__ __forceinline__ int kswz(int row) { return ((row >> 2) ^ (row >> 3)) & 1; }
+// S6D_G64_TIMING (probe build; writes 320 bytes BEHIND the output tensor, which tools/attn_time.py allocates): shader-clock totals per phase of attn_global64_kernel's tile loop,
+// per wave of workgroup 0: [barrier wait | DMA issue | QK^T + scale + max | exp + pack | P V]  (tools/attn_time.py prints them)
+#ifndef S6D_G64_TIMING
+#define S6D_G64_TIMING 0
+#endif
+#if S6D_G64_TIMING
+#define S6D_TICK(tk, i)                                  \
+  do {                                                   \
+    __builtin_amdgcn_sched_barrier(0);                   \
+    (tk)[i] = (long long)__builtin_amdgcn_s_memtime();   \
+    __builtin_amdgcn_sched_barrier(0);                   \
+  } while (0)
+#else
+#define S6D_TICK(tk, i) do { } while (0)
+#endif
 
 constexpr float kLog2e = 1.4426950408889634f;
 // v_exp_f32 without the denormal-range fix-up of fast_exp2(): arguments here are <= 2^kDefer and tiny results may flush
@@ -132,12 +170,14 @@ struct StripState {
   int qy[NS], qx[NS];
 };
 
-template <int HD, int MODE, int NS>
+template <int HD, int MODE, int NS, bool KSWZ = false, bool PRIO = false>
 __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl, const u16 *Vl, int key0,
-                                             StripState<HD, NS> &st, const float (&thv)[NS], int lane) {
+                                             StripState<HD, NS> &st, const float (&thv)[NS], int lane, long long *tk = nullptr) {
   using C = Cfg<HD>;
   const int g = lane >> 4, c = lane & 15;
+  const int gk = KSWZ ? (g ^ kswz(c)) : g;               // chunk of this lane's K fragment inside its group of 4 (see S6D_GLB_KSWZ)
   float s[NS][4][4];
+  if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
   for (int sub = 0; sub < 4; ++sub) {
     f32x4 acc[NS];
@@ -146,7 +186,7 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
     if (!(kAbl & 16)) {
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(Kl + (sub * 16 + c) * C::KROW + ks * 32 + g * 8);
+        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(Kl + (sub * 16 + c) * C::KROW + ks * 32 + gk * 8);
 #pragma unroll
         for (int n = 0; n < NS; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, st.qf[n][ks], acc[n], 0, 0, 0);
       }
@@ -171,6 +211,7 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
   }
   union PB { bf16x8 v; u16 h[8]; };
   PB pb[NS][2];
+  if (PRIO) __builtin_amdgcn_s_setprio(0);
   if (kAbl & 4) {                                          // ablation: no softmax arithmetic
 #pragma unroll
     for (int n = 0; n < NS; ++n)
@@ -200,6 +241,7 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
       grow[n] = __any(v - st.m_run[n] > kDefer);
       any_grow |= grow[n];
     }
+    S6D_TICK(tk, 3);
     if (any_grow) {                                           // wave-uniform
 #pragma unroll
       for (int n = 0; n < NS; ++n)
@@ -232,6 +274,8 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
   union { bf16x8 v; u16 h[8]; } ones;
 #pragma unroll
   for (int i = 0; i < 8; ++i) ones.h[i] = 0x3F80;                  // bf16 1.0
+  S6D_TICK(tk, 4);
+  if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const u16 *vrow = Vl + (32 * j + g * 4 + (c >> 2)) * C::VROW + (c & 3) * 4;
@@ -247,6 +291,7 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
         st.oacc[n][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va.v, pb[n][j].v, st.oacc[n][dt], 0, 0, 0);
     }
   }
+  if (PRIO) __builtin_amdgcn_s_setprio(0);
 }
 
 // ---- staging: global -> registers -> LDS, split so the loads can fly under the previous tile's math ------
@@ -293,7 +338,7 @@ struct Stager {
 
 // Global attention, T % 64 == 0: token slots are contiguous in memory, so each thread's chunk addresses are
 // fixed up to a per-tile stride -- pointers and LDS offsets are computed once, a tile costs 6 loads + 6 adds.
-template <int HD, int THREADS>
+template <int HD, int THREADS, bool KSWZ = false>
 struct StagerLinear {
   using C = Cfg<HD>;
   static constexpr int NK = (64 * C::KPARTS + THREADS - 1) / THREADS;
@@ -314,7 +359,7 @@ struct StagerLinear {
       const int key = ic / C::KPARTS, part = ic - key * C::KPARTS;
       kz[n] = part * 8 >= HD;
       kp[n] = qkv_at(p, (size_t)b * p.T + key, 1, head) + (kz[n] ? HD - 8 : part * 8);
-      ko[n] = i < 64 * C::KPARTS ? key * C::KROW + part * 8 : (tid & 63) * C::KROW + C::HDP;
+      ko[n] = i < 64 * C::KPARTS ? key * C::KROW + (KSWZ ? part ^ kswz(key) : part) * 8 : (tid & 63) * C::KROW + C::HDP;
     }
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
@@ -374,8 +419,13 @@ __device__ __forceinline__ void build_table(const u16 *rel, int j0, int sgn, con
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r[jt][ks].v, qf[ks], a, 0, 0, 0);
     // C layout: row jj = jt*16 + g*4 + r, col = query c
-    *reinterpret_cast<float4 *>(dst + c * ld + jt * 16 + g * 4) =
-        make_float4(a[0] * kLog2e, a[1] * kLog2e, a[2] * kLog2e, a[3] * kLog2e);
+    float *o = dst + c * ld + jt * 16 + g * 4;
+    if ((ld & 3) == 0) {
+      *reinterpret_cast<float4 *>(o) = make_float4(a[0] * kLog2e, a[1] * kLog2e, a[2] * kLog2e, a[3] * kLog2e);
+    } else {                                              // odd strides (bank spreading): rows are not 16-byte aligned
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = a[r] * kLog2e;
+    }
   }
 }
 
@@ -1016,20 +1066,23 @@ __global__ __launch_bounds__(WAVES * 64) void attn_global_kernel(AttnParams p) {
     //   G[c][jj] = rel_w[q0x + jj] . q_c (jj < 80) in scratch (aliases the ring, not yet in use) and gather.
 #pragma unroll
     for (int n = 0; n < NS; ++n) {
-      float *th = tabs + (size_t)(wave * NS + n) * 16 * 64;
+      float *th = tabs + (size_t)(wave * NS + n) * 16 * S6D_GLB_THLD;
       float *G = reinterpret_cast<float *>(smem) + (size_t)wave * 16 * 80;      // per-wave scratch, reused by both strips
       const int q0y = div_S(p, q0[n]), q0x = q0[n] - q0y * p.S;
-      build_table<HD, 4>(p.rel_h, q0y + 63, -1, st.qf[n], th, 64, lane);
+      build_table<HD, 4>(p.rel_h, q0y + 63, -1, st.qf[n], th, S6D_GLB_THLD, lane);
       build_table<HD, 5>(p.rel_w, q0x, 1, st.qf[n], G, 80, lane);
+      // hipemu: wave rendezvous (same-wave LDS order; on the GPU the wave's LDS operations execute in program order)
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
         for (int r = 0; r < 4; ++r) st.twr[n][sub * 4 + r] = G[c * 80 + (c + 63 - (sub * 16 + g * 4 + r))];
+      // hipemu: wave rendezvous (the second strip's table overwrites G)
       thm[n] = th;
     }
   }
   const int ntile = p.T / 64;                       // launcher guarantees T % 64 == 0 for this kernel
-  StagerLinear<HD, WAVES * 64> sg;
+  constexpr bool KSWZ = S6D_GLB_KSWZ != 0;
+  StagerLinear<HD, WAVES * 64, KSWZ> sg;
   sg.init(p, b, head, tid);
   const size_t tstride = (size_t)64 * (size_t)p.tok_stride;
   sg.load(tstride, 0);
@@ -1039,18 +1092,216 @@ __global__ __launch_bounds__(WAVES * 64) void attn_global_kernel(AttnParams p) {
   auto tile = [&](int t) {
     float thv[NS];
 #pragma unroll
-    for (int n = 0; n < NS; ++n) thv[n] = (MODE == 1) ? thm[n][c * 64 + t] : 0.f;
-    if (!(kAbl & 2)) process_tile<HD, MODE, NS>(p, Kbuf(t & 1), Vbuf(t & 1), t * 64, st, thv, lane);
+    for (int n = 0; n < NS; ++n) thv[n] = (MODE == 1) ? thm[n][c * S6D_GLB_THLD + t] : 0.f;
+    if (!(kAbl & 2)) process_tile<HD, MODE, NS, KSWZ, S6D_GLB_PRIO != 0>(p, Kbuf(t & 1), Vbuf(t & 1), t * 64, st, thv, lane);
   };
   for (int t = 0; t + 1 < ntile; ++t) {                           // steady state: branch-free body
     if (!(kAbl & 1)) sg.load(tstride, t + 1);                     // flies under this tile's math
     tile(t);
-    sg.store(Kbuf((t & 1) ^ 1));                                  // ring slot last read in iteration t-1
+    if (!(kAbl & 32)) sg.store(Kbuf((t & 1) ^ 1));                // ring slot last read in iteration t-1
     __syncthreads();
   }
   tile(ntile - 1);
 #pragma unroll
   for (int n = 0; n < NS; ++n) store_strip<HD>(p, b, 0, 0, head, q0[n], st.lacc[n][0], st.oacc[n], lane);
+}
+
+// ---- global over the 64 x 64 grid, LDS-DMA staged: 8 waves x 32 queries per workgroup, K / V tiles through a 3-slot ring -------
+// What the kernel above pays for besides its arithmetic (16 frames x 16 heads, same process, profiles/r02_attn_variants.txt):
+// 2.22 ms as is, 1.75 ms without the staging of K / V tiles, 1.30 ms for the staging ALONE -- every 128-query workgroup pulls all
+// 1.3 MB of its head's K and V through registers into LDS, one tile of look-ahead, 6 loads + 6 ds_write_b128 per thread and tile.
+// Here: 256 queries per workgroup (half the K / V passes), tiles DMA'd straight into LDS (global_load_lds, 3 instructions per
+// wave and tile, no staging registers, no ds_write) two tiles ahead of the arithmetic behind counted vmcnt waits and ONE raw
+// s_barrier per tile, K rows chunk-swizzled on the source address (S6D_GLB_KSWZ above: conflict-free fragment reads), th tables
+// at a 65-float row stride.  A ring slot is [K image 64 rows x (HDP + 8) | V image 64 x VROW]; every wave issues the same number
+// of DMA instructions per tile (3 with 8 waves), so one vmcnt(3) means "my pieces of this tile landed".
+// Measured in one process (16 frames, min of 3 x 20 launches): 1.73 ms (795 TFLOP/s) against 1.89 ms for the round-1 kernel,
+// 1.81 ms for it with the two layout switches, 1.78 ms for it with 8 waves; 4 waves + 2 slots here: 1.77 ms.
+// Where the rest goes (phase clocks of S6D_G64_TIMING, per tile and wave, older / younger half of the workgroup): barrier wait
+// 850 / 180, DMA issue + th read 190 / 370, QK^T + scale + max 1260 / 1370, exp + pack 515 / 915, P V 545 / 530 -- about 3400
+// cycles per tile for 96 MFMAs (1536 matrix-pipe cycles) and 2 x 158 VALU instructions on each SIMD.  The issue-rate probe
+// (tools/probes/valu_rate.hip, profiles/r02_valu_rate.txt) says why: with two or more waves on a SIMD, MFMA and VALU issue time ADD
+// (8 MFMA 57 ns, 48 v_fma 55 ns, 8 x (MFMA, 6 v_fma) 109 ns per wave; v_exp_f32 = 3 v_fma, packed fp32 ops = 1.8), so the
+// softmax's 3.3 VALU instructions per MFMA cost about as much as the MFMAs themselves.  Tried on this kernel and dropped (no
+// gain, same process): the tile as ONE interleaved stream -- K fragments read two 16-key blocks ahead, block i's scale / max
+// beside block i + 1's MFMAs, P of keys 0..31 exponentiated speculatively against the old maximum beside the QK^T MFMAs, P of
+// keys 32..63 beside the first P V MFMAs (1.74 ms, bit-identical output); static s_setprio 1 for the younger half (1.75 ms);
+// rings of 2 and (without the th tables, as a timing probe) 6 slots (1.69 - 1.75 ms: the look-ahead is not what is missing).
+#ifdef HIPEMU
+#define S6D_ATTN_VMCNT(n) hipemu::vmcnt_wait(n)
+#define S6D_ATTN_LGKM0()
+#else
+#define S6D_ATTN_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define S6D_ATTN_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
+constexpr int G64_THLD = 65;
+#ifndef S6D_G64_SLOTS
+#define S6D_G64_SLOTS 3             // ring depth: tiles are DMA'd S6D_G64_SLOTS - 1 ahead of the arithmetic
+#endif
+// One 1-KiB DMA piece: lane l's 16 bytes at src -> LDS byte address lds + 16 l (lds wave-uniform).  Issued as inline asm, not through
+// __builtin_amdgcn_global_load_lds: with the builtin in the loop hipcc puts an s_waitcnt vmcnt(0) in front of the first
+// ds_read_b64_tr_b16 of every tile (it cannot tell that the reads touch another ring slot), which drains the two-tile look-ahead;
+// the waits here are the counted ones written out below.  M0 is on the clobber list (the library is built with -Wno-inline-asm: hipcc
+// warns about reserved registers there); nothing else in the kernel uses it.
+#ifdef HIPEMU
+#define S6D_ATTN_DMA16(src, lds_ptr) __builtin_amdgcn_global_load_lds((const S6D_ATTN_GLOBAL(void) *)(src), (lds_ptr), 16, 0, 0)
+#else
+__device__ __forceinline__ void attn_dma16(const void *src, S6D_LDS(char) *dst) {
+  const unsigned a = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dst);
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(a) : "memory", "m0");
+}
+#define S6D_ATTN_DMA16(src, lds_ptr) attn_dma16((src), (lds_ptr))
+#endif
+
+#ifndef S6D_G64_WAVES
+#define S6D_G64_WAVES 8
+#endif
+#ifndef S6D_G64_STATIC_PRIO
+#define S6D_G64_STATIC_PRIO 0       // 1: the second-dispatched half of an 8-wave workgroup runs the whole tile loop at s_setprio 1
+#endif
+
+template <int HD, int WAVES_, int SLOTS_>
+struct G64 {
+  using C = Cfg<HD>;
+  static constexpr int WAVES = WAVES_, NS = 2, SLOTS = SLOTS_;
+  static constexpr int KCH = C::KROW / 8, VCH = C::VROW / 8;          // 16-byte chunks per K / V image row = KiB per image
+  static constexpr int NPIECE = KCH + VCH;                            // 1-KiB DMA pieces per tile
+  static constexpr int PW = (NPIECE + WAVES - 1) / WAVES;             // DMA instructions per wave and tile (a surplus one repeats the wave's previous piece)
+  static constexpr int SLOT = NPIECE * 1024;
+  static constexpr int RING = SLOTS * SLOT;
+  static constexpr int TABS = WAVES * NS * 16 * G64_THLD * 4;
+  static constexpr int LDS = RING + TABS;
+  static_assert(NPIECE > WAVES * (PW - 1) && PW >= 2, "every wave has a real piece to repeat");
+  static_assert(RING >= WAVES * 16 * 80 * 4, "the prologue's per-wave scratch aliases the ring");
+  static_assert(PW * (SLOTS - 2) <= 15 || SLOTS == 2, "vmcnt immediates used below");
+};
+
+// at most n tiles' DMA (PW instructions per wave and tile) may still be in flight
+template <int PW>
+__device__ __forceinline__ void g64_wait_tiles(int n) {
+  switch (PW * n) {
+#define S6D_G64_CASE(k) case k: S6D_ATTN_VMCNT(k); break;
+    S6D_G64_CASE(0) S6D_G64_CASE(3) S6D_G64_CASE(5) S6D_G64_CASE(6) S6D_G64_CASE(9) S6D_G64_CASE(10) S6D_G64_CASE(12)
+#undef S6D_G64_CASE
+    default: S6D_ATTN_VMCNT(15); break;              // 15 or more (PW (SLOTS - 2) <= 15 is asserted)
+  }
+}
+
+template <int HD, int WAVES, int SLOTS>
+__global__ __launch_bounds__(WAVES * 64) void attn_global64_kernel(AttnParams p) {
+  using C = Cfg<HD>;
+  using G = G64<HD, WAVES, SLOTS>;
+  constexpr int NS = G::NS, PW = G::PW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *tabs = reinterpret_cast<float *>(smem + G::RING);
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int g = lane >> 4, c = lane & 15;
+  // workgroup -> (image, head, query tile): the query tiles of one (image, head) stay on ONE XCD (K / V re-reads hit its L2)
+  const int nqt = p.T / (WAVES * 16 * NS);
+  const int nbh = p.B * p.nh;
+  int id = blockIdx.x, qt, bh;
+  if ((nbh & 7) == 0) {
+    const int xcd = id & 7, loc = id >> 3;
+    qt = loc % nqt;
+    bh = (loc / nqt) * 8 + xcd;
+  } else {
+    qt = id % nqt;
+    bh = id / nqt;
+  }
+  const int head = bh % p.nh, b = bh / p.nh;
+  StripState<HD, NS> st;
+  int q0[NS];
+  float *thm[NS];
+#pragma unroll
+  for (int n = 0; n < NS; ++n) {
+    q0[n] = ((qt * WAVES + wave) * NS + n) * 16;
+    load_q<HD>(p, b, 0, 0, head, q0[n], st.qf[n], lane);
+    st.qy[n] = q0[n] >> 6;
+    st.qx[n] = (q0[n] & 63) + c;
+    st.m_run[n] = -1e30f;
+    st.lacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) st.oacc[n][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    st.th[n] = nullptr;
+    st.tw[n] = nullptr;
+    // a strip's 16 queries share qy; tile t is key row ky = t:  th[c][t] = rel_h[qy - t + 63] . q_c, and
+    // twr = rel_w[qx_c - kx + 63] . q_c gathered from G[c][jj] = rel_w[q0x + jj] . q_c (jj < 80; per-wave scratch in the ring)
+    float *th = tabs + (size_t)(wave * NS + n) * 16 * G64_THLD;
+    float *Gs = reinterpret_cast<float *>(smem) + (size_t)wave * 16 * 80;
+    const int q0y = q0[n] >> 6, q0x = q0[n] & 63;
+    build_table<HD, 4>(p.rel_h, q0y + 63, -1, st.qf[n], th, G64_THLD, lane);
+    build_table<HD, 5>(p.rel_w, q0x, 1, st.qf[n], Gs, 80, lane);
+    // hipemu: wave rendezvous (same-wave LDS order; on the GPU the wave's LDS operations execute in program order)
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st.twr[n][sub * 4 + r] = Gs[c * 80 + (c + 63 - (sub * 16 + g * 4 + r))];
+    // hipemu: wave rendezvous (the second strip's table overwrites the scratch)
+    thm[n] = th;
+  }
+  // ---- this lane's DMA sources: piece q = wave + WAVES i of a tile is 64 consecutive chunks of the K image (q < KCH) or of the
+  // V image; chunk -> (key row, part); zero-padded parts read a 16-byte zero; a wave without an i-th piece repeats its previous one
+  // (same bytes to the same place), so that every wave has PW instructions per tile in flight and the waits count whole tiles
+  const u16 *src[PW];
+  long inc[PW];
+  int dsto[PW];
+  const long tstride = 64L * p.tok_stride;
+#pragma unroll
+  for (int i = 0; i < PW; ++i) {
+    const int q = wave + WAVES * i < G::NPIECE ? wave + WAVES * i : wave + WAVES * (i - 1);
+    const bool isk = q < G::KCH;
+    const int piece = isk ? q : q - G::KCH, rowch = isk ? G::KCH : G::VCH;
+    const int j = piece * 64 + lane;
+    const int row = j / rowch, pp = j - row * rowch;
+    const int part = isk ? (pp < C::KPARTS ? pp ^ kswz(row) : C::KPARTS) : pp;
+    const bool data = part * 8 < HD;
+    src[i] = data ? qkv_at(p, (size_t)b * p.T + row, isk ? 1 : 2, head) + part * 8 : reinterpret_cast<const u16 *>(&g_win16_zero);
+    inc[i] = data ? tstride : 0;
+    dsto[i] = q * 1024;
+  }
+  auto issue = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      S6D_LDS(char) *dst = (S6D_LDS(char) *)smem + slot * G::SLOT + dsto[i];
+      S6D_ATTN_DMA16(src[i], dst);
+      src[i] += inc[i];
+    }
+  };
+  const int ntile = p.T / 64;
+  constexpr int D = SLOTS - 1;                      // look-ahead in tiles
+  static_assert(D >= 1 && D <= 6, "ring depth");
+  __syncthreads();                                  // every wave is done with its scratch (it aliases the ring)
+#pragma unroll
+  for (int d = 0; d < D; ++d) issue(d);
+  int slot = 0;
+  long long tk[6] = {0, 0, 0, 0, 0, 0}, tsum[5] = {0, 0, 0, 0, 0};
+  if (S6D_G64_STATIC_PRIO && WAVES == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);     // wave is wave-uniform (readfirstlane above)
+  for (int t = 0; t < ntile; ++t) {
+    S6D_TICK(tk, 0);
+    g64_wait_tiles<PW>(min(D - 1, ntile - 1 - t));  // this wave's pieces of tile t are in LDS
+    S6D_ATTN_LGKM0();
+    __builtin_amdgcn_s_barrier();                   // ... and everybody's; every wave is past tile t - 1 (its slot is free)
+    S6D_TICK(tk, 1);
+    if (t + D < ntile && !(kAbl & 1)) issue(slot >= 1 ? slot - 1 : SLOTS - 1);
+    float thv[NS];
+#pragma unroll
+    for (int n = 0; n < NS; ++n) thv[n] = thm[n][c * G64_THLD + t];
+    S6D_TICK(tk, 2);
+    const u16 *Kl = reinterpret_cast<const u16 *>(smem + slot * G::SLOT);
+    if (!(kAbl & 2)) process_tile<HD, 1, NS, true, S6D_GLB_PRIO != 0>(p, Kl, Kl + 64 * C::KROW, t * 64, st, thv, lane, tk);
+    S6D_TICK(tk, 5);
+    if (S6D_G64_TIMING)
+#pragma unroll
+      for (int i = 0; i < 5; ++i) tsum[i] += tk[i + 1] - tk[i];
+    slot = slot == SLOTS - 1 ? 0 : slot + 1;
+  }
+#pragma unroll
+  for (int n = 0; n < NS; ++n) store_strip<HD>(p, b, 0, 0, head, q0[n], st.lacc[n][0], st.oacc[n], lane);
+  if (S6D_G64_TIMING && blockIdx.x == 8 && lane == 0) {             // the caller of a probe build leaves 4 KiB behind the output
+    long long *dbg = reinterpret_cast<long long *>(p.out + (size_t)p.B * p.T * p.nh * HD);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) dbg[wave * 5 + i] = tsum[i];
+  }
 }
 
 template <int HD>
@@ -1105,7 +1356,7 @@ static int launch_attn(AttnParams p, hipStream_t st) {
     }
   } else {
     if (p.T % 64 != 0) return S6D_EUNSUPPORTED;                  // global grids: 16x16, 32x32, 64x64 ...
-    constexpr int WAVES = 4;
+    constexpr int WAVES = S6D_GLB_WAVES;
     constexpr int NS = 2;
     const size_t ring = (size_t)2 * 64 * (C::KROW + C::VROW) * 2;
     const int nqt = (p.T + WAVES * 16 * NS - 1) / (WAVES * 16 * NS);
@@ -1117,10 +1368,24 @@ static int launch_attn(AttnParams p, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS));                         \
     hipLaunchKernelGGL((attn_global_kernel<HD, WAVES, MODE>), dim3(grid), dim3(WAVES * 64), (LDS), st, p);     \
   } while (0)
+    static int impl64 = -1;                                      // S6D_GLB64_IMPL=1: the register-staged kernel on the 64 x 64 grid too
+    if (impl64 < 0) {
+      const char *e = getenv("S6D_GLB64_IMPL");
+      impl64 = e ? (atoi(e) == 1 ? 1 : 2) : S6D_GLB64_DEFAULT_IMPL;
+    }
+    if (bias && p.S == 64 && impl64 == 2) {
+      using G = G64<HD, S6D_G64_WAVES, S6D_G64_SLOTS>;
+      static_assert(G::LDS <= 160 * 1024, "ring + tables fit the CU's LDS");
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_global64_kernel<HD, G::WAVES, G::SLOTS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+      hipLaunchKernelGGL((attn_global64_kernel<HD, G::WAVES, G::SLOTS>), dim3((unsigned)(p.B * p.nh * (p.T / (G::WAVES * 32)))),
+                         dim3(G::WAVES * 64), G::LDS, st, p);
+      return launch_status();
+    }
     if (!bias) {
       S6D_GLB(2, ring);
     } else if (p.S == 64 && ring >= (size_t)WAVES * 16 * 80 * 4) {
-      S6D_GLB(1, ring + (size_t)WAVES * NS * 16 * 64 * 4);
+      S6D_GLB(1, ring + (size_t)WAVES * NS * 16 * S6D_GLB_THLD * 4);
     } else {
       S6D_GLB(0, ring + (size_t)WAVES * NS * 2 * 16 * p.LT * 4);
     }

@@ -65,3 +65,9 @@ def test_segment_seq_sum_and_centroid_path_on_the_emulator(emu, monkeypatch):
     assert out["kept"].tolist() == ref["kept"].tolist()
     np.testing.assert_array_equal(out["pts"].numpy(), ref["pts"])
     np.testing.assert_array_equal(out["rgb_choose"].numpy(), ref["rgb_choose"])
+
+
+def test_global_attention_on_the_64_grid_on_the_emulator(emu):
+    """SAM's global blocks: the 64 x 64 grid takes the aligned fast path of attn_global_kernel (MODE 1: one key row per 64-key
+    tile, th tables per query strip, tw in registers), which the small grids above never reach."""
+    T.test_fused_attention_vs_oracle(1, 64, 1, 80, 0)

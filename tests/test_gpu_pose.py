@@ -264,8 +264,8 @@ def test_cross_attention_and_linear_attention_vs_oracle(ops):
 def test_fine_match_properties_at_the_benched_size(ops):
     """B = 32, 2049 x 2049 (BASELINE configs[1]; too large for the CPU oracle in seconds): (1) against the other device
     formulation (library bmm -> s6d_fine_assign_f32, itself oracle-checked at small sizes): identical labels, weights 5e-5
-    relative; (2) equivariance: permuting the observed rows (background row kept) permutes the outputs and nothing else -- every
-    owner row is reduced on its own; (3) weights are probabilities mass: 0 <= wsum <= 1 + 1e-5, and rows labelled background
+    relative; (2) equivariance: permuting the observed rows (background row kept) permutes the outputs -- every owner row is reduced
+    on its own; (3) weights are probabilities mass: 0 <= wsum <= 1 + 1e-5, and rows labelled background
     carry exactly zero weight and a zero point."""
     g = torch.Generator().manual_seed(11)
     B, M = 32, 2049
@@ -281,7 +281,10 @@ def test_fine_match_properties_at_the_benched_size(ops):
     assert ((wsum - ws0).abs() <= 5e-5 * ws0.abs().clamp(min=1e-3)).all() and (pred - p0).abs().max() < 1e-4
     rp = torch.cat([torch.zeros(1, dtype=torch.long), 1 + torch.randperm(M - 1, generator=g)]).cuda()
     pred2, wsum2, w12 = ops.fine_match(f1[:, rp].contiguous(), f2, pts2, 0.1)
-    assert torch.equal(w12, w1[:, rp[1:] - 1]) and torch.equal(wsum2, wsum[:, rp[1:] - 1]) and torch.equal(pred2, pred[:, rp[1:] - 1])
+    # labels exactly; weights and points to fp32 rounding (a row's running-maximum updates are decided per 16-row strip, so the
+    # reference point of its exponentials, not their ratio, depends on its neighbours)
+    assert torch.equal(w12, w1[:, rp[1:] - 1])
+    assert torch.allclose(wsum2, wsum[:, rp[1:] - 1], rtol=2e-5, atol=1e-7) and torch.allclose(pred2, pred[:, rp[1:] - 1], rtol=2e-5, atol=2e-6)
     assert (wsum >= 0).all() and (wsum <= 1 + 1e-5).all()
     off = w1 == 0
     assert (wsum[off] == 0).all() and (pred[off] == 0).all()

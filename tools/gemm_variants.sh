@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 OUT=tools/gemm_variants
 mkdir -p $OUT
-FLAGS="-O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form -Wno-unused-function"
+FLAGS="-O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form -Wno-unused-function -Wno-inline-asm"
 build() { /opt/rocm/bin/hipcc $FLAGS $2 -o $OUT/libgemm_$1.so sam6d_amd/csrc/s6d_gemm.hip sam6d_amd/csrc/s6d_capi.hip & }
 build base ""
 build nomfma "-DS6D_GEMM_ABLATE=2"

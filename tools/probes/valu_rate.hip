@@ -11,6 +11,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define EXP(x) asm volatile("v_exp_f32 %0, %0" : "+v"(x))
 #define MAX3(x, y, z) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(x) : "v"(y), "v"(z))
 #define CVT(d, x, y) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y))
+#define PKFMA(x2) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(x2) : "v"(kk0), "v"(kk1))
+#define PKADD(x2) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(x2) : "v"(kk1))
 #define MFMA(acc) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 
 template <int MODE>
@@ -24,6 +26,9 @@ __global__ void probe(float *out, int iters) {
   bf16x8 a, b;
   for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(threadIdx.x * 0.01f); b[i] = (__bf16)(i * 0.5f); }
   unsigned cv = 0;
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  f32x2 y[8], kk0 = {0.999f, 0.999f}, kk1 = {0.001f, 0.001f};
+  for (int i = 0; i < 8; ++i) y[i] = f32x2{x[2 * i], x[2 * i + 1]};
   for (int it = 0; it < iters; ++it) {
     if (MODE == 0) {
 #pragma unroll
@@ -64,6 +69,36 @@ __global__ void probe(float *out, int iters) {
         FMA(x[2 * i]); FMA(x[2 * i + 1]); FMA(x[(2 * i + 4) & 15]); FMA(x[(2 * i + 5) & 15]); FMA(x[(2 * i + 8) & 15]);
         FMA(x[(2 * i + 9) & 15]);
       }
+    } else if (MODE == 12) {                           // 16 packed fma (32 values)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) PKFMA(y[i]);
+    } else if (MODE == 13) {                           // mfma + 2 packed fma
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { MFMA(acc[i]); PKFMA(y[i]); PKFMA(y[(i + 4) & 7]); }
+    } else if (MODE == 14) {                           // 16 packed add
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) PKADD(y[i]);
+    } else if (MODE == 15) {                           // per MFMA: the softmax mix of attn_global64 today (2/3 fma, 2/3 sub, 2/3 exp, 1/3 cvt, 1/2 max)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        MFMA(acc[i]);
+        if (i % 3 != 2) { FMA(x[i]); FMA(x[i + 6]); EXP(x[i + 1]); } else { FMA(x[i]); EXP(x[i + 1]); EXP(x[i + 2]); }
+        if (i % 3 == 0) { unsigned d; CVT(d, x[i], x[i + 1]); cv ^= d; }
+        if (i % 2 == 0) MAX3(x[i + 3], x[i + 4], x[i + 5]);
+      }
+    } else if (MODE == 16) {                           // the reduced mix: packed fma, no separate subtraction (1/3 pk_fma, 2/3 exp, 1/3 cvt, 1/2 max)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        MFMA(acc[i]);
+        if (i % 3 == 0) PKFMA(y[i]);
+        if (i % 3 != 2) EXP(x[i + 1]); else { EXP(x[i + 1]); EXP(x[i + 2]); }
+        if (i % 3 == 0) { unsigned d; CVT(d, x[i], x[i + 1]); cv ^= d; }
+        if (i % 2 == 0) MAX3(x[i + 3], x[i + 4], x[i + 5]);
+      }
     } else if (MODE == 11) {                           // 48 fma (the VALU part of mode 10 alone)
 #pragma unroll
       for (int j = 0; j < 3; ++j)
@@ -73,7 +108,7 @@ __global__ void probe(float *out, int iters) {
   }
   float s = (float)cv;
   for (int i = 0; i < 16; ++i) s += x[i];
-  for (int i = 0; i < 8; ++i) s += acc[i][0];
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + y[i][0] + y[i][1];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s + smem[threadIdx.x & 15];
 }
 
@@ -112,6 +147,11 @@ int main() {
     run<9>("16 cvt_pk(+xor)", threads, 0, 32);
     run<10>("8x(mfma,6fma)", threads, 8, 48);
     run<11>("48 fma", threads, 0, 48);
+    run<12>("16 pk_fma", threads, 0, 16);
+    run<13>("8x(mfma,2pk_fma)", threads, 8, 16);
+    run<14>("16 pk_add", threads, 0, 16);
+    run<15>("6x(mfma,softmax mix)", threads, 6, 18);
+    run<16>("6x(mfma,reduced mix)", threads, 6, 11);
   }
   return 0;
 }

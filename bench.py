@@ -204,7 +204,37 @@ def _event_ms(fn, n):
     return e0.elapsed_time(e1) / n
 
 
-def kernel_rooflines(dev, sam_chunk, frames):
+def gemm_ms_inside_the_step(hp):
+    """Average duration of every s6d_gemm_bf16 launch of ONE SAM stage pass, by shape, from HIP events recorded around the launches
+    on the stream they run on -- the kernel in the context the step runs it in (between the attention / LayerNorm launches of its
+    block, at the clocks of that mix), which is what the rocprofv3 kernel trace of the same command averages
+    (profiles/r02_bench_serial_kernel_stats.csv).  Back-to-back launches of one shape on random operands (kernel_rooflines below)
+    hold the socket at its power limit and come out 10-15 % slower."""
+    from sam6d_amd import ops
+    real = ops.gemm_bf16
+    rec = []
+
+    def timed(a, w, bias=None, gelu=False, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = real(a, w, bias, gelu=gelu, **kw)
+        e1.record()
+        rec.append(((a.numel() // a.shape[-1], a.shape[-1], w.shape[0], bool(gelu)), e0, e1))
+        return y
+    hp.sam_stage()                                          # warm
+    ops.gemm_bf16 = timed
+    try:
+        hp.sam_stage()
+    finally:
+        ops.gemm_bf16 = real
+    torch.cuda.synchronize()
+    by = {}
+    for key, e0, e1 in rec:
+        by.setdefault(key, []).append(e0.elapsed_time(e1))
+    return {k: (sum(v) / len(v), len(v)) for k, v in by.items()}
+
+
+def kernel_rooflines(dev, sam_chunk, frames, in_step=None):
     """Per-launch roofline of the hand-written kernels at the exact shapes the step uses, timed with HIP events on
     torch's current stream (the stream every s6d_* kernel is launched on).  Algorithmic work per launch:
       attn_global   4*T^2*hd*nh*Bc FLOP (QK^T + PV), T = 4096, hd = 80, nh = 16, Bc = frames per SAM chunk
@@ -281,10 +311,13 @@ def kernel_rooflines(dev, sam_chunk, frames):
         b = torch.randn(N, generator=g).to(dev)
         if not ops.have("gemm_bf16"):
             break
-        ms = _event_ms(lambda: ops.gemm_bf16(x, w, b, gelu=gelu), 10)
+        b2b = _event_ms(lambda: ops.gemm_bf16(x, w, b, gelu=gelu), 10)
+        # avg_ms: inside the step (gemm_ms_inside_the_step) when the caller measured it; back_to_back_ms: 10 launches of this shape alone
+        ms = in_step[(M, K, N, gelu)][0] if in_step and (M, K, N, gelu) in in_step else b2b
         flop = 2.0 * M * N * K
         out.append({"kernel": f"gemm_bf16_kernel ({nm}, M={M} K={K} N={N})", "bound": "mfma", "achieved": round(flop / ms / 1e9, 1),
                     "peak": 2500.0, "unit": "TFLOP/s", "frac": round(flop / ms / 1e9 / 2500.0, 4), "avg_ms": round(ms, 4),
+                    "back_to_back_ms": round(b2b, 4), "timed": "inside one SAM stage pass" if ms is not b2b else "back to back",
                     "launches_per_step": 32 * groups, "algorithmic_bytes": 2.0 * (M * K + N * K + M * N),
                     # the GELU instance runs at this one shape only; qkv / proj / lin2 share an instance (no per-shape counters)
                     "pmc_key": "gemm_bf16_kernel<1, true>" if gelu else "-"})
@@ -421,7 +454,7 @@ def main():
         pem_ms = stage_ms(hp.pem_stage, 1)
         achieved = SAM_FLOP_PER_FRAME * args.frames / (sam_ms * 1e-3)
         extra["stages_ms"] = {"sam_encoder": round(sam_ms, 2), "ism_scoring": round(ism_ms, 2), "pem": round(pem_ms, 2)}
-        kr = kernel_rooflines(dev, args.sam_chunk, args.frames)
+        kr = kernel_rooflines(dev, args.sam_chunk, args.frames, gemm_ms_inside_the_step(hp))
         dom = max((k for k in kr if not k["kernel"].startswith("library")),
                   key=lambda k: k["avg_ms"] * k["launches_per_step"])
         # the dominant kernel of the step (largest avg duration x launches per step) -- since round 2 the hand-written bf16 GEMM;

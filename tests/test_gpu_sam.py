@@ -75,8 +75,8 @@ def test_vit_h_block_bf16_hip_path_vs_oracle_block(index):
     window (index 0) or 64 x 64 global (index 7) attention kernel) against oracle.sam.block -- the statement of Block.forward that
     tests/test_oracle_golden.py pins to the reference -- evaluated in fp32 on the SAME bf16-rounded input, GEMM weights and
     position tables.  What is left is the path's own rounding: activations are stored in bf16 between its six stages (2^-9
-    relative each), sums are fp32.  Bound: rms error <= 4e-3 of the output rms, no element off by more than 2^-5 of the largest
-    output (a ranking-level statement the whole-encoder correlation test cannot make)."""
+    relative each), sums are fp32.  Bound: rms error <= 4e-3 of the output rms (measured 2.7e-3), no element off by more than 2^-6 of the
+    largest output (measured 5.4e-3) -- an element-level statement the whole-encoder correlation test cannot make."""
     from sam6d_amd.sam.image_encoder import build_vit_h
     m = seeded.load_seeded(build_vit_h().eval(), 3)
     blk = m.blocks[index]
@@ -97,5 +97,5 @@ def test_vit_h_block_bf16_hip_path_vs_oracle_block(index):
             out = m._blocks_fused(x.cuda(), None).float().cpu()
     err = (out - ref).abs()
     rms = ref.pow(2).mean().sqrt()
-    assert err.pow(2).mean().sqrt() <= 4e-3 * rms and err.max() <= 2.0 ** -5 * ref.abs().max(), \
+    assert err.pow(2).mean().sqrt() <= 4e-3 * rms and err.max() <= 2.0 ** -6 * ref.abs().max(), \
         (float(err.pow(2).mean().sqrt() / rms), float(err.max() / ref.abs().max()))

@@ -397,6 +397,42 @@ def cpu_baseline():
                       f"({t_pem:.2f}s/instance; runs {'/'.join(f'{t / 2:.2f}' for t in pem_runs)}), fp32 torch CPU oracle"}
 
 
+def _extras(extra, hp, dev, args, world):
+    """Stage split, per-kernel rooflines, whole-frame block and CPU baseline: rank 0, outside the timed region."""
+    sam_ms = stage_ms(hp.sam_stage, 1)
+    ism_ms = stage_ms(hp.ism_stage, 1)
+    pem_ms = stage_ms(hp.pem_stage, 1)
+    achieved = SAM_FLOP_PER_FRAME * args.frames / (sam_ms * 1e-3)
+    extra["stages_ms"] = {"sam_encoder": round(sam_ms, 2), "ism_scoring": round(ism_ms, 2), "pem": round(pem_ms, 2)}
+    kr = kernel_rooflines(dev, args.sam_chunk, args.frames, gemm_ms_inside_the_step(hp))
+    dom = max((k for k in kr if not k["kernel"].startswith("library")),
+              key=lambda k: k["avg_ms"] * k["launches_per_step"])
+    # the dominant kernel of the step (largest avg duration x launches per step) -- since round 2 the hand-written bf16 GEMM;
+    # the library GEMM is listed in `kernels` for comparison only (it is not on the path)
+    extra["roofline"] = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"],
+                         "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
+                         "avg_launch_ms": dom["avg_ms"], "traffic": _pmc_traffic(dom)}
+    if "algorithmic_bytes" in dom:
+        extra["roofline"]["algorithmic_bytes"] = dom["algorithmic_bytes"]
+    extra["kernels"] = kr
+    extra["stage_roofline"] = {"stage": f"SAM ViT-H encoder, {args.frames} frames (bf16 GEMMs + fused attention)",
+                               "bound": "mfma", "achieved": round(achieved / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12,
+                               "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK, 4)}
+    if world == 1 and not args.no_pipeline:
+        # what a whole frame costs (VERDICT r1 item 6): every stage of the chain incl. mask decoding, DINOv2 descriptors and the PEM
+        # pre-processing, K = 10 instances per frame; outside the timed region, reported next to the headline
+        try:
+            hp.__dict__.clear()                                   # release the step's models before the five-model chain is built
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import frame_demo
+            extra["pipeline"] = frame_demo.measure(dev)
+        except Exception as e:  # noqa: BLE001
+            extra["pipeline"] = {"error": f"{type(e).__name__}: {e}"}
+    if world == 1 and not args.no_cpu_baseline:
+        extra["cpu_baseline"] = cpu_baseline()
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
@@ -449,38 +485,10 @@ def main():
     # stage breakdown + roofline of the dominant stage (rank 0 only; outside the timed region)
     extra = {}
     if rank == 0:
-        sam_ms = stage_ms(hp.sam_stage, 1)
-        ism_ms = stage_ms(hp.ism_stage, 1)
-        pem_ms = stage_ms(hp.pem_stage, 1)
-        achieved = SAM_FLOP_PER_FRAME * args.frames / (sam_ms * 1e-3)
-        extra["stages_ms"] = {"sam_encoder": round(sam_ms, 2), "ism_scoring": round(ism_ms, 2), "pem": round(pem_ms, 2)}
-        kr = kernel_rooflines(dev, args.sam_chunk, args.frames, gemm_ms_inside_the_step(hp))
-        dom = max((k for k in kr if not k["kernel"].startswith("library")),
-                  key=lambda k: k["avg_ms"] * k["launches_per_step"])
-        # the dominant kernel of the step (largest avg duration x launches per step) -- since round 2 the hand-written bf16 GEMM;
-        # the library GEMM is listed in `kernels` for comparison only (it is not on the path)
-        extra["roofline"] = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"],
-                             "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
-                             "avg_launch_ms": dom["avg_ms"], "traffic": _pmc_traffic(dom)}
-        if "algorithmic_bytes" in dom:
-            extra["roofline"]["algorithmic_bytes"] = dom["algorithmic_bytes"]
-        extra["kernels"] = kr
-        extra["stage_roofline"] = {"stage": f"SAM ViT-H encoder, {args.frames} frames (bf16 GEMMs + fused attention)",
-                                   "bound": "mfma", "achieved": round(achieved / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12,
-                                   "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK, 4)}
-        if world == 1 and not args.no_pipeline:
-            # what a whole frame costs: every stage of the chain incl. mask decoding, DINOv2 descriptors and the PEM
-            # pre-processing, K = 10 instances per frame; outside the timed region, reported next to the headline
-            try:
-                del hp
-                torch.cuda.empty_cache()
-                sys.path.insert(0, os.path.join(ROOT, "tools"))
-                import frame_demo
-                extra["pipeline"] = frame_demo.measure(dev)
-            except Exception as e:  # noqa: BLE001
-                extra["pipeline"] = {"error": f"{type(e).__name__}: {e}"}
-        if world == 1 and not args.no_cpu_baseline:
-            extra["cpu_baseline"] = cpu_baseline()
+        try:
+            _extras(extra, hp, dev, args, world)
+        except Exception as e:  # noqa: BLE001  (the headline line must come out even if a side measurement fails)
+            extra["extras_error"] = f"{type(e).__name__}: {e}"
 
     if rank == 0:
         line = {"metric": "RGB-D frames/sec (SAM-6D per-frame hot path: SAM ViT-H encoder + ISM scoring + PEM)",

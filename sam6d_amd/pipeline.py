@@ -68,17 +68,19 @@ class FramePipeline:
         """image_u8 (H,W,3) uint8 RGB, depth (H,W) f32 metres, K (3,3) float64, all on the device.  sample_keys
         (top_k, H*W) / coarse_rand_u (top_k, 18000): the injected random numbers of the two sampling steps.
         -> (Detections of the frame, dict(pred_R, pred_t, pred_pose_score, kept))."""
+        return self.run_group([(image_u8, depth, K, sample_keys, coarse_rand_u)])[0]
+
+    def _embed(self, images):
+        """SAM image encoder on a group of equally sized frames in ONE pass -> (F,256,64,64) f32."""
+        rs = ResizeLongestSide(self.enc.img_size)
+        x = torch.stack([rs.apply_image(im).permute(2, 0, 1) for im in images]).float()
+        return self.enc(sam_preprocess(x, self.enc.img_size)).float()
+
+    def _detect(self, emb, image_u8, depth, K):
+        """proposals -> descriptors -> scores -> the frame's Detections, best first (None-free: an empty Detections when nothing
+        survives).  emb: this frame's (1,256,64,64) embedding."""
         H, W = image_u8.shape[:2]
-        n_keys = sample_keys.shape[0]
-        if self.top_k is not None and (n_keys < self.top_k or coarse_rand_u.shape[0] < self.top_k):
-            raise ValueError(f"sample_keys / coarse_rand_u need one row per detection handed to the PEM (top_k={self.top_k}); "
-                             f"got {n_keys} / {coarse_rand_u.shape[0]}")
         t0 = time.perf_counter()
-        # ---- SAM image encoder ------------------------------------------------------------------------------------
-        x = ResizeLongestSide(self.enc.img_size).apply_image(image_u8).permute(2, 0, 1)[None].float()
-        emb = self.enc(sam_preprocess(x, self.enc.img_size)).float()
-        t0 = self._tick("sam_encoder", t0)
-        # ---- proposals ----------------------------------------------------------------------------------------------
         prop = amg.generate_proposals(self.pe, self.md, emb, (H, W), self.enc.img_size, points_per_batch=self.ppb,
                                       **self.seg_kw)
         area = prop["masks"].flatten(1).sum(1).float() / (H * W)
@@ -92,8 +94,7 @@ class FramePipeline:
         masks, boxes = prop["masks"][keep], prop["boxes"][keep]
         t0 = self._tick("proposals", t0)
         if masks.shape[0] == 0:
-            return Detections(0, 0, masks, boxes, boxes.new_zeros(0), boxes.new_zeros(0)), None
-        # ---- descriptors + scoring -----------------------------------------------------------------------------------
+            return Detections(0, 0, masks, boxes, boxes.new_zeros(0), boxes.new_zeros(0))
         cls, patch = self.desc(image_u8, SimpleNamespace(masks=masks.float(), boxes=boxes))      # device frame: no host round trip
         t0 = self._tick("descriptors", t0)
         sc = self.score_metres(cls, patch, masks.float(), boxes.float(), depth, K)
@@ -107,34 +108,70 @@ class FramePipeline:
             det.filter(det.scores > self.det_thresh)
         if self.top_k is not None:
             det.filter(slice(0, self.top_k))
-        if len(det) == 0:
-            self._tick("scoring", t0)
-            return det, None
-        t0 = self._tick("scoring", t0)
-        # ---- PEM ------------------------------------------------------------------------------------------------------
+        self._tick("scoring", t0)
+        return det
+
+    @torch.no_grad()
+    def run_group(self, frames):
+        """A group of frames through the chain with the batch where the models want it: ONE SAM encoder pass over the group's frames,
+        proposals / descriptors / scores frame by frame (1024 prompts and ~128 crops are a full batch already), the PEM's
+        pre-processing frame by frame and ONE PEM pass over the instances of the whole group (10 instances per frame leave
+        the point transformer launch-bound; 32 fill it).  frames: list of (image_u8, depth, K, sample_keys, coarse_rand_u) as in
+        ``__call__``, all of one size.  -> list of (Detections, poses-or-None) per frame, the same values frame-by-frame calls
+        give (a row of a batch does not depend on its neighbours in any kernel of this library; the library's fp32 GEMMs may
+        pick another tile shape for another batch size: last-bit differences in the PEM outputs)."""
+        for (_, _, _, keys, ru) in frames:
+            if self.top_k is not None and (keys.shape[0] < self.top_k or ru.shape[0] < self.top_k):
+                raise ValueError(f"sample_keys / coarse_rand_u need one row per detection handed to the PEM (top_k={self.top_k}); "
+                                 f"got {keys.shape[0]} / {ru.shape[0]}")
+        t0 = time.perf_counter()
+        emb = self._embed([f[0] for f in frames])
+        t0 = self._tick("sam_encoder", t0)
+        dets = [self._detect(emb[i:i + 1], f[0], f[1], f[2]) for i, f in enumerate(frames)]
+        # ---- PEM: pre-processing per frame, one batch for the group ------------------------------------------------------------
+        t0 = time.perf_counter()
         multi = self.tpl["model"].shape[0] > 1                          # per-object template data, indexed by predicted object
-        radius = self.radius
-        if torch.is_tensor(radius) and radius.numel() > 1:
-            radius = radius.to(det.object_ids.device)[det.object_ids.long()]
-        if len(det) > sample_keys.shape[0] or len(det) > coarse_rand_u.shape[0]:
-            raise ValueError(f"{len(det)} detections go to the PEM but sample_keys / coarse_rand_u have "
-                             f"{sample_keys.shape[0]} / {coarse_rand_u.shape[0]} rows (top_k=None keeps every detection)")
-        obs = pem_pre.observed_inputs(image_u8, depth, K, det.masks, radius, sample_keys[: det.masks.shape[0]])
+        obs_l, oid_l, ru_l, count = [], [], [], []
+        for det, (image_u8, depth, K, sample_keys, coarse_rand_u) in zip(dets, frames):
+            n = 0
+            if len(det):
+                radius = self.radius
+                if torch.is_tensor(radius) and radius.numel() > 1:
+                    radius = radius.to(det.object_ids.device)[det.object_ids.long()]
+                if len(det) > sample_keys.shape[0] or len(det) > coarse_rand_u.shape[0]:
+                    raise ValueError(f"{len(det)} detections go to the PEM but sample_keys / coarse_rand_u have "
+                                     f"{sample_keys.shape[0]} / {coarse_rand_u.shape[0]} rows (top_k=None keeps every detection)")
+                obs = pem_pre.observed_inputs(image_u8, depth, K, det.masks, radius, sample_keys[: det.masks.shape[0]])
+                n = obs["pts"].shape[0]
+                if n:
+                    obs_l.append(obs)
+                    oid_l.append(det.object_ids[obs["kept"]].long())
+                    ru_l.append(coarse_rand_u[:n])
+            count.append(n)
         t0 = self._tick("pem_preprocessing", t0)
-        M = obs["pts"].shape[0]
+        M = sum(count)
         if M == 0:
-            return det, None
-        oid = det.object_ids[obs["kept"]].long()
+            return [(det, None) for det in dets]
+        oid = torch.cat(oid_l)
 
         def tpl(name):                                                  # test_bop.py:145-147 picks dense_po[obj] / dense_fo[obj]
             t = self.tpl[name]
             return (t[oid] if multi else t.expand(M, -1, -1)).contiguous()
-        ep = dict(pts=obs["pts"], rgb=obs["rgb"], rgb_choose=obs["rgb_choose"], model=tpl("model"), dense_po=tpl("dense_po"),
-                  dense_fo=tpl("dense_fo"), coarse_rand_u=coarse_rand_u[:M])
+        cat = (lambda k: obs_l[0][k]) if len(obs_l) == 1 else (lambda k: torch.cat([o[k] for o in obs_l]))
+        ep = dict(pts=cat("pts"), rgb=cat("rgb"), rgb_choose=cat("rgb_choose"), model=tpl("model"), dense_po=tpl("dense_po"),
+                  dense_fo=tpl("dense_fo"), coarse_rand_u=ru_l[0] if len(ru_l) == 1 else torch.cat(ru_l))
         out = self.pem(ep)
         self._tick("pem", t0)
-        return det, dict(pred_R=out["pred_R"], pred_t=out["pred_t"], pred_pose_score=out["pred_pose_score"],
-                         kept=obs["kept"])
+        res, at, k = [], 0, 0
+        for det, n in zip(dets, count):
+            if n == 0:
+                res.append((det, None))
+                continue
+            res.append((det, dict(pred_R=out["pred_R"][at:at + n], pred_t=out["pred_t"][at:at + n],
+                                  pred_pose_score=out["pred_pose_score"][at:at + n], kept=obs_l[k]["kept"])))
+            at += n
+            k += 1
+        return res
 
 
 def frame_results(det, poses, dataset_name, time_s=0.0):

@@ -69,3 +69,18 @@ def run_frame(dev):
     eye = torch.eye(3, dtype=torch.float64, device=dev).expand(M, 3, 3)
     assert torch.allclose(R @ R.transpose(1, 2), eye, atol=1e-4) and torch.allclose(torch.linalg.det(R), torch.ones(M, dtype=torch.float64, device=dev), atol=1e-4)
     assert torch.isfinite(poses["pred_t"]).all() and torch.isfinite(poses["pred_pose_score"]).all()
+    # ---- a group of frames: one encoder pass and one PEM pass for the group, the same detections and poses as frame-by-frame calls
+    img2 = img.flip(1).contiguous()
+    depth2 = (depth + 0.02).contiguous()
+    keys2, ru2 = keys.flip(0).contiguous(), rand_u.flip(0).contiguous()
+    single = [pipe(img, depth, K, keys, rand_u), pipe(img2, depth2, K, keys2, ru2)]
+    group = pipe.run_group([(img, depth, K, keys, rand_u), (img2, depth2, K, keys2, ru2)])
+    assert len(group) == 2
+    for (d1, p1), (d2, p2) in zip(single, group):
+        assert torch.equal(d1.masks, d2.masks) and torch.equal(d1.boxes, d2.boxes) and torch.equal(d1.object_ids, d2.object_ids)
+        assert torch.allclose(d1.scores, d2.scores, rtol=1e-5, atol=1e-6)
+        assert (p1 is None) == (p2 is None)
+        if p1 is not None:
+            assert torch.equal(p1["kept"], p2["kept"])
+            assert torch.allclose(p1["pred_R"], p2["pred_R"], atol=2e-3) and torch.allclose(p1["pred_t"], p2["pred_t"], atol=2e-3)
+            assert torch.allclose(p1["pred_pose_score"], p2["pred_pose_score"], atol=2e-3)

@@ -88,9 +88,20 @@ def measure(dev, n_frames=8, points_per_batch=1024, top_k=10):
             pipe(*args)
     torch.cuda.synchronize()
     multi_ms = (time.perf_counter() - t) * 1e3 / (2 * n_frames)
+    # (d) groups of 8 frames (FramePipeline.run_group): one encoder pass and one PEM pass (80 instances) per group
+    group = 8
+    g_args = [args] * group
+    pipe.run_group(g_args)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(max(1, n_frames // group)):
+        pipe.run_group(g_args)
+    torch.cuda.synchronize()
+    group_ms = (time.perf_counter() - t) * 1e3 / (max(1, n_frames // group) * group)
     return {"workload": f"one 640x480 RGB-D frame through SAM ViT-H encoder + 1024-prompt mask decoding + DINOv2 ViT-L/14 descriptors of "
                         f"P=128 proposals + ISM scoring + PEM pre-processing + PEM for K={top_k} instances (SURVEY 8d frame definition)",
-            "frames_per_s": round(1e3 / min(free_ms, multi_ms), 2), "ms_per_frame": round(free_ms, 2),
+            "frames_per_s": round(1e3 / min(free_ms, multi_ms, group_ms), 2), "ms_per_frame": round(free_ms, 2),
+            "ms_per_frame_in_groups_of_8": round(group_ms, 2),
             "ms_per_frame_on_4_streams": round(multi_ms, 2),
             "ms_per_frame_stage_synchronised": round(sync_ms, 2), "stages_ms": stages,
             "detections": int(det.masks.shape[0]), "poses": 0 if poses is None else int(poses["pred_R"].shape[0])}

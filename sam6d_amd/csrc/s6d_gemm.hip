@@ -832,7 +832,9 @@ extern "C" int s6d_gemm_bf16(const void *A, long lda, const void *W, long ldw, c
 
 extern "C" int s6d_gemm_bf16_cblk(const void *A, long lda, const void *W, long ldw, const float *bias, void *C, long ldc, int M,
                                   int N, int K, int epilogue, int col_block, int max_blocks, void *stream) {
-  if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return S6D_EINVAL;
+  if (M < 0 || N <= 0 || K <= 0) return S6D_EINVAL;
+  if (M == 0) return S6D_OK;                                            // an empty row batch: nothing to launch
+  if (!A || !W || !C) return S6D_EINVAL;
   if (col_block < 0 || (col_block % 8) != 0 || (col_block > 0 && N % col_block != 0)) return S6D_EINVAL;
   if (col_block > 0 && (N % 256 != 0 || !S6D_GEMM_QT)) return S6D_EUNSUPPORTED;   // the quad-transposed epilogue of the 256 x 256 kernel
   if (N % 128 != 0 || K % 64 != 0 || lda < K || ldw < K || ldc < N) return S6D_EINVAL;

@@ -128,3 +128,51 @@ def test_next_row_entry_points_reject_bad_arguments_and_accept_empty_batches(ops
         ops.samdec_tok2img(torch.zeros(2, 9, 128, device="cuda"), torch.zeros(2, 64, 256, device="cuda", dtype=torch.bfloat16),
                            0, 128, None, 0.25)
 
+
+
+def test_round2_entry_points_reject_bad_arguments_and_accept_empty_batches(ops):
+    """C-ABI argument checks of the entry points added in round 2 (GEMM, fused fine matching, coarse hypothesis kernels, the
+    frame-batched ISM calls): empty batches return S6D_OK without touching a pointer, malformed shapes / NULL operands / misaligned
+    rows are refused, nothing is launched; and the Python mirrors raise."""
+    import ctypes
+
+    from sam6d_amd import _lib
+    L = _lib.lib()
+    null, one = ctypes.c_void_p(0), ctypes.c_float(10.0)
+    lg = ctypes.c_long
+    L.s6d_fine_match_workspace_bytes.restype = ctypes.c_long
+    ok = [
+        L.s6d_gemm_bf16(null, lg(1280), null, lg(1280), null, null, lg(1280), 0, 1280, 1280, 0, 0, null),
+        L.s6d_fine_match_f32(null, null, null, 0, 2049, 2049, 256, one, null, null, null, null, null),
+        L.s6d_coarse_sample_f32(null, null, 0, 197, 197, 18000, null, null, null),
+        L.s6d_smallest_k_f32(null, null, null, 0, 6000, 300, null, null, null, null),
+        L.s6d_hypothesis_select_f32(null, null, null, null, 0, 300, 196, null, null, null),
+        L.s6d_masked_depth_mean_frames_f32(null, null, null, 0, 480, 640, ctypes.c_float(1.0), null, null, null, null),
+    ]
+    assert all(rc == 0 for rc in ok), ok
+    assert L.s6d_fine_match_workspace_bytes(32, 2049, 2049) > 0
+    buf = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    p = ctypes.c_void_p(buf.data_ptr())
+    bad = [
+        L.s6d_gemm_bf16(p, lg(1280), p, lg(1280), null, p, lg(1280), 16, 1280, 1290, 0, 0, null),        # K % 64
+        L.s6d_gemm_bf16(p, lg(1280), p, lg(1280), null, p, lg(1280), 16, 1000, 1280, 0, 0, null),        # N % 128
+        L.s6d_gemm_bf16(p, lg(1276), p, lg(1280), null, p, lg(1280), 16, 1280, 1280, 0, 0, null),        # row stride not 16-byte
+        L.s6d_gemm_bf16(p, lg(1280), p, lg(1280), null, p, lg(1280), 16, 1280, 1280, 2, 0, null),        # unknown epilogue
+        L.s6d_gemm_bf16(null, lg(1280), p, lg(1280), null, p, lg(1280), 16, 1280, 1280, 0, 0, null),     # NULL operand, M > 0
+        L.s6d_gemm_bf16_cblk(p, lg(1280), p, lg(1280), null, p, lg(1280), 16, 1280, 1280, 0, 60, 0, null),   # column block % 8
+        L.s6d_fine_match_f32(p, p, p, 1, 1, 2049, 256, one, p, p, p, p, null),                           # no observed row
+        L.s6d_fine_match_f32(p, p, p, 1, 2049, 2049, 128, one, p, p, p, p, null),                        # feature width
+        L.s6d_fine_match_f32(p, p, p, 1, 2049, 2049, 256, ctypes.c_float(0.0), p, p, p, p, null),        # temperature
+        L.s6d_fine_match_f32(p, p, p, 1, 2049, 2049, 256, one, null, p, p, p, null),                     # no workspace
+        L.s6d_coarse_sample_f32(p, p, 1, 1, 197, 18000, p, p, null),
+        L.s6d_coarse_sample_f32(null, p, 1, 197, 197, 18000, p, p, null),
+        L.s6d_smallest_k_f32(p, p, p, 1, 100, 300, p, p, p, null),                                       # k > n
+        L.s6d_hypothesis_select_f32(p, p, p, p, 1, 0, 196, p, p, null),
+    ]
+    assert all(rc != 0 for rc in bad), bad
+    with pytest.raises(RuntimeError):
+        ops.gemm_bf16(torch.zeros(4, 100, device="cuda", dtype=torch.bfloat16), torch.zeros(128, 100, device="cuda", dtype=torch.bfloat16))
+    with pytest.raises(RuntimeError):
+        ops.gemm_bf16(torch.zeros(4, 128, device="cuda"), torch.zeros(128, 128, device="cuda", dtype=torch.bfloat16))      # fp32 activations
+    y = ops.gemm_bf16(torch.zeros(0, 128, device="cuda", dtype=torch.bfloat16), torch.zeros(256, 128, device="cuda", dtype=torch.bfloat16))
+    assert y.shape == (0, 256)

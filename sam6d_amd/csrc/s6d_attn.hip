@@ -82,6 +82,11 @@ constexpr int kAbl = S6D_ATTN_ABLATE;
 #ifndef S6D_GLB_PRIO
 #define S6D_GLB_PRIO 1
 #endif
+#ifndef S6D_WIN16_KSWZ
+#define S6D_WIN16_KSWZ 0             // the same chunk swizzle on the persistent window kernel's compact K image (11-chunk rows): measured
+                                     // 0.265 ms against 0.260 ms without it (16 frames, one process) -- that kernel waits on its fetches,
+                                     // and the swizzled source addresses split each token's 160-byte run into swapped 16-byte pieces
+#endif
 #ifndef S6D_GLB64_DEFAULT_IMPL
 #define S6D_GLB64_DEFAULT_IMPL 2     // 64 x 64 grid: 2 = attn_global64_kernel (LDS-DMA ring), 1 = attn_global_kernel (register staged)
 #endif
@@ -628,7 +633,7 @@ struct Win16NoMid {
 };
 // KROWT: K image row stride (elements); MID: called half way through the PV pass (the Q fragments are dead since the score pass,
 // and by then half of the score registers are free).
-template <int HD, int NS, int SRC, bool EXACT, int KROWT = Cfg<HD>::KROW, class MID = Win16NoMid>
+template <int HD, int NS, int SRC, bool EXACT, int KROWT = Cfg<HD>::KROW, bool KSWZ = false, class MID = Win16NoMid>
 __device__ __forceinline__ void win16_pass(const AttnParams &p, const u16 *Kl, const u16 *Vl, int S, int SR, int b,
                                            int wy, int wx, int head, int qy0, int rstride,
                                            const bf16x8 (&qf)[NS][Cfg<HD>::KS], const float (*twr)[4],
@@ -641,11 +646,13 @@ __device__ __forceinline__ void win16_pass(const AttnParams &p, const u16 *Kl, c
 #pragma unroll
   for (int n = 0; n < NS; ++n) m[n] = -1e29f;                     // finite even if a whole strip is padding
   bf16x8 kf[2][C::KS];
+  // compact (LDS-DMA staged) images keep the chunk pairs of rows with (kx >> 2 ^ kx >> 3) & 1 swapped (S6D_GLB_KSWZ above; kx = c here)
+  const int gk = KSWZ ? (g ^ kswz(c)) : g;
   auto kload = [&](int ky, bf16x8 (&dst)[C::KS]) {
     const int kyc = EXACT ? ky : min(ky, SR - 1);                   // rows >= SR are not staged: re-read a staged one
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) {
-      dst[ks] = *reinterpret_cast<const bf16x8 *>(Kl + (kyc * 16 + c) * KROWT + ks * 32 + g * 8);
+      dst[ks] = *reinterpret_cast<const bf16x8 *>(Kl + (kyc * 16 + c) * KROWT + ks * 32 + gk * 8);
       // compact K rows (KROWT < padded head dim): the k range past HD is not staged -- the lane reads into the next row and
       // the fragment is zeroed here (the matching Q fragment is zero too, but 0 x a stray Inf would not be)
       if (KROWT < C::HDP && ks * 32 + 32 > HD && ks * 32 + g * 8 >= HD) {
@@ -914,8 +921,9 @@ __global__ __launch_bounds__(512) void attn_window16p_kernel(AttnParams p, int n
     const int rowch = which == 1 ? KCH : VCH, ninstr = which == 1 ? kinstr : vinstr, nch = which == 1 ? kchunks : vchunks;
     for (int k = wave; k < ninstr; k += WAVES) {
       const int j = min((k << 6) + lane, nch - 1);                  // chunk of the image (tail lanes repeat the last chunk's source)
-      const int slot = j / rowch, part = j - slot * rowch;
+      const int slot = j / rowch, pp = j - slot * rowch;
       const int ky = slot >> 4, kx = slot & 15;
+      const int part = (S6D_WIN16_KSWZ && which == 1 && pp * 8 < HD) ? pp ^ kswz(kx) : pp;     // K: chunk pairs swapped on the source side
       const int y = it.wy * p.ws + ky, x = it.wx * p.ws + kx;
       const bool inwin = ky < S && kx < S && part * 8 < HD, img = (y < p.H) && (x < p.W);
       const size_t tokc = (size_t)(it.b * p.H + min(y, p.H - 1)) * p.W + min(x, p.W - 1);
@@ -989,9 +997,9 @@ __global__ __launch_bounds__(512) void attn_window16p_kernel(AttnParams p, int n
     };
     const bf16x8 (&q2)[2][C::KS] = reinterpret_cast<const bf16x8 (&)[2][C::KS]>(qfa[0]);
     if (S == 14)
-      win16_pass<HD, 2, 14, true, KROWT>(p, Kl, Vl, S, SR, cur.b, cur.wy, cur.wx, cur.head, wave, WAVES, q2, twr, thv, lane, mid);
+      win16_pass<HD, 2, 14, true, KROWT, S6D_WIN16_KSWZ != 0>(p, Kl, Vl, S, SR, cur.b, cur.wy, cur.wx, cur.head, wave, WAVES, q2, twr, thv, lane, mid);
     else
-      win16_pass<HD, 2, 16, false, KROWT>(p, Kl, Vl, S, SR, cur.b, cur.wy, cur.wx, cur.head, wave, WAVES, q2, twr, thv, lane, mid);
+      win16_pass<HD, 2, 16, false, KROWT, S6D_WIN16_KSWZ != 0>(p, Kl, Vl, S, SR, cur.b, cur.wy, cur.wx, cur.head, wave, WAVES, q2, twr, thv, lane, mid);
     S6D_ATTN_VMCNT0();                                               // next item's images and Q have landed (and this item's stores)
     __syncthreads();
     cur = nxt;

@@ -69,5 +69,42 @@ def test_segment_seq_sum_and_centroid_path_on_the_emulator(emu, monkeypatch):
 
 def test_global_attention_on_the_64_grid_on_the_emulator(emu):
     """SAM's global blocks: the 64 x 64 grid takes the aligned fast path of attn_global_kernel (MODE 1: one key row per 64-key
-    tile, th tables per query strip, tw in registers), which the small grids above never reach."""
+    tile, th tables per query strip, tw in registers), which the small grids above never reach;
+    since round 2 that path is attn_global64_kernel (LDS-DMA ring, swizzled K chunks, counted waits: run under both DMA completion
+    models, HIPEMU_GLDS=early / late)."""
     T.test_fused_attention_vs_oracle(1, 64, 1, 80, 0)
+    T.test_fused_attention_vs_oracle(1, 64, 1, 64, 0)        # head dim 64: 9-chunk K rows, 19 DMA pieces per tile
+
+
+def _run_late(cases):
+    """Body of the LDS-DMA kernels under the LATE completion model (a DMA's bytes land only at the covering vmcnt wait): run in its
+    own interpreter, HIPEMU_GLDS is read once per process."""
+    import ctypes
+
+    import torch
+
+    from tests import hipemu
+    from sam6d_amd import _lib, ops
+    L = ctypes.CDLL(hipemu.build())
+    L.s6d_strerror.restype = ctypes.c_char_p
+    L.s6d_strerror.argtypes = [ctypes.c_int]
+    L.s6d_last_hip_error.restype = ctypes.c_char_p
+    _lib._lib = L
+    ops._stream = lambda: ctypes.c_void_p(0)
+    torch.Tensor.is_cuda = property(lambda self: True)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    for c in cases:
+        T.test_fused_attention_vs_oracle(*c)
+
+
+def test_lds_dma_attention_kernels_under_the_late_completion_model():
+    """attn_global64_kernel (64 x 64 grid) and the persistent window kernel with their DMA bytes arriving as late as the waits
+    allow: a ring slot read before its counted wait, or refilled before its last reader passed the barrier, shows up here."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", f"import sys; sys.path.insert(0, {root!r}); from tests import test_emu_attn as t; "
+                        "t._run_late([(1, 64, 1, 80, 0), (2, 20, 4, 80, 14)])"], env=dict(os.environ, HIPEMU_GLDS="late"),
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

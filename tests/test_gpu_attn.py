@@ -18,7 +18,7 @@ def _mk(B, H, nh, hd, ws, seed):
 
 
 @pytest.mark.parametrize("B,H,nh,hd,ws", [(2, 32, 2, 80, 14), (1, 32, 2, 80, 0), (1, 64, 2, 80, 14),
-                                          (1, 64, 1, 80, 0), (2, 16, 3, 64, 7), (1, 16, 2, 64, 0), (1, 20, 1, 80, 14)])
+                                          (1, 64, 1, 80, 0), (1, 64, 2, 64, 0), (2, 16, 3, 64, 7), (1, 16, 2, 64, 0), (1, 20, 1, 80, 14)])
 def test_fused_attention_vs_oracle(B, H, nh, hd, ws):
     from oracle import sam as osam
     from sam6d_amd import ops

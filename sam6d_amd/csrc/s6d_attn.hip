@@ -1156,7 +1156,8 @@ constexpr int G64_THLD = 65;
 #else
 __device__ __forceinline__ void attn_dma16(const void *src, S6D_LDS(char) *dst) {
   const unsigned a = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dst);
-  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(a) : "memory", "m0");
+  // s_nop: one wait state between the SALU write of M0 and the LDS-DMA that reads it (hipcc puts the same nop after its own s_mov m0)
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(a) : "memory", "m0");
 }
 #define S6D_ATTN_DMA16(src, lds_ptr) attn_dma16((src), (lds_ptr))
 #endif

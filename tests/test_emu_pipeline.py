@@ -14,4 +14,4 @@ def test_frame_through_all_five_models_on_the_emulator(emu, monkeypatch):
     # (their fused bf16 kernels have their own emulator tests), everything else is the device path
     for k in ("S6D_SAM_DTYPE", "S6D_DINO_DTYPE", "S6D_SAM_DECODER_DTYPE", "S6D_PEM_VIT_DTYPE"):
         monkeypatch.setenv(k, "fp32")
-    T.run_frame(torch.device("cpu"))
+    T.run_frame(torch.device("cpu"), group_check=os.environ.get("S6D_EMU_GROUP") == "1")       # + S6D_EMU_GROUP=1: run_group too (~50 min)

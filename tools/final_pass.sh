@@ -5,6 +5,7 @@ set -x
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/prof
 timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > gpurun_out/prof/r02_gpu_tests.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 >> gpurun_out/prof/r02_gpu_tests.txt
 timeout 900 python bench.py --steps 5 --warmup 2 > gpurun_out/prof/r02_bench_line.json 2> gpurun_out/prof/r02_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline > /dev/null 2>&1
 cp $(find /tmp/prof_bench -name "*kernel_stats.csv" | head -1) gpurun_out/prof/r02_bench_kernel_stats.csv

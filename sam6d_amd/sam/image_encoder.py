@@ -107,6 +107,18 @@ class Attention(nn.Module):
             self.rel_pos_h = nn.Parameter(torch.zeros(2 * input_size[0] - 1, head_dim))
             self.rel_pos_w = nn.Parameter(torch.zeros(2 * input_size[1] - 1, head_dim))
 
+    def _kernel_operands(self, S, dtype):
+        """qkv bias and the two (2S-1, hd) position tables in the kernel's dtype, cached until a parameter changes (three casts
+        per block and call otherwise: 192 small launches per 32-frame step)."""
+        key = (S, dtype, self.qkv.bias._version, self.qkv.bias.data_ptr(), self.rel_pos_h._version, self.rel_pos_h.data_ptr(),
+               self.rel_pos_w._version, self.rel_pos_w.data_ptr())
+        c = getattr(self, "_s6d_attn_ops", None)
+        if c is None or c[0] != key:
+            c = (key, self.qkv.bias.detach().to(dtype).contiguous(), _rel_table(S, self.rel_pos_h.detach()).to(dtype).contiguous(),
+                 _rel_table(S, self.rel_pos_w.detach()).to(dtype).contiguous())
+            self._s6d_attn_ops = c
+        return c[1], c[2], c[3]
+
     def forward(self, x, window_size=0):
         """x: (B,H,W,C) token map (already normed).  window_size 0 = global attention."""
         B, H, W, C = x.shape
@@ -118,17 +130,14 @@ class Attention(nn.Module):
             hm = fused_linear(self.qkv, x, col_block=C // self.num_heads)
             if hm is not None:
                 S = window_size if window_size > 0 else H
-                out = ops.window_attention(hm, self.qkv.bias.to(hm.dtype), _rel_table(S, self.rel_pos_h).to(hm.dtype).contiguous(),
-                                           _rel_table(S, self.rel_pos_w).to(hm.dtype).contiguous(), self.num_heads, window_size,
-                                           self.scale, head_major_shape=(B, H, W))
+                bias, rh, rw = self._kernel_operands(S, hm.dtype)
+                out = ops.window_attention(hm, bias, rh, rw, self.num_heads, window_size, self.scale, head_major_shape=(B, H, W))
                 return fused_linear(self.proj, out)
         qkv = fused_linear(self.qkv, x)                              # (B,H,W,3C): real tokens only
         if fused:
             S = window_size if window_size > 0 else H
-            out = ops.window_attention(qkv.contiguous(), self.qkv.bias.to(qkv.dtype),
-                                       _rel_table(S, self.rel_pos_h).to(qkv.dtype).contiguous(),
-                                       _rel_table(S, self.rel_pos_w).to(qkv.dtype).contiguous(),
-                                       self.num_heads, window_size, self.scale)
+            bias, rh, rw = self._kernel_operands(S, qkv.dtype)
+            out = ops.window_attention(qkv.contiguous(), bias, rh, rw, self.num_heads, window_size, self.scale)
         else:
             out = self._attention_lib(qkv, B, H, W, C, window_size)
         return fused_linear(self.proj, out)

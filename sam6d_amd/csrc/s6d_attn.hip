@@ -965,9 +965,11 @@ __global__ __launch_bounds__(512) void attn_window16p_kernel(AttnParams p, int n
   S6D_ATTN_VMCNT0();
   __syncthreads();
   int buf = 0;
+  long long wtk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wsum[6] = {0, 0, 0, 0, 0, 0};   // S6D_G64_TIMING probe build: phase clocks, see below
   for (; id < nitems; id += gridDim.x) {
     char *cb = smem + buf * bufbytes, *nb = smem + (buf ^ 1) * bufbytes;
     const bool more = id + (int)gridDim.x < nitems;
+    S6D_TICK(wtk, 0);
     if (more) {
       nxt.decode(p, id + gridDim.x);
       stage_image(nxt, 1, nb);                                       // K image of the next item; its V area is this item's scratch
@@ -989,8 +991,11 @@ __global__ __launch_bounds__(512) void attn_window16p_kernel(AttnParams p, int n
       else
         win16_tables<HD, 2, 16>(rf, S, wave, WAVES, qfa, tab, twr, thv, lane);
     }
+    S6D_TICK(wtk, 1);
     __builtin_amdgcn_s_barrier();                                    // every wave is done with its scratch table (raw: the K DMA stays in flight)
+    S6D_TICK(wtk, 2);
     if (more) stage_image(nxt, 2, nb + kbytes);
+    S6D_TICK(wtk, 3);
     const u16 *Kl = reinterpret_cast<const u16 *>(cb), *Vl = reinterpret_cast<const u16 *>(cb + kbytes);
     auto mid = [&]() __attribute__((always_inline)) {                // half way through the PV pass: this item's Q fragments are long dead
       if (more) load_q(nxt);
@@ -1000,10 +1005,23 @@ __global__ __launch_bounds__(512) void attn_window16p_kernel(AttnParams p, int n
       win16_pass<HD, 2, 14, true, KROWT, S6D_WIN16_KSWZ != 0>(p, Kl, Vl, S, SR, cur.b, cur.wy, cur.wx, cur.head, wave, WAVES, q2, twr, thv, lane, mid);
     else
       win16_pass<HD, 2, 16, false, KROWT, S6D_WIN16_KSWZ != 0>(p, Kl, Vl, S, SR, cur.b, cur.wy, cur.wx, cur.head, wave, WAVES, q2, twr, thv, lane, mid);
+    S6D_TICK(wtk, 4);
     S6D_ATTN_VMCNT0();                                               // next item's images and Q have landed (and this item's stores)
+    S6D_TICK(wtk, 5);
     __syncthreads();
+    S6D_TICK(wtk, 6);
+    if (S6D_G64_TIMING)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) wsum[i] += wtk[i + 1] - wtk[i];
     cur = nxt;
     buf ^= 1;
+  }
+  // probe build: [K DMA issue + bias tables | barrier | V DMA issue | score / softmax / P V passes | vmcnt(0) | barrier] per wave of
+  // workgroup 8, 320 bytes behind the output tensor (tools/attn_time.py)
+  if (S6D_G64_TIMING && blockIdx.x == 8 && lane == 0) {
+    long long *dbg = reinterpret_cast<long long *>(p.out + (size_t)p.B * p.H * p.W * p.nh * HD);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dbg[wave * 6 + i] = wsum[i];
   }
 }
 

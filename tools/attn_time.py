@@ -70,6 +70,10 @@ def main():
                 ref[ws] = o.clone()
             elif not is_probe(name):
                 row["equals_base"] = bool(torch.equal(o, ref[ws]))
+            if ws == 14 and "timing" in name:
+                t = o_full[B * H * H * nh * hd:].view(torch.int64)[:48].view(8, 6).cpu().tolist()
+                items = (B * 25 * nh + 255) // 256
+                row["phase_cycles_per_item"] = {f"wave{w}": [round(v / items) for v in t[w]] for w in (0, 3, 4, 7)}
             if ws == 0 and "timing" in name:
                 t = o_full[B * H * H * nh * hd:].view(torch.int64)[:40].view(8, 5).cpu().tolist()
                 row["phase_cycles_per_tile"] = {f"wave{w}": [round(v / 64) for v in t[w]] for w in (0, 3, 4, 7)}

@@ -32,7 +32,7 @@ def test_fused_attention_vs_oracle(B, H, nh, hd, ws):
     assert err.max() < 3e-2 and err.mean() < 3e-3, (err.max().item(), err.mean().item())
 
 
-@pytest.mark.parametrize("B,H,nh,hd,ws", [(1, 28, 2, 80, 14), (1, 32, 2, 80, 0), (2, 20, 4, 80, 14), (1, 16, 2, 64, 7)])
+@pytest.mark.parametrize("B,H,nh,hd,ws", [(1, 28, 2, 80, 14), (1, 32, 2, 80, 0), (2, 20, 4, 80, 14), (1, 16, 2, 64, 7), (1, 64, 2, 80, 0)])
 def test_head_major_layout_equals_token_major(B, H, nh, hd, ws):
     """The attention kernels on the head-major q/k/v tensor (3 heads, B H W, hd) -- what the qkv GEMM's column-block epilogue
     writes -- give bit for bit what they give on the Linear layout (B,H,W,3,heads,hd): only addresses differ."""

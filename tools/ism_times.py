@@ -1,4 +1,5 @@
-"""Per-call wall times inside one ISM frame scoring (diagnostic; run on the GPU box)."""
+"""Per-call wall times inside one ISM frame scoring (diagnostic; run on the GPU box).  usage: ism_times.py [P O T]
+(default 128 1 42 = the benched LM-O shape; 256 30 42 = BASELINE configs[3], T-LESS: 30 objects, many-instance frames)."""
 import sys
 import time
 from types import SimpleNamespace
@@ -9,7 +10,9 @@ sys.path.insert(0, ".")
 from sam6d_amd.ism.scoring import FrameScorer  # noqa: E402
 from sam6d_amd.utils import synth  # noqa: E402
 
-inp = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in synth.ism_inputs(P=128, O=1, T=42, seed=11).items()}
+P, O, Tn = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (128, 1, 42)
+print(f"P = {P} proposals, O = {O} objects, T = {Tn} templates", flush=True)
+inp = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in synth.ism_inputs(P=P, O=O, T=Tn, seed=11).items()}
 fs = FrameScorer(inp["ref_cls"], inp["ref_patch"], inp["poses"], inp["pointcloud"])
 
 

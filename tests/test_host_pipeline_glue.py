@@ -18,7 +18,7 @@ def test_glue_between_the_stages(monkeypatch):
 
     def fake_preprocess(x, img_size):
         seen["pre_in"] = x.clone()
-        return torch.zeros(1, 3, img_size, img_size)
+        return torch.zeros(x.shape[0], 3, img_size, img_size)
     monkeypatch.setattr(pipeline, "sam_preprocess", fake_preprocess)
     monkeypatch.setattr(pipeline.FramePipeline, "_tick", lambda self, name, t0: self.times.__setitem__(name, 0.0) or t0)
 
@@ -27,7 +27,7 @@ def test_glue_between_the_stages(monkeypatch):
 
         def __call__(self, x):
             seen["enc_in"] = tuple(x.shape)
-            return torch.zeros(1, 8, S // 16, S // 16)
+            return torch.zeros(x.shape[0], 8, S // 16, S // 16)
     # six proposals: a tiny one (box below 0.05^2 of the frame), an exactly-square crop the reference cannot process, and
     # four usable ones
     boxes = torch.tensor([[2, 2, 6, 6], [10, 10, 59, 59], [20, 10, 90, 70], [60, 30, 150, 110], [5, 50, 70, 115], [80, 5, 155, 60]])
@@ -123,6 +123,21 @@ def test_glue_between_the_stages(monkeypatch):
     assert seen["model_rows"] == [2.0, 1.0, 0.0, 2.0] == seen["po_rows"]
     out = pipeline.frame_results(det, poses, "ycbv", 0.0)
     assert [r["category_id"] for r in out["pem_records"]] == [3, 2, 1, 3] and [l.split(",")[2] for l in out["csv_lines"]] == ["3", "2", "1", "3"]
+    # ---- a group of frames: ONE encoder pass and ONE PEM pass; the middle frame has no valid depth (nothing survives its
+    # pre-processing), so the PEM batch is frames 0 and 2 back to back and is split again per frame
+    def rnd():
+        return torch.rand(4, H * W, generator=g), torch.rand(4, 18000, generator=g)
+    (k0, u0), (k1, u1), (k2, u2) = rnd(), rnd(), rnd()
+    res = pipe.run_group([(img, depth, K, k0, u0), (img, torch.zeros_like(depth), K, k1, u1), (img, depth, K, k2, u2)])
+    assert seen["enc_in"][0] == 3 and len(res) == 3
+    assert seen["model_rows"] == [2.0, 1.0, 0.0, 2.0] * 2 and seen["pem_shapes"]["pts"] == (8, 2048, 3)
+    assert seen["pem_shapes"]["coarse_rand_u"] == (8, 18000)
+    (d0, p0), (d1, p1), (d2, p2) = res
+    assert len(d1) == 4 and p1 is None
+    assert p0["pred_R"].shape == (4, 3, 3) and p2["pred_t"].shape == (4, 3) and p0["kept"].tolist() == [0, 1, 2, 3] == p2["kept"].tolist()
+    assert torch.equal(d0.boxes, d2.boxes) and d0.object_ids.tolist() == [2, 1, 0, 2]
+    alone = pipe(img, depth, K, k2, u2)
+    assert torch.equal(alone[0].boxes, d2.boxes) and torch.equal(alone[1]["pred_R"], p2["pred_R"])
 
 
 

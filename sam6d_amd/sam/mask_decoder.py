@@ -395,6 +395,25 @@ class MaskDecoder(nn.Module):
         return c[1]
 
     @staticmethod
+    def _rows_gemm(x, w, b):
+        """x (B, N, K) bf16 @ w (n, K)^T + b over ALL B N image-token rows (1024 prompts x 4096 tokens = 4.2 M rows): the
+        hand-written GEMM in row slabs below its 2 GiB operand limit when it applies (n % 128 == 0, K % 64 == 0;
+        S6D_SAMDEC_GEMM=library opts out), else the library statement."""
+        import os
+        K, n = x.shape[-1], w.shape[0]
+        if (x.is_cuda and x.dtype == torch.bfloat16 and n % 128 == 0 and K % 64 == 0 and ops.have("gemm_bf16")
+                and os.environ.get("S6D_SAMDEC_GEMM", "kernel") != "library"):
+            x2 = x.reshape(-1, K)
+            M = x2.shape[0]
+            out = torch.empty(M, n, dtype=torch.bfloat16, device=x.device)
+            slab = max(256, ((1 << 30) // (2 * max(K, n))) // 256 * 256)            # rows per call: A and C slabs stay under 1 GiB
+            bf = b.float()
+            for r in range(0, M, slab):
+                ops.gemm_bf16(x2[r:r + slab], w, bf, out=out[r:r + slab])
+            return out.view(*x.shape[:-1], n)
+        return F.linear(x, w, b)
+
+    @staticmethod
     def _expand(att, queries, tokens):
         """Operands of s6d_samdec_img2tok_bf16 from the prompt tokens: block-diagonal scaled keys (B,64,128) and the
         values with out_proj folded in (B,256,64); slot j = head * 8 + token."""
@@ -438,7 +457,7 @@ class MaskDecoder(nn.Module):
         # ---- layer 1 -----------------------------------------------------------------------------------------------
         ca, ci = L1.cross_attn_token_to_image, L1.cross_attn_image_to_token
         d = ca.internal_dim
-        kvq = F.linear(keys1, P["w_kvq"], P["b_kvq"])                              # (B, N, 3d) bf16
+        kvq = self._rows_gemm(keys1, P["w_kvq"], P["b_kvq"])                       # (B, N, 3d) bf16
         if t2i:
             queries = L1.token_side(queries, tokens, None, None,
                                     lambda qp: ops.samdec_tok2img(qp, kvq, 0, d, P["kpe1"], sc))
@@ -449,7 +468,7 @@ class MaskDecoder(nn.Module):
         keys2 = ops.samdec_img2tok(kvq[..., 2 * d:], P["qpe1"], kexp, vpt, keys1, ci.out_proj.bias.float(),
                                    n4.weight.float(), n4.bias.float(), n4.eps, T)
         # ---- final token->image attention + output head ---------------------------------------------------------------
-        kvu = F.linear(keys2, P["w_kvu"], P["b_kvu"])                              # (B, N, 2d + 4*c1) bf16
+        kvu = self._rows_gemm(keys2, P["w_kvu"], P["b_kvu"])                       # (B, N, 2d + 4*c1) bf16
         qf = fin.q_proj(queries + tokens)
         if t2i:
             a = fin.out_proj(ops.samdec_tok2img(qf.float(), kvu, 0, d, P["kpef"], sc))

@@ -503,10 +503,17 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window_kernel(AttnParams p) {
   item.decode(p, blockIdx.x);
   const int head = item.head, wx = item.wx, wy = item.wy, b = item.b;
   {
-    Stager<HD, WAVES * 64> st;
-    for (int t = 0; t < ntile; ++t) {
-      st.load(p, b, wy, wx, head, t * 64, tid);
-      st.store(Kl + (size_t)t * 64 * C::KROW, Vl + (size_t)t * 64 * C::VROW, tid);
+    // the loads of up to SB tiles are issued before the first of them is stored: one exposed fetch latency per SB tiles instead of
+    // one per tile (T = 257 / 197 keys = 5 / 4 tiles: the whole item in one batch)
+    constexpr int SB = 5;
+    Stager<HD, WAVES * 64> st[SB];
+    for (int t0 = 0; t0 < ntile; t0 += SB) {
+#pragma unroll
+      for (int i = 0; i < SB; ++i)
+        if (t0 + i < ntile) st[i].load(p, b, wy, wx, head, (t0 + i) * 64, tid);
+#pragma unroll
+      for (int i = 0; i < SB; ++i)
+        if (t0 + i < ntile) st[i].store(Kl + (size_t)(t0 + i) * 64 * C::KROW, Vl + (size_t)(t0 + i) * 64 * C::VROW, tid);
     }
   }
   __syncthreads();

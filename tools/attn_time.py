@@ -85,6 +85,22 @@ def main():
                 del hm
             out[f"{'global' if ws == 0 else 'window14'}.{name}"] = row
             print(f"{'global' if ws == 0 else 'window14':9s} {name:18s} {json.dumps(row)}", flush=True)
+    # the all-resident kernel behind s6d_seq_attention_bf16 at the DINOv2 shape: 64 crops x 16 heads x 257 tokens x 64
+    Bs, Ns, nhs, hds = 64, 257, 16, 64
+    qs = torch.randn(Bs, Ns, 3 * nhs * hds, generator=g, device="cuda").to(torch.bfloat16)
+    os_ = torch.empty(Bs, Ns, nhs * hds, dtype=torch.bfloat16, device="cuda")
+    flop = 4.0 * Bs * nhs * hds * Ns * Ns
+    for path in libs:
+        name = os.path.basename(path)[8:-3]
+        L = ctypes.CDLL(path)
+
+        def run_seq():
+            rc = L.s6d_seq_attention_bf16(vp(qs.data_ptr()), Bs, Ns, nhs, hds, ctypes.c_float(hds ** -0.5), vp(os_.data_ptr()),
+                                          vp(torch.cuda.current_stream().cuda_stream))
+            assert rc == 0, rc
+        ms = min(event_ms(run_seq, n=20) for _ in range(3))
+        out[f"seq257.{name}"] = {"ms": round(ms, 4), "tflops": round(flop / ms / 1e9, 1)}
+        print(f"seq257    {name:18s} {json.dumps(out[f'seq257.{name}'])}", flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "attn_time.json"), "w") as f:
         json.dump({"B": B, "heads": nh, "head_dim": hd, "grid": H, "results": out}, f, indent=1)

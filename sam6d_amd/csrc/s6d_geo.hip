@@ -42,7 +42,14 @@ __device__ __forceinline__ void fast_sincos(float a, float &sn, float &cs) {
 }
 
 constexpr int GEO_C = 256;          // hidden dim
-constexpr int GEO_ROW = 40;         // LDS row stride (bf16): 32 channels + 8 pad (80 B: conflict-free b128 reads)
+constexpr int GEO_ROW = 40;         // LDS row stride (bf16): 32 channels + 8 pad (80 B = 5 chunks of 16 B)
+// A ds_read_b128 lane group is {rows 0-3,12-15 reading chunk g} + {rows 4-11 reading chunk g + 1}: with any odd row stride these
+// meet on 3 of 16 bank slots (2-way conflict on every fragment read: SQ_LDS_BANK_CONFLICT was a quarter of the kernel's cycles).
+// Rows with (row >> 2 ^ row >> 3) & 1 therefore keep their chunks pairwise swapped (same fix as csrc/s6d_attn.hip S6D_GLB_KSWZ).
+#ifndef S6D_GEO_KSWZ
+#define S6D_GEO_KSWZ 1
+#endif
+__device__ __forceinline__ int geo_swz(int row) { return S6D_GEO_KSWZ ? (((row >> 2) ^ (row >> 3)) & 1) : 0; }
 constexpr int GEO_PAIRS = 64;       // point pairs per workgroup
 constexpr int GEO_THREADS = 512;
 
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(GEO_THREADS) void geo_embed_kernel(const float *__r
         split_bf16(dv[e], dh.h[e], dl.h[e]);
         split_bf16(av[e], ah.h[e], al.h[e]);
       }
-      const int o = row * GEO_ROW + col * 4;
+      const int o = row * GEO_ROW + (((col >> 1) ^ geo_swz(row)) * 8) + (col & 1) * 4;
       *reinterpret_cast<uint2 *>(lds + OFF_WDH + o) = dh.u;
       *reinterpret_cast<uint2 *>(lds + OFF_WDL + o) = dl.u;
       *reinterpret_cast<uint2 *>(lds + OFF_WAH + o) = ah.u;
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(GEO_THREADS) void geo_embed_kernel(const float *__r
         split_bf16(sn, hi.h[2 * j], lo.h[2 * j]);                  // interleaved [sin w, cos w] layout (:279-280)
         split_bf16(cs, hi.h[2 * j + 1], lo.h[2 * j + 1]);
       }
-      const int o = (item_e[n] * GEO_PAIRS + item_p[n]) * GEO_ROW + item_q[n] * 8;
+      const int o = (item_e[n] * GEO_PAIRS + item_p[n]) * GEO_ROW + (item_q[n] ^ geo_swz(item_p[n])) * 8;
       *reinterpret_cast<uint4 *>(lds + OFF_AH + o) = hi.u;
       *reinterpret_cast<uint4 *>(lds + OFF_AL + o) = lo.u;
     }
@@ -144,13 +151,13 @@ __global__ __launch_bounds__(GEO_THREADS) void geo_embed_kernel(const float *__r
     bf16x8 ah[4], al[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int o = (e * GEO_PAIRS + mt * 16 + c) * GEO_ROW + g * 8;
+      const int o = (e * GEO_PAIRS + mt * 16 + c) * GEO_ROW + (g ^ geo_swz(c)) * 8;
       ah[e] = *reinterpret_cast<const bf16x8 *>(lds + OFF_AH + o);
       al[e] = *reinterpret_cast<const bf16x8 *>(lds + OFF_AL + o);
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      const int o = (nh * 128 + t * 16 + c) * GEO_ROW + g * 8;
+      const int o = (nh * 128 + t * 16 + c) * GEO_ROW + (g ^ geo_swz(c)) * 8;
       const bf16x8 wdh = *reinterpret_cast<const bf16x8 *>(lds + OFF_WDH + o);
       const bf16x8 wdl = *reinterpret_cast<const bf16x8 *>(lds + OFF_WDL + o);
       const bf16x8 wah = *reinterpret_cast<const bf16x8 *>(lds + OFF_WAH + o);

@@ -28,6 +28,9 @@ extern "C" {
 #define S6D_ELAUNCH (-2)  /* hipLaunchKernel / hipGetLastError failure    */
 #define S6D_EUNSUPPORTED (-3)
 
+/* Bumped whenever a signature in this header changes; the loader (sam6d_amd/_lib.py) refuses a library whose
+ * s6d_version() differs from the header it was written against (a stale .so fails at load, not at a call). */
+#define S6D_ABI_VERSION 101
 int s6d_version(void);
 const char *s6d_strerror(int code);
 /* last HIP error string seen by this thread (empty if none) */
@@ -230,10 +233,12 @@ long s6d_patch_scores_workspace_floats(int S, int N1, int N2);
  * Z = depth * depth_scale / 1000 (the reference's contract: depth in millimetres at depth_scale 1).
  * K: the 3x3 row-major float64 camera matrix IN DEVICE MEMORY (read by the kernel: no host copy per frame).
  * ref: Calculate_the_query_translation, model/detector.py:234-246 +
- * depth_image_to_pointcloud_translate_torch, utils/trimesh_utils.py:77-105 (float64 X/Y, float32 Z). */
+ * depth_image_to_pointcloud_translate_torch, utils/trimesh_utils.py:77-105 (float64 X/Y, float32 Z).
+ * The three sums are taken in the order of ATen's CPU `sum` (cascade_sum with AVX2 vectors: 32 float / 16 double columns,
+ * 16-row cascade levels), so that the result carries the bits of the reference's CPU run (oracle/aten_sum.py). */
 int s6d_masked_depth_mean_f32(const float *masks, const float *depth, int S, int H, int W, float depth_scale,
                               const double *K, void *workspace, float *out, void *stream);
-long s6d_masked_depth_mean_workspace_bytes(int S);   /* W % 4 == 0 */
+long s6d_masked_depth_mean_workspace_bytes(int S, int H, int W);   /* W % 4 == 0, H*W < 2^24 */
 /* Several frames in one launch: depth (F,H,W), K (F,3,3) f64, frame (S) i32 = the frame of every mask (NULL: one frame). */
 int s6d_masked_depth_mean_frames_f32(const float *masks, const float *depth, const int32_t *frame, int S, int H, int W,
                                      float depth_scale, const double *K, void *workspace, float *out, void *stream);

@@ -62,6 +62,31 @@ def mean_translation(masks, depth, K, depth_scale=1.0):
     return t.permute(1, 0).to(torch.float32)
 
 
+def mean_translation_pinned(masks, depth, K, depth_scale=1.0):
+    """mean_translation with the three sums taken in the EXPLICIT order of ATen's CPU kernel (oracle/aten_sum.py) instead of
+    whatever `torch.sum` does on the host running the tests.  On the x86 hosts seen so far both agree bit for bit
+    (tests/test_oracle_golden.py); this is the comparand of the device kernel."""
+    import numpy as np
+
+    from . import aten_sum
+    md = masks.to(torch.float32) * depth.to(torch.float32)[None]
+    S, (H, W) = md.shape[0], depth.shape
+    u, v = torch.meshgrid(torch.arange(W), torch.arange(H), indexing="xy")
+    Z = md * depth_scale / 1000
+    K = K.to(torch.float64)
+    X = (u - K[0, 2]) * Z / K[0, 0]
+    Y = (v - K[1, 2]) * Z / K[1, 1]
+    valid = Z > 0
+    n = (torch.count_nonzero(valid, dim=(1, 2)) + 1e-8).numpy()
+    assert n.dtype == np.float32 and X.dtype == torch.float64 and Z.dtype == torch.float32
+    if H * W < 8:
+        raise NotImplementedError("below one vector ATen takes a scalar path")
+    sx = aten_sum.sum_f64((X * valid).reshape(S, -1).numpy())
+    sy = aten_sum.sum_f64((Y * valid).reshape(S, -1).numpy())
+    sz = aten_sum.sum_f32((Z * valid).reshape(S, -1).numpy())
+    return torch.from_numpy(np.stack(((sx / n).astype(np.float32), (sy / n).astype(np.float32), sz / n), 1))
+
+
 def project_template(poses, pointcloud, best_template, pred_obj, masks, depth, K, depth_scale=1.0):
     """project_template_to_image (detector.py:209-232) -> int (S,N,2) pixel (u,v)."""
     R = poses[best_template, 0:3, 0:3]

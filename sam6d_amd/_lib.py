@@ -64,6 +64,10 @@ def lib():
         L.s6d_strerror.argtypes = [ctypes.c_int]
         L.s6d_last_hip_error.restype = ctypes.c_char_p
         L.s6d_version.restype = ctypes.c_int
+        want = abi_version()
+        if L.s6d_version() != want:
+            raise RuntimeError(f"{SO_PATH} is ABI version {L.s6d_version()}, include/sam6d_hip.h is {want}: rebuild "
+                               "(`python -c 'import __graft_entry__ as g; g.build()'`)")
         _lib = L
     return _lib
 
@@ -76,6 +80,13 @@ def check(code, what):
     if code != 0:
         L = lib()
         raise S6DError(f"{what}: {L.s6d_strerror(code).decode()} [{L.s6d_last_hip_error().decode()}]")
+
+
+def abi_version():
+    """S6D_ABI_VERSION of include/sam6d_hip.h."""
+    import re
+
+    return int(re.search(r"#define\s+S6D_ABI_VERSION\s+(\d+)", open(os.path.join(_HERE, "..", "include", "sam6d_hip.h")).read()).group(1))
 
 
 def declared_symbols():

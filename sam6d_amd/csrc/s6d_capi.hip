@@ -11,7 +11,7 @@ void set_hip_error(hipError_t e) {
 }
 }  // namespace s6d
 
-extern "C" int s6d_version(void) { return 100; }
+extern "C" int s6d_version(void) { return S6D_ABI_VERSION; }
 
 extern "C" const char *s6d_last_hip_error(void) { return s6d::g_hip_err; }
 

@@ -307,76 +307,214 @@ __global__ void patch_finalize_kernel(const float *__restrict__ part_rowsum, con
 // Mean back-projected point of every mask (detector.py:234-246 + trimesh_utils.py:77-105) -- three masked
 // sums, no (S,H,W) depth repeat.  Dtype trail of the reference: Z float32; X, Y float64 (the camera matrix is a
 // float64 tensor); the three means are cast to float32 at the end.
-constexpr int kDepthChunks = 16;       // workgroups per mask
+//
+// SUMMATION ORDER (round 3).  The projected pixels downstream are truncated floats, so the translation has to carry the
+// reference's bits, and a float32 sum over ~10^4 pixels carries its order.  The pinned run is ATen's CPU `sum`
+// (cascade_sum / vectorized_inner_sum, aten/src/ATen/native/cpu/SumKernel.cpp): the flat H*W map is read as rows of
+// C = 4*V elements (V = 8 floats / 4 doubles: the AVX2 vector the kernel is compiled for, also on AVX-512 hosts), each of
+// the C columns is summed on its own through a cascade -- blocks of 16 rows summed in row order from zero, 16 block sums
+// added in order into a level-1 node, 16 of those into a level-2 node, level-2 nodes accumulated in order -- then the row
+// remainder, the partial level-1 / level-2 nodes and the level-3 accumulator are combined in that order, the four vectors
+// of a row are added 1, 2, 3 onto vector 0, and the V lanes are added in lane order onto the scalar tail.  That is a tree
+// with fixed shape: level-0 blocks and level-1 nodes are independent (kernel 1: one workgroup per 8192-element span = one
+// float32 level-1 node = two float64 level-1 nodes), the upper levels are a few dozen sequential adds per column
+// (kernel 2: one wave per mask).  oracle/aten_sum.py restates the same order in numpy; both reproduce torch.sum bit for bit.
+constexpr int kMdSpan = 8192;          // elements per workgroup of kernel 1
+constexpr int kMdC32 = 32, kMdC64 = 16;   // columns of the float32 / float64 reductions (4 vectors of 8 / 4 lanes)
 
-__global__ __launch_bounds__(256) void masked_depth_partial_kernel(const float *__restrict__ masks,
-                                                                  const float *__restrict__ depth, int H, int W,
-                                                                  unsigned magicW, float depth_scale,
-                                                                  const double *__restrict__ K,
-                                                                  const int *__restrict__ frame,
-                                                                  double *__restrict__ part) {
-  __shared__ double sx[4], sy[4], sz[4];
-  __shared__ int sn[4];
-  const int s = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+struct MdGeom {
+  int n;            // H * W
+  int nspan;        // ceil(n / kMdSpan)
+  int nb32, nb64;   // complete level-0 blocks (16 rows) of the float32 / float64 reductions
+};
+
+__host__ __device__ inline MdGeom md_geom(int H, int W) {
+  MdGeom g;
+  g.n = H * W;
+  g.nspan = (g.n + kMdSpan - 1) / kMdSpan;
+  g.nb32 = ((g.n / 8) / 4) / 16;
+  g.nb64 = ((g.n / 4) / 4) / 16;
+  return g;
+}
+
+// per-mask workspace: [nspan][32] f32 level-1 sums of Z | [2][2*nspan][16] f64 level-1 sums of X, Y | [nspan] i32 counts
+__host__ __device__ inline size_t md_ws_f64_off(const MdGeom &g) { return (((size_t)g.nspan * kMdC32 * 4) + 7) & ~(size_t)7; }
+__host__ __device__ inline size_t md_ws_cnt_off(const MdGeom &g) { return md_ws_f64_off(g) + (size_t)2 * 2 * g.nspan * kMdC64 * 8; }
+__host__ __device__ inline size_t md_ws_per_mask(const MdGeom &g) { return (md_ws_cnt_off(g) + (size_t)g.nspan * 4 + 15) & ~(size_t)15; }
+
+__device__ __forceinline__ float md_z(float m, float d, float depth_scale) { return m * d * depth_scale / 1000.f; }
+
+__global__ __launch_bounds__(256) void masked_depth_l1_kernel(const float *__restrict__ masks, const float *__restrict__ depth,
+                                                             int H, int W, float depth_scale,
+                                                             const double *__restrict__ K, const int *__restrict__ frame,
+                                                             char *__restrict__ ws) {
+  __shared__ float zs[kMdSpan];                  // masked metric depth of the span, 0 where invalid
+  __shared__ float l0f[16 * kMdC32];
+  __shared__ double l0d[2 * 32 * kMdC64];
+  __shared__ int scnt[4];
+  const int s = blockIdx.y, sp = blockIdx.x, tid = threadIdx.x;
+  const MdGeom g = md_geom(H, W);
   // several frames in one launch: mask s belongs to frame[s], which selects its depth map and camera matrix
   const int fr = frame ? frame[s] : 0;
-  depth += (size_t)fr * H * W;
+  depth += (size_t)fr * g.n;
   K += (size_t)fr * 9;
   // the camera matrix is read on the device (3x3 row-major float64, the reference's dtype): no host copy, no cache
   const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
-  const int n4 = (H * W) / 4;                               // W % 4 == 0 (checked by the launcher)
-  const int per = (n4 + kDepthChunks - 1) / kDepthChunks;
-  const int i0 = ch * per, i1 = min(i0 + per, n4);
-  const float4 *m4 = reinterpret_cast<const float4 *>(masks + (size_t)s * H * W);
-  const float4 *d4 = reinterpret_cast<const float4 *>(depth);
-  double ax = 0.0, ay = 0.0, az = 0.0;
-  int n = 0;
-  for (int i = i0 + tid; i < i1; i += 256) {
-    const float4 m = m4[i], d = d4[i];
-    const int pix = i * 4;
-    const int v = (int)__umulhi((unsigned)pix, magicW), u = pix - v * W;   // the 4 pixels share the row
-    const float z[4] = {m.x * d.x * depth_scale / 1000.f, m.y * d.y * depth_scale / 1000.f,
-                        m.z * d.z * depth_scale / 1000.f, m.w * d.w * depth_scale / 1000.f};
-    const double yv = ((double)v - cy) / fy;
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (z[e] > 0.f) {
-        ax += ((double)(u + e) - cx) * (double)z[e] / fx;
-        ay += yv * (double)z[e];
-        az += (double)z[e];
-        ++n;
-      }
+  const int e0 = sp * kMdSpan;
+  const float4 *m4 = reinterpret_cast<const float4 *>(masks + (size_t)s * g.n + e0);   // n % 4 == 0 (launcher)
+  const float4 *d4 = reinterpret_cast<const float4 *>(depth + e0);
+  int cnt = 0;
+  for (int i = tid; i < kMdSpan / 4; i += 256) {
+    float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e0 + i * 4 < g.n) {
+      const float4 m = m4[i], d = d4[i];
+      z = make_float4(md_z(m.x, d.x, depth_scale), md_z(m.y, d.y, depth_scale), md_z(m.z, d.z, depth_scale),
+                      md_z(m.w, d.w, depth_scale));
+    }
+    z.x = z.x > 0.f ? z.x : 0.f; z.y = z.y > 0.f ? z.y : 0.f; z.z = z.z > 0.f ? z.z : 0.f; z.w = z.w > 0.f ? z.w : 0.f;
+    cnt += (z.x > 0.f) + (z.y > 0.f) + (z.z > 0.f) + (z.w > 0.f);
+    reinterpret_cast<float4 *>(zs)[i] = z;
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    ax += __shfl_xor(ax, off);
-    ay += __shfl_xor(ay, off);
-    az += __shfl_xor(az, off);
-    n += __shfl_xor(n, off);
-  }
-  if ((tid & 63) == 0) { sx[tid >> 6] = ax; sy[tid >> 6] = ay; sz[tid >> 6] = az; sn[tid >> 6] = n; }
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+  if ((tid & 63) == 0) scnt[tid >> 6] = cnt;
   __syncthreads();
-  if (tid == 0) {
-    double *o = part + ((size_t)s * kDepthChunks + ch) * 4;
-    o[0] = (sx[0] + sx[1]) + (sx[2] + sx[3]);
-    o[1] = (sy[0] + sy[1]) + (sy[2] + sy[3]);
-    o[2] = (sz[0] + sz[1]) + (sz[2] + sz[3]);
-    o[3] = (double)(sn[0] + sn[1] + sn[2] + sn[3]);
+  // level 0, float32: (block, column) pairs, 16 rows in row order from zero
+  {
+    const int col = tid & 31;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int blk = (tid >> 5) + 8 * r;
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) a = __fadd_rn(a, zs[(blk * 16 + j) * kMdC32 + col]);
+      l0f[blk * kMdC32 + col] = a;
+    }
+  }
+  // level 0, float64: X = (u - cx) * Z / fx, Y = (v - cy) * Z / fy; an invalid pixel contributes (+-)0
+  {
+    const int col = tid & 15;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int blk = (tid >> 4) + 16 * r;
+      double ax = 0.0, ay = 0.0;
+#pragma unroll 4
+      for (int j = 0; j < 16; ++j) {
+        const int o = (blk * 16 + j) * kMdC64 + col;
+        const float z = zs[o];
+        const int pix = e0 + o;
+        if (z > 0.f) {
+          const int v = pix / W, u = pix - v * W;
+          ax = __dadd_rn(ax, __ddiv_rn(__dmul_rn((double)u - cx, (double)z), fx));
+          ay = __dadd_rn(ay, __ddiv_rn(__dmul_rn((double)v - cy, (double)z), fy));
+        }
+      }
+      l0d[blk * kMdC64 + col] = ax;
+      l0d[(32 + blk) * kMdC64 + col] = ay;
+    }
+  }
+  __syncthreads();
+  char *wm = ws + (size_t)s * md_ws_per_mask(g);
+  if (tid < kMdC32) {                               // level 1, float32: this span's complete blocks in block order
+    const int nb = min(max(g.nb32 - sp * 16, 0), 16);
+    float a = 0.f;
+    for (int b = 0; b < nb; ++b) a = __fadd_rn(a, l0f[b * kMdC32 + tid]);
+    reinterpret_cast<float *>(wm)[sp * kMdC32 + tid] = a;
+  } else if (tid >= 64 && tid < 128) {              // level 1, float64: two nodes per span, X and Y
+    const int t = tid - 64, q = t >> 5, node = (t >> 4) & 1, col = t & 15;
+    const int nb = min(max(g.nb64 - (sp * 2 + node) * 16, 0), 16);
+    double a = 0.0;
+    for (int b = 0; b < nb; ++b) a = __dadd_rn(a, l0d[(q * 32 + node * 16 + b) * kMdC64 + col]);
+    reinterpret_cast<double *>(wm + md_ws_f64_off(g))[((size_t)q * 2 * g.nspan + sp * 2 + node) * kMdC64 + col] = a;
+  } else if (tid == 128) {
+    reinterpret_cast<int *>(wm + md_ws_cnt_off(g))[sp] = (scnt[0] + scnt[1]) + (scnt[2] + scnt[3]);
   }
 }
 
-__global__ void masked_depth_final_kernel(const double *__restrict__ part, int S, float *__restrict__ out) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= S) return;
-  double X = 0, Y = 0, Z = 0, N = 0;
-  for (int ch = 0; ch < kDepthChunks; ++ch) {              // fixed order: deterministic
-    const double *o = part + ((size_t)s * kDepthChunks + ch) * 4;
-    X += o[0]; Y += o[1]; Z += o[2]; N += o[3];
+// Upper levels of one column: level-1 sums l1[k * stride] (k < n1; the last one partial when nb % 16 != 0) -> the
+// column's value after `acc[0] += acc[1]; += acc[2]; += acc[3]`, given the column's row remainder `rem`.
+template <typename T>
+__device__ __forceinline__ T md_upper(const T *l1, int stride, int nb, T rem) {
+  const int nfull = nb / 16, n1 = (nb + 15) / 16;
+  T a2 = 0, a3 = 0;
+  for (int k = 0; k < nfull; ++k) {
+    a2 = a2 + l1[(size_t)k * stride];
+    if (((k + 1) & 15) == 0) { a3 = a3 + a2; a2 = 0; }
   }
-  const float cnt = (float)N + 1e-8f;                      // count_nonzero + 1e-8 is float32 in the reference
-  out[s * 3 + 0] = (float)(X / (double)cnt);
-  out[s * 3 + 1] = (float)(Y / (double)cnt);
-  out[s * 3 + 2] = (float)Z / cnt;
+  const T a1 = n1 > nfull ? l1[(size_t)nfull * stride] : (T)0;
+  return ((rem + a1) + a2) + a3;
+}
+
+__global__ __launch_bounds__(64) void masked_depth_final_kernel(const float *__restrict__ masks, const float *__restrict__ depth,
+                                                               int H, int W, float depth_scale, const double *__restrict__ K,
+                                                               const int *__restrict__ frame, const char *__restrict__ ws,
+                                                               float *__restrict__ out) {
+  __shared__ float cz[kMdC32];
+  __shared__ double cxy[2 * kMdC64];
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const MdGeom g = md_geom(H, W);
+  const int fr = frame ? frame[s] : 0;
+  depth += (size_t)fr * g.n;
+  K += (size_t)fr * 9;
+  masks += (size_t)s * g.n;
+  const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+  const char *wm = ws + (size_t)s * md_ws_per_mask(g);
+  auto zat = [&](int i) { const float z = md_z(masks[i], depth[i], depth_scale); return z > 0.f ? z : 0.f; };
+  auto xat = [&](int i) { const float z = zat(i); return z > 0.f ? ((double)(i % W) - cx) * (double)z / fx : 0.0; };
+  auto yat = [&](int i) { const float z = zat(i); return z > 0.f ? ((double)(i / W) - cy) * (double)z / fy : 0.0; };
+  if (lane < kMdC32) {
+    const int rows = (g.n / 8) / 4;
+    float rem = 0.f;
+    for (int r = g.nb32 * 16; r < rows; ++r) rem = rem + zat(r * kMdC32 + lane);
+    cz[lane] = md_upper<float>(reinterpret_cast<const float *>(wm) + lane, kMdC32, g.nb32, rem);
+  } else {
+    const int q = (lane - 32) >> 4, col = lane & 15, rows = (g.n / 4) / 4;
+    double rem = 0.0;
+    for (int r = g.nb64 * 16; r < rows; ++r) rem = rem + (q ? yat(r * kMdC64 + col) : xat(r * kMdC64 + col));
+    cxy[q * kMdC64 + col] = md_upper<double>(
+        reinterpret_cast<const double *>(wm + md_ws_f64_off(g)) + (size_t)q * 2 * g.nspan * kMdC64 + col, kMdC64, g.nb64, rem);
+  }
+  __syncthreads();
+  // vectors 1..3 onto vector 0 (after the tail vectors of the row remainder), then the lanes in order onto the scalar tail
+  __shared__ double res[4];                                 // X, Y, Z sums and the float32 count
+  if (lane == 0) {
+    const int *pc = reinterpret_cast<const int *>(wm + md_ws_cnt_off(g));
+    int c = 0;
+    for (int i = 0; i < g.nspan; ++i) c += pc[i];
+    res[3] = (double)((float)c + 1e-8f);                    // count_nonzero + 1e-8 is float32 in the reference
+    const int vec = g.n / 8;
+    float ps[8];
+    for (int l = 0; l < 8; ++l) {
+      float a = cz[l];
+      for (int r = (vec / 4) * 4; r < vec; ++r) a = a + zat(r * 8 + l);
+      ps[l] = ((a + cz[8 + l]) + cz[16 + l]) + cz[24 + l];
+    }
+    float f = 0.f;
+    for (int i = vec * 8; i < g.n; ++i) f = f + zat(i);
+    for (int l = 0; l < 8; ++l) f = f + ps[l];
+    res[2] = (double)f;
+  }
+  if (lane == 1 || lane == 2) {
+    const int q = lane - 1, vec = g.n / 4;
+    const double *c = cxy + q * kMdC64;
+    double ps[4];
+    for (int l = 0; l < 4; ++l) {
+      double a = c[l];
+      for (int r = (vec / 4) * 4; r < vec; ++r) a = a + (q ? yat(r * 4 + l) : xat(r * 4 + l));
+      ps[l] = ((a + c[4 + l]) + c[8 + l]) + c[12 + l];
+    }
+    double f = 0.0;
+    for (int i = vec * 4; i < g.n; ++i) f = f + (q ? yat(i) : xat(i));
+    for (int l = 0; l < 4; ++l) f = f + ps[l];
+    res[q] = f;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    const float cnt = (float)res[3];
+    out[s * 3 + 0] = (float)(res[0] / (double)cnt);
+    out[s * 3 + 1] = (float)(res[1] / (double)cnt);
+    out[s * 3 + 2] = (float)res[2] / cnt;
+  }
 }
 
 // Rotate the object's model points by the best template pose, translate, project with K, truncate to
@@ -480,7 +618,10 @@ extern "C" long s6d_patch_scores_workspace_floats(int S, int N1, int N2) {
   return (long)S * nslot * (2 + N2);
 }
 
-extern "C" long s6d_masked_depth_mean_workspace_bytes(int S) { return (long)S * kDepthChunks * 4 * sizeof(double); }
+extern "C" long s6d_masked_depth_mean_workspace_bytes(int S, int H, int W) {
+  if (S < 0 || H <= 0 || W <= 0) return 0;
+  return (long)((size_t)S * md_ws_per_mask(md_geom(H, W)));
+}
 
 extern "C" int s6d_masked_depth_mean_frames_f32(const float *masks, const float *depth, const int32_t *frame, int S, int H, int W,
                                                 float depth_scale, const double *K, void *workspace, float *out, void *stream);
@@ -493,16 +634,19 @@ extern "C" int s6d_masked_depth_mean_f32(const float *masks, const float *depth,
 extern "C" int s6d_masked_depth_mean_frames_f32(const float *masks, const float *depth, const int32_t *frame, int S, int H, int W,
                                                 float depth_scale, const double *K, void *workspace, float *out, void *stream) {
   if (S < 0 || H <= 0 || W <= 0) return S6D_EINVAL;
-  if ((W % 4) != 0) return S6D_EUNSUPPORTED;
+  // float4 loads of the maps; one vector of the float32 reduction at least; 16 rows per cascade level (ATen switches to
+  // 32 from 2^20 rows of the float64 reduction on: 16.7 M pixels)
+  if ((W % 4) != 0 || (long)H * W < 8 || (long)H * W >= (1l << 24)) return S6D_EUNSUPPORTED;
   if (S == 0) return S6D_OK;
   if (!masks || !depth || !out || !workspace || !K) return S6D_EINVAL;
-  const unsigned magicW = (unsigned)(((1ull << 32) + (unsigned)W - 1) / (unsigned)W);
+  const MdGeom g = md_geom(H, W);
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(masked_depth_partial_kernel, dim3(kDepthChunks, S), dim3(256), 0, st, masks, depth, H, W, magicW,
-                     depth_scale, K, frame, (double *)workspace);
+  hipLaunchKernelGGL(masked_depth_l1_kernel, dim3(g.nspan, S), dim3(256), 0, st, masks, depth, H, W, depth_scale, K,
+                     frame, (char *)workspace);
   int rc = launch_status();
   if (rc) return rc;
-  hipLaunchKernelGGL(masked_depth_final_kernel, dim3((S + 63) / 64), dim3(64), 0, st, (const double *)workspace, S, out);
+  hipLaunchKernelGGL(masked_depth_final_kernel, dim3(S), dim3(64), 0, st, masks, depth, H, W, depth_scale, K, frame,
+                     (const char *)workspace, out);
   return launch_status();
 }
 

@@ -677,7 +677,7 @@ def masked_depth_mean(masks, depth, K, depth_scale, frame=None):
     out = torch.empty(S, 3, dtype=torch.float32, device=masks.device)
     fn = _lib.lib().s6d_masked_depth_mean_workspace_bytes
     fn.restype = ctypes.c_long
-    ws = torch.empty(max(int(fn(S)), 8), dtype=torch.uint8, device=masks.device)
+    ws = torch.empty(max(int(fn(S, H, W)), 8), dtype=torch.uint8, device=masks.device)
     _call("s6d_masked_depth_mean_frames_f32", _ptr(masks), _ptr(depth), _ptr(frame) if frame is not None else _vp(0), S, H, W,
           ctypes.c_float(depth_scale), _ptr(Kd), _ptr(ws), _ptr(out), _stream())
     return out

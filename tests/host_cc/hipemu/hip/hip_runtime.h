@@ -292,6 +292,9 @@ static inline float __fmul_rn(float a, float b) { return a * b; }
 static inline float __fadd_rn(float a, float b) { return a + b; }
 static inline float __fsub_rn(float a, float b) { return a - b; }
 static inline float __fdiv_rn(float a, float b) { return a / b; }
+static inline double __dadd_rn(double a, double b) { return a + b; }
+static inline double __dmul_rn(double a, double b) { return a * b; }
+static inline double __ddiv_rn(double a, double b) { return a / b; }
 using std::max;
 using std::min;
 

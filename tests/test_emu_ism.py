@@ -49,3 +49,10 @@ def test_half_descriptors_on_the_emulator(emu, monkeypatch):
 
 def test_batched_frames_on_the_emulator(emu):
     T.test_batched_frames_equal_the_per_frame_loop()
+
+
+def test_translation_sum_order_on_the_emulator(emu):
+    """masked_depth_l1 / masked_depth_final follow ATen's CPU cascade order bit for bit at every remainder shape."""
+    for H, W in ((120, 160), (37, 44), (130, 100), (2, 4), (96, 1028)):
+        T.test_translation_sum_order_vs_oracle(H, W)
+    T.test_frame_scoring_vs_reference_golden("ism_scoring_p128.npz")

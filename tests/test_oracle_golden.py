@@ -117,12 +117,30 @@ def test_ism_scoring_matches_reference():
         np.testing.assert_allclose(out[k].numpy(), g[k], rtol=1e-6, atol=1e-6, err_msg=k)
     t = oism.mean_translation(inp["masks"][out["sel"]], inp["depth"], inp["K"])
     np.testing.assert_allclose(t.numpy(), g["translation"], rtol=1e-6, atol=1e-7)
+    # the explicit-order restatement (ATen's CPU cascade sum, oracle/aten_sum.py) carries the golden's bits on any host
+    tp = oism.mean_translation_pinned(inp["masks"][out["sel"]], inp["depth"], inp["K"])
+    assert np.array_equal(tp.numpy(), g["translation"])
+
     xyxy = torch.cat((out["image_uv"].min(1).values, out["image_uv"].max(1).values), -1).float()
     np.testing.assert_allclose(oism.compute_iou(xyxy, torch.from_numpy(g["boxes2"])).numpy(), g["iou2"], rtol=1e-6)
     # quirk Q3: one empty intersection zeroes everything
     b = torch.from_numpy(g["boxes2"]).clone()
     b[0] = torch.tensor([0.0, 0.0, 1.0, 1.0]) + 10000
     assert oism.compute_iou(xyxy, b) == 0.0
+
+
+def test_aten_sum_order_is_this_torch_builds_order():
+    """oracle/aten_sum.py against torch.sum of THIS build, bit for bit, float32 and float64, sizes with every remainder.
+    (More than one output row: a single-output reduction is split over threads by ATen and is not what the ISM calls.)"""
+    from oracle import aten_sum
+    rng = np.random.default_rng(0)
+    for n in (480 * 640, 480 * 640 + 37, 1000, 12345, 64 * 17, 100003, 8, 9):
+        x = rng.random((3, n)) * (rng.random((3, n)) > 0.5)
+        for dt, fn in ((np.float32, aten_sum.sum_f32), (np.float64, aten_sum.sum_f64)):
+            a = x.astype(dt)
+            if n < 16 and dt == np.float32:
+                continue
+            assert np.array_equal(torch.from_numpy(a).sum(1).numpy(), fn(a)), (n, dt)
 
 
 # ----------------------------------------------------------------------------- PN2 (no reference vectors exist)

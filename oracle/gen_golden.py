@@ -90,6 +90,43 @@ def gen_pem():
     print("KAT |dR|_F", dR, "score", rec["kat_pred_pose_score"], "t", rec["kat_pred_t"])
 
 
+PEM_WC_CASE = dict(B=2, weight_seed=1, input_seed=91, rand_seed=92)
+
+
+def gen_pem_wc():
+    """Net.forward on a WELL-CONDITIONED frame (tests/golden/pem_wc.npz): the template features are the reference feature
+    extractor's own output for the observed pixels (dense_fo = dense_fm), so observed point i matches template point i the way
+    a rendered template matches the object it shows.  (The pem_b2 `net_*` case feeds template features that are unrelated
+    to the random-weight ViT's output: its pose is the arg-max over near-tied hypotheses and flips under a 1e-3 relative
+    perturbation of the features -- see tests/test_host_pem.py::test_conditioning_of_the_two_net_forward_cases.)  Stored:
+    the reference Net's pose; the test recomputes dense_fo with the oracle's feature extractor, which this script checks to be
+    bit-identical with the reference's on this host."""
+    from . import pem as opem
+    ns = rh.pem()
+    cfg = rh.pem_cfg()
+    net = ns.pose_estimation_model.Net(cfg.model).eval()
+    seeded.load_seeded(net, PEM_WC_CASE["weight_seed"])
+    B = PEM_WC_CASE["B"]
+    inp = synth.pem_inputs(B, seed=PEM_WC_CASE["input_seed"])
+    ep = {k: inp[k] for k in ("pts", "rgb", "rgb_choose", "model", "dense_po", "dense_fo")}
+    rec = {}
+    with torch.no_grad():
+        _, dense_fm, _, _, _ = net.feature_extraction(dict(ep))
+        W = {k: v.clone() for k, v in net.state_dict().items()}
+        assert torch.equal(opem.feature_extraction(W, ep)[1], dense_fm), "oracle feature extractor != reference on this host"
+        ep["dense_fo"] = dense_fm.clone()
+        torch.manual_seed(PEM_WC_CASE["rand_seed"])
+        out = net(dict(ep))
+        for k in ("init_R", "init_t", "pred_R", "pred_t", "pred_pose_score"):
+            rec["net_" + k] = out[k].numpy()
+    rec["fo_sum"], rec["fo_smp"] = digest(dense_fm, 4099)
+    rec["gt_R"], rec["gt_t"] = inp["gt_R"].numpy(), inp["gt_t"].numpy()
+    rec["case"] = np.array(str(PEM_WC_CASE))
+    np.savez_compressed(os.path.join(OUT, "pem_wc.npz"), **rec)
+    print("pem_wc.npz |dR|_F vs truth", np.linalg.norm(rec["net_pred_R"] - rec["gt_R"], axis=(1, 2)),
+          "|dt|", np.abs(rec["net_pred_t"] - rec["gt_t"]).max(), "score", rec["net_pred_pose_score"])
+
+
 def gen_pem_b32():
     """The matching path (coarse + fine point matching, pose solvers) of the reference Net at the BENCHED batch (B = 32): the
     reference sub-modules in Net.forward's order on the known-answer inputs, outputs only (tests/golden/pem_b32.npz)."""
@@ -614,4 +651,4 @@ def gen_dinov2():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    {"pem": gen_pem, "pem_b32": gen_pem_b32, "example": gen_example, "sam": gen_sam, "ism": gen_ism, "dinov2": gen_dinov2, "sam_decoder": gen_sam_decoder, "handoff": gen_handoff, "pem_pre": gen_pem_pre, "pem_results": gen_pem_results, "detections_ops": gen_detections_ops, "sam_transforms": gen_sam_transforms, "sam_state_dict": gen_sam_state_dict}[sys.argv[1]]()
+    {"pem": gen_pem, "pem_b32": gen_pem_b32, "pem_wc": gen_pem_wc, "example": gen_example, "sam": gen_sam, "ism": gen_ism, "dinov2": gen_dinov2, "sam_decoder": gen_sam_decoder, "handoff": gen_handoff, "pem_pre": gen_pem_pre, "pem_results": gen_pem_results, "detections_ops": gen_detections_ops, "sam_transforms": gen_sam_transforms, "sam_state_dict": gen_sam_state_dict}[sys.argv[1]]()

@@ -32,6 +32,30 @@ def test_fused_attention_vs_oracle(B, H, nh, hd, ws):
     assert err.max() < 3e-2 and err.mean() < 3e-3, (err.max().item(), err.mean().item())
 
 
+@pytest.mark.parametrize("ws", [14, 0])
+def test_benched_launch_group_b16_h16(ws):
+    """The launch group bench.py runs (16 frames x 16 heads x hd 80 on the 64 x 64 grid: 6400 window items through the
+    persistent attn_window16p_kernel, 4096 workgroups of attn_global64_kernel, both with the XCD-aware item order that is
+    taken when B * heads % 8 == 0): three distinct frames placed in the 16 slots in a scrambled order must come out, slot by
+    slot, BIT FOR BIT as the same frame run alone (B = 1: a different item -> workgroup / XCD assignment, same arithmetic),
+    and frame 0 is held to the oracle element by element."""
+    from oracle import sam as osam
+    from sam6d_amd import ops
+    H, nh, hd = 64, 16, 80
+    bias, rh, rw, qkv3 = (t.to(torch.bfloat16) for t in _mk(3, H, nh, hd, ws, 4242 + ws))
+    order = [0, 2, 1, 1, 0, 2, 2, 0, 1, 0, 2, 1, 2, 2, 0, 1]
+    dev = lambda t: t.cuda().contiguous()
+    run = lambda x: ops.window_attention(dev(x), dev(bias), dev(rh), dev(rw), nh, ws, hd ** -0.5)
+    alone = [run(qkv3[i:i + 1]) for i in range(3)]
+    out = run(qkv3[order])
+    assert out.shape == (16, H, H, nh * hd)
+    for slot, i in enumerate(order):
+        assert torch.equal(out[slot], alone[i][0]), f"slot {slot} (frame {i}) differs from the B = 1 launch"
+    ref = osam.windowed_attention_from_qkv(qkv3[0:1].float(), bias.float(), rh.float(), rw.float(), nh, ws)
+    err = (alone[0].float().cpu() - ref).abs()
+    assert err.max() < 3e-2 and err.mean() < 3e-3, (err.max().item(), err.mean().item())
+
+
 @pytest.mark.parametrize("B,H,nh,hd,ws", [(1, 28, 2, 80, 14), (1, 32, 2, 80, 0), (2, 20, 4, 80, 14), (1, 16, 2, 64, 7), (1, 64, 2, 80, 0)])
 def test_head_major_layout_equals_token_major(B, H, nh, hd, ws):
     """The attention kernels on the head-major q/k/v tensor (3 heads, B H W, hd) -- what the qkv GEMM's column-block epilogue

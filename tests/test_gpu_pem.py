@@ -40,8 +40,36 @@ def test_net_forward_vs_reference_golden(net):
         out = net(_to(ep, "cuda"))
     dR = np.linalg.norm(out["pred_R"].cpu().numpy() - g["net_pred_R"], axis=(1, 2))
     dt = np.abs(out["pred_t"].cpu().numpy() - g["net_pred_t"]).max()
-    assert dR.max() <= R_TOL and dt <= T_TOL_M * 10, (dR, dt)   # random-ViT features: ill-conditioned case
+    util.record_margin("net_forward_pem_b2_fp32vit", dR=dR.max(), dt_m=dt)
+    # the fp32 feature path at the stated bar (the case is chaotic beyond fp32-class feature noise:
+    # tests/test_host_pem.py::test_conditioning_of_the_two_net_forward_cases)
+    assert dR.max() <= R_TOL and dt <= T_TOL_M, (dR, dt)
     np.testing.assert_allclose(out["pred_pose_score"].cpu().numpy(), g["net_pred_pose_score"], atol=5e-3)
+
+
+@pytest.mark.parametrize("vit", ["fp32", "bf16"])
+def test_net_forward_well_conditioned_vs_reference_golden(net, vit, monkeypatch):
+    """Net.forward on the well-conditioned frame of tests/golden/pem_wc.npz (template features = the reference feature
+    extractor's own output for the observed pixels; pose by the reference Net).  fp32 ViT-B: |R - R_ref|_F <= 1e-3 and
+    |t - t_ref| <= 1e-3 mm.  bf16 ViT-B (the throughput configuration of BASELINE configs[1]): rotation at the same bar;
+    the translation carries the linear response of the matcher to bf16-class feature noise measured on the oracle
+    (|dt| ~ 3e-4 m per unit relative noise): bound 1e-2 mm, the measured value is recorded under profiles/."""
+    g = util.golden("pem_wc.npz")
+    case = ast.literal_eval(str(g["case"]))
+    inp = synth.pem_inputs(case["B"], seed=case["input_seed"])
+    ep = {k: inp[k] for k in ("pts", "rgb", "rgb_choose", "model", "dense_po", "dense_fo")}
+    W = util.pem_weights(case["weight_seed"])
+    with torch.no_grad():
+        ep["dense_fo"] = opem.feature_extraction(W, ep)[1]          # the checker's fp32 features stand for the template store
+    util.assert_digest_close(ep["dense_fo"], g["fo_sum"], g["fo_smp"], 4099, 1e-4, 1e-5, "template features")
+    ep["coarse_rand_u"] = synth.coarse_uniforms(case["B"], case["rand_seed"])
+    monkeypatch.setenv("S6D_PEM_VIT_DTYPE", vit)
+    with torch.no_grad():
+        out = net(_to(ep, "cuda"))
+    dR = np.linalg.norm(out["pred_R"].cpu().numpy() - g["net_pred_R"], axis=(1, 2)).max()
+    dt = np.abs(out["pred_t"].cpu().numpy() - g["net_pred_t"]).max()
+    util.record_margin(f"net_forward_pem_wc_{vit}vit", dR=dR, dt_m=dt)
+    assert dR <= R_TOL and dt <= (T_TOL_M if vit == "fp32" else 10 * T_TOL_M), (vit, dR, dt)
 
 
 def test_known_answer_vs_reference_golden_and_truth(net):
@@ -128,8 +156,12 @@ def test_bf16_vit_features_keep_the_pose(net, monkeypatch):
     e32 = (out32["pred_R"].cpu() - gt).norm(dim=(1, 2))
     e16 = (out16["pred_R"].cpu() - gt).norm(dim=(1, 2))
     d = (out16["pred_R"] - out32["pred_R"]).norm(dim=(1, 2)).cpu()
-    assert e32.max() < 2e-3 and e16.max() < 2e-3 and d.max() < 2e-3, (e32, e16, d)
-    assert (out16["pred_t"] - out32["pred_t"]).abs().max().item() < 2e-4
+    dt = (out16["pred_t"] - out32["pred_t"]).abs().max().item()
+    util.record_margin("bf16_vs_fp32_vit_features", e32=e32.max(), e16=e16.max(), dR=d.max(), dt_m=dt)
+    # both recover the synthetic pose (truth carries the 1e-4 m point noise) and agree with each other at the rotation bar;
+    # translation: the matcher's linear response to bf16-class feature noise (see test_net_forward_well_conditioned_*)
+    assert e32.max() < 2e-3 and e16.max() < 2e-3 and d.max() <= R_TOL, (e32, e16, d)
+    assert dt <= 10 * T_TOL_M, dt
 
 
 def test_upsample_gather_kernel_vs_dense_reference(net):
@@ -178,4 +210,5 @@ def test_real_example_frame_through_preprocessing_and_net(net):
             os.environ["S6D_PEM_VIT_DTYPE"] = old
     dR = np.linalg.norm(res["pred_R"].cpu().numpy() - g["ref_pred_R"], axis=(1, 2))
     dt = np.abs(res["pred_t"].cpu().numpy() - g["ref_pred_t"]).max()
-    assert dR.max() <= R_TOL * 10 and dt <= T_TOL_M * 100, (dR, dt)    # random-ViT features on a real crop: ill-conditioned pose
+    util.record_margin("example_frame_fp32vit", dR=dR.max(), dt_m=dt)
+    assert dR.max() <= R_TOL and dt <= T_TOL_M, (dR, dt)

@@ -50,12 +50,46 @@ def test_vit_h_two_blocks_and_full_vs_reference_golden(monkeypatch):
     with torch.no_grad():
         t = m.forward_tokens(x, upto=2)
     util.assert_digest_close(t, g["h_blk2_sum"], g["h_blk2_smp"], 1009, 1e-3, 1e-4, "vit-h 2 blocks fp32")
+    # the full 32-block fp32 path on the device against the reference's fp32 output (sample of the golden)
+    with torch.no_grad():
+        y32 = m(x).float().cpu()
+    smp = y32.reshape(-1)[::251].numpy()
+    np.testing.assert_allclose(smp, g["h_smp"], rtol=1e-3, atol=1e-3 * np.abs(g["h_smp"]).max())
+
+
+E_BLOCK = 4e-3       # per-block rms rounding of the bf16 path relative to the block's output rms (test_vit_h_block_bf16_* bound)
+
+
+def test_vit_h_bf16_error_growth_model(monkeypatch):
+    """The whole ViT-H in the benched dtype, 1024^2 input, held to an ERROR MODEL instead of a correlation.
+    One block of the bf16 path adds an rms error of at most E_BLOCK of its output rms (element-level test above, measured
+    2.7e-3); the blocks' roundings are independent, the residual stream carries them forward, so after k blocks the token map
+    must sit within E_BLOCK * sqrt(k + 1) * GAIN of the fp32 path's (rms over the map, relative to the fp32 rms; "+1" = the
+    bf16 patch embedding; GAIN = 1.5 allows for the Jacobian of the later blocks acting on earlier errors).  Checked at
+    k = 1, 2, 4, 8, 16, 32 against the SAME model in fp32 on the device (pinned to the reference golden by the test above),
+    then once more on the neck's output, whose two LayerNorm2d renormalise the map (same bound)."""
+    from sam6d_amd.sam.image_encoder import build_vit_h
+    m = seeded.load_seeded(build_vit_h().eval(), 3).cuda()
+    x = synth.sam_input(1, 5, 1024).cuda()
+    GAIN = 1.5
+    rel = {}
+    for k in (1, 2, 4, 8, 16, 32):
+        with torch.no_grad():
+            t32 = m.forward_tokens(x, upto=k).float()
+            with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                t16 = m.forward_tokens(x.to(torch.bfloat16), upto=k).float()
+        rel[k] = ((t16 - t32).pow(2).mean().sqrt() / t32.pow(2).mean().sqrt()).item()
+    monkeypatch.setenv("S6D_SAM_DTYPE", "fp32")
+    with torch.no_grad():
+        y32 = m(x).float()
     monkeypatch.setenv("S6D_SAM_DTYPE", "bf16")
     with torch.no_grad():
-        y = m(x).float().cpu()
-    smp = y.reshape(-1)[::251].numpy()
-    assert np.corrcoef(smp, g["h_smp"])[0, 1] > 0.995, np.corrcoef(smp, g["h_smp"])[0, 1]
-    assert np.abs(smp - g["h_smp"]).mean() < 5e-2
+        y16 = m(x).float()
+    rel["neck"] = ((y16 - y32).pow(2).mean().sqrt() / y32.pow(2).mean().sqrt()).item()
+    util.record_margin("vit_h_bf16_error_growth", **{f"rel_{k}": v for k, v in rel.items()})
+    for k in (1, 2, 4, 8, 16, 32):
+        assert rel[k] <= E_BLOCK * (k + 1) ** 0.5 * GAIN, rel
+    assert rel["neck"] <= E_BLOCK * 33 ** 0.5 * GAIN, rel
 
 
 def test_preprocess_matches_oracle():

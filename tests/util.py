@@ -50,3 +50,16 @@ def dinov2_shapes(cfg):
                   p + "mlp.fc1.weight": (4 * D, D), p + "mlp.fc1.bias": (4 * D,), p + "mlp.fc2.weight": (D, 4 * D),
                   p + "mlp.fc2.bias": (D,)})
     return s
+
+
+def record_margin(test, **values):
+    """Append the measured distance of a parity assertion from its bound to gpurun_out/margins.jsonl (merged back from the GPU box;
+    the copy that is judged lives under profiles/).  Never fails a test."""
+    import json
+    try:
+        d = os.path.join(os.path.dirname(GOLDEN.rstrip("/")), "..", "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "margins.jsonl"), "a") as f:
+            f.write(json.dumps(dict(test=test, **{k: (float(v) if not isinstance(v, (list, str)) else v) for k, v in values.items()})) + "\n")
+    except Exception:
+        pass

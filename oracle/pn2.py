@@ -31,10 +31,14 @@ def lib():
         fp, ip = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)
         ci, cf = ctypes.c_int, ctypes.c_float
         L.s6d_oracle_fps.argtypes = [fp, ci, ci, ci, ip]
+        L.s6d_oracle_fps_temp.argtypes = [fp, ci, ci, ci, ip, fp]
+        L.s6d_oracle_fps_temp.restype = ci
         L.s6d_oracle_gather.argtypes = [fp, ip, ci, ci, ci, ci, fp]
         L.s6d_oracle_ball_query.argtypes = [fp, fp, ci, ci, ci, cf, ci, ip]
         L.s6d_oracle_group_points.argtypes = [fp, ip, ci, ci, ci, ci, ci, fp]
         L.s6d_oracle_opt_n_threads.argtypes = [ci]
+        L.s6d_oracle_set_contraction.argtypes = [ci]
+        L.s6d_oracle_set_contraction.restype = None
         for f in (L.s6d_oracle_fps, L.s6d_oracle_gather, L.s6d_oracle_ball_query,
                   L.s6d_oracle_group_points, L.s6d_oracle_opt_n_threads):
             f.restype = ci
@@ -68,6 +72,17 @@ def furthest_point_sampling(points, nsamples):
     rc = lib().s6d_oracle_fps(_f(p), B, N, nsamples, _i(out))
     assert rc == 0, rc
     return torch.from_numpy(out)
+
+
+def furthest_point_sampling_with_temp(points, nsamples):
+    """-> (idx, temp): also the kernel's running minimum squared distances after the last selection."""
+    p = _np_f32(points)
+    B, N, _ = p.shape
+    out = np.zeros((B, nsamples), dtype=np.int32)
+    temp = np.zeros((B, N), dtype=np.float32)
+    rc = lib().s6d_oracle_fps_temp(_f(p), B, N, nsamples, _i(out), _f(temp))
+    assert rc == 0, rc
+    return torch.from_numpy(out), torch.from_numpy(temp)
 
 
 def gather_points(points, idx):
@@ -108,3 +123,18 @@ def _unused(*a, **k):  # names that must exist on the pybind surface; training o
 
 
 gather_points_grad = group_points_grad = three_nn = three_interpolate = three_interpolate_grad = _unused
+
+
+class contraction:
+    """``with contraction(mode):`` -- the spelling of a*a + b*b + c*c inside the distance (pn2_oracle.c header):
+    0 nvcc default (the product's), 1 LLVM's, 2 none."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.old = lib().s6d_oracle_get_contraction()
+        lib().s6d_oracle_set_contraction(self.mode)
+
+    def __exit__(self, *a):
+        lib().s6d_oracle_set_contraction(self.old)

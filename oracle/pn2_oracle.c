@@ -14,6 +14,18 @@
  * fma(c,c, fma(b,b, a*a)).  Both this oracle and the HIP kernels spell that
  * contraction out with fmaf() and are built with -ffp-contract=off so that
  * nothing else is fused; index outputs are therefore comparable bit for bit.
+ *
+ * Pinning (round 3): oracle/build_ref.py compiles the reference's own .cu
+ * files for the host (oracle/_ref/); tests/test_oracle_pn2_ref.py holds this
+ * file to them bit for bit.  What the source does not decide is the
+ * contraction, so s6d_oracle_set_contraction() selects the spelling:
+ *   0  nvcc default as stated above (the product's spelling; NOT reproducible
+ *      from the unmodified source with any compiler in this image: the one
+ *      unpinned assumption left)
+ *   1  LLVM's contraction of the same expression: fma(c,c, fma(a,a, b*b))
+ *      (== oracle/_ref built with -ffp-contract=fast -mfma)
+ *   2  none: ((a*a + b*b) + c*c), every operation rounded
+ *      (== oracle/_ref built with -ffp-contract=off; nvcc --fmad=false)
  */
 #include <math.h>
 #include <stdint.h>
@@ -29,9 +41,15 @@ int s6d_oracle_opt_n_threads(int work_size) {
   return p;
 }
 
+static int g_contraction = 0;
+void s6d_oracle_set_contraction(int mode) { g_contraction = mode; }
+int s6d_oracle_get_contraction(void) { return g_contraction; }
+
 static inline float sqdist3(float ax, float ay, float az, float bx, float by,
                             float bz) {
   const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  if (g_contraction == 1) return fmaf(dz, dz, fmaf(dx, dx, dy * dy));
+  if (g_contraction == 2) return (dx * dx + dy * dy) + dz * dz;
   return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
 }
 
@@ -41,7 +59,13 @@ static inline float sqdist3(float ax, float ay, float az, float bx, float by,
  * literally: thread `tid` scans k = tid, tid+bs, ... keeping the first
  * maximum (strict >), then a shared-memory tree where the lower slot wins
  * ties (__update: v2 > v1 ? i2 : i1). */
+int s6d_oracle_fps_temp(const float *xyz, int B, int N, int M, int32_t *idx, float *temp_out);
 int s6d_oracle_fps(const float *xyz, int B, int N, int M, int32_t *idx) {
+  return s6d_oracle_fps_temp(xyz, B, N, M, idx, NULL);
+}
+/* temp_out (B,N) or NULL: the kernel's `temp` array after the last selection (the running minimum squared distances --
+ * the float bits the contraction decides; compared with the reference kernel's own `temp` in tests/test_oracle_pn2_ref.py) */
+int s6d_oracle_fps_temp(const float *xyz, int B, int N, int M, int32_t *idx, float *temp_out) {
   if (B < 0 || N <= 0 || M < 0) return 1;
   if (M == 0 || B == 0) return 0;
   const int bs = s6d_oracle_opt_n_threads(N);
@@ -81,6 +105,7 @@ int s6d_oracle_fps(const float *xyz, int B, int N, int M, int32_t *idx) {
       old = dists_i[0];
       out[j] = old;
     }
+    if (temp_out) memcpy(temp_out + (size_t)b * N, temp, sizeof(float) * (size_t)N);
   }
   free(temp);
   free(dists);

@@ -65,13 +65,13 @@ def test_vit_h_bf16_error_growth_model(monkeypatch):
     One block of the bf16 path adds an rms error of at most E_BLOCK of its output rms (element-level test above, measured
     2.7e-3); the blocks' roundings are independent, the residual stream carries them forward, so after k blocks the token map
     must sit within E_BLOCK * sqrt(k + 1) * GAIN of the fp32 path's (rms over the map, relative to the fp32 rms; "+1" = the
-    bf16 patch embedding; GAIN = 1.5 allows for the Jacobian of the later blocks acting on earlier errors).  Checked at
+    bf16 patch embedding; GAIN = 1: measured 4.3e-3 at k = 1 and 1.3e-2 at k = 32, profiles/r03_parity_margins_*.jsonl).  Checked at
     k = 1, 2, 4, 8, 16, 32 against the SAME model in fp32 on the device (pinned to the reference golden by the test above),
     then once more on the neck's output, whose two LayerNorm2d renormalise the map (same bound)."""
     from sam6d_amd.sam.image_encoder import build_vit_h
     m = seeded.load_seeded(build_vit_h().eval(), 3).cuda()
     x = synth.sam_input(1, 5, 1024).cuda()
-    GAIN = 1.5
+    GAIN = 1.0
     rel = {}
     for k in (1, 2, 4, 8, 16, 32):
         with torch.no_grad():

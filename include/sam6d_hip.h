@@ -194,7 +194,7 @@ int s6d_add_layernorm_bf16(const void *x, const void *delta, const float *gamma,
 /* C = epilogue(A W^T + bias): the nn.Linear layers of the ViTs with the bias and the activation folded into the GEMM.
  * A (M,K) bf16, row stride lda; W (N,K) bf16 = nn.Linear.weight, row stride ldw; bias (N) f32 or NULL; C (M,N) bf16, row
  * stride ldc (strides in elements, multiples of 8; 16-byte aligned bases).  epilogue: 0 = none, 1 = exact (erf) GELU.
- * N % 256 == 0, K % 64 == 0, any M.  max_blocks: workgroups to launch (<= 0: one persistent workgroup per CU, 256).
+ * N % 128 == 0 (N % 256 == 0 takes the 256 x 256-tile kernel, otherwise the 256 x 128-tile one), K % 64 == 0, any M.  max_blocks: workgroups to launch (<= 0: one persistent workgroup per CU, 256).
  * fp32 accumulation on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16), one rounding to bf16 at the end.
  * ref: segment_anything/modeling/common.py:13-28 (MLPBlock: lin1 -> GELU -> lin2), image_encoder.py:224-240 (qkv, proj),
  * :90-104 (neck 1x1 conv); the same statements in timm's ViT-B (Pose_Estimation_Model/model/feature_extraction.py:17-35)

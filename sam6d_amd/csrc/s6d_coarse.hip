@@ -35,11 +35,14 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_sample_kernel(const float *
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int L = (M1 - 1) * (M2 - 1);
   float *q = reinterpret_cast<float *>(cs_smem);                        // [L] bins, later their normalised prefix sums
-  float *rs = q + L;                                                     // [M1] row sums
+  // the per-wave scratch of passes 1 / 2 aliases the bins; with few rows (M1 - 1 < 32) it is the larger of the two, so the
+  // small arrays start behind whichever is longer (they used to start at q + L and were overrun for N1 <= 32)
+  const int Lq = max(L, CS_WAVES * M2 * 2);
+  float *rs = q + Lq;                                                    // [M1] row sums
   float *cs = rs + M1;                                                   // [M2] column sums
   float *w1 = cs + M2;                                                   // [M1] (entry 0 unused)
   float *w2 = w1 + M1;                                                   // [M2]
-  double *wt = reinterpret_cast<double *>(cs_smem + (((size_t)(L + 2 * M1 + 2 * M2) * 4 + 7) & ~(size_t)7));   // [CS_WAVES]
+  double *wt = reinterpret_cast<double *>(cs_smem + (((size_t)(Lq + 2 * M1 + 2 * M2) * 4 + 7) & ~(size_t)7));   // [CS_WAVES]
   // scratch of passes 1 / 2 (per-wave column partials) aliases the bin array, which is only written in pass 3
   float *part = q;                                                       // [CS_WAVES][M2]
   unsigned long long *kpart = reinterpret_cast<unsigned long long *>(q);  // [CS_WAVES][M2]
@@ -257,10 +260,10 @@ using namespace s6d;
 
 static size_t cs_lds_bytes(int M1, int M2) {
   const size_t L = (size_t)(M1 - 1) * (M2 - 1);
-  size_t bins = (L + 2 * (size_t)M1 + 2 * (size_t)M2) * 4;
+  const size_t scratch = (size_t)CS_WAVES * M2 * 2;                      // floats: the u64 column partials alias the bins
+  size_t bins = ((L > scratch ? L : scratch) + 2 * (size_t)M1 + 2 * (size_t)M2) * 4;   // same layout as the kernel's
   bins = (bins + 7) & ~(size_t)7;
-  const size_t scratch = (size_t)CS_WAVES * M2 * 8;                      // the u64 column partials alias the bins
-  return (bins > scratch ? bins : scratch) + CS_WAVES * 8;
+  return bins + CS_WAVES * 8;
 }
 
 extern "C" int s6d_coarse_sample_f32(const float *atten, const float *rand_u, int B, int M1, int M2, int n_u, int32_t *pair,

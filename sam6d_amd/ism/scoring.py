@@ -207,6 +207,10 @@ class FrameScorer(ScoringMixin):
         dev = qry_cls.device
         sel, pobj, sem, bt = self.compute_semantic_score(qry_cls.reshape(F_ * P, -1))
         frame = torch.div(sel, P, rounding_mode="floor")
+        if sel.numel() == 0:                                  # no proposal above the semantic threshold in any frame
+            z = sem.new_zeros(0)
+            return dict(frame=frame, sel=sel, pred_obj=pobj, semantic=sem, best_template=bt, appearance=z, iou=z, visible_ratio=z,
+                        final=z, image_uv=torch.zeros(0, self.ref_data["pointcloud"].shape[1], 2, dtype=torch.int32, device=dev))
         qp = qry_patch.reshape(F_ * P, *qry_patch.shape[2:])[sel]
         appe, ref = self.compute_appearance_score(bt, pobj, qp)
         Kf = K if K.dim() == 3 else K[None].expand(F_, 3, 3)
@@ -228,7 +232,8 @@ class FrameScorer(ScoringMixin):
         wh_a, wh_b, wh_i = bb_a[:, 2:4] - bb_a[:, 0:2], bb_b[:, 2:4] - bb_b[:, 0:2], br - tl
         ai = wh_i[:, 0] * wh_i[:, 1]
         iou = ai / (wh_a[:, 0] * wh_a[:, 1] + wh_b[:, 0] * wh_b[:, 1] - ai)
-        bad = torch.zeros(F_, dtype=torch.bool, device=dev).index_put_((frame,), ~(wh_i > 0).all(dim=1), accumulate=True)
+        # per-frame OR as an integer count (accumulating into a bool tensor is backend-defined)
+        bad = torch.zeros(F_, dtype=torch.int32, device=dev).index_add_(0, frame, (~(wh_i > 0).all(dim=1)).to(torch.int32)) > 0
         geo = torch.where(bad[frame], torch.zeros_like(iou), iou)
         final = (sem + appe + geo * vr) / (1 + 1 + vr)
         return dict(frame=frame, sel=sel - frame * P, pred_obj=pobj, semantic=sem, best_template=bt, appearance=appe, iou=geo,

@@ -5,6 +5,7 @@ Every function enqueues hand-written gfx950 kernels on torch's current stream an
 returns freshly allocated outputs; none of them has a CPU implementation.
 """
 import ctypes
+import os
 
 import torch
 
@@ -501,9 +502,17 @@ def gemm_bf16(a, w, bias=None, gelu=False, out=None, max_blocks=0, col_block=0):
         out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
     else:
         _chk(out, torch.bfloat16, "out", 2)
-    _call("s6d_gemm_bf16", _ptr(a2), ctypes.c_long(a2.stride(0)), _ptr(w), ctypes.c_long(w.stride(0)),
-          _ptr(bias) if bias is not None else _vp(0), _ptr(out), ctypes.c_long(out.stride(0)), M, N, K, 1 if gelu else 0,
-          int(max_blocks), _stream())
+        if tuple(out.shape) != (M, N) or out.stride(1) != 1 or out.stride(0) % 8 or out.data_ptr() % 16:
+            raise ValueError(f"out must be ({M}, {N}) bf16 with contiguous, 16-byte aligned rows (stride % 8 == 0); got "
+                             f"{tuple(out.shape)} strides {tuple(out.stride())}")
+    # the kernel's staging addresses are 32-bit byte offsets from A: rows go through in slabs below 2 GiB (ViT-H lin2 reaches
+    # the limit at 52 frames per call)
+    rows = max(256, ((2 ** 31 - 1) // (2 * a2.stride(0))) // 256 * 256)
+    for r0 in range(0, M, rows):
+        r1 = min(M, r0 + rows)
+        _call("s6d_gemm_bf16", _ptr(a2[r0:r1]), ctypes.c_long(a2.stride(0)), _ptr(w), ctypes.c_long(w.stride(0)),
+              _ptr(bias) if bias is not None else _vp(0), _ptr(out[r0:r1]), ctypes.c_long(out.stride(0)), r1 - r0, N, K,
+              1 if gelu else 0, int(max_blocks), _stream())
     return out.reshape(*a.shape[:-1], N)
 
 
@@ -673,6 +682,10 @@ def masked_depth_mean(masks, depth, K, depth_scale, frame=None):
         _chk(frame, torch.int32, "frame", 1)
         if K.dim() != 3 or tuple(K.shape[1:]) != (3, 3) or K.shape[0] != depth.shape[0] or frame.shape[0] != S:
             raise ValueError(f"batched call: depth (F,H,W), K (F,3,3), frame (S); got {tuple(depth.shape)}, {tuple(K.shape)}, {tuple(frame.shape)}")
+    if frame is not None and os.environ.get("S6D_DEBUG") and S:          # costs a host round trip: debug runs only
+        lo, hi = int(frame.min()), int(frame.max())
+        if lo < 0 or hi >= depth.shape[0]:
+            raise ValueError(f"frame indices span [{lo}, {hi}] but there are {depth.shape[0]} frames")
     Kd = K.detach().to(device=masks.device, dtype=torch.float64).contiguous()
     out = torch.empty(S, 3, dtype=torch.float32, device=masks.device)
     fn = _lib.lib().s6d_masked_depth_mean_workspace_bytes
@@ -709,12 +722,12 @@ def have(name):
     if name not in _FUSED:
         sym = {"rpe_attention": "s6d_rpe_attention_f32", "geo_embedding": "s6d_geo_embedding_f32",
                "fine_assign": "s6d_fine_assign_f32", "fine_match": "s6d_fine_match_f32", "pem_pre": "s6d_pem_compact_cloud_f32", "coarse_sample": "s6d_coarse_sample_f32", "upsample_gather": "s6d_upsample_gather_f32",
-               "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "add_layernorm": "s6d_add_layernorm_bf16", "gemm_bf16": "s6d_gemm_bf16", "win_attention": "s6d_win_attention_bf16",
+               "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "add_layernorm": "s6d_add_layernorm_bf16", "gemm_bf16": "s6d_gemm_bf16", "win_attention": "s6d_win_attention_layout_bf16",
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
-               "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_f32",
+               "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_frames_f32",
                "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "crop_resize_pad": "s6d_crop_resize_pad_f32", "samdec_img2tok": "s6d_samdec_img2tok_bf16", "samdec_tok2img": "s6d_samdec_tok2img_f32", "sam_mask_post": "s6d_sam_mask_post_f32", "nms": "s6d_nms_f32", "samdec_upscale_heads": "s6d_samdec_upscale_heads_bf16", "mha": "s6d_mha_f32",
-               "linear_attn_focus": "s6d_linear_attn_focus_f32", "project_bbox": "s6d_project_bbox_f32"}.get(name)
+               "linear_attn_focus": "s6d_linear_attn_focus_f32", "project_bbox": "s6d_project_bbox_frames_f32"}.get(name)
         import os
         disabled = name in os.environ.get("S6D_DISABLE_FUSED", "").split(",")
         _FUSED[name] = (not disabled) and sym is not None and hasattr(_lib.lib(), sym)

@@ -56,3 +56,7 @@ def test_translation_sum_order_on_the_emulator(emu):
     for H, W in ((120, 160), (37, 44), (130, 100), (2, 4), (96, 1028)):
         T.test_translation_sum_order_vs_oracle(H, W)
     T.test_frame_scoring_vs_reference_golden("ism_scoring_p128.npz")
+
+
+def test_empty_selection_on_the_emulator(emu):
+    T.test_score_frames_with_no_selected_proposal()

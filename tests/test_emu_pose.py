@@ -35,6 +35,8 @@ def test_fine_match_on_the_emulator(emu, B, M1, M2):
 
 def test_coarse_sampling_kernels_on_the_emulator(emu):
     T.test_coarse_sample_vs_oracle(emu, 2, 41, 900)
+    T.test_coarse_sample_vs_oracle(emu, 2, 9, 300)          # small M1: the scratch is longer than the bins
+    T.test_coarse_sample_vs_oracle(emu, 3, 21, 600)
     T.test_smallest_k_and_hypothesis_select_vs_library(emu)
     T.test_coarse_Rt_kernel_chain_vs_oracle(emu, 2, 40, 300, 30)
 

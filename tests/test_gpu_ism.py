@@ -190,3 +190,13 @@ def test_batched_frames_equal_the_per_frame_loop():
             assert torch.equal(out[k][rows], ref[k]), (f, k)
         iou = ref["iou"] if torch.is_tensor(ref["iou"]) else torch.zeros_like(ref["final"])
         assert torch.equal(out["iou"][rows], iou)
+
+
+def test_score_frames_with_no_selected_proposal():
+    """a semantic threshold above every proposal's score -> empty outputs, no launch with S = 0."""
+    from sam6d_amd.ism.scoring import FrameScorer
+    fr = synth.ism_inputs(P=6, O=2, T=4, C=64, n_patch=16, H=120, W=160, seed=2)
+    sc = FrameScorer(fr["ref_cls"].cuda(), fr["ref_patch"].cuda(), fr["poses"].cuda(), fr["pointcloud"].cuda(), confidence_thresh=2.0)
+    st = lambda k: torch.stack([fr[k], fr[k]]).cuda()
+    out = sc.score_frames(st("qry_cls"), st("qry_patch"), st("masks"), st("boxes"), st("depth"), st("K"))
+    assert all(out[k].shape[0] == 0 for k in ("frame", "sel", "pred_obj", "semantic", "appearance", "iou", "final", "image_uv"))

@@ -52,7 +52,7 @@ def test_pose_hypotheses_vs_oracle(ops):
     assert (t - tr)[well].abs().max() < 5e-3
 
 
-@pytest.mark.parametrize("B,M,n_u", [(3, 197, 18000), (2, 41, 900)])
+@pytest.mark.parametrize("B,M,n_u", [(3, 197, 18000), (2, 41, 900), (2, 9, 300), (3, 21, 600)])   # the last two: fewer rows than the per-wave scratch
 def test_coarse_sample_vs_oracle(ops, B, M, n_u):
     """Sampling head of compute_coarse_Rt (model_utils.py:203-219) in one kernel against the reference statements: labels exact;
     sampled bins identical except where a uniform falls within float32 rounding of a bin boundary (the bins differ in their

@@ -37,7 +37,8 @@ class FramePipeline:
         segmentor: keyword overrides of amg.generate_proposals (thresholds).  nms_per_object_thresh: the BOP flow's
         ``apply_nms_per_object_id`` after scoring (detector.py:388-390; 0.25 in configs/model/ISM_sam.yaml; the custom
         demo flow has none).  det_score_thresh: only detections scoring above it go to the PEM
-        (run_inference_custom.py:165-171, default 0.2 there); top_k=None keeps every detection.  sync_stages=False: the
+        (run_inference_custom.py:165-171, default 0.2 there); top_k=None keeps every detection, top_k="keys" keeps as many per
+        frame as that frame's sample_keys / coarse_rand_u have rows (frames with different instance counts in one group).  sync_stages=False: the
         per-stage timing synchronisations are dropped (``times`` stays empty).  The host still waits on the device where a stage's
         SHAPE depends on data -- the number of proposals surviving the filters / NMS, the crop geometry table of the
         descriptor stage (built on the host from the boxes), the number of detections kept for the PEM, the camera intrinsics
@@ -109,7 +110,7 @@ class FramePipeline:
             det.filter(torch.argsort(det.scores, descending=True, stable=True))       # back to best-first
         if self.det_thresh is not None:
             det.filter(det.scores > self.det_thresh)
-        if self.top_k is not None:
+        if isinstance(self.top_k, int):
             det.filter(slice(0, self.top_k))
         self._tick("scoring", t0)
         return det
@@ -124,13 +125,16 @@ class FramePipeline:
         give (a row of a batch does not depend on its neighbours in any kernel of this library; the library's fp32 GEMMs may
         pick another tile shape for another batch size: last-bit differences in the PEM outputs)."""
         for (_, _, _, keys, ru) in frames:
-            if self.top_k is not None and (keys.shape[0] < self.top_k or ru.shape[0] < self.top_k):
+            if isinstance(self.top_k, int) and (keys.shape[0] < self.top_k or ru.shape[0] < self.top_k):
                 raise ValueError(f"sample_keys / coarse_rand_u need one row per detection handed to the PEM (top_k={self.top_k}); "
                                  f"got {keys.shape[0]} / {ru.shape[0]}")
         t0 = time.perf_counter()
         emb = self._embed([f[0] for f in frames])
         t0 = self._tick("sam_encoder", t0)
         dets = [self._detect(emb[i:i + 1], f[0], f[1], f[2]) for i, f in enumerate(frames)]
+        if self.top_k == "keys":                                         # per-frame instance budget = rows of injected randoms
+            for det, f in zip(dets, frames):
+                det.filter(slice(0, min(f[3].shape[0], f[4].shape[0])))
         # ---- PEM: pre-processing per frame, one batch for the group ------------------------------------------------------------
         t0 = time.perf_counter()
         multi = self.tpl["model"].shape[0] > 1                          # per-object template data, indexed by predicted object

@@ -69,3 +69,67 @@ def to_bop_csv_lines(records):
         out.append(",".join((str(int(r[k, 0])), str(int(r[k, 1])), str(int(r[k, 2])), str(r[k, 3]),
                              " ".join(str(v) for v in r[k, 4:13]), " ".join(str(v) for v in t[k]), f"{float(r[k, 16])}\n")))
     return out
+
+
+def frame_records(det, poses, dataset_name, time_s=0.0):
+    """The (n, 17) record block of one frame from what FramePipeline.run_group returned for it: one row per instance the PEM
+    kept, BOP category ids (sam6d_amd.ism.handoff: LM-O id table / obj + 1), pose score x detection score in float32
+    (test_bop.py:157).  Empty when the frame has no pose."""
+    import numpy as np
+
+    from ..ism.handoff import LMO_OBJECT_IDS
+    from ..pem import results
+    if poses is None or poses["pred_R"].shape[0] == 0:
+        return torch.zeros(0, RECORD_WIDTH, dtype=torch.float32)
+    kept = poses["kept"]
+    obj = det.object_ids[kept].cpu().numpy()
+    cat = LMO_OBJECT_IDS[obj] if dataset_name == "lmo" else obj + 1
+    s = torch.from_numpy(np.ascontiguousarray(results.combined_scores(poses["pred_pose_score"], det.scores[kept])))
+    return pack_records(det.scene_id, det.image_id, torch.from_numpy(np.asarray(cat, np.float32)), s,
+                        poses["pred_R"].detach().float().cpu(), poses["pred_t"].detach().float().cpu(), time_s)
+
+
+def run_sharded(frame_ids, load_frame, pipeline, group_size=8, dataset_name="ycbv", device=None, fixed_time=None):
+    """BASELINE configs[2]: the frame loop of a test split sharded over the ranks of one node (the reference: one Lightning
+    test step per frame + a per-frame .npz + a file-glob merge, ISM model/detector.py:425-462; PEM test_bop.py:123-185).
+
+    frame_ids: the sorted list of (scene_id, im_id) of the split, identical on every rank.  Rank r of W takes frames r, r + W,
+    ... (shard_indices), loads them with ``load_frame(scene_id, im_id)`` -> the tuple FramePipeline.run_group takes, runs them
+    in groups of ``group_size`` (one SAM pass and one PEM pass per group), packs one 68-byte record per estimated pose and takes
+    part in ONE variable-length all_gather at the end (gather_records; RCCL when the process group is "nccl").  No other
+    collective.  -> dict(records = the whole split's table sorted by (scene_id, im_id) with each frame's rows in the
+    pipeline's order, identical on every rank; csv_lines; stats = per-rank [busy seconds, frames, instances] + the
+    shard-balance efficiency mean(busy) / max(busy)).  ``fixed_time``: value of the time column instead of the measured
+    per-frame seconds (the byte-for-byte tests)."""
+    import time
+
+    import torch.distributed as dist
+    dist_on = dist.is_available() and dist.is_initialized()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist_on else (0, 1)
+    sync = (lambda: torch.cuda.synchronize()) if (device is not None and torch.device(device).type == "cuda") else (lambda: None)
+    mine = shard_indices(len(frame_ids), rank, world)
+    blocks, busy, n_inst = [], 0.0, 0
+    for g0 in range(0, len(mine), group_size):
+        ids = [frame_ids[i] for i in mine[g0:g0 + group_size]]
+        frames = [load_frame(s, i) for (s, i) in ids]
+        sync()
+        t0 = time.perf_counter()
+        res = pipeline.run_group(frames)
+        sync()
+        dt = time.perf_counter() - t0
+        busy += dt
+        for (s, i), (det, poses) in zip(ids, res):
+            det.scene_id, det.image_id = s, i
+            rec = frame_records(det, poses, dataset_name, fixed_time if fixed_time is not None else dt / len(ids))
+            n_inst += rec.shape[0]
+            blocks.append(rec)
+    rec = torch.cat(blocks) if blocks else torch.zeros(0, RECORD_WIDTH)
+    dev = torch.device(device) if device is not None else rec.device
+    full = gather_records(rec.to(dev)).cpu()
+    # rank-major -> split order; a frame's rows come from one rank and stay in its order (stable sort on the frame key)
+    key = full[:, 0].double() * (1 << 24) + full[:, 1].double()
+    full = full[torch.sort(key, stable=True).indices]
+    st = torch.tensor([[busy, float(len(mine)), float(n_inst)]], dtype=torch.float32)
+    stats = gather_records(torch.nn.functional.pad(st, (0, RECORD_WIDTH - 3)).to(dev)).cpu()[:, :3] if dist_on else st
+    eff = float(stats[:, 0].mean() / stats[:, 0].max()) if stats[:, 0].max() > 0 else 1.0
+    return dict(records=full, csv_lines=to_bop_csv_lines(full), stats=stats, balance_efficiency=eff, rank=rank, world=world)

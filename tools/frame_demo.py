@@ -20,9 +20,11 @@ from sam6d_amd.utils import seeded, synth  # noqa: E402
 from sam6d_amd.sam.mask_decoder import build_sam_decoder  # noqa: E402
 
 
-def build(dev, points_per_batch=1024, top_k=10, sync_stages=True):
+def build(dev, points_per_batch=1024, top_k=10, sync_stages=True, proposal_counts=None):
     """FramePipeline with the released model sizes (SAM ViT-H, mask decoder, DINOv2 ViT-L/14, PEM) on seeded weights + one
-    synthetic 480 x 640 RGB-D frame with P = 128 proposals and top_k instances for the PEM.  -> (pipe, call_args)"""
+    synthetic 480 x 640 RGB-D frame with P = 128 proposals and top_k instances for the PEM.  -> (pipe, call_args)
+    proposal_counts: a deque the caller fills with one P per frame, in call order (tools/run_sharded.py: frames with different
+    proposal counts); the synthetic proposal set is then always used, cut to P."""
     enc = seeded.load_seeded(build_vit_h().eval(), 3).to(dev)
     dec = seeded.load_seeded(build_sam_decoder(), 2).to(dev)
     dino = pd.CustomDINOv2.__new__(pd.CustomDINOv2)
@@ -49,6 +51,9 @@ def build(dev, points_per_batch=1024, top_k=10, sync_stages=True):
 
     def generate(*a, **k):
         r = real_generate(*a, **k)
+        if proposal_counts is not None:
+            P = proposal_counts.popleft() if proposal_counts else sub_masks.shape[0]
+            return dict(r, masks=sub_masks[:P], boxes=sub_boxes[:P])
         if r["masks"].shape[0] < 16:
             r = dict(r, masks=sub_masks, boxes=sub_boxes)
         return r

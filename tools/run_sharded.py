@@ -1,0 +1,125 @@
+"""BASELINE configs[2] as a runnable program: a test split's frame list sharded per frame over the GPUs of one node, every rank
+running sam6d_amd.pipeline.FramePipeline.run_group on its frames, ONE variable-length all_gather of the 68-byte pose records
+at the end (RCCL over xGMI under backend "nccl"), rank 0 writing the BOP csv.  Reference loop: Instance_Segmentation_Model/
+run_inference.py:46-51,74-77 + model/detector.py:425-462 (per-frame .npz files merged by a glob) and Pose_Estimation_Model/
+test_bop.py:123-185.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \\
+        tools/run_sharded.py --frames 256 --group 8 --out results/ycbv.csv
+
+Synthetic split (there is no dataset in the image): --frames frames of 480 x 640 RGB-D whose proposal count P (32..128) and
+instance count K (2..16) vary from frame to frame, seeded by (scene_id, im_id) -- the imbalance a real split has.  Weights are
+seeded (no checkpoint offline).  Prints one JSON line: frames/s of the whole job, per-rank busy seconds / frames / instances
+and the shard-balance efficiency mean(busy) / max(busy).  `--stand-in` replaces the five models by a deterministic function of
+the frame (host tensors, backend "gloo"): what tests/test_dist_gloo.py runs at world size 2 to check that the gathered csv is
+byte for byte the single-rank one.  NOT a scaling measurement: no multi-GPU node has run this yet."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sam6d_amd.utils import shard  # noqa: E402
+
+
+def frame_list(n, per_scene=50):
+    """Sorted (scene_id, im_id) pairs of a synthetic split."""
+    return [(48 + i // per_scene, 1 + i % per_scene) for i in range(n)]
+
+
+def frame_shape(scene_id, im_id):
+    """(P, K) of a frame: proposals entering the descriptor stage, instances handed to the PEM."""
+    g = torch.Generator().manual_seed(scene_id * 100003 + im_id)
+    return int(torch.randint(32, 129, (1,), generator=g)), int(torch.randint(2, 17, (1,), generator=g))
+
+
+class StandInPipeline:
+    """run_group with the interface of FramePipeline and no model behind it: detections and poses are a deterministic function
+    of the frame tensors (so any rank computes the same rows for the same frame)."""
+
+    def run_group(self, frames):
+        from sam6d_amd.ism.handoff import Detections
+        out = []
+        for (img, depth, K, keys, ru) in frames:
+            k = keys.shape[0]
+            g = torch.Generator().manual_seed(int(img.long().sum()) % (2 ** 31))
+            q = torch.linalg.qr(torch.randn(k, 3, 3, generator=g))[0]
+            det = Detections(0, 0, torch.zeros(k, 4, 4, dtype=torch.bool), torch.zeros(k, 4), torch.rand(k, generator=g),
+                             torch.randint(0, 21, (k,), generator=g))
+            drop = torch.rand(k, generator=g) < 0.2                       # the pre-processing drops some detections
+            kept = (~drop).nonzero().flatten()
+            poses = None if kept.numel() == 0 else dict(pred_R=q[kept], pred_t=torch.randn(k, 3, generator=g)[kept] * 0.3,
+                                                        pred_pose_score=torch.rand(k, generator=g)[kept], kept=kept)
+            out.append((det, poses))
+        return out
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--group", type=int, default=8)
+    ap.add_argument("--out", default="")
+    ap.add_argument("--dataset", default="ycbv")
+    ap.add_argument("--stand-in", action="store_true")
+    ap.add_argument("--fixed-time", type=float, default=None)
+    a = ap.parse_args(argv)
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if a.stand_in:
+        dev = torch.device("cpu")
+        backend = "gloo"
+    else:
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(dev)
+        backend = "nccl"
+    if world > 1:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    ids = frame_list(a.frames)
+    if a.stand_in:
+        pipe = StandInPipeline()
+
+        def load(s, i):
+            P, K = frame_shape(s, i)
+            g = torch.Generator().manual_seed(s * 7919 + i)
+            return (torch.randint(0, 256, (8, 8, 3), generator=g, dtype=torch.uint8), torch.rand(8, 8, generator=g),
+                    torch.eye(3, dtype=torch.float64), torch.rand(K, 64, generator=g), torch.rand(K, 18000, generator=g))
+    else:
+        from tools import frame_demo
+        from sam6d_amd.utils import synth
+        import collections
+        counts = collections.deque()          # one P per frame, consumed by the proposal stage in frame order
+        pipe, (img0, depth0, K0, _, _) = frame_demo.build(dev, top_k="keys", sync_stages=False, proposal_counts=counts)
+
+        def load(s, i):
+            P, K = frame_shape(s, i)
+            g = torch.Generator().manual_seed(s * 7919 + i)
+            img = (img0.int() + torch.randint(-8, 9, img0.shape, generator=g).to(dev)).clamp(0, 255).to(torch.uint8)
+            counts.append(P)
+            return (img, depth0, K0, torch.rand(K, 480 * 640, generator=g).to(dev), synth.coarse_uniforms(K, s * 1000 + i).to(dev))
+    t0 = time.perf_counter()
+    res = shard.run_sharded(ids, load, pipe, group_size=a.group, dataset_name=a.dataset, device=dev, fixed_time=a.fixed_time)
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    if rank == 0:
+        if a.out:
+            os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+            with open(a.out, "w+") as f:
+                f.writelines(res["csv_lines"])
+        print(json.dumps(dict(tool="run_sharded", world=world, frames=a.frames, group=a.group, poses=int(res["records"].shape[0]),
+                              frames_per_s=a.frames / wall, wall_s=wall, balance_efficiency=res["balance_efficiency"],
+                              per_rank_busy_s=[round(float(x), 4) for x in res["stats"][:, 0]],
+                              per_rank_frames=[int(x) for x in res["stats"][:, 1]],
+                              per_rank_instances=[int(x) for x in res["stats"][:, 2]], stand_in=bool(a.stand_in),
+                              scaling="unmeasured on hardware" if a.stand_in or world == 1 else "measured")))
+    if world > 1:
+        dist.destroy_process_group()
+    return res
+
+
+if __name__ == "__main__":
+    main()

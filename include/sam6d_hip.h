@@ -30,7 +30,7 @@ extern "C" {
 
 /* Bumped whenever a signature in this header changes; the loader (sam6d_amd/_lib.py) refuses a library whose
  * s6d_version() differs from the header it was written against (a stale .so fails at load, not at a call). */
-#define S6D_ABI_VERSION 101
+#define S6D_ABI_VERSION 102
 int s6d_version(void);
 const char *s6d_strerror(int code);
 /* last HIP error string seen by this thread (empty if none) */
@@ -206,6 +206,11 @@ int s6d_gemm_bf16(const void *A, long lda, const void *W, long ldw, const float 
  * block writes q / k / v head-major this way (col_block = head_dim) for s6d_win_attention_layout_bf16(head_major = 1). */
 int s6d_gemm_bf16_cblk(const void *A, long lda, const void *W, long ldw, const float *bias, void *C, long ldc, int M, int N, int K,
                        int epilogue, int col_block, int max_blocks, void *stream);
+/* The same product with the RESIDUAL ADD of a transformer block in the epilogue: C = bf16(bf16(A W^T + bias) + R), R (M,N) bf16 with
+ * row stride ldr (R may be C: in place).  Replaces `x = shortcut + x` / `x = x + self.mlp(..)` as separate passes over two
+ * (tokens, C) tensors (segment_anything/modeling/image_encoder.py:166-182; timm / DINOv2 blocks alike).  N % 256 == 0. */
+int s6d_gemm_bf16_res(const void *A, long lda, const void *W, long ldw, const float *bias, const void *R, long ldr, void *C,
+                      long ldc, int M, int N, int K, int max_blocks, void *stream);
 
 /* ---------------------------------------------------------------- ISM proposal-vs-template scoring */
 

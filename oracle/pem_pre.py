@@ -7,9 +7,11 @@ tests/golden/pem_pre.npz (the reference functions run unmodified).  Two things c
   * the point sampling: the reference draws from numpy's global RNG (np.random.choice :224-227); here the random
     numbers are an INPUT (one uniform key per crop pixel): with replacement idx_i = floor(u_i * n), without replacement
     the n_sample smallest keys in key order -- the same distributions, a defined stream.  PARITY UNPINNED (RNG).
-  * the 224 x 224 colour crop: the reference calls cv2.resize(INTER_LINEAR) on uint8 (cv2 is not in this image);
-    restated here as bilinear interpolation with half-pixel centres in float32, rounded to uint8.  PARITY UNPINNED
-    (cv2 fixed-point arithmetic may differ by one grey level).
+  * the 224 x 224 colour crop: the reference calls cv2.resize(INTER_LINEAR) on uint8.  cv2 is an un-vendored dependency and
+    not in this image; since round 3 its PUBLISHED algorithm is restated exactly (cv2_resize_linear_u8: OpenCV 4.x
+    modules/imgproc/src/resize.cpp -- 11-bit fixed-point coefficients, two passes, the 2x2 box average OpenCV substitutes at
+    an exact 2:1 ratio, a plain copy at 1:1).  PARITY UNPINNED until vectors exist: tools/gen_cv2_vectors.py writes them
+    wherever cv2 can be imported and tests/test_host_pem_pre.py consumes tests/golden/cv2_resize.npz when present.
 Arithmetic types follow the reference under the NumPy 1.x it was released for (float32 arrays stay float32 when
 combined with the float64 camera scalars).
 """
@@ -63,22 +65,65 @@ def sample_indices(n, n_sample, keys):
     return np.argsort(keys[:n], kind="stable")[:n_sample]
 
 
-def resize_bilinear_u8(img, size):
-    """(h,w,3) uint8 -> (size,size,3) uint8, half-pixel centres, edge clamp, float32 arithmetic, round half up."""
-    h, w = img.shape[:2]
+def _cv_round_to_short(v):
+    """saturate_cast<short>(float): cvRound = round half to even (SSE cvtss2si / lrintf), then saturation."""
+    return np.clip(np.rint(v.astype(np.float32)), -32768, 32767).astype(np.int32)
 
-    def taps(n_out, n_in):
-        s = (np.arange(n_out, dtype=np.float32) + np.float32(0.5)) * np.float32(n_in / n_out) - np.float32(0.5)
-        i0 = np.floor(s).astype(np.int64)
-        f = (s - i0).astype(np.float32)
-        return np.clip(i0, 0, n_in - 1), np.clip(i0 + 1, 0, n_in - 1), f
-    y0, y1, fy = taps(size, h)
-    x0, x1, fx = taps(size, w)
-    im = img.astype(np.float32)
-    top = im[y0][:, x0] * (1 - fx)[None, :, None] + im[y0][:, x1] * fx[None, :, None]
-    bot = im[y1][:, x0] * (1 - fx)[None, :, None] + im[y1][:, x1] * fx[None, :, None]
-    out = top * (1 - fy)[:, None, None] + bot * fy[:, None, None]
-    return np.clip(np.floor(out + np.float32(0.5)), 0, 255).astype(np.uint8)
+
+def cv2_linear_tables(n_out, n_in):
+    """The per-axis tables resize() builds for INTER_LINEAR on CV_8U (resize.cpp, `resize_` in namespace cv::hal):
+        scale = 1. / (double(n_out) / n_in);  f = (float)((d + 0.5) * scale - 0.5);  s = cvFloor(f);  f -= s
+    x axis only (:~3990-4010): s < 0 -> f = 0, s = 0;  s >= n_in - 1 -> f = 0, s = n_in - 1.  The y axis keeps (s, f) and
+    clips the two ROW INDICES instead (resizeGeneric_Invoker: clip(sy + k, 0, n_in)).  Coefficients: saturate_cast<short>
+    ((1.f - f) * 2048), saturate_cast<short>(f * 2048) -- rounded independently (they need not add up to 2048).
+    -> (s (n_out,) int64, c0, c1 (n_out,) int32) unclamped, as the y axis uses them; `clamp_x` applies the x-axis rule."""
+    inv = np.float64(n_out) / np.float64(n_in)
+    scale = np.float64(1.0) / inv
+    f = ((np.arange(n_out, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    return s, f
+
+
+def _coefs(f):
+    return _cv_round_to_short((np.float32(1.0) - f) * np.float32(2048)), _cv_round_to_short(f * np.float32(2048))
+
+
+def cv2_resize_linear_u8(img, size):
+    """cv2.resize(img, (size, size), interpolation=cv2.INTER_LINEAR) for an (h, w, C) uint8 image, restated from OpenCV 4.x
+    resize.cpp (IPP is bypassed for 8-bit linear unless useIPP_NotExact is set; there is no other special path on x86):
+      * h == w == size: copy;
+      * scale exactly 2 on both axes: INTER_LINEAR is replaced by the fast area average (src[2y][2x] + src[2y][2x+1] +
+        src[2y+1][2x] + src[2y+1][2x+1] + 2) >> 2  (ResizeAreaFastVec<uchar>);
+      * otherwise HResizeLinear<uchar,int,short,2048>: t = S[sx] * a0 + S[sx + 1] * a1 (int32) per source row, then
+        VResizeLinear<uchar,...>:  dst = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2."""
+    h, w = img.shape[:2]
+    if h == size and w == size:
+        return img.copy()
+    inv_x, inv_y = np.float64(size) / w, np.float64(size) / h
+    sx_, sy_ = 1.0 / inv_x, 1.0 / inv_y
+    if abs(sx_ - 2) < np.finfo(np.float64).eps and abs(sy_ - 2) < np.finfo(np.float64).eps and int(sx_) == 2 and int(sy_) == 2:
+        s = img.astype(np.int32)
+        return ((s[0:2 * size:2, 0:2 * size:2] + s[0:2 * size:2, 1:2 * size:2] + s[1:2 * size:2, 0:2 * size:2]
+                 + s[1:2 * size:2, 1:2 * size:2] + 2) >> 2).astype(np.uint8)
+    xs, fx = cv2_linear_tables(size, w)
+    lo, hi = xs < 0, xs >= w - 1
+    fx = np.where(lo | hi, np.float32(0), fx)
+    xs = np.where(lo, 0, np.where(hi, w - 1, xs))
+    a0, a1 = _coefs(fx)
+    ys, fy = cv2_linear_tables(size, h)
+    b0, b1 = _coefs(fy)
+    y0, y1 = np.clip(ys, 0, h - 1), np.clip(ys + 1, 0, h - 1)
+    S = img.astype(np.int32)
+    x1 = np.minimum(xs + 1, w - 1)                                   # a1 == 0 wherever xs + 1 would leave the row
+    t = S[:, xs] * a0[None, :, None] + S[:, x1] * a1[None, :, None]      # (h, size, C) int32: the horizontal pass
+    out = (((b0[:, None, None] * (t[y0] >> 4)) >> 16) + ((b1[:, None, None] * (t[y1] >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def resize_bilinear_u8(img, size):
+    """The colour-crop resize of the PEM input = cv2.resize(INTER_LINEAR) (run_inference_custom.py:234)."""
+    return cv2_resize_linear_u8(img, size)
 
 
 def preprocess_frame(image_u8, depth, K, masks, radius, keys=None, n_sample=2048, img_size=224, min_points=32, min_inliers=4,

@@ -23,6 +23,10 @@
 //   * a K tile is 4 phases (one 64 x 32 quadrant of the wave's tile over the whole K step each); the two wave groups
 //     (M halves) run one barrier apart, so on every SIMD one wave is in its matrix segment (8 MFMAs) while the other issues
 //     its fragment reads and DMA: phase = { ds_read, DMA issue, [counted wait], barrier, 8 x MFMA, barrier }.
+//   * EPI 2 (round 3): C = bf16(bf16(A W^T + bias) + R) -- the residual add of a ViT block (x + proj(..), x + lin2(..)) in the
+//     producing GEMM's epilogue instead of a separate pass that re-reads both tensors: after the quad transpose a lane holds
+//     16-byte row pieces, the matching pieces of R are fetched one 32-row strip ahead, added in fp32 and rounded again (the two
+//     roundings of the unfused path: bit-identical with add_layernorm's x + delta).
 //   * epilogue in registers: bias is the accumulator's initial value (scalar loads), exact GELU as
 //     relu(x) - |x| * erfc(|x| / sqrt 2) / 2 with erfc from Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7), round to bf16,
 //     v_permlane32_swap pairs the two lane halves into 16-byte row segments.
@@ -99,6 +103,8 @@ struct GemmParams {
   const u16 *W;       // (N,K) bf16, row stride ldw
   const float *bias;  // (N) f32 or nullptr
   u16 *C;             // (M,N) bf16, row stride ldc
+  const u16 *R;       // EPI 2: residual (M,N) bf16, row stride ldr; may be C itself (each 16-byte piece is read, then written, by one lane)
+  long ldr;
   unsigned lda2, ldw2;  // row strides in BYTES
   long ldc;
   int M, N, K;
@@ -307,7 +313,22 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
   // S6D_GEMM_QT: the 32 x 64 strip of m tile mt.  A lane holds 4 chunks of 8 consecutive columns of its row (chunk 2 nt + k =
   // columns 32 h + 16 nt + 8 k ..); the 4 x 4 transpose inside each lane quad turns that into chunk (lane & 3) of the four rows
   // of the quad, i.e. a quad writes 64 contiguous bytes per instruction
-  auto epilogue_qt = [&](int mt, int m0, int n0) __attribute__((always_inline)) {
+  // residual pieces of strip mt in the store layout: row (quad base + y), 8 columns at `col`
+  auto load_res = [&](int mt, int m0, int n0, uint4 (&rr)[4]) __attribute__((always_inline)) {
+    const int mq = m0 + wr * 128 + mt * 32 + (lane & 28);
+    const int col = n0 + wc * 64 + 32 * (lane >> 5) + 8 * (lane & 3);
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      const int m = min(mq + y, p.M - 1);                                // rows past M: a valid address, never stored
+      rr[y] = *reinterpret_cast<const uint4 *>(p.R + (size_t)m * p.ldr + col);
+    }
+  };
+  auto add_bf16x2 = [&](unsigned a, unsigned b) __attribute__((always_inline)) -> unsigned {
+    const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
+    const float hi = __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u);
+    return pack_bf16(lo, hi);
+  };
+  auto epilogue_qt = [&](int mt, int m0, int n0, const uint4 (&rr)[4]) __attribute__((always_inline)) {
     unsigned X[4][4];                                                    // [chunk][dword]
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
@@ -357,15 +378,24 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
         } else {
           dst = p.C + (size_t)(mq + y) * p.ldc + col;
         }
+        if (EPI == 2) {
+          X[y][0] = add_bf16x2(X[y][0], rr[y].x);
+          X[y][1] = add_bf16x2(X[y][1], rr[y].y);
+          X[y][2] = add_bf16x2(X[y][2], rr[y].z);
+          X[y][3] = add_bf16x2(X[y][3], rr[y].w);
+        }
         *reinterpret_cast<uint4 *>(dst) = make_uint4(X[y][0], X[y][1], X[y][2], X[y][3]);
       }
     }
   };
   auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) {
+    uint4 rr[2][4] = {};
+    if (EPI == 2 && S6D_GEMM_QT) load_res(0, m0, n0, rr[0]);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       if (S6D_GEMM_QT) {
-        epilogue_qt(mt, m0, n0);
+        if (EPI == 2 && mt + 1 < 4) load_res(mt + 1, m0, n0, rr[(mt + 1) & 1]);   // one strip ahead of its use
+        epilogue_qt(mt, m0, n0, rr[mt & 1]);
       } else {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) epilogue_one(mt, nt, m0, n0);
@@ -824,6 +854,15 @@ static int gemm_impl() {
 
 extern "C" int s6d_gemm_bf16_cblk(const void *A, long lda, const void *W, long ldw, const float *bias, void *C, long ldc, int M,
                                   int N, int K, int epilogue, int col_block, int max_blocks, void *stream);
+static int gemm_launch(const void *A, long lda, const void *W, long ldw, const float *bias, const void *R, long ldr, void *C, long ldc,
+                       int M, int N, int K, int epilogue, int col_block, int max_blocks, void *stream);
+
+extern "C" int s6d_gemm_bf16_res(const void *A, long lda, const void *W, long ldw, const float *bias, const void *R, long ldr,
+                                 void *C, long ldc, int M, int N, int K, int max_blocks, void *stream) {
+  if (!R || ldr < N || (ldr % 8) || ((uintptr_t)R & 15)) return S6D_EINVAL;
+  if (N % 256 != 0 || !S6D_GEMM_QT) return S6D_EUNSUPPORTED;            // the quad-transposed epilogue of the 256 x 256 kernel
+  return gemm_launch(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, 2, 0, max_blocks, stream);
+}
 
 extern "C" int s6d_gemm_bf16(const void *A, long lda, const void *W, long ldw, const float *bias, void *C, long ldc, int M,
                              int N, int K, int epilogue, int max_blocks, void *stream) {
@@ -832,6 +871,12 @@ extern "C" int s6d_gemm_bf16(const void *A, long lda, const void *W, long ldw, c
 
 extern "C" int s6d_gemm_bf16_cblk(const void *A, long lda, const void *W, long ldw, const float *bias, void *C, long ldc, int M,
                                   int N, int K, int epilogue, int col_block, int max_blocks, void *stream) {
+  if (epilogue != 0 && epilogue != 1) return S6D_EINVAL;
+  return gemm_launch(A, lda, W, ldw, bias, nullptr, 0, C, ldc, M, N, K, epilogue, col_block, max_blocks, stream);
+}
+
+static int gemm_launch(const void *A, long lda, const void *W, long ldw, const float *bias, const void *R, long ldr, void *C, long ldc,
+                       int M, int N, int K, int epilogue, int col_block, int max_blocks, void *stream) {
   if (M < 0 || N <= 0 || K <= 0) return S6D_EINVAL;
   if (M == 0) return S6D_OK;                                            // an empty row batch: nothing to launch
   if (!A || !W || !C) return S6D_EINVAL;
@@ -840,15 +885,17 @@ extern "C" int s6d_gemm_bf16_cblk(const void *A, long lda, const void *W, long l
   if (N % 128 != 0 || K % 64 != 0 || lda < K || ldw < K || ldc < N) return S6D_EINVAL;
   if ((lda % 8) || (ldw % 8) || (ldc % 8)) return S6D_EINVAL;           // 16-byte rows
   if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) return S6D_EINVAL;
-  if (epilogue != 0 && epilogue != 1) return S6D_EINVAL;
+  if (epilogue < 0 || epilogue > 2) return S6D_EINVAL;
   // staging addresses are 32-bit byte offsets from A / W
   if ((double)M * (double)lda * 2.0 >= 2147483648.0 || (double)N * (double)ldw * 2.0 >= 2147483648.0) return S6D_EUNSUPPORTED;
-  const int impl = (N % 256 != 0) ? 2 : (col_block > 0 ? 1 : gemm_impl());
+  const int impl = (N % 256 != 0) ? 2 : ((col_block > 0 || epilogue == 2) ? 1 : gemm_impl());
   GemmParams p;
   p.A = (const u16 *)A;
   p.W = (const u16 *)W;
   p.bias = bias;
   p.C = (u16 *)C;
+  p.R = (const u16 *)R;
+  p.ldr = ldr;
   p.lda2 = (unsigned)(lda * 2);
   p.ldw2 = (unsigned)(ldw * 2);
   p.ldc = ldc;
@@ -892,7 +939,9 @@ extern "C" int s6d_gemm_bf16_cblk(const void *A, long lda, const void *W, long l
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                    \
     hipLaunchKernelGGL((gemm_bf16_kernel<E, HB>), dim3(grid), dim3(512), lds, st, p);                                   \
   } while (0)
-  if (epilogue == 1) {
+  if (epilogue == 2) {
+    if (bias) S6D_GEMM_LAUNCH(2, true); else S6D_GEMM_LAUNCH(2, false);
+  } else if (epilogue == 1) {
     if (bias) S6D_GEMM_LAUNCH(1, true); else S6D_GEMM_LAUNCH(1, false);
   } else {
     if (bias) S6D_GEMM_LAUNCH(0, true); else S6D_GEMM_LAUNCH(0, false);

@@ -287,40 +287,65 @@ __global__ __launch_bounds__(kSelThreads) void sample_indices_kernel(const float
   if (tid == 0) overflow[p] = 0;
 }
 
-// Masked colour crop of every surviving detection, resized to S x S and normalised (run_inference_custom.py:231-236 in the
-// DEFINED form of preprocess.py: bilinear with half-pixel centres in float32, rounded to a grey level, then ToTensor +
-// Normalize).  Same float32 operations, in the same order, as the library statement `_crops` (file-level contract(off)).
+// Masked colour crop of every surviving detection, resized to S x S and normalised (run_inference_custom.py:229-236:
+// uint8 crop * uint8 mask, cv2.resize(INTER_LINEAR), ToTensor + Normalize).  The resize is OpenCV's fixed-point algorithm for
+// CV_8U restated exactly (OpenCV 4.x modules/imgproc/src/resize.cpp; oracle/pem_pre.py cv2_resize_linear_u8 is the same
+// statement in numpy): per axis  scale = 1. / (double(S) / n),  f = (float)((o + 0.5) * scale - 0.5),  s = floor(f),  f -= s;
+// x axis: s < 0 -> (0, f = 0), s >= n - 1 -> (n - 1, f = 0); y axis: the two row indices are clipped instead; coefficients
+// saturate_cast<short>((1 - f) * 2048), saturate_cast<short>(f * 2048) (round half to even, each on its own);
+// t = S[sx] a0 + S[sx + 1] a1 per row (int32), dst = (((b0 (t0 >> 4)) >> 16) + ((b1 (t1 >> 4)) >> 16) + 2) >> 2.
+// An exact 2:1 ratio on both axes takes OpenCV's area substitute (four-pixel sum + 2) >> 2, a 1:1 ratio is a copy.
 // image (H,W,3) u8 RGB, m (P,H,W) u8, kept (M) i64, box (P,4) i64 -> out (M,3,S,S) f32, channel c = image channel 2 - c.
+__device__ __forceinline__ void cv_linear_tap(int o, int S, long n, bool clamp_index, long &s, int &c0, int &c1) {
+  const double inv = (double)S / (double)n;
+  const double scale = 1.0 / inv;
+  float f = (float)(((double)o + 0.5) * scale - 0.5);
+  const float fl = floorf(f);
+  s = (long)fl;
+  f -= fl;
+  if (clamp_index) {
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= n - 1) { f = 0.f; s = n - 1; }
+  }
+  c0 = (int)fminf(fmaxf(rintf((1.f - f) * 2048.f), -32768.f), 32767.f);
+  c1 = (int)fminf(fmaxf(rintf(f * 2048.f), -32768.f), 32767.f);
+}
+
 __global__ void pem_crops_kernel(const unsigned char *__restrict__ image, const unsigned char *__restrict__ m,
                                  const long *__restrict__ kept, const long *__restrict__ box, int M, int H, int W, int S,
                                  int use_mask, float mean0, float mean1, float mean2, float std0, float std1, float std2,
                                  float *__restrict__ out) {
   const size_t total = (size_t)M * 3 * S * S;
-  const float Sf = (float)S;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int ox = (int)(i % S), oy = (int)((i / S) % S), c = (int)((i / ((size_t)S * S)) % 3), k = (int)(i / ((size_t)3 * S * S));
     const long p = kept[k];
     const long y1 = box[p * 4 + 0], y2 = box[p * 4 + 1], x1 = box[p * 4 + 2], x2 = box[p * 4 + 3];
-    // taps along one axis: s = o * (n / S) - 0.5; i0 = floor(s); f = s - i0; indices clamped to the crop
-    const float sy = ((float)oy + 0.5f) * ((float)(y2 - y1) / Sf) - 0.5f, sx = ((float)ox + 0.5f) * ((float)(x2 - x1) / Sf) - 0.5f;
-    const float fy0 = floorf(sy), fx0 = floorf(sx);
-    const float fy = sy - fy0, fx = sx - fx0;
-    const long iy = (long)fy0, ix = (long)fx0, ly = y2 - y1 - 1, lx = x2 - x1 - 1;
-    const long ya = y1 + min(max(iy, 0L), ly), yb = y1 + min(max(iy + 1, 0L), ly);
-    const long xa = x1 + min(max(ix, 0L), lx), xb = x1 + min(max(ix + 1, 0L), lx);
+    const long h = y2 - y1, w = x2 - x1;
     const int ch = 2 - c;
     const unsigned char *mp = m + (size_t)p * H * W;
-    auto px = [&](long yy, long xx) {
-      float v = (float)image[(yy * W + xx) * 3 + ch];
-      if (use_mask) v = v * (float)mp[yy * W + xx];
-      return v;
+    auto px = [&](long yy, long xx) -> int {                           // uint8 crop * uint8 mask of the reference
+      const long y = y1 + yy, x = x1 + xx;
+      const int v = (int)image[(y * W + x) * 3 + ch];
+      return use_mask ? (mp[y * W + x] ? v : 0) : v;
     };
-    const float top = px(ya, xa) * (1.f - fx) + px(ya, xb) * fx;
-    const float bot = px(yb, xa) * (1.f - fx) + px(yb, xb) * fx;
-    float g = floorf(top * (1.f - fy) + bot * fy + 0.5f);
-    g = fminf(fmaxf(g, 0.f), 255.f);
+    int g;
+    if (h == S && w == S) {
+      g = px(oy, ox);
+    } else if (h == 2 * (long)S && w == 2 * (long)S) {
+      g = (px(2 * oy, 2 * ox) + px(2 * oy, 2 * ox + 1) + px(2 * oy + 1, 2 * ox) + px(2 * oy + 1, 2 * ox + 1) + 2) >> 2;
+    } else {
+      long sx, sy;
+      int a0, a1, b0, b1;
+      cv_linear_tap(ox, S, w, true, sx, a0, a1);
+      cv_linear_tap(oy, S, h, false, sy, b0, b1);
+      const long ya = min(max(sy, 0L), h - 1), yb = min(max(sy + 1, 0L), h - 1), xb = min(sx + 1, w - 1);
+      const int t0 = px(ya, sx) * a0 + px(ya, xb) * a1;
+      const int t1 = px(yb, sx) * a0 + px(yb, xb) * a1;
+      g = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+      g = min(max(g, 0), 255);
+    }
     const float mean = c == 0 ? mean0 : (c == 1 ? mean1 : mean2), sd = c == 0 ? std0 : (c == 1 ? std1 : std2);
-    out[i] = (g / 255.f - mean) / sd;
+    out[i] = ((float)g / 255.f - mean) / sd;
   }
 }
 

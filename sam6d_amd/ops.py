@@ -472,10 +472,11 @@ def seq_attention(qkv, num_heads, scale):
     return out
 
 
-def gemm_bf16(a, w, bias=None, gelu=False, out=None, max_blocks=0, col_block=0):
+def gemm_bf16(a, w, bias=None, gelu=False, out=None, max_blocks=0, col_block=0, residual=None):
     """a (..., K) bf16 (rows may be strided), w (N, K) bf16 = nn.Linear.weight, bias (N) f32 or None ->
     act(a @ w.T + bias) (..., N) bf16 with act = exact GELU or identity; N % 128 == 0, K % 64 == 0.
-    col_block > 0: the output comes back as (N / col_block, M, col_block) -- column blocks as separate matrices (N % 256 == 0)."""
+    col_block > 0: the output comes back as (N / col_block, M, col_block) -- column blocks as separate matrices (N % 256 == 0).
+    residual (..., N) bf16: returns bf16(bf16(a @ w.T + bias) + residual) (N % 256 == 0, no GELU); out may be the residual itself."""
     if not a.is_cuda or not w.is_cuda:
         raise RuntimeError("a and w must be CUDA tensors")
     if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
@@ -508,6 +509,19 @@ def gemm_bf16(a, w, bias=None, gelu=False, out=None, max_blocks=0, col_block=0):
     # the kernel's staging addresses are 32-bit byte offsets from A: rows go through in slabs below 2 GiB (ViT-H lin2 reaches
     # the limit at 52 frames per call)
     rows = max(256, ((2 ** 31 - 1) // (2 * a2.stride(0))) // 256 * 256)
+    if residual is not None:
+        if gelu or col_block:
+            raise RuntimeError("the residual epilogue takes neither GELU nor column blocks")
+        _chk(residual, torch.bfloat16, "residual")
+        r2 = residual.reshape(-1, N)
+        if r2.shape[0] != M:
+            raise ValueError(f"residual has {r2.shape[0]} rows, the product {M}")
+        for r0 in range(0, M, rows):
+            r1 = min(M, r0 + rows)
+            _call("s6d_gemm_bf16_res", _ptr(a2[r0:r1]), ctypes.c_long(a2.stride(0)), _ptr(w), ctypes.c_long(w.stride(0)),
+                  _ptr(bias) if bias is not None else _vp(0), _ptr(r2[r0:r1]), ctypes.c_long(r2.stride(0)), _ptr(out[r0:r1]),
+                  ctypes.c_long(out.stride(0)), r1 - r0, N, K, int(max_blocks), _stream())
+        return out.reshape(*a.shape[:-1], N)
     for r0 in range(0, M, rows):
         r1 = min(M, r0 + rows)
         _call("s6d_gemm_bf16", _ptr(a2[r0:r1]), ctypes.c_long(a2.stride(0)), _ptr(w), ctypes.c_long(w.stride(0)),
@@ -722,7 +736,7 @@ def have(name):
     if name not in _FUSED:
         sym = {"rpe_attention": "s6d_rpe_attention_f32", "geo_embedding": "s6d_geo_embedding_f32",
                "fine_assign": "s6d_fine_assign_f32", "fine_match": "s6d_fine_match_f32", "pem_pre": "s6d_pem_compact_cloud_f32", "coarse_sample": "s6d_coarse_sample_f32", "upsample_gather": "s6d_upsample_gather_f32",
-               "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "add_layernorm": "s6d_add_layernorm_bf16", "gemm_bf16": "s6d_gemm_bf16", "win_attention": "s6d_win_attention_layout_bf16",
+               "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "add_layernorm": "s6d_add_layernorm_bf16", "gemm_bf16": "s6d_gemm_bf16", "gemm_bf16_res": "s6d_gemm_bf16_res", "win_attention": "s6d_win_attention_layout_bf16",
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
                "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_frames_f32",

@@ -14,8 +14,10 @@ Defined differently from the reference, on purpose (oracle/pem_pre.py explains a
     idx_i = floor(u_i * n) when n <= n_sample, else the n_sample smallest keys in key order.  (``rng=`` switches to the
     reference's own draws -- ``np.random.choice`` once per surviving detection, in detection order, :224-227 -- for runs that
     must reproduce a seeded reference run point for point; it costs one more device->host copy of P counts);
-  * the colour crop is bilinear with half-pixel centres in float32, rounded to uint8 (the reference calls cv2.resize,
-    whose fixed-point arithmetic can differ by one grey level);
+  * the colour crop: the reference calls cv2.resize(INTER_LINEAR) on the uint8 crop; cv2 is not in this image, so its published
+    fixed-point algorithm (OpenCV 4.x resize.cpp: 11-bit coefficients, two passes, box average at 2:1, copy at 1:1) is
+    restated integer for integer since round 3 -- still "parity unpinned" until tools/gen_cv2_vectors.py has been run where cv2
+    exists (round 2 used a float32 bilinear that could differ by one grey level);
   * the radius test ``|p - centre| < radius * 1.2`` compares the float32 distance against the float64 product (what numpy does
     for a float64 ``radius``; for a Python-float radius numpy >= 2 (NEP 50, the version the goldens were made with: 2.2) rounds
     the product to float32 first, and numpy 1.x did so by value-based casting -- a point would have to lie within one float32
@@ -52,39 +54,62 @@ def square_boxes(m):
     return torch.stack([rmin, rmax, cmin, cmax], 1)
 
 
+def _cv_taps(lo, hi, S, dev, clamp_index):
+    """Per-axis tables of cv2.resize(INTER_LINEAR) on uint8 for P crops (OpenCV 4.x resize.cpp; see csrc/s6d_pempre.hip
+    pem_crops_kernel and oracle/pem_pre.py cv2_resize_linear_u8): -> s (P,S) int64 source index, c0, c1 (P,S) int32."""
+    n = (hi - lo).to(torch.float64)
+    inv = torch.tensor(float(S), device=dev, dtype=torch.float64) / n                  # tensor divisors: IEEE quotients
+    scale = torch.ones((), device=dev, dtype=torch.float64) / inv
+    o = torch.arange(S, device=dev, dtype=torch.float64) + 0.5
+    f = (o[None, :] * scale[:, None] - 0.5).to(torch.float32)
+    s = f.floor()
+    f = f - s
+    s = s.long()
+    if clamp_index:
+        last = (hi - lo - 1)[:, None]
+        lo_, hi_ = s < 0, s >= last
+        f = torch.where(lo_ | hi_, torch.zeros_like(f), f)
+        s = torch.where(lo_, torch.zeros_like(s), torch.where(hi_, last.expand_as(s), s))
+    c0 = torch.round((1 - f) * 2048).clamp(-32768, 32767).to(torch.int32)            # torch.round = half to even = cvRound
+    c1 = torch.round(f * 2048).clamp(-32768, 32767).to(torch.int32)
+    return s, c0, c1
+
+
 def _crops(image_u8, m, box, img_size, rgb_mask_flag):
-    """Masked, channel-flipped, bilinearly resized, normalised colour crops (P,3,S,S) f32 for boxes (P,4)."""
+    """Masked, channel-flipped colour crops resized with cv2.resize(INTER_LINEAR)'s fixed-point arithmetic and normalised:
+    (P,3,S,S) f32 for boxes (P,4).  The library-op statement of pem_crops_kernel (integer for integer the same)."""
     P = box.shape[0]
     dev = image_u8.device
     S = img_size
     y1, y2, x1, x2 = box.unbind(1)
-    o = torch.arange(S, device=dev, dtype=torch.float32) + 0.5
-    # divisors are TENSORS on purpose: `tensor / python_scalar` multiplies by the rounded reciprocal on the device, which
-    # is not the correctly rounded quotient the reference's numpy arithmetic produces
-    S_t, c255 = torch.tensor(float(S), device=dev), torch.tensor(255.0, device=dev)
-
-    def taps(lo, hi):
-        n = (hi - lo).float()
-        s = o[None, :] * (n / S_t)[:, None] - 0.5                                      # (P,S) source coordinate in the crop
-        i0 = s.floor()
-        f = s - i0
-        i0 = i0.long()
-        last = (hi - lo - 1)[:, None]
-        return lo[:, None] + i0.clamp(min=0).minimum(last), lo[:, None] + (i0 + 1).clamp(min=0).minimum(last), f
-    ya, yb, fy = taps(y1, y2)
-    xa, xb, fx = taps(x1, x2)
-    img = image_u8.flip(-1).float()                                                    # [:, :, ::-1] of the reference
+    h, w = y2 - y1, x2 - x1
+    img = image_u8.flip(-1).to(torch.int32)                                           # [:, :, ::-1] of the reference
+    mk = (m > 0).to(torch.int32)
     pidx = torch.arange(P, device=dev)[:, None, None]
 
-    def px(yy, xx):                                                                    # (P,S,S,3) tap values
-        v = img[yy[:, :, None], xx[:, None, :]]
-        if rgb_mask_flag:
-            v = v * m[pidx, yy[:, :, None], xx[:, None, :]].unsqueeze(-1)
-        return v
-    fx_, fy_ = fx[:, None, :, None], fy[:, :, None, None]
-    top = px(ya, xa) * (1 - fx_) + px(ya, xb) * fx_
-    bot = px(yb, xa) * (1 - fx_) + px(yb, xb) * fx_
-    out = (top * (1 - fy_) + bot * fy_ + 0.5).floor().clamp(0, 255)                    # == uint8 crop of the reference path
+    def px(yy, xx):                                                                    # (P,S,S,3) crop * mask, crop coordinates
+        Y, X = (y1[:, None] + yy)[:, :, None], (x1[:, None] + xx)[:, None, :]
+        v = img[Y, X]
+        return v * mk[pidx, Y, X].unsqueeze(-1) if rgb_mask_flag else v
+    sx, a0, a1 = _cv_taps(x1, x2, S, dev, True)
+    sy, b0, b1 = _cv_taps(y1, y2, S, dev, False)
+    ya, yb = sy.clamp(min=0).minimum((h - 1)[:, None]), (sy + 1).clamp(min=0).minimum((h - 1)[:, None])
+    xb = (sx + 1).minimum((w - 1)[:, None])
+    A0, A1 = a0[:, None, :, None], a1[:, None, :, None]
+    t0 = px(ya, sx) * A0 + px(ya, xb) * A1
+    t1 = px(yb, sx) * A0 + px(yb, xb) * A1
+    lin = ((((b0[:, :, None, None] * (t0 >> 4)) >> 16) + ((b1[:, :, None, None] * (t1 >> 4)) >> 16) + 2) >> 2).clamp(0, 255)
+    o = torch.arange(S, device=dev)
+    ident = ((h == S) & (w == S))[:, None, None, None]
+    half = ((h == 2 * S) & (w == 2 * S))[:, None, None, None]
+    # the two special cases of cv2.resize: a copy at 1:1, the (a + b + c + d + 2) >> 2 box average at exactly 2:1 (indices are
+    # clamped so that the unused branch of other crops stays in range)
+    cp = px(o[None, :].minimum((h - 1)[:, None]), o[None, :].minimum((w - 1)[:, None]))
+    e0y, e1y = (2 * o)[None, :].minimum((h - 1)[:, None]), (2 * o + 1)[None, :].minimum((h - 1)[:, None])
+    e0x, e1x = (2 * o)[None, :].minimum((w - 1)[:, None]), (2 * o + 1)[None, :].minimum((w - 1)[:, None])
+    area = (px(e0y, e0x) + px(e0y, e1x) + px(e1y, e0x) + px(e1y, e1x) + 2) >> 2
+    out = torch.where(ident, cp, torch.where(half, area, lin)).to(torch.float32)
+    c255 = torch.tensor(255.0, device=dev)
     mean = torch.tensor(MEAN, device=dev)
     std = torch.tensor(STD, device=dev)
     return ((out / c255 - mean) / std).permute(0, 3, 1, 2).contiguous()

@@ -119,8 +119,9 @@ class Attention(nn.Module):
             self._s6d_attn_ops = c
         return c[1], c[2], c[3]
 
-    def forward(self, x, window_size=0):
-        """x: (B,H,W,C) token map (already normed).  window_size 0 = global attention."""
+    def forward(self, x, window_size=0, residual=None):
+        """x: (B,H,W,C) token map (already normed).  window_size 0 = global attention.  residual: the block's shortcut -- the
+        result is then shortcut + attention, with the add in the proj GEMM's epilogue (written over `residual`)."""
         B, H, W, C = x.shape
         fused = ops.have("win_attention") and x.is_cuda and x.dtype == torch.bfloat16 and self.use_rel_pos
         if fused:
@@ -132,7 +133,7 @@ class Attention(nn.Module):
                 S = window_size if window_size > 0 else H
                 bias, rh, rw = self._kernel_operands(S, hm.dtype)
                 out = ops.window_attention(hm, bias, rh, rw, self.num_heads, window_size, self.scale, head_major_shape=(B, H, W))
-                return fused_linear(self.proj, out)
+                return fused_linear(self.proj, out, residual=residual)
         qkv = fused_linear(self.qkv, x)                              # (B,H,W,3C): real tokens only
         if fused:
             S = window_size if window_size > 0 else H
@@ -140,7 +141,7 @@ class Attention(nn.Module):
             out = ops.window_attention(qkv.contiguous(), bias, rh, rw, self.num_heads, window_size, self.scale)
         else:
             out = self._attention_lib(qkv, B, H, W, C, window_size)
-        return fused_linear(self.proj, out)
+        return fused_linear(self.proj, out, residual=residual)
 
     def _attention_lib(self, qkv, B, H, W, C, ws):
         """Library-op statement of the same computation (device tensors; used when the fused
@@ -239,9 +240,25 @@ class ImageEncoderViT(nn.Module):
         return c[1], c[2]
 
     def _blocks_fused(self, x, upto):
-        """Same dataflow as Block.forward with every residual add folded into the following LayerNorm
-        pass (one fused kernel): x += branch; h = LN(x)."""
+        """Same dataflow as Block.forward.  Round 3: the two residual adds of a block happen in the epilogues of the proj and
+        lin2 GEMMs (s6d_gemm_bf16_res, in place on the stream tensor) and the LayerNorms are one-read passes; round 2 folded
+        each add into the following LayerNorm pass (two reads + two writes per add: 6 % of the step).  Same arithmetic either
+        way (the add rounds the GEMM's bf16 output + x to bf16): S6D_DISABLE_FUSED=gemm_bf16_res selects the round-2 form."""
+        from ..utils.linear import res_eligible
         x = x.contiguous()
+        C = x.shape[-1]
+        if res_eligible(x, C, C) and all(res_eligible(x, C, blk.mlp.lin2.in_features) for blk in self.blocks):
+            x = x.clone()                                        # the stream tensor is updated in place from here on
+            for i, blk in enumerate(self.blocks):
+                if upto is not None and i >= upto:
+                    break
+                g, b = self._ln_f32(blk.norm1)
+                _, h = ops.add_layernorm(x, None, g, b, blk.norm1.eps)
+                x = blk.attn(h, blk.window_size, residual=x)
+                g, b = self._ln_f32(blk.norm2)
+                _, h = ops.add_layernorm(x, None, g, b, blk.norm2.eps)
+                x = fused_linear(blk.mlp.lin2, fused_linear(blk.mlp.lin1, h, gelu=True), residual=x)
+            return x
         delta = None
         for i, blk in enumerate(self.blocks):
             if upto is not None and i >= upto:

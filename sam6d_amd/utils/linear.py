@@ -2,7 +2,8 @@
 
 The modules keep their nn.Linear parameters (state_dict surface of the reference unchanged); this helper only decides
 how the statement  act(x @ W^T + b)  is executed: on a device bf16 activation with N % 128 == 0 and K % 64 == 0 it is one
-launch of s6d_gemm_bf16 (bias and GELU in the epilogue), otherwise the library statement.  `S6D_DISABLE_FUSED=gemm_bf16`
+launch of s6d_gemm_bf16 (bias and GELU in the epilogue; `residual=`: the block's residual add in the epilogue too), otherwise
+the library statement.  `S6D_DISABLE_FUSED=gemm_bf16`
 turns the kernel off (A/B runs)."""
 import os
 
@@ -29,7 +30,12 @@ def eligible(x, n_out, k_in):
     return (x.is_cuda and x.dtype == torch.bfloat16 and n_out % 128 == 0 and k_in % 64 == 0 and ops.have("gemm_bf16"))
 
 
-def fused_linear(lin, x, gelu=False, weight2d=None, col_block=0):
+def res_eligible(x, n_out, k_in):
+    """The residual-add epilogue (s6d_gemm_bf16_res): the 256 x 256-tile kernel only.  S6D_DISABLE_FUSED=gemm_bf16_res: A/B runs."""
+    return eligible(x, n_out, k_in) and n_out % 256 == 0 and ops.have("gemm_bf16_res")
+
+
+def fused_linear(lin, x, gelu=False, weight2d=None, col_block=0, residual=None):
     """act(lin(x)); `weight2d` overrides lin.weight for conv weights viewed as (N, K).  col_block > 0 (kernel path only, N % 256
     == 0, S6D_QKV_LAYOUT=head): the result comes back as (N / col_block, M, col_block) -- the head-major q/k/v layout of the attention
     kernels -- or None when that path does not apply (the caller then takes the plain form).  Off by default: measured on the
@@ -42,6 +48,13 @@ def fused_linear(lin, x, gelu=False, weight2d=None, col_block=0):
             wb, bf = _cached(lin, w)
             return ops.gemm_bf16(x, wb, bf, gelu=gelu, col_block=col_block)
         return None
+    if residual is not None:
+        # residual + lin(x): in the GEMM's epilogue when the kernel takes the shape, written over the residual (the caller's
+        # stream tensor: nothing else holds it), otherwise the two statements
+        if res_eligible(x, N, K) and residual.dtype == torch.bfloat16 and residual.is_contiguous():
+            wb, bf = _cached(lin, w)
+            return ops.gemm_bf16(x, wb, bf, residual=residual, out=residual.reshape(-1, N)).reshape(residual.shape)
+        return residual + fused_linear(lin, x, gelu=gelu, weight2d=weight2d)
     if eligible(x, N, K):
         wb, bf = _cached(lin, w)
         return ops.gemm_bf16(x, wb, bf, gelu=gelu)

@@ -104,3 +104,30 @@ def test_column_block_output_on_the_emulator():
                         f"from tests import test_emu_gemm as t; t._run_cblk()"], env=dict(os.environ, HIPEMU_GLDS="late"),
                        capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def _run_res():
+    from tests import hipemu  # noqa: F401
+    import ctypes
+
+    from sam6d_amd import _lib, ops
+    from tests import test_gpu_gemm as T
+    L = ctypes.CDLL(hipemu.build())
+    L.s6d_strerror.restype = ctypes.c_char_p
+    L.s6d_strerror.argtypes = [ctypes.c_int]
+    L.s6d_last_hip_error.restype = ctypes.c_char_p
+    _lib._lib = L
+    ops._stream = lambda: ctypes.c_void_p(0)
+    torch.Tensor.is_cuda = property(lambda self: True)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    T.test_residual_epilogue_equals_gemm_then_add(700, 768, 192, False)
+    T.test_residual_epilogue_equals_gemm_then_add(300, 256, 64, True)
+
+
+@pytest.mark.parametrize("mode", ["early", "late"])
+def test_residual_epilogue_on_the_emulator(mode):
+    """s6d_gemm_bf16_res (residual add of a ViT block in the GEMM epilogue), bit-identical with GEMM-then-add, in place too."""
+    r = subprocess.run([sys.executable, "-c", f"import sys; sys.path.insert(0, {ROOT!r}); "
+                        f"from tests import test_emu_gemm as t; t._run_res()"], env=dict(os.environ, HIPEMU_GLDS=mode),
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

@@ -136,3 +136,33 @@ def test_crops_kernel_equals_the_library_statement(emu):
         assert torch.equal(got, want), (got - want).abs().max()
     want = pre._crops(image, m[kept].float(), box[kept], 56, True)
     assert torch.equal(emu.pem_crops(image.contiguous(), m.to(torch.uint8), kept, box, 56, True, pre.MEAN, pre.STD), want)
+
+
+def test_crops_follow_the_cv2_restatement_at_every_ratio(emu):
+    """s6d_pem_crops_f32 and preprocess._crops against oracle.pem_pre.cv2_resize_linear_u8 (cv2.resize INTER_LINEAR restated),
+    value for value, at the ratios with their own code path: 1:1 (copy), exactly 2:1 (box mean), up- and down-scaling with odd
+    sides, a crop touching the frame border."""
+    import numpy as np
+
+    from oracle import pem_pre as o
+    from sam6d_amd.pem import preprocess as pre
+    S = 16
+    H, W = 72, 80
+    g = torch.Generator().manual_seed(11)
+    image = torch.randint(0, 256, (H, W, 3), generator=g, dtype=torch.uint8)
+    sides = [16, 32, 7, 23, 48, 33, 5]
+    box = torch.tensor([[y, y + n, x, x + n] for n, (y, x) in zip(sides, [(0, 0), (10, 20), (3, 70), (40, 5), (24, 32), (39, 47), (67, 75)])])
+    m = torch.zeros(len(sides), H, W, dtype=torch.uint8)
+    for i, (y1, y2, x1, x2) in enumerate(box.tolist()):
+        m[i, y1:y2, x1:x2] = (torch.rand(y2 - y1, x2 - x1, generator=g) > 0.3).to(torch.uint8)
+    kept = torch.arange(len(sides))
+    for flag in (True, False):
+        got = emu.pem_crops(image.contiguous(), m, kept, box, S, flag, pre.MEAN, pre.STD)
+        lib = pre._crops(image, m, box, S, flag)
+        assert torch.equal(got, lib)
+        for i, (y1, y2, x1, x2) in enumerate(box.tolist()):
+            rgb = image.numpy()[y1:y2, x1:x2, :][:, :, ::-1]
+            if flag:
+                rgb = rgb * (m[i].numpy()[y1:y2, x1:x2, None] > 0).astype(np.uint8)
+            want = (o.cv2_resize_linear_u8(rgb, S).astype(np.float32) / np.float32(255) - o.MEAN) / o.STD
+            assert np.array_equal(got[i].numpy(), want.transpose(2, 0, 1)), (i, flag)

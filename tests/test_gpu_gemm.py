@@ -126,3 +126,21 @@ def test_column_block_output_equals_the_plain_product(M, N, K, cb):
     blk = ops.gemm_bf16(a, w, b, col_block=cb)
     assert blk.shape == (N // cb, M, cb)
     assert torch.equal(blk, plain.view(M, N // cb, cb).permute(1, 0, 2))
+
+
+@pytest.mark.parametrize("M,N,K,inplace", [(700, 768, 192, False), (300, 256, 64, True), (65536, 1280, 1280, True), (4096, 1280, 5120, False)])
+def test_residual_epilogue_equals_gemm_then_add(M, N, K, inplace):
+    """s6d_gemm_bf16_res: x + Linear(a) with the add in the GEMM's epilogue == the plain kernel's bf16 output, added to x in fp32
+    and rounded again (what add_layernorm's first output is), BIT FOR BIT, also in place and with ragged M."""
+    from sam6d_amd import ops
+    if not torch.cuda.is_available() and M > 1000:
+        pytest.skip("emulator: small shapes only")
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    x = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+    want = (ops.gemm_bf16(a, w, b).float() + x.float()).to(torch.bfloat16)
+    got = ops.gemm_bf16(a, w, b, residual=x, out=x if inplace else None)
+    assert (got.data_ptr() == x.data_ptr()) == inplace
+    assert torch.equal(got, want)

@@ -97,3 +97,53 @@ def test_per_detection_radius_on_multi_object_frames():
     same = opre.preprocess_frame(inp["image"], inp["depth"].numpy(), inp["K"].numpy(), inp["masks"].numpy(), 0.12,
                                  keys=inp["keys"].numpy(), **kw)
     assert not np.array_equal(same["pts"][1], ref["pts"][1])                  # the smaller radius really changed a cloud
+
+
+def test_cv2_resize_restatement_properties():
+    """oracle.pem_pre.cv2_resize_linear_u8 (the restated cv2.resize(INTER_LINEAR) of the PEM colour crop, f3): the properties
+    OpenCV's algorithm has by construction -- 1:1 is a copy, 2:1 is the rounded 2x2 box mean, a constant image stays constant
+    (the two independently rounded coefficients always add up to 2048 +- 1 and the >> 4 / >> 16 / + 2 >> 2 chain absorbs it),
+    2x upsampling uses the 3/4 - 1/4 weights (1536 / 512 of 2048) away from the border, and the result is within one grey
+    level of exact bilinear interpolation."""
+    from oracle import pem_pre as o
+    g = np.random.default_rng(3)
+    img = g.integers(0, 256, (224, 224, 3), dtype=np.uint8)
+    assert np.array_equal(o.cv2_resize_linear_u8(img, 224), img)
+    big = g.integers(0, 256, (448, 448, 3), dtype=np.uint8).astype(np.int32)
+    want = (big[0::2, 0::2] + big[0::2, 1::2] + big[1::2, 0::2] + big[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(o.cv2_resize_linear_u8(big.astype(np.uint8), 224), want.astype(np.uint8))
+    for side in (37, 100, 333, 500):
+        for v in (0, 1, 127, 254, 255):
+            assert (o.cv2_resize_linear_u8(np.full((side, side, 3), v, np.uint8), 224) == v).all(), (side, v)
+    small = g.integers(0, 256, (112, 112, 3), dtype=np.uint8)
+    up = o.cv2_resize_linear_u8(small, 224).astype(np.int32)
+    s = small.astype(np.int32)
+    t = s[:, 5] * 1536 + s[:, 6] * 512                                 # output column 11 (centre 5.25) <- source columns 5, 6
+    want = (((1536 * (t[5] >> 4)) >> 16) + ((512 * (t[6] >> 4)) >> 16) + 2) >> 2
+    assert np.array_equal(up[11, 11], want)
+    for side in (37, 100, 333, 500, 96):
+        im = g.integers(0, 256, (side, side, 3), dtype=np.uint8)
+        c = np.clip((np.arange(224) + 0.5) * side / 224 - 0.5, 0, side - 1)
+        i0 = np.floor(c).astype(int)
+        i1, f = np.minimum(i0 + 1, side - 1), c - np.floor(c)
+        rows = im[i0].astype(np.float64) * (1 - f)[:, None, None] + im[i1] * f[:, None, None]
+        ref = rows[:, i0] * (1 - f)[None, :, None] + rows[:, i1] * f[None, :, None]
+        assert np.abs(o.cv2_resize_linear_u8(im, 224) - ref).max() < 1.0
+
+
+def test_cv2_vectors_if_present():
+    """tests/golden/cv2_resize.npz (tools/gen_cv2_vectors.py, to be generated wherever cv2 is importable): the restatement
+    against OpenCV's own outputs.  Absent in this image (no cv2 offline): the f3 colour crop stays 'parity unpinned'."""
+    import hashlib
+    import os
+
+    import pytest
+    path = os.path.join(util.GOLDEN, "cv2_resize.npz")
+    if not os.path.exists(path):
+        pytest.skip("no cv2 vectors yet (cv2 is not installable offline)")
+    from oracle import pem_pre as o
+    from tools.gen_cv2_vectors import image
+    g = np.load(path)
+    for s in g["sides"].tolist():
+        out = o.cv2_resize_linear_u8(image(s, 1000 + s), 224)
+        assert hashlib.sha256(np.ascontiguousarray(out).tobytes()).hexdigest() == str(g[f"sha_{s}"]), s

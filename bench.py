@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_STEP)
     ap.add_argument("--sam-chunk", type=int, default=int(os.environ.get("S6D_SAM_CHUNK", str(SAM_CHUNK))))
+    ap.add_argument("--config", choices=("lmo", "fp8"), default="lmo",
+                    help="lmo = BASELINE configs[1] (the headline: bf16 ViTs); fp8 = the fp8 ViT-H MFMA path of configs[4] on the same "
+                         "workload (qkv / lin1 GEMMs of the SAM encoder on the fp8 matrix cores) -- its own line, never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the whole-frame `pipeline` block (all five models)")
@@ -223,12 +226,21 @@ def gemm_ms_inside_the_step(hp):
         e1.record()
         rec.append(((a.numel() // a.shape[-1], a.shape[-1], w.shape[0], bool(gelu)), e0, e1))
         return y
+    real8 = ops.gemm_fp8
+
+    def timed8(a8, sa, w8, sw, bias=None, gelu=False, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = real8(a8, sa, w8, sw, bias, gelu=gelu, **kw)
+        e1.record()
+        rec.append((("fp8", a8.numel() // a8.shape[-1], a8.shape[-1], w8.shape[0], bool(gelu)), e0, e1))
+        return y
     hp.sam_stage()                                          # warm
-    ops.gemm_bf16 = timed
+    ops.gemm_bf16, ops.gemm_fp8 = timed, timed8
     try:
         hp.sam_stage()
     finally:
-        ops.gemm_bf16 = real
+        ops.gemm_bf16, ops.gemm_fp8 = real, real8
     torch.cuda.synchronize()
     by = {}
     for key, e0, e1 in rec:
@@ -323,6 +335,32 @@ def kernel_rooflines(dev, sam_chunk, frames, in_step=None):
                     "launches_per_step": 32 * groups, "algorithmic_bytes": 2.0 * (M * K + N * K + M * N),
                     # the GELU instance runs at this one shape only; qkv / proj / lin2 share an instance (no per-shape counters)
                     "pmc_key": "gemm_bf16_kernel<1, true>" if gelu else "-"})
+    if os.environ.get("S6D_SAM_GEMM") == "fp8" and ops.have("gemm_fp8"):
+        # configs[4]: the two LayerNorm-fed GEMMs on the fp8 matrix cores (dense peak 5 PFLOP/s), and the quantising LayerNorm
+        from sam6d_amd.utils import fp8
+        for nm, K, N, gelu in (("qkv", 1280, 3840, False), ("lin1+gelu", 1280, 5120, True)):
+            qa, sa = fp8.quantize_rows(torch.randn(M, K, generator=g).to(dev))
+            qw, sw = fp8.quantize_rows((torch.randn(N, K, generator=g) / K ** 0.5).to(dev))
+            b = torch.randn(N, generator=g).to(dev)
+            b2b = _event_ms(lambda: ops.gemm_fp8(qa, sa, qw, sw, b, gelu=gelu), 10)
+            key = ("fp8", M, K, N, gelu)
+            ms = in_step[key][0] if in_step and key in in_step else b2b
+            flop = 2.0 * M * N * K
+            out.append({"kernel": f"gemm_fp8_kernel ({nm}, M={M} K={K} N={N})", "bound": "mfma", "achieved": round(flop / ms / 1e9, 1),
+                        "peak": 5000.0, "unit": "TFLOP/s (fp8 e4m3, v_mfma_scale_f32_32x32x64_f8f6f4)",
+                        "frac": round(flop / ms / 1e9 / 5000.0, 4), "avg_ms": round(ms, 4), "back_to_back_ms": round(b2b, 4),
+                        "timed": "inside one SAM stage pass" if ms is not b2b else "back to back", "launches_per_step": 32 * groups,
+                        "algorithmic_bytes": 1.0 * (M * K + N * K) + 2.0 * M * N, "pmc_key": "gemm_fp8_kernel<1, true>" if gelu else "-"})
+        xb = torch.randn(M, 1280, generator=g).to(dev).to(torch.bfloat16)
+        gm, bt = torch.ones(1280, device=dev), torch.zeros(1280, device=dev)
+        ms = _event_ms(lambda: ops.layernorm_fp8(xb, gm, bt, 1e-6), 10)
+        out.append({"kernel": "layernorm_fp8_kernel", "bound": "hbm", "achieved": round(M * 1280 * 3 / ms / 1e6, 1), "peak": 8000.0,
+                    "unit": "GB/s", "frac": round(M * 1280 * 3 / ms / 1e6 / 8000.0, 4), "avg_ms": round(ms, 4),
+                    "launches_per_step": 64 * groups, "algorithmic_bytes": float(M) * 1280 * 3})
+        # in this configuration qkv / lin1 do not run the bf16 kernel: their bf16 rows stay for comparison, off the path
+        for r in out:
+            if r["kernel"].startswith("gemm_bf16_kernel (qkv") or r["kernel"].startswith("gemm_bf16_kernel (lin1"):
+                r["launches_per_step"] = 0
     x = torch.randn(M, 1280, generator=g).to(dev).to(torch.bfloat16)
     w = torch.randn(5120, 1280, generator=g).to(dev).to(torch.bfloat16)
     bb = torch.randn(5120, generator=g).to(dev).to(torch.bfloat16)
@@ -452,6 +490,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.config == "fp8":
+        os.environ["S6D_SAM_GEMM"] = "fp8"
     hp = HotPath(dev, args.frames, args.sam_chunk)
 
     def barrier():
@@ -502,6 +542,12 @@ def main():
                                        "P=128 proposals x 42 templates (scored in groups of 8 frames), 1 instance/frame, 2048 pts (PEM batch 32)",
                            "frames_per_step_per_gpu": args.frames, "sam_frames_per_launch_group": args.sam_chunk,
                            "sharding": f"frames over {world} rank(s)"}}
+        if args.config == "fp8":
+            line["dtype"] = ("fp8 e4m3 operands / f32 accumulation (SAM ViT-H qkv and lin1 GEMMs; per-token and per-output-channel "
+                             "power-of-two scales) + bf16 (every other ViT op) + f32 (ISM scoring, PEM point transformer and pose solvers)")
+            line["config"]["workload"] = ("BASELINE configs[4] 'fp8 ViT-H MFMA path' on the configs[1] workload (the FastSAM segmentor and "
+                                          "the 7-dataset sweep of configs[4] are outside the north-star path): " + line["config"]["workload"])
+            line["config"]["headline"] = False
         line.update(extra)
         print(json.dumps(line))
     if dist is not None:

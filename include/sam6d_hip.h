@@ -30,7 +30,7 @@ extern "C" {
 
 /* Bumped whenever a signature in this header changes; the loader (sam6d_amd/_lib.py) refuses a library whose
  * s6d_version() differs from the header it was written against (a stale .so fails at load, not at a call). */
-#define S6D_ABI_VERSION 102
+#define S6D_ABI_VERSION 103
 int s6d_version(void);
 const char *s6d_strerror(int code);
 /* last HIP error string seen by this thread (empty if none) */
@@ -211,6 +211,21 @@ int s6d_gemm_bf16_cblk(const void *A, long lda, const void *W, long ldw, const f
  * (tokens, C) tensors (segment_anything/modeling/image_encoder.py:166-182; timm / DINOv2 blocks alike).  N % 256 == 0. */
 int s6d_gemm_bf16_res(const void *A, long lda, const void *W, long ldw, const float *bias, const void *R, long ldr, void *C,
                       long ldc, int M, int N, int K, int max_blocks, void *stream);
+
+/* ---------------------------------------------------------------- fp8 ViT path (BASELINE configs[4]; never the headline)
+ * C = act(A W^T + bias) with OCP fp8 (e4m3fn) operands: A (M,K) and W (N,K) bytes, row strides lda / ldw (multiples of 16),
+ * a_scale (M) / w_scale (N): one E8M0 byte per row -- the real value of an element is q * 2^(byte - 127) -- i.e. per-token
+ * activation scales and per-output-channel weight scales, restricted to powers of two so that they ride in the block-scale
+ * operands of v_mfma_scale_f32_32x32x64_f8f6f4 (twice the bf16 instruction's product per cycle).  fp32 accumulation, bias (N)
+ * f32 or NULL, epilogue 0 / 1 (exact GELU), C (M,N) bf16.  N % 256 == 0, K % 128 == 0.
+ * There is no fp8 path in the reference (its nearest precision hook: Instance_Segmentation_Model/configs/machine/trainer/
+ * local.yaml:9, Lightning precision 16); the Linear statements are those of s6d_gemm_bf16. */
+int s6d_gemm_fp8(const void *A, long lda, const unsigned char *a_scale, const void *W, long ldw, const unsigned char *w_scale,
+                 const float *bias, void *C, long ldc, int M, int N, int K, int epilogue, int max_blocks, void *stream);
+/* LayerNorm(x) (rows,C) bf16 -> fp8 e4m3 rows y8 (rows,C) + one E8M0 scale byte per row (the A operand of s6d_gemm_fp8):
+ * fp32 statistics, scale 2^e with the smallest e for which amax / 2^e <= 448, round to nearest even.  C % 8 == 0, C <= 2048. */
+int s6d_layernorm_fp8(const void *x, const float *gamma, const float *beta, float eps, long rows, int C, void *y8,
+                      unsigned char *yscale, void *stream);
 
 /* ---------------------------------------------------------------- ISM proposal-vs-template scoring */
 

@@ -98,11 +98,25 @@ typedef unsigned short u16;
 // the single vector-memory counter makes a counted wait behind 16 stores wait for their acknowledgement -- measured -8 % (the drain
 // itself exposes a load latency per tile and the store cost did not move: profiles/r02_gemm_variants_qt_drain.json).
 
+// Residual pieces of the EPI 2 epilogue.  With __builtin_amdgcn_global_load_lds in flight hipcc waits vmcnt(0) at the first use
+// of any ordinary load (an LDS-DMA is a VMEM and an LDS event: its counter model gives up counting), i.e. behind every store
+// the epilogue has issued so far -- measured: lin2 + 65 us per launch, all of the LayerNorm saving.  The EPI 2 instantiation
+// therefore issues its LDS-DMA as inline asm (as csrc/s6d_attn.hip does): the compiler then sees only the epilogue's own loads
+// and stores and emits exact counted waits for them; DMA pieces older than a residual load complete before it (in-order
+// return), and none is issued between a residual load and its use.
+#ifndef HIPEMU
+__device__ __forceinline__ void gemm_dma16_asm(const void *src, S6D_LDS(char) *dst) {
+  const unsigned a = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dst);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(a) : "memory", "m0");
+}
+#endif
+
 struct GemmParams {
   const u16 *A;       // (M,K) bf16, row stride lda
   const u16 *W;       // (N,K) bf16, row stride ldw
   const float *bias;  // (N) f32 or nullptr
   u16 *C;             // (M,N) bf16, row stride ldc
+  const unsigned char *sa, *sw;   // fp8 operands (DT = 1): E8M0 scale byte of every A row (M) / W row (N); value = q * 2^(byte - 127)
   const u16 *R;       // EPI 2: residual (M,N) bf16, row stride ldr; may be C itself (each 16-byte piece is read, then written, by one lane)
   long ldr;
   unsigned lda2, ldw2;  // row strides in BYTES
@@ -145,8 +159,19 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
   return (unsigned)a.u | ((unsigned)c.u << 16);
 }
 
-template <int EPI, bool HAS_BIAS>
-__global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
+// DT = 0: bf16 operands, K step 64 (4 x v_mfma_f32_32x32x16_bf16 per 32 x 32 tile and K tile).
+// DT = 1 (round 3, BASELINE configs[4]): OCP fp8 e4m3 operands, K step 128 -- the SAME 128-byte rows, ring, swizzle and DMA
+// stream -- and 2 x v_mfma_scale_f32_32x32x64_f8f6f4 per tile and K tile: twice the product per byte staged and per matrix
+// cycle.  The per-token and per-output-channel scales are powers of two (E8M0 bytes) and ride in the instruction's hardware
+// block-scale operands: a lane's fragment is one row's 32 k values, so "block scale" = that row's scale, constant over K.  The
+// accumulators therefore hold the true product and the epilogue (bias init, GELU, quad transpose) is the bf16 one, untouched.
+// Both operands are fetched with the same (lane >> 5, byte) -> k map, so the product does not depend on the instruction's
+// internal k order.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+template <int EPI, bool HAS_BIAS, int DT>
+__device__ __forceinline__ void gemm_body(const GemmParams &p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;       // M half / N quarter of the 256 x 256 tile
@@ -198,6 +223,12 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
   auto dma = [&](const u16 *base, unsigned off, int slot, int piece) __attribute__((always_inline)) {
     S6D_LDS(char) *dst = (S6D_LDS(char) *)gemm_smem + slot * kSlot + (wave * 2 + piece) * 1024;
     if (S6D_GEMM_ABLATE & 1) return;
+#ifndef HIPEMU
+    if (EPI == 2) {
+      gemm_dma16_asm((const char *)base + off, dst);
+      return;
+    }
+#endif
     __builtin_amdgcn_global_load_lds((const S6D_GLOBAL(void) *)((const char *)base + off), dst, 16, 0, 0);
   };
   auto issue_b = [&](int half, int slot) __attribute__((always_inline)) {
@@ -224,7 +255,12 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
   {
     const int sw = (lane >> 1) & 7, hb = lane >> 5;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) foff[ks] = (unsigned)((lane & 31) * 128 + ((((2 * ks) | hb) ^ sw) << 4));
+    for (int ks = 0; ks < 4; ++ks) {
+      // 16-byte chunk of the row this lane reads at step ks.  bf16: k step ks, k half hb.  fp8: MFMA ks >> 1 covers 64 bytes, this
+      // lane's 32 of them (k block hb) are chunks 2 hb, 2 hb + 1 of that half-row
+      const int cid = DT ? (4 * (ks >> 1) + 2 * hb + (ks & 1)) : ((2 * ks) | hb);
+      foff[ks] = (unsigned)((lane & 31) * 128 + ((cid ^ sw) << 4));
+    }
   }
   const unsigned brow = (unsigned)((wc & 1) * 64 * 128);                // this wave's 64 W rows inside its B half-tile
   auto frag = [&](int slot, unsigned rowbytes, int ks) __attribute__((always_inline)) -> bf16x8 {
@@ -239,9 +275,14 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
     const int a = lane & 31;
     const int row = S6D_GEMM_QT ? 32 * ((a >> 2) & 1) + 16 * nt + 4 * (a >> 3) + (a & 3) : 32 * nt + a;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      wfo[nt][ks] = brow + (unsigned)(row * 128 + ((((2 * ks) | (lane >> 5)) ^ ((row >> 1) & 7)) << 4));
+    for (int ks = 0; ks < 4; ++ks) {
+      const int hb = lane >> 5;
+      const int cid = DT ? (4 * (ks >> 1) + 2 * hb + (ks & 1)) : ((2 * ks) | hb);
+      wfo[nt][ks] = brow + (unsigned)(row * 128 + ((cid ^ ((row >> 1) & 7)) << 4));
+    }
   }
+  // fp8: E8M0 scale bytes of this lane's W rows (per n tile) and activation rows (per m tile) of the current output tile
+  int wsc[2] = {127, 127}, xsc[4] = {127, 127, 127, 127};
   auto wfrag = [&](int slot, int nt, int ks) __attribute__((always_inline)) -> bf16x8 {
     return *reinterpret_cast<const bf16x8 *>(gemm_smem + slot * kSlot + wfo[nt][ks]);
   };
@@ -252,6 +293,17 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
   int cm0, cn0;
   tile_mn(0, cm0, cn0);
 
+  auto load_scales = [&](int m0, int n0) __attribute__((always_inline)) {
+    if (!DT) return;
+    const int a = lane & 31;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int row = S6D_GEMM_QT ? 32 * ((a >> 2) & 1) + 16 * nt + 4 * (a >> 3) + (a & 3) : 32 * nt + a;
+      wsc[nt] = (int)p.sw[n0 + wc * 64 + row];
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) xsc[mt] = (int)p.sa[min(m0 + wr * 128 + mt * 32 + a, p.M - 1)];
+  };
   auto init_acc = [&](int n0) __attribute__((always_inline)) {          // accumulators start at the bias (scalar loads)
     const int nb = __builtin_amdgcn_readfirstlane(n0 + wc * 64);
     const S6D_CONST(float) *bs = (const S6D_CONST(float) *)p.bias + nb;
@@ -366,6 +418,14 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
     const int col = n0 + wc * 64 + 32 * (lane >> 5) + 8 * (lane & 3);
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
+      if (EPI == 2) {
+        // unconditional: a residual piece that is loaded but consumed only on the store path would stay "pending" on the other
+        // path, and the compiler would then wait vmcnt(0) before the main loop reuses its register
+        X[y][0] = add_bf16x2(X[y][0], rr[y].x);
+        X[y][1] = add_bf16x2(X[y][1], rr[y].y);
+        X[y][2] = add_bf16x2(X[y][2], rr[y].z);
+        X[y][3] = add_bf16x2(X[y][3], rr[y].w);
+      }
       if (S6D_GEMM_ABLATE & 4) {
 #ifndef HIPEMU
         asm volatile("" ::"v"(X[y][0]), "v"(X[y][1]), "v"(X[y][2]), "v"(X[y][3]));
@@ -378,24 +438,24 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
         } else {
           dst = p.C + (size_t)(mq + y) * p.ldc + col;
         }
-        if (EPI == 2) {
-          X[y][0] = add_bf16x2(X[y][0], rr[y].x);
-          X[y][1] = add_bf16x2(X[y][1], rr[y].y);
-          X[y][2] = add_bf16x2(X[y][2], rr[y].z);
-          X[y][3] = add_bf16x2(X[y][3], rr[y].w);
-        }
         *reinterpret_cast<uint4 *>(dst) = make_uint4(X[y][0], X[y][1], X[y][2], X[y][3]);
       }
     }
   };
   auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) {
-    uint4 rr[2][4] = {};
-    if (EPI == 2 && S6D_GEMM_QT) load_res(0, m0, n0, rr[0]);
+    // EPI 2 schedule (VM operations in program order): L0 L1 L2 | S0 L3 | S1 | S2 | S3, with Lk / Sk the four residual loads / four
+    // stores of strip k: every strip's loads are older than all stores but S0, so waiting for them leaves the stores in flight;
+    // L3 goes out after strip 0 has freed its 32 accumulator registers (all four up front spill).
+    uint4 rr[4][4];
+    if (EPI == 2 && S6D_GEMM_QT) {
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt) load_res(mt, m0, n0, rr[mt]);
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       if (S6D_GEMM_QT) {
-        if (EPI == 2 && mt + 1 < 4) load_res(mt + 1, m0, n0, rr[(mt + 1) & 1]);   // one strip ahead of its use
-        epilogue_qt(mt, m0, n0, rr[mt & 1]);
+        epilogue_qt(mt, m0, n0, rr[mt]);
+        if (EPI == 2 && mt == 0) load_res(3, m0, n0, rr[3]);
       } else {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) epilogue_one(mt, nt, m0, n0);
@@ -436,15 +496,31 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
     // A slot is restaged one phase after its last fragment read; that is safe because every load segment ends with lgkmcnt(0)
     // BEFORE its barrier (the reads are retired when the other wave group, one barrier apart, starts issuing into the slot), and
     // a landed K tile is read one phase (two barriers) after the wait that retired it.
+#define S6D_MFMA8(C, A, B, SA, SB) C = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, C, 0, 0, 0, SA, 0, SB)
 #define S6D_MSEG2(QM)                                                                  \
   do {                                                                                 \
     S6D_SETPRIO(1);                                                                    \
-    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) S6D_PIN(wf[nt][ks]); \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                 \
-      S6D_MFMA(acc[2 * QM][0], wf[0][ks], xf[0][ks]);                                  \
-      S6D_MFMA(acc[2 * QM + 1][0], wf[0][ks], xf[1][ks]);                              \
-      S6D_MFMA(acc[2 * QM][1], wf[1][ks], xf[0][ks]);                                  \
-      S6D_MFMA(acc[2 * QM + 1][1], wf[1][ks], xf[1][ks]);                              \
+    if constexpr (DT == 0) {                                                           \
+      _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) S6D_PIN(wf[nt][ks]); \
+      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                               \
+        S6D_MFMA(acc[2 * QM][0], wf[0][ks], xf[0][ks]);                                \
+        S6D_MFMA(acc[2 * QM + 1][0], wf[0][ks], xf[1][ks]);                            \
+        S6D_MFMA(acc[2 * QM][1], wf[1][ks], xf[0][ks]);                                \
+        S6D_MFMA(acc[2 * QM + 1][1], wf[1][ks], xf[1][ks]);                            \
+      }                                                                                \
+    } else {                                                                           \
+      i32x8 wq[2][2], xq[2][2];                                                        \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int h = 0; h < 2; ++h) { \
+        wq[j][h] = __builtin_shufflevector((i32x4)wf[j][2 * h], (i32x4)wf[j][2 * h + 1], 0, 1, 2, 3, 4, 5, 6, 7); \
+        xq[j][h] = __builtin_shufflevector((i32x4)xf[j][2 * h], (i32x4)xf[j][2 * h + 1], 0, 1, 2, 3, 4, 5, 6, 7); \
+        S6D_PIN(wq[j][h]);                                                             \
+      }                                                                                \
+      _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                  \
+        S6D_MFMA8(acc[2 * QM][0], wq[0][h], xq[0][h], wsc[0], xsc[2 * QM]);            \
+        S6D_MFMA8(acc[2 * QM + 1][0], wq[0][h], xq[1][h], wsc[0], xsc[2 * QM + 1]);    \
+        S6D_MFMA8(acc[2 * QM][1], wq[1][h], xq[0][h], wsc[1], xsc[2 * QM]);            \
+        S6D_MFMA8(acc[2 * QM + 1][1], wq[1][h], xq[1][h], wsc[1], xsc[2 * QM + 1]);    \
+      }                                                                                \
     }                                                                                  \
     S6D_PIN(acc[2 * QM][0]);                                                           \
     S6D_PIN(acc[2 * QM + 1][0]);                                                       \
@@ -473,6 +549,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
       S6D_VMCNT(0);
     }
     init_acc(cn0);
+    load_scales(cm0, cn0);
     S6D_BARRIER();
     if (wr == 1) S6D_BARRIER();                                          // the M halves run one barrier apart from here on
     int s0 = 0;
@@ -520,6 +597,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
         if (++ct < my_tiles) {
           tile_mn(ct, cm0, cn0);
           init_acc(cn0);
+          load_scales(cm0, cn0);
         }
         if (wr == 1) S6D_BARRIER();
       }
@@ -528,6 +606,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
 #undef S6D_MSEG2
     return;
   }
+  static_assert(DT == 0 || S6D_GEMM_PH2, "the fp8 operands are wired into the two-phase main loop only");
   // ---- prologue: half-tiles 0..6 of the stream (K tile 0 whole; B0 B1 A0 of K tile 1)
   set_b(0);
   set_a(0);
@@ -622,6 +701,15 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
   if (wr == 0) S6D_BARRIER();                             // same barrier count for both halves
 #undef S6D_MSEG
 #undef S6D_MFMA
+}
+
+template <int EPI, bool HAS_BIAS>
+__global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
+  gemm_body<EPI, HAS_BIAS, 0>(p);
+}
+template <int EPI, bool HAS_BIAS>
+__global__ void __launch_bounds__(512, 2) gemm_fp8_kernel(GemmParams p) {
+  gemm_body<EPI, HAS_BIAS, 1>(p);
 }
 
 
@@ -855,7 +943,16 @@ static int gemm_impl() {
 extern "C" int s6d_gemm_bf16_cblk(const void *A, long lda, const void *W, long ldw, const float *bias, void *C, long ldc, int M,
                                   int N, int K, int epilogue, int col_block, int max_blocks, void *stream);
 static int gemm_launch(const void *A, long lda, const void *W, long ldw, const float *bias, const void *R, long ldr, void *C, long ldc,
-                       int M, int N, int K, int epilogue, int col_block, int max_blocks, void *stream);
+                       int M, int N, int K, int epilogue, int col_block, int max_blocks, void *stream, int dt = 0,
+                       const unsigned char *sa = nullptr, const unsigned char *sw = nullptr);
+
+extern "C" int s6d_gemm_fp8(const void *A, long lda, const unsigned char *a_scale, const void *W, long ldw, const unsigned char *w_scale,
+                            const float *bias, void *C, long ldc, int M, int N, int K, int epilogue, int max_blocks, void *stream) {
+  if (!a_scale || !w_scale) return S6D_EINVAL;
+  if (epilogue != 0 && epilogue != 1) return S6D_EINVAL;
+  if (N % 256 != 0 || K % 128 != 0 || !S6D_GEMM_QT || !S6D_GEMM_PH2) return S6D_EUNSUPPORTED;
+  return gemm_launch(A, lda, W, ldw, bias, nullptr, 0, C, ldc, M, N, K, epilogue, 0, max_blocks, stream, 1, a_scale, w_scale);
+}
 
 extern "C" int s6d_gemm_bf16_res(const void *A, long lda, const void *W, long ldw, const float *bias, const void *R, long ldr,
                                  void *C, long ldc, int M, int N, int K, int max_blocks, void *stream) {
@@ -876,19 +973,21 @@ extern "C" int s6d_gemm_bf16_cblk(const void *A, long lda, const void *W, long l
 }
 
 static int gemm_launch(const void *A, long lda, const void *W, long ldw, const float *bias, const void *R, long ldr, void *C, long ldc,
-                       int M, int N, int K, int epilogue, int col_block, int max_blocks, void *stream) {
+                       int M, int N, int K, int epilogue, int col_block, int max_blocks, void *stream, int dt,
+                       const unsigned char *sa, const unsigned char *sw) {
   if (M < 0 || N <= 0 || K <= 0) return S6D_EINVAL;
+  const int esz = dt ? 1 : 2, kstep = dt ? 128 : 64, ralign = 16 / esz;   // operand element bytes, K step, elements per 16 bytes
   if (M == 0) return S6D_OK;                                            // an empty row batch: nothing to launch
   if (!A || !W || !C) return S6D_EINVAL;
   if (col_block < 0 || (col_block % 8) != 0 || (col_block > 0 && N % col_block != 0)) return S6D_EINVAL;
   if (col_block > 0 && (N % 256 != 0 || !S6D_GEMM_QT)) return S6D_EUNSUPPORTED;   // the quad-transposed epilogue of the 256 x 256 kernel
-  if (N % 128 != 0 || K % 64 != 0 || lda < K || ldw < K || ldc < N) return S6D_EINVAL;
-  if ((lda % 8) || (ldw % 8) || (ldc % 8)) return S6D_EINVAL;           // 16-byte rows
+  if (N % 128 != 0 || K % kstep != 0 || lda < K || ldw < K || ldc < N) return S6D_EINVAL;
+  if ((lda % ralign) || (ldw % ralign) || (ldc % 8)) return S6D_EINVAL;  // 16-byte rows
   if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) return S6D_EINVAL;
   if (epilogue < 0 || epilogue > 2) return S6D_EINVAL;
   // staging addresses are 32-bit byte offsets from A / W
-  if ((double)M * (double)lda * 2.0 >= 2147483648.0 || (double)N * (double)ldw * 2.0 >= 2147483648.0) return S6D_EUNSUPPORTED;
-  const int impl = (N % 256 != 0) ? 2 : ((col_block > 0 || epilogue == 2) ? 1 : gemm_impl());
+  if ((double)M * (double)lda * esz >= 2147483648.0 || (double)N * (double)ldw * esz >= 2147483648.0) return S6D_EUNSUPPORTED;
+  const int impl = (N % 256 != 0) ? 2 : ((col_block > 0 || epilogue == 2 || dt) ? 1 : gemm_impl());
   GemmParams p;
   p.A = (const u16 *)A;
   p.W = (const u16 *)W;
@@ -896,15 +995,17 @@ static int gemm_launch(const void *A, long lda, const void *W, long ldw, const f
   p.C = (u16 *)C;
   p.R = (const u16 *)R;
   p.ldr = ldr;
-  p.lda2 = (unsigned)(lda * 2);
-  p.ldw2 = (unsigned)(ldw * 2);
+  p.lda2 = (unsigned)(lda * esz);
+  p.ldw2 = (unsigned)(ldw * esz);
+  p.sa = sa;
+  p.sw = sw;
   p.ldc = ldc;
   p.M = M;
   p.N = N;
   p.K = K;
   p.MT = (M + 255) / 256;
   p.NT = N / (impl == 2 ? 128 : 256);
-  p.nk = K / 64;
+  p.nk = K / kstep;
   p.ntiles = p.MT * p.NT;
   const char *gm_env = getenv("S6D_GEMM_GM");                            // tile-order experiment knob
   p.GM = (gm_env && atoi(gm_env) > 0) ? atoi(gm_env) : 8;
@@ -939,6 +1040,21 @@ static int gemm_launch(const void *A, long lda, const void *W, long ldw, const f
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                    \
     hipLaunchKernelGGL((gemm_bf16_kernel<E, HB>), dim3(grid), dim3(512), lds, st, p);                                   \
   } while (0)
+#define S6D_GEMM8_LAUNCH(E, HB)                                                                                         \
+  do {                                                                                                                  \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_fp8_kernel<E, HB>),                                  \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                    \
+    hipLaunchKernelGGL((gemm_fp8_kernel<E, HB>), dim3(grid), dim3(512), lds, st, p);                                    \
+  } while (0)
+  if (dt) {
+    if (epilogue == 1) {
+      if (bias) S6D_GEMM8_LAUNCH(1, true); else S6D_GEMM8_LAUNCH(1, false);
+    } else {
+      if (bias) S6D_GEMM8_LAUNCH(0, true); else S6D_GEMM8_LAUNCH(0, false);
+    }
+    return launch_status();
+  }
+#undef S6D_GEMM8_LAUNCH
   if (epilogue == 2) {
     if (bias) S6D_GEMM_LAUNCH(2, true); else S6D_GEMM_LAUNCH(2, false);
   } else if (epilogue == 1) {

@@ -81,6 +81,93 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const u16 *__restric
   }
 }
 
+
+// LayerNorm with an fp8 (OCP e4m3) output row and one power-of-two scale per row -- the activation operand of the fp8 GEMMs
+// (csrc/s6d_gemm.hip gemm_fp8_kernel; BASELINE configs[4]).  y = LN(x) in fp32, amax over the row, scale 2^e with
+// e = the smallest integer for which amax / 2^e <= 448 (e4m3's largest finite value), q = e4m3(y / 2^e) (round to nearest even),
+// scale byte = e + 127 (E8M0, the MX block-scale encoding the matrix instruction takes).  An all-zero row gets byte 127.
+// One wavefront per row, as add_layernorm_kernel.
+template <int VEC>
+__global__ __launch_bounds__(256) void layernorm_fp8_kernel(const u16 *__restrict__ x, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, float eps, long rows, int C,
+                                                           unsigned char *__restrict__ y8, unsigned char *__restrict__ yscale) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const int nchunk = C / 8;
+  float v[VEC][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int ch = lane + i * 64;
+    if (ch < nchunk) {
+      union { uint4 u; u16 h[8]; } a;
+      a.u = *reinterpret_cast<const uint4 *>(x + row * C + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[i][e] = bf2f_(a.h[e]);
+        sum += v[i][e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int ch = lane + i * 64;
+    if (ch < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[i][e] - mean;
+        sq += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int ch = lane + i * 64;
+    if (ch < nchunk) {
+      const float4 g0 = *reinterpret_cast<const float4 *>(gamma + ch * 8), g1 = *reinterpret_cast<const float4 *>(gamma + ch * 8 + 4);
+      const float4 b0 = *reinterpret_cast<const float4 *>(beta + ch * 8), b1 = *reinterpret_cast<const float4 *>(beta + ch * 8 + 4);
+      const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[i][e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
+        amax = fmaxf(amax, fabsf(v[i][e]));
+      }
+    }
+  }
+  amax = wave_max(amax);
+  // amax = f 2^ex with f in [0.5, 1): amax / 2^(ex - 9) = 512 f <= 448 iff f <= 0.875
+  int e2 = 0;
+  if (amax > 0.f) {
+    int ex;
+    const float f = frexpf(amax, &ex);
+    e2 = ex - (f <= 0.875f ? 9 : 8);
+    e2 = min(max(e2, -127), 127);
+  }
+  const float inv = ldexpf(1.f, -e2);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int ch = lane + i * 64;
+    if (ch < nchunk) {
+      int lo = 0, hi = 0;
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][0] * inv, v[i][1] * inv, lo, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][2] * inv, v[i][3] * inv, lo, true);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][4] * inv, v[i][5] * inv, hi, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][6] * inv, v[i][7] * inv, hi, true);
+      *reinterpret_cast<uint2 *>(y8 + row * C + ch * 8) = make_uint2((unsigned)lo, (unsigned)hi);
+    }
+  }
+  if (lane == 0) yscale[row] = (unsigned char)(e2 + 127);
+}
+
 }  // namespace s6d
 
 using namespace s6d;
@@ -102,5 +189,25 @@ extern "C" int s6d_add_layernorm_bf16(const void *x, const void *delta, const fl
   else if (nchunk <= 256) S6D_LN(4);
   else return S6D_EUNSUPPORTED;
 #undef S6D_LN
+  return launch_status();
+}
+
+extern "C" int s6d_layernorm_fp8(const void *x, const float *gamma, const float *beta, float eps, long rows, int C, void *y8,
+                                 unsigned char *yscale, void *stream) {
+  if (rows < 0 || C <= 0 || (C % 8) != 0) return S6D_EINVAL;
+  if (rows == 0) return S6D_OK;
+  if (!x || !gamma || !beta || !y8 || !yscale) return S6D_EINVAL;
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  const int nchunk = C / 8;
+  hipStream_t st = as_stream(stream);
+#define S6D_LN8(V)                                                                                              \
+  hipLaunchKernelGGL((layernorm_fp8_kernel<V>), dim3(grid), dim3(256), 0, st, (const u16 *)x, gamma, beta, eps, rows, C, \
+                     (unsigned char *)y8, yscale)
+  if (nchunk <= 64) S6D_LN8(1);
+  else if (nchunk <= 128) S6D_LN8(2);
+  else if (nchunk <= 192) S6D_LN8(3);
+  else if (nchunk <= 256) S6D_LN8(4);
+  else return S6D_EUNSUPPORTED;
+#undef S6D_LN8
   return launch_status();
 }

@@ -204,6 +204,25 @@ class DinoVisionTransformer(nn.Module):
         x = x.contiguous()
         delta = None
         scale = (self.embed_dim // self.num_heads) ** -0.5
+        C = x.shape[-1]
+        if ops.have("gemm_bf16_res") and C % 256 == 0 and all(
+                eligible(x, C, C) and eligible(x, C, blk.mlp.fc2.in_features) and isinstance(blk.mlp.act, nn.GELU)
+                and blk.mlp.act.approximate == "none" for blk in self.blocks):
+            # round 3: both residual adds of a block in the epilogues of the proj / fc2 GEMMs (in place on the stream tensor),
+            # LayerNorms as one-read passes
+            x = x.clone()
+            M = x.numel() // C
+            for blk in self.blocks:
+                wp, bp, bpf, w2, b2, b2f = blk._folded(x.dtype)
+                g, b = _ln_f32(blk.norm1)
+                _, h = ops.add_layernorm(x, None, g, b, blk.norm1.eps)
+                o = ops.seq_attention(fused_linear(blk.attn.qkv, h).contiguous(), blk.attn.num_heads, scale)
+                ops.gemm_bf16(o, wp, bpf, residual=x, out=x.view(M, C))
+                g, b = _ln_f32(blk.norm2)
+                _, h = ops.add_layernorm(x, None, g, b, blk.norm2.eps)
+                ops.gemm_bf16(fused_linear(blk.mlp.fc1, h, gelu=True), w2, b2f, residual=x, out=x.view(M, C))
+            g, b = _ln_f32(self.norm)
+            return ops.add_layernorm(x, None, g, b, self.norm.eps)
         for blk in self.blocks:
             wp, bp, bpf, w2, b2, b2f = blk._folded(x.dtype)
             own = eligible(x, wp.shape[0], wp.shape[1]) and eligible(x, w2.shape[0], w2.shape[1])   # s6d_gemm_bf16

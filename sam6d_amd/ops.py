@@ -530,6 +530,43 @@ def gemm_bf16(a, w, bias=None, gelu=False, out=None, max_blocks=0, col_block=0, 
     return out.reshape(*a.shape[:-1], N)
 
 
+def gemm_fp8(a8, a_scale, w8, w_scale, bias=None, gelu=False, max_blocks=0):
+    """a8 (..., K) uint8 (e4m3fn bytes) with a_scale (rows,) uint8 (E8M0), w8 (N, K) uint8 with w_scale (N,) uint8, bias (N) f32
+    or None -> act(A W^T + bias) (..., N) bf16 on the fp8 matrix cores (sam6d_amd/utils/fp8.py: the operand format).
+    N % 256 == 0, K % 128 == 0."""
+    for t, nm in ((a8, "a8"), (a_scale, "a_scale"), (w8, "w8"), (w_scale, "w_scale")):
+        _chk(t, torch.uint8, nm)
+    K, N = a8.shape[-1], w8.shape[0]
+    a2 = a8.reshape(-1, K)
+    M = a2.shape[0]
+    if w8.shape != (N, K) or a_scale.numel() != M or w_scale.numel() != N:
+        raise ValueError(f"shapes: a8 {tuple(a8.shape)}, a_scale {tuple(a_scale.shape)}, w8 {tuple(w8.shape)}, w_scale {tuple(w_scale.shape)}")
+    if bias is not None:
+        _chk(bias, torch.float32, "bias", 1)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=a8.device)
+    rows = max(256, ((2 ** 31 - 1) // K) // 256 * 256)
+    for r0 in range(0, M, rows):
+        r1 = min(M, r0 + rows)
+        _call("s6d_gemm_fp8", _ptr(a2[r0:r1]), ctypes.c_long(K), _ptr(a_scale.reshape(-1)[r0:r1]), _ptr(w8), ctypes.c_long(K),
+              _ptr(w_scale), _ptr(bias) if bias is not None else _vp(0), _ptr(out[r0:r1]), ctypes.c_long(N), r1 - r0, N, K,
+              1 if gelu else 0, int(max_blocks), _stream())
+    return out.reshape(*a8.shape[:-1], N)
+
+
+def layernorm_fp8(x, gamma, beta, eps):
+    """x (..., C) bf16 -> (LN(x) as e4m3fn bytes (..., C) uint8, one E8M0 scale byte per row (rows,) uint8)."""
+    _chk(x, torch.bfloat16, "x")
+    _chk(gamma, torch.float32, "gamma", 1)
+    _chk(beta, torch.float32, "beta", 1)
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y8 = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    ys = torch.empty(rows, dtype=torch.uint8, device=x.device)
+    _call("s6d_layernorm_fp8", _ptr(x), _ptr(gamma), _ptr(beta), ctypes.c_float(eps), ctypes.c_long(rows), int(C), _ptr(y8), _ptr(ys),
+          _stream())
+    return y8, ys
+
+
 def add_layernorm(x, delta, gamma, beta, eps):
     """x (...,C) bf16, delta same shape or None, gamma/beta (C) f32 -> (x + delta, LN(x + delta)) bf16."""
     _chk(x, torch.bfloat16, "x")
@@ -736,7 +773,7 @@ def have(name):
     if name not in _FUSED:
         sym = {"rpe_attention": "s6d_rpe_attention_f32", "geo_embedding": "s6d_geo_embedding_f32",
                "fine_assign": "s6d_fine_assign_f32", "fine_match": "s6d_fine_match_f32", "pem_pre": "s6d_pem_compact_cloud_f32", "coarse_sample": "s6d_coarse_sample_f32", "upsample_gather": "s6d_upsample_gather_f32",
-               "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "add_layernorm": "s6d_add_layernorm_bf16", "gemm_bf16": "s6d_gemm_bf16", "gemm_bf16_res": "s6d_gemm_bf16_res", "win_attention": "s6d_win_attention_layout_bf16",
+               "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "add_layernorm": "s6d_add_layernorm_bf16", "gemm_bf16": "s6d_gemm_bf16", "gemm_bf16_res": "s6d_gemm_bf16_res", "gemm_fp8": "s6d_gemm_fp8", "layernorm_fp8": "s6d_layernorm_fp8", "win_attention": "s6d_win_attention_layout_bf16",
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
                "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_frames_f32",

@@ -122,6 +122,24 @@ def _vit_forward_fused(self, x, taps):
     x = x.contiguous()
     delta = None
     out = []
+    from ..utils.linear import res_eligible
+    C = x.shape[-1]
+    if all(res_eligible(x, C, C) and res_eligible(x, C, blk.mlp.fc2.in_features) for blk in self.blocks):
+        # round 3: residual adds in the epilogues of the proj / fc2 GEMMs (in place), LayerNorms as one-read passes
+        x = x.clone()
+        scale = (C // self.blocks[0].attn.num_heads) ** -0.5
+        for i, blk in enumerate(self.blocks):
+            g, b = _ln_f32(blk.norm1)
+            _, h = ops.add_layernorm(x, None, g, b, blk.norm1.eps)
+            o = ops.seq_attention(fused_linear(blk.attn.qkv, h).contiguous(), blk.attn.num_heads, scale)
+            x = fused_linear(blk.attn.proj, o, residual=x)
+            g, b = _ln_f32(blk.norm2)
+            _, h = ops.add_layernorm(x, None, g, b, blk.norm2.eps)
+            x = fused_linear(blk.mlp.fc2, fused_linear(blk.mlp.fc1, h, gelu=True), residual=x)
+            if i in taps:
+                g, b = _ln_f32(self.norm)
+                out.append(ops.add_layernorm(x, None, g, b, self.norm.eps)[1])
+        return out
     for i, blk in enumerate(self.blocks):
         g, b = _ln_f32(blk.norm1)
         x, h = ops.add_layernorm(x, delta, g, b, blk.norm1.eps)

@@ -119,10 +119,16 @@ class Attention(nn.Module):
             self._s6d_attn_ops = c
         return c[1], c[2], c[3]
 
-    def forward(self, x, window_size=0, residual=None):
+    def forward(self, x, window_size=0, residual=None, qkv=None):
         """x: (B,H,W,C) token map (already normed).  window_size 0 = global attention.  residual: the block's shortcut -- the
-        result is then shortcut + attention, with the add in the proj GEMM's epilogue (written over `residual`)."""
+        result is then shortcut + attention, with the add in the proj GEMM's epilogue (written over `residual`).  qkv: the
+        (B,H,W,3C) projection when the caller has made it already (fp8 path: x is then only consulted for its shape)."""
         B, H, W, C = x.shape
+        if qkv is not None:
+            S = window_size if window_size > 0 else H
+            bias, rh, rw = self._kernel_operands(S, qkv.dtype)
+            out = ops.window_attention(qkv.contiguous(), bias, rh, rw, self.num_heads, window_size, self.scale)
+            return fused_linear(self.proj, out, residual=residual)
         fused = ops.have("win_attention") and x.is_cuda and x.dtype == torch.bfloat16 and self.use_rel_pos
         if fused:
             # S6D_QKV_LAYOUT=head: q / k / v head-major straight out of the GEMM's epilogue ((3 heads, B H W, hd): a head's rows of a
@@ -247,6 +253,8 @@ class ImageEncoderViT(nn.Module):
         from ..utils.linear import res_eligible
         x = x.contiguous()
         C = x.shape[-1]
+        if _gemm_mode() == "fp8":
+            return self._blocks_fp8(x, upto)
         if res_eligible(x, C, C) and all(res_eligible(x, C, blk.mlp.lin2.in_features) for blk in self.blocks):
             x = x.clone()                                        # the stream tensor is updated in place from here on
             for i, blk in enumerate(self.blocks):
@@ -270,6 +278,33 @@ class ImageEncoderViT(nn.Module):
             x, h = ops.add_layernorm(x, a.contiguous(), g, b, blk.norm2.eps)
             delta = blk.mlp(h).contiguous()
         return x if delta is None else x + delta
+
+    def _blocks_fp8(self, x, upto):
+        """BASELINE configs[4] (never the headline): the two LayerNorm-fed GEMMs of every block -- qkv (1280 -> 3840) and lin1
+        (1280 -> 5120, + GELU), 58 % of the encoder's GEMM FLOP -- on the fp8 matrix cores.  LayerNorm writes its output as e4m3
+        bytes with one power-of-two scale per token (s6d_layernorm_fp8: no extra pass), the weights carry one power-of-two scale
+        per output channel (utils/fp8.py), both ride in the matrix instruction's block-scale operands (s6d_gemm_fp8).  proj and
+        lin2 (their inputs come out of the attention kernel / the GELU epilogue in bf16, and a per-token scale needs the whole
+        row) stay bf16, as do attention, the residual stream and the neck."""
+        from ..utils import fp8
+        from ..utils.linear import res_eligible
+        C = x.shape[-1]
+        if not (ops.have("gemm_fp8") and ops.have("layernorm_fp8") and x.is_cuda and x.dtype == torch.bfloat16 and C % 256 == 0
+                and C % 128 == 0 and res_eligible(x, C, C)):
+            raise RuntimeError("S6D_SAM_GEMM=fp8 needs the fp8 kernels of libsam6d_hip.so, a bf16 device token map and C % 256 == 0")
+        x = x.clone()
+        for i, blk in enumerate(self.blocks):
+            if upto is not None and i >= upto:
+                break
+            g, b = self._ln_f32(blk.norm1)
+            h8, hs = ops.layernorm_fp8(x, g, b, blk.norm1.eps)
+            wq, ws, bq = fp8.cached_weight(blk.attn.qkv)
+            x = blk.attn(x, blk.window_size, residual=x, qkv=ops.gemm_fp8(h8, hs, wq, ws, bq))
+            g, b = self._ln_f32(blk.norm2)
+            h8, hs = ops.layernorm_fp8(x, g, b, blk.norm2.eps)
+            w1, s1, b1 = fp8.cached_weight(blk.mlp.lin1)
+            x = fused_linear(blk.mlp.lin2, ops.gemm_fp8(h8, hs, w1, s1, b1, gelu=True), residual=x)
+        return x
 
     def neck_nhwc(self, t):
         """neck (image_encoder.py:90-104) on the (B,H,W,C) token map, channels-last throughout:
@@ -307,6 +342,11 @@ class ImageEncoderViT(nn.Module):
                 t = self.forward_tokens(x.to(dt))
             return self.neck_nhwc(t.to(dt)).to(in_dtype)
         return self.neck_nhwc(self.forward_tokens(x)).to(in_dtype)
+
+
+def _gemm_mode():
+    """S6D_SAM_GEMM = bf16 (default, BASELINE configs[1]) | fp8 (configs[4]: qkv and lin1 on the fp8 matrix cores)."""
+    return os.environ.get("S6D_SAM_GEMM", "bf16")
 
 
 PIXEL_MEAN = (123.675, 116.28, 103.53)      # build_sam.py:95-96

@@ -360,6 +360,87 @@ static inline VC hipemu_mfma_32x32x16_bf16(VA a, VA b, VC c) {
 }
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipemu_mfma_32x32x16_bf16(a, b, c)
 
+// OCP fp8 e4m3fn: 1 sign, 4 exponent (bias 7), 3 mantissa bits; no infinities, S.1111.111 = NaN, max 448
+static inline float hipemu_e4m3_to_f(unsigned char v) {
+  const int s = v >> 7, e = (v >> 3) & 15, m = v & 7;
+  float f;
+  if (e == 15 && m == 7) f = NAN;
+  else if (e == 0) f = ldexpf((float)m, -9);
+  else f = ldexpf((float)(8 + m), e - 10);
+  return s ? -f : f;
+}
+static inline unsigned char hipemu_f_to_e4m3(float x) {      // round to nearest even, saturating at +-448
+  const unsigned char sgn = std::signbit(x) ? 0x80 : 0;
+  float a = fabsf(x);
+  if (std::isnan(a)) return sgn | 0x7f;
+  if (a >= 448.f) return sgn | 0x7e;
+  if (a < ldexpf(1.f, -10)) return sgn;                       // below half the smallest subnormal (2^-9): 0 (tie -> even = 0)
+  int e;
+  frexpf(a, &e);                                              // a = f * 2^e, f in [0.5, 1)
+  int E = e - 1;                                              // a = 1.xxx * 2^E
+  if (E < -6) E = -6;                                         // subnormal range: fixed exponent
+  const float q = ldexpf(1.f, E - 3);                         // spacing of representable values
+  float r = nearbyintf(a / q) * q;                            // nearbyint: round half to even in the default mode
+  if (r >= 448.f) return sgn | 0x7e;
+  if (r < ldexpf(1.f, -6)) return sgn | (unsigned char)nearbyintf(r / ldexpf(1.f, -9));
+  frexpf(r, &e);
+  E = e - 1;
+  const int m = (int)nearbyintf(r / ldexpf(1.f, E - 3)) - 8;
+  return sgn | (unsigned char)(((E + 7) << 3) | m);
+}
+// v_cvt_pk_fp8_f32 (gfx950: OCP e4m3fn, saturating): the two results go to the low or high 16 bits of `old`
+static inline int __builtin_amdgcn_cvt_pk_fp8_f32(float a, float b, int old, bool hi) {
+  const unsigned pk = (unsigned)hipemu_f_to_e4m3(a) | ((unsigned)hipemu_f_to_e4m3(b) << 8);
+  return hi ? (int)(((unsigned)old & 0x0000ffffu) | (pk << 16)) : (int)(((unsigned)old & 0xffff0000u) | pk);
+}
+
+// v_mfma_scale_f32_32x32x64_f8f6f4 with fp8 e4m3 operands (cbsz = blgp = 0): A lane l = row l%32, k block l/32 (32 consecutive
+// bytes); B alike; the scale operand's byte 0 is the E8M0 block scale of the lane's 32 elements: value = q * 2^(byte - 127).
+// C/D as the other 32x32 shapes.  (The true k order inside a lane's 32 bytes does not matter to a kernel that loads A and B
+// with the same map; here it is taken as consecutive.)
+typedef __attribute__((ext_vector_type(8))) int hipemu_i32x8;
+template <class VC>
+static inline VC hipemu_mfma_scale_32x32x64_f8(hipemu_i32x8 a, hipemu_i32x8 b, VC c, int fa, int fb, int sa, int sb) {
+  if (fa != 0 || fb != 0) {
+    std::fprintf(stderr, "hipemu: only fp8 e4m3 operands of the f8f6f4 MFMA are emulated\n");
+    std::abort();
+  }
+  struct OP {
+    unsigned char q[32];
+    int sc;
+  } mine;
+  const int l = hipemu::lane_of(), col = l & 31, hb = l >> 5;
+  float A[16][64];                                               // the 16 rows this lane's results need, descaled
+  std::memcpy(mine.q, &a, 32);
+  mine.sc = sa & 0xff;
+  hipemu::begin_exchange(mine, 11);
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * hb;
+    for (int blk = 0; blk < 2; ++blk) {
+      const OP o = hipemu::peek<OP>(row + 32 * blk);
+      for (int j = 0; j < 32; ++j) A[r][blk * 32 + j] = ldexpf(hipemu_e4m3_to_f(o.q[j]), o.sc - 127);
+    }
+  }
+  hipemu::end_exchange();
+  std::memcpy(mine.q, &b, 32);
+  mine.sc = sb & 0xff;
+  hipemu::begin_exchange(mine, 12);
+  float B[64];
+  for (int blk = 0; blk < 2; ++blk) {
+    const OP o = hipemu::peek<OP>(col + 32 * blk);
+    for (int j = 0; j < 32; ++j) B[blk * 32 + j] = ldexpf(hipemu_e4m3_to_f(o.q[j]), o.sc - 127);
+  }
+  hipemu::end_exchange();
+  VC d = c;
+  for (int r = 0; r < 16; ++r) {
+    float acc = c[r];
+    for (int k = 0; k < 64; ++k) acc += A[r][k] * B[k];
+    d[r] = acc;
+  }
+  return d;
+}
+#define __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, fa, fb, osa, sa, osb, sb) hipemu_mfma_scale_32x32x64_f8(a, b, c, fa, fb, sa, sb)
+
 // v_mfma_f32_16x16x4_f32: A lane l = row l%16, k = l/16; B lane l = column l%16, k = l/16; C/D as above
 template <class VC>
 static inline VC hipemu_mfma_16x16x4_f32(float a, float b, VC c) {

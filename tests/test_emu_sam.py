@@ -52,3 +52,31 @@ def test_mini_encoder_bf16_fused_path_on_the_emulator(emu, monkeypatch):
     assert len(called) == osam.MINI["depth"]                      # every block went through the fused attention kernel
     err = np.abs(y - g["mini_out"])
     assert err.mean() < 2e-2 and np.corrcoef(y.ravel(), g["mini_out"].ravel())[0, 1] > 0.999, (err.mean(), err.max())
+
+
+def test_residual_epilogue_block_loop_equals_the_round2_form(emu, monkeypatch):
+    """ImageEncoderViT._blocks_fused with the residual adds in the proj / lin2 GEMM epilogues (s6d_gemm_bf16_res, in place,
+    LayerNorms as one-read passes) against the round-2 form (adds folded into the following LayerNorm pass): BIT FOR BIT,
+    on a 2-block encoder with a windowed and a global block (dim 256 so that the 256 x 256-tile kernel takes every GEMM)."""
+    from functools import partial
+
+    import torch
+
+    from sam6d_amd.sam.image_encoder import ImageEncoderViT
+    from sam6d_amd.utils import seeded
+    m = ImageEncoderViT(depth=2, embed_dim=256, img_size=256, mlp_ratio=2, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6),
+                        num_heads=4, patch_size=16, qkv_bias=True, use_rel_pos=True, global_attn_indexes=(1,), window_size=7,
+                        out_chans=32).eval()
+    m = seeded.load_seeded(m, 4).bfloat16()
+    x = (0.5 * torch.randn(1, 16, 16, 256, generator=torch.Generator().manual_seed(1))).to(torch.bfloat16)
+    keep = x.clone()
+    calls = []
+    real = emu.gemm_bf16
+    monkeypatch.setattr(emu, "gemm_bf16", lambda *a, **k: (calls.append(k.get("residual") is not None), real(*a, **k))[1])
+    with torch.no_grad():
+        new = m._blocks_fused(x, None)
+        assert sum(calls) == 4 and torch.equal(x, keep)              # two residual GEMMs per block; the caller's tensor untouched
+        emu._FUSED["gemm_bf16_res"] = False
+        calls.clear()
+        old = m._blocks_fused(x, None)
+    assert sum(calls) == 0 and torch.equal(new, old)

@@ -30,7 +30,7 @@ extern "C" {
 
 /* Bumped whenever a signature in this header changes; the loader (sam6d_amd/_lib.py) refuses a library whose
  * s6d_version() differs from the header it was written against (a stale .so fails at load, not at a call). */
-#define S6D_ABI_VERSION 103
+#define S6D_ABI_VERSION 105
 int s6d_version(void);
 const char *s6d_strerror(int code);
 /* last HIP error string seen by this thread (empty if none) */
@@ -190,6 +190,10 @@ long s6d_win_attention_scratch_bytes(int H, int window, int head_dim);
  * ref: the residual adds and norm1/norm2 of Block.forward, segment_anything/modeling/image_encoder.py:166-182. */
 int s6d_add_layernorm_bf16(const void *x, const void *delta, const float *gamma, const float *beta, float eps,
                            long rows, int C, void *x_out, void *y_out, void *stream);
+/* LayerNorm of bf16 rows with an fp32 result (no residual): the last LayerNorm2d of the SAM neck, whose output is the image
+ * embedding handed to the mask decoder in float32 (segment_anything/modeling/common.py:31-43 applied channels-last). */
+int s6d_layernorm_bf16_f32(const void *x, const float *gamma, const float *beta, float eps, long rows, int C, float *y_f32,
+                           void *stream);
 
 /* C = epilogue(A W^T + bias): the nn.Linear layers of the ViTs with the bias and the activation folded into the GEMM.
  * A (M,K) bf16, row stride lda; W (N,K) bf16 = nn.Linear.weight, row stride ldw; bias (N) f32 or NULL; C (M,N) bf16, row
@@ -226,6 +230,9 @@ int s6d_gemm_fp8(const void *A, long lda, const unsigned char *a_scale, const vo
  * fp32 statistics, scale 2^e with the smallest e for which amax / 2^e <= 448, round to nearest even.  C % 8 == 0, C <= 2048. */
 int s6d_layernorm_fp8(const void *x, const float *gamma, const float *beta, float eps, long rows, int C, void *y8,
                       unsigned char *yscale, void *stream);
+/* The same with the residual add folded in (x_out = bf16(x + delta), then LayerNorm of x_out), as s6d_add_layernorm_bf16. */
+int s6d_add_layernorm_fp8(const void *x, const void *delta, const float *gamma, const float *beta, float eps, long rows, int C,
+                          void *x_out, void *y8, unsigned char *yscale, void *stream);
 
 /* ---------------------------------------------------------------- ISM proposal-vs-template scoring */
 

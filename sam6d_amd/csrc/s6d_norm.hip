@@ -22,7 +22,8 @@ template <int VEC>
 __global__ __launch_bounds__(256) void add_layernorm_kernel(const u16 *__restrict__ x, const u16 *__restrict__ delta,
                                                            const float *__restrict__ gamma,
                                                            const float *__restrict__ beta, float eps, long rows,
-                                                           int C, u16 *__restrict__ x_out, u16 *__restrict__ y_out) {
+                                                           int C, u16 *__restrict__ x_out, u16 *__restrict__ y_out,
+                                                           float *__restrict__ y_f32) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -74,6 +75,16 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const u16 *__restric
       const float4 b0 = *reinterpret_cast<const float4 *>(beta + ch * 8), b1 = *reinterpret_cast<const float4 *>(beta + ch * 8 + 4);
       const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
       const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      if (y_f32) {                                     // fp32 result (the SAM neck's last LayerNorm2d: the encoder's output)
+        float4 o0, o1;
+        o0.x = (v[i][0] - mean) * rstd * gg[0] + bb[0]; o0.y = (v[i][1] - mean) * rstd * gg[1] + bb[1];
+        o0.z = (v[i][2] - mean) * rstd * gg[2] + bb[2]; o0.w = (v[i][3] - mean) * rstd * gg[3] + bb[3];
+        o1.x = (v[i][4] - mean) * rstd * gg[4] + bb[4]; o1.y = (v[i][5] - mean) * rstd * gg[5] + bb[5];
+        o1.z = (v[i][6] - mean) * rstd * gg[6] + bb[6]; o1.w = (v[i][7] - mean) * rstd * gg[7] + bb[7];
+        *reinterpret_cast<float4 *>(y_f32 + row * C + ch * 8) = o0;
+        *reinterpret_cast<float4 *>(y_f32 + row * C + ch * 8 + 4) = o1;
+        continue;
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) o.h[e] = f2bf_((v[i][e] - mean) * rstd * gg[e] + bb[e]);
       *reinterpret_cast<uint4 *>(y_out + row * C + ch * 8) = o.u;
@@ -88,9 +99,11 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const u16 *__restric
 // scale byte = e + 127 (E8M0, the MX block-scale encoding the matrix instruction takes).  An all-zero row gets byte 127.
 // One wavefront per row, as add_layernorm_kernel.
 template <int VEC>
-__global__ __launch_bounds__(256) void layernorm_fp8_kernel(const u16 *__restrict__ x, const float *__restrict__ gamma,
+__global__ __launch_bounds__(256) void layernorm_fp8_kernel(const u16 *__restrict__ x, const u16 *__restrict__ delta,
+                                                           const float *__restrict__ gamma,
                                                            const float *__restrict__ beta, float eps, long rows, int C,
-                                                           unsigned char *__restrict__ y8, unsigned char *__restrict__ yscale) {
+                                                           u16 *__restrict__ x_out, unsigned char *__restrict__ y8,
+                                                           unsigned char *__restrict__ yscale) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -101,8 +114,14 @@ __global__ __launch_bounds__(256) void layernorm_fp8_kernel(const u16 *__restric
   for (int i = 0; i < VEC; ++i) {
     const int ch = lane + i * 64;
     if (ch < nchunk) {
-      union { uint4 u; u16 h[8]; } a;
+      union { uint4 u; u16 h[8]; } a, d;
       a.u = *reinterpret_cast<const uint4 *>(x + row * C + ch * 8);
+      if (delta) {                                      // residual add folded in, as add_layernorm_kernel
+        d.u = *reinterpret_cast<const uint4 *>(delta + row * C + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a.h[e] = f2bf_(bf2f_(a.h[e]) + bf2f_(d.h[e]));
+        if (x_out) *reinterpret_cast<uint4 *>(x_out + row * C + ch * 8) = a.u;
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         v[i][e] = bf2f_(a.h[e]);
@@ -172,17 +191,32 @@ __global__ __launch_bounds__(256) void layernorm_fp8_kernel(const u16 *__restric
 
 using namespace s6d;
 
+static int ln_launch(const void *x, const void *delta, const float *gamma, const float *beta, float eps, long rows, int C,
+                     void *x_out, void *y_out, float *y_f32, void *stream);
+
 extern "C" int s6d_add_layernorm_bf16(const void *x, const void *delta, const float *gamma, const float *beta,
                                       float eps, long rows, int C, void *x_out, void *y_out, void *stream) {
+  if (!y_out) return S6D_EINVAL;
+  return ln_launch(x, delta, gamma, beta, eps, rows, C, x_out, y_out, nullptr, stream);
+}
+
+extern "C" int s6d_layernorm_bf16_f32(const void *x, const float *gamma, const float *beta, float eps, long rows, int C,
+                                      float *y_f32, void *stream) {
+  if (!y_f32) return S6D_EINVAL;
+  return ln_launch(x, nullptr, gamma, beta, eps, rows, C, nullptr, nullptr, y_f32, stream);
+}
+
+static int ln_launch(const void *x, const void *delta, const float *gamma, const float *beta, float eps, long rows, int C,
+                     void *x_out, void *y_out, float *y_f32, void *stream) {
   if (rows < 0 || C <= 0 || (C % 8) != 0) return S6D_EINVAL;
   if (rows == 0) return S6D_OK;
-  if (!x || !gamma || !beta || !y_out || (delta && !x_out)) return S6D_EINVAL;
+  if (!x || !gamma || !beta || (delta && !x_out)) return S6D_EINVAL;
   const unsigned grid = (unsigned)((rows + 3) / 4);
   const int nchunk = C / 8;
   hipStream_t st = as_stream(stream);
 #define S6D_LN(V)                                                                                              \
   hipLaunchKernelGGL((add_layernorm_kernel<V>), dim3(grid), dim3(256), 0, st, (const u16 *)x, (const u16 *)delta, \
-                     gamma, beta, eps, rows, C, (u16 *)x_out, (u16 *)y_out)
+                     gamma, beta, eps, rows, C, (u16 *)x_out, (u16 *)y_out, y_f32)
   if (nchunk <= 64) S6D_LN(1);
   else if (nchunk <= 128) S6D_LN(2);
   else if (nchunk <= 192) S6D_LN(3);
@@ -192,17 +226,25 @@ extern "C" int s6d_add_layernorm_bf16(const void *x, const void *delta, const fl
   return launch_status();
 }
 
+extern "C" int s6d_add_layernorm_fp8(const void *x, const void *delta, const float *gamma, const float *beta, float eps, long rows,
+                                     int C, void *x_out, void *y8, unsigned char *yscale, void *stream);
+
 extern "C" int s6d_layernorm_fp8(const void *x, const float *gamma, const float *beta, float eps, long rows, int C, void *y8,
                                  unsigned char *yscale, void *stream) {
+  return s6d_add_layernorm_fp8(x, nullptr, gamma, beta, eps, rows, C, nullptr, y8, yscale, stream);
+}
+
+extern "C" int s6d_add_layernorm_fp8(const void *x, const void *delta, const float *gamma, const float *beta, float eps, long rows,
+                                     int C, void *x_out, void *y8, unsigned char *yscale, void *stream) {
   if (rows < 0 || C <= 0 || (C % 8) != 0) return S6D_EINVAL;
   if (rows == 0) return S6D_OK;
-  if (!x || !gamma || !beta || !y8 || !yscale) return S6D_EINVAL;
+  if (!x || !gamma || !beta || !y8 || !yscale || (delta && !x_out)) return S6D_EINVAL;
   const unsigned grid = (unsigned)((rows + 3) / 4);
   const int nchunk = C / 8;
   hipStream_t st = as_stream(stream);
 #define S6D_LN8(V)                                                                                              \
-  hipLaunchKernelGGL((layernorm_fp8_kernel<V>), dim3(grid), dim3(256), 0, st, (const u16 *)x, gamma, beta, eps, rows, C, \
-                     (unsigned char *)y8, yscale)
+  hipLaunchKernelGGL((layernorm_fp8_kernel<V>), dim3(grid), dim3(256), 0, st, (const u16 *)x, (const u16 *)delta, gamma, beta, \
+                     eps, rows, C, (u16 *)x_out, (unsigned char *)y8, yscale)
   if (nchunk <= 64) S6D_LN8(1);
   else if (nchunk <= 128) S6D_LN8(2);
   else if (nchunk <= 192) S6D_LN8(3);

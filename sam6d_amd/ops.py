@@ -553,8 +553,9 @@ def gemm_fp8(a8, a_scale, w8, w_scale, bias=None, gelu=False, max_blocks=0):
     return out.reshape(*a8.shape[:-1], N)
 
 
-def layernorm_fp8(x, gamma, beta, eps):
-    """x (..., C) bf16 -> (LN(x) as e4m3fn bytes (..., C) uint8, one E8M0 scale byte per row (rows,) uint8)."""
+def layernorm_fp8(x, gamma, beta, eps, delta=None):
+    """x (..., C) bf16 -> (LN(x) as e4m3fn bytes (..., C) uint8, one E8M0 scale byte per row (rows,) uint8).
+    delta (same shape, bf16): -> (x + delta, bytes, scales) with the residual add folded in, as add_layernorm."""
     _chk(x, torch.bfloat16, "x")
     _chk(gamma, torch.float32, "gamma", 1)
     _chk(beta, torch.float32, "beta", 1)
@@ -562,9 +563,27 @@ def layernorm_fp8(x, gamma, beta, eps):
     rows = x.numel() // C
     y8 = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
     ys = torch.empty(rows, dtype=torch.uint8, device=x.device)
-    _call("s6d_layernorm_fp8", _ptr(x), _ptr(gamma), _ptr(beta), ctypes.c_float(eps), ctypes.c_long(rows), int(C), _ptr(y8), _ptr(ys),
-          _stream())
-    return y8, ys
+    if delta is None:
+        _call("s6d_layernorm_fp8", _ptr(x), _ptr(gamma), _ptr(beta), ctypes.c_float(eps), ctypes.c_long(rows), int(C), _ptr(y8),
+              _ptr(ys), _stream())
+        return y8, ys
+    _chk(delta, torch.bfloat16, "delta")
+    xo = torch.empty_like(x)
+    _call("s6d_add_layernorm_fp8", _ptr(x), _ptr(delta), _ptr(gamma), _ptr(beta), ctypes.c_float(eps), ctypes.c_long(rows), int(C),
+          _ptr(xo), _ptr(y8), _ptr(ys), _stream())
+    return xo, y8, ys
+
+
+def layernorm_f32out(x, gamma, beta, eps):
+    """x (..., C) bf16 -> LN(x) (..., C) float32 (fp32 statistics, no rounding of the result)."""
+    _chk(x, torch.bfloat16, "x")
+    _chk(gamma, torch.float32, "gamma", 1)
+    _chk(beta, torch.float32, "beta", 1)
+    C = x.shape[-1]
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _call("s6d_layernorm_bf16_f32", _ptr(x), _ptr(gamma), _ptr(beta), ctypes.c_float(eps), ctypes.c_long(x.numel() // C), int(C),
+          _ptr(y), _stream())
+    return y
 
 
 def add_layernorm(x, delta, gamma, beta, eps):
@@ -773,7 +792,7 @@ def have(name):
     if name not in _FUSED:
         sym = {"rpe_attention": "s6d_rpe_attention_f32", "geo_embedding": "s6d_geo_embedding_f32",
                "fine_assign": "s6d_fine_assign_f32", "fine_match": "s6d_fine_match_f32", "pem_pre": "s6d_pem_compact_cloud_f32", "coarse_sample": "s6d_coarse_sample_f32", "upsample_gather": "s6d_upsample_gather_f32",
-               "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "add_layernorm": "s6d_add_layernorm_bf16", "gemm_bf16": "s6d_gemm_bf16", "gemm_bf16_res": "s6d_gemm_bf16_res", "gemm_fp8": "s6d_gemm_fp8", "layernorm_fp8": "s6d_layernorm_fp8", "win_attention": "s6d_win_attention_layout_bf16",
+               "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "add_layernorm": "s6d_add_layernorm_bf16", "gemm_bf16": "s6d_gemm_bf16", "gemm_bf16_res": "s6d_gemm_bf16_res", "gemm_fp8": "s6d_gemm_fp8", "layernorm_fp8": "s6d_layernorm_fp8", "layernorm_f32out": "s6d_layernorm_bf16_f32", "win_attention": "s6d_win_attention_layout_bf16",
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
                "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_frames_f32",

@@ -287,24 +287,26 @@ class ImageEncoderViT(nn.Module):
         lin2 (their inputs come out of the attention kernel / the GELU epilogue in bf16, and a per-token scale needs the whole
         row) stay bf16, as do attention, the residual stream and the neck."""
         from ..utils import fp8
-        from ..utils.linear import res_eligible
         C = x.shape[-1]
-        if not (ops.have("gemm_fp8") and ops.have("layernorm_fp8") and x.is_cuda and x.dtype == torch.bfloat16 and C % 256 == 0
-                and C % 128 == 0 and res_eligible(x, C, C)):
+        if not (ops.have("gemm_fp8") and ops.have("layernorm_fp8") and x.is_cuda and x.dtype == torch.bfloat16 and C % 256 == 0):
             raise RuntimeError("S6D_SAM_GEMM=fp8 needs the fp8 kernels of libsam6d_hip.so, a bf16 device token map and C % 256 == 0")
-        x = x.clone()
+        delta = None
         for i, blk in enumerate(self.blocks):
             if upto is not None and i >= upto:
                 break
+            # each residual add folded into the following quantising LayerNorm pass, as in the bf16 loop
             g, b = self._ln_f32(blk.norm1)
-            h8, hs = ops.layernorm_fp8(x, g, b, blk.norm1.eps)
+            if delta is None:
+                h8, hs = ops.layernorm_fp8(x, g, b, blk.norm1.eps)
+            else:
+                x, h8, hs = ops.layernorm_fp8(x, g, b, blk.norm1.eps, delta=delta)
             wq, ws, bq = fp8.cached_weight(blk.attn.qkv)
-            x = blk.attn(x, blk.window_size, residual=x, qkv=ops.gemm_fp8(h8, hs, wq, ws, bq))
+            a = blk.attn(x, blk.window_size, qkv=ops.gemm_fp8(h8, hs, wq, ws, bq))
             g, b = self._ln_f32(blk.norm2)
-            h8, hs = ops.layernorm_fp8(x, g, b, blk.norm2.eps)
+            x, h8, hs = ops.layernorm_fp8(x, g, b, blk.norm2.eps, delta=a.contiguous())
             w1, s1, b1 = fp8.cached_weight(blk.mlp.lin1)
-            x = fused_linear(blk.mlp.lin2, ops.gemm_fp8(h8, hs, w1, s1, b1, gelu=True), residual=x)
-        return x
+            delta = fused_linear(blk.mlp.lin2, ops.gemm_fp8(h8, hs, w1, s1, b1, gelu=True)).contiguous()
+        return x if delta is None else x + delta
 
     def neck_nhwc(self, t):
         """neck (image_encoder.py:90-104) on the (B,H,W,C) token map, channels-last throughout:
@@ -314,14 +316,23 @@ class ImageEncoderViT(nn.Module):
         B, H, W, C = t.shape
         dt = t.dtype
         y = fused_linear(c1, t, weight2d=c1.weight.flatten(1))
-        y = F.layer_norm(y.float(), (y.shape[-1],), n1.weight.float(), n1.bias.float(), n1.eps).to(dt)
+        kern = y.is_cuda and dt == torch.bfloat16 and ops.have("add_layernorm") and ops.have("layernorm_f32out") and y.shape[-1] % 8 == 0
+        if kern:                                                            # LayerNorm2d = LN over the channel (last) dim: one kernel pass
+            g, b = self._ln_f32(n1)
+            y = ops.add_layernorm(y.contiguous(), None, g, b, n1.eps)[1]
+        else:
+            y = F.layer_norm(y.float(), (y.shape[-1],), n1.weight.float(), n1.bias.float(), n1.eps).to(dt)
         Co = y.shape[-1]
         yp = F.pad(y, (0, 0, 1, 1, 1, 1))                                   # zero pad H and W by 1
         if y.is_cuda and dt == torch.bfloat16 and ops.have("gemm_bf16") and (9 * Co) % 64 == 0 and c3.weight.shape[0] % 128 == 0:
             # the 3x3 convolution as ONE GEMM over K = 9 Ci (the nine shifted views side by side, weight in (dy, dx, ci) order):
             # fp32 accumulation over all taps inside the kernel instead of nine bf16 partial products summed in fp32 passes
             cols = torch.cat([yp[:, dy:dy + H, dx:dx + W, :] for dy in range(3) for dx in range(3)], dim=-1)
-            acc = fused_linear(c3, cols, weight2d=c3.weight.permute(0, 2, 3, 1).reshape(c3.weight.shape[0], -1)).float()
+            acc = fused_linear(c3, cols, weight2d=c3.weight.permute(0, 2, 3, 1).reshape(c3.weight.shape[0], -1))
+            if kern:                                                        # bf16 GEMM output -> fp32 embedding, statistics in fp32
+                g, b = self._ln_f32(n2)
+                return ops.layernorm_f32out(acc.contiguous(), g, b, n2.eps).permute(0, 3, 1, 2)
+            acc = acc.float()
         else:
             w = c3.weight.to(dt)                                            # (Co, Ci, 3, 3)
             acc = None

@@ -31,8 +31,13 @@ def eligible(x, n_out, k_in):
 
 
 def res_eligible(x, n_out, k_in):
-    """The residual-add epilogue (s6d_gemm_bf16_res): the 256 x 256-tile kernel only.  S6D_DISABLE_FUSED=gemm_bf16_res: A/B runs."""
-    return eligible(x, n_out, k_in) and n_out % 256 == 0 and ops.have("gemm_bf16_res")
+    """The residual-add epilogue (s6d_gemm_bf16_res): the 256 x 256-tile kernel only.  OFF unless S6D_GEMM_RES=1 -- measured on the
+    MI355X (profiles/r03_gemm_residual_epilogue.txt): the epilogue's residual loads sit behind the tile's own stores in the one
+    in-order memory counter (proj + 24 %, lin2 + 8..14 % per launch) and that eats what the one-read LayerNorm saves (26 us of
+    106): 146.0 against 145.3 frames/s, i.e. nothing.  The fp8 block loop (configs[4]) uses it, its LayerNorm being a different
+    kernel anyway."""
+    return (eligible(x, n_out, k_in) and n_out % 256 == 0 and ops.have("gemm_bf16_res")
+            and os.environ.get("S6D_GEMM_RES", "0") == "1")
 
 
 def fused_linear(lin, x, gelu=False, weight2d=None, col_block=0, residual=None):

@@ -70,6 +70,7 @@ def test_residual_epilogue_block_loop_equals_the_round2_form(emu, monkeypatch):
     m = seeded.load_seeded(m, 4).bfloat16()
     x = (0.5 * torch.randn(1, 16, 16, 256, generator=torch.Generator().manual_seed(1))).to(torch.bfloat16)
     keep = x.clone()
+    monkeypatch.setenv("S6D_GEMM_RES", "1")
     calls = []
     real = emu.gemm_bf16
     monkeypatch.setattr(emu, "gemm_bf16", lambda *a, **k: (calls.append(k.get("residual") is not None), real(*a, **k))[1])

@@ -26,9 +26,12 @@ def test_row_quantiser_roundtrip_properties():
                                                     (700, 512, 256, True, True, 8), (1280, 768, 128, True, False, 8),
                                                     (65536, 3840, 1280, True, False, 0), (8192, 5120, 1280, True, True, 0)])
 def test_gemm_fp8_vs_float_on_the_quantised_operands(M, N, K, bias, gelu, blocks):
-    """s6d_gemm_fp8 == act(dequant(A) @ dequant(W)^T + bias) in float32 (exact products of e4m3 values, fp32 accumulation),
-    rounded to bf16: the only differences are the accumulation order and one bf16 rounding.  Rows with scales 2^-20 .. 2^20
-    check that the per-token / per-channel scales reach the right rows through the instruction's scale operands."""
+    """s6d_gemm_fp8 == act(dequant(A) @ dequant(W)^T + bias) (exact products of e4m3 values), rounded to bf16, up to the matrix
+    instruction's accumulation: measured on the MI355X (tools/probes/fp8_gemm_diag.py, profiles/r03_fp8_gemm_diag.txt) the
+    block-scaled instruction is EXACT on small-integer operands with arbitrary power-of-two row scales (operand layout and scale
+    routing) and within 6.5e-6 of sum |a||w| on random operands -- its 64-term sums are aligned to the block's largest product
+    with about 17 bits, not carried in full fp32.  Tolerance: one bf16 rounding + 2^-16 of sum |a||w|.  Rows with scales
+    2^-20 .. 2^20 check that the per-token / per-channel scales reach the right rows through the scale operands."""
     from sam6d_amd import ops
     if not torch.cuda.is_available() and M > 2000:
         pytest.skip("emulator: small shapes only")
@@ -51,7 +54,7 @@ def test_gemm_fp8_vs_float_on_the_quantised_operands(M, N, K, bias, gelu, blocks
     ref = ref.float()
     err = (out.float().cpu()[rows] - ref).abs()
     scale = (fp8.dequantize_rows(qa[rows], sa[rows]).abs().double() @ fp8.dequantize_rows(qw, sw).abs().double().t()).float()
-    tol = 2.0 ** -8 * ref.abs() + 2e-6 * scale + 1e-30        # one bf16 rounding + fp32 accumulation noise
+    tol = 2.0 ** -8 * ref.abs() + 2.0 ** -16 * scale + 1e-30    # one bf16 rounding + the instruction's block-sum precision
     assert (err <= tol * 1.01 + (1e-5 if gelu else 0)).all(), (err / tol).max().item()
 
 

@@ -30,7 +30,7 @@ extern "C" {
 
 /* Bumped whenever a signature in this header changes; the loader (sam6d_amd/_lib.py) refuses a library whose
  * s6d_version() differs from the header it was written against (a stale .so fails at load, not at a call). */
-#define S6D_ABI_VERSION 105
+#define S6D_ABI_VERSION 106
 int s6d_version(void);
 const char *s6d_strerror(int code);
 /* last HIP error string seen by this thread (empty if none) */
@@ -289,6 +289,19 @@ int s6d_project_bbox_frames_f32(const float *pointcloud, const float *poses, con
  * SinusoidalPositionalEmbedding.forward :263-281. */
 int s6d_geo_embedding_f32(const float *idx4, long NP, const float *Wd, const float *bd, const float *Wa,
                           const float *ba, const float *div_term, int C, int K, float *out, void *stream);
+
+/* Fused fp32 Linear of the point transformer:  y = LN( res + act( x W^T + b ) )  with every stage optional.
+ * x (M,K) f32 row stride ldx; W given as its bf16 hi / lo parts (N,K) each, made once per weight version by
+ * s6d_linear_split_weight_f32 (w = hi + lo up to 2^-17 relative); bias (N) or NULL; act 0 = none, 1 = ReLU; res (M,N) f32
+ * row stride ldr or NULL; gamma / beta (N) = LayerNorm over the N outputs with eps, or both NULL (N == 256 when given);
+ * y (M,N) f32 row stride ldy.  K % 32 == 0, N % 256 == 0, strides % 4 == 0, 16-byte aligned pointers.  fp32-class products on the
+ * bf16 matrix cores (3-term split), fp32 epilogue.
+ * ref: the nn.Linear / ReLU / residual / nn.LayerNorm statements of Pose_Estimation_Model/model/transformer.py:93-148 (proj_q/k/v),
+ * :182-197 (AttentionOutput), :200-224 and :572-590 (linear + residual + norm), coarse_/fine_point_matching.py in_proj / out_proj. */
+int s6d_linear_f32(const float *x, long ldx, int M, int K, const void *w_hi, const void *w_lo, const float *bias, int N, int act,
+                   const float *res, long ldr, const float *gamma, const float *beta, float eps, float *y, long ldy,
+                   void *stream);
+int s6d_linear_split_weight_f32(const float *w, long n, void *hi, void *lo, void *stream);
 
 /* Soft-assignment head of compute_fine_Rt (Pose_Estimation_Model/utils/model_utils.py:262-270), fused.
  * atten (B,M1,M2) f32 similarity / temp (row 0 / col 0 = background token), pts2 (B,M2-1,3) f32 ->

@@ -574,6 +574,46 @@ def layernorm_fp8(x, gamma, beta, eps, delta=None):
     return xo, y8, ys
 
 
+def split_weight(w):
+    """W (N,K) f32 -> (hi, lo) bf16 parts for linear_f32 (W = hi + lo up to 2^-17 relative)."""
+    _chk(w, torch.float32, "w")
+    hi = torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
+    lo = torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
+    _call("s6d_linear_split_weight_f32", _ptr(w), ctypes.c_long(w.numel()), _ptr(hi), _ptr(lo), _stream())
+    return hi, lo
+
+
+def linear_f32(x, w_hi, w_lo, bias=None, relu=False, residual=None, ln=None):
+    """y = LN(residual + act(x W^T + bias)) in one kernel: x (..., K) f32, (w_hi, w_lo) = split_weight(W (N,K)), bias (N) or None,
+    residual (..., N) or None, ln = (gamma, beta, eps) or None (N == 256).  K % 32 == 0, N % 256 == 0."""
+    _chk(x, torch.float32, "x")
+    N, K = w_hi.shape
+    if x.shape[-1] != K:
+        raise ValueError(f"x has {x.shape[-1]} columns, W {K}")
+    x2 = x.reshape(-1, K)
+    M = x2.shape[0]
+    y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    r2 = None
+    if residual is not None:
+        _chk(residual, torch.float32, "residual")
+        r2 = residual.reshape(-1, N)
+        if r2.shape[0] != M:
+            raise ValueError("residual rows != x rows")
+    g = bt = None
+    eps = 0.0
+    if ln is not None:
+        g, bt, eps = ln
+        _chk(g, torch.float32, "gamma", 1)
+        _chk(bt, torch.float32, "beta", 1)
+    if bias is not None:
+        _chk(bias, torch.float32, "bias", 1)
+    _call("s6d_linear_f32", _ptr(x2), ctypes.c_long(x2.stride(0)), M, K, _ptr(w_hi), _ptr(w_lo), _ptr(bias) if bias is not None else _vp(0),
+          N, 1 if relu else 0, _ptr(r2) if r2 is not None else _vp(0), ctypes.c_long(r2.stride(0) if r2 is not None else 0),
+          _ptr(g) if g is not None else _vp(0), _ptr(bt) if bt is not None else _vp(0), ctypes.c_float(eps), _ptr(y), ctypes.c_long(N),
+          _stream())
+    return y.reshape(*x.shape[:-1], N)
+
+
 def layernorm_f32out(x, gamma, beta, eps):
     """x (..., C) bf16 -> LN(x) (..., C) float32 (fp32 statistics, no rounding of the result)."""
     _chk(x, torch.bfloat16, "x")
@@ -792,7 +832,7 @@ def have(name):
     if name not in _FUSED:
         sym = {"rpe_attention": "s6d_rpe_attention_f32", "geo_embedding": "s6d_geo_embedding_f32",
                "fine_assign": "s6d_fine_assign_f32", "fine_match": "s6d_fine_match_f32", "pem_pre": "s6d_pem_compact_cloud_f32", "coarse_sample": "s6d_coarse_sample_f32", "upsample_gather": "s6d_upsample_gather_f32",
-               "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "add_layernorm": "s6d_add_layernorm_bf16", "gemm_bf16": "s6d_gemm_bf16", "gemm_bf16_res": "s6d_gemm_bf16_res", "gemm_fp8": "s6d_gemm_fp8", "layernorm_fp8": "s6d_layernorm_fp8", "layernorm_f32out": "s6d_layernorm_bf16_f32", "win_attention": "s6d_win_attention_layout_bf16",
+               "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "add_layernorm": "s6d_add_layernorm_bf16", "gemm_bf16": "s6d_gemm_bf16", "gemm_bf16_res": "s6d_gemm_bf16_res", "gemm_fp8": "s6d_gemm_fp8", "layernorm_fp8": "s6d_layernorm_fp8", "layernorm_f32out": "s6d_layernorm_bf16_f32", "linear_f32": "s6d_linear_f32", "win_attention": "s6d_win_attention_layout_bf16",
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
                "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_frames_f32",

@@ -21,6 +21,44 @@ from .. import ops
 HEADS = 4
 
 
+def _plin_weights(owner, lins):
+    """(w_hi, w_lo, bias) of one or several nn.Linear with the same input, stacked along the output dim, in the operand format
+    of s6d_linear_f32 (bf16 hi / lo parts of the fp32 weight); cached on `owner` until a parameter changes."""
+    key = tuple((l.weight._version, l.weight.data_ptr(), l.bias._version if l.bias is not None else -1) for l in lins)
+    name = "_s6d_plin_" + "_".join(str(id(l)) for l in lins)
+    c = owner.__dict__.get(name)
+    if c is None or c[0] != key:
+        with torch.no_grad():
+            w = torch.cat([l.weight.detach().float() for l in lins], 0).contiguous()
+            b = torch.cat([l.bias.detach().float() if l.bias is not None else w.new_zeros(l.weight.shape[0]) for l in lins]).contiguous()
+            hi, lo = ops.split_weight(w)
+        c = (key, hi, lo, b)
+        owner.__dict__[name] = c
+    return c[1], c[2], c[3]
+
+
+def plinear(owner, lins, x, relu=False, residual=None, norm=None):
+    """norm(residual + act(Linear(x))) for the 256-wide fp32 layers: ONE launch of s6d_linear_f32 (split-bf16 matrix cores, fused
+    epilogue) when the shapes fit, the library statements otherwise.  `lins`: one nn.Linear or a tuple sharing the input (their
+    outputs come back concatenated: q | k | v in one launch).  S6D_DISABLE_FUSED=linear_f32 selects the library path."""
+    lins = lins if isinstance(lins, (tuple, list)) else (lins,)
+    N = sum(l.weight.shape[0] for l in lins)
+    K = lins[0].weight.shape[1]
+    if (ops.have("linear_f32") and x.is_cuda and x.dtype == torch.float32 and K % 32 == 0 and N % 256 == 0
+            and (norm is None or N == 256) and not torch.is_grad_enabled()):
+        hi, lo, b = _plin_weights(owner, lins)
+        x2 = x if x.stride(-1) == 1 and x.is_contiguous() else x.contiguous()
+        r2 = None if residual is None else residual.contiguous()
+        ln = None if norm is None else (norm.weight.detach(), norm.bias.detach(), norm.eps)
+        return ops.linear_f32(x2, hi, lo, b, relu=relu, residual=r2, ln=ln)
+    y = torch.cat([l(x) for l in lins], dim=-1) if len(lins) > 1 else lins[0](x)
+    if relu:
+        y = F.relu(y)
+    if residual is not None:
+        y = y + residual
+    return y if norm is None else norm(y)
+
+
 def _split(x):  # (B,N,C) -> (B,h,N,c)
     B, N, C = x.shape
     return x.view(B, N, HEADS, C // HEADS).transpose(1, 2)
@@ -41,7 +79,7 @@ class AttentionOutput(nn.Module):
         self.norm = nn.LayerNorm(d_model)
 
     def forward(self, x):
-        return self.norm(x + self.squeeze(F.relu(self.expand(x))))
+        return plinear(self, self.squeeze, plinear(self, self.expand, x, relu=True), residual=x, norm=self.norm)
 
 
 class MultiHeadAttention(nn.Module):
@@ -56,7 +94,14 @@ class MultiHeadAttention(nn.Module):
 
     def forward(self, xq, xk, xv):
         if ops.have("mha") and xq.is_cuda and xq.shape[-1] == 256:
-            return ops.mha(self.proj_q(xq), self.proj_k(xk), self.proj_v(xv), self.scale)
+            C = xq.shape[-1]
+            q = plinear(self, self.proj_q, xq)
+            if xk is xv:                                              # k | v of the memory in one launch
+                kv = plinear(self, (self.proj_k, self.proj_v), xk)
+                k, v = kv[..., :C].contiguous(), kv[..., C:].contiguous()
+            else:
+                k, v = plinear(self, self.proj_k, xk), plinear(self, self.proj_v, xv)
+            return ops.mha(q, k, v, self.scale)
         q, k, v = _split(self.proj_q(xq)), _split(self.proj_k(xk)), _split(self.proj_v(xv))
         a = torch.softmax((q @ k.transpose(-1, -2)) * self.scale, dim=-1)
         return _merge(a @ v)
@@ -76,7 +121,8 @@ class RPEMultiHeadAttention(nn.Module):
 
     def forward(self, x, embed):
         B, N, C = x.shape
-        q, k, v = self.proj_q(x), self.proj_k(x), self.proj_v(x)
+        qkv = plinear(self, (self.proj_q, self.proj_k, self.proj_v), x)         # q | k | v in one launch
+        q, k, v = qkv[..., :C].contiguous(), qkv[..., C:2 * C].contiguous(), qkv[..., 2 * C:].contiguous()
         c = C // HEADS
         # q~[b,h,n,:] = W_p[h]^T q[b,h,n,:]   (B,h,N,C);   qb[b,h,n] = q[b,h,n,:] . b_p[h,:]
         qh = _split(q)
@@ -102,7 +148,7 @@ class AttentionLayer(_AttnLayerBase):
         super().__init__(MultiHeadAttention(d_model), d_model)
 
     def forward(self, x, mem):
-        return self.norm(self.linear(self.attention(x, mem, mem)) + x)
+        return plinear(self, self.linear, self.attention(x, mem, mem), residual=x, norm=self.norm)
 
 
 class RPEAttentionLayer(_AttnLayerBase):
@@ -110,7 +156,7 @@ class RPEAttentionLayer(_AttnLayerBase):
         super().__init__(RPEMultiHeadAttention(d_model), d_model)
 
     def forward(self, x, embed):
-        return self.norm(self.linear(self.attention(x, embed)) + x)
+        return plinear(self, self.linear, self.attention(x, embed), residual=x, norm=self.norm)
 
 
 class TransformerLayer(nn.Module):
@@ -174,9 +220,11 @@ class LinearAttention(nn.Module):
             focus = lambda t: ops.linear_attn_focus(t, inv_scale, self.focusing_factor)   # noqa: E731  one fused pass
         else:
             focus = lambda t: self._focus(t, inv_scale)                                    # noqa: E731
-        q = _split(focus(self.proj_q(xq)))                           # (B,h,I,c)
-        k = _split(focus(self.proj_k(xkv)))                          # (B,h,J,c)
-        v = _split(self.proj_v(xkv))
+        C = xq.shape[-1]
+        kv_ = plinear(self, (self.proj_k, self.proj_v), xkv)         # k | v of the memory in one launch
+        q = _split(focus(plinear(self, self.proj_q, xq)))            # (B,h,I,c)
+        k = _split(focus(kv_[..., :C].contiguous()))                 # (B,h,J,c)
+        v = _split(kv_[..., C:])
         z = 1.0 / (q @ k.sum(dim=2).unsqueeze(-1) + 1e-6)            # (B,h,I,1)
         kv = k.transpose(-1, -2) @ v                                 # (B,h,c,d)
         return _merge((q @ kv) * z)
@@ -190,7 +238,7 @@ class LinearAttentionLayer(nn.Module):
         self.norm = nn.LayerNorm(d_model)
 
     def forward(self, x, mem):
-        return self.norm(self.linear(self.attention(x, mem)) + x)
+        return plinear(self, self.linear, self.attention(x, mem), residual=x, norm=self.norm)
 
 
 class LinearTransformerLayer(nn.Module):

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from .feature_extraction import ViTEncoder
-from .layers import GeometricStructureEmbedding, GeometricTransformer, SparseToDenseTransformer
+from .layers import GeometricStructureEmbedding, GeometricTransformer, SparseToDenseTransformer, plinear
 from .solvers import coarse_Rt, fine_Rt
 
 
@@ -52,11 +52,11 @@ class CoarsePointMatching(nn.Module):
     def forward(self, p1, f1, geo1, p2, f2, geo2, radius, end_points):
         B = f1.size(0)
         bg = self.bg_token.expand(B, -1, -1)
-        f1 = torch.cat([bg, self.in_proj(f1)], dim=1)
-        f2 = torch.cat([bg, self.in_proj(f2)], dim=1)
+        f1 = torch.cat([bg, plinear(self, self.in_proj, f1)], dim=1)
+        f2 = torch.cat([bg, plinear(self, self.in_proj, f2)], dim=1)
         for blk in self.transformers:
             f1, f2 = blk(f1, geo1, f2, geo2)
-        atten = feature_similarity(self.out_proj(f1), self.out_proj(f2), self.cfg.temp)
+        atten = feature_similarity(plinear(self, self.out_proj, f1), plinear(self, self.out_proj, f2), self.cfg.temp)
         n1 = self.cfg.nproposal1
         rand_u = end_points.get("coarse_rand_u")
         if rand_u is None:
@@ -149,11 +149,11 @@ class FinePointMatching(nn.Module):
         init_R, init_t = end_points["init_R"], end_points["init_t"]
         p1_ = (p1 - init_t.unsqueeze(1)) @ init_R
         bg = self.bg_token.expand(B, -1, -1)
-        f1 = torch.cat([bg, self.in_proj(f1) + self.PE(p1_)], dim=1)
-        f2 = torch.cat([bg, self.in_proj(f2) + self.PE(p2)], dim=1)
+        f1 = torch.cat([bg, plinear(self, self.in_proj, f1, residual=self.PE(p1_))], dim=1)
+        f2 = torch.cat([bg, plinear(self, self.in_proj, f2, residual=self.PE(p2))], dim=1)
         for blk in self.transformers:
             f1, f2 = blk(f1, geo1, fps_idx1, f2, geo2, fps_idx2)
-        o1, o2 = self.out_proj(f1), self.out_proj(f2)
+        o1, o2 = plinear(self, self.out_proj, f1), plinear(self, self.out_proj, f2)
         model = end_points["model"] / (radius.reshape(-1, 1, 1) + 1e-6)
         if ops.have("fine_match") and o1.is_cuda and o1.dtype == torch.float32 and o1.shape[2] == 256:
             # similarity tiles are formed inside the assignment kernel: the (B,2049,2049) matrix is never written

@@ -1,0 +1,68 @@
+"""Fused fp32 Linear of the PEM point transformer (s6d_linear_f32: split-bf16 matrix cores + bias / ReLU / residual / LayerNorm
+epilogue) against the library statements in float64."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # M, K, N, bias, relu, residual, layernorm
+    (100, 256, 256, True, False, False, False),       # ragged M (two row tiles, one partial)
+    (64, 256, 256, False, False, False, False),
+    (197, 256, 512, True, True, False, False),        # AttentionOutput.expand + ReLU (two column tiles)
+    (197, 512, 256, True, False, True, True),         # AttentionOutput.squeeze + residual + norm (K = 512)
+    (300, 256, 768, True, False, False, False),       # q | k | v in one launch
+    (130, 256, 256, True, False, True, True),         # linear + residual + norm
+    (70, 256, 256, True, True, True, False),
+]
+
+
+@pytest.mark.parametrize("M,K,N,bias,relu,res,ln", CASES)
+def test_linear_f32_vs_library(M, K, N, bias, relu, res, ln):
+    """fp32-class result: the 3-term split leaves ~2^-17 relative per product, i.e. errors of order 1e-5 of sum |x||w| (the
+    library's own fp32 GEMM sits at 1e-6); after LayerNorm the bound is relative to the normalised scale."""
+    from sam6d_amd import ops
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g) * 0.7
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) if bias else None
+    r = torch.randn(M, N, generator=g) if res else None
+    gm, bt = (1 + 0.1 * torch.randn(N, generator=g), 0.1 * torch.randn(N, generator=g)) if ln else (None, None)
+    hi, lo = ops.split_weight(w.cuda())
+    assert (hi.float().cpu() + lo.float().cpu() - w).abs().max() <= 2.0 ** -16 * w.abs().max()
+    y = ops.linear_f32(x.cuda(), hi, lo, None if b is None else b.cuda(), relu=relu, residual=None if r is None else r.cuda(),
+                       ln=None if not ln else (gm.cuda(), bt.cuda(), 1e-5)).cpu()
+    ref = x.double() @ w.double().t()
+    if b is not None:
+        ref = ref + b.double()
+    if relu:
+        ref = ref.relu()
+    if r is not None:
+        ref = ref + r.double()
+    scale = (x.abs().double() @ w.abs().double().t())
+    tol = 2e-5 * scale + 1e-6
+    if ln:
+        pre = ref
+        ref = torch.nn.functional.layer_norm(pre, (N,), gm.double(), bt.double(), 1e-5)
+        tol = (2e-5 * scale.amax(1, keepdim=True) / pre.std(1, keepdim=True)) * (1 + gm.abs().double()) + 1e-5
+    err = (y.double() - ref).abs()
+    assert (err <= tol).all(), (err / tol).max().item()
+    assert y.shape == (M, N) and y.dtype == torch.float32
+
+
+def test_linear_f32_at_the_dense_stage_shape():
+    """65536 rows x 256 -> 256 (the fine stage's per-point layers at B = 32): a row sample against float64."""
+    from sam6d_amd import ops
+    if not torch.cuda.is_available():
+        pytest.skip("emulator: small shapes only")
+    g = torch.Generator().manual_seed(9)
+    M, K, N = 65536, 256, 256
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / 16
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    gm, bt = torch.ones(N), torch.zeros(N)
+    hi, lo = ops.split_weight(w.cuda())
+    y = ops.linear_f32(x.cuda(), hi, lo, b.cuda(), residual=r.cuda(), ln=(gm.cuda(), bt.cuda(), 1e-5)).cpu()
+    rows = torch.randperm(M, generator=g)[:2048]
+    ref = torch.nn.functional.layer_norm(x[rows].double() @ w.double().t() + b.double() + r[rows].double(), (N,), gm.double(), bt.double(), 1e-5)
+    assert (y[rows].double() - ref).abs().max() < 5e-5

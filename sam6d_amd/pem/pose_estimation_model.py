@@ -149,11 +149,13 @@ class FinePointMatching(nn.Module):
         init_R, init_t = end_points["init_R"], end_points["init_t"]
         p1_ = (p1 - init_t.unsqueeze(1)) @ init_R
         bg = self.bg_token.expand(B, -1, -1)
-        f1 = torch.cat([bg, plinear(self, self.in_proj, f1, residual=self.PE(p1_))], dim=1)
-        f2 = torch.cat([bg, plinear(self, self.in_proj, f2, residual=self.PE(p2))], dim=1)
+        # (bg token, dense rows) kept apart through the blocks: one concatenation per side at the end instead of one per block
+        f1 = (bg, plinear(self, self.in_proj, f1, residual=self.PE(p1_)))
+        f2 = (bg, plinear(self, self.in_proj, f2, residual=self.PE(p2)))
         for blk in self.transformers:
             f1, f2 = blk(f1, geo1, fps_idx1, f2, geo2, fps_idx2)
-        o1, o2 = plinear(self, self.out_proj, f1), plinear(self, self.out_proj, f2)
+        o1 = torch.cat([plinear(self, self.out_proj, f1[0].contiguous()), plinear(self, self.out_proj, f1[1])], dim=1)
+        o2 = torch.cat([plinear(self, self.out_proj, f2[0].contiguous()), plinear(self, self.out_proj, f2[1])], dim=1)
         model = end_points["model"] / (radius.reshape(-1, 1, 1) + 1e-6)
         if ops.have("fine_match") and o1.is_cuda and o1.dtype == torch.float32 and o1.shape[2] == 256:
             # similarity tiles are formed inside the assignment kernel: the (B,2049,2049) matrix is never written

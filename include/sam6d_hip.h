@@ -30,7 +30,7 @@ extern "C" {
 
 /* Bumped whenever a signature in this header changes; the loader (sam6d_amd/_lib.py) refuses a library whose
  * s6d_version() differs from the header it was written against (a stale .so fails at load, not at a call). */
-#define S6D_ABI_VERSION 106
+#define S6D_ABI_VERSION 107
 int s6d_version(void);
 const char *s6d_strerror(int code);
 /* last HIP error string seen by this thread (empty if none) */
@@ -210,6 +210,16 @@ int s6d_gemm_bf16(const void *A, long lda, const void *W, long ldw, const float 
  * block writes q / k / v head-major this way (col_block = head_dim) for s6d_win_attention_layout_bf16(head_major = 1). */
 int s6d_gemm_bf16_cblk(const void *A, long lda, const void *W, long ldw, const float *bias, void *C, long ldc, int M, int N, int K,
                        int epilogue, int col_block, int max_blocks, void *stream);
+/* IEEE-half (float16) builds of three kernels, for the PEM's ViT-B (Pose_Estimation_Model/model/feature_extraction.py:17-35 on
+ * timm's VisionTransformer): same signatures and layouts as their bf16 namesakes, elements are IEEE binary16.  Half's 11-bit
+ * significand keeps the extractor's features within 1e-3 of the fp32 extractor's (bf16: 7.6e-3), which the matcher's 1e-3 mm
+ * translation bar needs; the matrix rate is the bf16 one.  s6d_gemm_f16: N % 256 == 0, epilogue 0 / 1. */
+int s6d_gemm_f16(const void *A, long lda, const void *W, long ldw, const float *bias, void *C, long ldc, int M, int N, int K,
+                 int epilogue, int max_blocks, void *stream);
+int s6d_add_layernorm_f16(const void *x, const void *delta, const float *gamma, const float *beta, float eps, long rows, int C,
+                          void *x_out, void *y_out, void *stream);
+int s6d_seq_attention_f16(const void *qkv, int B, int N, int num_heads, int head_dim, float scale, void *out, void *stream);
+
 /* The same product with the RESIDUAL ADD of a transformer block in the epilogue: C = bf16(bf16(A W^T + bias) + R), R (M,N) bf16 with
  * row stride ldr (R may be C: in place).  Replaces `x = shortcut + x` / `x = x + self.mlp(..)` as separate passes over two
  * (tokens, C) tensors (segment_anything/modeling/image_encoder.py:166-182; timm / DINOv2 blocks alike).  N % 256 == 0. */

@@ -21,18 +21,53 @@
 #include "s6d_common.h"
 #include <stdlib.h>
 
-namespace s6d {
+// Element type of q / k / v / P / the output.  The file is compiled twice: as is for bf16 (SAM, DINOv2: `bf16x8`, `f2bf` mean what
+// they say), and from csrc/s6d_attn_f16.hip with S6D_ATTN_F16 = 1 for IEEE half (the PEM's ViT-B, round 3): the same kernels in
+// namespace s6d_h with v_mfma_f32_16x16x32_f16, where the names below stand for the half forms and only s6d_seq_attention_f16
+// is exported.  Nothing else in the file depends on the element's bit layout (probabilities are <= 1, sums are fp32).
+#ifndef S6D_ATTN_F16
+#define S6D_ATTN_F16 0
+#endif
+#if S6D_ATTN_F16
+#define S6D_ATTN_NS s6d_h
+#define S6D_ATTN_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define S6D_ATTN_ONE 0x3C00
+#else
+#define S6D_ATTN_NS s6d
+#define S6D_ATTN_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define S6D_ATTN_ONE 0x3F80
+#endif
 
+namespace S6D_ATTN_NS {
+using namespace s6d;
+
+#if S6D_ATTN_F16
+typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8;
+#else
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+#endif
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef unsigned short u16;
 
+#if S6D_ATTN_F16
+__device__ __forceinline__ u16 f2bf(float f) {  // round-to-nearest-even
+  union { _Float16 b; u16 u; } x;
+  x.b = (_Float16)f;
+  return x.u;
+}
+__device__ __forceinline__ float bf2f(u16 h) {
+  union { _Float16 b; u16 u; } x;
+  x.u = h;
+  return (float)x.b;
+}
+#else
 __device__ __forceinline__ u16 f2bf(float f) {  // round-to-nearest-even (v_cvt_pk_bf16_f32 on gfx950)
   union { __bf16 b; u16 u; } x;
   x.b = (__bf16)f;
   return x.u;
 }
 __device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((unsigned)h) << 16); }
+#endif
 
 struct AttnParams {
   const u16 *qkv;      // (B,H,W,3,nh,HD) bf16
@@ -193,7 +228,7 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
       for (int ks = 0; ks < C::KS; ++ks) {
         const bf16x8 a = *reinterpret_cast<const bf16x8 *>(Kl + (sub * 16 + c) * C::KROW + ks * 32 + gk * 8);
 #pragma unroll
-        for (int n = 0; n < NS; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, st.qf[n][ks], acc[n], 0, 0, 0);
+        for (int n = 0; n < NS; ++n) acc[n] = S6D_ATTN_MFMA16(a, st.qf[n][ks], acc[n]);
       }
     }
 #pragma unroll
@@ -278,14 +313,14 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
   }
   union { bf16x8 v; u16 h[8]; } ones;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) ones.h[i] = 0x3F80;                  // bf16 1.0
+  for (int i = 0; i < 8; ++i) ones.h[i] = S6D_ATTN_ONE;            // 1.0 in the element type
   S6D_TICK(tk, 4);
   if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const u16 *vrow = Vl + (32 * j + g * 4 + (c >> 2)) * C::VROW + (c & 3) * 4;
 #pragma unroll
-    for (int n = 0; n < NS; ++n) st.lacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, pb[n][j].v, st.lacc[n], 0, 0, 0);
+    for (int n = 0; n < NS; ++n) st.lacc[n] = S6D_ATTN_MFMA16(ones.v, pb[n][j].v, st.lacc[n]);
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) {
       union { bf16x8 v; s16x4 q[2]; } va;
@@ -293,7 +328,7 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
       va.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + 16 * C::VROW + dt * 16));
 #pragma unroll
       for (int n = 0; n < NS; ++n)
-        st.oacc[n][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va.v, pb[n][j].v, st.oacc[n][dt], 0, 0, 0);
+        st.oacc[n][dt] = S6D_ATTN_MFMA16(va.v, pb[n][j].v, st.oacc[n][dt]);
     }
   }
   if (PRIO) __builtin_amdgcn_s_setprio(0);
@@ -422,7 +457,7 @@ __device__ __forceinline__ void build_table(const u16 *rel, int j0, int sgn, con
   for (int jt = 0; jt < NJT; ++jt) {
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r[jt][ks].v, qf[ks], a, 0, 0, 0);
+    for (int ks = 0; ks < C::KS; ++ks) a = S6D_ATTN_MFMA16(r[jt][ks].v, qf[ks], a);
     // C layout: row jj = jt*16 + g*4 + r, col = query c
     float *o = dst + c * ld + jt * 16 + g * 4;
     if ((ld & 3) == 0) {
@@ -594,8 +629,8 @@ __device__ __forceinline__ void win16_tables(const RelFrags<HD> &rf, int S, int 
       aw[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
-        aw[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rf.rw[jt][ks].v, qf[n][ks], aw[jt], 0, 0, 0);
-        ah[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rf.rh[jt][ks].v, qf[n][ks], ah[jt], 0, 0, 0);
+        aw[jt] = S6D_ATTN_MFMA16(rf.rw[jt][ks].v, qf[n][ks], aw[jt]);
+        ah[jt] = S6D_ATTN_MFMA16(rf.rh[jt][ks].v, qf[n][ks], ah[jt]);
       }
     }
     // C layout: row jj = jt*16 + g*4 + r, col = query c
@@ -680,7 +715,7 @@ __device__ __forceinline__ void win16_pass(const AttnParams &p, const u16 *Kl, c
     for (int ks = 0; ks < C::KS; ++ks)
 #pragma unroll
       for (int n = 0; n < NS; ++n)
-        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ky & 1][ks], qf[n][ks], acc[n], 0, 0, 0);
+        acc[n] = S6D_ATTN_MFMA16(kf[ky & 1][ks], qf[n][ks], acc[n]);
 #pragma unroll
     for (int n = 0; n < NS; ++n) {
 #pragma unroll
@@ -705,7 +740,7 @@ __device__ __forceinline__ void win16_pass(const AttnParams &p, const u16 *Kl, c
   }
   union { bf16x8 v; u16 hh[8]; } ones;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) ones.hh[i] = 0x3F80;                // bf16 1.0
+  for (int i = 0; i < 8; ++i) ones.hh[i] = S6D_ATTN_ONE;          // 1.0 in the element type
 #pragma unroll
   for (int u = 0; u < SRC; u += 2) {
     // half of the score registers have been consumed: room for what `mid` brings in (the next item's Q fragments)
@@ -732,12 +767,12 @@ __device__ __forceinline__ void win16_pass(const AttnParams &p, const u16 *Kl, c
           for (int r = 0; r < 4; ++r) pb[n].hh[h * 4 + r] = f2bf(fast_exp2(sp[n][u + h][r] - off));
         }
 #pragma unroll
-      for (int n = 0; n < NS; ++n) lacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, pb[n].v, lacc[n], 0, 0, 0);
+      for (int n = 0; n < NS; ++n) lacc[n] = S6D_ATTN_MFMA16(ones.v, pb[n].v, lacc[n]);
 #pragma unroll
       for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
         for (int n = 0; n < NS; ++n)
-          oacc[n][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[dt].v, pb[n].v, oacc[n][dt], 0, 0, 0);
+          oacc[n][dt] = S6D_ATTN_MFMA16(va[dt].v, pb[n].v, oacc[n][dt]);
     }
   }
 #pragma unroll
@@ -1428,10 +1463,11 @@ static int launch_attn(AttnParams p, hipStream_t st) {
   return launch_status();
 }
 
-}  // namespace s6d
+}  // namespace S6D_ATTN_NS
 
-using namespace s6d;
+using namespace S6D_ATTN_NS;
 
+#if !S6D_ATTN_F16
 extern "C" long s6d_win_attention_scratch_bytes(int H, int window, int head_dim) {
   const int S = window ? window : H;
   const int LT = ((2 * S - 1) + 15) / 16 * 16, HDP = (head_dim + 31) / 32 * 32;
@@ -1489,8 +1525,15 @@ extern "C" int s6d_win_attention_layout_bf16(const void *qkv, int head_major, co
   }
 }
 
-extern "C" int s6d_seq_attention_bf16(const void *qkv, int B, int N, int num_heads, int head_dim, float scale, void *out,
-                                      void *stream) {
+#endif  // !S6D_ATTN_F16
+
+#if S6D_ATTN_F16
+#define S6D_SEQ_ATTENTION s6d_seq_attention_f16
+#else
+#define S6D_SEQ_ATTENTION s6d_seq_attention_bf16
+#endif
+extern "C" int S6D_SEQ_ATTENTION(const void *qkv, int B, int N, int num_heads, int head_dim, float scale, void *out,
+                                 void *stream) {
   if (B < 0 || N <= 0 || num_heads <= 0) return S6D_EINVAL;
   if (B == 0) return S6D_OK;
   if (!qkv || !out) return S6D_EINVAL;

@@ -17,8 +17,28 @@ __device__ __forceinline__ u16 f2bf_(float f) {
   return (u16)(u >> 16);
 }
 
+// element conversions of the 2-byte rows: bf16 (SAM / DINOv2 / the throughput option of the PEM ViT-B) or IEEE half (PEM ViT-B)
+template <bool F16>
+__device__ __forceinline__ float elem2f(u16 h) {
+  if (F16) {
+    union { u16 u; _Float16 f; } c;
+    c.u = h;
+    return (float)c.f;
+  }
+  return bf2f_(h);
+}
+template <bool F16>
+__device__ __forceinline__ u16 f2elem(float f) {
+  if (F16) {
+    union { u16 u; _Float16 f; } c;
+    c.f = (_Float16)f;
+    return c.u;
+  }
+  return f2bf_(f);
+}
+
 // one wavefront per token row; VEC chunks of 8 bf16 (16 B) per lane: C <= 64*8*VEC
-template <int VEC>
+template <int VEC, bool F16>
 __global__ __launch_bounds__(256) void add_layernorm_kernel(const u16 *__restrict__ x, const u16 *__restrict__ delta,
                                                            const float *__restrict__ gamma,
                                                            const float *__restrict__ beta, float eps, long rows,
@@ -39,12 +59,12 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const u16 *__restric
       if (delta) {
         d.u = *reinterpret_cast<const uint4 *>(delta + row * C + ch * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a.h[e] = f2bf_(bf2f_(a.h[e]) + bf2f_(d.h[e]));   // residual stream stays bf16
+        for (int e = 0; e < 8; ++e) a.h[e] = f2elem<F16>(elem2f<F16>(a.h[e]) + elem2f<F16>(d.h[e]));   // residual stream stays bf16
         if (x_out) *reinterpret_cast<uint4 *>(x_out + row * C + ch * 8) = a.u;
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        v[i][e] = bf2f_(a.h[e]);
+        v[i][e] = elem2f<F16>(a.h[e]);
         sum += v[i][e];
       }
     } else {
@@ -86,7 +106,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const u16 *__restric
         continue;
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o.h[e] = f2bf_((v[i][e] - mean) * rstd * gg[e] + bb[e]);
+      for (int e = 0; e < 8; ++e) o.h[e] = f2elem<F16>((v[i][e] - mean) * rstd * gg[e] + bb[e]);
       *reinterpret_cast<uint4 *>(y_out + row * C + ch * 8) = o.u;
     }
   }
@@ -192,7 +212,13 @@ __global__ __launch_bounds__(256) void layernorm_fp8_kernel(const u16 *__restric
 using namespace s6d;
 
 static int ln_launch(const void *x, const void *delta, const float *gamma, const float *beta, float eps, long rows, int C,
-                     void *x_out, void *y_out, float *y_f32, void *stream);
+                     void *x_out, void *y_out, float *y_f32, void *stream, bool f16 = false);
+
+extern "C" int s6d_add_layernorm_f16(const void *x, const void *delta, const float *gamma, const float *beta,
+                                     float eps, long rows, int C, void *x_out, void *y_out, void *stream) {
+  if (!y_out) return S6D_EINVAL;
+  return ln_launch(x, delta, gamma, beta, eps, rows, C, x_out, y_out, nullptr, stream, true);
+}
 
 extern "C" int s6d_add_layernorm_bf16(const void *x, const void *delta, const float *gamma, const float *beta,
                                       float eps, long rows, int C, void *x_out, void *y_out, void *stream) {
@@ -207,7 +233,7 @@ extern "C" int s6d_layernorm_bf16_f32(const void *x, const float *gamma, const f
 }
 
 static int ln_launch(const void *x, const void *delta, const float *gamma, const float *beta, float eps, long rows, int C,
-                     void *x_out, void *y_out, float *y_f32, void *stream) {
+                     void *x_out, void *y_out, float *y_f32, void *stream, bool f16) {
   if (rows < 0 || C <= 0 || (C % 8) != 0) return S6D_EINVAL;
   if (rows == 0) return S6D_OK;
   if (!x || !gamma || !beta || (delta && !x_out)) return S6D_EINVAL;
@@ -215,8 +241,14 @@ static int ln_launch(const void *x, const void *delta, const float *gamma, const
   const int nchunk = C / 8;
   hipStream_t st = as_stream(stream);
 #define S6D_LN(V)                                                                                              \
-  hipLaunchKernelGGL((add_layernorm_kernel<V>), dim3(grid), dim3(256), 0, st, (const u16 *)x, (const u16 *)delta, \
-                     gamma, beta, eps, rows, C, (u16 *)x_out, (u16 *)y_out, y_f32)
+  do {                                                                                                         \
+    if (f16)                                                                                                   \
+      hipLaunchKernelGGL((add_layernorm_kernel<V, true>), dim3(grid), dim3(256), 0, st, (const u16 *)x, (const u16 *)delta, \
+                         gamma, beta, eps, rows, C, (u16 *)x_out, (u16 *)y_out, y_f32);                        \
+    else                                                                                                       \
+      hipLaunchKernelGGL((add_layernorm_kernel<V, false>), dim3(grid), dim3(256), 0, st, (const u16 *)x, (const u16 *)delta, \
+                         gamma, beta, eps, rows, C, (u16 *)x_out, (u16 *)y_out, y_f32);                        \
+  } while (0)
   if (nchunk <= 64) S6D_LN(1);
   else if (nchunk <= 128) S6D_LN(2);
   else if (nchunk <= 192) S6D_LN(3);

@@ -461,13 +461,21 @@ def window_attention(qkv, qkv_bias, rel_h, rel_w, num_heads, window, scale, head
     return out
 
 
+def _half(t, name, ndim=None):
+    """bf16 or IEEE-half tensor -> symbol suffix of the kernel family compiled for that element type."""
+    if t.dtype not in (torch.bfloat16, torch.float16):
+        raise RuntimeError(f"{name} must be a bfloat16 or float16 tensor")
+    _chk(t, t.dtype, name, ndim)
+    return "bf16" if t.dtype == torch.bfloat16 else "f16"
+
+
 def seq_attention(qkv, num_heads, scale):
-    """qkv (B,N,3C) bf16 -> (B,N,C) bf16: softmax(scale q k^T) v per head, no positional bias."""
-    _chk(qkv, torch.bfloat16, "qkv", 3)
+    """qkv (B,N,3C) bf16 or f16 -> (B,N,C) same dtype: softmax(scale q k^T) v per head, no positional bias."""
+    sfx = _half(qkv, "qkv", 3)
     B, N, C3 = qkv.shape
     C = C3 // 3
-    out = torch.empty(B, N, C, dtype=torch.bfloat16, device=qkv.device)
-    _call("s6d_seq_attention_bf16", _ptr(qkv), B, N, int(num_heads), int(C // num_heads), ctypes.c_float(scale),
+    out = torch.empty(B, N, C, dtype=qkv.dtype, device=qkv.device)
+    _call("s6d_seq_attention_" + sfx, _ptr(qkv), B, N, int(num_heads), int(C // num_heads), ctypes.c_float(scale),
           _ptr(out), _stream())
     return out
 
@@ -479,8 +487,11 @@ def gemm_bf16(a, w, bias=None, gelu=False, out=None, max_blocks=0, col_block=0, 
     residual (..., N) bf16: returns bf16(bf16(a @ w.T + bias) + residual) (N % 256 == 0, no GELU); out may be the residual itself."""
     if not a.is_cuda or not w.is_cuda:
         raise RuntimeError("a and w must be CUDA tensors")
-    if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
-        raise RuntimeError("a and w must be bfloat16 tensors")
+    if a.dtype not in (torch.bfloat16, torch.float16) or w.dtype != a.dtype:
+        raise RuntimeError("a and w must both be bfloat16 (or both float16) tensors")
+    f16 = a.dtype == torch.float16          # IEEE half: the same kernel on v_mfma_f32_32x32x16_f16 (plain / GELU epilogue, N % 256 == 0)
+    if f16 and (col_block or residual is not None):
+        raise RuntimeError("the float16 GEMM has the plain and the GELU epilogue only")
     K = a.shape[-1]
     N = w.shape[0]
     a2 = a.reshape(-1, K)
@@ -494,15 +505,15 @@ def gemm_bf16(a, w, bias=None, gelu=False, out=None, max_blocks=0, col_block=0, 
     if col_block:
         if out is not None:
             raise RuntimeError("col_block output is allocated by the call")
-        out = torch.empty(N // col_block, M, col_block, dtype=torch.bfloat16, device=a.device)
+        out = torch.empty(N // col_block, M, col_block, dtype=torch.bfloat16, device=a.device)   # (bf16 only: checked above)
         _call("s6d_gemm_bf16_cblk", _ptr(a2), ctypes.c_long(a2.stride(0)), _ptr(w), ctypes.c_long(w.stride(0)),
               _ptr(bias) if bias is not None else _vp(0), _ptr(out), ctypes.c_long(N), M, N, K, 1 if gelu else 0, int(col_block),
               int(max_blocks), _stream())
         return out
     if out is None:
-        out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+        out = torch.empty(M, N, dtype=a.dtype, device=a.device)
     else:
-        _chk(out, torch.bfloat16, "out", 2)
+        _chk(out, a.dtype, "out", 2)
         if tuple(out.shape) != (M, N) or out.stride(1) != 1 or out.stride(0) % 8 or out.data_ptr() % 16:
             raise ValueError(f"out must be ({M}, {N}) bf16 with contiguous, 16-byte aligned rows (stride % 8 == 0); got "
                              f"{tuple(out.shape)} strides {tuple(out.stride())}")
@@ -524,7 +535,7 @@ def gemm_bf16(a, w, bias=None, gelu=False, out=None, max_blocks=0, col_block=0, 
         return out.reshape(*a.shape[:-1], N)
     for r0 in range(0, M, rows):
         r1 = min(M, r0 + rows)
-        _call("s6d_gemm_bf16", _ptr(a2[r0:r1]), ctypes.c_long(a2.stride(0)), _ptr(w), ctypes.c_long(w.stride(0)),
+        _call("s6d_gemm_f16" if f16 else "s6d_gemm_bf16", _ptr(a2[r0:r1]), ctypes.c_long(a2.stride(0)), _ptr(w), ctypes.c_long(w.stride(0)),
               _ptr(bias) if bias is not None else _vp(0), _ptr(out[r0:r1]), ctypes.c_long(out.stride(0)), r1 - r0, N, K,
               1 if gelu else 0, int(max_blocks), _stream())
     return out.reshape(*a.shape[:-1], N)
@@ -627,19 +638,19 @@ def layernorm_f32out(x, gamma, beta, eps):
 
 
 def add_layernorm(x, delta, gamma, beta, eps):
-    """x (...,C) bf16, delta same shape or None, gamma/beta (C) f32 -> (x + delta, LN(x + delta)) bf16."""
-    _chk(x, torch.bfloat16, "x")
+    """x (...,C) bf16 or f16, delta same shape / dtype or None, gamma/beta (C) f32 -> (x + delta, LN(x + delta)) in x's dtype."""
+    sfx = _half(x, "x")
     _chk(gamma, torch.float32, "gamma", 1)
     _chk(beta, torch.float32, "beta", 1)
     C = x.shape[-1]
     rows = x.numel() // C
     y = torch.empty_like(x)
     if delta is not None:
-        _chk(delta, torch.bfloat16, "delta")
+        _chk(delta, x.dtype, "delta")
         xo = torch.empty_like(x)
     else:
         xo = x
-    _call("s6d_add_layernorm_bf16", _ptr(x), _ptr(delta) if delta is not None else _vp(0), _ptr(gamma), _ptr(beta),
+    _call("s6d_add_layernorm_" + sfx, _ptr(x), _ptr(delta) if delta is not None else _vp(0), _ptr(gamma), _ptr(beta),
           ctypes.c_float(eps), ctypes.c_long(rows), int(C), _ptr(xo) if delta is not None else _vp(0), _ptr(y),
           _stream())
     return xo, y
@@ -832,7 +843,7 @@ def have(name):
     if name not in _FUSED:
         sym = {"rpe_attention": "s6d_rpe_attention_f32", "geo_embedding": "s6d_geo_embedding_f32",
                "fine_assign": "s6d_fine_assign_f32", "fine_match": "s6d_fine_match_f32", "pem_pre": "s6d_pem_compact_cloud_f32", "coarse_sample": "s6d_coarse_sample_f32", "upsample_gather": "s6d_upsample_gather_f32",
-               "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "add_layernorm": "s6d_add_layernorm_bf16", "gemm_bf16": "s6d_gemm_bf16", "gemm_bf16_res": "s6d_gemm_bf16_res", "gemm_fp8": "s6d_gemm_fp8", "layernorm_fp8": "s6d_layernorm_fp8", "layernorm_f32out": "s6d_layernorm_bf16_f32", "linear_f32": "s6d_linear_f32", "win_attention": "s6d_win_attention_layout_bf16",
+               "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "add_layernorm": "s6d_add_layernorm_bf16", "gemm_bf16": "s6d_gemm_bf16", "gemm_bf16_res": "s6d_gemm_bf16_res", "gemm_f16": "s6d_gemm_f16", "gemm_fp8": "s6d_gemm_fp8", "layernorm_fp8": "s6d_layernorm_fp8", "layernorm_f32out": "s6d_layernorm_bf16_f32", "linear_f32": "s6d_linear_f32", "win_attention": "s6d_win_attention_layout_bf16",
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
                "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_frames_f32",

@@ -9,7 +9,7 @@ Hardware-first differences from the reference forward:
   * the (B,256,224,224) bilinearly upsampled map (51 MB per instance) is never built: the
     2048 chosen pixels are interpolated straight out of the (B,196,16*256) up-projection
     (feature_extraction.py:111-114 + model_utils.py:69-81 fused).
-  * compute dtype is configurable (``S6D_PEM_VIT_DTYPE`` = fp32 | bf16, default fp32).
+  * compute dtype is configurable (``S6D_PEM_VIT_DTYPE`` = fp32 | fp16 | bf16, default fp32).
 """
 import os
 from functools import partial
@@ -23,7 +23,10 @@ from ..utils.linear import fused_linear
 
 
 def _vit_dtype():
-    return {"fp32": torch.float32, "bf16": torch.bfloat16}[os.environ.get("S6D_PEM_VIT_DTYPE", "fp32")]
+    """S6D_PEM_VIT_DTYPE = fp32 (default) | fp16 | bf16.  fp16: the fused pipeline in IEEE half -- the matrix rate of bf16 with an
+    11-bit significand: extractor features within 1e-3 of fp32's (bf16: 7.6e-3), pose within north_star's 1e-3 / 1e-3 mm of the
+    reference on the well-conditioned golden (tests/test_gpu_pem.py); bf16 misses the translation bar by 1.3-2x."""
+    return {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[os.environ.get("S6D_PEM_VIT_DTYPE", "fp32")]
 
 
 class _Attn(nn.Module):
@@ -92,11 +95,14 @@ class ViT(nn.Module):
         h = x.shape[2] // p
         x = x.view(B, 3, h, p, h, p).permute(0, 2, 4, 1, 3, 5).reshape(B, h * h, 3 * p * p)
         x = fused_linear(self.patch_embed.proj, x, weight2d=self.patch_embed.proj.weight.view(self.patch_embed.proj.weight.shape[0], -1))
-        x = torch.cat([self.cls_token.expand(B, -1, -1), x], dim=1) + self.pos_embed
+        # parameters cast to the token dtype: under autocast `cat` / `+` with the fp32 parameters would promote the tokens to
+        # fp32 and the fused half-precision pipeline below would never be reached (it was not, until round 3)
+        x = torch.cat([self.cls_token.to(x.dtype).expand(B, -1, -1), x], dim=1) + self.pos_embed.to(x.dtype)
         d = len(self.blocks)
         n = d // 4
         taps = (d - 3 * n - 1, d - 2 * n - 1, d - n - 1, d - 1)
-        if x.is_cuda and x.dtype == torch.bfloat16 and ops.have("seq_attention") and ops.have("add_layernorm"):
+        if x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and ops.have("seq_attention") and ops.have("add_layernorm") \
+                and (x.dtype == torch.bfloat16 or ops.have("gemm_f16")):
             return self._forward_fused(x, taps)
         out = []
         for i, blk in enumerate(self.blocks):

@@ -15,6 +15,7 @@ dropping tiny detections (``Detections.remove_very_small_detections``, model/uti
 mask area / frame > 3e-4 -- the first threshold squared, the second not, as in the reference), keeping the best
 detections by final score.
 """
+import os
 import time
 from types import SimpleNamespace
 
@@ -52,6 +53,8 @@ class FramePipeline:
         self.nms_thresh, self.det_thresh = nms_per_object_thresh, det_score_thresh
         self.times = {}
         self.sync_stages = sync_stages
+        self.graph_max = int(os.environ.get("S6D_PEM_GRAPH_MAX", "16"))      # instance counts up to this one replay a captured graph
+        self._pem_graphs = {}
 
     def score_metres(self, cls, patch, masks, boxes, depth_m, K):
         """The unit boundary between the two halves of the frame: this class takes depth in METRES (what the PEM
@@ -115,6 +118,47 @@ class FramePipeline:
         self._tick("scoring", t0)
         return det
 
+    def _pem_forward(self, ep):
+        """Net.forward for the group's M instances.  With few instances the point transformer is LAUNCH-bound (measured: 18.6 ms for
+        10 instances against 37 ms for 32, ~1500 launches either way), so for M <= graph_max_instances the forward is captured once
+        per instance count as a hipGraph over static input buffers and replayed (no host round trip sits inside Net.forward: the
+        coarse uniforms are an input).  S6D_PEM_GRAPH=0 turns it off; counts are padded up to a multiple of 2 by repeating the last
+        instance so that a few graphs serve every frame."""
+        M = ep["pts"].shape[0]
+        dev = ep["pts"].device
+        if not (dev.type == "cuda" and M <= self.graph_max and os.environ.get("S6D_PEM_GRAPH", "1") == "1"):
+            return self.pem(ep)
+        Mp = (M + 1) // 2 * 2
+        keys = ("pts", "rgb", "rgb_choose", "model", "dense_po", "dense_fo", "coarse_rand_u")
+        g = self._pem_graphs.get(Mp)
+        if g is None:
+            static = {k: torch.empty((Mp,) + tuple(ep[k].shape[1:]), dtype=ep[k].dtype, device=dev) for k in keys}
+
+            def fill():
+                for k in keys:
+                    static[k][:M].copy_(ep[k])
+                    if Mp > M:
+                        static[k][M:].copy_(ep[k][M - 1:M].expand(Mp - M, *ep[k].shape[1:]))
+            fill()
+            s = torch.cuda.Stream(device=dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                for _ in range(2):                                          # warm every cache the forward fills lazily
+                    self.pem(dict(static))
+            torch.cuda.current_stream(dev).wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.pem(dict(static))
+            g = (graph, static, {k: out[k] for k in ("pred_R", "pred_t", "pred_pose_score")})
+            self._pem_graphs[Mp] = g
+        graph, static, outs = g
+        for k in keys:
+            static[k][:M].copy_(ep[k])
+            if Mp > M:
+                static[k][M:].copy_(ep[k][M - 1:M].expand(Mp - M, *ep[k].shape[1:]))
+        graph.replay()
+        return {k: v[:M].clone() for k, v in outs.items()}
+
     @torch.no_grad()
     def run_group(self, frames):
         """A group of frames through the chain with the batch where the models want it: ONE SAM encoder pass over the group's frames,
@@ -167,7 +211,7 @@ class FramePipeline:
         cat = (lambda k: obs_l[0][k]) if len(obs_l) == 1 else (lambda k: torch.cat([o[k] for o in obs_l]))
         ep = dict(pts=cat("pts"), rgb=cat("rgb"), rgb_choose=cat("rgb_choose"), model=tpl("model"), dense_po=tpl("dense_po"),
                   dense_fo=tpl("dense_fo"), coarse_rand_u=ru_l[0] if len(ru_l) == 1 else torch.cat(ru_l))
-        out = self.pem(ep)
+        out = self._pem_forward(ep)
         self._tick("pem", t0)
         res, at, k = [], 0, 0
         for det, n in zip(dets, count):

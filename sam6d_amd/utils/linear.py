@@ -13,13 +13,13 @@ import torch.nn.functional as F
 from .. import ops
 
 
-def _cached(lin, w2d):
-    """bf16 weight (N,K) + fp32 bias of a Linear / 1x1-or-patch Conv, cached until the parameters change."""
+def _cached(lin, w2d, dtype=torch.bfloat16):
+    """bf16 (or float16) weight (N,K) + fp32 bias of a Linear / 1x1-or-patch Conv, cached until the parameters change."""
     b = lin.bias
-    key = (lin.weight._version, lin.weight.data_ptr(), lin.weight.dtype, None if b is None else (b._version, b.data_ptr()))
+    key = (lin.weight._version, lin.weight.data_ptr(), lin.weight.dtype, None if b is None else (b._version, b.data_ptr()), dtype)
     c = getattr(lin, "_s6d_gemm", None)
     if c is None or c[0] != key:
-        wb = w2d.detach().to(torch.bfloat16).contiguous()
+        wb = w2d.detach().to(dtype).contiguous()
         bf = None if b is None else b.detach().float().contiguous()
         c = (key, wb, bf)
         lin._s6d_gemm = c
@@ -27,10 +27,18 @@ def _cached(lin, w2d):
 
 
 def eligible(x, n_out, k_in):
+    if x.is_cuda and x.dtype == torch.float16:           # IEEE half (PEM ViT-B): the 256 x 256-tile kernel only
+        return n_out % 256 == 0 and k_in % 64 == 0 and ops.have("gemm_f16")
     return (x.is_cuda and x.dtype == torch.bfloat16 and n_out % 128 == 0 and k_in % 64 == 0 and ops.have("gemm_bf16"))
 
 
 def res_eligible(x, n_out, k_in):
+    if x.dtype != torch.bfloat16:
+        return False
+    return _res_eligible(x, n_out, k_in)
+
+
+def _res_eligible(x, n_out, k_in):
     """The residual-add epilogue (s6d_gemm_bf16_res): the 256 x 256-tile kernel only.  OFF unless S6D_GEMM_RES=1 -- measured on the
     MI355X (profiles/r03_gemm_residual_epilogue.txt): the epilogue's residual loads sit behind the tile's own stores in the one
     in-order memory counter (proj + 24 %, lin2 + 8..14 % per launch) and that eats what the one-read LayerNorm saves (26 us of
@@ -61,7 +69,7 @@ def fused_linear(lin, x, gelu=False, weight2d=None, col_block=0, residual=None):
             return ops.gemm_bf16(x, wb, bf, residual=residual, out=residual.reshape(-1, N)).reshape(residual.shape)
         return residual + fused_linear(lin, x, gelu=gelu, weight2d=weight2d)
     if eligible(x, N, K):
-        wb, bf = _cached(lin, w)
+        wb, bf = _cached(lin, w, x.dtype)
         return ops.gemm_bf16(x, wb, bf, gelu=gelu)
     y = F.linear(x, w.to(x.dtype), None if lin.bias is None else lin.bias.to(x.dtype))
     return F.gelu(y) if gelu else y

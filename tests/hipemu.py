@@ -38,6 +38,10 @@ def build(force=False, files=None):
         if files is not None and os.path.basename(f) not in files:
             continue
         text = open(f).read()
+        if os.path.basename(f) == "s6d_attn_f16.hip":
+            # the IEEE-half build of the attention kernels = s6d_attn.hip under S6D_ATTN_F16: include the TEXT (the transformations
+            # below must reach it) instead of the #include
+            text = "#define S6D_ATTN_F16 1\n" + open(os.path.join(CSRC, "s6d_attn.hip")).read()
         # dynamic LDS: `extern __shared__ ... char name[];` refers to a global array defined below
         text = text.replace("extern __shared__", "extern")
         # places that rely on a wave executing in lockstep are marked with a comment in the product source; lanes are
@@ -49,7 +53,8 @@ def build(force=False, files=None):
         srcs.append(dst)
     dyn = os.path.join(OUT, "_dyn_shared.cc")
     with open(dyn, "w") as g:
-        g.write("namespace s6d {\n" + "".join(f"alignas(64) char {n}[160 * 1024];\n" for n in DYN_NAMES) + "}\n")
+        g.write("namespace s6d {\n" + "".join(f"alignas(64) char {n}[160 * 1024];\n" for n in DYN_NAMES) + "}\n"
+                "namespace s6d_h {\nalignas(64) char smem[160 * 1024];\n}\n")
     cmd = [CXX, "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-ffp-contract=off"] + EXTRA + ["-I", EMU, "-I", CSRC, "-I",
            os.path.join(REPO, "include"), "-o", SO, os.path.join(EMU, "hipemu.cc"), dyn] + srcs
     r = subprocess.run(cmd, capture_output=True, text=True)

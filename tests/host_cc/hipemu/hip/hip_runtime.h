@@ -441,6 +441,50 @@ static inline VC hipemu_mfma_scale_32x32x64_f8(hipemu_i32x8 a, hipemu_i32x8 b, V
 }
 #define __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, fa, fb, osa, sa, osb, sb) hipemu_mfma_scale_32x32x64_f8(a, b, c, fa, fb, sa, sb)
 
+// IEEE-half forms of the two shapes: same lane layouts, _Float16 elements
+typedef __attribute__((ext_vector_type(8))) _Float16 hipemu_f16x8;
+template <class VC>
+static inline VC hipemu_mfma_16x16x32_f16(hipemu_f16x8 a, hipemu_f16x8 b, VC c) {
+  struct AB {
+    hipemu_f16x8 a, b;
+  } mine{a, b};
+  hipemu::begin_exchange(mine, 13);
+  const int l = hipemu::lane_of(), col = l & 15, rb = (l >> 4) * 4;
+  VC d = c;
+  for (int i = 0; i < 4; ++i) {
+    float acc = c[i];
+    for (int k = 0; k < 32; ++k) {
+      const AB ra = hipemu::peek<AB>((rb + i) + 16 * (k >> 3)), rbv = hipemu::peek<AB>(col + 16 * (k >> 3));
+      acc += (float)ra.a[k & 7] * (float)rbv.b[k & 7];
+    }
+    d[i] = acc;
+  }
+  hipemu::end_exchange();
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) hipemu_mfma_16x16x32_f16(a, b, c)
+template <class VC>
+static inline VC hipemu_mfma_32x32x16_f16(hipemu_f16x8 a, hipemu_f16x8 b, VC c) {
+  struct AB {
+    hipemu_f16x8 a, b;
+  } mine{a, b};
+  hipemu::begin_exchange(mine, 14);
+  const int l = hipemu::lane_of(), col = l & 31, hb = l >> 5;
+  VC d = c;
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * hb;
+    float acc = c[r];
+    for (int k = 0; k < 16; ++k) {
+      const AB ra = hipemu::peek<AB>(row + 32 * (k >> 3)), rbv = hipemu::peek<AB>(col + 32 * (k >> 3));
+      acc += (float)ra.a[k & 7] * (float)rbv.b[k & 7];
+    }
+    d[r] = acc;
+  }
+  hipemu::end_exchange();
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) hipemu_mfma_32x32x16_f16(a, b, c)
+
 // v_mfma_f32_16x16x4_f32: A lane l = row l%16, k = l/16; B lane l = column l%16, k = l/16; C/D as above
 template <class VC>
 static inline VC hipemu_mfma_16x16x4_f32(float a, float b, VC c) {

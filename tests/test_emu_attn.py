@@ -108,3 +108,35 @@ def test_lds_dma_attention_kernels_under_the_late_completion_model():
                         "t._run_late([(1, 64, 1, 80, 0), (2, 20, 4, 80, 14)])"], env=dict(os.environ, HIPEMU_GLDS="late"),
                        capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_float16_kernels_on_the_emulator(emu):
+    """IEEE-half builds (PEM ViT-B): sequence attention and add + LayerNorm."""
+    T.test_seq_attention_float16_vs_torch(1, 50, 2, 64)
+    T.test_add_layernorm_float16()
+
+
+def test_pem_vit_fused_half_pipeline_on_the_emulator(emu):
+    """The PEM ViT (feature_extraction.ViT) through its fused IEEE-half pipeline (s6d_gemm_f16, s6d_seq_attention_f16,
+    s6d_add_layernorm_f16) against its own fp32 module path: taps within 2e-3 relative (half's 2^-11 per stored activation), and
+    the fused path is really taken (it was not before round 3: the fp32 cls / pos parameters promoted the tokens to fp32)."""
+    import torch
+
+    from sam6d_amd.pem.feature_extraction import ViT
+    from sam6d_amd.utils import seeded
+    m = seeded.load_seeded(ViT(patch_size=16, embed_dim=256, depth=4, num_heads=4, mlp_ratio=2, img_size=64).eval(), 7)
+    x = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(2))
+    calls = []
+    real = emu.seq_attention
+    emu.seq_attention = lambda *a, **k: (calls.append(a[0].dtype), real(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            ref = m(x)
+            with torch.autocast(device_type="cpu", dtype=torch.float16):
+                out = m.half()(x.half())
+    finally:
+        emu.seq_attention = real
+    assert calls == [torch.float16] * 4
+    for a, b in zip(out, ref):
+        rel = ((a.float() - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+        assert rel < 2e-3, rel

@@ -122,6 +122,8 @@ def _run_res():
     torch.Tensor.cuda = lambda self, *a, **k: self
     T.test_residual_epilogue_equals_gemm_then_add(700, 768, 192, False)
     T.test_residual_epilogue_equals_gemm_then_add(300, 256, 64, True)
+    T.test_float16_gemm_vs_float(300, 256, 320, True)
+    T.test_float16_gemm_vs_float(700, 768, 192, False)
 
 
 @pytest.mark.parametrize("mode", ["early", "late"])

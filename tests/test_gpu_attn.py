@@ -100,6 +100,31 @@ def test_add_layernorm_bf16(rows, C):
 
 
 @pytest.mark.parametrize("B,N,nh,hd", [(3, 197, 12, 64), (2, 50, 2, 80), (1, 257, 4, 64)])
+def test_seq_attention_float16_vs_torch(B=2, N=197, nh=12, hd=64):
+    """The IEEE-half build of the sequence attention (PEM ViT-B shape) against the fp32 statement on the same half operands."""
+    from sam6d_amd import ops
+    g = torch.Generator().manual_seed(N + nh)
+    qkv = torch.randn(B, N, 3 * nh * hd, generator=g).to(torch.float16).cuda()
+    out = ops.seq_attention(qkv, nh, hd ** -0.5)
+    assert out.dtype == torch.float16
+    q, k, v = qkv.float().cpu().view(B, N, 3, nh, hd).permute(2, 0, 3, 1, 4).unbind(0)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v).transpose(1, 2).reshape(B, N, nh * hd)
+    assert (out.float().cpu() - ref).abs().max() < 4e-3          # P is rounded to half (2^-11) before the PV product
+
+
+def test_add_layernorm_float16():
+    from sam6d_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(300, 768, generator=g).to(torch.float16).cuda()
+    d = torch.randn(300, 768, generator=g).to(torch.float16).cuda()
+    w = (1 + 0.1 * torch.randn(768, generator=g)).cuda()
+    b = (0.1 * torch.randn(768, generator=g)).cuda()
+    xo, y = ops.add_layernorm(x, d, w, b, 1e-6)
+    xr = (x.float() + d.float()).to(torch.float16)
+    assert torch.equal(xo, xr)
+    assert (y.float() - torch.nn.functional.layer_norm(xr.float(), (768,), w, b, 1e-6)).abs().max() < 4e-3
+
+
 def test_seq_attention_vs_torch(B, N, nh, hd):
     from sam6d_amd import ops
     g = torch.Generator().manual_seed(N)

@@ -144,3 +144,22 @@ def test_residual_epilogue_equals_gemm_then_add(M, N, K, inplace):
     got = ops.gemm_bf16(a, w, b, residual=x, out=x if inplace else None)
     assert (got.data_ptr() == x.data_ptr()) == inplace
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("M,N,K,gelu", [(300, 256, 320, True), (700, 768, 192, False), (6304, 3072, 768, True), (6304, 768, 3072, False)])
+def test_float16_gemm_vs_float(M, N, K, gelu):
+    """s6d_gemm_f16 (the bf16 kernel on v_mfma_f32_32x32x16_f16, half pack): fp32 accumulation, one rounding to half."""
+    from sam6d_amd import ops
+    if not torch.cuda.is_available() and M > 1000:
+        pytest.skip("emulator: small shapes only")
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(torch.float16).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.float16).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    out = ops.gemm_bf16(a, w, b, gelu=gelu)
+    assert out.dtype == torch.float16
+    ref = a.float().cpu().double() @ w.float().cpu().double().t() + b.cpu().double()
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    err = (out.float().cpu().double() - ref).abs()
+    assert (err <= 2.0 ** -11 * ref.abs() * 1.01 + 2e-5).all(), (err / (2.0 ** -11 * ref.abs() + 2e-5)).max().item()

@@ -47,13 +47,14 @@ def test_net_forward_vs_reference_golden(net):
     np.testing.assert_allclose(out["pred_pose_score"].cpu().numpy(), g["net_pred_pose_score"], atol=5e-3)
 
 
-@pytest.mark.parametrize("vit", ["fp32", "bf16"])
+@pytest.mark.parametrize("vit", ["fp32", "fp16", "bf16"])
 def test_net_forward_well_conditioned_vs_reference_golden(net, vit, monkeypatch):
     """Net.forward on the well-conditioned frame of tests/golden/pem_wc.npz (template features = the reference feature
-    extractor's own output for the observed pixels; pose by the reference Net).  fp32 ViT-B: |R - R_ref|_F <= 1e-3 and
-    |t - t_ref| <= 1e-3 mm.  bf16 ViT-B (the throughput configuration of BASELINE configs[1]): rotation at the same bar;
-    the translation carries the linear response of the matcher to bf16-class feature noise measured on the oracle
-    (|dt| ~ 3e-4 m per unit relative noise): bound 1e-2 mm, the measured value is recorded under profiles/."""
+    extractor's own output for the observed pixels; pose by the reference Net).  fp32 ViT-B and the fused IEEE-half ViT-B
+    (fp16: what bench.py runs since round 3): |R - R_ref|_F <= 1e-3 and |t - t_ref| <= 1e-3 mm, north_star's bar.  bf16 ViT-B
+    (kept as an option): rotation at the same bar; its translation carries the linear response of the matcher to bf16-class
+    feature noise measured on the oracle (|dt| ~ 3e-4 m per unit relative noise; features 7.6e-3 off): bound 1e-2 mm, measured
+    1.3e-3 mm -- which is why it is not the benched dtype.  The half-precision runs must go through the fused pipeline."""
     g = util.golden("pem_wc.npz")
     case = ast.literal_eval(str(g["case"]))
     inp = synth.pem_inputs(case["B"], seed=case["input_seed"])
@@ -64,12 +65,18 @@ def test_net_forward_well_conditioned_vs_reference_golden(net, vit, monkeypatch)
     util.assert_digest_close(ep["dense_fo"], g["fo_sum"], g["fo_smp"], 4099, 1e-4, 1e-5, "template features")
     ep["coarse_rand_u"] = synth.coarse_uniforms(case["B"], case["rand_seed"])
     monkeypatch.setenv("S6D_PEM_VIT_DTYPE", vit)
+    from sam6d_amd import ops
+    calls = []
+    real = ops.seq_attention
+    monkeypatch.setattr(ops, "seq_attention", lambda *a, **k: (calls.append(a[0].dtype), real(*a, **k))[1])
     with torch.no_grad():
         out = net(_to(ep, "cuda"))
+    if vit != "fp32":                                             # 12 blocks through the fused attention kernel of that element type
+        assert calls == [dict(fp16=torch.float16, bf16=torch.bfloat16)[vit]] * 12, calls
     dR = np.linalg.norm(out["pred_R"].cpu().numpy() - g["net_pred_R"], axis=(1, 2)).max()
     dt = np.abs(out["pred_t"].cpu().numpy() - g["net_pred_t"]).max()
     util.record_margin(f"net_forward_pem_wc_{vit}vit", dR=dR, dt_m=dt)
-    assert dR <= R_TOL and dt <= (T_TOL_M if vit == "fp32" else 10 * T_TOL_M), (vit, dR, dt)
+    assert dR <= R_TOL and dt <= (10 * T_TOL_M if vit == "bf16" else T_TOL_M), (vit, dR, dt)
 
 
 def test_known_answer_vs_reference_golden_and_truth(net):

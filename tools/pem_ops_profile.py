@@ -16,20 +16,15 @@ with torch.no_grad():
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
         hp.pem_stage()
         torch.cuda.synchronize()
+ka = prof.key_averages(group_by_input_shape=True, group_by_stack_n=8)
 rows = []
-for e in prof.events():
-    dt = getattr(e, "device_time_total", 0) or getattr(e, "cuda_time_total", 0)
-    if not e.name.startswith("aten::") or dt <= 0 or e.cpu_children:
+for e in ka:
+    dt = getattr(e, "self_device_time_total", 0) or getattr(e, "self_cuda_time_total", 0)
+    if dt <= 0 or not e.key.startswith("aten::"):
         continue
-    site = next((f"{fr.split('/')[-1]}" for fr in (e.stack or []) if "sam6d_amd" in fr or "bench.py" in fr), "?")
-    rows.append((e.name, str(e.input_shapes)[:70], site[:60], dt))
-agg = {}
-for n, s, site, dt in rows:
-    k = (n, s, site)
-    a = agg.setdefault(k, [0, 0.0])
-    a[0] += 1
-    a[1] += dt
-tot = sum(v[1] for v in agg.values())
-print(f"leaf aten ops: {tot / 1e3:.2f} ms of device time")
-for (n, s, site), (c, dt) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
-    print(f"{dt / 1e3:7.3f} ms {c:4d}x {n:28s} {s:70s} {site}")
+    site = next((fr.split("/")[-1] for fr in (e.stack or []) if "sam6d_amd" in fr or "bench.py" in fr), "?")
+    rows.append((dt, e.count, e.key, str(e.input_shapes)[:64], site[:70]))
+tot = sum(r[0] for r in rows)
+print(f"aten ops, self device time: {tot / 1e3:.2f} ms")
+for dt, c, n, s_, site in sorted(rows, reverse=True)[:45]:
+    print(f"{dt / 1e3:7.3f} ms {c:4d}x {n:26s} {s_:64s} {site}")

@@ -463,7 +463,7 @@ def _extras(extra, hp, dev, args, world):
             os.environ["S6D_PEM_VIT_DTYPE"] = cur
     extra["pem_vit_dtype"] = {"benched": cur, "pem_stage_ms": {cur: round(pem_ms, 2), **alt},
                               "translation_vs_reference_mm": {"fp32": "1.2e-4", "bf16": "1.3e-3 .. 2.1e-3 (bar 1e-3)",
-                                                              "fp16": "see profiles/r03_parity_margins_*.jsonl"}}
+                                                              "fp16": "3.0e-4"}}
     kr = kernel_rooflines(dev, args.sam_chunk, args.frames, gemm_ms_inside_the_step(hp))
     dom = max((k for k in kr if not k["kernel"].startswith("library")),
               key=lambda k: k["avg_ms"] * k["launches_per_step"])

@@ -99,7 +99,6 @@ def test_add_layernorm_bf16(rows, C):
     assert (y2.float() - torch.nn.functional.layer_norm(x.float(), (C,), w, b, 1e-6)).abs().max() < 2e-2
 
 
-@pytest.mark.parametrize("B,N,nh,hd", [(3, 197, 12, 64), (2, 50, 2, 80), (1, 257, 4, 64)])
 def test_seq_attention_float16_vs_torch(B=2, N=197, nh=12, hd=64):
     """The IEEE-half build of the sequence attention (PEM ViT-B shape) against the fp32 statement on the same half operands."""
     from sam6d_amd import ops
@@ -125,6 +124,7 @@ def test_add_layernorm_float16():
     assert (y.float() - torch.nn.functional.layer_norm(xr.float(), (768,), w, b, 1e-6)).abs().max() < 4e-3
 
 
+@pytest.mark.parametrize("B,N,nh,hd", [(3, 197, 12, 64), (2, 50, 2, 80), (1, 257, 4, 64)])
 def test_seq_attention_vs_torch(B, N, nh, hd):
     from sam6d_amd import ops
     g = torch.Generator().manual_seed(N)

@@ -1,0 +1,92 @@
+"""ONE frame through the whole chain in the reference's order against tests/golden/frame.npz (VERDICT r2 missing #7): the
+reference's Data/Example frame, ten deterministic proposals, synthetic descriptors; golden made by the reference's own
+statements -- ISM scoring methods, Detections / save_to_file / convert_npz_to_json, the score threshold of get_test_data, its
+rle decoder, the reference Net and its result statements (oracle/gen_golden.py frame; the per-detection loop in between is the
+oracle's, pycocotools / cv2 not being installable) -- and the PRODUCT functions chained the same way here."""
+import ast
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from sam6d_amd.utils import seeded, synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def test_frame_chain_vs_reference_golden():
+    run_chain(torch.device("cuda", 0))
+
+
+def run_chain(dev, net_check=True):
+    from sam6d_amd.ism.handoff import Detections, detection_records
+    from sam6d_amd.ism.scoring import FrameScorer
+    from sam6d_amd.pem import pose_estimation_model as pm
+    from sam6d_amd.pem import preprocess as pre
+    from sam6d_amd.pem import results
+    g = util.golden("frame.npz")
+    c = ast.literal_eval(str(g["case"]))
+    inp = util.frame_inputs(c)
+    T = lambda k: inp[k].to(dev)
+    # ---- ISM scoring (run_inference_custom.py:168-199): selection, pixels, scores
+    fs = FrameScorer(T("ref_cls"), T("ref_patch"), T("poses"), T("pointcloud"))
+    sc = fs.score(T("qry_cls"), T("qry_patch"), T("masks"), T("boxes"), T("depth_mm"), inp["K"], depth_scale=inp["depth_scale"])
+    assert sc["sel"].cpu().tolist() == g["ism_sel"].tolist()
+    assert np.array_equal(sc["image_uv"].cpu().numpy(), g["ism_image_uv"])
+    assert np.array_equal(sc["best_template"].cpu().numpy(), g["ism_best_template"])
+    for k in ("semantic", "appearance", "visible_ratio", "final"):
+        np.testing.assert_allclose(sc[k].cpu().numpy(), g["ism_" + k], rtol=0, atol=1e-5, err_msg=k)
+    iou = torch.as_tensor(sc["iou"]).cpu().numpy() * np.ones(len(g["ism_sel"]), np.float32)
+    np.testing.assert_allclose(iou, g["ism_iou"], rtol=0, atol=1e-6)
+    # ---- hand-off records (Detections.save_to_file -> convert_npz_to_json)
+    sel = sc["sel"]
+    det = Detections(0, 0, T("masks")[sel] > 0, T("boxes")[sel], sc["final"], torch.zeros_like(sc["final"]).long())
+    recs = detection_records(det, "Custom")
+    ref = json.loads(str(g["ism_json"]))
+    assert len(recs) == len(ref)
+    for a, b in zip(recs, ref):
+        assert a["segmentation"] == b["segmentation"] and a["bbox"] == b["bbox"] and a["category_id"] == b["category_id"]
+        assert abs(a["score"] - b["score"]) < 1e-5
+    # ---- the PEM's score threshold, its pre-processing with the reference's own draws, the Net, the result records
+    keep = [i for i, r in enumerate(recs) if r["score"] > c["det_score_thresh"]]
+    assert keep == g["kept_ism"].tolist()
+    depth_m = T("depth_mm") * inp["depth_scale"] / 1000.0
+    obs = pre.observed_inputs(torch.from_numpy(inp["rgb"]).to(dev), depth_m, inp["K"], det.masks[keep], inp["radius"],
+                              rng=np.random.RandomState(c["rng_seed"]))
+    assert obs["kept"].cpu().tolist() == g["kept_pre"].tolist()
+    np.testing.assert_array_equal(obs["pts"].cpu().numpy(), g["pts"])
+    np.testing.assert_array_equal(obs["rgb_choose"].cpu().numpy(), g["rgb_choose"])
+    util.assert_digest_close(obs["rgb"].cpu(), g["rgb_sum"], g["rgb_smp"], 4099, 1e-6, 1e-6, "rgb crops")
+    if not net_check:
+        return
+    import os
+    M = obs["pts"].shape[0]
+    net = seeded.load_seeded(pm.Net(pm.default_cfg()).eval(), c["weight_seed"]).to(dev)
+    dense_fo = torch.randn(1, 2048, 256, generator=torch.Generator().manual_seed(c["feat_seed"])).expand(M, -1, -1).contiguous().to(dev)
+    ep = dict(pts=obs["pts"], rgb=obs["rgb"], rgb_choose=obs["rgb_choose"],
+              model=torch.from_numpy(inp["model"])[None].expand(M, -1, -1).contiguous().to(dev),
+              dense_po=torch.from_numpy(inp["dense_po"])[None].expand(M, -1, -1).contiguous().to(dev), dense_fo=dense_fo,
+              coarse_rand_u=synth.coarse_uniforms(M, c["rand_seed"]).to(dev))
+    old = os.environ.get("S6D_PEM_VIT_DTYPE")
+    os.environ["S6D_PEM_VIT_DTYPE"] = "fp32"             # template features unrelated to the ViT's output: fp32-class features only
+    try:
+        with torch.no_grad():
+            out = net(ep)
+    finally:
+        os.environ.pop("S6D_PEM_VIT_DTYPE") if old is None else os.environ.__setitem__("S6D_PEM_VIT_DTYPE", old)
+    dR = np.linalg.norm(out["pred_R"].cpu().numpy() - g["pred_R"], axis=(1, 2)).max()
+    dt = np.abs(out["pred_t"].cpu().numpy() - g["pred_t"]).max()
+    util.record_margin("frame_chain", dR=dR, dt_m=dt)
+    assert dR <= 1e-3 and dt <= 1e-6, (dR, dt)
+    sub = [recs[i] for i in keep]
+    sub = [sub[i] for i in obs["kept"].cpu().tolist()]
+    s = results.combined_scores(out["pred_pose_score"], det.scores[keep][obs["kept"]])
+    mine = results.detection_pem_records(sub, s, out["pred_R"], out["pred_t"])
+    want = json.loads(str(g["pem_json"]))
+    assert len(mine) == len(want)
+    for a, b in zip(mine, want):
+        assert a["segmentation"] == b["segmentation"] and a["bbox"] == b["bbox"]
+        assert abs(a["score"] - b["score"]) < 2e-3                                         # pose score: a ratio of counted inliers
+        assert np.abs(np.array(a["R"]) - np.array(b["R"])).max() < 1e-3 and np.abs(np.array(a["t"]) - np.array(b["t"])).max() < 1e-3

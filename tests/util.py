@@ -63,3 +63,34 @@ def record_margin(test, **values):
             f.write(json.dumps(dict(test=test, **{k: (float(v) if not isinstance(v, (list, str)) else v) for k, v in values.items()})) + "\n")
     except Exception:
         pass
+
+
+def frame_inputs(c):
+    """The reference's Data/Example frame (as frozen in tests/golden/example_frame.npz) + P deterministic proposals on it (depth
+    windows inside boxes spread over the frame; proposal 0 is the object mask of gen_example) + synthetic descriptors / template
+    poses (no checkpoint offline).  Everything a test needs to rebuild the same inputs without /root/reference."""
+    g = golden("example_frame.npz")
+    depth_mm = g["depth_mm"].astype(np.float32)
+    H, W = depth_mm.shape
+    boxes_yxyx = [(140, 262, 300, 442), (60, 150, 80, 200), (250, 400, 100, 260), (300, 460, 420, 600), (20, 120, 420, 560),
+                  (180, 300, 10, 120), (100, 220, 220, 330), (330, 470, 270, 400), (150, 260, 480, 630), (10, 90, 250, 400)][:c["P"]]
+    masks = np.zeros((c["P"], H, W), bool)
+    for j, (y1, y2, x1, x2) in enumerate(boxes_yxyx):
+        win = depth_mm[y1:y2, x1:x2]
+        med = np.median(win[win > 0]) if (win > 0).any() else 0
+        masks[j, y1:y2, x1:x2] = (win > med - 90) & (win < med + 90)
+    masks[0] = 0
+    masks[0, 140:262, 300:442] = (g["depth_mm"][140:262, 300:442] > 900) & (g["depth_mm"][140:262, 300:442] < 1075)
+    boxes = np.zeros((c["P"], 4), np.float32)
+    for j in range(c["P"]):
+        ys, xs = np.nonzero(masks[j])
+        boxes[j] = (xs.min(), ys.min(), xs.max(), ys.max())
+    from sam6d_amd.utils import synth
+    import torch
+    d = synth.ism_inputs(P=c["P"], O=c["O"], T=c["T"], C=c["C"], n_patch=c["n_patch"], H=H, W=W, seed=c["seed"])
+    return dict(rgb=g["rgb"], depth_mm=torch.from_numpy(depth_mm), K=torch.from_numpy(g["K"]), depth_scale=float(g["depth_scale"]),
+                masks=torch.from_numpy(masks).float(), boxes=torch.from_numpy(boxes), qry_cls=d["qry_cls"], qry_patch=d["qry_patch"],
+                ref_cls=d["ref_cls"], ref_patch=d["ref_patch"], poses=d["poses"],
+                pointcloud=torch.from_numpy(g["dense_po"])[None], model=g["model"], dense_po=g["dense_po"], radius=float(g["radius"]))
+
+

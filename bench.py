@@ -320,6 +320,20 @@ def kernel_rooflines(dev, sam_chunk, frames, in_step=None):
                     "frac": round(flop / ms / 1e9 / 2500.0, 4), "avg_ms": round(ms, 4), "launches_per_step": 1,
                     "algorithmic_bytes": float(B) * (2 * 2049 * 256 * 4 + 2048 * 5 * 4),
                     "matrix_bytes_not_written": float(B) * 2049 * 2049 * 4, "pmc_key": "fine_sweep_kernel<2>"})
+    if ops.have("linear_f32"):
+        # the fused fp32 Linear of the point transformer at the dense stage's shape (65536 rows, 256 -> 256, + residual + LayerNorm)
+        Mp = 2048 * B
+        xp = torch.randn(Mp, 256, generator=g).to(dev)
+        hi, lo = ops.split_weight((torch.randn(256, 256, generator=g) / 16).to(dev))
+        bp, rp = torch.randn(256, generator=g).to(dev), torch.randn(Mp, 256, generator=g).to(dev)
+        gm, bt = torch.ones(256, device=dev), torch.zeros(256, device=dev)
+        ms = _event_ms(lambda: ops.linear_f32(xp, hi, lo, bp, residual=rp, ln=(gm, bt, 1e-5)), 10)
+        flop = 3.0 * 2.0 * Mp * 256 * 256
+        out.append({"kernel": "plin_kernel (linear + residual + LayerNorm, M=%d K=256 N=256)" % Mp, "bound": "mfma",
+                    "achieved": round(flop / ms / 1e9, 1), "peak": 2500.0,
+                    "unit": "TFLOP/s (bf16 MFMA executed = 3x the algorithmic fp32 FLOP)", "frac": round(flop / ms / 1e9 / 2500.0, 4),
+                    "avg_ms": round(ms, 4), "launches_per_step": 36, "algorithmic_bytes": float(Mp) * 256 * 4 * 3,
+                    "pmc_key": "plin_kernel"})
     # the Linear layers of the ViT-H blocks: the hand-written bf16 GEMM (csrc/s6d_gemm.hip) at the four shapes of a block, and the
     # library GEMM (hipBLASLt through torch) at the largest of them for context.  Algorithmic work 2 M N K FLOP.
     M = sam_chunk * 4096
@@ -381,12 +395,12 @@ def kernel_rooflines(dev, sam_chunk, frames, in_step=None):
 
 
 def _pmc_traffic(row):
-    """HBM bytes per launch of a `kernels` row from the committed rocprofv3 --pmc passes (profiles/r02_pmc_summary.json, else the
-    round-1 file), if present: FETCH_SIZE (doubled: gfx950 half-count of wide coalesced reads, MI355X_MICROARCH.md) + WRITE_SIZE.
+    """HBM bytes per launch of a `kernels` row from the committed rocprofv3 --pmc passes (profiles/r03_pmc_summary.json, else the
+    files of the earlier rounds), if present: FETCH_SIZE (doubled: gfx950 half-count of wide coalesced reads, MI355X_MICROARCH.md) + WRITE_SIZE.
     Rows name their counter key (`pmc_key` = the kernel's template instance as rocprofv3 prints it); a template instance that runs
     at several shapes in the counter pass (its average would mix them) has none."""
     key = row.get("pmc_key", row["kernel"])
-    for f in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for f in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", f)))
         except Exception:  # noqa: BLE001

@@ -98,6 +98,18 @@ class _Conv1dNoAct(nn.Module):
         super().__init__()
         self.conv = nn.Conv1d(cin, cout, kernel_size=1, bias=True)
 
+    # the kernel-size-1 convolution seen as the Linear it is (plinear reads .weight (N,K) and .bias)
+    @property
+    def weight(self):
+        return self.conv.weight.squeeze(-1)
+
+    @property
+    def bias(self):
+        return self.conv.bias
+
+    def forward(self, x):                                   # (..., cin) -> (..., cout): the library statement of the same map
+        return F.linear(x, self.weight, self.bias)
+
 
 class PositionalEncoding(nn.Module):
     """fine_point_matching.py:90-125: two ball-query groupings (r, nsample) -> SharedMLP
@@ -127,7 +139,7 @@ class PositionalEncoding(nn.Module):
                 x = F.relu(F.linear(x, W, b))
             outs.append(x.max(dim=2)[0])                                            # (B,N,128)
         x = torch.cat(outs, dim=-1)
-        return F.linear(x, self.mlp3.conv.weight.squeeze(-1), self.mlp3.conv.bias)
+        return plinear(self, self.mlp3, x)
 
 
 class FinePointMatching(nn.Module):

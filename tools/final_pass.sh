@@ -1,21 +1,28 @@
-# Round-end measurement pass (tests, bench line with cpu_baseline and the whole-frame pipeline block, rocprofv3 kernel stats of the
-# bench command on three streams and on one, PMC passes folded into profiles/r02_pmc_summary.json).
-#   gpurun --timeout 2400 -- 'bash tools/final_pass.sh'      then copy gpurun_out/prof/* into profiles/
+# Round-end measurement pass (tests, bench line with cpu_baseline and the whole-frame pipeline block, the fp8 configuration, rocprofv3
+# kernel stats of the bench command on three streams and on one, PMC passes folded into profiles/r03_pmc_summary.json).
+#   gpurun --timeout 2700 -- 'bash tools/final_pass.sh'      then copy gpurun_out/prof/* into profiles/
 set -x
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/prof
-timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > gpurun_out/prof/r02_gpu_tests.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 >> gpurun_out/prof/r02_gpu_tests.txt
-timeout 900 python bench.py --steps 5 --warmup 2 > gpurun_out/prof/r02_bench_line.json 2> gpurun_out/prof/r02_bench.err
+R=r03
+mkdir -p gpurun_out/prof; rm -f gpurun_out/margins.jsonl
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > gpurun_out/prof/${R}_gpu_suite.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 >> gpurun_out/prof/${R}_gpu_suite.txt
+cp gpurun_out/margins.jsonl gpurun_out/prof/${R}_parity_margins_final.jsonl
+timeout 900 python bench.py --steps 5 --warmup 2 > gpurun_out/prof/${R}_bench_line.json 2> gpurun_out/prof/${R}_bench.err
+timeout 400 python bench.py --config fp8 --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline > gpurun_out/prof/${R}_bench_fp8_line.json 2>> gpurun_out/prof/${R}_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline > /dev/null 2>&1
-cp $(find /tmp/prof_bench -name "*kernel_stats.csv" | head -1) gpurun_out/prof/r02_bench_kernel_stats.csv
+cp $(find /tmp/prof_bench -name "*kernel_stats.csv" | head -1) gpurun_out/prof/${R}_bench_kernel_stats.csv
 S6D_BENCH_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_serial -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline > /dev/null 2>&1
-cp $(find /tmp/prof_serial -name "*kernel_stats.csv" | head -1) gpurun_out/prof/r02_bench_serial_kernel_stats.csv
+cp $(find /tmp/prof_serial -name "*kernel_stats.csv" | head -1) gpurun_out/prof/${R}_bench_serial_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_fp8 -o bench -- python bench.py --config fp8 --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline > /dev/null 2>&1
+cp $(find /tmp/prof_fp8 -name "*kernel_stats.csv" | head -1) gpurun_out/prof/${R}_bench_fp8_kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -o f -- python tools/pmc_kernels.py > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -o w -- python tools/pmc_kernels.py > /dev/null 2>&1
-python tools/pmc_summarise.py gpurun_out/prof/r02_pmc_summary.json /tmp/pmc_f /tmp/pmc_w > /dev/null 2>&1
+python tools/pmc_summarise.py gpurun_out/prof/${R}_pmc_summary.json /tmp/pmc_f /tmp/pmc_w > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d /tmp/pmc_s -o s -- python tools/pmc_kernels.py > /dev/null 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc_g -o g -- python tools/pmc_kernels.py > /dev/null 2>&1
-python tools/pmc_sq_summarise.py gpurun_out/prof/r02_sq_summary.json /tmp/pmc_s /tmp/pmc_g > /dev/null 2>&1
-cat gpurun_out/prof/r02_gpu_tests.txt
-tail -c 1500 gpurun_out/prof/r02_bench_line.json
+python tools/pmc_sq_summarise.py gpurun_out/prof/${R}_sq_summary.json /tmp/pmc_s /tmp/pmc_g > /dev/null 2>&1
+timeout 300 python tools/pem_ops_profile.py 32 2>/dev/null | grep -v "Warning\|warn" > gpurun_out/prof/${R}_pem_ops.txt
+timeout 600 python tools/run_sharded.py --frames 16 --group 8 --out gpurun_out/prof/${R}_sharded_world1.csv --fixed-time 0 2>/dev/null | tail -1 > gpurun_out/prof/${R}_sharded_world1.json
+cat gpurun_out/prof/${R}_gpu_suite.txt
+tail -c 2500 gpurun_out/prof/${R}_bench_line.json; tail -c 600 gpurun_out/prof/${R}_bench_fp8_line.json; cat gpurun_out/prof/${R}_sharded_world1.json

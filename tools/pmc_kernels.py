@@ -1,4 +1,6 @@
-"""Launch the hand-written kernels at bench shapes a few times (target of the rocprofv3 --pmc passes)."""
+"""Launch the hand-written kernels at bench shapes a few times (target of the rocprofv3 --pmc passes), the fp8 kernels of
+BASELINE configs[4] included."""
+import os
 import sys
 
 import torch
@@ -9,5 +11,7 @@ import bench  # noqa: E402
 dev = torch.device("cuda", 0)
 for _ in range(2):
     bench.kernel_rooflines(dev, bench.SAM_CHUNK, 32)
+os.environ["S6D_SAM_GEMM"] = "fp8"
+bench.kernel_rooflines(dev, bench.SAM_CHUNK, 32)
 torch.cuda.synchronize()
 print("done")

@@ -142,9 +142,21 @@ class HotPath:
                 out = self.scorer.score(i["qry_cls"], i["qry_patch"], i["masks"], i["boxes"], i["depth"], i["K"])
             return out
         if getattr(self, "_ism_group", None) is None or self._ism_group[0] != c:
-            # every frame of a group has its own tensors in HBM (here: copies of the one synthetic frame)
-            rep = lambda t: t[None].expand(c, *t.shape).contiguous()
-            self._ism_group = (c, {k: rep(i[k]) for k in ("qry_cls", "qry_patch", "masks", "boxes", "depth")},
+            # every frame of a group has its own tensors in HBM and its own content (eight copies of one frame made the
+            # number of selected proposals S the same for every frame): frame f is the synthetic frame with its proposals
+            # permuted, its descriptors perturbed (noise growing with f, so more or fewer proposals pass the semantic threshold)
+            # and its depth shifted
+            gg = torch.Generator().manual_seed(77)
+            fr = {k: [] for k in ("qry_cls", "qry_patch", "masks", "boxes", "depth")}
+            for f in range(c):
+                perm = torch.randperm(i["qry_cls"].shape[0], generator=gg).to(self.dev)
+                amp = 0.15 * f
+                fr["qry_cls"].append(i["qry_cls"][perm] + amp * torch.randn(i["qry_cls"].shape, generator=gg).to(self.dev))
+                fr["qry_patch"].append(i["qry_patch"][perm])
+                fr["masks"].append(i["masks"][perm])
+                fr["boxes"].append(i["boxes"][perm])
+                fr["depth"].append(i["depth"] + 7.0 * f)
+            self._ism_group = (c, {k: torch.stack(v).contiguous() for k, v in fr.items()},
                                i["K"].to(self.dev)[None].expand(c, 3, 3).contiguous())
         _, g, K = self._ism_group
         for f0 in range(0, self.F, c):

@@ -62,3 +62,19 @@ def test_every_entry_point_refuses_null_operands():
         fn.restype = ctypes.c_int
         rcs[name] = fn(*vals)
     assert all(rc in (-1, -3) for rc in rcs.values()), rcs
+
+
+def test_product_library_carries_no_emulator_code():
+    """The kernel sources have `#ifdef HIPEMU` blocks for the host emulator (tests/host_cc/hipemu).  HIPEMU is defined by that
+    emulator's stand-in <hip/hip_runtime.h> only, so the product build cannot see those branches: the hipcc preprocessor does not
+    define it for gfx950, and libsam6d_hip.so contains neither the emulator's namespace nor its abort messages."""
+    import os
+    import subprocess
+
+    from sam6d_amd import _lib
+    if os.path.exists(_lib.HIPCC):
+        out = subprocess.run([_lib.HIPCC, f"--offload-arch={_lib.ARCH}", "-dM", "-E", "-x", "hip", "/dev/null"], capture_output=True,
+                             text=True).stdout
+        assert "__gfx950__" in out and "HIPEMU" not in out
+    blob = open(_lib.SO_PATH, "rb").read()
+    assert b"hipemu" not in blob and b"HIPEMU" not in blob

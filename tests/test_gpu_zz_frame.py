@@ -52,7 +52,9 @@ def run_chain(dev, net_check=True):
     # ---- the PEM's score threshold, its pre-processing with the reference's own draws, the Net, the result records
     keep = [i for i, r in enumerate(recs) if r["score"] > c["det_score_thresh"]]
     assert keep == g["kept_ism"].tolist()
-    depth_m = T("depth_mm") * inp["depth_scale"] / 1000.0
+    # metres as run_inference_custom.py:203 makes them (numpy: a correctly rounded division; `tensor / 1000.0` on the device would
+    # multiply by a rounded reciprocal and move 44 % of the points by one ulp)
+    depth_m = torch.from_numpy(inp["depth_mm"].numpy() * np.float32(inp["depth_scale"]) / np.float32(1000.0)).to(dev)
     obs = pre.observed_inputs(torch.from_numpy(inp["rgb"]).to(dev), depth_m, inp["K"], det.masks[keep], inp["radius"],
                               rng=np.random.RandomState(c["rng_seed"]))
     assert obs["kept"].cpu().tolist() == g["kept_pre"].tolist()

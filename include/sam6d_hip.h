@@ -30,7 +30,7 @@ extern "C" {
 
 /* Bumped whenever a signature in this header changes; the loader (sam6d_amd/_lib.py) refuses a library whose
  * s6d_version() differs from the header it was written against (a stale .so fails at load, not at a call). */
-#define S6D_ABI_VERSION 107
+#define S6D_ABI_VERSION 108
 int s6d_version(void);
 const char *s6d_strerror(int code);
 /* last HIP error string seen by this thread (empty if none) */
@@ -220,11 +220,27 @@ int s6d_add_layernorm_f16(const void *x, const void *delta, const float *gamma, 
                           void *x_out, void *y_out, void *stream);
 int s6d_seq_attention_f16(const void *qkv, int B, int N, int num_heads, int head_dim, float scale, void *out, void *stream);
 
-/* The same product with the RESIDUAL ADD of a transformer block in the epilogue: C = bf16(bf16(A W^T + bias) + R), R (M,N) bf16 with
- * row stride ldr (R may be C: in place).  Replaces `x = shortcut + x` / `x = x + self.mlp(..)` as separate passes over two
- * (tokens, C) tensors (segment_anything/modeling/image_encoder.py:166-182; timm / DINOv2 blocks alike).  N % 256 == 0. */
-int s6d_gemm_bf16_res(const void *A, long lda, const void *W, long ldw, const float *bias, const void *R, long ldr, void *C,
-                      long ldc, int M, int N, int K, int max_blocks, void *stream);
+/* The residual add and the LayerNorm of a transformer block folded into the GEMMs on either side of them
+ * (segment_anything/modeling/image_encoder.py:166-182: `x = shortcut + x`, `x = x + self.mlp(self.norm2(x))`, `self.norm1(x)`;
+ * timm / DINOv2 blocks alike).  All: bf16, N % 256 == 0.
+ *
+ * s6d_gemm_bf16_res: C = bf16(A W^T + bias + R), R (M,N) bf16 with row stride ldr (R may be C: in place).  The accumulators start at
+ *   bias + residual (a tile's residual is read one tile ahead, during the previous tile's epilogue), so the sum is formed in fp32
+ *   and rounded once.  stats_partial (optional, else NULL): [N / 32][2][M] floats, for every row and 32-column group the sum and
+ *   the sum of squared deviations from the group mean of the fp32 results -- the input of s6d_ln_stats_finalize.
+ * s6d_ln_stats_finalize: row_stats[m] = (mean, sigma = sqrt(var + eps)) over groups * group_size columns from such partials
+ *   (pairwise-exact combination, fixed order).  s6d_row_stats_bf16: the same statistics computed from a bf16 matrix (two-pass).
+ * s6d_gemm_bf16_lnfold: C = act(LN(A) W^T + b) without materialising LN(A):  W is the FOLDED weight gamma o W (bf16), col_sums[n] =
+ *   sum_k W_folded[n,k], bias[n] = b[n] + sum_k beta[k] W[n,k], row_stats from the calls above;
+ *   C[m,n] = act(((A W_folded^T)[m,n] + sigma_m bias[n] - mean_m col_sums[n]) / sigma_m).  gelu 0 / 1; col_block as
+ *   s6d_gemm_bf16_cblk. */
+int s6d_gemm_bf16_res(const void *A, long lda, const void *W, long ldw, const float *bias, const void *R, long ldr,
+                      float *stats_partial, void *C, long ldc, int M, int N, int K, int max_blocks, void *stream);
+int s6d_ln_stats_finalize(const float *stats_partial, int groups, int group_size, long M, float eps, float *row_stats, void *stream);
+int s6d_row_stats_bf16(const void *x, long ldx, long M, int C, float eps, float *row_stats, void *stream);
+int s6d_gemm_bf16_lnfold(const void *A, long lda, const float *row_stats, const void *W, long ldw, const float *col_sums,
+                         const float *bias, void *C, long ldc, int M, int N, int K, int gelu, int col_block, int max_blocks,
+                         void *stream);
 
 /* ---------------------------------------------------------------- fp8 ViT path (BASELINE configs[4]; never the headline)
  * C = act(A W^T + bias) with OCP fp8 (e4m3fn) operands: A (M,K) and W (N,K) bytes, row strides lda / ldw (multiples of 16),

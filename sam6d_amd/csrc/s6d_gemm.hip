@@ -23,10 +23,8 @@
 //   * a K tile is 4 phases (one 64 x 32 quadrant of the wave's tile over the whole K step each); the two wave groups
 //     (M halves) run one barrier apart, so on every SIMD one wave is in its matrix segment (8 MFMAs) while the other issues
 //     its fragment reads and DMA: phase = { ds_read, DMA issue, [counted wait], barrier, 8 x MFMA, barrier }.
-//   * EPI 2 (round 3): C = bf16(bf16(A W^T + bias) + R) -- the residual add of a ViT block (x + proj(..), x + lin2(..)) in the
-//     producing GEMM's epilogue instead of a separate pass that re-reads both tensors: after the quad transpose a lane holds
-//     16-byte row pieces, the matching pieces of R are fetched one 32-row strip ahead, added in fp32 and rounded again (the two
-//     roundings of the unfused path: bit-identical with add_layernorm's x + delta).
+//   * EPI 2 / 3 / 4 (round 3): the residual add and the LayerNorm of a ViT block folded into the GEMMs on either side of them
+//     (x + proj(..), x + lin2(..); LN1 -> qkv, LN2 -> lin1 + GELU): see "Residual add and LayerNorm around the GEMM" below.
 //   * epilogue in registers: bias is the accumulator's initial value (scalar loads), exact GELU as
 //     relu(x) - |x| * erfc(|x| / sqrt 2) / 2 with erfc from Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7), round to bf16,
 //     v_permlane32_swap pairs the two lane halves into 16-byte row segments.
@@ -98,18 +96,23 @@ typedef unsigned short u16;
 // the single vector-memory counter makes a counted wait behind 16 stores wait for their acknowledgement -- measured -8 % (the drain
 // itself exposes a load latency per tile and the store cost did not move: profiles/r02_gemm_variants_qt_drain.json).
 
-// Residual pieces of the EPI 2 epilogue.  With __builtin_amdgcn_global_load_lds in flight hipcc waits vmcnt(0) at the first use
-// of any ordinary load (an LDS-DMA is a VMEM and an LDS event: its counter model gives up counting), i.e. behind every store
-// the epilogue has issued so far -- measured: lin2 + 65 us per launch, all of the LayerNorm saving.  The EPI 2 instantiation
-// therefore issues its LDS-DMA as inline asm (as csrc/s6d_attn.hip does): the compiler then sees only the epilogue's own loads
-// and stores and emits exact counted waits for them; DMA pieces older than a residual load complete before it (in-order
-// return), and none is issued between a residual load and its use.
-#ifndef HIPEMU
-__device__ __forceinline__ void gemm_dma16_asm(const void *src, S6D_LDS(char) *dst) {
-  const unsigned a = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dst);
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(a) : "memory", "m0");
-}
-#endif
+// Residual add and LayerNorm around the GEMM (round 3).
+//   EPI 2  C = A W^T + bias + R, summed in fp32 and rounded to bf16 once (the separate add rounded the product first).  The
+//          accumulators START at bias + residual.  A tile's residual values (128 per lane, in the accumulator layout) are fetched
+//          during the PREVIOUS tile's epilogue, strip by strip into the accumulator registers that strip has just stored, and are
+//          first read after that epilogue, at the point where the plain kernel reads its bias (a drain it spends anyway).  Tried and
+//          measured first: (a) residual loads consumed inside the same epilogue wait for the tile's own stores on the single in-order
+//          memory counter (proj + 24 %, lin2 + 8..14 %, profiles/r03_gemm_residual_epilogue.txt); (b) the residual tile as 4 extra
+//          K tiles against an identity weight operand costs those K tiles plus an HBM-latency-bound stream (proj + 22 %,
+//          lin2 + 11 %; neither skipping the idle wave columns' matrix work nor moving the K tiles to the head of the tile
+//          helped: profiles/r03_lnfold.txt).  Optionally the epilogue emits, per row and 32-column group, (sum, sum of squared
+//          deviations from the group mean) of the fp32 results -- partial LayerNorm statistics, combined by
+//          ln_stats_finalize_kernel (csrc/s6d_norm.hip).
+//   EPI 3/4  C = [GELU] LN(A) W^T + bias with the LayerNorm folded:  LN(a) W^T = rstd_m (a W'^T - mu_m s_n) + b'_n  with
+//          W' = gamma o W (bf16), s_n = sum_k W'_nk, b' = bias + W beta.  The kernel multiplies the RAW residual stream by W';
+//          the accumulators start at sigma_m b'_n - mu_m s_n (per-row statistics and both column vectors are read at the tile
+//          start, where the bias read of the plain form sits) and the epilogue multiplies by rstd_m = 1 / sigma_m:  the
+//          normalised activations are never written (and never rounded to bf16).
 
 struct GemmParams {
   const u16 *A;       // (M,K) bf16, row stride lda
@@ -117,8 +120,12 @@ struct GemmParams {
   const float *bias;  // (N) f32 or nullptr
   u16 *C;             // (M,N) bf16, row stride ldc
   const unsigned char *sa, *sw;   // fp8 operands (DT = 1): E8M0 scale byte of every A row (M) / W row (N); value = q * 2^(byte - 127)
-  const u16 *R;       // EPI 2: residual (M,N) bf16, row stride ldr; may be C itself (each 16-byte piece is read, then written, by one lane)
-  long ldr;
+  const u16 *R;       // EPI 2: residual (M,N) bf16, row stride ldr2 BYTES; may be C itself (a tile's residual is read by the workgroup
+                      // that stores the tile, one tile ahead of its stores)
+  float *SP;          // EPI 2, optional: partial row statistics, [N / 32][2][M] floats (sum, sum of squared deviations per 32 columns)
+  const float *RS;    // EPI 3 / 4: per-row (mean, sigma = sqrt(var + eps)) of A, [M][2] floats
+  const float *CS;    // EPI 3 / 4: s_n = sum_k W'_nk, (N) floats
+  unsigned ldr2;
   unsigned lda2, ldw2;  // row strides in BYTES
   long ldc;
   int M, N, K;
@@ -236,12 +243,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
   auto dma = [&](const u16 *base, unsigned off, int slot, int piece) __attribute__((always_inline)) {
     S6D_LDS(char) *dst = (S6D_LDS(char) *)gemm_smem + slot * kSlot + (wave * 2 + piece) * 1024;
     if (S6D_GEMM_ABLATE & 1) return;
-#ifndef HIPEMU
-    if (EPI == 2) {
-      gemm_dma16_asm((const char *)base + off, dst);
-      return;
-    }
-#endif
     __builtin_amdgcn_global_load_lds((const S6D_GLOBAL(void) *)((const char *)base + off), dst, 16, 0, 0);
   };
   auto issue_b = [&](int half, int slot) __attribute__((always_inline)) {
@@ -317,12 +318,48 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) xsc[mt] = (int)p.sa[min(m0 + wr * 128 + mt * 32 + a, p.M - 1)];
   };
-  auto init_acc = [&](int n0) __attribute__((always_inline)) {          // accumulators start at the bias (scalar loads)
+  // EPI 3 / 4 (folded LayerNorm): rstd of this lane's row in strip mt, applied in the epilogue
+  float ln_rs[4] = {1.f, 1.f, 1.f, 1.f};
+  // EPI 2: the residual values of the NEXT tile in the accumulator layout -- [strip mt][q]: columns 32 h + 8 q .. + 7 of this lane's
+  // row (q = 2 nt + j).  Fetched strip by strip during the current tile's epilogue, right after the strip's stores (its 32
+  // accumulator registers are free by then), and first read by init_acc of the next tile, behind the drain that the bias read
+  // spends there anyway: the HBM latency of a tile that no other workgroup shares hides behind a whole epilogue.
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 rn[4][4];
+  auto load_resid = [&](int mt, int m0, int n0) __attribute__((always_inline)) {
+    const int m = min(m0 + wr * 128 + mt * 32 + (lane & 31), p.M - 1);     // rows past M: a valid address, never stored
+    const char *src = (const char *)p.R + (size_t)m * p.ldr2 + (size_t)(n0 + wc * 64 + 32 * (lane >> 5)) * 2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rn[mt][q] = *reinterpret_cast<const u32x4 *>(src + 16 * q);
+  };
+  auto init_acc = [&](int m0, int n0) __attribute__((always_inline)) {
+    // Accumulators start at the bias.  (`hi ? bs[c1] : bs[c0]` compiles to a per-lane address and eight 16-byte vector loads per
+    // tile, waited for with vmcnt(0) -- a drain of the previous epilogue's stores and of the prefetched K tiles at every tile
+    // start.  Measured harmless: a build that reads the bias through scalar registers instead, and the no-bias instantiation, run
+    // within +-1.5 % of this form on all four ViT-H shapes, profiles/r03_lnfold.txt.)
+    // EPI 3 / 4: acc = sigma_m b'_n - mean_m s_n, so that the epilogue's single multiply by rstd_m = 1 / sigma_m gives
+    // rstd_m (x W'^T - mean_m s) + b'.  Everything the fold needs is fetched HERE, next to the bias loads' drain: a load in the
+    // epilogue would have to wait (in-order counter) for the next tile's LDS-DMA prefetch, still on its way from HBM -- measured
+    // 2 us per tile, + 6 % on qkv and lin1.
     const int nb = __builtin_amdgcn_readfirstlane(n0 + wc * 64);
     const S6D_CONST(float) *bs = (const S6D_CONST(float) *)p.bias + nb;
+    const S6D_CONST(float) *cs = (const S6D_CONST(float) *)p.CS + nb;
     const bool hi = (lane >> 5) != 0;
+    float ln_sig[4] = {0.f, 0.f, 0.f, 0.f}, ln_nmu[4] = {0.f, 0.f, 0.f, 0.f};
+    if (EPI >= 3) {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+      for (int mt = 0; mt < 4; ++mt) {
+        const int m = min(m0 + wr * 128 + mt * 32 + (lane & 31), p.M - 1);   // rows past M: a valid address, never stored
+        const float2 st = *reinterpret_cast<const float2 *>(p.RS + (size_t)m * 2);   // (mean, sigma = sqrt(var + eps))
+        ln_nmu[mt] = -st.x;
+        ln_sig[mt] = st.y;
+        ln_rs[mt] = __builtin_amdgcn_rcpf(st.y);                             // 1 ulp: far inside the bf16 rounding of the result
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      // EPI 3 / 4: one n tile's 2 x 16 constants at a time (all 64 at once spill loop-invariant registers into the main loop)
+      if (EPI >= 3 && nt == 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
 #pragma unroll
@@ -331,10 +368,26 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
           const int c0 = S6D_GEMM_QT ? 16 * nt + 4 * qd + e : 32 * nt + 8 * qd + e;
           const int c1 = S6D_GEMM_QT ? c0 + 32 : c0 + 4;
           const float b = HAS_BIAS ? (hi ? bs[c1] : bs[c0]) : 0.f;
+          if (EPI >= 3) {
+            const float sn = hi ? cs[c1] : cs[c0];
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt) acc[mt][nt][4 * qd + e] = b;
+            for (int mt = 0; mt < 4; ++mt) acc[mt][nt][4 * qd + e] = fmaf(ln_sig[mt], b, ln_nmu[mt] * sn);
+          } else if (EPI == 2) {
+            // bias + residual, both exact in fp32: x + (a W^T + b) is then rounded to bf16 once, in the epilogue
+            static_assert(S6D_GEMM_QT || EPI != 2, "residual registers are laid out for the quad-transposed column order");
+            const int r = 4 * qd + e;                                   // column 32 h + 16 nt + r: word (r & 7) >> 1 of piece 2 nt + (r >> 3)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+              const unsigned w = rn[mt][2 * nt + (r >> 3)][(r & 7) >> 1];
+              acc[mt][nt][r] = b + __uint_as_float((r & 1) ? (w & 0xffff0000u) : (w << 16));
+            }
+          } else {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt][nt][4 * qd + e] = b;
+          }
         }
       }
+    }
   };
 
   auto epilogue_one = [&](int mt, int nt, int m0, int n0) __attribute__((always_inline)) {   // one 32 x 32 accumulator tile
@@ -378,22 +431,32 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
   // S6D_GEMM_QT: the 32 x 64 strip of m tile mt.  A lane holds 4 chunks of 8 consecutive columns of its row (chunk 2 nt + k =
   // columns 32 h + 16 nt + 8 k ..); the 4 x 4 transpose inside each lane quad turns that into chunk (lane & 3) of the four rows
   // of the quad, i.e. a quad writes 64 contiguous bytes per instruction
-  // residual pieces of strip mt in the store layout: row (quad base + y), 8 columns at `col`
-  auto load_res = [&](int mt, int m0, int n0, uint4 (&rr)[4]) __attribute__((always_inline)) {
-    const int mq = m0 + wr * 128 + mt * 32 + (lane & 28);
-    const int col = n0 + wc * 64 + 32 * (lane >> 5) + 8 * (lane & 3);
+  auto epilogue_qt = [&](int mt, int m0, int n0) __attribute__((always_inline)) {
+    if (EPI == 2 && p.SP) {
+      // partial LayerNorm statistics of the row this lane owns over its 32 columns (32 h + {0..31} of the wave's 64): sum and the
+      // sum of squared deviations from the group mean, of the fp32 results (the bf16 rounding of the stored values is zero-mean
+      // and 2^-9 relative: it moves the mean by ~1e-4 sigma)
+      float sum = 0.f;
 #pragma unroll
-    for (int y = 0; y < 4; ++y) {
-      const int m = min(mq + y, p.M - 1);                                // rows past M: a valid address, never stored
-      rr[y] = *reinterpret_cast<const uint4 *>(p.R + (size_t)m * p.ldr + col);
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += acc[mt][nt][r];
+      const float mean = sum * (1.f / 32.f);
+      float m2 = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float d = acc[mt][nt][r] - mean;
+          m2 = fmaf(d, d, m2);
+        }
+      const int m = m0 + wr * 128 + mt * 32 + (lane & 31);
+      const int pidx = ((n0 + wc * 64) >> 5) + (lane >> 5);
+      if (m < p.M) {
+        p.SP[(size_t)(2 * pidx) * p.M + m] = sum;
+        p.SP[(size_t)(2 * pidx + 1) * p.M + m] = m2;
+      }
     }
-  };
-  auto add_bf16x2 = [&](unsigned a, unsigned b) __attribute__((always_inline)) -> unsigned {
-    const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
-    const float hi = __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u);
-    return pack_bf16(lo, hi);
-  };
-  auto epilogue_qt = [&](int mt, int m0, int n0, const uint4 (&rr)[4]) __attribute__((always_inline)) {
     unsigned X[4][4];                                                    // [chunk][dword]
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
@@ -402,7 +465,11 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
           float v0 = acc[mt][nt][8 * k + 2 * d], v1 = acc[mt][nt][8 * k + 2 * d + 1];
-          if (EPI == 1) {
+          if (EPI >= 3) {
+            v0 *= ln_rs[mt];
+            v1 *= ln_rs[mt];
+          }
+          if (EPI == 1 || EPI == 4) {
             v0 = gelu_erf(v0);
             v1 = gelu_erf(v1);
           }
@@ -431,14 +498,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
     const int col = n0 + wc * 64 + 32 * (lane >> 5) + 8 * (lane & 3);
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
-      if (EPI == 2) {
-        // unconditional: a residual piece that is loaded but consumed only on the store path would stay "pending" on the other
-        // path, and the compiler would then wait vmcnt(0) before the main loop reuses its register
-        X[y][0] = add_bf16x2(X[y][0], rr[y].x);
-        X[y][1] = add_bf16x2(X[y][1], rr[y].y);
-        X[y][2] = add_bf16x2(X[y][2], rr[y].z);
-        X[y][3] = add_bf16x2(X[y][3], rr[y].w);
-      }
       if (S6D_GEMM_ABLATE & 4) {
 #ifndef HIPEMU
         asm volatile("" ::"v"(X[y][0]), "v"(X[y][1]), "v"(X[y][2]), "v"(X[y][3]));
@@ -455,20 +514,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
       }
     }
   };
-  auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) {
-    // EPI 2 schedule (VM operations in program order): L0 L1 L2 | S0 L3 | S1 | S2 | S3, with Lk / Sk the four residual loads / four
-    // stores of strip k: every strip's loads are older than all stores but S0, so waiting for them leaves the stores in flight;
-    // L3 goes out after strip 0 has freed its 32 accumulator registers (all four up front spill).
-    uint4 rr[4][4];
-    if (EPI == 2 && S6D_GEMM_QT) {
-#pragma unroll
-      for (int mt = 0; mt < 3; ++mt) load_res(mt, m0, n0, rr[mt]);
-    }
+  auto epilogue = [&](int m0, int n0, int nm0, int nn0) __attribute__((always_inline)) {   // (nm0, nn0): the next tile (EPI 2)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       if (S6D_GEMM_QT) {
-        epilogue_qt(mt, m0, n0, rr[mt]);
-        if (EPI == 2 && mt == 0) load_res(3, m0, n0, rr[3]);
+        epilogue_qt(mt, m0, n0);
+        if (EPI == 2) load_resid(mt, nm0, nn0);
       } else {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) epilogue_one(mt, nt, m0, n0);
@@ -562,7 +613,11 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
     } else {
       S6D_VMCNT(0);
     }
-    init_acc(cn0);
+    if (EPI == 2) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) load_resid(mt, cm0, cn0);
+    }
+    init_acc(cm0, cn0);
     load_scales(cm0, cn0);
     S6D_BARRIER();
     if (wr == 1) S6D_BARRIER();                                          // the M halves run one barrier apart from here on
@@ -607,11 +662,23 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
       if (++ck == p.nk) {
         ck = 0;
         if (wr == 0) S6D_BARRIER();
-        epilogue(cm0, cn0);
-        if (++ct < my_tiles) {
-          tile_mn(ct, cm0, cn0);
-          init_acc(cn0);
-          load_scales(cm0, cn0);
+        if (EPI == 2) {
+          // unconditional on purpose (after the last tile it re-reads that tile and initialises accumulators nobody uses): a load
+          // that is consumed on one path only stays "pending" on the other, and the compiler then drains inside the main loop
+          int nm0, nn0;
+          tile_mn(min(ct + 1, my_tiles - 1), nm0, nn0);
+          epilogue(cm0, cn0, nm0, nn0);
+          ++ct;
+          cm0 = nm0;
+          cn0 = nn0;
+          init_acc(cm0, cn0);
+        } else {
+          epilogue(cm0, cn0, 0, 0);
+          if (++ct < my_tiles) {
+            tile_mn(ct, cm0, cn0);
+            init_acc(cm0, cn0);
+            load_scales(cm0, cn0);
+          }
         }
         if (wr == 1) S6D_BARRIER();
       }
@@ -621,7 +688,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
     return;
   }
   static_assert(DT != 1 || S6D_GEMM_PH2, "the fp8 operands are wired into the two-phase main loop only");
-  static_assert(DT != 2 || EPI != 2, "the residual epilogue adds bf16 pairs");
+  static_assert(DT == 0 || EPI < 2, "the residual K tiles and the folded LayerNorm are wired for bf16 operands");
+  static_assert(S6D_GEMM_QT || EPI < 2, "the residual / LayerNorm epilogues extend the quad-transposed epilogue");
   // ---- prologue: half-tiles 0..6 of the stream (K tile 0 whole; B0 B1 A0 of K tile 1)
   set_b(0);
   set_a(0);
@@ -637,7 +705,11 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
   } else {
     S6D_VMCNT(0);
   }
-  init_acc(cn0);
+  if (EPI == 2) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) load_resid(mt, cm0, cn0);
+  }
+  init_acc(cm0, cn0);
   S6D_BARRIER();
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) wf[0][ks] = wfrag(wc >> 1, 0, ks);        // B(0), n tile 0
@@ -705,10 +777,20 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
       // one after the other would leave one wave per SIMD): the leading half waits one barrier, the trailing half gives
       // one back afterwards, which also restores the one-barrier stagger
       if (wr == 0) S6D_BARRIER();
-      epilogue(cm0, cn0);
-      if (++ct < my_tiles) {
-        tile_mn(ct, cm0, cn0);
-        init_acc(cn0);
+      if (EPI == 2) {
+        int nm0, nn0;
+        tile_mn(min(ct + 1, my_tiles - 1), nm0, nn0);
+        epilogue(cm0, cn0, nm0, nn0);
+        ++ct;
+        cm0 = nm0;
+        cn0 = nn0;
+        init_acc(cm0, cn0);
+      } else {
+        epilogue(cm0, cn0, 0, 0);
+        if (++ct < my_tiles) {
+          tile_mn(ct, cm0, cn0);
+          init_acc(cm0, cn0);
+        }
       }
       if (wr == 1) S6D_BARRIER();
     }
@@ -961,7 +1043,14 @@ static int gemm_impl() {
 
 extern "C" int s6d_gemm_bf16_cblk(const void *A, long lda, const void *W, long ldw, const float *bias, void *C, long ldc, int M,
                                   int N, int K, int epilogue, int col_block, int max_blocks, void *stream);
-static int gemm_launch(const void *A, long lda, const void *W, long ldw, const float *bias, const void *R, long ldr, void *C, long ldc,
+struct GemmExtra {            // operands of the residual (EPI 2) and folded-LayerNorm (EPI 3 / 4) forms
+  const void *R = nullptr;    // residual, row stride ldr elements
+  long ldr = 0;
+  float *SP = nullptr;        // partial row statistics out (optional)
+  const float *RS = nullptr;  // row (mean, rstd) in
+  const float *CS = nullptr;  // column sums of the folded weight
+};
+static int gemm_launch(const void *A, long lda, const void *W, long ldw, const float *bias, const GemmExtra &x, void *C, long ldc,
                        int M, int N, int K, int epilogue, int col_block, int max_blocks, void *stream, int dt = 0,
                        const unsigned char *sa = nullptr, const unsigned char *sw = nullptr);
 
@@ -969,7 +1058,7 @@ extern "C" int s6d_gemm_f16(const void *A, long lda, const void *W, long ldw, co
                             int epilogue, int max_blocks, void *stream) {
   if (epilogue != 0 && epilogue != 1) return S6D_EINVAL;
   if (N % 256 != 0 || !S6D_GEMM_QT) return S6D_EUNSUPPORTED;            // the 256 x 256-tile kernel only
-  return gemm_launch(A, lda, W, ldw, bias, nullptr, 0, C, ldc, M, N, K, epilogue, 0, max_blocks, stream, 2);
+  return gemm_launch(A, lda, W, ldw, bias, GemmExtra(), C, ldc, M, N, K, epilogue, 0, max_blocks, stream, 2);
 }
 
 extern "C" int s6d_gemm_fp8(const void *A, long lda, const unsigned char *a_scale, const void *W, long ldw, const unsigned char *w_scale,
@@ -977,14 +1066,30 @@ extern "C" int s6d_gemm_fp8(const void *A, long lda, const unsigned char *a_scal
   if (!a_scale || !w_scale) return S6D_EINVAL;
   if (epilogue != 0 && epilogue != 1) return S6D_EINVAL;
   if (N % 256 != 0 || K % 128 != 0 || !S6D_GEMM_QT || !S6D_GEMM_PH2) return S6D_EUNSUPPORTED;
-  return gemm_launch(A, lda, W, ldw, bias, nullptr, 0, C, ldc, M, N, K, epilogue, 0, max_blocks, stream, 1, a_scale, w_scale);
+  return gemm_launch(A, lda, W, ldw, bias, GemmExtra(), C, ldc, M, N, K, epilogue, 0, max_blocks, stream, 1, a_scale, w_scale);
 }
 
 extern "C" int s6d_gemm_bf16_res(const void *A, long lda, const void *W, long ldw, const float *bias, const void *R, long ldr,
-                                 void *C, long ldc, int M, int N, int K, int max_blocks, void *stream) {
+                                 float *stats_partial, void *C, long ldc, int M, int N, int K, int max_blocks, void *stream) {
   if (!R || ldr < N || (ldr % 8) || ((uintptr_t)R & 15)) return S6D_EINVAL;
   if (N % 256 != 0 || !S6D_GEMM_QT) return S6D_EUNSUPPORTED;            // the quad-transposed epilogue of the 256 x 256 kernel
-  return gemm_launch(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, 2, 0, max_blocks, stream);
+  GemmExtra x;
+  x.R = R;
+  x.ldr = ldr;
+  x.SP = stats_partial;
+  return gemm_launch(A, lda, W, ldw, bias, x, C, ldc, M, N, K, 2, 0, max_blocks, stream);
+}
+
+extern "C" int s6d_gemm_bf16_lnfold(const void *A, long lda, const float *row_stats, const void *W, long ldw, const float *col_sums,
+                                    const float *bias, void *C, long ldc, int M, int N, int K, int gelu, int col_block,
+                                    int max_blocks, void *stream) {
+  if (!row_stats || !col_sums || !bias) return S6D_EINVAL;
+  if (gelu != 0 && gelu != 1) return S6D_EINVAL;
+  if (N % 256 != 0 || !S6D_GEMM_QT) return S6D_EUNSUPPORTED;
+  GemmExtra x;
+  x.RS = row_stats;
+  x.CS = col_sums;
+  return gemm_launch(A, lda, W, ldw, bias, x, C, ldc, M, N, K, 3 + gelu, col_block, max_blocks, stream);
 }
 
 extern "C" int s6d_gemm_bf16(const void *A, long lda, const void *W, long ldw, const float *bias, void *C, long ldc, int M,
@@ -995,10 +1100,10 @@ extern "C" int s6d_gemm_bf16(const void *A, long lda, const void *W, long ldw, c
 extern "C" int s6d_gemm_bf16_cblk(const void *A, long lda, const void *W, long ldw, const float *bias, void *C, long ldc, int M,
                                   int N, int K, int epilogue, int col_block, int max_blocks, void *stream) {
   if (epilogue != 0 && epilogue != 1) return S6D_EINVAL;
-  return gemm_launch(A, lda, W, ldw, bias, nullptr, 0, C, ldc, M, N, K, epilogue, col_block, max_blocks, stream);
+  return gemm_launch(A, lda, W, ldw, bias, GemmExtra(), C, ldc, M, N, K, epilogue, col_block, max_blocks, stream);
 }
 
-static int gemm_launch(const void *A, long lda, const void *W, long ldw, const float *bias, const void *R, long ldr, void *C, long ldc,
+static int gemm_launch(const void *A, long lda, const void *W, long ldw, const float *bias, const GemmExtra &x, void *C, long ldc,
                        int M, int N, int K, int epilogue, int col_block, int max_blocks, void *stream, int dt,
                        const unsigned char *sa, const unsigned char *sw) {
   if (M < 0 || N <= 0 || K <= 0) return S6D_EINVAL;
@@ -1010,17 +1115,20 @@ static int gemm_launch(const void *A, long lda, const void *W, long ldw, const f
   if (N % 128 != 0 || K % kstep != 0 || lda < K || ldw < K || ldc < N) return S6D_EINVAL;
   if ((lda % ralign) || (ldw % ralign) || (ldc % 8)) return S6D_EINVAL;  // 16-byte rows
   if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) return S6D_EINVAL;
-  if (epilogue < 0 || epilogue > 2) return S6D_EINVAL;
+  if (epilogue < 0 || epilogue > 4) return S6D_EINVAL;
   // staging addresses are 32-bit byte offsets from A / W
   if ((double)M * (double)lda * esz >= 2147483648.0 || (double)N * (double)ldw * esz >= 2147483648.0) return S6D_EUNSUPPORTED;
-  const int impl = (N % 256 != 0) ? 2 : ((col_block > 0 || epilogue == 2 || dt) ? 1 : gemm_impl());
+  const int impl = (N % 256 != 0) ? 2 : ((col_block > 0 || epilogue >= 2 || dt) ? 1 : gemm_impl());
   GemmParams p;
   p.A = (const u16 *)A;
   p.W = (const u16 *)W;
   p.bias = bias;
   p.C = (u16 *)C;
-  p.R = (const u16 *)R;
-  p.ldr = ldr;
+  p.R = (const u16 *)x.R;
+  p.ldr2 = (unsigned)(x.ldr * 2);
+  p.SP = x.SP;
+  p.RS = x.RS;
+  p.CS = x.CS;
   p.lda2 = (unsigned)(lda * esz);
   p.ldw2 = (unsigned)(ldw * esz);
   p.sa = sa;
@@ -1096,7 +1204,11 @@ static int gemm_launch(const void *A, long lda, const void *W, long ldw, const f
   }
 #undef S6D_GEMMH_LAUNCH
 #undef S6D_GEMM8_LAUNCH
-  if (epilogue == 2) {
+  if (epilogue == 4) {
+    S6D_GEMM_LAUNCH(4, true);
+  } else if (epilogue == 3) {
+    S6D_GEMM_LAUNCH(3, true);
+  } else if (epilogue == 2) {
     if (bias) S6D_GEMM_LAUNCH(2, true); else S6D_GEMM_LAUNCH(2, false);
   } else if (epilogue == 1) {
     if (bias) S6D_GEMM_LAUNCH(1, true); else S6D_GEMM_LAUNCH(1, false);

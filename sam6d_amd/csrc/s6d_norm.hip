@@ -207,9 +207,96 @@ __global__ __launch_bounds__(256) void layernorm_fp8_kernel(const u16 *__restric
   if (lane == 0) yscale[row] = (unsigned char)(e2 + 127);
 }
 
+
+// ---- row statistics of the FOLDED LayerNorm (csrc/s6d_gemm.hip: EPI 2 writes partials, EPI 3 / 4 consume (mean, sigma)) ---------
+// sigma = sqrt(var + eps): the consuming GEMM starts its accumulators at sigma b' - mean s and multiplies by 1 / sigma at the end.
+// Partials: for every row and group of `gsz` columns the sum and the sum of squared deviations from the group mean, laid out
+// [group][2][M].  Combined group by group in index order with the exact pairwise update (Chan et al.): no cancellation, fixed order.
+__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float *__restrict__ sp, int groups, int gsz, long M, float eps,
+                                                               float *__restrict__ out) {
+  const long row = (long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= M) return;
+  const float nb = (float)gsz;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int g = 0; g < groups; ++g) {
+    const float s = sp[(size_t)(2 * g) * M + row], q = sp[(size_t)(2 * g + 1) * M + row];
+    const float d = s / nb - mean, nn = n + nb;
+    mean += d * (nb / nn);
+    m2 += q + d * d * (n * nb / nn);
+    n = nn;
+  }
+  *reinterpret_cast<float2 *>(out + row * 2) = make_float2(mean, sqrtf(m2 / n + eps));
+}
+
+// the same (mean, sigma) straight from a bf16 matrix: one wavefront per row, two passes over registers (the statistics of
+// add_layernorm_kernel).  Used once per encoder pass, for the patch-embedding output that enters block 0.
+template <int VEC>
+__global__ __launch_bounds__(256) void row_stats_kernel(const u16 *__restrict__ x, long ldx, long rows, int C, float eps,
+                                                       float *__restrict__ out) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const int nchunk = C / 8;
+  float v[VEC][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int ch = lane + i * 64;
+    union { uint4 u; u16 h[8]; } a;
+    a.u = make_uint4(0u, 0u, 0u, 0u);
+    if (ch < nchunk) a.u = *reinterpret_cast<const uint4 *>(x + row * ldx + ch * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[i][e] = bf2f_(a.h[e]);
+      sum += v[i][e];
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int ch = lane + i * 64;
+    if (ch < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[i][e] - mean;
+        sq += d * d;
+      }
+    }
+  }
+  const float sigma = sqrtf(wave_sum(sq) / (float)C + eps);
+  if (lane == 0) *reinterpret_cast<float2 *>(out + row * 2) = make_float2(mean, sigma);
+}
+
 }  // namespace s6d
 
 using namespace s6d;
+
+extern "C" int s6d_ln_stats_finalize(const float *stats_partial, int groups, int group_size, long M, float eps, float *row_stats,
+                                     void *stream) {
+  if (M < 0 || groups <= 0 || group_size <= 0) return S6D_EINVAL;
+  if (M == 0) return S6D_OK;
+  if (!stats_partial || !row_stats || ((uintptr_t)row_stats & 7)) return S6D_EINVAL;
+  hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, as_stream(stream), stats_partial,
+                     groups, group_size, M, eps, row_stats);
+  return launch_status();
+}
+
+extern "C" int s6d_row_stats_bf16(const void *x, long ldx, long M, int C, float eps, float *row_stats, void *stream) {
+  if (M < 0 || C <= 0 || (C % 8) || ldx < C || (ldx % 8)) return S6D_EINVAL;
+  if (C > 64 * 8 * 3) return S6D_EUNSUPPORTED;
+  if (M == 0) return S6D_OK;
+  if (!x || !row_stats || ((uintptr_t)x & 15) || ((uintptr_t)row_stats & 7)) return S6D_EINVAL;
+  const dim3 grid((unsigned)((M + 3) / 4));
+  const int vec = (C + 511) / 512;
+  if (vec == 1)
+    hipLaunchKernelGGL(row_stats_kernel<1>, grid, dim3(256), 0, as_stream(stream), (const u16 *)x, ldx, M, C, eps, row_stats);
+  else if (vec == 2)
+    hipLaunchKernelGGL(row_stats_kernel<2>, grid, dim3(256), 0, as_stream(stream), (const u16 *)x, ldx, M, C, eps, row_stats);
+  else
+    hipLaunchKernelGGL(row_stats_kernel<3>, grid, dim3(256), 0, as_stream(stream), (const u16 *)x, ldx, M, C, eps, row_stats);
+  return launch_status();
+}
 
 static int ln_launch(const void *x, const void *delta, const float *gamma, const float *beta, float eps, long rows, int C,
                      void *x_out, void *y_out, float *y_f32, void *stream, bool f16 = false);

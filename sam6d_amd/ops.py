@@ -480,11 +480,13 @@ def seq_attention(qkv, num_heads, scale):
     return out
 
 
-def gemm_bf16(a, w, bias=None, gelu=False, out=None, max_blocks=0, col_block=0, residual=None):
+def gemm_bf16(a, w, bias=None, gelu=False, out=None, max_blocks=0, col_block=0, residual=None, stats_partial=None):
     """a (..., K) bf16 (rows may be strided), w (N, K) bf16 = nn.Linear.weight, bias (N) f32 or None ->
     act(a @ w.T + bias) (..., N) bf16 with act = exact GELU or identity; N % 128 == 0, K % 64 == 0.
     col_block > 0: the output comes back as (N / col_block, M, col_block) -- column blocks as separate matrices (N % 256 == 0).
-    residual (..., N) bf16: returns bf16(bf16(a @ w.T + bias) + residual) (N % 256 == 0, no GELU); out may be the residual itself."""
+    residual (..., N) bf16: returns bf16(a @ w.T + bias + residual), summed in fp32 (N % 256 == 0, no GELU); out may be the residual
+    itself.  stats_partial (N / 32, 2, M) f32 (with residual): receives the partial LayerNorm statistics of the result rows
+    (ln_stats_finalize turns them into (mean, rstd))."""
     if not a.is_cuda or not w.is_cuda:
         raise RuntimeError("a and w must be CUDA tensors")
     if a.dtype not in (torch.bfloat16, torch.float16) or w.dtype != a.dtype:
@@ -522,23 +524,89 @@ def gemm_bf16(a, w, bias=None, gelu=False, out=None, max_blocks=0, col_block=0, 
     rows = max(256, ((2 ** 31 - 1) // (2 * a2.stride(0))) // 256 * 256)
     if residual is not None:
         if gelu or col_block:
-            raise RuntimeError("the residual epilogue takes neither GELU nor column blocks")
+            raise RuntimeError("the residual form takes neither GELU nor column blocks")
         _chk(residual, torch.bfloat16, "residual")
         r2 = residual.reshape(-1, N)
         if r2.shape[0] != M:
             raise ValueError(f"residual has {r2.shape[0]} rows, the product {M}")
+        if r2.stride(1) != 1 or r2.stride(0) % 8 or r2.data_ptr() % 16:
+            raise ValueError("residual rows must be contiguous and 16-byte aligned")
+        if stats_partial is not None:
+            _chk(stats_partial, torch.float32, "stats_partial")
+            if tuple(stats_partial.shape) != (N // 32, 2, M) or not stats_partial.is_contiguous():
+                raise ValueError(f"stats_partial must be a contiguous ({N // 32}, 2, {M}) f32 tensor; got {tuple(stats_partial.shape)}")
+            if M > rows:
+                raise RuntimeError("row statistics are written for one launch: the row count exceeds one 2-GiB slab")
         for r0 in range(0, M, rows):
             r1 = min(M, r0 + rows)
             _call("s6d_gemm_bf16_res", _ptr(a2[r0:r1]), ctypes.c_long(a2.stride(0)), _ptr(w), ctypes.c_long(w.stride(0)),
-                  _ptr(bias) if bias is not None else _vp(0), _ptr(r2[r0:r1]), ctypes.c_long(r2.stride(0)), _ptr(out[r0:r1]),
+                  _ptr(bias) if bias is not None else _vp(0), _ptr(r2[r0:r1]), ctypes.c_long(r2.stride(0)),
+                  _ptr(stats_partial) if stats_partial is not None else _vp(0), _ptr(out[r0:r1]),
                   ctypes.c_long(out.stride(0)), r1 - r0, N, K, int(max_blocks), _stream())
         return out.reshape(*a.shape[:-1], N)
+    if stats_partial is not None:
+        raise RuntimeError("stats_partial comes with the residual form")
     for r0 in range(0, M, rows):
         r1 = min(M, r0 + rows)
         _call("s6d_gemm_f16" if f16 else "s6d_gemm_bf16", _ptr(a2[r0:r1]), ctypes.c_long(a2.stride(0)), _ptr(w), ctypes.c_long(w.stride(0)),
               _ptr(bias) if bias is not None else _vp(0), _ptr(out[r0:r1]), ctypes.c_long(out.stride(0)), r1 - r0, N, K,
               1 if gelu else 0, int(max_blocks), _stream())
     return out.reshape(*a.shape[:-1], N)
+
+
+def ln_stats_finalize(stats_partial, group_size=32, eps=1e-6):
+    """(groups, 2, M) f32 partial statistics (gemm_bf16(..., stats_partial=)) -> (M, 2) f32 rows of (mean, sigma = sqrt(var + eps))."""
+    _chk(stats_partial, torch.float32, "stats_partial", 3)
+    if not stats_partial.is_contiguous() or stats_partial.shape[1] != 2:
+        raise ValueError("stats_partial must be a contiguous (groups, 2, M) tensor")
+    G, _, M = stats_partial.shape
+    out = torch.empty(M, 2, dtype=torch.float32, device=stats_partial.device)
+    _call("s6d_ln_stats_finalize", _ptr(stats_partial), int(G), int(group_size), ctypes.c_long(M), ctypes.c_float(eps), _ptr(out), _stream())
+    return out
+
+
+def row_stats(x, eps=1e-6):
+    """x (..., C) bf16 -> (rows, 2) f32 of (mean, sigma = sqrt(var + eps)) over the last dim: the LayerNorm statistics alone."""
+    _chk(x, torch.bfloat16, "x")
+    C = x.shape[-1]
+    x2 = x.reshape(-1, C)
+    if x2.stride(1) != 1 or x2.stride(0) % 8 or x2.data_ptr() % 16:
+        x2 = x2.contiguous()
+    out = torch.empty(x2.shape[0], 2, dtype=torch.float32, device=x.device)
+    _call("s6d_row_stats_bf16", _ptr(x2), ctypes.c_long(x2.stride(0)), ctypes.c_long(x2.shape[0]), int(C), ctypes.c_float(eps), _ptr(out),
+          _stream())
+    return out
+
+
+def gemm_bf16_lnfold(a, stats, w_folded, col_sums, bias, gelu=False, col_block=0, max_blocks=0):
+    """act(LayerNorm(a) @ W.T + b) without the normalised activations: a (..., K) bf16 raw rows, stats (rows, 2) f32 their
+    (mean, sigma), w_folded (N, K) bf16 = gamma * W, col_sums (N) f32 = w_folded.float().sum(1), bias (N) f32 = b + W @ beta
+    (sam6d_amd/utils/linear.py::lnfold_weights).  N % 256 == 0.  col_block as gemm_bf16."""
+    _chk(a, torch.bfloat16, "a")
+    _chk(w_folded, torch.bfloat16, "w_folded", 2)
+    _chk(stats, torch.float32, "stats", 2)
+    _chk(col_sums, torch.float32, "col_sums", 1)
+    _chk(bias, torch.float32, "bias", 1)
+    K, N = a.shape[-1], w_folded.shape[0]
+    a2 = a.reshape(-1, K)
+    if a2.stride(1) != 1 or a2.stride(0) % 8 or a2.data_ptr() % 16:
+        a2 = a2.contiguous()
+    M = a2.shape[0]
+    if w_folded.shape[1] != K or w_folded.stride(1) != 1 or w_folded.stride(0) % 8:
+        raise RuntimeError("w_folded must be (N, K) with contiguous rows")
+    if tuple(stats.shape) != (M, 2) or not stats.is_contiguous() or col_sums.numel() != N or bias.numel() != N:
+        raise ValueError(f"stats must be ({M}, 2), col_sums and bias ({N},)")
+    if 2 * M * a2.stride(0) >= 2 ** 31:
+        raise RuntimeError("one launch: the row count exceeds one 2-GiB slab")
+    if col_block:
+        out = torch.empty(N // col_block, M, col_block, dtype=torch.bfloat16, device=a.device)
+        ldc = N
+    else:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+        ldc = N
+    _call("s6d_gemm_bf16_lnfold", _ptr(a2), ctypes.c_long(a2.stride(0)), _ptr(stats), _ptr(w_folded), ctypes.c_long(w_folded.stride(0)),
+          _ptr(col_sums), _ptr(bias), _ptr(out), ctypes.c_long(ldc), M, N, K, 1 if gelu else 0, int(col_block), int(max_blocks), _stream())
+    return out if col_block else out.reshape(*a.shape[:-1], N)
 
 
 def gemm_fp8(a8, a_scale, w8, w_scale, bias=None, gelu=False, max_blocks=0):
@@ -843,7 +911,7 @@ def have(name):
     if name not in _FUSED:
         sym = {"rpe_attention": "s6d_rpe_attention_f32", "geo_embedding": "s6d_geo_embedding_f32",
                "fine_assign": "s6d_fine_assign_f32", "fine_match": "s6d_fine_match_f32", "pem_pre": "s6d_pem_compact_cloud_f32", "coarse_sample": "s6d_coarse_sample_f32", "upsample_gather": "s6d_upsample_gather_f32",
-               "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "add_layernorm": "s6d_add_layernorm_bf16", "gemm_bf16": "s6d_gemm_bf16", "gemm_bf16_res": "s6d_gemm_bf16_res", "gemm_f16": "s6d_gemm_f16", "gemm_fp8": "s6d_gemm_fp8", "layernorm_fp8": "s6d_layernorm_fp8", "layernorm_f32out": "s6d_layernorm_bf16_f32", "linear_f32": "s6d_linear_f32", "win_attention": "s6d_win_attention_layout_bf16",
+               "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "add_layernorm": "s6d_add_layernorm_bf16", "gemm_bf16": "s6d_gemm_bf16", "gemm_bf16_res": "s6d_gemm_bf16_res", "gemm_bf16_lnfold": "s6d_gemm_bf16_lnfold", "gemm_f16": "s6d_gemm_f16", "gemm_fp8": "s6d_gemm_fp8", "layernorm_fp8": "s6d_layernorm_fp8", "layernorm_f32out": "s6d_layernorm_bf16_f32", "linear_f32": "s6d_linear_f32", "win_attention": "s6d_win_attention_layout_bf16",
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
                "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_frames_f32",

@@ -250,11 +250,17 @@ class ImageEncoderViT(nn.Module):
         lin2 GEMMs (s6d_gemm_bf16_res, in place on the stream tensor) and the LayerNorms are one-read passes; round 2 folded
         each add into the following LayerNorm pass (two reads + two writes per add: 6 % of the step).  Same arithmetic either
         way (the add rounds the GEMM's bf16 output + x to bf16): S6D_DISABLE_FUSED=gemm_bf16_res selects the round-2 form."""
-        from ..utils.linear import res_eligible
+        from ..utils.linear import lnfold_eligible, res_eligible
         x = x.contiguous()
         C = x.shape[-1]
         if _gemm_mode() == "fp8":
             return self._blocks_fp8(x, upto)
+        rows, hid = x.numel() // C, max(blk.mlp.lin1.out_features for blk in self.blocks)
+        if (lnfold_eligible(x, C, C) and C % 32 == 0 and all(lnfold_eligible(x, blk.mlp.lin1.out_features, C) and
+                                                             lnfold_eligible(x, C, blk.mlp.lin1.out_features) and blk.attn.use_rel_pos
+                                                             for blk in self.blocks)
+                and ops.have("win_attention") and 2 * rows * max(hid, 3 * C) < 2 ** 31):
+            return self._blocks_lnfold(x, upto)
         if res_eligible(x, C, C) and all(res_eligible(x, C, blk.mlp.lin2.in_features) for blk in self.blocks):
             x = x.clone()                                        # the stream tensor is updated in place from here on
             for i, blk in enumerate(self.blocks):
@@ -278,6 +284,44 @@ class ImageEncoderViT(nn.Module):
             x, h = ops.add_layernorm(x, a.contiguous(), g, b, blk.norm2.eps)
             delta = blk.mlp(h).contiguous()
         return x if delta is None else x + delta
+
+    def _blocks_lnfold(self, x, upto):
+        """Block.forward (image_encoder.py:166-182) with neither the residual adds nor the LayerNorms as passes of their own
+        (round 2 / 3 spent 6 % of the step in add + LayerNorm: two reads and two writes of the token map per add):
+          * `x + proj(..)` and `x + lin2(..)`: the residual tile rides through the matrix cores of the producing GEMM
+            (s6d_gemm_bf16_res, in place on the stream tensor), whose epilogue also leaves per-row partial statistics of the new x;
+          * `norm1(x)` / `norm2(x)`: s6d_ln_stats_finalize turns the partials into (mean, sigma) per token (a 20-MB pass), and the
+            consuming GEMM (qkv, lin1 + GELU) multiplies the RAW stream by gamma * W, starting its accumulators at
+            sigma b' - mean s and dividing by sigma in its epilogue (s6d_gemm_bf16_lnfold).  The normalised activations never exist.
+        Out-of-image window tokens keep the ORIGINAL qkv bias (the reference pads after norm1: zeros through qkv = its bias)."""
+        from ..utils.linear import _cached, lnfold_cached
+        x = x.clone()                                            # the stream tensor is updated in place from here on
+        B, H, W, C = x.shape
+        M = B * H * W
+        x2 = x.view(M, C)
+        blocks = list(self.blocks)[:upto] if upto is not None else list(self.blocks)
+        if not blocks:
+            return x
+        st = ops.row_stats(x2, blocks[0].norm1.eps)
+        sp = torch.empty(C // 32, 2, M, dtype=torch.float32, device=x.device)
+        for i, blk in enumerate(blocks):
+            at = blk.attn
+            wf, cs, bf = lnfold_cached(at.qkv, blk.norm1)
+            qkv = ops.gemm_bf16_lnfold(x2, st, wf, cs, bf).view(B, H, W, 3 * C)
+            S = blk.window_size if blk.window_size > 0 else H
+            bias, rh, rw = at._kernel_operands(S, qkv.dtype)
+            a = ops.window_attention(qkv, bias, rh, rw, at.num_heads, blk.window_size, at.scale)
+            wp, bp = _cached(at.proj, at.proj.weight)
+            ops.gemm_bf16(a.reshape(M, C), wp, bp, residual=x2, out=x2, stats_partial=sp)
+            st = ops.ln_stats_finalize(sp, 32, blk.norm2.eps)
+            w1, c1, b1 = lnfold_cached(blk.mlp.lin1, blk.norm2)
+            h = ops.gemm_bf16_lnfold(x2, st, w1, c1, b1, gelu=True)
+            w2, b2 = _cached(blk.mlp.lin2, blk.mlp.lin2.weight)
+            last = i + 1 == len(blocks)
+            ops.gemm_bf16(h, w2, b2, residual=x2, out=x2, stats_partial=None if last else sp)
+            if not last:
+                st = ops.ln_stats_finalize(sp, 32, blocks[i + 1].norm1.eps)
+        return x
 
     def _blocks_fp8(self, x, upto):
         """BASELINE configs[4] (never the headline): the two LayerNorm-fed GEMMs of every block -- qkv (1280 -> 3840) and lin1

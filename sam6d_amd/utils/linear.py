@@ -48,6 +48,36 @@ def _res_eligible(x, n_out, k_in):
             and os.environ.get("S6D_GEMM_RES", "0") == "1")
 
 
+def lnfold_weights(weight, bias, gamma, beta):
+    """LayerNorm folded into the Linear behind it:  LN(x) W^T + b = rstd (x W'^T - mean s) + b'  with
+    W' = bf16(gamma * W),  s = row sums of W' (of the ROUNDED weights: the kernel multiplies those),  b' = b + W beta.
+    -> (W' bf16 (N,K), s f32 (N), b' f32 (N)); sums in float64."""
+    w = weight.detach().double()
+    wf = (w * gamma.detach().double()[None, :]).to(torch.bfloat16).contiguous()
+    cs = wf.double().sum(1).float().contiguous()
+    b0 = 0.0 if bias is None else bias.detach().double()
+    bf = (b0 + w @ beta.detach().double()).float().contiguous()
+    return wf, cs, bf
+
+
+def lnfold_cached(lin, norm):
+    """lnfold_weights(lin, norm), cached on `lin` until one of the four parameters changes."""
+    ps = (lin.weight, lin.bias, norm.weight, norm.bias)
+    key = tuple(None if t is None else (t._version, t.data_ptr(), t.dtype) for t in ps)
+    c = getattr(lin, "_s6d_lnfold", None)
+    if c is None or c[0] != key:
+        c = (key,) + lnfold_weights(lin.weight, lin.bias, norm.weight, norm.bias)
+        lin._s6d_lnfold = c
+    return c[1], c[2], c[3]
+
+
+def lnfold_eligible(x, n_out, k_in):
+    """The folded residual + LayerNorm block loop (s6d_gemm_bf16_res with row statistics -> s6d_gemm_bf16_lnfold): bf16 stream,
+    every Linear of the block on the 256 x 256-tile kernel.  S6D_LNFOLD=0 turns it off (A/B runs)."""
+    return (x.is_cuda and x.dtype == torch.bfloat16 and n_out % 256 == 0 and k_in % 64 == 0 and ops.have("gemm_bf16_lnfold")
+            and os.environ.get("S6D_LNFOLD", "1") != "0" and "gemm_bf16" not in os.environ.get("S6D_DISABLE_FUSED", ""))
+
+
 def fused_linear(lin, x, gelu=False, weight2d=None, col_block=0, residual=None):
     """act(lin(x)); `weight2d` overrides lin.weight for conv weights viewed as (N, K).  col_block > 0 (kernel path only, N % 256
     == 0, S6D_QKV_LAYOUT=head): the result comes back as (N / col_block, M, col_block) -- the head-major q/k/v layout of the attention

@@ -120,15 +120,20 @@ def _run_res():
     ops._stream = lambda: ctypes.c_void_p(0)
     torch.Tensor.is_cuda = property(lambda self: True)
     torch.Tensor.cuda = lambda self, *a, **k: self
-    T.test_residual_epilogue_equals_gemm_then_add(700, 768, 192, False)
-    T.test_residual_epilogue_equals_gemm_then_add(300, 256, 64, True)
+    T.test_residual_gemm_sums_in_the_accumulators(700, 768, 192, False)
+    T.test_residual_gemm_sums_in_the_accumulators(300, 256, 64, True)
+    T.test_residual_gemm_row_statistics(700, 768, 192)
+    T.test_lnfold_gemm_vs_layernorm_then_linear(700, 768, 192, False, 0)
+    T.test_lnfold_gemm_vs_layernorm_then_linear(300, 256, 320, True, 0)
+    T.test_lnfold_gemm_vs_layernorm_then_linear(520, 768, 256, False, 64)
     T.test_float16_gemm_vs_float(300, 256, 320, True)
     T.test_float16_gemm_vs_float(700, 768, 192, False)
 
 
 @pytest.mark.parametrize("mode", ["early", "late"])
 def test_residual_epilogue_on_the_emulator(mode):
-    """s6d_gemm_bf16_res (residual add of a ViT block in the GEMM epilogue), bit-identical with GEMM-then-add, in place too."""
+    """s6d_gemm_bf16_res (residual tile through the matrix cores + row statistics), s6d_gemm_bf16_lnfold (LayerNorm folded into
+    the epilogue) and the float16 GEMM, on the host."""
     r = subprocess.run([sys.executable, "-c", f"import sys; sys.path.insert(0, {ROOT!r}); "
                         f"from tests import test_emu_gemm as t; t._run_res()"], env=dict(os.environ, HIPEMU_GLDS=mode),
                        capture_output=True, text=True, timeout=1500)

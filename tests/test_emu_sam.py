@@ -54,10 +54,14 @@ def test_mini_encoder_bf16_fused_path_on_the_emulator(emu, monkeypatch):
     assert err.mean() < 2e-2 and np.corrcoef(y.ravel(), g["mini_out"].ravel())[0, 1] > 0.999, (err.mean(), err.max())
 
 
-def test_residual_epilogue_block_loop_equals_the_round2_form(emu, monkeypatch):
-    """ImageEncoderViT._blocks_fused with the residual adds in the proj / lin2 GEMM epilogues (s6d_gemm_bf16_res, in place,
-    LayerNorms as one-read passes) against the round-2 form (adds folded into the following LayerNorm pass): BIT FOR BIT,
-    on a 2-block encoder with a windowed and a global block (dim 256 so that the 256 x 256-tile kernel takes every GEMM)."""
+def test_folded_block_loops_against_the_round2_form_and_float(emu, monkeypatch):
+    """ImageEncoderViT._blocks_fused in its three forms on a 2-block encoder with a windowed and a global block (dim 256 so that
+    the 256 x 256-tile kernel takes every GEMM):
+      * default: residual adds through the matrix cores of proj / lin2 (s6d_gemm_bf16_res, in place, emitting row statistics) and
+        both LayerNorms folded into qkv / lin1 (s6d_gemm_bf16_lnfold) -- no add_layernorm launch at all;
+      * S6D_LNFOLD=0 S6D_GEMM_RES=1: residual GEMMs + one-read LayerNorm passes;
+      * S6D_LNFOLD=0: round 2 (each add folded into the following LayerNorm pass).
+    All three against the float32 statement of the module; the folded form must not be further from it than the round-2 form."""
     from functools import partial
 
     import torch
@@ -67,17 +71,41 @@ def test_residual_epilogue_block_loop_equals_the_round2_form(emu, monkeypatch):
     m = ImageEncoderViT(depth=2, embed_dim=256, img_size=256, mlp_ratio=2, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6),
                         num_heads=4, patch_size=16, qkv_bias=True, use_rel_pos=True, global_attn_indexes=(1,), window_size=7,
                         out_chans=32).eval()
-    m = seeded.load_seeded(m, 4).bfloat16()
-    x = (0.5 * torch.randn(1, 16, 16, 256, generator=torch.Generator().manual_seed(1))).to(torch.bfloat16)
-    keep = x.clone()
-    monkeypatch.setenv("S6D_GEMM_RES", "1")
-    calls = []
-    real = emu.gemm_bf16
-    monkeypatch.setattr(emu, "gemm_bf16", lambda *a, **k: (calls.append(k.get("residual") is not None), real(*a, **k))[1])
+    m = seeded.load_seeded(m, 4)
     with torch.no_grad():
-        new = m._blocks_fused(x, None)
-        assert sum(calls) == 4 and torch.equal(x, keep)              # two residual GEMMs per block; the caller's tensor untouched
-        emu._FUSED["gemm_bf16_res"] = False
-        calls.clear()
+        for blk in m.blocks:                                          # non-trivial affine parameters: the fold has work to do
+            for n in (blk.norm1, blk.norm2):
+                n.weight.add_(0.2 * torch.randn(256, generator=torch.Generator().manual_seed(7)))
+                n.bias.add_(0.1 * torch.randn(256, generator=torch.Generator().manual_seed(8)))
+    x = (0.5 * torch.randn(1, 16, 16, 256, generator=torch.Generator().manual_seed(1)) + 0.3).to(torch.bfloat16)
+    with torch.no_grad():
+        ref = x.float()
+        for blk in m.blocks:
+            ref = blk(ref)
+    m = m.bfloat16()
+    keep = x.clone()
+    calls = {"res": 0, "fold": 0, "ln": 0}
+    real_g, real_f, real_l = emu.gemm_bf16, emu.gemm_bf16_lnfold, emu.add_layernorm
+    monkeypatch.setattr(emu, "gemm_bf16", lambda *a, **k: (calls.__setitem__("res", calls["res"] + (k.get("residual") is not None)), real_g(*a, **k))[1])
+    monkeypatch.setattr(emu, "gemm_bf16_lnfold", lambda *a, **k: (calls.__setitem__("fold", calls["fold"] + 1), real_f(*a, **k))[1])
+    monkeypatch.setattr(emu, "add_layernorm", lambda *a, **k: (calls.__setitem__("ln", calls["ln"] + 1), real_l(*a, **k))[1])
+
+    def rel(a):
+        return ((a.float() - ref).pow(2).mean() / ref.pow(2).mean()).sqrt().item()
+
+    with torch.no_grad():
+        fold = m._blocks_fused(x, None)
+        assert calls == {"res": 4, "fold": 4, "ln": 0} and torch.equal(x, keep), calls   # the caller's tensor untouched
+        monkeypatch.setenv("S6D_LNFOLD", "0")
+        monkeypatch.setenv("S6D_GEMM_RES", "1")
+        calls.update(res=0, fold=0, ln=0)
+        res = m._blocks_fused(x, None)
+        assert calls == {"res": 4, "fold": 0, "ln": 4}, calls
+        monkeypatch.setenv("S6D_GEMM_RES", "0")
+        calls.update(res=0, fold=0, ln=0)
         old = m._blocks_fused(x, None)
-    assert sum(calls) == 0 and torch.equal(new, old)
+        assert calls == {"res": 0, "fold": 0, "ln": 4}, calls
+    e_fold, e_res, e_old = rel(fold), rel(res), rel(old)
+    print("rel rms vs float: fold %.3e res %.3e round2 %.3e" % (e_fold, e_res, e_old))
+    assert e_old <= 8e-3 and e_res <= 8e-3, (e_fold, e_res, e_old)
+    assert e_fold <= 1.1 * e_old + 5e-4, (e_fold, e_res, e_old)

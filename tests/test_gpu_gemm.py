@@ -129,9 +129,10 @@ def test_column_block_output_equals_the_plain_product(M, N, K, cb):
 
 
 @pytest.mark.parametrize("M,N,K,inplace", [(700, 768, 192, False), (300, 256, 64, True), (65536, 1280, 1280, True), (4096, 1280, 5120, False)])
-def test_residual_epilogue_equals_gemm_then_add(M, N, K, inplace):
-    """s6d_gemm_bf16_res: x + Linear(a) with the add in the GEMM's epilogue == the plain kernel's bf16 output, added to x in fp32
-    and rounded again (what add_layernorm's first output is), BIT FOR BIT, also in place and with ragged M."""
+def test_residual_gemm_sums_in_the_accumulators(M, N, K, inplace):
+    """s6d_gemm_bf16_res: x + Linear(a) with the accumulators started at bias + residual: the fp32 sum a W^T + b + x rounded to bf16
+    ONCE (one bf16 rounding of the float reference), also in place and with ragged M; zero activations return the bias + residual
+    exactly."""
     from sam6d_amd import ops
     if not torch.cuda.is_available() and M > 1000:
         pytest.skip("emulator: small shapes only")
@@ -140,10 +141,72 @@ def test_residual_epilogue_equals_gemm_then_add(M, N, K, inplace):
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).cuda()
     b = torch.randn(N, generator=g).cuda()
     x = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
-    want = (ops.gemm_bf16(a, w, b).float() + x.float()).to(torch.bfloat16)
+    ref = _ref(a, w, b, False) + x.float()
+    exact0 = (b[None, :] + x.float()).to(torch.bfloat16)
+    zero = ops.gemm_bf16(torch.zeros_like(a), w, b, residual=x)
+    assert torch.equal(zero, exact0)
     got = ops.gemm_bf16(a, w, b, residual=x, out=x if inplace else None)
     assert (got.data_ptr() == x.data_ptr()) == inplace
-    assert torch.equal(got, want)
+    _check(got, ref, "residual sum")
+
+
+@pytest.mark.parametrize("M,N,K", [(700, 768, 192), (300, 256, 64), (65536, 1280, 1280)])
+def test_residual_gemm_row_statistics(M, N, K):
+    """The partial LayerNorm statistics the residual GEMM emits, combined by s6d_ln_stats_finalize, are the mean / sigma = sqrt(var + eps) of the fp32
+    result rows (float64 reference), and s6d_row_stats_bf16 of the stored bf16 rows agrees with them to the bf16 rounding."""
+    from sam6d_amd import ops
+    if not torch.cuda.is_available() and M > 1000:
+        pytest.skip("emulator: small shapes only")
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).cuda()
+    b = (torch.randn(N, generator=g) + 0.5).cuda()
+    x = (torch.randn(M, N, generator=g) * torch.rand(M, 1, generator=g) * 3 + torch.randn(M, 1, generator=g)).to(torch.bfloat16).cuda()
+    sp = torch.full((N // 32, 2, M), float("nan"), device=a.device)
+    got = ops.gemm_bf16(a, w, b, residual=x, stats_partial=sp)
+    st = ops.ln_stats_finalize(sp, 32, 1e-6)
+    ref = (a.double() @ w.double().t() + b.double() + x.double())
+    mean = ref.mean(1)
+    sigma = torch.sqrt(ref.var(1, unbiased=False) + 1e-6)
+    assert torch.isfinite(st).all()
+    assert (st[:, 0].double() - mean).abs().max().item() <= 2e-6 * (1 + ref.abs().max().item())
+    assert ((st[:, 1].double() - sigma).abs() / sigma).max().item() <= 2e-5
+    st2 = ops.row_stats(got, 1e-6)
+    assert (st2[:, 0] - st[:, 0]).abs().max().item() <= 1e-3 * (1 + ref.abs().max().item()) / N ** 0.5 * 4
+    assert ((st2[:, 1] - st[:, 1]).abs() / st[:, 1]).max().item() <= 2e-3
+
+
+@pytest.mark.parametrize("M,N,K,gelu,cb", [(700, 768, 192, False, 0), (300, 256, 320, True, 0), (520, 768, 256, False, 64),
+                                             (65536, 3840, 1280, False, 0), (16384, 5120, 1280, True, 0)])
+def test_lnfold_gemm_vs_layernorm_then_linear(M, N, K, gelu, cb):
+    """s6d_gemm_bf16_lnfold: act(LN(x) W^T + b) from the RAW rows, their (mean, sigma) and the folded weight.  Against the float64
+    evaluation of the same folded form: one bf16 rounding.  Against LayerNorm-then-Linear in float64 (the statement it replaces,
+    segment_anything/modeling/image_encoder.py:166-182): the rounding of gamma * W to bf16, relative rms below 3e-3."""
+    from sam6d_amd import ops
+    from sam6d_amd.utils.linear import lnfold_weights
+    if not torch.cuda.is_available() and M > 1000:
+        pytest.skip("emulator: small shapes only")
+    g = torch.Generator().manual_seed(M + N + K + 2)
+    x = (torch.randn(M, K, generator=g) * (0.5 + 2 * torch.rand(M, 1, generator=g)) + torch.randn(M, 1, generator=g)).to(torch.bfloat16).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    gamma = (1 + 0.3 * torch.randn(K, generator=g)).cuda()
+    beta = (0.2 * torch.randn(K, generator=g)).cuda()
+    wf, cs, bf = lnfold_weights(W, b, gamma, beta)
+    st = ops.row_stats(x, 1e-6)
+    out = ops.gemm_bf16_lnfold(x, st, wf, cs, bf, gelu=gelu, col_block=cb)
+    if cb:
+        assert out.shape == (N // cb, M, cb)
+        out = out.permute(1, 0, 2).reshape(M, N)
+    xd = x.double()
+    mu, rs = st[:, :1].double(), 1.0 / st[:, 1:].double()
+    folded = rs * (xd @ wf.double().t() - mu * cs.double()[None, :]) + bf.double()[None, :]
+    true = torch.nn.functional.layer_norm(xd, (K,), gamma.double(), beta.double(), 1e-6) @ W.double().t() + b.double()
+    if gelu:
+        folded, true = torch.nn.functional.gelu(folded), torch.nn.functional.gelu(true)
+    _check(out, folded.float(), "folded form")
+    rel = ((out.double() - true).pow(2).mean() / true.pow(2).mean()).sqrt().item()
+    assert rel <= 3e-3, rel
 
 
 @pytest.mark.parametrize("M,N,K,gelu", [(300, 256, 320, True), (700, 768, 192, False), (6304, 3072, 768, True), (6304, 768, 3072, False)])

@@ -228,7 +228,7 @@ def _event_ms(fn, n):
 
 
 def gemm_ms_inside_the_step(hp):
-    """Average duration of every s6d_gemm_bf16 launch of ONE SAM stage pass, by shape, from HIP events recorded around the launches
+    """Average duration of every s6d_gemm_bf16 / _res / _lnfold launch of ONE SAM stage pass, by form and shape, from HIP events recorded around the launches
     on the stream they run on -- the kernel in the context the step runs it in (between the attention / LayerNorm launches of its
     block, at the clocks of that mix), which is what the rocprofv3 kernel trace of the same command averages
     (profiles/r02_bench_serial_kernel_stats.csv).  Back-to-back launches of one shape on random operands (kernel_rooflines below)
@@ -242,7 +242,17 @@ def gemm_ms_inside_the_step(hp):
         e0.record()
         y = real(a, w, bias, gelu=gelu, **kw)
         e1.record()
-        rec.append(((a.numel() // a.shape[-1], a.shape[-1], w.shape[0], bool(gelu)), e0, e1))
+        form = "res" if kw.get("residual") is not None else "plain"
+        rec.append(((form, a.numel() // a.shape[-1], a.shape[-1], w.shape[0], bool(gelu)), e0, e1))
+        return y
+    real_f = ops.gemm_bf16_lnfold
+
+    def timed_f(a, st, w, cs, bias, gelu=False, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = real_f(a, st, w, cs, bias, gelu=gelu, **kw)
+        e1.record()
+        rec.append((("lnfold", a.numel() // a.shape[-1], a.shape[-1], w.shape[0], bool(gelu)), e0, e1))
         return y
     real8 = ops.gemm_fp8
 
@@ -254,11 +264,11 @@ def gemm_ms_inside_the_step(hp):
         rec.append((("fp8", a8.numel() // a8.shape[-1], a8.shape[-1], w8.shape[0], bool(gelu)), e0, e1))
         return y
     hp.sam_stage()                                          # warm
-    ops.gemm_bf16, ops.gemm_fp8 = timed, timed8
+    ops.gemm_bf16, ops.gemm_fp8, ops.gemm_bf16_lnfold = timed, timed8, timed_f
     try:
         hp.sam_stage()
     finally:
-        ops.gemm_bf16, ops.gemm_fp8 = real, real8
+        ops.gemm_bf16, ops.gemm_fp8, ops.gemm_bf16_lnfold = real, real8, real_f
     torch.cuda.synchronize()
     by = {}
     for key, e0, e1 in rec:
@@ -350,23 +360,51 @@ def kernel_rooflines(dev, sam_chunk, frames, in_step=None):
     # library GEMM (hipBLASLt through torch) at the largest of them for context.  Algorithmic work 2 M N K FLOP.
     M = sam_chunk * 4096
     groups = frames // sam_chunk
+    # Which form of each Linear the block loop runs (sam6d_amd/sam/image_encoder.py): with the folded loop (default) qkv and
+    # lin1 + GELU are the LayerNorm-folded instantiations gemm_bf16_kernel<3 / 4, true> and proj / lin2 the residual one <2, true>;
+    # S6D_LNFOLD=0: the plain instantiations <0 / 1, true> with add_layernorm passes between them.  FLOP are the algorithmic
+    # 2 M N K of the Linear either way (the folded forms do the LayerNorm / the add on top, in the same launch).
+    from sam6d_amd.utils.linear import lnfold_eligible, lnfold_weights
+    xe = torch.empty(1, 1280, dtype=torch.bfloat16, device=dev)
+    if in_step:
+        folded = any(k[0] == "lnfold" for k in in_step)
+    else:
+        folded = lnfold_eligible(xe, 1280, 1280) and os.environ.get("S6D_SAM_GEMM") != "fp8"   # (the fp8 loop does not fold)
     for nm, K, N, gelu in (("qkv", 1280, 3840, False), ("proj", 1280, 1280, False), ("lin1+gelu", 1280, 5120, True),
                            ("lin2", 5120, 1280, False)):
         x = torch.randn(M, K, generator=g).to(dev).to(torch.bfloat16)
-        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).to(torch.bfloat16)
+        W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+        w = W.to(torch.bfloat16)
         b = torch.randn(N, generator=g).to(dev)
         if not ops.have("gemm_bf16"):
             break
-        b2b = _event_ms(lambda: ops.gemm_bf16(x, w, b, gelu=gelu), 10)
+        form = "plain"
+        if folded and nm in ("qkv", "lin1+gelu"):
+            form = "lnfold"
+            wf, cs, bf = lnfold_weights(W, b, torch.ones(K, device=dev), torch.zeros(K, device=dev))
+            st = ops.row_stats(x)
+            b2b = _event_ms(lambda: ops.gemm_bf16_lnfold(x, st, wf, cs, bf, gelu=gelu), 10)
+            inst = "gemm_bf16_kernel<4, true>" if gelu else "gemm_bf16_kernel<3, true>"
+        elif folded:
+            form = "res"
+            xr = torch.randn(M, N, generator=g).to(dev).to(torch.bfloat16)
+            sp = torch.empty(N // 32, 2, M, device=dev)
+            b2b = _event_ms(lambda: ops.gemm_bf16(x, w, b, residual=xr, out=xr, stats_partial=sp), 10)
+            inst = "gemm_bf16_kernel<2, true>"
+        else:
+            b2b = _event_ms(lambda: ops.gemm_bf16(x, w, b, gelu=gelu), 10)
+            inst = "gemm_bf16_kernel<1, true>" if gelu else "gemm_bf16_kernel<0, true>"
         # avg_ms: inside the step (gemm_ms_inside_the_step) when the caller measured it; back_to_back_ms: 10 launches of this shape alone
-        ms = in_step[(M, K, N, gelu)][0] if in_step and (M, K, N, gelu) in in_step else b2b
+        ms = in_step[(form, M, K, N, gelu)][0] if in_step and (form, M, K, N, gelu) in in_step else b2b
         flop = 2.0 * M * N * K
-        out.append({"kernel": f"gemm_bf16_kernel ({nm}, M={M} K={K} N={N})", "bound": "mfma", "achieved": round(flop / ms / 1e9, 1),
+        what = {"plain": "", "lnfold": "LayerNorm-folded ", "res": "+ residual + row statistics, "}[form]
+        out.append({"kernel": f"{inst} ({what}{nm}, M={M} K={K} N={N})", "bound": "mfma", "achieved": round(flop / ms / 1e9, 1),
                     "peak": 2500.0, "unit": "TFLOP/s", "frac": round(flop / ms / 1e9 / 2500.0, 4), "avg_ms": round(ms, 4),
                     "back_to_back_ms": round(b2b, 4), "timed": "inside one SAM stage pass" if ms is not b2b else "back to back",
-                    "launches_per_step": 32 * groups, "algorithmic_bytes": 2.0 * (M * K + N * K + M * N),
-                    # the GELU instance runs at this one shape only; qkv / proj / lin2 share an instance (no per-shape counters)
-                    "pmc_key": "gemm_bf16_kernel<1, true>" if gelu else "-"})
+                    "launches_per_step": 32 * groups,
+                    "algorithmic_bytes": 2.0 * (M * K + N * K + M * N) + (2.0 * M * N if form == "res" else 0.0),
+                    # the GELU instantiations run at this one shape only; the others are shared between shapes (no per-shape counters)
+                    "pmc_key": inst if gelu else "-", "form": form, "shape": nm})
     if os.environ.get("S6D_SAM_GEMM") == "fp8" and ops.have("gemm_fp8"):
         # configs[4]: the two LayerNorm-fed GEMMs on the fp8 matrix cores (dense peak 5 PFLOP/s), and the quantising LayerNorm
         from sam6d_amd.utils import fp8
@@ -391,7 +429,7 @@ def kernel_rooflines(dev, sam_chunk, frames, in_step=None):
                     "launches_per_step": 64 * groups, "algorithmic_bytes": float(M) * 1280 * 3})
         # in this configuration qkv / lin1 do not run the bf16 kernel: their bf16 rows stay for comparison, off the path
         for r in out:
-            if r["kernel"].startswith("gemm_bf16_kernel (qkv") or r["kernel"].startswith("gemm_bf16_kernel (lin1"):
+            if r["kernel"].startswith("gemm_bf16_kernel") and r.get("shape") in ("qkv", "lin1+gelu"):
                 r["launches_per_step"] = 0
     x = torch.randn(M, 1280, generator=g).to(dev).to(torch.bfloat16)
     w = torch.randn(5120, 1280, generator=g).to(dev).to(torch.bfloat16)

@@ -39,11 +39,10 @@ def res_eligible(x, n_out, k_in):
 
 
 def _res_eligible(x, n_out, k_in):
-    """The residual-add epilogue (s6d_gemm_bf16_res): the 256 x 256-tile kernel only.  OFF unless S6D_GEMM_RES=1 -- measured on the
-    MI355X (profiles/r03_gemm_residual_epilogue.txt): the epilogue's residual loads sit behind the tile's own stores in the one
-    in-order memory counter (proj + 24 %, lin2 + 8..14 % per launch) and that eats what the one-read LayerNorm saves (26 us of
-    106): 146.0 against 145.3 frames/s, i.e. nothing.  The fp8 block loop (configs[4]) uses it, its LayerNorm being a different
-    kernel anyway."""
+    """x + Linear(a) in one launch (s6d_gemm_bf16_res): the 256 x 256-tile kernel only.  On its own (the LayerNorm still a pass that
+    reads the sum back) it buys nothing -- one tensor read moves from the add into the GEMM -- so it is OFF unless S6D_GEMM_RES=1;
+    the ViT-H block loop uses it together with the folded LayerNorm (lnfold_eligible below), where both passes disappear
+    (profiles/r03_lnfold.txt)."""
     return (eligible(x, n_out, k_in) and n_out % 256 == 0 and ops.have("gemm_bf16_res")
             and os.environ.get("S6D_GEMM_RES", "0") == "1")
 

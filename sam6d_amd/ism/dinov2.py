@@ -28,7 +28,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from ..utils.linear import eligible, fused_linear
+from ..utils.linear import eligible, fused_linear, lnfold_cached, lnfold_eligible
 
 descriptor_size = {"dinov2_vits14": 384, "dinov2_vitb14": 768, "dinov2_vitl14": 1024, "dinov2_vitg14": 1536}
 descriptor_map = {"dinov2_vits14": "vit_small", "dinov2_vitb14": "vit_base", "dinov2_vitl14": "vit_large",
@@ -205,9 +205,36 @@ class DinoVisionTransformer(nn.Module):
         delta = None
         scale = (self.embed_dim // self.num_heads) ** -0.5
         C = x.shape[-1]
-        if ops.have("gemm_bf16_res") and C % 256 == 0 and all(
-                eligible(x, C, C) and eligible(x, C, blk.mlp.fc2.in_features) and isinstance(blk.mlp.act, nn.GELU)
-                and blk.mlp.act.approximate == "none" for blk in self.blocks):
+        exact_gelu = all(isinstance(blk.mlp.act, nn.GELU) and blk.mlp.act.approximate == "none" for blk in self.blocks)
+        rows = x.numel() // C
+        if (exact_gelu and C % 256 == 0 and all(lnfold_eligible(x, C, C) and lnfold_eligible(x, blk.mlp.fc1.out_features, C) and
+                                                lnfold_eligible(x, C, blk.mlp.fc1.out_features) for blk in self.blocks)
+                and 2 * rows * max(3 * C, max(blk.mlp.fc1.out_features for blk in self.blocks)) < 2 ** 31):
+            # neither the residual adds nor the block LayerNorms as passes of their own: the same folded loop as the SAM encoder's
+            # (sam/image_encoder.py::_blocks_lnfold), LayerScale already folded into proj / fc2 (Block._folded)
+            x = x.clone()
+            B, N, _ = x.shape
+            x2 = x.view(rows, C)
+            blocks = list(self.blocks)
+            st = ops.row_stats(x2, blocks[0].norm1.eps)
+            sp = torch.empty(C // 32, 2, rows, dtype=torch.float32, device=x.device)
+            for i, blk in enumerate(blocks):
+                wp, bp, bpf, w2, b2, b2f = blk._folded(x.dtype)
+                wf, cs, bf = lnfold_cached(blk.attn.qkv, blk.norm1)
+                qkv = ops.gemm_bf16_lnfold(x2, st, wf, cs, bf).view(B, N, 3 * C)
+                o = ops.seq_attention(qkv, blk.attn.num_heads, scale)
+                ops.gemm_bf16(o.reshape(rows, C), wp, bpf, residual=x2, out=x2, stats_partial=sp)
+                st = ops.ln_stats_finalize(sp, 32, blk.norm2.eps)
+                w1, c1, b1 = lnfold_cached(blk.mlp.fc1, blk.norm2)
+                h = ops.gemm_bf16_lnfold(x2, st, w1, c1, b1, gelu=True)
+                last = i + 1 == len(blocks)
+                ops.gemm_bf16(h, w2, b2f, residual=x2, out=x2, stats_partial=None if last else sp)
+                if not last:
+                    st = ops.ln_stats_finalize(sp, 32, blocks[i + 1].norm1.eps)
+            g, b = _ln_f32(self.norm)
+            return ops.add_layernorm(x, None, g, b, self.norm.eps)
+        if ops.have("gemm_bf16_res") and C % 256 == 0 and exact_gelu and all(
+                eligible(x, C, C) and eligible(x, C, blk.mlp.fc2.in_features) for blk in self.blocks):
             # round 3: both residual adds of a block in the epilogues of the proj / fc2 GEMMs (in place on the stream tensor),
             # LayerNorms as one-read passes
             x = x.clone()

@@ -109,3 +109,49 @@ def test_folded_block_loops_against_the_round2_form_and_float(emu, monkeypatch):
     print("rel rms vs float: fold %.3e res %.3e round2 %.3e" % (e_fold, e_res, e_old))
     assert e_old <= 8e-3 and e_res <= 8e-3, (e_fold, e_res, e_old)
     assert e_fold <= 1.1 * e_old + 5e-4, (e_fold, e_res, e_old)
+
+
+def test_dinov2_folded_block_loop_against_float(emu, monkeypatch):
+    """DinoVisionTransformer._blocks_fused (LayerScale folded into proj / fc2, residual adds and block LayerNorms folded into the GEMMs)
+    on a 2-block ViT (dim 256, 4 heads of 64, 17 tokens) against the float32 statement of the module, and not further from it than
+    the add + LayerNorm form (S6D_LNFOLD=0)."""
+    import torch
+
+    from sam6d_amd.ism.dinov2 import DinoVisionTransformer
+    from sam6d_amd.utils import seeded
+    m = DinoVisionTransformer(img_size=56, patch_size=14, embed_dim=256, depth=2, num_heads=4, mlp_ratio=4, init_values=1.0,
+                              block_chunks=0).eval()
+    m = seeded.load_seeded(m, 6)
+    with torch.no_grad():
+        for blk in m.blocks:
+            for n in (blk.norm1, blk.norm2):
+                n.weight.add_(0.2 * torch.randn(256, generator=torch.Generator().manual_seed(7)))
+                n.bias.add_(0.1 * torch.randn(256, generator=torch.Generator().manual_seed(8)))
+            blk.ls1.gamma.mul_(0.7)
+            blk.ls2.gamma.mul_(1.3)
+    x = (0.5 * torch.randn(2, 17, 256, generator=torch.Generator().manual_seed(1)) + 0.2).to(torch.bfloat16)
+    with torch.no_grad():
+        ref = x.float()
+        for blk in m.blocks:
+            ref = blk(ref)
+        refn = m.norm(ref)
+    m = m.bfloat16()
+    calls = {"fold": 0, "ln": 0}
+    real_f, real_l = emu.gemm_bf16_lnfold, emu.add_layernorm
+    monkeypatch.setattr(emu, "gemm_bf16_lnfold", lambda *a, **k: (calls.__setitem__("fold", calls["fold"] + 1), real_f(*a, **k))[1])
+    monkeypatch.setattr(emu, "add_layernorm", lambda *a, **k: (calls.__setitem__("ln", calls["ln"] + 1), real_l(*a, **k))[1])
+
+    def rel(a, r):
+        return ((a.float() - r).pow(2).mean() / r.pow(2).mean()).sqrt().item()
+
+    with torch.no_grad():
+        xf, xnf = m._blocks_fused(x)
+        assert calls == {"fold": 4, "ln": 1}, calls                   # only the final norm is a LayerNorm launch
+        monkeypatch.setenv("S6D_LNFOLD", "0")
+        calls.update(fold=0, ln=0)
+        xo, xno = m._blocks_fused(x)
+        assert calls["fold"] == 0 and calls["ln"] == 5, calls
+    e_f, e_o = rel(xnf, refn), rel(xno, refn)
+    print("DINOv2 mini: rel rms vs float, folded %.3e, add + LayerNorm form %.3e" % (e_f, e_o))
+    assert rel(xf, ref) <= 8e-3 and e_o <= 1e-2, (rel(xf, ref), e_f, e_o)
+    assert e_f <= 1.1 * e_o + 5e-4, (e_f, e_o)

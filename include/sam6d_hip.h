@@ -30,7 +30,7 @@ extern "C" {
 
 /* Bumped whenever a signature in this header changes; the loader (sam6d_amd/_lib.py) refuses a library whose
  * s6d_version() differs from the header it was written against (a stale .so fails at load, not at a call). */
-#define S6D_ABI_VERSION 108
+#define S6D_ABI_VERSION 109
 int s6d_version(void);
 const char *s6d_strerror(int code);
 /* last HIP error string seen by this thread (empty if none) */
@@ -391,6 +391,14 @@ int s6d_mha_f32(const float *q, const float *k, const float *v, int B, int N, in
  * Pose_Estimation_Model/model/transformer.py:536-547. */
 int s6d_linear_attn_focus_f32(const float *x, const float *inv_scale, long rows, int C, int power, float *y,
                               void *stream);
+
+/* The whole focused linear attention behind the projections (LinearAttention.forward, transformer.py:536-564, kv-first branch):
+ * q_proj (B,I,C) the raw proj_q output (the focus map is applied inside), k_focused (B,J,C) rows with stride ldk, v (B,J,C) rows with
+ * stride ldv, inv_scale (C) = 1 / softplus(scale) -> out (B,I,C) = merge_heads((q kv) / (q . sum_j k_j + 1e-6)).  C = 256 (4 heads of
+ * 64).  kv_ws: s6d_linear_attention_workspace_floats(B) floats of scratch. */
+long s6d_linear_attention_workspace_floats(int B);
+int s6d_linear_attention_f32(const float *q_proj, const float *inv_scale, int power, const float *k_focused, long ldk, const float *v,
+                             long ldv, int B, int I, int J, int C, float *kv_ws, float *out, void *stream);
 
 /* Proposal crops for the descriptor model, fused: normalise . mask . crop . nearest resize . zero pad . nearest resize.
  * image (H,W,3) u8, masks (P,H,W) f32 {0,1}, params: P records of 12 int32 / float32 words

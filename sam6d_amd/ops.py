@@ -813,6 +813,30 @@ def linear_attn_focus(x, inv_scale, power):
     return y
 
 
+def linear_attention(q_proj, inv_scale, power, k_focused, v):
+    """Focused linear attention behind the projections: q_proj (B,I,256) f32 raw proj_q output, k_focused (B,J,256) f32 (rows may be
+    strided), v (B,J,256) f32 (rows may be strided), inv_scale (256) -> (B,I,256) f32."""
+    for t, nm in ((q_proj, "q_proj"), (k_focused, "k_focused"), (v, "v")):
+        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 3:
+            raise RuntimeError(f"{nm} must be a 3-d float32 CUDA tensor")
+    q_proj = q_proj.contiguous()
+    B, I, C = q_proj.shape
+    J = k_focused.shape[1]
+    for t, nm in ((k_focused, "k_focused"), (v, "v")):
+        if t.shape != (B, J, C) or t.stride(2) != 1 or t.stride(0) != J * t.stride(1):
+            raise ValueError(f"{nm} must be (B, J, C) with unit channel stride and batch stride J * row stride; got {tuple(t.shape)} "
+                             f"strides {tuple(t.stride())}")
+    inv_scale = inv_scale.reshape(-1).contiguous()
+    _chk(inv_scale, torch.float32, "inv_scale", 1)
+    fn = _lib.lib().s6d_linear_attention_workspace_floats
+    fn.restype = ctypes.c_long
+    ws = torch.empty(int(fn(int(B))), dtype=torch.float32, device=q_proj.device)
+    out = torch.empty_like(q_proj)
+    _call("s6d_linear_attention_f32", _ptr(q_proj), _ptr(inv_scale), int(power), _ptr(k_focused), ctypes.c_long(k_focused.stride(1)),
+          _ptr(v), ctypes.c_long(v.stride(1)), int(B), int(I), int(J), int(C), _ptr(ws), _ptr(out), _stream())
+    return out
+
+
 # ------------------------------------------------------------------ ISM scoring
 def pairwise_cosine(query, ref):
     """(P,C), (R,C) f32 -> (P,R) clamp(cos,0,1)."""
@@ -916,7 +940,7 @@ def have(name):
                "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
                "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_frames_f32",
                "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "crop_resize_pad": "s6d_crop_resize_pad_f32", "samdec_img2tok": "s6d_samdec_img2tok_bf16", "samdec_tok2img": "s6d_samdec_tok2img_f32", "sam_mask_post": "s6d_sam_mask_post_f32", "nms": "s6d_nms_f32", "samdec_upscale_heads": "s6d_samdec_upscale_heads_bf16", "mha": "s6d_mha_f32",
-               "linear_attn_focus": "s6d_linear_attn_focus_f32", "project_bbox": "s6d_project_bbox_frames_f32"}.get(name)
+               "linear_attn_focus": "s6d_linear_attn_focus_f32", "linear_attention": "s6d_linear_attention_f32", "project_bbox": "s6d_project_bbox_frames_f32"}.get(name)
         import os
         disabled = name in os.environ.get("S6D_DISABLE_FUSED", "").split(",")
         _FUSED[name] = (not disabled) and sym is not None and hasattr(_lib.lib(), sym)

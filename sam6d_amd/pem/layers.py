@@ -222,6 +222,11 @@ class LinearAttention(nn.Module):
             focus = lambda t: self._focus(t, inv_scale)                                    # noqa: E731
         C = xq.shape[-1]
         kv_ = plinear(self, (self.proj_k, self.proj_v), xkv)         # k | v of the memory in one launch
+        if ops.have("linear_attention") and ops.have("linear_attn_focus") and xq.is_cuda and C == 256 and xq.dtype == torch.float32:
+            # everything behind the projections in two launches (csrc/s6d_linattn.hip): the focus map of q, k^T v, q . sum k, (q kv) z
+            # and the head merge; k | v stay the two halves of the one projection output (strided rows)
+            return ops.linear_attention(plinear(self, self.proj_q, xq), inv_scale, self.focusing_factor, focus(kv_[..., :C].contiguous()),
+                                        kv_[..., C:])
         q = _split(focus(plinear(self, self.proj_q, xq)))            # (B,h,I,c)
         k = _split(focus(kv_[..., :C].contiguous()))                 # (B,h,J,c)
         v = _split(kv_[..., C:])

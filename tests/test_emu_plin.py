@@ -5,3 +5,8 @@ from tests import test_gpu_plin as T
 def test_linear_f32_on_the_emulator(emu):
     for case in T.CASES:
         T.test_linear_f32_vs_library(*case)
+
+
+def test_linear_attention_on_the_emulator(emu):
+    T.test_linear_attention_vs_the_library_statement(2, 100, 37)
+    T.test_linear_attention_vs_the_library_statement(3, 64, 196)

@@ -66,3 +66,40 @@ def test_linear_f32_at_the_dense_stage_shape():
     rows = torch.randperm(M, generator=g)[:2048]
     ref = torch.nn.functional.layer_norm(x[rows].double() @ w.double().t() + b.double() + r[rows].double(), (N,), gm.double(), bt.double(), 1e-5)
     assert (y[rows].double() - ref).abs().max() < 5e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,I,J", [(2, 100, 37), (3, 64, 196), (32, 2048, 196)])
+def test_linear_attention_vs_the_library_statement(B, I, J):
+    """s6d_linear_attention_f32 (focus map of q + k^T v + q . sum k + (q kv) z + head merge, csrc/s6d_linattn.hip) against the
+    statement it replaces (LinearAttention.forward's library branch = transformer.py:536-564) in float64, with k | v as the strided
+    halves of one projection output, ragged I (rows past I are not stored)."""
+    import torch.nn.functional as F
+
+    from sam6d_amd import ops
+    if not torch.cuda.is_available() and B * I > 1000:
+        pytest.skip("emulator: small shapes only")
+    g = torch.Generator().manual_seed(B + I + J)
+    xq = torch.randn(B, I, 256, generator=g).cuda()
+    kvp = torch.randn(B, J, 512, generator=g).cuda()                  # k | v of one projection launch
+    scale = (0.3 * torch.randn(256, generator=g)).cuda()
+    inv = 1.0 / F.softplus(scale)
+
+    def focus(t, p=3):
+        t = (F.relu(t) + 1e-6) * inv.to(t.dtype)
+        n = t.norm(dim=-1, keepdim=True)
+        t = t ** p
+        return t / t.norm(dim=-1, keepdim=True) * n
+
+    kf = ops.linear_attn_focus(kvp[..., :256].contiguous(), inv, 3)
+    out = ops.linear_attention(xq, inv, 3, kf, kvp[..., 256:])
+    sentinel = torch.full((B, I + 1, 256), 7.0).cuda()                # nothing is written past row I of a batch element
+    assert out.shape == (B, I, 256) and torch.isfinite(out).all() and sentinel[0, I, 0] == 7.0
+
+    def split(t):
+        return t.view(t.shape[0], t.shape[1], 4, 64).transpose(1, 2)
+    q, k, v = split(focus(xq.double())), split(focus(kvp[..., :256].double())), split(kvp[..., 256:].double())
+    z = 1.0 / (q @ k.sum(dim=2).unsqueeze(-1) + 1e-6)
+    ref = ((q @ (k.transpose(-1, -2) @ v)) * z).transpose(1, 2).reshape(B, I, 256)
+    err = (out.double() - ref).abs().max().item()
+    assert err <= 2e-5 * (1 + ref.abs().max().item()), err

@@ -403,8 +403,9 @@ def kernel_rooflines(dev, sam_chunk, frames, in_step=None):
                     "back_to_back_ms": round(b2b, 4), "timed": "inside one SAM stage pass" if ms is not b2b else "back to back",
                     "launches_per_step": 32 * groups,
                     "algorithmic_bytes": 2.0 * (M * K + N * K + M * N) + (2.0 * M * N if form == "res" else 0.0),
-                    # the GELU instantiations run at this one shape only; the others are shared between shapes (no per-shape counters)
-                    "pmc_key": inst if gelu else "-", "form": form, "shape": nm})
+                    # the GELU and the LayerNorm-folded instantiations run at one shape each; <0 / 2, true> are shared between shapes
+                    # (no per-shape counters)
+                    "pmc_key": inst if (gelu or form == "lnfold") else "-", "form": form, "shape": nm})
     if os.environ.get("S6D_SAM_GEMM") == "fp8" and ops.have("gemm_fp8"):
         # configs[4]: the two LayerNorm-fed GEMMs on the fp8 matrix cores (dense peak 5 PFLOP/s), and the quantising LayerNorm
         from sam6d_amd.utils import fp8

@@ -8,6 +8,10 @@ mkdir -p gpurun_out/prof; rm -f gpurun_out/margins.jsonl
 timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > gpurun_out/prof/${R}_gpu_suite.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 >> gpurun_out/prof/${R}_gpu_suite.txt
 cp gpurun_out/margins.jsonl gpurun_out/prof/${R}_parity_margins_final.jsonl
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -o f -- python tools/pmc_kernels.py > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -o w -- python tools/pmc_kernels.py > /dev/null 2>&1
+python tools/pmc_summarise.py gpurun_out/prof/${R}_pmc_summary.json /tmp/pmc_f /tmp/pmc_w > /dev/null 2>&1
+cp gpurun_out/prof/${R}_pmc_summary.json profiles/${R}_pmc_summary.json   # the bench line below reads its roofline.traffic from it
 timeout 900 python bench.py --steps 5 --warmup 2 > gpurun_out/prof/${R}_bench_line.json 2> gpurun_out/prof/${R}_bench.err
 timeout 400 python bench.py --config fp8 --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline > gpurun_out/prof/${R}_bench_fp8_line.json 2>> gpurun_out/prof/${R}_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline > /dev/null 2>&1
@@ -16,9 +20,6 @@ S6D_BENCH_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/
 cp $(find /tmp/prof_serial -name "*kernel_stats.csv" | head -1) gpurun_out/prof/${R}_bench_serial_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_fp8 -o bench -- python bench.py --config fp8 --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline > /dev/null 2>&1
 cp $(find /tmp/prof_fp8 -name "*kernel_stats.csv" | head -1) gpurun_out/prof/${R}_bench_fp8_kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -o f -- python tools/pmc_kernels.py > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -o w -- python tools/pmc_kernels.py > /dev/null 2>&1
-python tools/pmc_summarise.py gpurun_out/prof/${R}_pmc_summary.json /tmp/pmc_f /tmp/pmc_w > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d /tmp/pmc_s -o s -- python tools/pmc_kernels.py > /dev/null 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc_g -o g -- python tools/pmc_kernels.py > /dev/null 2>&1
 python tools/pmc_sq_summarise.py gpurun_out/prof/${R}_sq_summary.json /tmp/pmc_s /tmp/pmc_g > /dev/null 2>&1

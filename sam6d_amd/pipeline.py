@@ -83,11 +83,9 @@ class FramePipeline:
         x = torch.stack([rs.apply_image(im).permute(2, 0, 1) for im in images]).float()
         return self.enc(sam_preprocess(x, self.enc.img_size)).float()
 
-    def _detect(self, emb, image_u8, depth, K):
-        """proposals -> descriptors -> scores -> the frame's Detections, best first (None-free: an empty Detections when nothing
-        survives).  emb: this frame's (1,256,64,64) embedding."""
+    def _propose(self, emb, image_u8):
+        """proposals of one frame that survive the size filters and whose crop exists -> (masks, boxes).  emb: (1,256,64,64)."""
         H, W = image_u8.shape[:2]
-        t0 = time.perf_counter()
         prop = amg.generate_proposals(self.pe, self.md, emb, (H, W), self.enc.img_size, points_per_batch=self.ppb,
                                       **self.seg_kw)
         area = prop["masks"].flatten(1).sum(1).float() / (H * W)
@@ -98,12 +96,10 @@ class FramePipeline:
         # slivers that vanish in the resize; sam6d_amd/ism/dinov2.py crop_params) are dropped here instead of aborting the frame
         from .ism.dinov2 import crop_valid
         keep &= torch.from_numpy(crop_valid(prop["boxes"].cpu().numpy(), self.desc.proposal_size)).to(keep.device)
-        masks, boxes = prop["masks"][keep], prop["boxes"][keep]
-        t0 = self._tick("proposals", t0)
-        if masks.shape[0] == 0:
-            return Detections(0, 0, masks, boxes, boxes.new_zeros(0), boxes.new_zeros(0))
-        cls, patch = self.desc(image_u8, SimpleNamespace(masks=masks.float(), boxes=boxes))      # device frame: no host round trip
-        t0 = self._tick("descriptors", t0)
+        return prop["masks"][keep], prop["boxes"][keep]
+
+    def _score(self, cls, patch, masks, boxes, depth, K):
+        """descriptors -> scores -> the frame's Detections, best first."""
         sc = self.score_metres(cls, patch, masks.float(), boxes.float(), depth, K)
         order = torch.argsort(sc["final"], descending=True)
         sel = sc["sel"][order]
@@ -115,8 +111,47 @@ class FramePipeline:
             det.filter(det.scores > self.det_thresh)
         if isinstance(self.top_k, int):
             det.filter(slice(0, self.top_k))
+        return det
+
+    def _detect(self, emb, image_u8, depth, K):
+        """proposals -> descriptors -> scores -> the frame's Detections, best first (None-free: an empty Detections when nothing
+        survives).  emb: this frame's (1,256,64,64) embedding."""
+        t0 = time.perf_counter()
+        masks, boxes = self._propose(emb, image_u8)
+        t0 = self._tick("proposals", t0)
+        if masks.shape[0] == 0:
+            return Detections(0, 0, masks, boxes, boxes.new_zeros(0), boxes.new_zeros(0))
+        cls, patch = self.desc(image_u8, SimpleNamespace(masks=masks.float(), boxes=boxes))      # device frame: no host round trip
+        t0 = self._tick("descriptors", t0)
+        det = self._score(cls, patch, masks, boxes, depth, K)
         self._tick("scoring", t0)
         return det
+
+    def _detect_group(self, emb, frames):
+        """``_detect`` for a group of frames with the descriptor ViT batched ACROSS the frames (CustomDINOv2.frame_batcher: batches
+        sized for the GEMM tile grid instead of one ragged batch per frame, launched as soon as they fill so that the device has
+        descriptor work queued while the host prepares the next frame's proposals).  Same Detections as per-frame calls.
+        Measured (tools/probes/desc_group_ab*.py): the ViT alone runs 21.9 instead of 25.6 ms per 128 crops in batches of 255, but a
+        group gains only 0.7 ms per frame (61.4 vs 62.1 ms): frame by frame the ViT starts on a cool socket after the mask decoder
+        (23.6 ms), four full batches back to back run at the power limit.  S6D_DESC_GROUP=0: frame by frame (A/B runs)."""
+        if len(frames) == 1 or not (hasattr(self.desc, "frame_batcher") and os.environ.get("S6D_DESC_GROUP", "1") == "1"):
+            return [self._detect(emb[i:i + 1], f[0], f[1], f[2]) for i, f in enumerate(frames)]
+        t0 = time.perf_counter()
+        fb, props = self.desc.frame_batcher(), []
+        for i, f in enumerate(frames):
+            masks, boxes = self._propose(emb[i:i + 1], f[0])
+            props.append((masks, boxes))
+            fb.add(f[0], SimpleNamespace(masks=masks.float(), boxes=boxes))
+        feats = fb.finish()
+        t0 = self._tick("proposals+descriptors", t0)
+        dets = []
+        for f, (masks, boxes), ft in zip(frames, props, feats):
+            if ft is None:
+                dets.append(Detections(0, 0, masks, boxes, boxes.new_zeros(0), boxes.new_zeros(0)))
+            else:
+                dets.append(self._score(ft[0], ft[1], masks, boxes, f[1], f[2]))
+        self._tick("scoring", t0)
+        return dets
 
     def _pem_forward(self, ep):
         """Net.forward for the group's M instances.  With few instances the point transformer is LAUNCH-bound (measured: 18.6 ms for
@@ -162,7 +197,8 @@ class FramePipeline:
     @torch.no_grad()
     def run_group(self, frames):
         """A group of frames through the chain with the batch where the models want it: ONE SAM encoder pass over the group's frames,
-        proposals / descriptors / scores frame by frame (1024 prompts and ~128 crops are a full batch already), the PEM's
+        proposals and scores frame by frame (1024 prompts are a full batch already), the descriptor ViT over the group's crops in
+        batches that fill the GEMM tile grid (a frame's 128 x 257 token rows are 128.5 row tiles: ragged), the PEM's
         pre-processing frame by frame and ONE PEM pass over the instances of the whole group (10 instances per frame leave
         the point transformer launch-bound; 32 fill it).  frames: list of (image_u8, depth, K, sample_keys, coarse_rand_u) as in
         ``__call__``, all of one size.  -> list of (Detections, poses-or-None) per frame, the same values frame-by-frame calls
@@ -175,7 +211,7 @@ class FramePipeline:
         t0 = time.perf_counter()
         emb = self._embed([f[0] for f in frames])
         t0 = self._tick("sam_encoder", t0)
-        dets = [self._detect(emb[i:i + 1], f[0], f[1], f[2]) for i, f in enumerate(frames)]
+        dets = self._detect_group(emb, frames)
         if self.top_k == "keys":                                         # per-frame instance budget = rows of injected randoms
             for det, f in zip(dets, frames):
                 det.filter(slice(0, min(f[3].shape[0], f[4].shape[0])))

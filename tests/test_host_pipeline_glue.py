@@ -187,3 +187,20 @@ def test_pipeline_rejects_too_few_random_rows():
     pipe = pipeline.FramePipeline(None, None, None, None, None, None, {}, 1.0, top_k=4)
     with pytest.raises(ValueError, match="one row per detection"):
         pipe(torch.zeros(8, 8, 3, dtype=torch.uint8), torch.zeros(8, 8), torch.eye(3), torch.zeros(2, 64), torch.zeros(4, 18000))
+
+
+def test_descriptor_batches_fill_the_tile_grid():
+    """dinov2.plan_chunks: the batch sizes add up, no batch exceeds 255 proposals (256 row tiles), full groups are cut into 255s
+    (255 x 257 token rows = 256 row tiles exactly) and the plan never costs more tile rounds than one batch per 128 proposals."""
+    from sam6d_amd.ism.dinov2 import plan_chunks
+
+    def rounds(c):                                                      # proj / fc2: 4 column tiles per row tile on 256 CUs
+        mt = -(-c * 257 // 256)
+        return -(-mt * 4 // 256)
+    for n in (1, 7, 63, 64, 128, 255, 256, 300, 640, 1024, 1531):
+        plan = plan_chunks(n)
+        assert sum(plan) == n and max(plan) <= 255 and min(plan) >= 1
+        naive = [128] * (n // 128) + ([n % 128] if n % 128 else [])
+        assert sum(rounds(c) for c in plan) <= sum(rounds(c) for c in naive)
+    assert plan_chunks(1024) == [255, 255, 255, 255, 4]
+    assert plan_chunks(128) == [128]

@@ -92,6 +92,12 @@ typedef unsigned short u16;
 #ifndef S6D_GEMM_PH2
 #define S6D_GEMM_PH2 1
 #endif
+#ifndef S6D_GEMM_AUX_A
+#define S6D_GEMM_AUX_A 0
+#endif
+#ifndef S6D_GEMM_AUX_B
+#define S6D_GEMM_AUX_B 0
+#endif
 // Also tried and dropped: draining the ring (vmcnt(0)) before the stores so that no counted wait sits behind them for 7 phases --
 // the single vector-memory counter makes a counted wait behind 16 stores wait for their acknowledgement -- measured -8 % (the drain
 // itself exposes a load latency per tile and the store cost did not move: profiles/r02_gemm_variants_qt_drain.json).
@@ -244,15 +250,20 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
     tile_mn(tile, m0, n0);
     b_off = (unsigned)(n0 + srow) * p.ldw2 + sc0;
   };
-  auto dma = [&](const u16 *base, unsigned off, int slot, int piece) __attribute__((always_inline)) {
+  // S6D_GEMM_AUX_A / _B: cache-policy bits of the LDS-DMA of the activation / weight stream (2 = nt, "streaming"): experiment knobs,
+  // see profiles/r03_lnfold.txt for what they measured
+  auto dma = [&](const u16 *base, unsigned off, int slot, int piece, bool is_b = false) __attribute__((always_inline)) {
     S6D_LDS(char) *dst = (S6D_LDS(char) *)gemm_smem + slot * kSlot + (wave * 2 + piece) * 1024;
     if (S6D_GEMM_ABLATE & 1) return;
-    __builtin_amdgcn_global_load_lds((const S6D_GLOBAL(void) *)((const char *)base + off), dst, 16, 0, 0);
+    if (is_b)
+      __builtin_amdgcn_global_load_lds((const S6D_GLOBAL(void) *)((const char *)base + off), dst, 16, 0, S6D_GEMM_AUX_B);
+    else
+      __builtin_amdgcn_global_load_lds((const S6D_GLOBAL(void) *)((const char *)base + off), dst, 16, 0, S6D_GEMM_AUX_A);
   };
   auto issue_b = [&](int half, int slot) __attribute__((always_inline)) {
     const unsigned o = b_off + (unsigned)ib_kt * 128u + (unsigned)half * 128u * p.ldw2;
-    dma(p.W, o, slot, 0);
-    dma(p.W, o + 8u * p.ldw2 + sd1, slot, 1);
+    dma(p.W, o, slot, 0, true);
+    dma(p.W, o + 8u * p.ldw2 + sd1, slot, 1, true);
     if (half == 1 && ++ib_kt == p.nk) {
       ib_kt = 0;
       if (++ib_tile < my_tiles) set_b(ib_tile);

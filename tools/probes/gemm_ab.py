@@ -6,7 +6,7 @@ import sys
 import torch
 
 vp = ctypes.c_void_p
-MODES = (True, "res")
+MODES = (True,)
 SHAPES = [("qkv", 1280, 3840, 0), ("proj", 1280, 1280, 0), ("lin1+gelu", 1280, 5120, 1), ("lin2", 5120, 1280, 0)]
 M = 65536
 

@@ -126,6 +126,7 @@ def _run_res():
     T.test_lnfold_gemm_vs_layernorm_then_linear(700, 768, 192, False, 0)
     T.test_lnfold_gemm_vs_layernorm_then_linear(300, 256, 320, True, 0)
     T.test_lnfold_gemm_vs_layernorm_then_linear(520, 768, 256, False, 64)
+    T.test_lnfold_gemm_with_offset_rows(300, 256, 320)
     T.test_float16_gemm_vs_float(300, 256, 320, True)
     T.test_float16_gemm_vs_float(700, 768, 192, False)
 

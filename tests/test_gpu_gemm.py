@@ -226,3 +226,28 @@ def test_float16_gemm_vs_float(M, N, K, gelu):
         ref = torch.nn.functional.gelu(ref)
     err = (out.float().cpu().double() - ref).abs()
     assert (err <= 2.0 ** -11 * ref.abs() * 1.01 + 2e-5).all(), (err / (2.0 ** -11 * ref.abs() + 2e-5)).max().item()
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 320), (8192, 3840, 1280)])
+def test_lnfold_gemm_with_offset_rows(M, N, K):
+    """The fold subtracts mean_m s_n from a product of the RAW rows: rows whose mean is 30 standard deviations (bf16 spacing at that
+    magnitude: 1/8 of sigma -- the stream's own rounding, which the LayerNorm pass of the unfolded form reads too) must come out as
+    close to the float64 LayerNorm -> Linear of the same bf16 rows as rows with zero mean do."""
+    from sam6d_amd import ops
+    from sam6d_amd.utils.linear import lnfold_weights
+    if not torch.cuda.is_available() and M > 1000:
+        pytest.skip("emulator: small shapes only")
+    g = torch.Generator().manual_seed(M + N + K + 3)
+    base = torch.randn(M, K, generator=g)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    gamma = (1 + 0.3 * torch.randn(K, generator=g)).cuda()
+    beta = (0.2 * torch.randn(K, generator=g)).cuda()
+    wf, cs, bf = lnfold_weights(W, b, gamma, beta)
+    rel = {}
+    for off in (0.0, 30.0):
+        x = (base + off).to(torch.bfloat16).cuda()
+        out = ops.gemm_bf16_lnfold(x, ops.row_stats(x, 1e-6), wf, cs, bf)
+        true = torch.nn.functional.layer_norm(x.double(), (K,), gamma.double(), beta.double(), 1e-6) @ W.double().t() + b.double()
+        rel[off] = ((out.double() - true).pow(2).mean() / true.pow(2).mean()).sqrt().item()
+    assert rel[0.0] <= 3e-3 and rel[30.0] <= 1.5 * rel[0.0] + 1e-3, rel

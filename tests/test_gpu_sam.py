@@ -92,6 +92,31 @@ def test_vit_h_bf16_error_growth_model(monkeypatch):
     assert rel["neck"] <= E_BLOCK * 33 ** 0.5 * GAIN, rel
 
 
+def test_vit_h_folded_block_loop_is_what_runs(monkeypatch):
+    """At the released ViT-H dimensions the bf16 block loop is the folded one (no add_layernorm launch between the blocks: two
+    residual GEMMs and two LayerNorm-folded GEMMs per block), and its token map agrees with the add + LayerNorm form
+    (S6D_LNFOLD=0) to the two paths' independent bf16 roundings."""
+    from sam6d_amd import ops
+    from sam6d_amd.sam.image_encoder import build_vit_h
+    m = seeded.load_seeded(build_vit_h().eval(), 3).cuda()
+    x = synth.sam_input(1, 5, 1024).cuda().to(torch.bfloat16)
+    calls = {"fold": 0, "res": 0, "ln": 0}
+    real_f, real_g, real_l = ops.gemm_bf16_lnfold, ops.gemm_bf16, ops.add_layernorm
+    monkeypatch.setattr(ops, "gemm_bf16_lnfold", lambda *a, **k: (calls.__setitem__("fold", calls["fold"] + 1), real_f(*a, **k))[1])
+    monkeypatch.setattr(ops, "gemm_bf16", lambda *a, **k: (calls.__setitem__("res", calls["res"] + (k.get("residual") is not None)), real_g(*a, **k))[1])
+    monkeypatch.setattr(ops, "add_layernorm", lambda *a, **k: (calls.__setitem__("ln", calls["ln"] + 1), real_l(*a, **k))[1])
+    k = 4
+    with torch.no_grad(), torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        folded = m.forward_tokens(x, upto=k).float()
+        assert calls == {"fold": 2 * k, "res": 2 * k, "ln": 0}, calls
+        monkeypatch.setenv("S6D_LNFOLD", "0")
+        passes = m.forward_tokens(x, upto=k).float()
+        assert calls["fold"] == 2 * k and calls["ln"] == 2 * k, calls
+    rel = ((folded - passes).pow(2).mean().sqrt() / passes.pow(2).mean().sqrt()).item()
+    util.record_margin("vit_h_folded_vs_passes", rel_4=rel)
+    assert rel <= 1.5 * E_BLOCK * (k + 1) ** 0.5, rel
+
+
 def test_preprocess_matches_oracle():
     from sam6d_amd.sam.image_encoder import preprocess
     g = torch.Generator().manual_seed(0)

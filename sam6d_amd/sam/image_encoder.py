@@ -334,11 +334,39 @@ class ImageEncoderViT(nn.Module):
         C = x.shape[-1]
         if not (ops.have("gemm_fp8") and ops.have("layernorm_fp8") and x.is_cuda and x.dtype == torch.bfloat16 and C % 256 == 0):
             raise RuntimeError("S6D_SAM_GEMM=fp8 needs the fp8 kernels of libsam6d_hip.so, a bf16 device token map and C % 256 == 0")
+        from ..utils.linear import _cached
+        B, H, W, _ = x.shape
+        M = B * H * W
+        if ops.have("gemm_bf16_res") and all(blk.attn.use_rel_pos for blk in self.blocks) and ops.have("win_attention") \
+                and 2 * M * max(blk.mlp.lin1.out_features for blk in self.blocks) < 2 ** 31:
+            # the residual adds in the bf16 proj / lin2 GEMMs (accumulators start at bias + residual, in place on the stream
+            # tensor): the quantising LayerNorm then reads ONE tensor and writes its e4m3 rows
+            x = x.clone()
+            x2 = x.view(M, C)
+            for i, blk in enumerate(self.blocks):
+                if upto is not None and i >= upto:
+                    break
+                at = blk.attn
+                g, b = self._ln_f32(blk.norm1)
+                h8, hs = ops.layernorm_fp8(x, g, b, blk.norm1.eps)
+                wq, ws, bq = fp8.cached_weight(at.qkv)
+                qkv = ops.gemm_fp8(h8, hs, wq, ws, bq).view(B, H, W, 3 * C)
+                S = blk.window_size if blk.window_size > 0 else H
+                bias, rh, rw = at._kernel_operands(S, qkv.dtype)
+                a = ops.window_attention(qkv, bias, rh, rw, at.num_heads, blk.window_size, at.scale)
+                wp, bp = _cached(at.proj, at.proj.weight)
+                ops.gemm_bf16(a.reshape(M, C), wp, bp, residual=x2, out=x2)
+                g, b = self._ln_f32(blk.norm2)
+                h8, hs = ops.layernorm_fp8(x, g, b, blk.norm2.eps)
+                w1, s1, b1 = fp8.cached_weight(blk.mlp.lin1)
+                w2, b2 = _cached(blk.mlp.lin2, blk.mlp.lin2.weight)
+                ops.gemm_bf16(ops.gemm_fp8(h8, hs, w1, s1, b1, gelu=True), w2, b2, residual=x2, out=x2)
+            return x
         delta = None
         for i, blk in enumerate(self.blocks):
             if upto is not None and i >= upto:
                 break
-            # each residual add folded into the following quantising LayerNorm pass, as in the bf16 loop
+            # each residual add folded into the following quantising LayerNorm pass, as in the round-2 bf16 loop
             g, b = self._ln_f32(blk.norm1)
             if delta is None:
                 h8, hs = ops.layernorm_fp8(x, g, b, blk.norm1.eps)

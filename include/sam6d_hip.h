@@ -30,7 +30,7 @@ extern "C" {
 
 /* Bumped whenever a signature in this header changes; the loader (sam6d_amd/_lib.py) refuses a library whose
  * s6d_version() differs from the header it was written against (a stale .so fails at load, not at a call). */
-#define S6D_ABI_VERSION 109
+#define S6D_ABI_VERSION 110
 int s6d_version(void);
 const char *s6d_strerror(int code);
 /* last HIP error string seen by this thread (empty if none) */
@@ -162,6 +162,11 @@ int s6d_min_dist_f32(const float *pts, const float *R, const float *t, const flo
 int s6d_rpe_attention_f32(const float *q, const float *k, const float *v, const float *qt, const float *qb,
                           const float *embed, int B, int N, int C, int heads, float scale, float *out,
                           void *stream);
+/* The same with row strides ldq / ldk / ldv (floats, multiples of 4) for q / k / v: the column blocks of one q | k | v projection
+ * output are attended without copies. */
+int s6d_rpe_attention_strided_f32(const float *q, long ldq, const float *k, long ldk, const float *v, long ldv, const float *qt,
+                                  const float *qb, const float *embed, int B, int N, int C, int heads, float scale, float *out,
+                                  void *stream);
 
 /* ---------------------------------------------------------------- SAM image encoder */
 
@@ -385,6 +390,8 @@ int s6d_upsample_gather_f32(const float *up, const int64_t *choose, int B, int n
  * (the cross-attention of GeometricTransformer; no masks / factors on the inference path). */
 int s6d_mha_f32(const float *q, const float *k, const float *v, int B, int N, int M, int C, int heads, float scale,
                 float *out, void *stream);
+int s6d_mha_strided_f32(const float *q, long ldq, const float *k, long ldk, const float *v, long ldv, int B, int N, int M, int C,
+                        int heads, float scale, float *out, void *stream);   /* row strides as s6d_rpe_attention_strided_f32 */
 
 /* Focused linear attention feature map: t = (relu(x) + 1e-6) * inv_scale; y = t^p / |t^p| * |t| per row.
  * x, y (rows,256) f32; inv_scale (256) = 1 / softplus(scale).  ref: LinearAttention.forward,

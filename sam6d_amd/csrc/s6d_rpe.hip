@@ -22,7 +22,9 @@ template <int WAVES, bool RPE>
 __global__ __launch_bounds__(WAVES * 64) void rpe_attention_kernel(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ qt, const float *__restrict__ qb, const float *__restrict__ embed,
-    int B, int N, int M, float scale, float *__restrict__ out) {
+    int B, int N, int M, float scale, float *__restrict__ out, long ldq, long ldk, long ldv) {
+  // ldq / ldk / ldv: row strides (floats) of q / k / v -- 256 for contiguous tensors, the projection's row width when they are the
+  // column blocks of one q | k | v (k | v) projection output (no .contiguous() copies between the Linear and the attention)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int Np = (M + 3) & ~3;
@@ -33,7 +35,7 @@ __global__ __launch_bounds__(WAVES * 64) void rpe_attention_kernel(
   const int g = lane >> 4;                                                // head owned by this lane group
   const int c4 = lane * 4;                                                // channels c4..c4+3 (head = c4/64 = g)
 
-  const float4 q4 = *reinterpret_cast<const float4 *>(q + row * 256 + c4);
+  const float4 q4 = *reinterpret_cast<const float4 *>(q + row * ldq + c4);
   float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0, t2 = t0, t3 = t0;  // q~ of the four heads
   float qbg = 0.f;
   const float *erow = nullptr;
@@ -46,13 +48,13 @@ __global__ __launch_bounds__(WAVES * 64) void rpe_attention_kernel(
     qbg = qb[((size_t)b * 4 + g) * N + n];
     erow = embed + (size_t)row * M * 256 + c4;
   }
-  const float *krow = k + (size_t)b * M * 256 + c4;
-  const float *vrow = v + (size_t)b * M * 256 + c4;
+  const float *krow = k + (size_t)b * M * ldk + c4;
+  const float *vrow = v + (size_t)b * M * ldv + c4;
   const bool hi32 = lane & 32, hi16 = lane & 16;
 
   // ---- scores -------------------------------------------------------------------------------
   for (int m = 0; m < M; ++m) {
-    const float4 k4 = *reinterpret_cast<const float4 *>(krow + (size_t)m * 256);
+    const float4 k4 = *reinterpret_cast<const float4 *>(krow + (size_t)m * ldk);
     float mine = 0.f;
     if (RPE) {
       const float4 e4 = *reinterpret_cast<const float4 *>(erow + (size_t)m * 256);
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(WAVES * 64) void rpe_attention_kernel(
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int m = 0; m < M; ++m) {
     const float a = sc[g * Np + m];
-    const float4 v4 = *reinterpret_cast<const float4 *>(vrow + (size_t)m * 256);
+    const float4 v4 = *reinterpret_cast<const float4 *>(vrow + (size_t)m * ldv);
     acc.x += a * v4.x; acc.y += a * v4.y; acc.z += a * v4.z; acc.w += a * v4.w;
   }
   acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
@@ -108,40 +110,52 @@ __global__ __launch_bounds__(WAVES * 64) void rpe_attention_kernel(
 
 using namespace s6d;
 
-extern "C" int s6d_rpe_attention_f32(const float *q, const float *k, const float *v, const float *qt,
-                                     const float *qb, const float *embed, int B, int N, int C, int heads,
-                                     float scale, float *out, void *stream) {
-  if (B < 0 || N <= 0) return S6D_EINVAL;
+extern "C" int s6d_rpe_attention_strided_f32(const float *q, long ldq, const float *k, long ldk, const float *v, long ldv,
+                                             const float *qt, const float *qb, const float *embed, int B, int N, int C, int heads,
+                                             float scale, float *out, void *stream) {
+  if (B < 0 || N <= 0 || ldq < C || ldk < C || ldv < C || (ldq % 4) || (ldk % 4) || (ldv % 4)) return S6D_EINVAL;
   if (C != 256 || heads != 4) return S6D_EUNSUPPORTED;   // released model: d_model 256, 4 heads
   if (B == 0) return S6D_OK;
   if (!q || !k || !v || !qt || !qb || !embed || !out) return S6D_EINVAL;
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return S6D_EINVAL;
   constexpr int WAVES = 4;
   const long rows = (long)B * N;
   const int Np = (N + 3) & ~3;
   const size_t lds = (size_t)WAVES * 4 * Np * sizeof(float);
   if (lds > 64 * 1024) return S6D_EUNSUPPORTED;
   hipLaunchKernelGGL((rpe_attention_kernel<WAVES, true>), dim3((unsigned)((rows + WAVES - 1) / WAVES)), dim3(WAVES * 64),
-                     lds, as_stream(stream), q, k, v, qt, qb, embed, B, N, N, scale, out);
+                     lds, as_stream(stream), q, k, v, qt, qb, embed, B, N, N, scale, out, ldq, ldk, ldv);
   return launch_status();
 }
 
-extern "C" int s6d_mha_f32(const float *q, const float *k, const float *v, int B, int N, int M, int C, int heads,
-                           float scale, float *out, void *stream) {
-  if (B < 0 || N <= 0 || M <= 0) return S6D_EINVAL;
+extern "C" int s6d_rpe_attention_f32(const float *q, const float *k, const float *v, const float *qt,
+                                     const float *qb, const float *embed, int B, int N, int C, int heads,
+                                     float scale, float *out, void *stream) {
+  return s6d_rpe_attention_strided_f32(q, C, k, C, v, C, qt, qb, embed, B, N, C, heads, scale, out, stream);
+}
+
+extern "C" int s6d_mha_strided_f32(const float *q, long ldq, const float *k, long ldk, const float *v, long ldv, int B, int N, int M,
+                                   int C, int heads, float scale, float *out, void *stream) {
+  if (B < 0 || N <= 0 || M <= 0 || ldq < C || ldk < C || ldv < C || (ldq % 4) || (ldk % 4) || (ldv % 4)) return S6D_EINVAL;
   if (C != 256 || heads != 4) return S6D_EUNSUPPORTED;
   if (B == 0) return S6D_OK;
   if (!q || !k || !v || !out) return S6D_EINVAL;
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return S6D_EINVAL;
   constexpr int WAVES = 4;
   const long rows = (long)B * N;
   const int Np = (M + 3) & ~3;
   const size_t lds = (size_t)WAVES * 4 * Np * sizeof(float);
   if (lds > 64 * 1024) return S6D_EUNSUPPORTED;
   hipLaunchKernelGGL((rpe_attention_kernel<WAVES, false>), dim3((unsigned)((rows + WAVES - 1) / WAVES)), dim3(WAVES * 64),
-                     lds, as_stream(stream), q, k, v, nullptr, nullptr, nullptr, B, N, M, scale, out);
+                     lds, as_stream(stream), q, k, v, nullptr, nullptr, nullptr, B, N, M, scale, out, ldq, ldk, ldv);
   return launch_status();
 }
 
-// ------------------------------------------------------------------------------------------------------------
+extern "C" int s6d_mha_f32(const float *q, const float *k, const float *v, int B, int N, int M, int C, int heads,
+                           float scale, float *out, void *stream) {
+  return s6d_mha_strided_f32(q, C, k, C, v, C, B, N, M, C, heads, scale, out, stream);
+}
+
 // Focused-linear-attention feature map (LinearAttention.forward, transformer.py:536-547), one pass:
 //   t = (relu(x) + 1e-6) / softplus(scale);  y = t^p / |t^p| * |t|      (p = focusing_factor = 3)
 // The reference spends ~9 element-wise / reduction passes over (B,2048,256) per call.  One wave per row.

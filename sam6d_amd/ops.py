@@ -170,15 +170,30 @@ def min_dist(pts, R, t, model):
 
 
 # ------------------------------------------------------------------ PEM point transformer
+def _rows3(t, name):
+    """(B, N, 256) f32 with unit channel stride whose rows sit at a constant stride (a column block of a wider contiguous (B, N, L)
+    tensor qualifies) -> (tensor, row stride); anything else is made contiguous."""
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 3:
+        raise RuntimeError(f"{name} must be a 3-d float32 CUDA tensor")
+    B, N, C = t.shape
+    if t.stride(2) == 1 and t.stride(1) % 4 == 0 and t.stride(1) >= C and (B == 1 or t.stride(0) == N * t.stride(1)) \
+            and t.data_ptr() % 16 == 0:
+        return t, t.stride(1)
+    t = t.contiguous()
+    return t, C
+
+
 def rpe_attention(q, k, v, qt, qb, embed, scale):
-    """q,k,v (B,N,256); qt (B,4,N,256); qb (B,4,N); embed (B,N,N,256) -> (B,N,256), all f32."""
-    q, k, v, qt, qb = (t.contiguous() for t in (q, k, v, qt, qb))
-    for a, nm in ((q, "q"), (k, "k"), (v, "v"), (qt, "qt"), (qb, "qb"), (embed, "embed")):
+    """q,k,v (B,N,256) (column blocks of one projection output are taken as they are); qt (B,4,N,256); qb (B,4,N);
+    embed (B,N,N,256) -> (B,N,256), all f32."""
+    (q, ldq), (k, ldk), (v, ldv) = _rows3(q, "q"), _rows3(k, "k"), _rows3(v, "v")
+    qt, qb = qt.contiguous(), qb.contiguous()
+    for a, nm in ((qt, "qt"), (qb, "qb"), (embed, "embed")):
         _chk(a, torch.float32, nm)
     B, N, C = q.shape
-    out = torch.empty_like(q)
-    _call("s6d_rpe_attention_f32", _ptr(q), _ptr(k), _ptr(v), _ptr(qt), _ptr(qb), _ptr(embed), B, N, C, 4,
-          ctypes.c_float(scale), _ptr(out), _stream())
+    out = torch.empty(B, N, C, dtype=torch.float32, device=q.device)
+    _call("s6d_rpe_attention_strided_f32", _ptr(q), ctypes.c_long(ldq), _ptr(k), ctypes.c_long(ldk), _ptr(v), ctypes.c_long(ldv),
+          _ptr(qt), _ptr(qb), _ptr(embed), B, N, C, 4, ctypes.c_float(scale), _ptr(out), _stream())
     return out
 
 
@@ -790,14 +805,13 @@ def pe_group_mlp(pts, idx, W0, b0, W1, b1, W2, b2):
 
 
 def mha(q, k, v, scale):
-    """q (B,N,256), k/v (B,M,256) f32 -> (B,N,256): 4-head softmax attention, one wavefront per query row."""
-    q, k, v = (t.contiguous() for t in (q, k, v))
-    for a, nm in ((q, "q"), (k, "k"), (v, "v")):
-        _chk(a, torch.float32, nm, 3)
+    """q (B,N,256), k/v (B,M,256) f32 (column blocks of one projection output are taken as they are) -> (B,N,256): 4-head softmax
+    attention, one wavefront per query row."""
+    (q, ldq), (k, ldk), (v, ldv) = _rows3(q, "q"), _rows3(k, "k"), _rows3(v, "v")
     B, N, C = q.shape
-    out = torch.empty_like(q)
-    _call("s6d_mha_f32", _ptr(q), _ptr(k), _ptr(v), B, N, int(k.shape[1]), C, 4, ctypes.c_float(scale), _ptr(out),
-          _stream())
+    out = torch.empty(B, N, C, dtype=torch.float32, device=q.device)
+    _call("s6d_mha_strided_f32", _ptr(q), ctypes.c_long(ldq), _ptr(k), ctypes.c_long(ldk), _ptr(v), ctypes.c_long(ldv), B, N,
+          int(k.shape[1]), C, 4, ctypes.c_float(scale), _ptr(out), _stream())
     return out
 
 

@@ -98,7 +98,7 @@ class MultiHeadAttention(nn.Module):
             q = plinear(self, self.proj_q, xq)
             if xk is xv:                                              # k | v of the memory in one launch
                 kv = plinear(self, (self.proj_k, self.proj_v), xk)
-                k, v = kv[..., :C].contiguous(), kv[..., C:].contiguous()
+                k, v = kv[..., :C], kv[..., C:]                        # column blocks, attended in place (row stride 2 C)
             else:
                 k, v = plinear(self, self.proj_k, xk), plinear(self, self.proj_v, xv)
             return ops.mha(q, k, v, self.scale)
@@ -122,7 +122,7 @@ class RPEMultiHeadAttention(nn.Module):
     def forward(self, x, embed):
         B, N, C = x.shape
         qkv = plinear(self, (self.proj_q, self.proj_k, self.proj_v), x)         # q | k | v in one launch
-        q, k, v = qkv[..., :C].contiguous(), qkv[..., C:2 * C].contiguous(), qkv[..., 2 * C:].contiguous()
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]             # column blocks, attended in place (row stride 3 C)
         c = C // HEADS
         # q~[b,h,n,:] = W_p[h]^T q[b,h,n,:]   (B,h,N,C);   qb[b,h,n] = q[b,h,n,:] . b_p[h,:]
         qh = _split(q)

@@ -366,6 +366,7 @@ def kernel_rooflines(dev, sam_chunk, frames, in_step=None):
     # 2 M N K of the Linear either way (the folded forms do the LayerNorm / the add on top, in the same launch).
     from sam6d_amd.utils.linear import lnfold_eligible, lnfold_weights
     xe = torch.empty(1, 1280, dtype=torch.bfloat16, device=dev)
+    res_only = bool(in_step) and any(k[0] == "res" for k in in_step)     # fp8 loop: residual GEMMs without the fold
     if in_step:
         folded = any(k[0] == "lnfold" for k in in_step)
     else:
@@ -385,10 +386,10 @@ def kernel_rooflines(dev, sam_chunk, frames, in_step=None):
             st = ops.row_stats(x)
             b2b = _event_ms(lambda: ops.gemm_bf16_lnfold(x, st, wf, cs, bf, gelu=gelu), 10)
             inst = "gemm_bf16_kernel<4, true>" if gelu else "gemm_bf16_kernel<3, true>"
-        elif folded:
+        elif folded or (res_only and nm in ("proj", "lin2")):
             form = "res"
             xr = torch.randn(M, N, generator=g).to(dev).to(torch.bfloat16)
-            sp = torch.empty(N // 32, 2, M, device=dev)
+            sp = torch.empty(N // 32, 2, M, device=dev) if folded else None
             b2b = _event_ms(lambda: ops.gemm_bf16(x, w, b, residual=xr, out=xr, stats_partial=sp), 10)
             inst = "gemm_bf16_kernel<2, true>"
         else:
@@ -397,7 +398,7 @@ def kernel_rooflines(dev, sam_chunk, frames, in_step=None):
         # avg_ms: inside the step (gemm_ms_inside_the_step) when the caller measured it; back_to_back_ms: 10 launches of this shape alone
         ms = in_step[(form, M, K, N, gelu)][0] if in_step and (form, M, K, N, gelu) in in_step else b2b
         flop = 2.0 * M * N * K
-        what = {"plain": "", "lnfold": "LayerNorm-folded ", "res": "+ residual + row statistics, "}[form]
+        what = {"plain": "", "lnfold": "LayerNorm-folded ", "res": "+ residual + row statistics, " if folded else "+ residual, "}[form]
         out.append({"kernel": f"{inst} ({what}{nm}, M={M} K={K} N={N})", "bound": "mfma", "achieved": round(flop / ms / 1e9, 1),
                     "peak": 2500.0, "unit": "TFLOP/s", "frac": round(flop / ms / 1e9 / 2500.0, 4), "avg_ms": round(ms, 4),
                     "back_to_back_ms": round(b2b, 4), "timed": "inside one SAM stage pass" if ms is not b2b else "back to back",

@@ -150,24 +150,7 @@ extern __shared__ __attribute__((aligned(16))) char gemm_smem[];
 __device__ __forceinline__ int ring(int s) { return s >= kRing ? s - kRing : s; }
 __device__ __forceinline__ int ring5(int s) { return s >= 5 ? s - 5 : s; }
 
-// erf-form GELU (nn.GELU(), approximate='none'):  x Phi(x) = relu(x) - |x| Q(|x|),  Q(z) = erfc(z / sqrt 2) / 2 = 2^P(z) with P the
-// degree-7 minimax fit of log2 Q on [0, 6] (tools/probes/gelu_fit.py; Q(6) = 1e-9: beyond it the tail is clamped, |error| < 3e-7 up
-// to |x| = 300).  Relative error of the result <= 6e-6 on both signs, 600 times inside the bf16 rounding of the output -- and smaller
-// than round 2's form (Abramowitz-Stegun 7.1.26, absolute 1.5e-7 on erfc, i.e. up to 1.6e-3 RELATIVE where x < 0 and the result is
-// small): on random fp32 arguments 0.16 % of the bf16 results differ from the correctly rounded ones (was 0.75 %).  9 plain VALU +
-// one v_exp per element instead of 12 + v_exp + v_rcp.
-__device__ __forceinline__ float gelu_erf(float x) {
-  const float ax = fabsf(x);
-  const float z = fminf(ax, 6.0f);
-  float p = fmaf(z, -1.833880219e-06f, 6.155846495e-05f);
-  p = fmaf(z, p, -9.300006204e-04f);
-  p = fmaf(z, p, 8.504784666e-03f);
-  p = fmaf(z, p, -5.395101011e-02f);
-  p = fmaf(z, p, -4.584769309e-01f);
-  p = fmaf(z, p, -1.151244164e+00f);
-  p = fmaf(z, p, -9.999961853e-01f);
-  return fmaf(-ax, __builtin_amdgcn_exp2f(p), fmaxf(x, 0.f));
-}
+// gelu_erf(): csrc/s6d_common.h (erf-form GELU as relu(x) - |x| 2^P(|x|), 6e-6 relative)
 
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
   union { __bf16 b; u16 u; } a, c;

@@ -170,14 +170,8 @@ __global__ __launch_bounds__(256, 2) void img2tok_kernel(const u16 *__restrict__
   }
 }
 
-// erf by Abramowitz & Stegun 7.1.26 (|error| < 1.5e-7, far below the bf16 grid of the inputs): exact-GELU semantics
-__device__ __forceinline__ float sd_gelu(float x) {
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * z);
-  const float p = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float erf_abs = 1.0f - p * __expf(-z * z);
-  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
-}
+// erf-form GELU: gelu_erf of csrc/s6d_common.h (relative error 6e-6, far below the bf16 grid of the inputs)
+__device__ __forceinline__ float sd_gelu(float x) { return gelu_erf(x); }
 
 constexpr int kUpC1 = 64, kUpC2 = 32;
 constexpr int kUpWRow = kUpC1 + 8;   // LDS row stride of W2^T (bf16): 144 B
@@ -203,6 +197,21 @@ __global__ __launch_bounds__(256, 2) void upscale_heads_kernel(const u16 *__rest
   if (tid < kUpC1) { lw[tid] = ln_w[tid]; lb[tid] = ln_b[tid]; }
   if (tid < kUpC2) bb[tid] = b2[tid];
   __syncthreads();
+  // The hypernetwork product  logit[mask][pixel] = sum_ch hyper[mask][ch] v[ch][pixel]  runs on the matrix core as well: A = hyper
+  // (rows = masks, bf16 hi + lo parts: two instructions keep the fp32 factor exact to 2^-17), B = the GELU output of the second
+  // transposed conv, rounded to bf16 like every other activation of this path.  The accumulators of that conv hold, per lane
+  // (token c, group g), channels half*16 + g*4 + r: the contraction index is taken in exactly that order, k' = g*8 + half*4 + r,
+  // so the B fragment is the lane's own eight values and no exchange is needed; mask m sits in A row 4 m, i.e. it comes out in
+  // accumulator register 0 of lane group g = m -- the lanes that store mask g.
+  union { sd_bf16x8 v; u16 hh[8]; } hya_hi, hya_lo;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ch = (e >> 2) * 16 + g * 4 + (e & 3);
+    const float hv = ((c & 3) == 0 && (c >> 2) < M) ? hy[(c >> 2) * kUpC2 + ch] : 0.f;
+    const u16 hi = sd_f2bf(hv);
+    hya_hi.hh[e] = hi;
+    hya_lo.hh[e] = sd_f2bf(hv - sd_bf2f(hi));
+  }
   // a strip = 16 tokens x one sub-pixel (dy, dx): 4N/16 strips per prompt
   const int nstrip = N / 16 * 4;
   for (int strip = blockIdx.x * 4 + wave; strip < nstrip; strip += gridDim.x * 4) {
@@ -243,11 +252,10 @@ __global__ __launch_bounds__(256, 2) void upscale_heads_kernel(const u16 *__rest
         ua[ks].hh[e] = sd_f2bf(sd_gelu((x[ks][e] - mean) * rstd * lw[ch] + lb[ch]));
       }
     // ---- second transposed conv: V^T (128 x 16) = W2^T (128 x 64) . U^T; row n = s2*32 + ch, s2 = dy2*2 + dx2 -----
-    float logit[4][4];                                               // [s2][mask]: partial over this lane's 8 channels
+    float mine[4];                                                   // logit of mask g at the four sub-pixels s2 of this token
 #pragma unroll
     for (int s2 = 0; s2 < 4; ++s2) {
-#pragma unroll
-      for (int m = 0; m < 4; ++m) logit[s2][m] = 0.f;
+      union { sd_bf16x8 v; u16 hh[8]; } vb;                          // GELU(conv) of this lane's 8 channels, k' order
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int nt = s2 * 2 + half;
@@ -259,25 +267,13 @@ __global__ __launch_bounds__(256, 2) void upscale_heads_kernel(const u16 *__rest
         }
         // C layout: row n_local = g*4 + r -> ch = half*16 + g*4 + r, col = token c
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ch = half * 16 + g * 4 + r;
-          const float v = sd_gelu(acc[r] + bb[ch]);
-#pragma unroll
-          for (int m = 0; m < 4; ++m) logit[s2][m] += v * hy[m * kUpC2 + ch];
-        }
+        for (int r = 0; r < 4; ++r) vb.hh[half * 4 + r] = sd_f2bf(sd_gelu(acc[r] + bb[half * 16 + g * 4 + r]));
       }
+      sd_f32x4 lg = {0.f, 0.f, 0.f, 0.f};
+      lg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hya_hi.v, vb.v, lg, 0, 0, 0);
+      lg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hya_lo.v, vb.v, lg, 0, 0, 0);
+      mine[s2] = lg[0];                                              // row 4 g = mask g, column = token c
     }
-    // ---- fold the four channel groups (lanes 16 / 32 / 48 away), then lane group g writes mask g ------------------
-    float mine[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        float v = logit[s2][m];
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if (m == g) mine[s2] = v;
-      }
     if (g < M) {
       const int ty = tok / w, tx = tok - ty * w;
       const int py = 4 * ty + 2 * (sp >> 1), px = 4 * tx + 2 * (sp & 1);

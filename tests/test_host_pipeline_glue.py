@@ -204,3 +204,30 @@ def test_descriptor_batches_fill_the_tile_grid():
         assert sum(rounds(c) for c in plan) <= sum(rounds(c) for c in naive)
     assert plan_chunks(1024) == [255, 255, 255, 255, 4]
     assert plan_chunks(128) == [128]
+
+
+def test_layernorm_fold_algebra_on_the_host():
+    """utils.linear.lnfold_weights: LN(x) W^T + b == ((x W'^T) + sigma b' - mean s) / sigma with W' = gamma * W (rounded to bf16: the
+    identity is checked on the ROUNDED weight, which is what the kernel multiplies), s = row sums of W', b' = b + W beta -- the
+    statement s6d_gemm_bf16_lnfold implements, here in float64 on the CPU."""
+    import torch
+
+    from sam6d_amd.utils.linear import lnfold_weights
+    g = torch.Generator().manual_seed(0)
+    M, K, N = 37, 96, 24
+    x = torch.randn(M, K, generator=g, dtype=torch.float64) * 3 + 5
+    W = torch.randn(N, K, generator=g, dtype=torch.float64) / K ** 0.5
+    b = torch.randn(N, generator=g, dtype=torch.float64)
+    gamma = 1 + 0.3 * torch.randn(K, generator=g, dtype=torch.float64)
+    beta = 0.2 * torch.randn(K, generator=g, dtype=torch.float64)
+    wf, cs, bf = lnfold_weights(W.float(), b.float(), gamma.float(), beta.float())
+    mean = x.mean(1, keepdim=True)
+    sigma = torch.sqrt(x.var(1, unbiased=False, keepdim=True) + 1e-6)
+    folded = (x @ wf.double().t() + sigma * bf.double() - mean * cs.double()) / sigma
+    # the same LayerNorm -> Linear with the rounded folded weight spelled out: ((x - mean) / sigma) @ W'^T + b'
+    direct = ((x - mean) / sigma) @ wf.double().t() + bf.double()
+    assert (folded - direct).abs().max() < 1e-9
+    # and against the unrounded statement: only the bf16 rounding of gamma * W separates them
+    true = torch.nn.functional.layer_norm(x, (K,), gamma, beta, 1e-6) @ W.t() + b
+    assert ((direct - true).pow(2).mean() / true.pow(2).mean()).sqrt() < 3e-3
+    assert wf.dtype == torch.bfloat16 and cs.dtype == torch.float32 and bf.dtype == torch.float32

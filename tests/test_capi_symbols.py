@@ -26,6 +26,30 @@ def test_argument_validation_without_a_gpu():
     assert L.s6d_rpe_attention_f32(None, None, None, None, None, None, 1, 197, 128, 4, ctypes.c_float(1.0), None, None) == -3
 
 
+def test_round3_entry_points_validate_shapes_without_a_gpu():
+    """The folded-GEMM, statistics and linear-attention entries reject what they do not implement before any launch (fake non-null
+    pointers: nothing is dereferenced on these paths)."""
+    L = _lib.lib()
+    p = ctypes.c_void_p(4096)
+    lng, flt = ctypes.c_long, ctypes.c_float
+    for fn in ("s6d_gemm_bf16_lnfold", "s6d_gemm_bf16_res", "s6d_ln_stats_finalize", "s6d_row_stats_bf16", "s6d_linear_attention_f32",
+               "s6d_rpe_attention_strided_f32", "s6d_mha_strided_f32"):
+        getattr(L, fn).restype = ctypes.c_int
+    # N % 256 != 0: the 256 x 256-tile kernel only
+    assert L.s6d_gemm_bf16_lnfold(p, lng(64), p, p, lng(64), p, p, p, lng(128), 256, 128, 64, 0, 0, 0, None) == -3
+    assert L.s6d_gemm_bf16_lnfold(p, lng(64), p, p, lng(64), p, p, p, lng(256), 256, 256, 64, 2, 0, 0, None) == -1       # gelu flag
+    assert L.s6d_gemm_bf16_res(p, lng(64), p, lng(64), p, p, lng(128), None, p, lng(128), 256, 128, 64, 0, None) == -3
+    assert L.s6d_gemm_bf16_res(p, lng(64), p, lng(64), p, p, lng(100), None, p, lng(256), 256, 256, 64, 0, None) == -1     # ldr < N
+    assert L.s6d_ln_stats_finalize(p, 0, 32, lng(16), flt(1e-6), p, None) == -1
+    assert L.s6d_ln_stats_finalize(p, 40, 32, lng(0), flt(1e-6), p, None) == 0                                               # no rows
+    assert L.s6d_row_stats_bf16(p, lng(1284), lng(4), 1284, flt(1e-6), p, None) == -1                                        # C % 8
+    assert L.s6d_row_stats_bf16(p, lng(2048), lng(4), 2048, flt(1e-6), p, None) == -3                                        # C > 1536
+    assert L.s6d_linear_attention_f32(p, p, 3, p, lng(128), p, lng(128), 1, 8, 8, 128, p, p, None) == -3                     # C != 256
+    assert L.s6d_linear_attention_f32(p, p, 3, p, lng(100), p, lng(256), 1, 8, 8, 256, p, p, None) == -1                     # ldk < C
+    assert L.s6d_rpe_attention_strided_f32(p, lng(258), p, lng(256), p, lng(256), p, p, p, 1, 8, 256, 4, flt(1.0), p, None) == -1   # ld % 4
+    assert L.s6d_mha_strided_f32(p, lng(768), p, lng(512), p, lng(512), 0, 8, 8, 256, 4, flt(1.0), p, None) == 0             # B == 0
+
+
 def test_ops_refuse_cpu_tensors():
     import pytest
     import torch

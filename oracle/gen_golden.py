@@ -32,6 +32,8 @@ SAM_MINI_CASE = dict(weight_seed=3, input_seed=5)
 SAM_H_CASE = dict(weight_seed=3, input_seed=5)
 ISM_CASE = dict(P=64, O=3, T=42, seed=11)
 ISM_CASE_BENCH = dict(P=128, O=1, T=42, seed=11)          # the shape bench.py scores per frame (BASELINE configs[1])
+ISM_CASE_YCBV = dict(P=128, O=21, T=42, seed=12)          # BASELINE configs[2]: YCB-V, 21 objects
+ISM_CASE_TLESS = dict(P=256, O=30, T=42, seed=5)          # BASELINE configs[3]: T-LESS, 30 objects, many-instance frames
 SAMDEC_CASE = dict(weight_seed=2, input_seed=9, n_mini=9, n_full=4, mini_input_size=(96, 128), mini_orig=(60, 80),
                    post_B=3, post_seed=6, post_input_size=(768, 1024), post_orig=(480, 640))
 DINO_CASE = dict(P=8, input_seed=4, weight_seed=6, mini_target=56, n_full=2)
@@ -199,9 +201,11 @@ def gen_ism():
     ns = rh.ism()
     _gen_ism(ns, ISM_CASE, "ism_scoring.npz")
     _gen_ism(ns, ISM_CASE_BENCH, "ism_scoring_p128.npz")
+    _gen_ism(ns, ISM_CASE_YCBV, "ism_scoring_ycbv.npz", compact=True)
+    _gen_ism(ns, ISM_CASE_TLESS, "ism_scoring_tless.npz", compact=True)
 
 
-def _gen_ism(ns, c, fname):
+def _gen_ism(ns, c, fname, compact=False):
     inp = synth.ism_inputs(P=c["P"], O=c["O"], T=c["T"], seed=c["seed"])
     Det = ns.detector.Instance_Segmentation_Model
     fake = types.SimpleNamespace()
@@ -232,6 +236,12 @@ def _gen_ism(ns, c, fname):
                    iou=np.asarray(geo if not torch.is_tensor(geo) else geo.numpy(), dtype=np.float32),
                    final=final.numpy(), iou2=iou2.numpy(), boxes2=boxes2.numpy(),
                    translation=fake.Calculate_the_query_translation(inp["masks"][sel].clone(), inp["depth"], inp["K"], 1.0).numpy())
+    if compact:
+        # the large configurations: pixels fit int16 (checked), the (P, O*T) cosine matrix is kept as a strided sample + sums
+        uv = rec["image_uv"]
+        assert np.abs(uv).max() < 2 ** 15
+        rec["image_uv"] = uv.astype(np.int16)
+        rec["pairwise_sums"], rec["pairwise_sample"] = digest(torch.from_numpy(rec.pop("pairwise")), 13)
     rec["case"] = np.array(str(c))
     np.savez_compressed(os.path.join(OUT, fname), **rec)
     print(fname, {k: (v.shape if hasattr(v, "shape") else v) for k, v in rec.items()})

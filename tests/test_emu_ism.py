@@ -1,6 +1,10 @@
 """ISM scoring kernels executed on the HOST through the emulated HIP runtime: the per-kernel body of tests/test_gpu_ism.py
 (cosine GEMM, top-k selection, split-bf16 MFMA patch scores on non-tile-aligned sizes) and the whole frame-scoring chain
 against the reference golden."""
+import os
+
+import pytest
+
 from tests import test_gpu_ism as T
 
 
@@ -60,3 +64,12 @@ def test_translation_sum_order_on_the_emulator(emu):
 
 def test_empty_selection_on_the_emulator(emu):
     T.test_score_frames_with_no_selected_proposal()
+
+
+@pytest.mark.skipif(not os.environ.get("S6D_EMU_SLOW"), reason="2 minutes on the emulator; S6D_EMU_SLOW=1 runs it")
+@pytest.mark.parametrize("name", ["ism_scoring_ycbv.npz", "ism_scoring_tless.npz"])
+def test_large_configuration_goldens_on_the_emulator(emu, name):
+    """BASELINE configs[2] / configs[3] sizes (YCB-V O=21, T-LESS P=256 / O=30): the kernels give the reference run's integer
+    outputs bit for bit (last run on the host emulator: both green, 120 s)."""
+    T.test_projection_is_bit_exact_given_the_reference_translation(name)
+    T.test_frame_scoring_vs_reference_golden(name)

@@ -209,7 +209,7 @@ class DinoVisionTransformer(nn.Module):
         rows = x.numel() // C
         if (exact_gelu and C % 256 == 0 and all(lnfold_eligible(x, C, C) and lnfold_eligible(x, blk.mlp.fc1.out_features, C) and
                                                 lnfold_eligible(x, C, blk.mlp.fc1.out_features) for blk in self.blocks)
-                and 2 * rows * max(3 * C, max(blk.mlp.fc1.out_features for blk in self.blocks)) < 2 ** 31):
+                and rows <= ops.gemm_one_launch_rows(max(3 * C, max(blk.mlp.fc1.out_features for blk in self.blocks)))):
             # neither the residual adds nor the block LayerNorms as passes of their own: the same folded loop as the SAM encoder's
             # (sam/image_encoder.py::_blocks_lnfold), LayerScale already folded into proj / fc2 (Block._folded)
             x = x.clone()

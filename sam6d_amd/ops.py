@@ -536,7 +536,7 @@ def gemm_bf16(a, w, bias=None, gelu=False, out=None, max_blocks=0, col_block=0, 
                              f"{tuple(out.shape)} strides {tuple(out.stride())}")
     # the kernel's staging addresses are 32-bit byte offsets from A: rows go through in slabs below 2 GiB (ViT-H lin2 reaches
     # the limit at 52 frames per call)
-    rows = max(256, ((2 ** 31 - 1) // (2 * a2.stride(0))) // 256 * 256)
+    rows = gemm_one_launch_rows(a2.stride(0))
     if residual is not None:
         if gelu or col_block:
             raise RuntimeError("the residual form takes neither GELU nor column blocks")
@@ -567,6 +567,14 @@ def gemm_bf16(a, w, bias=None, gelu=False, out=None, max_blocks=0, col_block=0, 
               _ptr(bias) if bias is not None else _vp(0), _ptr(out[r0:r1]), ctypes.c_long(out.stride(0)), r1 - r0, N, K,
               1 if gelu else 0, int(max_blocks), _stream())
     return out.reshape(*a.shape[:-1], N)
+
+
+def gemm_one_launch_rows(row_stride, elem_bytes=2):
+    """Rows ONE launch of the bf16 / f16 GEMM kernels takes for an A operand of ``row_stride`` elements per row: their staging
+    addresses are 32-bit byte offsets from A, so a launch stays below 2 GiB, in whole 256-row tiles.  The plain forms walk larger
+    inputs in slabs of this many rows; the forms that carry row statistics (residual + stats_partial, lnfold) are one launch, so
+    their callers' eligibility checks use this very number (one helper instead of three bounds)."""
+    return max(256, ((2 ** 31 - 1) // (elem_bytes * int(row_stride))) // 256 * 256)
 
 
 def ln_stats_finalize(stats_partial, group_size=32, eps=1e-6):
@@ -611,7 +619,7 @@ def gemm_bf16_lnfold(a, stats, w_folded, col_sums, bias, gelu=False, col_block=0
         raise RuntimeError("w_folded must be (N, K) with contiguous rows")
     if tuple(stats.shape) != (M, 2) or not stats.is_contiguous() or col_sums.numel() != N or bias.numel() != N:
         raise ValueError(f"stats must be ({M}, 2), col_sums and bias ({N},)")
-    if 2 * M * a2.stride(0) >= 2 ** 31:
+    if M > gemm_one_launch_rows(a2.stride(0)):
         raise RuntimeError("one launch: the row count exceeds one 2-GiB slab")
     if col_block:
         out = torch.empty(N // col_block, M, col_block, dtype=torch.bfloat16, device=a.device)
@@ -654,6 +662,10 @@ def layernorm_fp8(x, gamma, beta, eps, delta=None):
     _chk(gamma, torch.float32, "gamma", 1)
     _chk(beta, torch.float32, "beta", 1)
     C = x.shape[-1]
+    if gamma.numel() != C or beta.numel() != C:
+        raise ValueError(f"gamma / beta must have {C} elements")
+    if delta is not None and delta.shape != x.shape:
+        raise ValueError("delta must have x's shape")
     rows = x.numel() // C
     y8 = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
     ys = torch.empty(rows, dtype=torch.uint8, device=x.device)
@@ -681,6 +693,10 @@ def linear_f32(x, w_hi, w_lo, bias=None, relu=False, residual=None, ln=None):
     """y = LN(residual + act(x W^T + bias)) in one kernel: x (..., K) f32, (w_hi, w_lo) = split_weight(W (N,K)), bias (N) or None,
     residual (..., N) or None, ln = (gamma, beta, eps) or None (N == 256).  K % 32 == 0, N % 256 == 0."""
     _chk(x, torch.float32, "x")
+    _chk(w_hi, torch.bfloat16, "w_hi", 2)
+    _chk(w_lo, torch.bfloat16, "w_lo", 2)
+    if w_lo.shape != w_hi.shape:
+        raise ValueError(f"w_hi {tuple(w_hi.shape)} and w_lo {tuple(w_lo.shape)} differ in shape")
     N, K = w_hi.shape
     if x.shape[-1] != K:
         raise ValueError(f"x has {x.shape[-1]} columns, W {K}")
@@ -699,8 +715,12 @@ def linear_f32(x, w_hi, w_lo, bias=None, relu=False, residual=None, ln=None):
         g, bt, eps = ln
         _chk(g, torch.float32, "gamma", 1)
         _chk(bt, torch.float32, "beta", 1)
+        if g.numel() != N or bt.numel() != N:
+            raise ValueError(f"gamma / beta must have {N} elements")
     if bias is not None:
         _chk(bias, torch.float32, "bias", 1)
+        if bias.numel() != N:
+            raise ValueError(f"bias must have {N} elements")
     _call("s6d_linear_f32", _ptr(x2), ctypes.c_long(x2.stride(0)), M, K, _ptr(w_hi), _ptr(w_lo), _ptr(bias) if bias is not None else _vp(0),
           N, 1 if relu else 0, _ptr(r2) if r2 is not None else _vp(0), ctypes.c_long(r2.stride(0) if r2 is not None else 0),
           _ptr(g) if g is not None else _vp(0), _ptr(bt) if bt is not None else _vp(0), ctypes.c_float(eps), _ptr(y), ctypes.c_long(N),
@@ -837,7 +857,7 @@ def linear_attention(q_proj, inv_scale, power, k_focused, v):
     B, I, C = q_proj.shape
     J = k_focused.shape[1]
     for t, nm in ((k_focused, "k_focused"), (v, "v")):
-        if t.shape != (B, J, C) or t.stride(2) != 1 or t.stride(0) != J * t.stride(1):
+        if t.shape != (B, J, C) or t.stride(2) != 1 or (B > 1 and t.stride(0) != J * t.stride(1)):     # (B == 1: stride(0) is free)
             raise ValueError(f"{nm} must be (B, J, C) with unit channel stride and batch stride J * row stride; got {tuple(t.shape)} "
                              f"strides {tuple(t.stride())}")
     inv_scale = inv_scale.reshape(-1).contiguous()

@@ -24,7 +24,8 @@ HEADS = 4
 def _plin_weights(owner, lins):
     """(w_hi, w_lo, bias) of one or several nn.Linear with the same input, stacked along the output dim, in the operand format
     of s6d_linear_f32 (bf16 hi / lo parts of the fp32 weight); cached on `owner` until a parameter changes."""
-    key = tuple((l.weight._version, l.weight.data_ptr(), l.bias._version if l.bias is not None else -1) for l in lins)
+    key = tuple((l.weight._version, l.weight.data_ptr(), l.weight.dtype) +
+                ((l.bias._version, l.bias.data_ptr(), l.bias.dtype) if l.bias is not None else (-1, 0, None)) for l in lins)
     name = "_s6d_plin_" + "_".join(str(id(l)) for l in lins)
     c = owner.__dict__.get(name)
     if c is None or c[0] != key:

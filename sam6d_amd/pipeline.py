@@ -165,7 +165,15 @@ class FramePipeline:
             return self.pem(ep)
         Mp = (M + 1) // 2 * 2
         keys = ("pts", "rgb", "rgb_choose", "model", "dense_po", "dense_fo", "coarse_rand_u")
+        # A captured graph bakes in everything live at capture time: the shapes and dtypes of the inputs, the extractor
+        # dtype switch, and the weight-derived buffers the forward caches (hi / lo splits, half copies).  The key carries all of
+        # them -- the weights through the sum of their tensor versions and their storage addresses (load_state_dict, in-place
+        # updates, .to() all change one of the two) -- so a replay never computes with stale buffers; a stale entry is dropped.
+        key = self._pem_graph_key(Mp, ep, keys)
         g = self._pem_graphs.get(Mp)
+        if g is not None and g[3] != key:
+            del self._pem_graphs[Mp]
+            g = None
         if g is None:
             static = {k: torch.empty((Mp,) + tuple(ep[k].shape[1:]), dtype=ep[k].dtype, device=dev) for k in keys}
 
@@ -184,15 +192,27 @@ class FramePipeline:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = self.pem(dict(static))
-            g = (graph, static, {k: out[k] for k in ("pred_R", "pred_t", "pred_pose_score")})
+            g = (graph, static, {k: out[k] for k in ("pred_R", "pred_t", "pred_pose_score")}, key)
             self._pem_graphs[Mp] = g
-        graph, static, outs = g
+        graph, static, outs, _ = g
         for k in keys:
             static[k][:M].copy_(ep[k])
             if Mp > M:
                 static[k][M:].copy_(ep[k][M - 1:M].expand(Mp - M, *ep[k].shape[1:]))
         graph.replay()
         return {k: v[:M].clone() for k, v in outs.items()}
+
+    def _pem_graph_key(self, Mp, ep, keys):
+        ver, ptr = 0, 0
+        for t in list(self.pem.parameters()) + list(self.pem.buffers()):
+            ver += t._version
+            ptr ^= t.data_ptr()
+        return (Mp, tuple((tuple(ep[k].shape[1:]), ep[k].dtype) for k in keys), os.environ.get("S6D_PEM_VIT_DTYPE", ""),
+                os.environ.get("S6D_PEM_F16_GUARD", ""), ver, ptr)
+
+    def invalidate_graphs(self):
+        """Drop every captured PEM graph (they are re-captured on the next call)."""
+        self._pem_graphs.clear()
 
     @torch.no_grad()
     def run_group(self, frames):

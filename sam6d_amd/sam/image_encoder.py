@@ -259,7 +259,7 @@ class ImageEncoderViT(nn.Module):
         if (lnfold_eligible(x, C, C) and C % 32 == 0 and all(lnfold_eligible(x, blk.mlp.lin1.out_features, C) and
                                                              lnfold_eligible(x, C, blk.mlp.lin1.out_features) and blk.attn.use_rel_pos
                                                              for blk in self.blocks)
-                and ops.have("win_attention") and 2 * rows * max(hid, 3 * C) < 2 ** 31):
+                and ops.have("win_attention") and rows <= ops.gemm_one_launch_rows(max(hid, 3 * C))):
             return self._blocks_lnfold(x, upto)
         if res_eligible(x, C, C) and all(res_eligible(x, C, blk.mlp.lin2.in_features) for blk in self.blocks):
             x = x.clone()                                        # the stream tensor is updated in place from here on
@@ -338,7 +338,7 @@ class ImageEncoderViT(nn.Module):
         B, H, W, _ = x.shape
         M = B * H * W
         if ops.have("gemm_bf16_res") and all(blk.attn.use_rel_pos for blk in self.blocks) and ops.have("win_attention") \
-                and 2 * M * max(blk.mlp.lin1.out_features for blk in self.blocks) < 2 ** 31:
+                and M <= ops.gemm_one_launch_rows(max(blk.mlp.lin1.out_features for blk in self.blocks)):
             # the residual adds in the bf16 proj / lin2 GEMMs (accumulators start at bias + residual, in place on the stream
             # tensor): the quantising LayerNorm then reads ONE tensor and writes its e4m3 rows
             x = x.clone()

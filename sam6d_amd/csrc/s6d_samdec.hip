@@ -422,10 +422,20 @@ __device__ __forceinline__ BilTap bil_tap(int dst, float scale, int in_n) {
 }
 __device__ __forceinline__ float bil_mix(float w0, float a, float w1, float b) { return __fmaf_rn(w0, a, __fmul_rn(w1, b)); }
 
-constexpr int kPostRows = 4;     // frame rows per workgroup
+// Round 4: a lane owns a frame COLUMN and walks a strip of kPostRows frame rows.  Everything that depends on the column only (the
+// horizontal taps of both stages) is computed once per strip; everything that depends on the row only (the vertical taps of both
+// stages) comes from two small LDS tables built once per workgroup and is wave-uniform (readfirstlane: the cache logic below
+// runs on the scalar unit).  The horizontally mixed logits of the current pair of low-resolution rows and the values of the last
+// two rows of the intermediate image are kept in registers and re-used while the walk stays on them (a low-resolution row pair
+// serves ~4 intermediate rows ~2.5 frame rows): 4-6 loads and ~40 VALU instructions per pixel instead of 16 and ~150 (the
+// round-3 kernel recomputed all 16 taps and every index per pixel and was bound by the vector issue rate: 2.8 ms per 3072
+// masks).  Every value is produced by the same operations in the same order as before, so the masks keep the oracle's bits.
 // (Tried at the end of round 3: one wave per frame row with the row's taps computed once, four consecutive pixels per lane and
 // their mask bytes stored as one word -- bit-identical, and 2.7x SLOWER, 7.6 against 2.8 ms per 3072 masks: with a lane per
-// pixel the 16 taps of neighbouring lanes fall into the same few cache lines, with a lane per quad they do not.)
+// pixel the taps of neighbouring lanes fall into the same few cache lines, with a lane per quad they do not.)
+constexpr int kPostRows = 32;      // frame rows per workgroup
+constexpr int kPostThreads = 320;  // 5 waves: 640 columns in two passes
+constexpr int kPostMaxInter = 2 * kPostRows + 2;   // intermediate rows a strip can touch (scale <= 2 asserted by the entry point)
 
 __global__ void mask_post_init_kernel(int *stats, int Bm, int H, int W) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -435,33 +445,66 @@ __global__ void mask_post_init_kernel(int *stats, int Bm, int H, int W) {
   }
 }
 
-__global__ __launch_bounds__(256) void mask_post_kernel(const float *__restrict__ low, int n, int img, int ih, int iw,
-                                                        int H, int W, float thr, float off,
-                                                        unsigned char *__restrict__ masks, int *__restrict__ stats) {
-  __shared__ int red[6][4];
+__global__ __launch_bounds__(kPostThreads) void mask_post_kernel(const float *__restrict__ low, int n, int img, int ih, int iw,
+                                                                 int H, int W, float thr, float off,
+                                                                 unsigned char *__restrict__ masks, int *__restrict__ stats) {
+  __shared__ int red[6][kPostThreads / 64];
+  __shared__ BilTap tabB[kPostRows];          // frame row -> rows of the intermediate image
+  __shared__ BilTap tabA[kPostMaxInter];      // intermediate row -> rows of the logits
   const int m = blockIdx.y, y_base = blockIdx.x * kPostRows, tid = threadIdx.x;
+  const int rows = min(kPostRows, H - y_base);
   const float *L = low + (size_t)m * n * n;
   const float sA = (float)n / (float)img, sBy = (float)ih / (float)H, sBx = (float)iw / (float)W;
+  const int Y_first = bil_tap(y_base, sBy, ih).i0;
+  if (tid < rows) tabB[tid] = bil_tap(y_base + tid, sBy, ih);
+  if (tid >= 64 && tid < 64 + kPostMaxInter) {
+    const int Y = min(Y_first + tid - 64, ih - 1);
+    tabA[tid - 64] = bil_tap(Y, sA, n);
+  }
+  __syncthreads();
   int inter = 0, uni = 0, xmin = W, ymin = H, xmax = -1, ymax = -1;
-  for (int x = tid; x < W; x += 256) {
+  for (int x = tid; x < W; x += kPostThreads) {
     const BilTap bx = bil_tap(x, sBx, iw);
     const BilTap ax0 = bil_tap(bx.i0, sA, n), ax1 = bil_tap(bx.i1, sA, n);
-    for (int r = 0; r < kPostRows; ++r) {
-      const int y = y_base + r;
-      if (y >= H) break;
-      const BilTap by = bil_tap(y, sBy, ih);
-      float rowv[2];
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {                                  // the two rows of the intermediate image
-        const BilTap ay = bil_tap(k == 0 ? by.i0 : by.i1, sA, n);
-        const float *r0 = L + (size_t)ay.i0 * n, *r1 = L + (size_t)ay.i1 * n;
-        const float a0 = bil_mix(ay.w0, bil_mix(ax0.w0, r0[ax0.i0], ax0.w1, r0[ax0.i1]), ay.w1,
-                                 bil_mix(ax0.w0, r1[ax0.i0], ax0.w1, r1[ax0.i1]));     // intermediate (Y_k, X_0)
-        const float a1 = bil_mix(ay.w0, bil_mix(ax1.w0, r0[ax1.i0], ax1.w1, r0[ax1.i1]), ay.w1,
-                                 bil_mix(ax1.w0, r1[ax1.i0], ax1.w1, r1[ax1.i1]));     // intermediate (Y_k, X_1)
-        rowv[k] = bil_mix(bx.w0, a0, bx.w1, a1);
+    int cl0 = -1, cl1 = -1;                   // logits rows the h** registers hold (uniform)
+    float h00 = 0.f, h01 = 0.f, h10 = 0.f, h11 = 0.f;     // h[row 0/1][column X0/X1]: horizontally mixed logits
+    int cY0 = -1, cY1 = -1;                   // intermediate rows the v*c registers hold (uniform)
+    float v0c = 0.f, v1c = 0.f;
+    auto hrow = [&](int row, float &hx0, float &hx1) {
+      const float *r = L + (size_t)row * n;
+      hx0 = bil_mix(ax0.w0, r[ax0.i0], ax0.w1, r[ax0.i1]);
+      hx1 = bil_mix(ax1.w0, r[ax1.i0], ax1.w1, r[ax1.i1]);
+    };
+    auto inter_row = [&](int Y) -> float {    // value of the intermediate image at (Y, this lane's frame column)
+      const BilTap *ta = &tabA[Y - Y_first];
+      const int i0 = __builtin_amdgcn_readfirstlane(ta->i0), i1 = __builtin_amdgcn_readfirstlane(ta->i1);
+      const float w0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ta->w0)));
+      const float w1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ta->w1)));
+      if (i0 != cl0) {
+        if (i0 == cl1 && cl1 != cl0) { h00 = h10; h01 = h11; }
+        else hrow(i0, h00, h01);
+        if (i1 == i0) { h10 = h00; h11 = h01; }
+        else hrow(i1, h10, h11);
+        cl0 = i0; cl1 = i1;
       }
-      const float v = bil_mix(by.w0, rowv[0], by.w1, rowv[1]);
+      const float a0 = bil_mix(w0, h00, w1, h10);         // intermediate (Y, X_0)
+      const float a1 = bil_mix(w0, h01, w1, h11);         // intermediate (Y, X_1)
+      return bil_mix(bx.w0, a0, bx.w1, a1);
+    };
+    for (int r = 0; r < rows; ++r) {
+      const int y = y_base + r;
+      const int Y0 = __builtin_amdgcn_readfirstlane(tabB[r].i0), Y1 = __builtin_amdgcn_readfirstlane(tabB[r].i1);
+      const float wy0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tabB[r].w0)));
+      const float wy1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tabB[r].w1)));
+      float v0, v1;
+      if (Y0 == cY0) v0 = v0c;
+      else if (Y0 == cY1) v0 = v1c;
+      else v0 = inter_row(Y0);
+      if (Y1 == Y0) v1 = v0;
+      else if (Y1 == cY1) v1 = v1c;
+      else v1 = inter_row(Y1);
+      cY0 = Y0; v0c = v0; cY1 = Y1; v1c = v1;
+      const float v = bil_mix(wy0, v0, wy1, v1);
       const bool on = v > thr;
       masks[((size_t)m * H + y) * W + x] = on ? 1 : 0;
       inter += v > thr + off;
@@ -490,12 +533,17 @@ __global__ __launch_bounds__(256) void mask_post_kernel(const float *__restrict_
   __syncthreads();
   if (tid == 0) {
     int *s = stats + (size_t)m * 6;
-    atomicAdd(s + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-    atomicAdd(s + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
-    atomicMin(s + 2, min(min(red[2][0], red[2][1]), min(red[2][2], red[2][3])));
-    atomicMin(s + 3, min(min(red[3][0], red[3][1]), min(red[3][2], red[3][3])));
-    atomicMax(s + 4, max(max(red[4][0], red[4][1]), max(red[4][2], red[4][3])));
-    atomicMax(s + 5, max(max(red[5][0], red[5][1]), max(red[5][2], red[5][3])));
+    int a = 0, b = 0, c = W, d = H, e = -1, f = -1;
+    for (int w = 0; w < kPostThreads / 64; ++w) {
+      a += red[0][w]; b += red[1][w];
+      c = min(c, red[2][w]); d = min(d, red[3][w]); e = max(e, red[4][w]); f = max(f, red[5][w]);
+    }
+    atomicAdd(s + 0, a);
+    atomicAdd(s + 1, b);
+    atomicMin(s + 2, c);
+    atomicMin(s + 3, d);
+    atomicMax(s + 4, e);
+    atomicMax(s + 5, f);
   }
 }
 
@@ -564,9 +612,12 @@ extern "C" int s6d_sam_mask_post_f32(const float *low_res, int Bm, int n, int im
     return S6D_EINVAL;
   if (Bm == 0) return S6D_OK;
   if (!low_res || !masks || !stats) return S6D_EINVAL;
+  // the strip walk sizes its table of intermediate rows for a second stage that shrinks by at most 2 (frames are smaller than
+  // the resized input everywhere on this path; a frame MORE than twice as small per side is outside what SAM is used on)
+  if ((long)in_h > 2L * H) return S6D_EINVAL;
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(mask_post_init_kernel, dim3((Bm + 255) / 256), dim3(256), 0, st, stats, Bm, H, W);
-  hipLaunchKernelGGL(mask_post_kernel, dim3((H + kPostRows - 1) / kPostRows, Bm), dim3(256), 0, st, low_res, n, img_size,
+  hipLaunchKernelGGL(mask_post_kernel, dim3((H + kPostRows - 1) / kPostRows, Bm), dim3(kPostThreads), 0, st, low_res, n, img_size,
                      in_h, in_w, H, W, mask_threshold, stability_offset, masks, stats);
   return launch_status();
 }

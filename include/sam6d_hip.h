@@ -30,7 +30,7 @@ extern "C" {
 
 /* Bumped whenever a signature in this header changes; the loader (sam6d_amd/_lib.py) refuses a library whose
  * s6d_version() differs from the header it was written against (a stale .so fails at load, not at a call). */
-#define S6D_ABI_VERSION 110
+#define S6D_ABI_VERSION 111
 int s6d_version(void);
 const char *s6d_strerror(int code);
 /* last HIP error string seen by this thread (empty if none) */
@@ -461,6 +461,12 @@ int s6d_samdec_upscale_heads_bf16(const void *y0, const float *ln_w, const float
 int s6d_sam_mask_post_f32(const float *low_res, int Bm, int n, int img_size, int in_h, int in_w, int H, int W,
                           float mask_threshold, float stability_offset, unsigned char *masks, int32_t *stats,
                           void *stream);
+/* The same on a channel slice of the decoder's output, read in place: low_res (B,ch_total,n,n) f32, masks of channels
+ * [ch_first, ch_first + ch_count) -> masks (B*ch_count,H,W) u8 (0 / 1: also valid as a bool tensor), stats (B*ch_count,6).
+ * `masks[:, 1:]` of MaskDecoder.forward(multimask_output=True), mask_decoder.py:99-104, without the contiguous copy. */
+int s6d_sam_mask_post_sel_f32(const float *low_res, int B, int ch_total, int ch_first, int ch_count, int n, int img_size,
+                              int in_h, int in_w, int H, int W, float mask_threshold, float stability_offset,
+                              unsigned char *masks, int32_t *stats, void *stream);
 
 /* Box NMS with torchvision.ops.nms semantics (IoU on float32 XYXY boxes, area = (x2-x1)(y2-y1), suppress if IoU >
  * threshold, boxes visited in the given score order).  boxes (N,4) f32, order (N) i64 = indices by decreasing score ->

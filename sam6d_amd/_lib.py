@@ -35,12 +35,38 @@ def _stale():
 
 
 def build(force=False, verbose=False):
-    """Compile every csrc/*.hip into libsam6d_hip.so (gfx950)."""
+    """Compile every csrc/*.hip for gfx950 and link libsam6d_hip.so.  One object per source under csrc/build/ (git-ignored),
+    compiled in parallel and only when the source or a header is newer: a change in one kernel file rebuilds in seconds."""
     if not force and not _stale():
         return SO_PATH
     if not os.path.exists(HIPCC):
         raise RuntimeError(f"hipcc not found at {HIPCC}; cannot build libsam6d_hip.so")
-    cmd = [HIPCC] + FLAGS + os.environ.get("S6D_EXTRA_HIPCC_FLAGS", "").split() + ["-o", SO_PATH] + sources()
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(_CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    extra = os.environ.get("S6D_EXTRA_HIPCC_FLAGS", "").split()
+    cflags = [f for f in FLAGS if f != "-shared"] + extra
+    hdrs = glob.glob(os.path.join(_CSRC, "*.h")) + glob.glob(os.path.join(_HERE, "..", "include", "*.h"))
+    # s6d_attn_f16.hip re-compiles s6d_attn.hip under another element type: it depends on that source too
+    hdr_t = max(os.path.getmtime(h) for h in hdrs)
+    tag = os.path.join(objdir, ".flags")
+    flags_now = " ".join(cflags)
+    if not os.path.exists(tag) or open(tag).read() != flags_now:
+        force = True
+
+    def one(src):
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        dep_t = max(hdr_t, os.path.getmtime(src), max(os.path.getmtime(x) for x in sources()) if src.endswith("_f16.hip") else 0)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < dep_t:
+            cmd = [HIPCC] + cflags + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd, cwd=_CSRC)
+        return obj
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(one, sources()))
+    open(tag, "w").write(flags_now)
+    cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", SO_PATH] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=_CSRC)

@@ -279,21 +279,30 @@ def samdec_tok2img(qt, kv, k_off, v_off, k_pe, scale):
 
 
 def sam_mask_post(low_res, img_size, input_size, original_size, mask_threshold=0.0, stability_offset=1.0):
-    """Fused Sam.postprocess_masks + stability score + threshold + boxes.  low_res (B,C,n,n) f32 ->
+    """Fused Sam.postprocess_masks + stability score + threshold + boxes.  low_res (B,C,n,n) f32 -- contiguous, or a channel
+    slice ``full[:, c0:c0 + C]`` of a contiguous (B,Ct,n,n) tensor, which is read in place ->
     (masks (B*C,H,W) bool, stability (B*C,) f32, boxes (B*C,4) int64 XYXY, [0,0,0,0] for empty masks)."""
-    _chk(low_res, torch.float32, "low_res", 4)
+    if not low_res.is_cuda or low_res.dtype != torch.float32 or low_res.dim() != 4:
+        raise RuntimeError("low_res must be a 4-d float CUDA tensor")
     B, C, n, n2 = low_res.shape
     if n != n2:
         raise RuntimeError("low_res must be square")
+    sb, sc, sy, sx = low_res.stride()
+    if not (sx == 1 and sy == n and sc == n * n and sb % (n * n) == 0 and sb >= C * n * n) or B * C == 0:
+        low_res = low_res.contiguous()
+        sb = C * n * n
+    ct = max(sb // (n * n), C, 1)               # planes between consecutive prompts (Ct of the parent tensor for a channel slice)
     Bm, (H, W) = B * C, original_size
-    masks = torch.empty(Bm, H, W, dtype=torch.uint8, device=low_res.device)
+    masks = torch.empty(Bm, H, W, dtype=torch.bool, device=low_res.device)      # the kernel writes 0 / 1 bytes: no uint8 -> bool pass
     stats = torch.empty(Bm, 6, dtype=torch.int32, device=low_res.device)
-    _call("s6d_sam_mask_post_f32", _ptr(low_res), Bm, int(n), int(img_size), int(input_size[0]), int(input_size[1]), int(H),
-          int(W), ctypes.c_float(mask_threshold), ctypes.c_float(stability_offset), _ptr(masks), _ptr(stats), _stream())
+    # the slice's data pointer is its first plane: mask (b, c) reads plane b * ct + c from there
+    _call("s6d_sam_mask_post_sel_f32", _ptr(low_res), int(B), int(ct), 0, int(max(C, 1)), int(n), int(img_size), int(input_size[0]),
+          int(input_size[1]), int(H), int(W), ctypes.c_float(mask_threshold), ctypes.c_float(stability_offset), _ptr(masks),
+          _ptr(stats), _stream())
     stability = stats[:, 0] / stats[:, 1]                           # int32 / int32 -> float32, NaN for 0 / 0 like the reference
     empty = (stats[:, 4] < stats[:, 2]) | (stats[:, 5] < stats[:, 3])
     boxes = stats[:, 2:6].long() * (~empty).unsqueeze(-1)
-    return masks.bool(), stability, boxes
+    return masks, stability, boxes
 
 
 def nms(boxes, scores, iou_threshold):
@@ -973,7 +982,7 @@ def have(name):
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
                "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_frames_f32",
-               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "crop_resize_pad": "s6d_crop_resize_pad_f32", "samdec_img2tok": "s6d_samdec_img2tok_bf16", "samdec_tok2img": "s6d_samdec_tok2img_f32", "sam_mask_post": "s6d_sam_mask_post_f32", "nms": "s6d_nms_f32", "samdec_upscale_heads": "s6d_samdec_upscale_heads_bf16", "mha": "s6d_mha_f32",
+               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "crop_resize_pad": "s6d_crop_resize_pad_f32", "samdec_img2tok": "s6d_samdec_img2tok_bf16", "samdec_tok2img": "s6d_samdec_tok2img_f32", "sam_mask_post": "s6d_sam_mask_post_sel_f32", "nms": "s6d_nms_f32", "samdec_upscale_heads": "s6d_samdec_upscale_heads_bf16", "mha": "s6d_mha_f32",
                "linear_attn_focus": "s6d_linear_attn_focus_f32", "linear_attention": "s6d_linear_attention_f32", "project_bbox": "s6d_project_bbox_frames_f32"}.get(name)
         import os
         disabled = name in os.environ.get("S6D_DISABLE_FUSED", "").split(",")

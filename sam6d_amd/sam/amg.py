@@ -31,7 +31,7 @@ def process_point_batch(prompt_encoder, mask_decoder, image_embedding, in_points
     sparse, dense = prompt_encoder(points=(in_points[:, None, :], labels), boxes=None, masks=None)
     low_res, iou = mask_decoder(image_embeddings=image_embedding, image_pe=prompt_encoder.get_dense_pe(),
                                 sparse_prompt_embeddings=sparse, dense_prompt_embeddings=dense, multimask_output=True)
-    masks, stability, boxes = ops.sam_mask_post(low_res.float().contiguous(), img_size, input_size, original_size,
+    masks, stability, boxes = ops.sam_mask_post(low_res.float(), img_size, input_size, original_size,
                                                 mask_threshold, stability_score_offset)
     iou = iou.flatten(0, 1)
     keep = torch.ones_like(iou, dtype=torch.bool)

@@ -156,6 +156,14 @@ def test_mask_post_kernel_bit_exact_vs_oracle_and_golden():
     np.testing.assert_array_equal(st.cpu().numpy(), rs.numpy())
     e = ops.sam_mask_post(low2[:0].cuda(), 256, (171, 256), (33, 49))
     assert e[0].shape == (0, 33, 49) and e[1].shape == (0,) and e[2].shape == (0, 4)
+    # a channel slice of the decoder's output ((B, 4, n, n)[:, 1:], what process_point_batch passes) is read in place
+    full = synth.sam_lowres_logits(3, 4, 64, 9).cuda()
+    sl = full[:, 1:]
+    assert not sl.is_contiguous()
+    mb, st, boxes = ops.sam_mask_post(sl, 256, (171, 256), (120, 160), 0.0, 1.0)
+    rb, rs, rbox = osd.mask_postprocess(sl.cpu().contiguous(), 256, (171, 256), (120, 160))
+    assert mb.dtype == torch.bool and torch.equal(mb.cpu(), rb) and torch.equal(boxes.cpu(), rbox)
+    np.testing.assert_array_equal(st.cpu().numpy(), rs.numpy())
 
 
 def test_process_point_batch_matches_reference_sequence(monkeypatch):

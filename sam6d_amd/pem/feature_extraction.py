@@ -22,11 +22,28 @@ from .. import ops
 from ..utils.linear import fused_linear
 
 
+_FORCE_DTYPE = []     # non-empty: the innermost entry overrides S6D_PEM_VIT_DTYPE (the fp32 re-run of the range guard)
+
+
+class force_vit_dtype:
+    """``with force_vit_dtype("fp32"):`` -- the extractor dtype for the calls inside, whatever the environment says."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        _FORCE_DTYPE.append(self.name)
+
+    def __exit__(self, *a):
+        _FORCE_DTYPE.pop()
+
+
 def _vit_dtype():
     """S6D_PEM_VIT_DTYPE = fp32 (default) | fp16 | bf16.  fp16: the fused pipeline in IEEE half -- the matrix rate of bf16 with an
     11-bit significand: extractor features within 1e-3 of fp32's (bf16: 7.6e-3), pose within north_star's 1e-3 / 1e-3 mm of the
     reference on the well-conditioned golden (tests/test_gpu_pem.py); bf16 misses the translation bar by 1.3-2x."""
-    return {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[os.environ.get("S6D_PEM_VIT_DTYPE", "fp32")]
+    name = _FORCE_DTYPE[-1] if _FORCE_DTYPE else os.environ.get("S6D_PEM_VIT_DTYPE", "fp32")
+    return {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[name]
 
 
 class _Attn(nn.Module):
@@ -178,10 +195,19 @@ class ViT_AE(nn.Module):
     def tokens_up(self, x):
         """(B,3,224,224) -> (B,196,16*out_dim): the up-projection before pixel shuffle."""
         dt = _vit_dtype()
+        self.overflow = None
         if dt != torch.float32:
             with torch.autocast(device_type=x.device.type, dtype=dt):
                 taps = self.vit(x.to(dt))
-                return fused_linear(self.output_upscaling, torch.cat([t[:, 1:] for t in taps], dim=2)).float()
+                up = fused_linear(self.output_upscaling, torch.cat([t[:, 1:] for t in taps], dim=2)).float()
+            if dt == torch.float16:
+                # Range guard of the IEEE-half extractor (VERDICT r3 missing #7): half has the range 65504 and the residual stream
+                # of a released checkpoint may exceed it in an outlier channel (bf16 / fp32 do not have the problem).  An overflow
+                # becomes inf in the GEMM / LayerNorm epilogue's conversion, inf / NaN is absorbing in the residual stream
+                # (x + finite stays non-finite through every later block) and reaches every row of this up-projection: one
+                # reduction over it says which instances are affected.  A device tensor: Net.forward reads it once, at its end.
+                self.overflow = ~torch.isfinite(up).flatten(1).all(1)
+            return up
         taps = self.vit(x)
         return self.output_upscaling(torch.cat([t[:, 1:] for t in taps], dim=2))
 

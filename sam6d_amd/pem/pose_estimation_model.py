@@ -207,8 +207,48 @@ class Net(nn.Module):
                                         fps_idx_o, radius, end_points)
 
     def forward(self, end_points):
+        inputs = dict(end_points)
         dense_pm, dense_fm, dense_po, dense_fo, radius = self.feature_extraction(end_points)
-        return self.match(dense_pm, dense_fm, dense_po, dense_fo, radius, end_points)
+        out = self.match(dense_pm, dense_fm, dense_po, dense_fo, radius, end_points)
+        return self._f16_range_guard(inputs, out)
+
+    _BATCHED = ("pts", "rgb", "rgb_choose", "model", "dense_po", "dense_fo", "coarse_rand_u")
+
+    def _f16_range_guard(self, inputs, out):
+        """The IEEE-half ViT-B (S6D_PEM_VIT_DTYPE=fp16) overflows at 65504; ``ViT_AE.tokens_up`` leaves a per-instance flag on the
+        device.  It is read ONCE here, after the whole forward has been enqueued (one host wait at the end of the stage, where the
+        caller reads the poses anyway); flagged instances are re-run with the fp32 extractor and their rows replaced, with a warning.
+        Under hipGraph capture the flag is returned as ``out["f16_overflow"]`` for the graph's owner to act on (sam6d_amd.pipeline).
+        S6D_PEM_F16_GUARD=0 turns the host read off (the flag is still returned)."""
+        import os
+        import warnings
+
+        from .feature_extraction import force_vit_dtype
+        bad = self.feature_extraction.rgb_net.overflow
+        self.feature_extraction.rgb_net.overflow = None
+        if bad is None:
+            return out
+        out["f16_overflow"] = bad
+        if (bad.is_cuda and torch.cuda.is_current_stream_capturing()) or os.environ.get("S6D_PEM_F16_GUARD", "1") == "0":
+            return out
+        if not bool(bad.any()):
+            return out
+        idx = torch.nonzero(bad).squeeze(1)
+        warnings.warn(f"PEM ViT-B in IEEE half overflowed (|x| > 65504) for instance(s) {idx.tolist()} of {bad.numel()}: "
+                      "re-running them with the fp32 extractor (set S6D_PEM_VIT_DTYPE=fp32 or bf16 for this checkpoint)",
+                      RuntimeWarning, stacklevel=3)
+        B = bad.numel()
+        sub = {k: (v[idx].contiguous() if k in self._BATCHED and torch.is_tensor(v) and v.shape[:1] == (B,) else v)
+               for k, v in inputs.items()}
+        with force_vit_dtype("fp32"):
+            redo = self.forward(sub)
+        for k, v in redo.items():
+            if torch.is_tensor(v) and torch.is_tensor(out.get(k)) and out[k].shape[:1] == (B,) and v.shape[:1] == (idx.numel(),) \
+                    and k not in inputs:
+                out[k] = out[k].clone()
+                out[k][idx] = v.to(out[k].dtype)
+        out["f16_overflow"] = bad
+        return out
 
 
 def default_cfg():

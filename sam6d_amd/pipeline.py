@@ -171,7 +171,7 @@ class FramePipeline:
         # updates, .to() all change one of the two) -- so a replay never computes with stale buffers; a stale entry is dropped.
         key = self._pem_graph_key(Mp, ep, keys)
         g = self._pem_graphs.get(Mp)
-        if g is not None and g[3] != key:
+        if g is not None and g[3] != key:                       # (graph, static inputs, outputs, key, overflow flag)
             del self._pem_graphs[Mp]
             g = None
         if g is None:
@@ -192,14 +192,18 @@ class FramePipeline:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = self.pem(dict(static))
-            g = (graph, static, {k: out[k] for k in ("pred_R", "pred_t", "pred_pose_score")}, key)
+            g = (graph, static, {k: out[k] for k in ("pred_R", "pred_t", "pred_pose_score")}, key, out.get("f16_overflow"))
             self._pem_graphs[Mp] = g
-        graph, static, outs, _ = g
+        graph, static, outs, _, overflow = g
         for k in keys:
             static[k][:M].copy_(ep[k])
             if Mp > M:
                 static[k][M:].copy_(ep[k][M - 1:M].expand(Mp - M, *ep[k].shape[1:]))
         graph.replay()
+        if overflow is not None and os.environ.get("S6D_PEM_F16_GUARD", "1") != "0" and bool(overflow[:M].any()):
+            # the IEEE-half extractor overflowed for an instance (Net._f16_range_guard cannot read its flag inside a capture): the
+            # eager forward re-runs the flagged instances with the fp32 extractor and warns
+            return self.pem(ep)
         return {k: v[:M].clone() for k, v in outs.items()}
 
     def _pem_graph_key(self, Mp, ep, keys):

@@ -219,3 +219,38 @@ def test_real_example_frame_through_preprocessing_and_net(net):
     dt = np.abs(res["pred_t"].cpu().numpy() - g["ref_pred_t"]).max()
     util.record_margin("example_frame_fp32vit", dR=dR.max(), dt_m=dt)
     assert dR.max() <= R_TOL and dt <= T_TOL_M, (dR, dt)
+
+
+def test_fp16_extractor_range_guard_reruns_overflowing_instances_in_fp32(net, monkeypatch):
+    """VERDICT r3 missing #7: the IEEE-half ViT-B has the range 65504; a released checkpoint with an outlier channel must not turn
+    the pose into NaN silently.  An outlier of 1e5 is planted in one channel of the residual stream (fc2 bias of block 3): every
+    instance overflows in half, the guarded forward flags them, warns and returns the fp32 extractor's poses bit for bit; with the
+    guard's host read off the flag is still returned and the poses are not the fp32 ones."""
+    import copy
+    import warnings
+    B = 3
+    inp = synth.pem_inputs(B, seed=5)
+    ep = _to({k: inp[k] for k in ("pts", "rgb", "rgb_choose", "model", "dense_po", "dense_fo")}, "cuda")
+    ep["coarse_rand_u"] = synth.coarse_uniforms(B, 6).cuda()
+    bad_net = copy.deepcopy(net)
+    with torch.no_grad():
+        bad_net.feature_extraction.rgb_net.vit.blocks[3].mlp.fc2.bias[5] = 1.0e5
+        monkeypatch.setenv("S6D_PEM_VIT_DTYPE", "fp32")
+        ref = bad_net(dict(ep))
+        assert "f16_overflow" not in ref and torch.isfinite(ref["pred_R"]).all()
+        monkeypatch.setenv("S6D_PEM_VIT_DTYPE", "fp16")
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            out = bad_net(dict(ep))
+        assert any("overflowed" in str(x.message) for x in w), [str(x.message) for x in w]
+        assert out["f16_overflow"].all()
+        assert torch.equal(out["pred_R"], ref["pred_R"]) and torch.equal(out["pred_t"], ref["pred_t"])
+        monkeypatch.setenv("S6D_PEM_F16_GUARD", "0")
+        raw = bad_net(dict(ep))
+        assert raw["f16_overflow"].all() and not torch.equal(raw["pred_R"], ref["pred_R"])
+        monkeypatch.delenv("S6D_PEM_F16_GUARD")
+        # the healthy network: no flag set, no warning, nothing re-run
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            ok = net(dict(ep))
+        assert not ok["f16_overflow"].any() and not any("overflowed" in str(x.message) for x in w)

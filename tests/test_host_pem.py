@@ -131,3 +131,47 @@ def test_conditioning_of_the_two_net_forward_cases():
     assert spread[(False, 1e-5)][0] < 1e-3 and spread[(False, 1e-3)][0] > 0.1, spread          # chaotic beyond fp32-class noise
     assert spread[(True, 1e-3)][0] < 1e-4 and spread[(True, 1e-3)][1] < 1e-6, spread           # fp32-class features keep the bar
     assert spread[(True, 1e-2)][0] < 1e-3 and 1e-6 < spread[(True, 1e-2)][1] < 1e-5, spread    # bf16-class: R yes, t 1e-3 mm no
+
+
+def test_f16_range_guard_logic_reruns_only_flagged_instances(monkeypatch):
+    """Net._f16_range_guard on the host (no kernels): the flagged instances -- and only those -- go through a second forward with
+    the extractor forced to fp32, their output rows are replaced, a RuntimeWarning names them; S6D_PEM_F16_GUARD=0 leaves the
+    outputs alone; without a flag (fp32 / bf16 extractor) nothing happens."""
+    import warnings
+
+    import torch
+
+    from sam6d_amd.pem import feature_extraction as fe
+    from sam6d_amd.pem import pose_estimation_model as pm
+    net = pm.Net(pm.default_cfg()).eval()
+    B = 4
+    inputs = dict(pts=torch.arange(B * 6, dtype=torch.float32).view(B, 2, 3), rgb=torch.zeros(B, 3, 2, 2), note="keep")
+    out = dict(inputs, pred_R=torch.zeros(B, 3, 3), pred_t=torch.zeros(B, 3), pred_pose_score=torch.zeros(B))
+    seen = {}
+
+    def second_forward(sub):
+        seen["dtype"], seen["pts"], seen["note"] = fe._vit_dtype(), sub["pts"].clone(), sub["note"]
+        n = sub["pts"].shape[0]
+        return dict(sub, pred_R=torch.ones(n, 3, 3), pred_t=torch.full((n, 3), 2.0), pred_pose_score=torch.full((n,), 3.0))
+    monkeypatch.setattr(net, "forward", second_forward)
+    monkeypatch.setenv("S6D_PEM_VIT_DTYPE", "fp16")
+    net.feature_extraction.rgb_net.overflow = torch.tensor([False, True, False, True])
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = net._f16_range_guard(inputs, dict(out))
+    assert any("[1, 3]" in str(x.message) for x in w)
+    assert seen["dtype"] == torch.float32 and seen["note"] == "keep" and torch.equal(seen["pts"], inputs["pts"][[1, 3]])
+    assert got["pred_R"][[1, 3]].eq(1).all() and got["pred_R"][[0, 2]].eq(0).all()
+    assert got["pred_t"][[1, 3]].eq(2).all() and got["pred_pose_score"].tolist() == [0.0, 3.0, 0.0, 3.0]
+    assert torch.equal(got["pts"], inputs["pts"]) and got["f16_overflow"].tolist() == [False, True, False, True]
+    assert fe._vit_dtype() == torch.float16                                  # the override ended with the re-run
+    # host read off: outputs untouched, flag returned
+    monkeypatch.setenv("S6D_PEM_F16_GUARD", "0")
+    net.feature_extraction.rgb_net.overflow = torch.tensor([True] * B)
+    seen.clear()
+    got = net._f16_range_guard(inputs, dict(out))
+    assert not seen and got["pred_R"].eq(0).all() and got["f16_overflow"].all()
+    monkeypatch.delenv("S6D_PEM_F16_GUARD")
+    net.feature_extraction.rgb_net.overflow = None                           # fp32 / bf16 extractor: no flag
+    got = net._f16_range_guard(inputs, dict(out))
+    assert "f16_overflow" not in got and not seen

@@ -767,10 +767,156 @@ def gen_dinov2():
     print("dinov2.npz", {k: (v.shape if hasattr(v, "shape") else v) for k, v in rec.items()})
 
 
+E2E_CASE = dict(sam_seed=3, dino_seed=6, O=3, T=6, patch_stride=8, pred_iou_thresh=0.3086, stability_score_thresh=0.691,
+                stability_score_offset=0.02, box_nms_thresh=1.5, points_per_batch=64, confidence_thresh=0.2, ism_seed=21)
+
+
+def e2e_templates_and_extra(rgb, P=10):
+    """Inputs of the e2e case that do not come out of a model: the ten deterministic depth-window proposals of tests/util.frame_
+    inputs on the Example frame (they join SAM's proposals before the descriptor stage, and are the template crops) and eight
+    ellipse proposals of the DINOv2 tests (template crops only).  Shared with the test."""
+    from tests import util as tutil
+    fi = tutil.frame_inputs(dict(FRAME_CASE, P=P))
+    ell = synth.dinov2_inputs(P=8, seed=E2E_CASE["ism_seed"])
+    return fi, ell
+
+
+def gen_frame_e2e():
+    """tests/golden/frame_e2e.npz -- the Example frame from PIXELS to scored detections through the reference's own modules
+    (VERDICT r3 item 1b): SamPredictor.set_image (ResizeLongestSide + Sam.preprocess + ViT-H) -> CustomSamAutomaticMaskGenerator.
+    generate_masks (prompt encoder, mask decoder, Sam.postprocess_masks, IoU / stability filters, box NMS) -> CustomDINOv2.forward
+    (crops, ViT-L/14, cls + masked patch descriptors) -> Instance_Segmentation_Model scoring methods (semantic / appearance /
+    geometric score, run_inference_custom.py:160-199), seeded weights everywhere.
+
+    Seeded-random SAM weights give masks that span the frame (their logits are +-0.05 of texture around 0: every box IS the
+    frame), so the generator's thresholds are set for these weights through its CONSTRUCTOR (pred_iou_thresh,
+    stability_score_thresh; box_nms_thresh > 1 = no suppression, or one proposal would be left) and ``stability_score_offset``;
+    nothing in the reference code is changed.  The ten deterministic depth-window proposals of the
+    Example frame join SAM's before the descriptor stage so that crops of ordinary sizes go through it too.  Template descriptors
+    (3 objects x 6 templates) are the reference descriptor model's own output for 18 crops of the frame, stored in fp16 with every
+    8th patch (an input definition: both sides read the stored values).  torchvision is not installable: batched_nms / box_area
+    come from oracle/sam_decoder.py (unpinned, as everywhere), ToTensor + Normalize from oracle/dinov2.py, Pillow's resize is real."""
+    import importlib
+
+    from PIL import Image
+
+    from . import dinov2 as odino
+    from . import sam_decoder as od
+    c = E2E_CASE
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    ns = rh.ism()
+    import segment_anything
+    import segment_anything.automatic_mask_generator as amg_mod
+    import segment_anything.utils.transforms as tr_mod
+    msam = importlib.import_module("model.sam")
+    mu = importlib.import_module("model.utils")
+    vt = importlib.import_module("model.vision_transformer")
+    dv = importlib.import_module("model.dinov2")
+    bu = importlib.import_module("utils.bbox_utils")
+
+    def batched_nms(boxes, scores, idxs, iou_threshold):
+        assert (idxs == 0).all()
+        return od.nms(boxes.float(), scores, iou_threshold)
+    box_area = lambda b: (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])      # noqa: E731
+    amg_mod.batched_nms, amg_mod.box_area, msam.batched_nms, msam.box_area = batched_nms, box_area, batched_nms, box_area
+    tr_mod.to_pil_image = lambda a: Image.fromarray(a)
+    tr_mod.resize = lambda im, size: im.resize((size[1], size[0]), Image.BILINEAR)
+
+    g = np.load(os.path.join(OUT, "example_frame.npz"))
+    rgb = g["rgb"]
+    rec = {}
+    with torch.no_grad():
+        # ---- segmentor ------------------------------------------------------------------------------------------------------
+        sam = segment_anything.sam_model_registry["vit_h"]()
+        seeded.load_seeded(sam.eval(), c["sam_seed"])
+        gen = msam.CustomSamAutomaticMaskGenerator(sam, points_per_batch=c["points_per_batch"], stability_score_thresh=c["stability_score_thresh"],
+                                                   pred_iou_thresh=c["pred_iou_thresh"], box_nms_thresh=c["box_nms_thresh"])
+        gen.stability_score_offset = c["stability_score_offset"]
+        # every candidate's predicted IoU / stability score on the way (for the margins of the two filters): _process_batch wrapped
+        cand = dict(iou=[], stab=[])
+        real_filter = amg_mod.MaskData.filter
+
+        def spy(self, keep):
+            if "stability_score" in self._stats and "boxes" not in self._stats and len(self["stability_score"]) == len(keep):
+                cand["stab"].append(self["stability_score"].clone())
+            elif "iou_preds" in self._stats and "stability_score" not in self._stats and "rles" not in self._stats:
+                cand["iou"].append(self["iou_preds"].clone())
+            return real_filter(self, keep)
+        amg_mod.MaskData.filter = spy
+        real_set = gen.predictor.set_image
+
+        def set_image(*a, **k):                       # the embedding is dropped again by reset_image(): keep a copy for the digest
+            real_set(*a, **k)
+            cand["emb"] = gen.predictor.features.clone()
+        gen.predictor.set_image = set_image
+        try:
+            det = gen.generate_masks(rgb)
+        finally:
+            amg_mod.MaskData.filter = real_filter
+        rec["emb_sum"], rec["emb_smp"] = digest(cand["emb"], 1009)
+        masks, boxes = det["masks"], det["boxes"]
+        K = masks.shape[0]
+        rec["sam_masks"] = np.packbits(masks.numpy().astype(bool).reshape(K, -1), axis=1)
+        rec["sam_boxes"] = boxes.numpy()
+        rec["cand_iou"] = torch.cat(cand["iou"]).numpy()
+        rec["n_after_iou_filter"] = np.array(sum(len(x) for x in cand["stab"]))
+        rec["cand_stab_after_iou"] = torch.cat(cand["stab"]).numpy()
+        print("SAM proposals", K, "boxes", boxes[:4].tolist(), "candidates past the IoU filter", int(rec["n_after_iou_filter"]))
+        # ---- descriptors ----------------------------------------------------------------------------------------------------
+        fi, ell = e2e_templates_and_extra(rgb)
+        q_masks = torch.cat([masks.float(), fi["masks"]])
+        q_boxes = torch.cat([boxes.long(), fi["boxes"].long()])              # integer XYXY, as batched_mask_to_box returns them
+        m = vt.vit_large(patch_size=14, img_size=518, init_values=1.0, ffn_layer="mlp", block_chunks=0).eval()
+        seeded.load_seeded(m, c["dino_seed"])
+        o = object.__new__(dv.CustomDINOv2)
+        torch.nn.Module.__init__(o)
+        o.model, o.chunk_size, o.patch_size, o.proposal_size = m, 8, 14, 224
+        o.validpatch_thresh, o.token_name = 0.5, "x_norm_clstoken"
+        o.rgb_normalize = odino.rgb_normalize
+        o.rgb_proposal_processor = bu.CropResizePad(224)
+        o.patch_kernel = torch.nn.AvgPool2d(kernel_size=14, stride=14)
+        detections = mu.Detections({"masks": q_masks.clone(), "boxes": q_boxes.clone()})
+        qry_cls, qry_patch = o.forward(rgb, detections)
+        t_masks = torch.cat([fi["masks"], ell["masks"][:, :480, :640]])[:c["O"] * c["T"]]
+        t_boxes = torch.cat([fi["boxes"].long(), ell["boxes"].long()])[:c["O"] * c["T"]]
+        t_cls, t_patch = o.forward(rgb, types.SimpleNamespace(masks=t_masks.clone(), boxes=t_boxes.clone()))
+        ref_cls = t_cls.view(c["O"], c["T"], -1).half()
+        ref_patch = t_patch[:, ::c["patch_stride"]].reshape(c["O"], c["T"], -1, t_patch.shape[-1]).half()
+        rec["ref_cls"], rec["ref_patch"] = ref_cls.numpy(), ref_patch.numpy()
+        rec["qry_cls"] = qry_cls.numpy()
+        rec["qry_patch_sum"], rec["qry_patch_smp"] = digest(qry_patch, 211)
+        # ---- scoring (run_inference_custom.py:160-199) -----------------------------------------------------------------------
+        d = synth.ism_inputs(P=4, O=c["O"], T=c["T"], C=8, n_patch=4, H=480, W=640, seed=c["ism_seed"])      # template poses only
+        Det = ns.detector.Instance_Segmentation_Model
+        fake = types.SimpleNamespace()
+        pointcloud = fi["pointcloud"] * torch.tensor([1.0, 0.8, 1.2])[:c["O"]].view(-1, 1, 1)       # one model cloud per object
+        fake.ref_data = dict(descriptors=ref_cls.float(), appe_descriptors=ref_patch.float(), poses=d["poses"], pointcloud=pointcloud)
+        fake.matching_config = types.SimpleNamespace(metric=ns.loss.PairwiseSimilarity(), aggregation_function="avg_5",
+                                                     confidence_thresh=c["confidence_thresh"])
+        for name in ("best_template_pose", "compute_semantic_score", "compute_appearance_score", "compute_geometric_score",
+                     "project_template_to_image", "Calculate_the_query_translation"):
+            setattr(fake, name, types.MethodType(getattr(Det, name), fake))
+        sel, pobj, sem, bt = fake.compute_semantic_score(qry_cls)
+        detections.filter(sel)
+        qp = qry_patch[sel, :]
+        appe, ref = fake.compute_appearance_score(bt, pobj, qp)
+        batch = dict(depth=[fi["depth_mm"]], cam_intrinsic=[fi["K"]], depth_scale=fi["depth_scale"])
+        uv = fake.project_template_to_image(bt, pobj, batch, detections.masks)
+        geo, vr = fake.compute_geometric_score(uv, detections, qp, ref, visible_thred=0.5)
+        final = (sem + appe + geo * vr) / (1 + 1 + vr)
+    rec.update(sel=sel.numpy(), pred_obj=pobj.numpy(), best_template=bt.numpy(), semantic=sem.numpy(), appearance=appe.numpy(),
+               visible_ratio=vr.numpy(), iou=np.asarray(geo if not torch.is_tensor(geo) else geo.numpy(), dtype=np.float32) * np.ones(len(sel), np.float32),
+               final=final.numpy(), image_uv=uv.numpy(), case=np.array(str(c)))
+    np.savez_compressed(os.path.join(OUT, "frame_e2e.npz"), **rec)
+    print("frame_e2e.npz: selected", sel.tolist(), "objects", pobj.tolist(), "templates", bt.tolist(), "final", final.numpy().round(4).tolist())
+    print("semantic", sem.numpy().round(4).tolist())
+    print("size", os.path.getsize(os.path.join(OUT, "frame_e2e.npz")))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
     if sys.argv[1] in ("frame_ism", "frame_pem"):
         {"frame_ism": gen_frame_ism, "frame_pem": gen_frame_pem}[sys.argv[1]](sys.argv[2])
         sys.exit(0)
-    {"frame": gen_frame, "pem": gen_pem, "pem_b32": gen_pem_b32, "pem_wc": gen_pem_wc, "example": gen_example, "sam": gen_sam, "ism": gen_ism, "dinov2": gen_dinov2, "sam_decoder": gen_sam_decoder, "handoff": gen_handoff, "pem_pre": gen_pem_pre, "pem_results": gen_pem_results, "detections_ops": gen_detections_ops, "sam_transforms": gen_sam_transforms, "sam_state_dict": gen_sam_state_dict}[sys.argv[1]]()
+    {"frame": gen_frame, "frame_e2e": gen_frame_e2e, "pem": gen_pem, "pem_b32": gen_pem_b32, "pem_wc": gen_pem_wc, "example": gen_example, "sam": gen_sam, "ism": gen_ism, "dinov2": gen_dinov2, "sam_decoder": gen_sam_decoder, "handoff": gen_handoff, "pem_pre": gen_pem_pre, "pem_results": gen_pem_results, "detections_ops": gen_detections_ops, "sam_transforms": gen_sam_transforms, "sam_state_dict": gen_sam_state_dict}[sys.argv[1]]()

@@ -102,9 +102,43 @@ def test_mini_descriptors_fp32_and_bf16_vs_reference_golden(monkeypatch):
     assert cos.min() > 0.999, cos.min()
 
 
+E_BLOCK_L = 4e-3     # per-block rms rounding of the bf16 path relative to the residual stream's rms (as the ViT-H's, tests/test_gpu_sam.py)
+
+
+def test_vit_l14_bf16_error_growth_model(monkeypatch):
+    """ViT-L/14 in the dtype the descriptor stage runs (bf16, folded block loop) held to the ERROR MODEL the ViT-H is held to
+     instead of a cosine: every block adds an independent rms rounding of at most E_BLOCK_L of the residual
+    stream's rms, so after k blocks the stream sits within E_BLOCK_L * sqrt(k + 1) of the fp32 path's ("+1": the bf16 patch
+    embedding + positional term).  Checked at k = 1, 2, 4, 8, 16, 24 against the SAME model in fp32 on the device (pinned to the
+    reference golden below), on 8 crops of the golden's frame."""
+    import torch.nn as nn
+    g, c, inp = _case()
+    m = seeded.load_seeded(pd._make_dinov2_model(arch_name="vit_large").eval(), c["weight_seed"]).cuda()
+    o = _custom(m, 224, chunk=128)
+    rgbs, _ = o._crops(inp["image"], inp["masks"].cuda(), inp["boxes"].cuda(), True, True)
+    full = m.blocks
+    rel = {}
+    try:
+        for k in (1, 2, 4, 8, 16, 24):
+            m.blocks = nn.ModuleList(list(full)[:k])
+            with torch.no_grad():
+                monkeypatch.setenv("S6D_DINO_DTYPE", "fp32")
+                t32 = m.forward_features(rgbs)["x_prenorm"].float()
+                monkeypatch.setenv("S6D_DINO_DTYPE", "bf16")
+                t16 = m.forward_features(rgbs)["x_prenorm"].float()
+            rel[k] = ((t16 - t32).pow(2).mean().sqrt() / t32.pow(2).mean().sqrt()).item()
+    finally:
+        m.blocks = full
+    util.record_margin("vit_l14_bf16_error_growth", **{f"rel_{k}": v for k, v in rel.items()})
+    for k, v in rel.items():
+        assert v <= E_BLOCK_L * (k + 1) ** 0.5, rel
+
+
 def test_vit_l14_bf16_vs_reference_golden(monkeypatch):
-    """Released configuration (ViT-L/14, 224 crops, pos-embed interpolated 37x37 -> 16x16), fused bf16 pipeline
-    against the reference's fp32 descriptors: cosine of every descriptor > 0.995."""
+    """Released configuration (ViT-L/14, 224 crops, pos-embed interpolated 37x37 -> 16x16), fused bf16 pipeline against the
+    reference's fp32 descriptors: the final LayerNorm renormalises the stream, so the cls descriptors sit within the error model's
+    E_BLOCK_L * sqrt(25) of the reference's (rms of the difference relative to the reference's rms, per descriptor), the sampled
+    patch descriptors (unit vectors) likewise."""
     g, c, inp = _case()
     monkeypatch.setenv("S6D_DINO_DTYPE", "bf16")
     m = seeded.load_seeded(pd._make_dinov2_model(arch_name="vit_large").eval(), c["weight_seed"]).cuda()
@@ -113,7 +147,10 @@ def test_vit_l14_bf16_vs_reference_golden(monkeypatch):
     props = types.SimpleNamespace(masks=inp["masks"][:n].cuda(), boxes=inp["boxes"][:n].cuda())
     cls, patch = o.forward(inp["image"], props)
     cls = cls.cpu().numpy()
-    cos = (cls * g["l_cls"]).sum(-1) / np.linalg.norm(cls, axis=-1) / np.linalg.norm(g["l_cls"], axis=-1)
-    assert cos.min() > 0.995, cos
+    bound = E_BLOCK_L * 25 ** 0.5
+    rel = np.linalg.norm(cls - g["l_cls"], axis=-1) / np.linalg.norm(g["l_cls"], axis=-1)
     smp = patch.cpu().reshape(-1)[::53].numpy()
-    assert np.corrcoef(smp, g["l_patch_smp"])[0, 1] > 0.99 and np.abs(smp - g["l_patch_smp"]).mean() < 5e-3
+    rel_p = np.sqrt(((smp - g["l_patch_smp"]) ** 2).mean() / (g["l_patch_smp"] ** 2).mean())
+    util.record_margin("vit_l14_bf16_vs_reference", cls_rel_max=float(rel.max()), patch_rel_rms=float(rel_p), bound=bound)
+    assert rel.max() <= bound, rel
+    assert rel_p <= bound, rel_p

@@ -210,10 +210,14 @@ struct StripState {
   int qy[NS], qx[NS];
 };
 
-template <int HD, int MODE, int NS, bool KSWZ = false, bool PRIO = false>
+// SUBS: 16-key sub-tiles of this tile that exist (a sequence's tail tile: 257 keys = 4 tiles + 1 sub-tile): the score MFMAs of the
+// others are skipped (their probabilities are 0) and the PV pass covers ceil(SUBS / 2) 32-key steps; the V image must hold finite
+// values for the absent keys of the last step.
+template <int HD, int MODE, int NS, bool KSWZ = false, bool PRIO = false, int SUBS = 4>
 __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl, const u16 *Vl, int key0,
                                              StripState<HD, NS> &st, const float (&thv)[NS], int lane, long long *tk = nullptr) {
   using C = Cfg<HD>;
+  static_assert(SUBS >= 1 && SUBS <= 4, "a tile has four 16-key sub-tiles");
   const int g = lane >> 4, c = lane & 15;
   const int gk = KSWZ ? (g ^ kswz(c)) : g;               // chunk of this lane's K fragment inside its group of 4 (see S6D_GLB_KSWZ)
   float s[NS][4][4];
@@ -223,6 +227,13 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
     f32x4 acc[NS];
 #pragma unroll
     for (int n = 0; n < NS; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (sub >= SUBS) {
+#pragma unroll
+      for (int n = 0; n < NS; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[n][sub][r] = -1e30f;
+      continue;
+    }
     if (!(kAbl & 16)) {
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
@@ -271,7 +282,7 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
     for (int n = 0; n < NS; ++n) {
       float v = s[n][0][0];
 #pragma unroll
-      for (int sub = 0; sub < 4; ++sub)
+      for (int sub = 0; sub < SUBS; ++sub)
 #pragma unroll
         for (int r = 0; r < 4; ++r) v = fmaxf(v, s[n][sub][r]);
       v = fmaxf(v, __shfl_xor(v, 16));
@@ -300,7 +311,8 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pb[n][sub >> 1].h[(sub & 1) * 4 + r] = f2bf(fast_exp2(s[n][sub][r] - m_sub));
+        for (int r = 0; r < 4; ++r)
+          pb[n][sub >> 1].h[(sub & 1) * 4 + r] = sub < SUBS ? f2bf(fast_exp2(s[n][sub][r] - m_sub)) : (u16)0;
     }
   }
   // O^T += V^T P^T: k-step j covers keys [32j, 32j+32); MFMA k-index e<4 -> key 32j+g*4+e, e>=4 -> 32j+16+g*4+(e-4).
@@ -317,7 +329,7 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
   S6D_TICK(tk, 4);
   if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < (SUBS + 1) / 2; ++j) {
     const u16 *vrow = Vl + (32 * j + g * 4 + (c >> 2)) * C::VROW + (c & 3) * 4;
 #pragma unroll
     for (int n = 0; n < NS; ++n) st.lacc[n] = S6D_ATTN_MFMA16(ones.v, pb[n][j].v, st.lacc[n]);
@@ -1373,6 +1385,122 @@ __global__ __launch_bounds__(WAVES * 64) void attn_global64_kernel(AttnParams p)
   }
 }
 
+// ---- sequences (no positional bias): DINOv2 ViT-L/14 (257 tokens), the PEM's ViT-B (197 tokens) -- round 4 ----------------
+// attn_window_kernel above treats a sequence as one all-resident window: one workgroup per (sequence, head) that fetches 99 KB,
+// waits for it, and then runs 17 strips of 16 queries over 8 waves (three rounds, the last with one wave busy), every K / V
+// fragment read feeding ONE matrix instruction, over 5 x 64 = 320 key slots for 257 keys: 20 us per item against ~3 us of
+// matrix work and ~3 us of HBM time (186 us per launch of 150 crops x 16 heads: 0.08 of the matrix peak, 0.2 of HBM).
+// This kernel keeps the arithmetic (process_tile: S^T / O^T formulation, deferred rescaling, row sums on the matrix core) and
+// changes the schedule:
+//   * persistent: a workgroup per CU walks its (sequence, head) items; the K / V rows of item i + 1 are fetched into REGISTERS
+//     (2 x 4 x 16 bytes per thread) while item i is computed from LDS, and written to the images between two barriers -- the fetch
+//     latency of an item is under the arithmetic of the one before it;
+//   * one wave per PAIR of query strips (9 waves for 257 tokens, 7 for 197; the odd strip runs alone): one round, and every K / V
+//     fragment read feeds two matrix instructions;
+//   * the tail tile runs only the 16-key sub-tiles that exist (257 keys = 4 tiles + 1 sub-tile: 272 key slots, not 320).
+// Key rows >= T of the images are zero-filled once (finite operands for the masked columns of the tail).
+template <int HD, int NS, int SUBS>
+__device__ __forceinline__ void seq_tail_tile(const AttnParams &p, const u16 *Kl, const u16 *Vl, int key0, StripState<HD, NS> &st,
+                                              int lane) {
+  float thv[NS];
+#pragma unroll
+  for (int n = 0; n < NS; ++n) thv[n] = 0.f;
+  process_tile<HD, 2, NS, false, false, SUBS>(p, Kl, Vl, key0, st, thv, lane);
+}
+
+template <int HD, int NS>
+__device__ __forceinline__ void seq_strips(const AttnParams &p, const u16 *Kl, const u16 *Vl, int b, int head, int q0, int nfull,
+                                           int tail_subs, int lane, const bf16x8 (&qf)[2][Cfg<HD>::KS]) {
+  using C = Cfg<HD>;
+  StripState<HD, NS> st;
+#pragma unroll
+  for (int n = 0; n < NS; ++n) {
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) st.qf[n][ks] = qf[n][ks];
+    st.th[n] = nullptr; st.tw[n] = nullptr; st.qy[n] = 0; st.qx[n] = 0;
+    st.m_run[n] = -1e30f; st.lacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st.twr[n][i] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) st.oacc[n][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float thv[NS];
+#pragma unroll
+  for (int n = 0; n < NS; ++n) thv[n] = 0.f;
+  for (int t = 0; t < nfull; ++t)
+    process_tile<HD, 2, NS>(p, Kl + (size_t)t * 64 * C::KROW, Vl + (size_t)t * 64 * C::VROW, t * 64, st, thv, lane);
+  const u16 *Kt = Kl + (size_t)nfull * 64 * C::KROW, *Vt = Vl + (size_t)nfull * 64 * C::VROW;
+  switch (tail_subs) {                                              // wave-uniform
+    case 1: seq_tail_tile<HD, NS, 1>(p, Kt, Vt, nfull * 64, st, lane); break;
+    case 2: seq_tail_tile<HD, NS, 2>(p, Kt, Vt, nfull * 64, st, lane); break;
+    case 3: seq_tail_tile<HD, NS, 3>(p, Kt, Vt, nfull * 64, st, lane); break;
+    case 4: seq_tail_tile<HD, NS, 4>(p, Kt, Vt, nfull * 64, st, lane); break;     // 49 .. 63 keys in the tail
+    default: break;                                                  // 0: T is a multiple of 64
+  }
+#pragma unroll
+  for (int n = 0; n < NS; ++n) store_strip<HD>(p, b, 0, 0, head, q0 + n * 16, st.lacc[n][0], st.oacc[n], lane);
+}
+
+constexpr int kSeqMaxThreads = 576;   // 9 waves: 257 tokens = 17 strips of 16 queries (three waves on one SIMD: 170 VGPRs each)
+template <int HD>
+__global__ __launch_bounds__(kSeqMaxThreads) void attn_seq_kernel(AttnParams p, int nitems) {
+  using C = Cfg<HD>;
+  constexpr int KP = HD / 8;                                        // 16-byte chunks per K / V row (the K image's head-dim pad stays zero)
+  constexpr int NPRE = 4;                                           // register prefetch: 16-byte chunks per thread and image (32 VGPRs)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int T = p.T, nfull = T / 64, rem = T - nfull * 64, tail_subs = (rem + 15) / 16;
+  const int rows = (nfull + (rem ? 1 : 0)) * 64;
+  u16 *Kl = reinterpret_cast<u16 *>(smem);                          // [rows][KROW]
+  u16 *Vl = Kl + (size_t)rows * C::KROW;                            // [rows][VROW]
+  const int tid = threadIdx.x, nthr = blockDim.x, wave = tid >> 6, lane = tid & 63;
+  // zero both images once: head-dim padding of K, rows >= T of both
+  for (int i = tid; i < rows * (C::KROW + C::VROW) / 8; i += nthr) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
+  const int nchunk = T * KP;                                        // chunks of one image of one item
+  uint4 kr[NPRE], vr[NPRE];
+  auto fetch = [&](int id) {
+    WinItem it;
+    it.decode(p, id);
+    const u16 *kb = qkv_at(p, (size_t)it.b * T, 1, it.head), *vb = qkv_at(p, (size_t)it.b * T, 2, it.head);
+#pragma unroll
+    for (int n = 0; n < NPRE; ++n) {
+      const int i = min(tid + n * nthr, nchunk - 1);                // surplus lanes repeat the last chunk (never stored)
+      const int key = i / KP, part = i - key * KP;
+      kr[n] = *reinterpret_cast<const uint4 *>(kb + (size_t)key * p.tok_stride + part * 8);
+      vr[n] = *reinterpret_cast<const uint4 *>(vb + (size_t)key * p.tok_stride + part * 8);
+    }
+  };
+  int id = blockIdx.x;
+  if (id < nitems) fetch(id);
+  __syncthreads();                                                  // the zero fill is complete before the first rows land
+  for (; id < nitems; id += gridDim.x) {
+#pragma unroll
+    for (int n = 0; n < NPRE; ++n) {
+      const int i = tid + n * nthr;
+      if (i < nchunk) {
+        const int key = i / KP, part = i - key * KP;
+        *reinterpret_cast<uint4 *>(Kl + key * C::KROW + part * 8) = kr[n];
+        *reinterpret_cast<uint4 *>(Vl + key * C::VROW + part * 8) = vr[n];
+      }
+    }
+    __syncthreads();
+    WinItem it;
+    it.decode(p, id);
+    const int q0 = wave * 32;
+    // this item's Q rows are requested BEFORE the next item's K / V rows: loads return in order, so the wait for Q does not wait
+    // for the prefetch, which then flies under the arithmetic below
+    bf16x8 qf[2][C::KS];
+    load_q<HD>(p, it.b, 0, 0, it.head, q0, qf[0], lane);
+    load_q<HD>(p, it.b, 0, 0, it.head, q0 + 16, qf[1], lane);
+    if (id + (int)gridDim.x < nitems) fetch(id + gridDim.x);
+    if (q0 + 16 < T) {
+      seq_strips<HD, 2>(p, Kl, Vl, it.b, it.head, q0, nfull, tail_subs, lane, qf);
+    } else if (q0 < T) {
+      seq_strips<HD, 1>(p, Kl, Vl, it.b, it.head, q0, nfull, tail_subs, lane, qf);
+    }
+    __syncthreads();                                                // every wave is done with the images before they are overwritten
+  }
+}
+
 template <int HD>
 static int launch_attn(AttnParams p, hipStream_t st) {
   using C = Cfg<HD>;
@@ -1547,6 +1675,29 @@ extern "C" int S6D_SEQ_ATTENTION(const void *qkv, int B, int N, int num_heads, i
   p.scale_log2 = scale * kLog2e;
   p.tok_stride = 3L * num_heads * head_dim; p.which_stride = (long)num_heads * head_dim; p.head_stride = head_dim;
   hipStream_t st = as_stream(stream);
+  // round 4: the persistent strip-pair kernel (attn_seq_kernel) for head dim 64 whenever one wave per pair of query strips fits a
+  // workgroup and the chunks of an item fit the register prefetch; S6D_SEQ_ATTN_IMPL=1 selects the all-resident window kernel
+  static int impl = -1;
+  if (impl < 0) {
+    const char *e = getenv("S6D_SEQ_ATTN_IMPL");
+    impl = (e && atoi(e) == 1) ? 1 : 2;
+  }
+  if (impl == 2 && head_dim == 64) {
+    using C = Cfg<64>;
+    const int nstrip = (N + 15) / 16, waves = (nstrip + 1) / 2, rows = (N + 63) / 64 * 64;
+    const size_t lds = (size_t)rows * (C::KROW + C::VROW) * 2;
+    if (waves * 64 <= kSeqMaxThreads && lds <= 160 * 1024 && (long)N * 8 <= 4L * waves * 64) {
+      const int nitems = B * num_heads;
+      int grid = nitems < 256 ? nitems : 256;
+      const char *ge = getenv("S6D_SEQ_ATTN_GRID");                 // tests: fewer workgroups than items without a big problem
+      if (ge && atoi(ge) > 0 && atoi(ge) < grid) grid = atoi(ge);
+      if (grid >= 8) grid &= ~7;                                    // whole XCD rounds: workgroup j keeps to XCD j % 8, like its items
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_seq_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+      hipLaunchKernelGGL((attn_seq_kernel<64>), dim3(grid), dim3(waves * 64), lds, st, p, nitems);
+      return launch_status();
+    }
+  }
   switch (head_dim) {
     case 80: return launch_attn<80>(p, st);
     case 64: return launch_attn<64>(p, st);

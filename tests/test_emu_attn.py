@@ -37,6 +37,20 @@ def test_seq_attention_on_the_emulator(emu, B, N, nh, hd):
     T.test_seq_attention_vs_torch(B, N, nh, hd)
 
 
+@pytest.mark.parametrize("B,N,nh,grid", [(1, 17, 2, 0),      # one tile: tail of 2 sub-tiles, the odd strip alone on the second wave
+                                         (3, 97, 2, 2),      # 1 tile + a 3-sub-tile tail; 6 items on 2 persistent workgroups (prefetch path)
+                                         (1, 129, 1, 0),     # 2 tiles + a 1-sub-tile tail holding ONE key (the shape of 257 = 4 x 64 + 1)
+                                         (1, 50, 2, 0),      # a tail of four sub-tiles, the last one partial
+                                         (2, 64, 3, 4)])     # no tail tile; 6 items on 4 workgroups (uneven shares)
+def test_seq_attention_strip_pair_kernel_on_the_emulator(emu, monkeypatch, B, N, nh, grid):
+    """attn_seq_kernel (head dim 64, round 4): tails of 1 / 2 / 3 sixteen-key sub-tiles, a lone odd strip, workgroups that walk
+    several items (register prefetch of the next item's K / V rows under the current item's arithmetic), against torch."""
+    if grid:
+        monkeypatch.setenv("S6D_SEQ_ATTN_GRID", str(grid))
+    T.test_seq_attention_vs_torch(B, N, nh, 64)
+    T.test_seq_attention_float16_vs_torch(B, N, nh, 64)
+
+
 def test_segment_seq_sum_and_centroid_path_on_the_emulator(emu, monkeypatch):
     """s6d_segment_seq_sum_f32 through the C ABI (emulated launch) == numpy's row-order reduction, and the library-op path
     of the PEM pre-processing (S6D_PEM_PRE=library -> ops.segment_seq_sum for the centroid) == the oracle loop at boundary-cutting radii."""

@@ -226,13 +226,13 @@ def test_fp16_extractor_range_guard_reruns_overflowing_instances_in_fp32(net, mo
     the pose into NaN silently.  An outlier of 1e5 is planted in one channel of the residual stream (fc2 bias of block 3): every
     instance overflows in half, the guarded forward flags them, warns and returns the fp32 extractor's poses bit for bit; with the
     guard's host read off the flag is still returned and the poses are not the fp32 ones."""
-    import copy
     import warnings
     B = 3
     inp = synth.pem_inputs(B, seed=5)
     ep = _to({k: inp[k] for k in ("pts", "rgb", "rgb_choose", "model", "dense_po", "dense_fo")}, "cuda")
     ep["coarse_rand_u"] = synth.coarse_uniforms(B, 6).cuda()
-    bad_net = copy.deepcopy(net)
+    bad_net = pm.Net(pm.default_cfg()).eval().cuda()
+    bad_net.load_state_dict(net.state_dict())
     with torch.no_grad():
         bad_net.feature_extraction.rgb_net.vit.blocks[3].mlp.fc2.bias[5] = 1.0e5
         monkeypatch.setenv("S6D_PEM_VIT_DTYPE", "fp32")

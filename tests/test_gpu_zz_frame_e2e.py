@@ -162,9 +162,13 @@ def test_frame_e2e_benched_dtypes_decisions_vs_fp32_chain(monkeypatch):
                        stability_diff_max=(a["stab"] - b["stab"]).abs().max().item(), filter_flip_rate=flips,
                        kept_fp32=int(keep_a.sum()), kept_bf16=int(keep_b.sum()))
     # seeded weights give logits of +-0.05 around the threshold everywhere (a trained decoder's are +-10): the mask IoU under bf16
-    # rounding is the hardest case there is; bounds = 2 x the measured values of round 4 (profiles/r04_parity_margins_*.jsonl)
+    # rounding is the hardest case there is.  Measured in round 4 (profiles/r04_parity_margins_final.jsonl): embedding 1.4e-2 of
+    # its rms off, mask IoU mean 0.991 / minimum 0.970 over the 3072 candidates, predicted IoU within 2.8e-3, stability score
+    # within 7.8e-3, ONE of the 3072 filter decisions flipped (3.3e-4).  Bounds = about twice the measured distance.
     assert emb_rel < 2.5e-2, emb_rel                       # the encoder's error model: 4e-3 * sqrt(33) (tests/test_gpu_sam.py)
-    assert miou.mean() > 0.80 and flips < 0.15, (miou.mean().item(), flips)
+    assert miou.mean() > 0.98 and miou.min() > 0.94, (miou.mean().item(), miou.min().item())
+    assert (a["iou"] - b["iou"]).abs().max() < 6e-3 and (a["stab"] - b["stab"]).abs().max() < 1.6e-2
+    assert flips <= 3 / 3072 + 1e-9, flips
     del res, a, b
     torch.cuda.empty_cache()
     # ---- descriptors + scoring on the SAME proposals (the golden's), bf16 against fp32 -------------------------------------------
@@ -188,6 +192,8 @@ def test_frame_e2e_benched_dtypes_decisions_vs_fp32_chain(monkeypatch):
     dfinal = (s32["final"][:n] - s16["final"][:n]).abs().max().item() if same_sel else float("nan")
     util.record_margin("frame_e2e_bf16_vs_fp32_scoring", cls_cos_min=cos.min().item(), same_sel=same_sel, pred_obj_flip_rate=obj_flips,
                        best_template_flip_rate=tpl_flips, final_score_diff_max=dfinal)
-    assert cos.min() > 0.999, cos.min().item()
+    # measured in round 4: cosine >= 0.99993, the same 26 proposals selected, no object and no template flipped, final scores
+    # within 1.9e-4.  The selection and the object decision must not move; one template of 26 may (near-ties between template views)
+    assert cos.min() > 0.9998, cos.min().item()
     assert same_sel and obj_flips == 0.0, (s32["sel"].tolist(), s16["sel"].tolist(), obj_flips)
-    assert tpl_flips <= 0.1 and dfinal < 2e-2, (tpl_flips, dfinal)
+    assert tpl_flips <= 1 / 26 + 1e-9 and dfinal < 1e-3, (tpl_flips, dfinal)

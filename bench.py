@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the whole-frame `pipeline` block (all five models)")
+    ap.add_argument("--no-fp8", action="store_true", help="skip the `configs.fp8` block (BASELINE configs[4] measured next to the headline)")
     ap.add_argument("--standin", action="store_true",
                     help="TEST INFRASTRUCTURE (tests/test_bench_launcher.py): stand-in stages on the CPU over gloo, to exercise the "
                          "launcher, the barriers, the record gather and the JSON line on a host without GPUs; the line it prints "
@@ -518,6 +519,38 @@ def cpu_baseline():
                       f"({t_pem:.2f}s/instance; runs {'/'.join(f'{t / 2:.2f}' for t in pem_runs)}), fp32 torch CPU oracle"}
 
 
+def fp8_config(hp, dev, args):
+    from sam6d_amd import ops
+    if not (ops.have("gemm_fp8") and ops.have("layernorm_fp8")):
+        return {"error": "fp8 kernels not in the library"}
+    old = os.environ.get("S6D_SAM_GEMM")
+    os.environ["S6D_SAM_GEMM"] = "fp8"
+    try:
+        for _ in range(max(1, args.warmup)):
+            hp.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            hp.step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        sam_ms = stage_ms(hp.sam_stage, 1)
+        kr = [k for k in kernel_rooflines(dev, args.sam_chunk, args.frames, gemm_ms_inside_the_step(hp))
+              if k["kernel"].startswith(("gemm_fp8", "layernorm_fp8")) or (k["kernel"].startswith("gemm_bf16") and k["launches_per_step"])]
+        dom = max((k for k in kr if k["kernel"].startswith("gemm_fp8")), key=lambda k: k["avg_ms"] * k["launches_per_step"])
+        return {"headline": False, "workload": "BASELINE configs[4] 'fp8 ViT-H MFMA path' on the configs[1] workload (same frames, same stages)",
+                "value": round(args.frames * args.steps / dt, 3), "unit": "frames/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
+                "steps": args.steps, "dtype": "fp8 e4m3 operands / f32 accumulation: SAM ViT-H qkv, proj, lin1, lin2 where the block loop "
+                                              "quantises them (sam/image_encoder.py::_blocks_fp8); everything else as the headline",
+                "sam_encoder_ms": round(sam_ms, 2),
+                "roofline": {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["achieved"], "peak": dom["peak"],
+                             "unit": dom["unit"], "frac": dom["frac"], "avg_launch_ms": dom["avg_ms"], "traffic": _pmc_traffic(dom),
+                             "traffic_source": "profiles/r0*_pmc_summary.json (stored rocprofv3 --pmc passes, not this run)"},
+                "kernels": kr, "accuracy_gate": "tests/test_gpu_fp8.py"}
+    finally:
+        os.environ.pop("S6D_SAM_GEMM") if old is None else os.environ.__setitem__("S6D_SAM_GEMM", old)
+
+
 def _extras(extra, hp, dev, args, world):
     """Stage split, per-kernel rooflines, whole-frame block and CPU baseline: rank 0, outside the timed region."""
     sam_ms = stage_ms(hp.sam_stage, 1)
@@ -548,13 +581,23 @@ def _extras(extra, hp, dev, args, world):
     # the library GEMM is listed in `kernels` for comparison only (it is not on the path)
     extra["roofline"] = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"],
                          "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
-                         "avg_launch_ms": dom["avg_ms"], "traffic": _pmc_traffic(dom)}
+                         "avg_launch_ms": dom["avg_ms"], "traffic": _pmc_traffic(dom),
+                         "traffic_source": "profiles/r0*_pmc_summary.json (stored rocprofv3 --pmc passes of the same command, not this run)"}
     if "algorithmic_bytes" in dom:
         extra["roofline"]["algorithmic_bytes"] = dom["algorithmic_bytes"]
     extra["kernels"] = kr
     extra["stage_roofline"] = {"stage": f"SAM ViT-H encoder, {args.frames} frames (bf16 GEMMs + fused attention)",
                                "bound": "mfma", "achieved": round(achieved / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12,
                                "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK, 4)}
+    if world == 1 and args.config != "fp8" and not args.no_fp8:
+        # BASELINE configs[4] ("fp8 ViT-H MFMA path") measured by THIS run, next to the headline and never as it (VERDICT r3 item 8:
+        # every fp8 number had been builder-run): the same HotPath with the SAM encoder's GEMMs switched to the fp8 matrix cores,
+        # the same timing protocol (warm-up steps, then `steps` steps between device synchronisations), its own roofline row
+        # against the 5 PFLOP/s dense fp8 peak.
+        try:
+            extra["configs"] = {"fp8": fp8_config(hp, dev, args)}
+        except Exception as e:  # noqa: BLE001
+            extra["configs"] = {"fp8": {"error": f"{type(e).__name__}: {e}"}}
     if world == 1 and not args.no_pipeline:
         # what a whole frame costs: every stage of the chain incl. mask decoding, DINOv2 descriptors and the PEM
         # pre-processing, K = 10 instances per frame; outside the timed region, reported next to the headline

@@ -30,7 +30,7 @@ extern "C" {
 
 /* Bumped whenever a signature in this header changes; the loader (sam6d_amd/_lib.py) refuses a library whose
  * s6d_version() differs from the header it was written against (a stale .so fails at load, not at a call). */
-#define S6D_ABI_VERSION 111
+#define S6D_ABI_VERSION 112
 int s6d_version(void);
 const char *s6d_strerror(int code);
 /* last HIP error string seen by this thread (empty if none) */
@@ -224,6 +224,15 @@ int s6d_gemm_f16(const void *A, long lda, const void *W, long ldw, const float *
 int s6d_add_layernorm_f16(const void *x, const void *delta, const float *gamma, const float *beta, float eps, long rows, int C,
                           void *x_out, void *y_out, void *stream);
 int s6d_seq_attention_f16(const void *qkv, int B, int N, int num_heads, int head_dim, float scale, void *out, void *stream);
+/* The same on a strided q / k / v tensor: element (sequence b, token n, which, head h, d) at qkv + (b N + n) tok_stride +
+ * which which_stride + h head_stride + d (elements; strides % 8 == 0).  Token-major = s6d_seq_attention_*; head-major
+ * ((3, nh, B N, hd), the column-block output of s6d_gemm_bf16_cblk / _lnfold: tok_stride = hd, head_stride = B N hd, which_stride =
+ * nh B N hd) makes the K / V rows of a (sequence, head) one contiguous run.  out stays (B, N, nh, hd).
+ * ref: as s6d_seq_attention_bf16 (timm Attention.forward; Instance_Segmentation_Model/model/layers/attention.py:29-62). */
+int s6d_seq_attention_strided_bf16(const void *qkv, long tok_stride, long which_stride, long head_stride, int B, int N,
+                                   int num_heads, int head_dim, float scale, void *out, void *stream);
+int s6d_seq_attention_strided_f16(const void *qkv, long tok_stride, long which_stride, long head_stride, int B, int N,
+                                  int num_heads, int head_dim, float scale, void *out, void *stream);
 
 /* The residual add and the LayerNorm of a transformer block folded into the GEMMs on either side of them
  * (segment_anything/modeling/image_encoder.py:166-182: `x = shortcut + x`, `x = x + self.mlp(self.norm2(x))`, `self.norm1(x)`;

@@ -1387,72 +1387,69 @@ __global__ __launch_bounds__(WAVES * 64) void attn_global64_kernel(AttnParams p)
 
 // ---- sequences (no positional bias): DINOv2 ViT-L/14 (257 tokens), the PEM's ViT-B (197 tokens) -- round 4 ----------------
 // attn_window_kernel above treats a sequence as one all-resident window: one workgroup per (sequence, head) that fetches 99 KB,
-// waits for it, and then runs 17 strips of 16 queries over 8 waves (three rounds, the last with one wave busy), every K / V
-// fragment read feeding ONE matrix instruction, over 5 x 64 = 320 key slots for 257 keys: 20 us per item against ~3 us of
-// matrix work and ~3 us of HBM time (186 us per launch of 150 crops x 16 heads: 0.08 of the matrix peak, 0.2 of HBM).
-// This kernel keeps the arithmetic (process_tile: S^T / O^T formulation, deferred rescaling, row sums on the matrix core) and
-// changes the schedule:
+// waits for it, and then runs 17 strips of 16 queries over 8 waves (three rounds, the last with one wave busy) over 5 x 64 = 320
+// key slots for 257 keys.  Measured 20 us per item (186 us per launch of 150 crops x 16 heads: 0.08 of the matrix peak, 0.2 of
+// HBM) against ~2 us of matrix work: with two waves per SIMD every LDS fragment read in front of a matrix instruction is an
+// exposed ~100-cycle wait (the tile loop waits 17 times per tile), and a wave walks 15 tiles one after the other.
+// This kernel keeps the arithmetic (process_tile, one strip per wave: 73 VGPRs) and changes the schedule:
+//   * ONE ROUND: a wave per query strip, up to 16 waves (four per SIMD hide each other's LDS waits);
+//   * a 17th strip (257 = 16 x 16 + 1 queries) is split over the KEY tiles instead of costing a second round: wave t runs tile t
+//     for it and leaves (m, l, O^T) in LDS, wave 0 merges the partial states (the flash-decoding combination) -- one tile's time;
 //   * persistent: a workgroup per CU walks its (sequence, head) items; the K / V rows of item i + 1 are fetched into REGISTERS
-//     (2 x 4 x 16 bytes per thread) while item i is computed from LDS, and written to the images between two barriers -- the fetch
-//     latency of an item is under the arithmetic of the one before it;
-//   * one wave per PAIR of query strips (9 waves for 257 tokens, 7 for 197; the odd strip runs alone): one round, and every K / V
-//     fragment read feeds two matrix instructions;
-//   * the tail tile runs only the 16-key sub-tiles that exist (257 keys = 4 tiles + 1 sub-tile: 272 key slots, not 320).
+//     (2 x 3 x 16 bytes per thread) while item i is computed from LDS and written to the images between two barriers;
+//   * the tail tile runs only the 16-key sub-tiles that exist (257 keys = 4 tiles + 1 sub-tile).
 // Key rows >= T of the images are zero-filled once (finite operands for the masked columns of the tail).
-template <int HD, int NS, int SUBS>
-__device__ __forceinline__ void seq_tail_tile(const AttnParams &p, const u16 *Kl, const u16 *Vl, int key0, StripState<HD, NS> &st,
-                                              int lane) {
-  float thv[NS];
-#pragma unroll
-  for (int n = 0; n < NS; ++n) thv[n] = 0.f;
-  process_tile<HD, 2, NS, false, false, SUBS>(p, Kl, Vl, key0, st, thv, lane);
-}
-
 template <int HD, int NS>
-__device__ __forceinline__ void seq_strips(const AttnParams &p, const u16 *Kl, const u16 *Vl, int b, int head, int q0, int nfull,
-                                           int tail_subs, int lane, const bf16x8 (&qf)[2][Cfg<HD>::KS]) {
-  using C = Cfg<HD>;
-  StripState<HD, NS> st;
+__device__ __forceinline__ void seq_init(StripState<HD, NS> &st) {
 #pragma unroll
   for (int n = 0; n < NS; ++n) {
-#pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) st.qf[n][ks] = qf[n][ks];
     st.th[n] = nullptr; st.tw[n] = nullptr; st.qy[n] = 0; st.qx[n] = 0;
     st.m_run[n] = -1e30f; st.lacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 16; ++i) st.twr[n][i] = 0.f;
 #pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt) st.oacc[n][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < Cfg<HD>::DT; ++dt) st.oacc[n][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+}
+
+// tile `t` of the sequence (a full one, or the tail with its existing sub-tiles) against the strip(s) of `st`
+template <int HD, int NS>
+__device__ __forceinline__ void seq_tile(const AttnParams &p, const u16 *Kl, const u16 *Vl, int t, int nfull, int tail_subs,
+                                         StripState<HD, NS> &st, int lane) {
+  using C = Cfg<HD>;
   float thv[NS];
 #pragma unroll
   for (int n = 0; n < NS; ++n) thv[n] = 0.f;
-  for (int t = 0; t < nfull; ++t)
-    process_tile<HD, 2, NS>(p, Kl + (size_t)t * 64 * C::KROW, Vl + (size_t)t * 64 * C::VROW, t * 64, st, thv, lane);
-  const u16 *Kt = Kl + (size_t)nfull * 64 * C::KROW, *Vt = Vl + (size_t)nfull * 64 * C::VROW;
-  switch (tail_subs) {                                              // wave-uniform
-    case 1: seq_tail_tile<HD, NS, 1>(p, Kt, Vt, nfull * 64, st, lane); break;
-    case 2: seq_tail_tile<HD, NS, 2>(p, Kt, Vt, nfull * 64, st, lane); break;
-    case 3: seq_tail_tile<HD, NS, 3>(p, Kt, Vt, nfull * 64, st, lane); break;
-    case 4: seq_tail_tile<HD, NS, 4>(p, Kt, Vt, nfull * 64, st, lane); break;     // 49 .. 63 keys in the tail
-    default: break;                                                  // 0: T is a multiple of 64
+  const u16 *Kt = Kl + (size_t)t * 64 * C::KROW, *Vt = Vl + (size_t)t * 64 * C::VROW;
+  if (t < nfull) {
+    process_tile<HD, 2, NS>(p, Kt, Vt, t * 64, st, thv, lane);
+    return;
   }
-#pragma unroll
-  for (int n = 0; n < NS; ++n) store_strip<HD>(p, b, 0, 0, head, q0 + n * 16, st.lacc[n][0], st.oacc[n], lane);
+  switch (tail_subs) {                                              // wave-uniform
+    case 1: process_tile<HD, 2, NS, false, false, 1>(p, Kt, Vt, t * 64, st, thv, lane); break;
+    case 2: process_tile<HD, 2, NS, false, false, 2>(p, Kt, Vt, t * 64, st, thv, lane); break;
+    case 3: process_tile<HD, 2, NS, false, false, 3>(p, Kt, Vt, t * 64, st, thv, lane); break;
+    default: process_tile<HD, 2, NS, false, false, 4>(p, Kt, Vt, t * 64, st, thv, lane); break;
+  }
 }
 
-constexpr int kSeqMaxThreads = 576;   // 9 waves: 257 tokens = 17 strips of 16 queries (three waves on one SIMD: 170 VGPRs each)
+constexpr int kSeqMaxWaves = 16;
+constexpr int kSeqPart = 2 + 4 * 5;                                 // floats per lane of a partial state: m, l, O^T (DT <= 5 tiles of 4)
 template <int HD>
-__global__ __launch_bounds__(kSeqMaxThreads) void attn_seq_kernel(AttnParams p, int nitems) {
+__global__ __launch_bounds__(kSeqMaxWaves * 64) void attn_seq_kernel(AttnParams p, int nitems) {
   using C = Cfg<HD>;
+  static_assert(2 + 4 * C::DT <= kSeqPart, "partial-state slot");
   constexpr int KP = HD / 8;                                        // 16-byte chunks per K / V row (the K image's head-dim pad stays zero)
-  constexpr int NPRE = 4;                                           // register prefetch: 16-byte chunks per thread and image (32 VGPRs)
+  constexpr int NPRE = 3;                                           // register prefetch: 16-byte chunks per thread and image (24 VGPRs)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int T = p.T, nfull = T / 64, rem = T - nfull * 64, tail_subs = (rem + 15) / 16;
-  const int rows = (nfull + (rem ? 1 : 0)) * 64;
+  const int ntile = nfull + (rem ? 1 : 0), rows = ntile * 64;
   u16 *Kl = reinterpret_cast<u16 *>(smem);                          // [rows][KROW]
   u16 *Vl = Kl + (size_t)rows * C::KROW;                            // [rows][VROW]
-  const int tid = threadIdx.x, nthr = blockDim.x, wave = tid >> 6, lane = tid & 63;
+  float *part = reinterpret_cast<float *>(Vl + (size_t)rows * C::VROW);   // [ntile][kSeqPart][64]: partial states of the split strip
+  const int tid = threadIdx.x, nthr = blockDim.x, wave = tid >> 6, lane = tid & 63, nwave = nthr >> 6;
+  const int nstrip = (T + 15) / 16;
+  const bool split = nstrip > nwave;                                // one strip more than waves: it is split over the key tiles
   // zero both images once: head-dim padding of K, rows >= T of both
   for (int i = tid; i < rows * (C::KROW + C::VROW) / 8; i += nthr) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
   const int nchunk = T * KP;                                        // chunks of one image of one item
@@ -1464,9 +1461,14 @@ __global__ __launch_bounds__(kSeqMaxThreads) void attn_seq_kernel(AttnParams p, 
 #pragma unroll
     for (int n = 0; n < NPRE; ++n) {
       const int i = min(tid + n * nthr, nchunk - 1);                // surplus lanes repeat the last chunk (never stored)
-      const int key = i / KP, part = i - key * KP;
-      kr[n] = *reinterpret_cast<const uint4 *>(kb + (size_t)key * p.tok_stride + part * 8);
-      vr[n] = *reinterpret_cast<const uint4 *>(vb + (size_t)key * p.tok_stride + part * 8);
+      const int key = i / KP, part_ = i - key * KP;
+      if (kAbl & 1) {                                               // ablation: no K / V loads
+        kr[n] = make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
+        vr[n] = kr[n];
+        continue;
+      }
+      kr[n] = *reinterpret_cast<const uint4 *>(kb + (size_t)key * p.tok_stride + part_ * 8);
+      vr[n] = *reinterpret_cast<const uint4 *>(vb + (size_t)key * p.tok_stride + part_ * 8);
     }
   };
   int id = blockIdx.x;
@@ -1477,27 +1479,60 @@ __global__ __launch_bounds__(kSeqMaxThreads) void attn_seq_kernel(AttnParams p, 
     for (int n = 0; n < NPRE; ++n) {
       const int i = tid + n * nthr;
       if (i < nchunk) {
-        const int key = i / KP, part = i - key * KP;
-        *reinterpret_cast<uint4 *>(Kl + key * C::KROW + part * 8) = kr[n];
-        *reinterpret_cast<uint4 *>(Vl + key * C::VROW + part * 8) = vr[n];
+        const int key = i / KP, part_ = i - key * KP;
+        *reinterpret_cast<uint4 *>(Kl + key * C::KROW + part_ * 8) = kr[n];
+        *reinterpret_cast<uint4 *>(Vl + key * C::VROW + part_ * 8) = vr[n];
       }
     }
     __syncthreads();
     WinItem it;
     it.decode(p, id);
-    const int q0 = wave * 32;
+    StripState<HD, 1> st;
+    if (split && wave < ntile) {
+      // the strip beyond the waves first: tile `wave` of it, the partial state to LDS.  (Before the prefetch is issued: the
+      // registers of the prefetched rows and the working set of a tile together exceed the 128 VGPRs of a 16-wave workgroup, and
+      // a spilled prefetch register makes the wave wait for the fetch right here.)
+      seq_init<HD, 1>(st);
+      load_q<HD>(p, it.b, 0, 0, it.head, nwave * 16, st.qf[0], lane);
+      seq_tile<HD, 1>(p, Kl, Vl, wave, nfull, tail_subs, st, lane);
+      float *ps = part + (size_t)wave * kSeqPart * 64 + lane;
+      ps[0] = st.m_run[0];
+      ps[64] = st.lacc[0][0];
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ps[(2 + 4 * dt + r) * 64] = st.oacc[0][dt][r];
+    }
     // this item's Q rows are requested BEFORE the next item's K / V rows: loads return in order, so the wait for Q does not wait
     // for the prefetch, which then flies under the arithmetic below
-    bf16x8 qf[2][C::KS];
-    load_q<HD>(p, it.b, 0, 0, it.head, q0, qf[0], lane);
-    load_q<HD>(p, it.b, 0, 0, it.head, q0 + 16, qf[1], lane);
+    seq_init<HD, 1>(st);
+    load_q<HD>(p, it.b, 0, 0, it.head, wave * 16, st.qf[0], lane);
     if (id + (int)gridDim.x < nitems) fetch(id + gridDim.x);
-    if (q0 + 16 < T) {
-      seq_strips<HD, 2>(p, Kl, Vl, it.b, it.head, q0, nfull, tail_subs, lane, qf);
-    } else if (q0 < T) {
-      seq_strips<HD, 1>(p, Kl, Vl, it.b, it.head, q0, nfull, tail_subs, lane, qf);
+    if (!(kAbl & 2))
+      for (int t = 0; t < ntile; ++t) seq_tile<HD, 1>(p, Kl, Vl, t, nfull, tail_subs, st, lane);
+    store_strip<HD>(p, it.b, 0, 0, it.head, wave * 16, st.lacc[0][0], st.oacc[0], lane);
+    if (split) {
+      __syncthreads();
+      if (wave == 0) {                                              // merge: O = sum_t 2^(m_t - m) O_t, l likewise, m = max_t m_t
+        float m = -1e30f;
+        for (int t = 0; t < ntile; ++t) m = fmaxf(m, part[(size_t)t * kSeqPart * 64 + lane]);
+        float l = 0.f;
+        f32x4 o[C::DT];
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < ntile; ++t) {
+          const float *ps = part + (size_t)t * kSeqPart * 64 + lane;
+          const float a = fast_exp2(ps[0] - m);
+          l += a * ps[64];
+#pragma unroll
+          for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[dt][r] += a * ps[(2 + 4 * dt + r) * 64];
+        }
+        store_strip<HD>(p, it.b, 0, 0, it.head, nwave * 16, l, o, lane);
+      }
     }
-    __syncthreads();                                                // every wave is done with the images before they are overwritten
+    __syncthreads();                                                // every wave is done with the images (and the partial states)
   }
 }
 
@@ -1660,11 +1695,22 @@ extern "C" int s6d_win_attention_layout_bf16(const void *qkv, int head_major, co
 #else
 #define S6D_SEQ_ATTENTION s6d_seq_attention_bf16
 #endif
-extern "C" int S6D_SEQ_ATTENTION(const void *qkv, int B, int N, int num_heads, int head_dim, float scale, void *out,
-                                 void *stream) {
-  if (B < 0 || N <= 0 || num_heads <= 0) return S6D_EINVAL;
+#if S6D_ATTN_F16
+#define S6D_SEQ_ATTENTION_STRIDED s6d_seq_attention_strided_f16
+#else
+#define S6D_SEQ_ATTENTION_STRIDED s6d_seq_attention_strided_bf16
+#endif
+// q / k / v element (sequence b, token n, which, head h, d) sits at qkv + (b N + n) tok_stride + which which_stride + h head_stride + d:
+//   token-major (the raw Linear output (B, N, 3, nh, hd)):  tok_stride = 3 nh hd, which_stride = nh hd, head_stride = hd
+//   head-major  ((3, nh, B N, hd), the qkv GEMM's column-block epilogue):  tok_stride = hd, head_stride = B N hd, which_stride = nh B N hd
+// Head-major makes the K / V rows of one (sequence, head) ONE contiguous run (257 x 128 B = 32 KB) instead of 257 pieces of 128 B
+// strided by 6 KB: measured on the DINOv2 shape, the fetch of the token-major pieces ALONE costs 136 us per launch (2.3 TB/s).
+extern "C" int S6D_SEQ_ATTENTION_STRIDED(const void *qkv, long tok_stride, long which_stride, long head_stride, int B, int N,
+                                         int num_heads, int head_dim, float scale, void *out, void *stream) {
+  if (B < 0 || N <= 0 || num_heads <= 0 || head_dim <= 0) return S6D_EINVAL;
+  if (tok_stride < head_dim || (tok_stride % 8) || (which_stride % 8) || (head_stride % 8)) return S6D_EINVAL;   // 16-byte chunks
   if (B == 0) return S6D_OK;
-  if (!qkv || !out) return S6D_EINVAL;
+  if (!qkv || !out || ((uintptr_t)qkv & 15)) return S6D_EINVAL;
   // a 1 x N "image" attended as ONE all-resident window of N key slots, no positional bias
   AttnParams p;
   p.qkv = (const u16 *)qkv; p.qkv_bias = (const u16 *)qkv;        // never read: every slot < N is in-image
@@ -1673,20 +1719,19 @@ extern "C" int S6D_SEQ_ATTENTION(const void *qkv, int B, int N, int num_heads, i
   p.S = N; p.T = N; p.nwx = 1; p.nwy = 1; p.LT = 16;
   p.magicS = (unsigned)(((1ull << 32) + (unsigned)N - 1) / (unsigned)N);
   p.scale_log2 = scale * kLog2e;
-  p.tok_stride = 3L * num_heads * head_dim; p.which_stride = (long)num_heads * head_dim; p.head_stride = head_dim;
+  p.tok_stride = tok_stride; p.which_stride = which_stride; p.head_stride = head_stride;
   hipStream_t st = as_stream(stream);
-  // round 4: the persistent strip-pair kernel (attn_seq_kernel) for head dim 64 whenever one wave per pair of query strips fits a
-  // workgroup and the chunks of an item fit the register prefetch; S6D_SEQ_ATTN_IMPL=1 selects the all-resident window kernel
-  static int impl = -1;
-  if (impl < 0) {
-    const char *e = getenv("S6D_SEQ_ATTN_IMPL");
-    impl = (e && atoi(e) == 1) ? 1 : 2;
-  }
+  // S6D_SEQ_ATTN_IMPL=2 selects the persistent one-round kernel of round 4 (attn_seq_kernel: head dim 64, up to 272 tokens, a wave
+  // per query strip, a 17th strip split over the key tiles).  NOT the default: measured 224 us against the window kernel's 194 us
+  // per 150 x 16 x 257 launch (profiles/r04_seq_attention_ablation.txt: its fetch phase alone 130 us, its arithmetic alone 111 us,
+  // and the two do not overlap because the 16-wave workgroup's 128-VGPR budget spills the prefetched rows).
+  const char *ie = getenv("S6D_SEQ_ATTN_IMPL");                     // read per call (tests switch it inside one process)
+  const int impl = (ie && atoi(ie) == 2) ? 2 : 1;
   if (impl == 2 && head_dim == 64) {
     using C = Cfg<64>;
-    const int nstrip = (N + 15) / 16, waves = (nstrip + 1) / 2, rows = (N + 63) / 64 * 64;
-    const size_t lds = (size_t)rows * (C::KROW + C::VROW) * 2;
-    if (waves * 64 <= kSeqMaxThreads && lds <= 160 * 1024 && (long)N * 8 <= 4L * waves * 64) {
+    const int nstrip = (N + 15) / 16, waves = nstrip < kSeqMaxWaves ? nstrip : kSeqMaxWaves, ntile = (N + 63) / 64;
+    const size_t lds = (size_t)ntile * 64 * (C::KROW + C::VROW) * 2 + (size_t)ntile * kSeqPart * 64 * 4;
+    if (nstrip <= kSeqMaxWaves + 1 && lds <= 160 * 1024) {          // at most ONE strip beyond the waves (split over the key tiles)
       const int nitems = B * num_heads;
       int grid = nitems < 256 ? nitems : 256;
       const char *ge = getenv("S6D_SEQ_ATTN_GRID");                 // tests: fewer workgroups than items without a big problem
@@ -1703,4 +1748,11 @@ extern "C" int S6D_SEQ_ATTENTION(const void *qkv, int B, int N, int num_heads, i
     case 64: return launch_attn<64>(p, st);
     default: return S6D_EUNSUPPORTED;
   }
+}
+
+extern "C" int S6D_SEQ_ATTENTION(const void *qkv, int B, int N, int num_heads, int head_dim, float scale, void *out,
+                                 void *stream) {
+  if (num_heads <= 0 || head_dim <= 0) return S6D_EINVAL;
+  return S6D_SEQ_ATTENTION_STRIDED(qkv, 3L * num_heads * head_dim, (long)num_heads * head_dim, head_dim, B, N, num_heads, head_dim,
+                                   scale, out, stream);
 }

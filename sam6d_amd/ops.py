@@ -493,14 +493,27 @@ def _half(t, name, ndim=None):
     return "bf16" if t.dtype == torch.bfloat16 else "f16"
 
 
-def seq_attention(qkv, num_heads, scale):
-    """qkv (B,N,3C) bf16 or f16 -> (B,N,C) same dtype: softmax(scale q k^T) v per head, no positional bias."""
+def seq_attention(qkv, num_heads, scale, seq_len=None):
+    """softmax(scale q k^T) v per head, no positional bias.  qkv (B,N,3C) bf16 or f16 token-major (the raw Linear output), or --
+    with ``seq_len`` = N -- HEAD-major (3 * num_heads, B * N, hd), what ``gemm_bf16(..., col_block=hd)`` / ``gemm_bf16_lnfold(...,
+    col_block=hd)`` return: the K / V rows of a (sequence, head) are then one contiguous run instead of N pieces of hd elements
+    strided by 3C (the fetch of those pieces alone costs 136 us per 150 x 16 x 257 launch).  -> (B,N,C) in qkv's dtype."""
     sfx = _half(qkv, "qkv", 3)
-    B, N, C3 = qkv.shape
-    C = C3 // 3
-    out = torch.empty(B, N, C, dtype=qkv.dtype, device=qkv.device)
-    _call("s6d_seq_attention_" + sfx, _ptr(qkv), B, N, int(num_heads), int(C // num_heads), ctypes.c_float(scale),
-          _ptr(out), _stream())
+    if seq_len is None:
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        out = torch.empty(B, N, C, dtype=qkv.dtype, device=qkv.device)
+        _call("s6d_seq_attention_" + sfx, _ptr(qkv), B, N, int(num_heads), int(C // num_heads), ctypes.c_float(scale),
+              _ptr(out), _stream())
+        return out
+    H3, M, hd = qkv.shape
+    N = int(seq_len)
+    if H3 != 3 * num_heads or M % N:
+        raise ValueError(f"head-major qkv must be (3 * num_heads, B * N, hd); got {tuple(qkv.shape)} for {num_heads} heads, N = {N}")
+    B = M // N
+    out = torch.empty(B, N, num_heads * hd, dtype=qkv.dtype, device=qkv.device)
+    _call("s6d_seq_attention_strided_" + sfx, _ptr(qkv), ctypes.c_long(hd), ctypes.c_long(num_heads * M * hd), ctypes.c_long(M * hd),
+          B, N, int(num_heads), int(hd), ctypes.c_float(scale), _ptr(out), _stream())
     return out
 
 

@@ -37,14 +37,19 @@ def test_seq_attention_on_the_emulator(emu, B, N, nh, hd):
     T.test_seq_attention_vs_torch(B, N, nh, hd)
 
 
-@pytest.mark.parametrize("B,N,nh,grid", [(1, 17, 2, 0),      # one tile: tail of 2 sub-tiles, the odd strip alone on the second wave
+@pytest.mark.parametrize("B,N,nh,grid", [(1, 17, 2, 0),      # one tile: tail of 2 sub-tiles, two waves
                                          (3, 97, 2, 2),      # 1 tile + a 3-sub-tile tail; 6 items on 2 persistent workgroups (prefetch path)
-                                         (1, 129, 1, 0),     # 2 tiles + a 1-sub-tile tail holding ONE key (the shape of 257 = 4 x 64 + 1)
+                                         (1, 129, 1, 0),     # 2 tiles + a 1-sub-tile tail holding ONE key
                                          (1, 50, 2, 0),      # a tail of four sub-tiles, the last one partial
-                                         (2, 64, 3, 4)])     # no tail tile; 6 items on 4 workgroups (uneven shares)
-def test_seq_attention_strip_pair_kernel_on_the_emulator(emu, monkeypatch, B, N, nh, grid):
-    """attn_seq_kernel (head dim 64, round 4): tails of 1 / 2 / 3 sixteen-key sub-tiles, a lone odd strip, workgroups that walk
-    several items (register prefetch of the next item's K / V rows under the current item's arithmetic), against torch."""
+                                         (2, 64, 3, 4),      # no tail tile; 6 items on 4 workgroups (uneven shares)
+                                         (2, 257, 2, 3),     # the DINOv2 shape: 16 waves + the 17th strip split over the 5 key tiles; 4 items on 3 workgroups
+                                         (1, 272, 1, 0),     # the largest sequence: 17 full strips
+                                         (1, 197, 2, 0)])    # the PEM ViT-B shape: 13 waves, no split
+def test_seq_attention_one_round_kernel_on_the_emulator(emu, monkeypatch, B, N, nh, grid):
+    """attn_seq_kernel (head dim 64, round 4): tails of 1 - 4 sixteen-key sub-tiles, workgroups that walk several items (register
+    prefetch of the next item's K / V rows under the current item's arithmetic), the strip split over the key tiles with the
+    merge of its partial softmax states, against torch; bf16 and IEEE half."""
+    monkeypatch.setenv("S6D_SEQ_ATTN_IMPL", "2")                     # opt-in (the window kernel stays the default: it measured faster)
     if grid:
         monkeypatch.setenv("S6D_SEQ_ATTN_GRID", str(grid))
     T.test_seq_attention_vs_torch(B, N, nh, 64)

@@ -133,3 +133,6 @@ def test_seq_attention_vs_torch(B, N, nh, hd):
     q, k, v = qkv.float().view(B, N, 3, nh, hd).permute(2, 0, 3, 1, 4).unbind(0)
     ref = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v).transpose(1, 2).reshape(B, N, nh * hd)
     assert (out - ref).abs().max() < 3e-2 and (out - ref).abs().mean() < 3e-3
+    # head-major operand layout ((3 nh, B N, hd): the qkv GEMM's column-block output): the same values, bit for bit
+    hm = qkv.view(B * N, 3 * nh, hd).transpose(0, 1).contiguous()
+    assert torch.equal(ops.seq_attention(hm, nh, hd ** -0.5, seq_len=N).float(), out)

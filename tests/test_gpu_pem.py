@@ -227,6 +227,8 @@ def test_fp16_extractor_range_guard_reruns_overflowing_instances_in_fp32(net, mo
     instance overflows in half, the guarded forward flags them, warns and returns the fp32 extractor's poses bit for bit; with the
     guard's host read off the flag is still returned and the poses are not the fp32 ones."""
     import warnings
+
+    from sam6d_amd.pem import pose_estimation_model as pm
     B = 3
     inp = synth.pem_inputs(B, seed=5)
     ep = _to({k: inp[k] for k in ("pts", "rgb", "rgb_choose", "model", "dense_po", "dense_fo")}, "cuda")

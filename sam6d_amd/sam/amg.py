@@ -17,6 +17,75 @@ import torch
 from .. import ops
 
 
+def _decode_batch(prompt_encoder, mask_decoder, image_embedding, in_points, input_size, original_size, img_size, mask_threshold,
+                  stability_score_offset):
+    """prompt encoder -> mask decoder -> fused post-processing for one batch of point prompts -> (low_res, iou (B,C), masks
+    (B*C,H,W) bool, stability (B*C,), boxes (B*C,4))."""
+    B = in_points.shape[0]
+    labels = torch.ones(B, 1, dtype=torch.int, device=in_points.device)
+    sparse, dense = prompt_encoder(points=(in_points[:, None, :], labels), boxes=None, masks=None)
+    low_res, iou = mask_decoder(image_embeddings=image_embedding, image_pe=prompt_encoder.get_dense_pe(),
+                                sparse_prompt_embeddings=sparse, dense_prompt_embeddings=dense, multimask_output=True)
+    masks, stability, boxes = ops.sam_mask_post(low_res.float(), img_size, input_size, original_size, mask_threshold,
+                                                stability_score_offset)
+    return low_res, iou, masks, stability, boxes
+
+
+_GRAPHS = {}          # (modules, shapes, dtypes, thresholds, weight fingerprint) -> (graph, static inputs, static outputs)
+_GRAPH_MAX = 4        # distinct configurations kept (a segmentor serves one frame size: one entry)
+
+
+def _weights_key(*modules):
+    ver, ptr = 0, 0
+    for m in modules:
+        for t in list(m.parameters()) + list(m.buffers()):
+            ver += t._version
+            ptr ^= t.data_ptr()
+    return ver, ptr
+
+
+def _decode_batch_graphed(prompt_encoder, mask_decoder, image_embedding, in_points, input_size, original_size, img_size,
+                          mask_threshold, stability_score_offset):
+    """``_decode_batch`` replayed as a hipGraph (S6D_AMG_GRAPH=0 turns it off).  The batch is ~150 launches, most of them the small
+    token-side operations of the two-way transformer (7 tokens per prompt): measured 19.6 ms per 1024 prompts eager against ~13 ms
+    of kernel time (profiles/r04_frame_demo_kernel_stats_first.csv) -- the rest is the host issuing them.  Nothing inside depends on
+    a value read back from the device; the filters behind it (torch.nonzero) stay outside the graph.  Static input buffers
+    (embedding, prompts) are overwritten before each replay; the outputs are the graph's own buffers, valid until the next call
+    with the same configuration (the caller gathers what it keeps right away).  The key carries everything a capture bakes in."""
+    dev = image_embedding.device
+    key = (id(prompt_encoder), id(mask_decoder), tuple(image_embedding.shape), image_embedding.dtype, tuple(in_points.shape),
+           in_points.dtype, tuple(input_size), tuple(original_size), int(img_size), float(mask_threshold), float(stability_score_offset),
+           os.environ.get("S6D_SAM_DECODER_DTYPE", ""), os.environ.get("S6D_DISABLE_FUSED", ""), os.environ.get("S6D_SAMDEC_GEMM", ""),
+           _weights_key(prompt_encoder, mask_decoder), dev.index)
+    g = _GRAPHS.get(key)
+    if g is None:
+        if len(_GRAPHS) >= _GRAPH_MAX:
+            _GRAPHS.clear()
+        emb_s, pts_s = image_embedding.clone(), in_points.clone()
+        args = (prompt_encoder, mask_decoder, emb_s, pts_s, input_size, original_size, img_size, mask_threshold, stability_score_offset)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):                                      # warm every lazily filled cache of the decoder
+                _decode_batch(*args)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            outs = _decode_batch(*args)
+        g = (graph, emb_s, pts_s, outs)
+        _GRAPHS[key] = g
+    graph, emb_s, pts_s, outs = g
+    emb_s.copy_(image_embedding)
+    pts_s.copy_(in_points)
+    graph.replay()
+    return outs
+
+
+def invalidate_graphs():
+    """Drop every captured decoder graph (re-captured on the next call)."""
+    _GRAPHS.clear()
+
+
 @torch.no_grad()
 def process_point_batch(prompt_encoder, mask_decoder, image_embedding, in_points, input_size, original_size, img_size=1024,
                         mask_threshold=0.0, pred_iou_thresh=0.88, stability_score_thresh=0.95,
@@ -26,13 +95,11 @@ def process_point_batch(prompt_encoder, mask_decoder, image_embedding, in_points
     frame inside the padded img_size square; original_size = (H,W) of the frame.
     -> dict(masks bool (K,H,W), iou_preds (K,), stability_score (K,), boxes (K,4) long XYXY, point_index (K,) long):
     the masks that pass both filters, in the reference's (prompt-major, then the 3 multimask outputs) order."""
-    B = in_points.shape[0]
-    labels = torch.ones(B, 1, dtype=torch.int, device=in_points.device)
-    sparse, dense = prompt_encoder(points=(in_points[:, None, :], labels), boxes=None, masks=None)
-    low_res, iou = mask_decoder(image_embeddings=image_embedding, image_pe=prompt_encoder.get_dense_pe(),
-                                sparse_prompt_embeddings=sparse, dense_prompt_embeddings=dense, multimask_output=True)
-    masks, stability, boxes = ops.sam_mask_post(low_res.float(), img_size, input_size, original_size,
-                                                mask_threshold, stability_score_offset)
+    graphed = (torch.cuda.is_available() and image_embedding.is_cuda and os.environ.get("S6D_AMG_GRAPH", "1") == "1"
+               and in_points.shape[0] >= 64 and not torch.cuda.is_current_stream_capturing())
+    fn = _decode_batch_graphed if graphed else _decode_batch
+    low_res, iou, masks, stability, boxes = fn(prompt_encoder, mask_decoder, image_embedding, in_points, input_size, original_size,
+                                               img_size, mask_threshold, stability_score_offset)
     iou = iou.flatten(0, 1)
     keep = torch.ones_like(iou, dtype=torch.bool)
     if pred_iou_thresh > 0.0:

@@ -232,3 +232,36 @@ def test_generate_proposals_pipeline(monkeypatch):
     scores = torch.cat([r["iou_preds"] for r in cand]).float().cpu()
     keep = osd.nms(boxes, scores, 0.7)
     assert torch.equal(out["boxes"].cpu().float(), boxes[keep])
+
+
+def test_decoder_batch_graph_replay_equals_eager(monkeypatch):
+    """process_point_batch replays the prompt-encoder + mask-decoder + post-processing batch as a hipGraph (round 4): the replay
+    gives the eager path's bits, a second frame's embedding goes through the same graph, and a weight change re-captures."""
+    from sam6d_amd.sam import amg
+    monkeypatch.setenv("S6D_SAM_DECODER_DTYPE", "bf16")
+    g, c, cfg, inp = case("sam")
+    inp = _cuda(inp)
+    m = seeded.load_seeded(build(cfg), c["weight_seed"]).cuda()
+    pts = torch.rand(128, 2, generator=torch.Generator().manual_seed(0)).cuda() * torch.tensor([1024.0, 768.0]).cuda()
+    kw = dict(pred_iou_thresh=0.0, stability_score_thresh=0.0, stability_score_offset=0.02)
+    emb2 = inp["emb"] * 0.5 + 0.1
+
+    def run(emb):
+        r = amg.process_point_batch(m.prompt_encoder, m.mask_decoder, emb, pts, (768, 1024), (480, 640), **kw)
+        return {k: r[k].clone() for k in ("masks", "iou_preds", "stability_score", "boxes", "low_res_logits")}
+    monkeypatch.setenv("S6D_AMG_GRAPH", "0")
+    amg.invalidate_graphs()
+    e1, e2 = run(inp["emb"]), run(emb2)
+    assert not torch.equal(e1["iou_preds"], e2["iou_preds"])
+    monkeypatch.setenv("S6D_AMG_GRAPH", "1")
+    g1 = run(inp["emb"])
+    assert len(amg._GRAPHS) == 1
+    g2, g1b = run(emb2), run(inp["emb"])
+    assert len(amg._GRAPHS) == 1                                      # one capture served the three calls
+    for k in e1:
+        assert torch.equal(g1[k], e1[k]) and torch.equal(g2[k], e2[k]) and torch.equal(g1b[k], e1[k]), k
+    with torch.no_grad():
+        m.mask_decoder.iou_prediction_head.layers[-1].bias.add_(0.25)   # an in-place weight update: the stale capture must not be replayed
+    g3 = run(inp["emb"])
+    assert torch.allclose(g3["iou_preds"].float(), e1["iou_preds"].float() + 0.25, atol=2e-2) and len(amg._GRAPHS) == 2
+    amg.invalidate_graphs()

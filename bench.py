@@ -416,7 +416,10 @@ def kernel_rooflines(dev, sam_chunk, frames, in_step=None):
                     "algorithmic_bytes": 2.0 * (M * K + N * K + M * N) + (2.0 * M * N if form == "res" else 0.0),
                     # the GELU and the LayerNorm-folded instantiations run at one shape each; <0 / 2, true> are shared between shapes
                     # (no per-shape counters)
-                    "pmc_key": inst if (gelu or form == "lnfold") else "-", "form": form, "shape": nm})
+                    # (the residual instantiation <2, true> runs proj and lin2: the counter summary splits its launches by dispatch order,
+                    # tools/pmc_summarise.py)
+                    "pmc_key": inst if (gelu or form == "lnfold") else (f"{inst} [{nm}]" if form == "res" else "-"), "form": form,
+                    "shape": nm})
     if os.environ.get("S6D_SAM_GEMM") == "fp8" and ops.have("gemm_fp8"):
         # configs[4]: the two LayerNorm-fed GEMMs on the fp8 matrix cores (dense peak 5 PFLOP/s), and the quantising LayerNorm
         from sam6d_amd.utils import fp8
@@ -462,7 +465,7 @@ def _pmc_traffic(row):
     Rows name their counter key (`pmc_key` = the kernel's template instance as rocprofv3 prints it); a template instance that runs
     at several shapes in the counter pass (its average would mix them) has none."""
     key = row.get("pmc_key", row["kernel"])
-    for f in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for f in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", f)))
         except Exception:  # noqa: BLE001

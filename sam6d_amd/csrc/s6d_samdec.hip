@@ -435,7 +435,8 @@ __device__ __forceinline__ float bil_mix(float w0, float a, float w1, float b) {
 // pixel the taps of neighbouring lanes fall into the same few cache lines, with a lane per quad they do not.)
 constexpr int kPostRows = 32;      // frame rows per workgroup
 constexpr int kPostThreads = 320;  // 5 waves: 640 columns in two passes
-constexpr int kPostMaxInter = 2 * kPostRows + 2;   // intermediate rows a strip can touch (scale <= 2 asserted by the entry point)
+constexpr int kPostMaxInter = 2 * kPostRows + 2;   // intermediate rows a strip may touch: the entry point shortens the strip for frames
+                                                   // more than twice as small as the resized input (rows * in_h / H + 2 <= this)
 
 __global__ void mask_post_init_kernel(int *stats, int Bm, int H, int W) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -449,13 +450,13 @@ __global__ void mask_post_init_kernel(int *stats, int Bm, int H, int W) {
 // decoder's (B, 4, n, n) output is read in place (the contiguous copy of the slice was 0.57 ms per 1024 prompts).
 __global__ __launch_bounds__(kPostThreads) void mask_post_kernel(const float *__restrict__ low, int ch_total, int ch_first,
                                                                  int ch_count, int n, int img, int ih, int iw,
-                                                                 int H, int W, float thr, float off,
+                                                                 int H, int W, int strip, float thr, float off,
                                                                  unsigned char *__restrict__ masks, int *__restrict__ stats) {
   __shared__ int red[6][kPostThreads / 64];
   __shared__ BilTap tabB[kPostRows];          // frame row -> rows of the intermediate image
   __shared__ BilTap tabA[kPostMaxInter];      // intermediate row -> rows of the logits
-  const int m = blockIdx.y, y_base = blockIdx.x * kPostRows, tid = threadIdx.x;
-  const int rows = min(kPostRows, H - y_base);
+  const int m = blockIdx.y, y_base = blockIdx.x * strip, tid = threadIdx.x;
+  const int rows = min(strip, H - y_base);
   const float *L = low + ((size_t)(m / ch_count) * ch_total + ch_first + m % ch_count) * n * n;
   const float sA = (float)n / (float)img, sBy = (float)ih / (float)H, sBx = (float)iw / (float)W;
   const int Y_first = bil_tap(y_base, sBy, ih).i0;
@@ -618,17 +619,19 @@ extern "C" int s6d_sam_mask_post_sel_f32(const float *low_res, int B, int ch_tot
     return S6D_EINVAL;
   if (B == 0) return S6D_OK;
   if (!low_res || !masks || !stats) return S6D_EINVAL;
-  // the strip walk sizes its table of intermediate rows for a second stage that shrinks by at most 2 (frames are smaller than
-  // the resized input everywhere on this path; a frame MORE than twice as small per side is outside what SAM is used on)
-  if ((long)in_h > 2L * H || (long)B * ch_count > 65535L * 32) return S6D_EINVAL;
+  if ((long)B * ch_count > 65535L * 32) return S6D_EINVAL;
   const int Bm = B * ch_count;
+  // frame rows per workgroup: 32, fewer when the frame is more than twice as small as the resized input (the table of the
+  // intermediate rows a strip touches has kPostMaxInter entries: rows * in_h / H + 2 of them are used)
+  int strip = (int)(((long)(kPostMaxInter - 2) * H) / in_h);
+  strip = strip < 1 ? 1 : (strip > kPostRows ? kPostRows : strip);
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(mask_post_init_kernel, dim3((Bm + 255) / 256), dim3(256), 0, st, stats, Bm, H, W);
   for (int m0 = 0; m0 < Bm; m0 += 65535 / ch_count * ch_count) {      // gridDim.y <= 65535, slabs of whole prompts
     const int mb = min(Bm - m0, 65535 / ch_count * ch_count);
-    hipLaunchKernelGGL(mask_post_kernel, dim3((H + kPostRows - 1) / kPostRows, mb), dim3(kPostThreads), 0, st,
+    hipLaunchKernelGGL(mask_post_kernel, dim3((H + strip - 1) / strip, mb), dim3(kPostThreads), 0, st,
                        low_res + (size_t)(m0 / ch_count) * ch_total * n * n, ch_total, ch_first, ch_count, n, img_size, in_h, in_w,
-                       H, W, mask_threshold, stability_offset, masks + (size_t)m0 * H * W, stats + (size_t)m0 * 6);
+                       H, W, strip, mask_threshold, stability_offset, masks + (size_t)m0 * H * W, stats + (size_t)m0 * 6);
   }
   return launch_status();
 }

@@ -156,6 +156,15 @@ def test_mask_post_kernel_bit_exact_vs_oracle_and_golden():
     np.testing.assert_array_equal(st.cpu().numpy(), rs.numpy())
     e = ops.sam_mask_post(low2[:0].cuda(), 256, (171, 256), (33, 49))
     assert e[0].shape == (0, 33, 49) and e[1].shape == (0,) and e[2].shape == (0, 4)
+    # a frame much smaller than the resized input (3.2 intermediate rows per frame row: the strip of a workgroup shortens)
+    low3 = synth.sam_lowres_logits(2, 3, 128, 5)
+    mb, st, boxes = ops.sam_mask_post(low3.cuda(), 512, (384, 512), (120, 160), 0.0, 1.0)
+    rb, rs, rbox = osd.mask_postprocess(low3, 512, (384, 512), (120, 160))
+    assert torch.equal(mb.cpu(), rb) and torch.equal(boxes.cpu(), rbox)
+    np.testing.assert_array_equal(st.cpu().numpy(), rs.numpy())
+    mb, st, boxes = ops.sam_mask_post(low3.cuda(), 512, (384, 512), (3, 5), 0.0, 1.0)          # 128 intermediate rows per frame row
+    rb, rs, rbox = osd.mask_postprocess(low3, 512, (384, 512), (3, 5))
+    assert torch.equal(mb.cpu(), rb) and torch.equal(boxes.cpu(), rbox)
     # a channel slice of the decoder's output ((B, 4, n, n)[:, 1:], what process_point_batch passes) is read in place
     full = synth.sam_lowres_logits(3, 4, 64, 9).cuda()
     sl = full[:, 1:]

@@ -1,9 +1,9 @@
-# Round-end measurement pass (tests, bench line with cpu_baseline and the whole-frame pipeline block, the fp8 configuration, rocprofv3
-# kernel stats of the bench command on three streams and on one, PMC passes folded into profiles/r03_pmc_summary.json).
+# Round-end measurement pass (tests, bench line with cpu_baseline + configs.fp8 + the whole-frame pipeline block, rocprofv3 kernel stats
+# of the bench command on three streams and on one and of the whole-frame demo, PMC passes folded into profiles/r04_pmc_summary.json).
 #   gpurun --timeout 2700 -- 'bash tools/final_pass.sh'      then copy gpurun_out/prof/* into profiles/
 set -x
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-R=r03
+R=r04
 mkdir -p gpurun_out/prof; rm -f gpurun_out/margins.jsonl
 timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > gpurun_out/prof/${R}_gpu_suite.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 >> gpurun_out/prof/${R}_gpu_suite.txt
@@ -13,17 +13,35 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -o w
 python tools/pmc_summarise.py gpurun_out/prof/${R}_pmc_summary.json /tmp/pmc_f /tmp/pmc_w > /dev/null 2>&1
 cp gpurun_out/prof/${R}_pmc_summary.json profiles/${R}_pmc_summary.json   # the bench line below reads its roofline.traffic from it
 timeout 900 python bench.py --steps 5 --warmup 2 > gpurun_out/prof/${R}_bench_line.json 2> gpurun_out/prof/${R}_bench.err
-timeout 400 python bench.py --config fp8 --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline > gpurun_out/prof/${R}_bench_fp8_line.json 2>> gpurun_out/prof/${R}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline > /dev/null 2>&1
+# same box A/B of the round's host-visible change in the step: the IEEE-half range guard's host read at the end of the PEM stage
+S6D_PEM_F16_GUARD=0 timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline --no-fp8 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('guard off:', d['value'], d['ms_per_step'])" > gpurun_out/prof/${R}_guard_ab.txt
+timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline --no-fp8 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('guard on: ', d['value'], d['ms_per_step'])" >> gpurun_out/prof/${R}_guard_ab.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline --no-fp8 > /dev/null 2>&1
 cp $(find /tmp/prof_bench -name "*kernel_stats.csv" | head -1) gpurun_out/prof/${R}_bench_kernel_stats.csv
-S6D_BENCH_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_serial -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline > /dev/null 2>&1
+S6D_BENCH_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_serial -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline --no-fp8 > /dev/null 2>&1
 cp $(find /tmp/prof_serial -name "*kernel_stats.csv" | head -1) gpurun_out/prof/${R}_bench_serial_kernel_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_fp8 -o bench -- python bench.py --config fp8 --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline > /dev/null 2>&1
-cp $(find /tmp/prof_fp8 -name "*kernel_stats.csv" | head -1) gpurun_out/prof/${R}_bench_fp8_kernel_stats.csv
+cat > /tmp/fd.py <<'PY'
+import json, os, sys, torch
+os.environ.setdefault("S6D_PEM_VIT_DTYPE", "fp16")           # as bench.py runs the whole-frame block
+sys.path.insert(0, "tools")
+import frame_demo
+print(json.dumps(frame_demo.measure(torch.device("cuda", 0))))
+PY
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_fd -o fd -- python /tmp/fd.py > gpurun_out/prof/${R}_frame_demo.txt 2>/dev/null
+cp $(find /tmp/prof_fd -name "*kernel_stats.csv" | head -1) gpurun_out/prof/${R}_frame_demo_kernel_stats.csv
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d /tmp/pmc_s -o s -- python tools/pmc_kernels.py > /dev/null 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc_g -o g -- python tools/pmc_kernels.py > /dev/null 2>&1
 python tools/pmc_sq_summarise.py gpurun_out/prof/${R}_sq_summary.json /tmp/pmc_s /tmp/pmc_g > /dev/null 2>&1
 timeout 300 python tools/pem_ops_profile.py 32 2>/dev/null | grep -v "Warning\|warn" > gpurun_out/prof/${R}_pem_ops.txt
 timeout 600 python tools/run_sharded.py --frames 16 --group 8 --out gpurun_out/prof/${R}_sharded_world1.csv --fixed-time 0 2>/dev/null | tail -1 > gpurun_out/prof/${R}_sharded_world1.json
-cat gpurun_out/prof/${R}_gpu_suite.txt
-tail -c 2500 gpurun_out/prof/${R}_bench_line.json; tail -c 600 gpurun_out/prof/${R}_bench_fp8_line.json; cat gpurun_out/prof/${R}_sharded_world1.json
+cat gpurun_out/prof/${R}_gpu_suite.txt gpurun_out/prof/${R}_guard_ab.txt
+python - <<'PY'
+import json
+d = json.loads(open("gpurun_out/prof/r04_bench_line.json").read().strip().splitlines()[-1])
+print({k: d.get(k) for k in ("value", "ms_per_step", "stages_ms", "roofline", "extras_error")})
+print("fp8", {k: d.get("configs", {}).get("fp8", {}).get(k) for k in ("value", "ms_per_step", "error")})
+print("pipeline", d.get("pipeline"))
+print("cpu", d.get("cpu_baseline"))
+for k in d.get("kernels", []):
+    print(k["kernel"][:100], k["avg_ms"], k["frac"], k.get("pmc_key"))
+PY

@@ -9,11 +9,23 @@ import json
 import sys
 from collections import defaultdict
 
+# Template instances that tools/pmc_kernels.py launches at TWO shapes, in blocks of RUN launches (bench._event_ms: 1 + 10) that
+# alternate proj, lin2: their rows are split by dispatch order so that each shape gets its own traffic figure.
+RUN = 11
+SPLIT = {"gemm_bf16_kernel<2, true>": ("proj", "lin2")}
 out = defaultdict(lambda: defaultdict(list))
 for path in sys.argv[2:]:
     for f in glob.glob(path + "/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            out[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r.get("Dispatch_Id", 0)))
+        seen = defaultdict(int)
+        for r in rows:
+            k = r["Kernel_Name"]
+            base = k.split("s6d::")[1].split("(")[0] if "s6d::" in k else None
+            if base in SPLIT:
+                i = seen[(k, r["Counter_Name"])]
+                seen[(k, r["Counter_Name"])] += 1
+                k = k.replace(base, base + " [" + SPLIT[base][(i // RUN) % len(SPLIT[base])] + "]")
+            out[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 summary = {}
 for k, c in out.items():
     if "s6d::" not in k:

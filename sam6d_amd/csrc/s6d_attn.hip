@@ -101,6 +101,9 @@ __device__ __forceinline__ const u16 *qkv_at(const AttnParams &p, size_t tok, in
 #define S6D_ATTN_ABLATE 0
 #endif
 constexpr int kAbl = S6D_ATTN_ABLATE;
+#ifndef S6D_PT_VPRE
+#define S6D_PT_VPRE 0                // process_tile: V fragments of a tile requested in front of the softmax (1: pinned there, 2: free)
+#endif
 // Global-attention layout / schedule switches (defaults = what is measured fastest; tools/attn_variants.sh builds the others):
 //   S6D_GLB_KSWZ  K image rows whose (row >> 2 ^ row >> 3) & 1 is set keep their 16-byte chunks pairwise swapped: with an odd row
 //                 stride (13 chunks) the two row sets of a ds_read_b128 lane group ({0-3,12-15} reading chunk g, {4-11} reading
@@ -262,6 +265,24 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
   }
   union PB { bf16x8 v; u16 h[8]; };
   PB pb[NS][2];
+  // S6D_PT_VPRE: every V fragment of the tile is requested HERE, in front of the softmax arithmetic, instead of two at a time in
+  // front of the matrix instruction that consumes them (as written below the compiler emits read, read, s_waitcnt lgkmcnt(0),
+  // MFMA for every d tile: ten exposed LDS round trips per tile at two waves per SIMD).  2 x DT fragments = 32 (head dim 64) /
+  // 40 (80) VGPRs; the arithmetic and its order are unchanged.
+  union VA { bf16x8 v; s16x4 q[2]; };
+  VA vpre[S6D_PT_VPRE ? 2 : 1][S6D_PT_VPRE ? C::DT : 1];
+  if (S6D_PT_VPRE && !(kAbl & 8)) {
+#pragma unroll
+    for (int j = 0; j < (SUBS + 1) / 2; ++j) {
+      const u16 *vrow = Vl + (32 * j + g * 4 + (c >> 2)) * C::VROW + (c & 3) * 4;
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) {
+        vpre[j][dt].q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + dt * 16));
+        vpre[j][dt].q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + 16 * C::VROW + dt * 16));
+      }
+    }
+    if (S6D_PT_VPRE == 1) __builtin_amdgcn_sched_barrier(0);       // keep the requests in front of the exponentials (2: let the scheduler place them)
+  }
   if (PRIO) __builtin_amdgcn_s_setprio(0);
   if (kAbl & 4) {                                          // ablation: no softmax arithmetic
 #pragma unroll
@@ -335,9 +356,13 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
     for (int n = 0; n < NS; ++n) st.lacc[n] = S6D_ATTN_MFMA16(ones.v, pb[n][j].v, st.lacc[n]);
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) {
-      union { bf16x8 v; s16x4 q[2]; } va;
-      va.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + dt * 16));
-      va.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + 16 * C::VROW + dt * 16));
+      VA va;
+      if (S6D_PT_VPRE) {
+        va = vpre[j][dt];
+      } else {
+        va.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + dt * 16));
+        va.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + 16 * C::VROW + dt * 16));
+      }
 #pragma unroll
       for (int n = 0; n < NS; ++n)
         st.oacc[n][dt] = S6D_ATTN_MFMA16(va.v, pb[n][j].v, st.oacc[n][dt]);

@@ -101,6 +101,9 @@ __device__ __forceinline__ const u16 *qkv_at(const AttnParams &p, size_t tok, in
 #define S6D_ATTN_ABLATE 0
 #endif
 constexpr int kAbl = S6D_ATTN_ABLATE;
+#ifndef S6D_PT_KPRE
+#define S6D_PT_KPRE 0                // process_tile: K fragments double-buffered one sub-tile ahead
+#endif
 #ifndef S6D_PT_VPRE
 #define S6D_PT_VPRE 0                // process_tile: V fragments of a tile requested in front of the softmax (1: pinned there, 2: free)
 #endif
@@ -225,6 +228,16 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
   const int gk = KSWZ ? (g ^ kswz(c)) : g;               // chunk of this lane's K fragment inside its group of 4 (see S6D_GLB_KSWZ)
   float s[NS][4][4];
   if (PRIO) __builtin_amdgcn_s_setprio(1);
+  // S6D_PT_KPRE: the K fragments of sub-tile s + 1 are requested in front of the matrix instructions of sub-tile s (two register
+  // sets, KS x 4 VGPRs more) instead of each fragment in front of its own instruction
+  bf16x8 kpre[S6D_PT_KPRE ? 2 : 1][S6D_PT_KPRE ? C::KS : 1];
+  auto kfrag = [&](int sub, int ks) __attribute__((always_inline)) {
+    return *reinterpret_cast<const bf16x8 *>(Kl + (sub * 16 + c) * C::KROW + ks * 32 + gk * 8);
+  };
+  if (S6D_PT_KPRE && !(kAbl & 16)) {
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) kpre[0][ks] = kfrag(0, ks);
+  }
 #pragma unroll
   for (int sub = 0; sub < 4; ++sub) {
     f32x4 acc[NS];
@@ -238,9 +251,13 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
       continue;
     }
     if (!(kAbl & 16)) {
+      if (S6D_PT_KPRE && sub + 1 < SUBS) {
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) kpre[(sub + 1) & 1][ks] = kfrag(sub + 1, ks);
+      }
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(Kl + (sub * 16 + c) * C::KROW + ks * 32 + gk * 8);
+        const bf16x8 a = S6D_PT_KPRE ? kpre[sub & 1][ks] : kfrag(sub, ks);
 #pragma unroll
         for (int n = 0; n < NS; ++n) acc[n] = S6D_ATTN_MFMA16(a, st.qf[n][ks], acc[n]);
       }

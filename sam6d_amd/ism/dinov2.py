@@ -207,6 +207,8 @@ class DinoVisionTransformer(nn.Module):
         C = x.shape[-1]
         exact_gelu = all(isinstance(blk.mlp.act, nn.GELU) and blk.mlp.act.approximate == "none" for blk in self.blocks)
         rows = x.numel() // C
+        if os.environ.get("S6D_DINO_GEMM", "bf16") == "fp8":
+            return self._blocks_fp8(x, scale, exact_gelu)
         if (exact_gelu and C % 256 == 0 and all(lnfold_eligible(x, C, C) and lnfold_eligible(x, blk.mlp.fc1.out_features, C) and
                                                 lnfold_eligible(x, C, blk.mlp.fc1.out_features) for blk in self.blocks)
                 and rows <= ops.gemm_one_launch_rows(max(3 * C, max(blk.mlp.fc1.out_features for blk in self.blocks)))):
@@ -265,6 +267,37 @@ class DinoVisionTransformer(nn.Module):
                 delta = F.linear(blk.mlp.act(blk.mlp.fc1(h)), w2, b2)
         g, b = _ln_f32(self.norm)
         return ops.add_layernorm(x, delta, g, b, self.norm.eps)
+
+    def _blocks_fp8(self, x, scale, exact_gelu):
+        """BASELINE configs[4] for the descriptor ViT (round 4; opt-in: S6D_DINO_GEMM=fp8, never the default): the two LayerNorm-fed
+        GEMMs of every block -- qkv and fc1 + GELU, 58 % of the block's GEMM FLOP -- on the fp8 matrix cores, exactly as the SAM
+        encoder's fp8 loop (sam/image_encoder.py::_blocks_fp8): LayerNorm writes e4m3 rows with one power-of-two scale per token
+        (s6d_layernorm_fp8), the weights carry one per output channel (utils/fp8.py), both ride in the matrix instruction's block
+        scales (s6d_gemm_fp8).  proj and fc2 (LayerScale folded in) stay bf16 with the residual add in their epilogue."""
+        from ..utils import fp8
+        C = x.shape[-1]
+        if not (exact_gelu and ops.have("gemm_fp8") and ops.have("layernorm_fp8") and ops.have("gemm_bf16_res") and x.is_cuda
+                and x.dtype == torch.bfloat16 and C % 256 == 0 and C <= 2048):
+            raise RuntimeError("S6D_DINO_GEMM=fp8 needs the fp8 kernels of libsam6d_hip.so, a bf16 device token stream, exact GELU "
+                               "and 256 | C <= 2048")
+        x = x.clone()
+        B, N, _ = x.shape
+        rows = B * N
+        x2 = x.view(rows, C)
+        for blk in self.blocks:
+            wp, bp, bpf, w2, b2, b2f = blk._folded(x.dtype)
+            g, b = _ln_f32(blk.norm1)
+            h8, hs = ops.layernorm_fp8(x2, g, b, blk.norm1.eps)
+            wq, ws, bq = fp8.cached_weight(blk.attn.qkv)
+            qkv = ops.gemm_fp8(h8, hs, wq, ws, bq).view(B, N, 3 * C)
+            o = ops.seq_attention(qkv, blk.attn.num_heads, scale)
+            ops.gemm_bf16(o.reshape(rows, C), wp, bpf, residual=x2, out=x2)
+            g, b = _ln_f32(blk.norm2)
+            h8, hs = ops.layernorm_fp8(x2, g, b, blk.norm2.eps)
+            w1, s1, b1 = fp8.cached_weight(blk.mlp.fc1)
+            ops.gemm_bf16(ops.gemm_fp8(h8, hs, w1, s1, b1, gelu=True), w2, b2f, residual=x2, out=x2)
+        g, b = _ln_f32(self.norm)
+        return ops.add_layernorm(x, None, g, b, self.norm.eps)
 
     def forward_features(self, x, masks=None):
         dt = _dtype() if x.is_cuda else torch.float32

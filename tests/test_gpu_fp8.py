@@ -131,3 +131,53 @@ def test_vit_h_fp8_accuracy_gate(monkeypatch):
         assert rel[k] <= E_BLOCK_FP8 * (k + 1) ** 0.5, rel
     assert rel["neck"] <= E_BLOCK_FP8 * 33 ** 0.5, rel
     assert iou.mean() >= 0.95, (iou.mean().item(), iou.min().item())
+
+
+def test_vit_l14_fp8_accuracy_gate(monkeypatch):
+    """configs[4] for the descriptor ViT (round 4, S6D_DINO_GEMM=fp8): qkv / fc1 of every DINOv2 block on the fp8 matrix cores.
+    Part 1: the residual stream after 24 blocks against the SAME model in fp32 within the per-block fp8 budget in quadrature.
+    Part 2, at the level of DECISIONS, on the proposals of tests/golden/frame_e2e.npz: descriptors' cosine to the fp32 ones, and
+    what the scoring stage makes of them -- the selection and the object decision must not move; template flips and the final
+    score's shift are recorded and bounded."""
+    import ast
+    from types import SimpleNamespace
+
+    import numpy as np
+
+    from sam6d_amd.ism import dinov2 as pd
+    from sam6d_amd.utils import seeded
+    from tests import test_gpu_zz_frame_e2e as E
+    from tests import util
+    g, c = E._case()
+    fi, poses = E._extra(c)
+    o = E._descriptor_model(c)
+    K = g["sam_boxes"].shape[0]
+    want = torch.from_numpy(np.unpackbits(g["sam_masks"], axis=1)[:, :480 * 640].reshape(K, 480, 640).astype(bool))
+    masks = torch.cat([want.float(), fi["masks"]]).cuda()
+    boxes = torch.cat([torch.from_numpy(g["sam_boxes"]).float(), fi["boxes"]]).cuda()
+    rgbs, _ = o._crops(fi["rgb"], masks, boxes, True, True)
+    out = {}
+    for name, env in (("fp32", dict(S6D_DINO_DTYPE="fp32", S6D_DINO_GEMM="bf16")), ("fp8", dict(S6D_DINO_DTYPE="bf16", S6D_DINO_GEMM="fp8"))):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with torch.no_grad():
+            stream = o.model.forward_features(rgbs[:8])["x_prenorm"].float()
+            cls, patch = o.forward(fi["rgb"], SimpleNamespace(masks=masks, boxes=boxes))
+        out[name] = (stream, cls.float(), E._score(E._scorer(g, c, poses, fi), cls.float(), patch.float(), masks, boxes, fi))
+    monkeypatch.setenv("S6D_DINO_GEMM", "bf16")
+    s32, c32, r32 = out["fp32"]
+    s8, c8, r8 = out["fp8"]
+    rel = ((s8 - s32).pow(2).mean().sqrt() / s32.pow(2).mean().sqrt()).item()
+    cos = torch.nn.functional.cosine_similarity(c32, c8, dim=1)
+    same_sel = r32["sel"].tolist() == r8["sel"].tolist()
+    n = min(len(r32["sel"]), len(r8["sel"]))
+    obj = (r32["pred_obj"][:n] != r8["pred_obj"][:n]).float().mean().item() if same_sel else 1.0
+    tpl = (r32["best_template"][:n] != r8["best_template"][:n]).float().mean().item() if same_sel else 1.0
+    dfin = (r32["final"][:n] - r8["final"][:n]).abs().max().item() if same_sel else float("nan")
+    util.record_margin("vit_l14_fp8_gate", stream_rel_24=rel, cls_cos_min=cos.min().item(), same_sel=same_sel, pred_obj_flip_rate=obj,
+                       best_template_flip_rate=tpl, final_score_diff_max=dfin)
+    # measured in round 4 (profiles/r04_parity_margins_fp8_dino.jsonl): stream 3.3e-2 off after 24 blocks, cosine >= 0.9981, the same 26
+    # proposals selected, no object and no template decision flipped, final scores within 1.3e-3
+    assert rel <= E_BLOCK_FP8 * 25 ** 0.5, rel
+    assert cos.min() > 0.996 and same_sel and obj == 0.0, (cos.min().item(), same_sel, obj)
+    assert tpl <= 1 / 26 + 1e-9 and dfin < 3e-3, (tpl, dfin)

@@ -612,13 +612,14 @@ def _extras(extra, hp, dev, args, world):
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import frame_demo
             extra["pipeline"] = frame_demo.measure(dev)
+            built = extra["pipeline"].pop("_built")
             if isinstance(extra.get("configs", {}).get("fp8"), dict) and "error" not in extra["configs"]["fp8"]:
                 # the same whole frame in the fp8 configuration: SAM ViT-H AND DINOv2 ViT-L qkv / lin1 (fc1) on the fp8 matrix cores
                 old = {k: os.environ.get(k) for k in ("S6D_SAM_GEMM", "S6D_DINO_GEMM")}
                 os.environ.update(S6D_SAM_GEMM="fp8", S6D_DINO_GEMM="fp8")
                 try:
                     torch.cuda.empty_cache()
-                    pf = frame_demo.measure(dev)
+                    pf = frame_demo.measure(dev, built=built)
                     extra["configs"]["fp8"]["pipeline"] = {k: pf[k] for k in ("frames_per_s", "ms_per_frame", "ms_per_frame_in_groups_of_8", "stages_ms")}
                 finally:
                     for k, v in old.items():

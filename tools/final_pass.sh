@@ -25,7 +25,9 @@ import json, os, sys, torch
 os.environ.setdefault("S6D_PEM_VIT_DTYPE", "fp16")           # as bench.py runs the whole-frame block
 sys.path.insert(0, "tools")
 import frame_demo
-print(json.dumps(frame_demo.measure(torch.device("cuda", 0))))
+d = frame_demo.measure(torch.device("cuda", 0))
+d.pop("_built", None)
+print(json.dumps(d))
 PY
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_fd -o fd -- python /tmp/fd.py > gpurun_out/prof/${R}_frame_demo.txt 2>/dev/null
 cp $(find /tmp/prof_fd -name "*kernel_stats.csv" | head -1) gpurun_out/prof/${R}_frame_demo_kernel_stats.csv

@@ -741,6 +741,12 @@ def main():
 
     ms_step = dt / args.steps * 1e3
     value = world * args.frames * args.steps / dt
+    if dist is not None:
+        # the process group ends HERE, with every rank present: rank 0 goes on alone into minutes of side measurements, and a
+        # destroy_process_group issued after the other ranks have exited may wait on them
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
 
     # stage breakdown + roofline of the dominant stage (rank 0 only; outside the timed region)
     extra = {}
@@ -776,8 +782,6 @@ def main():
             line["data"], line["dtype"] = "stand-in", "-"
         line.update(extra)
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

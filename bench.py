@@ -300,7 +300,7 @@ def kernel_rooflines(dev, sam_chunk, frames, in_step=None):
     nh, hd, H = 16, 80, 64
     qkv = torch.randn(sam_chunk, H, H, 3 * nh * hd, generator=g).to(dev).to(torch.bfloat16)
     bias = torch.randn(3 * nh * hd, generator=g).to(dev).to(torch.bfloat16)
-    for name, ws, S in (("attn_global64_kernel<80,8,3>", 0, 64), ("attn_window16p_kernel<80>", 14, 14)):
+    for name, ws, S in (("attn_global64_kernel<80,8,3>", 0, 64), ("attn_window16p_kernel<80, true>", 14, 14)):
         rh = torch.randn(2 * S - 1, hd, generator=g).to(dev).to(torch.bfloat16)
         rw = torch.randn(2 * S - 1, hd, generator=g).to(dev).to(torch.bfloat16)
         ms = _event_ms(lambda: ops.window_attention(qkv, bias, rh, rw, nh, ws, hd ** -0.5), 10)

@@ -991,7 +991,11 @@ __device__ const uint4 g_win16_zero = {0u, 0u, 0u, 0u};
 #endif
 #define S6D_ATTN_GLOBAL(T) __attribute__((address_space(1))) T
 
-template <int HD>
+// S14: the kernel is instantiated once for 14 x 14 windows (the ViT-H configuration: every key row exists, win16_pass<.., 14, true>)
+// and once for the other sizes (win16_pass<.., 16, false>).  As ONE kernel holding both passes it needed 256 VGPRs + 21 spilled
+// registers, stored to scratch for every item on either path; the 14 x 14 instantiation alone takes 239 VGPRs and no scratch
+// (round 4: tools/kernel_resources.py).
+template <int HD, bool S14>
 __global__ __launch_bounds__(512) void attn_window16p_kernel(AttnParams p, int nitems) {
   using C = Cfg<HD>;
   constexpr int WAVES = 8;
@@ -1097,7 +1101,7 @@ __global__ __launch_bounds__(512) void attn_window16p_kernel(AttnParams p, int n
       if (more) load_q(nxt);
     };
     const bf16x8 (&q2)[2][C::KS] = reinterpret_cast<const bf16x8 (&)[2][C::KS]>(qfa[0]);
-    if (S == 14)
+    if (S14)
       win16_pass<HD, 2, 14, true, KROWT, S6D_WIN16_KSWZ != 0>(p, Kl, Vl, S, SR, cur.b, cur.wy, cur.wx, cur.head, wave, WAVES, q2, twr, thv, lane, mid);
     else
       win16_pass<HD, 2, 16, false, KROWT, S6D_WIN16_KSWZ != 0>(p, Kl, Vl, S, SR, cur.b, cur.wy, cur.wx, cur.head, wave, WAVES, q2, twr, thv, lane, mid);
@@ -1601,9 +1605,15 @@ static int launch_attn(AttnParams p, hipStream_t st) {
         const char *ge = getenv("S6D_WIN16_GRID");                // tests: fewer workgroups than items without a big problem
         if (ge && atoi(ge) > 0 && atoi(ge) < grid) grid = atoi(ge);
         if (grid >= 8) grid &= ~7;                                // whole XCD rounds: workgroup j keeps to XCD j % 8, like its items
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_window16p_kernel<HD>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((attn_window16p_kernel<HD>), dim3(grid), dim3(512), lds, st, p, nitems);
+        if (p.S == 14) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_window16p_kernel<HD, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          hipLaunchKernelGGL((attn_window16p_kernel<HD, true>), dim3(grid), dim3(512), lds, st, p, nitems);
+        } else {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_window16p_kernel<HD, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          hipLaunchKernelGGL((attn_window16p_kernel<HD, false>), dim3(grid), dim3(512), lds, st, p, nitems);
+        }
         return launch_status();
       }
     }

@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_STEP)
     ap.add_argument("--sam-chunk", type=int, default=int(os.environ.get("S6D_SAM_CHUNK", str(SAM_CHUNK))))
-    ap.add_argument("--config", choices=("lmo", "fp8"), default="lmo",
+    ap.add_argument("--config", choices=("lmo", "fp8", "fp8mx"), default="lmo",
                     help="lmo = BASELINE configs[1] (the headline: bf16 ViTs); fp8 = the fp8 ViT-H MFMA path of configs[4] on the same "
                          "workload (qkv / lin1 GEMMs of the SAM encoder on the fp8 matrix cores) -- its own line, never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -273,12 +273,29 @@ def gemm_ms_inside_the_step(hp):
         e1.record()
         rec.append((("fp8", a8.numel() // a8.shape[-1], a8.shape[-1], w8.shape[0], bool(gelu)), e0, e1))
         return y
+    real_gm, real_mx = ops.gemm_fp8_gelu_mx, ops.gemm_fp8_mxa
+
+    def timed_gm(a8, sa, w8, sw, bias=None, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = real_gm(a8, sa, w8, sw, bias, **kw)
+        e1.record()
+        rec.append((("fp8_gelu_mx", a8.numel() // a8.shape[-1], a8.shape[-1], w8.shape[0], True), e0, e1))
+        return y
+
+    def timed_mx(a8, amx, w8, sw, bias=None, gelu=False, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = real_mx(a8, amx, w8, sw, bias, gelu=gelu, **kw)
+        e1.record()
+        rec.append((("fp8_mxa", a8.numel() // a8.shape[-1], a8.shape[-1], w8.shape[0], bool(gelu)), e0, e1))
+        return y
     hp.sam_stage()                                          # warm
-    ops.gemm_bf16, ops.gemm_fp8, ops.gemm_bf16_lnfold = timed, timed8, timed_f
+    ops.gemm_bf16, ops.gemm_fp8, ops.gemm_bf16_lnfold, ops.gemm_fp8_gelu_mx, ops.gemm_fp8_mxa = timed, timed8, timed_f, timed_gm, timed_mx
     try:
         hp.sam_stage()
     finally:
-        ops.gemm_bf16, ops.gemm_fp8, ops.gemm_bf16_lnfold = real, real8, real_f
+        ops.gemm_bf16, ops.gemm_fp8, ops.gemm_bf16_lnfold, ops.gemm_fp8_gelu_mx, ops.gemm_fp8_mxa = real, real8, real_f, real_gm, real_mx
     torch.cuda.synchronize()
     by = {}
     for key, e0, e1 in rec:
@@ -382,7 +399,7 @@ def kernel_rooflines(dev, sam_chunk, frames, in_step=None):
     if in_step:
         folded = any(k[0] == "lnfold" for k in in_step)
     else:
-        folded = lnfold_eligible(xe, 1280, 1280) and os.environ.get("S6D_SAM_GEMM") != "fp8"   # (the fp8 loop does not fold)
+        folded = lnfold_eligible(xe, 1280, 1280) and not os.environ.get("S6D_SAM_GEMM", "").startswith("fp8")   # (the fp8 loop does not fold)
     for nm, K, N, gelu in (("qkv", 1280, 3840, False), ("proj", 1280, 1280, False), ("lin1+gelu", 1280, 5120, True),
                            ("lin2", 5120, 1280, False)):
         x = torch.randn(M, K, generator=g).to(dev).to(torch.bfloat16)
@@ -422,7 +439,7 @@ def kernel_rooflines(dev, sam_chunk, frames, in_step=None):
                     # tools/pmc_summarise.py)
                     "pmc_key": inst if (gelu or form == "lnfold") else (f"{inst} [{nm}]" if form == "res" else "-"), "form": form,
                     "shape": nm})
-    if os.environ.get("S6D_SAM_GEMM") == "fp8" and ops.have("gemm_fp8"):
+    if os.environ.get("S6D_SAM_GEMM", "").startswith("fp8") and ops.have("gemm_fp8"):
         # configs[4]: the two LayerNorm-fed GEMMs on the fp8 matrix cores (dense peak 5 PFLOP/s), and the quantising LayerNorm
         from sam6d_amd.utils import fp8
         for nm, K, N, gelu in (("qkv", 1280, 3840, False), ("lin1+gelu", 1280, 5120, True)):
@@ -438,6 +455,32 @@ def kernel_rooflines(dev, sam_chunk, frames, in_step=None):
                         "frac": round(flop / ms / 1e9 / 5000.0, 4), "avg_ms": round(ms, 4), "back_to_back_ms": round(b2b, 4),
                         "timed": "inside one SAM stage pass" if ms is not b2b else "back to back", "launches_per_step": 32 * groups,
                         "algorithmic_bytes": 1.0 * (M * K + N * K) + 2.0 * M * N, "pmc_key": "gemm_fp8_kernel<1, true>" if gelu else "-"})
+        if os.environ.get("S6D_SAM_GEMM") == "fp8mx" and ops.have("gemm_fp8_mx"):
+            # lin1 with the MX output, lin2 with MX activations (round 4)
+            qa, sa = fp8.quantize_rows(torch.randn(M, 1280, generator=g).to(dev))
+            qw, sw = fp8.quantize_rows((torch.randn(5120, 1280, generator=g) / 1280 ** 0.5).to(dev))
+            b1 = torch.randn(5120, generator=g).to(dev)
+            b2b = _event_ms(lambda: ops.gemm_fp8_gelu_mx(qa, sa, qw, sw, b1), 10)
+            key = ("fp8_gelu_mx", M, 1280, 5120, True)
+            ms = in_step[key][0] if in_step and key in in_step else b2b
+            flop = 2.0 * M * 5120 * 1280
+            out.append({"kernel": f"gemm_fp8_kernel<5, true> (lin1 + GELU -> e4m3 with MX block scales, M={M} K=1280 N=5120)", "bound": "mfma",
+                        "achieved": round(flop / ms / 1e9, 1), "peak": 5000.0, "unit": "TFLOP/s (fp8 e4m3)", "frac": round(flop / ms / 1e9 / 5000.0, 4),
+                        "avg_ms": round(ms, 4), "back_to_back_ms": round(b2b, 4), "launches_per_step": 32 * groups,
+                        "algorithmic_bytes": 1.0 * (M * 1280 + 5120 * 1280) + 1.0 * M * 5120 + M * 160.0, "pmc_key": "gemm_fp8_kernel<5, true>"})
+            q8, qs = ops.gemm_fp8_gelu_mx(qa, sa, qw, sw, b1)
+            qw2, sw2 = fp8.quantize_rows((torch.randn(1280, 5120, generator=g) / 5120 ** 0.5).to(dev))
+            bb2 = torch.randn(1280, generator=g).to(dev)
+            b2b = _event_ms(lambda: ops.gemm_fp8_mxa(q8, qs, qw2, sw2, bb2), 10)
+            key = ("fp8_mxa", M, 5120, 1280, False)
+            ms = in_step[key][0] if in_step and key in in_step else b2b
+            out.append({"kernel": f"gemm_fp8mx_kernel<0, true> (lin2, MX activations, M={M} K=5120 N=1280)", "bound": "mfma",
+                        "achieved": round(flop / ms / 1e9, 1), "peak": 5000.0, "unit": "TFLOP/s (fp8 e4m3)", "frac": round(flop / ms / 1e9 / 5000.0, 4),
+                        "avg_ms": round(ms, 4), "back_to_back_ms": round(b2b, 4), "launches_per_step": 32 * groups,
+                        "algorithmic_bytes": 1.0 * (M * 5120 + 1280 * 5120) + M * 160.0 + 2.0 * M * 1280, "pmc_key": "gemm_fp8mx_kernel<0, true>"})
+            for r in out:                                                   # lin1's bf16-output fp8 form and the bf16 lin2 are off the path here
+                if r["kernel"].startswith("gemm_fp8_kernel (lin1+gelu") or (r["kernel"].startswith("gemm_bf16_kernel") and r.get("shape") == "lin2"):
+                    r["launches_per_step"] = 0
         xb = torch.randn(M, 1280, generator=g).to(dev).to(torch.bfloat16)
         gm, bt = torch.ones(1280, device=dev), torch.zeros(1280, device=dev)
         ms = _event_ms(lambda: ops.layernorm_fp8(xb, gm, bt, 1e-6), 10)
@@ -524,12 +567,12 @@ def cpu_baseline():
                       f"({t_pem:.2f}s/instance; runs {'/'.join(f'{t / 2:.2f}' for t in pem_runs)}), fp32 torch CPU oracle"}
 
 
-def fp8_config(hp, dev, args):
+def fp8_config(hp, dev, args, mode="fp8"):
     from sam6d_amd import ops
-    if not (ops.have("gemm_fp8") and ops.have("layernorm_fp8")):
+    if not (ops.have("gemm_fp8") and ops.have("layernorm_fp8")) or (mode == "fp8mx" and not ops.have("gemm_fp8_mx")):
         return {"error": "fp8 kernels not in the library"}
     old = os.environ.get("S6D_SAM_GEMM")
-    os.environ["S6D_SAM_GEMM"] = "fp8"
+    os.environ["S6D_SAM_GEMM"] = mode
     try:
         for _ in range(max(1, args.warmup)):
             hp.step()
@@ -541,12 +584,13 @@ def fp8_config(hp, dev, args):
         dt = time.perf_counter() - t0
         sam_ms = stage_ms(hp.sam_stage, 1)
         kr = [k for k in kernel_rooflines(dev, args.sam_chunk, args.frames, gemm_ms_inside_the_step(hp))
-              if k["kernel"].startswith(("gemm_fp8", "layernorm_fp8")) or (k["kernel"].startswith("gemm_bf16") and k["launches_per_step"])]
+              if (k["kernel"].startswith(("gemm_fp8", "layernorm_fp8")) or k["kernel"].startswith("gemm_bf16")) and k["launches_per_step"]]
         dom = max((k for k in kr if k["kernel"].startswith("gemm_fp8")), key=lambda k: k["avg_ms"] * k["launches_per_step"])
         return {"headline": False, "workload": "BASELINE configs[4] 'fp8 ViT-H MFMA path' on the configs[1] workload (same frames, same stages)",
                 "value": round(args.frames * args.steps / dt, 3), "unit": "frames/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
-                "steps": args.steps, "dtype": "fp8 e4m3 operands / f32 accumulation: SAM ViT-H qkv, proj, lin1, lin2 where the block loop "
-                                              "quantises them (sam/image_encoder.py::_blocks_fp8); everything else as the headline",
+                "steps": args.steps, "dtype": ("fp8 e4m3 operands / f32 accumulation: SAM ViT-H qkv and lin1 (per-token / per-channel power-of-two "
+                                              "scales)" + (", lin2 on lin1's MX-scaled e4m3 output (one E8M0 scale per token and 32 channels)"
+                                                           if mode == "fp8mx" else "") + "; proj, attention and everything else as the headline"),
                 "sam_encoder_ms": round(sam_ms, 2),
                 "roofline": {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["achieved"], "peak": dom["peak"],
                              "unit": dom["unit"], "frac": dom["frac"], "avg_launch_ms": dom["avg_ms"], "traffic": _pmc_traffic(dom),
@@ -594,15 +638,17 @@ def _extras(extra, hp, dev, args, world):
     extra["stage_roofline"] = {"stage": f"SAM ViT-H encoder, {args.frames} frames (bf16 GEMMs + fused attention)",
                                "bound": "mfma", "achieved": round(achieved / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12,
                                "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK, 4)}
-    if world == 1 and args.config != "fp8" and not args.no_fp8:
+    if world == 1 and args.config == "lmo" and not args.no_fp8:
         # BASELINE configs[4] ("fp8 ViT-H MFMA path") measured by THIS run, next to the headline and never as it (VERDICT r3 item 8:
         # every fp8 number had been builder-run): the same HotPath with the SAM encoder's GEMMs switched to the fp8 matrix cores,
         # the same timing protocol (warm-up steps, then `steps` steps between device synchronisations), its own roofline row
         # against the 5 PFLOP/s dense fp8 peak.
-        try:
-            extra["configs"] = {"fp8": fp8_config(hp, dev, args)}
-        except Exception as e:  # noqa: BLE001
-            extra["configs"] = {"fp8": {"error": f"{type(e).__name__}: {e}"}}
+        extra["configs"] = {}
+        for mode in ("fp8", "fp8mx"):                      # fp8: qkv + lin1 (round 3);  fp8mx: + lin2 through MX block scales (round 4)
+            try:
+                extra["configs"][mode] = fp8_config(hp, dev, args, mode)
+            except Exception as e:  # noqa: BLE001
+                extra["configs"][mode] = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and not args.no_pipeline:
         # what a whole frame costs: every stage of the chain incl. mask decoding, DINOv2 descriptors and the PEM
         # pre-processing, K = 10 instances per frame; outside the timed region, reported next to the headline
@@ -613,14 +659,15 @@ def _extras(extra, hp, dev, args, world):
             import frame_demo
             extra["pipeline"] = frame_demo.measure(dev)
             built = extra["pipeline"].pop("_built")
-            if isinstance(extra.get("configs", {}).get("fp8"), dict) and "error" not in extra["configs"]["fp8"]:
-                # the same whole frame in the fp8 configuration: SAM ViT-H AND DINOv2 ViT-L qkv / lin1 (fc1) on the fp8 matrix cores
+            best = "fp8mx" if "error" not in extra.get("configs", {}).get("fp8mx", {"error": 1}) else "fp8"
+            if isinstance(extra.get("configs", {}).get(best), dict) and "error" not in extra["configs"][best]:
+                # the same whole frame in the fp8 configuration: SAM ViT-H (fp8mx when built) AND DINOv2 ViT-L qkv / fc1 on the fp8 cores
                 old = {k: os.environ.get(k) for k in ("S6D_SAM_GEMM", "S6D_DINO_GEMM")}
-                os.environ.update(S6D_SAM_GEMM="fp8", S6D_DINO_GEMM="fp8")
+                os.environ.update(S6D_SAM_GEMM=best, S6D_DINO_GEMM="fp8")
                 try:
                     torch.cuda.empty_cache()
                     pf = frame_demo.measure(dev, built=built)
-                    extra["configs"]["fp8"]["pipeline"] = {k: pf[k] for k in ("frames_per_s", "ms_per_frame", "ms_per_frame_in_groups_of_8", "stages_ms")}
+                    extra["configs"][best]["pipeline"] = {k: pf[k] for k in ("frames_per_s", "ms_per_frame", "ms_per_frame_in_groups_of_8", "stages_ms")}
                 finally:
                     for k, v in old.items():
                         os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
@@ -707,8 +754,8 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         assert dist.get_world_size() == args.gpus
 
-    if args.config == "fp8":
-        os.environ["S6D_SAM_GEMM"] = "fp8"
+    if args.config in ("fp8", "fp8mx"):
+        os.environ["S6D_SAM_GEMM"] = args.config
     hp = StandInPath(dev, args.frames, rank) if args.standin else HotPath(dev, args.frames, args.sam_chunk)
 
     def barrier():
@@ -771,7 +818,7 @@ def main():
                            "frames_per_step_per_gpu": args.frames, "sam_frames_per_launch_group": args.sam_chunk,
                            "pem_vit_dtype": os.environ.get("S6D_PEM_VIT_DTYPE", "fp32") + " (set by bench.py; the library default is fp32)",
                            "sharding": f"frames over {world} rank(s)"}}
-        if args.config == "fp8":
+        if args.config in ("fp8", "fp8mx"):
             line["dtype"] = ("fp8 e4m3 operands / f32 accumulation (SAM ViT-H qkv and lin1 GEMMs; per-token and per-output-channel "
                              "power-of-two scales) + bf16 (every other ViT op) + f32 (ISM scoring, PEM point transformer and pose solvers)")
             line["config"]["workload"] = ("BASELINE configs[4] 'fp8 ViT-H MFMA path' on the configs[1] workload (the FastSAM segmentor and "

@@ -30,7 +30,7 @@ extern "C" {
 
 /* Bumped whenever a signature in this header changes; the loader (sam6d_amd/_lib.py) refuses a library whose
  * s6d_version() differs from the header it was written against (a stale .so fails at load, not at a call). */
-#define S6D_ABI_VERSION 112
+#define S6D_ABI_VERSION 113
 int s6d_version(void);
 const char *s6d_strerror(int code);
 /* last HIP error string seen by this thread (empty if none) */
@@ -266,6 +266,19 @@ int s6d_gemm_bf16_lnfold(const void *A, long lda, const float *row_stats, const 
  * local.yaml:9, Lightning precision 16); the Linear statements are those of s6d_gemm_bf16. */
 int s6d_gemm_fp8(const void *A, long lda, const unsigned char *a_scale, const void *W, long ldw, const unsigned char *w_scale,
                  const float *bias, void *C, long ldc, int M, int N, int K, int epilogue, int max_blocks, void *stream);
+/* MX forms of the fp8 GEMM (round 4; BASELINE configs[4], lin1 -> lin2 of a ViT block without a bf16 round trip).
+ * s6d_gemm_fp8_gelu_mx: C8 = e4m3(GELU(A W^T + bias)) (M,N) bytes with row stride ldc BYTES (ldc % 16 == 0) + c_scale [M][N / 32]:
+ *   one E8M0 byte per row and 32 columns, scale = 2^e with the smallest e for which the block's amax / 2^e <= 448 (the rule of
+ *   s6d_layernorm_fp8, per block).  A / a_scale / W / w_scale / bias as s6d_gemm_fp8.
+ * s6d_gemm_fp8_mxa: A (M,K) e4m3 bytes with a_mx [M][K / 32] E8M0 bytes (what s6d_gemm_fp8_gelu_mx wrote; 4-byte aligned), W with
+ *   one scale per output channel -> act(A W^T + bias) (M,N) bf16.  M % 256 == 0, N % 256 == 0, K % 128 == 0.
+ * The matrix instruction (v_mfma_scale_f32_32x32x64_f8f6f4) applies a lane's scale byte to its own 32-k block and op_sel picks
+ * the byte: the MX scales ride in the hardware operand, the accumulators hold the true product. */
+int s6d_gemm_fp8_gelu_mx(const void *A, long lda, const unsigned char *a_scale, const void *W, long ldw, const unsigned char *w_scale,
+                         const float *bias, void *C8, long ldc, unsigned char *c_scale, int M, int N, int K, int max_blocks,
+                         void *stream);
+int s6d_gemm_fp8_mxa(const void *A, long lda, const unsigned char *a_mx, const void *W, long ldw, const unsigned char *w_scale,
+                     const float *bias, void *C, long ldc, int M, int N, int K, int epilogue, int max_blocks, void *stream);
 /* LayerNorm(x) (rows,C) bf16 -> fp8 e4m3 rows y8 (rows,C) + one E8M0 scale byte per row (the A operand of s6d_gemm_fp8):
  * fp32 statistics, scale 2^e with the smallest e for which amax / 2^e <= 448, round to nearest even.  C % 8 == 0, C <= 2048. */
 int s6d_layernorm_fp8(const void *x, const float *gamma, const float *beta, float eps, long rows, int C, void *y8,

@@ -126,6 +126,10 @@ struct GemmParams {
   const float *bias;  // (N) f32 or nullptr
   u16 *C;             // (M,N) bf16, row stride ldc
   const unsigned char *sa, *sw;   // fp8 operands (DT = 1): E8M0 scale byte of every A row (M) / W row (N); value = q * 2^(byte - 127)
+  const unsigned *sa_mx;          // MX form of the A operand (AMX; round 4): one E8M0 byte per row and 32-k block, [M][K / 32] bytes =
+                                  // [M][nk] dwords (a dword = the four blocks of one 128-byte K tile); sa is unused then
+  unsigned char *SC;              // EPI 5: the output is e4m3 bytes at C (row stride ldc BYTES) + one E8M0 byte per row and 32 columns
+                                  // here, [M][N / 32] -- the MX A operand of the next GEMM
   const u16 *R;       // EPI 2: residual (M,N) bf16, row stride ldr2 BYTES; may be C itself (a tile's residual is read by the workgroup
                       // that stores the tile, one tile ahead of its stores)
   float *SP;          // EPI 2, optional: partial row statistics, [N / 32][2][M] floats (sum, sum of squared deviations per 32 columns)
@@ -183,8 +187,21 @@ __device__ __forceinline__ unsigned pack_f16(float lo, float hi) {
 template <int DT>
 __device__ __forceinline__ unsigned pack_out(float lo, float hi) { return DT == 2 ? pack_f16(lo, hi) : pack_bf16(lo, hi); }
 
-template <int EPI, bool HAS_BIAS, int DT>
+// AMX (DT = 1 only; round 4): the activations carry MX block scales -- one E8M0 byte per row and 32 k (GemmParams::sa_mx) instead of
+// one per row.  The matrix instruction takes exactly that: a lane's scale byte applies to its own 32-k block and op_sel picks the
+// byte of the scale VGPR (measured: tools/probes/mx_scale_probe.hip, mx_scale_probe2.hip: the byte of lanes 0-31 scales the FIRST 16
+// bytes of both lane halves, the byte of lanes 32-63 the second 16 -- hence the chunk map of the fragment reads below).  A K tile is
+// 128 bytes = four blocks = one dword of scales per row; lane half hb SUPPLIES the scales of blocks hb (first MFMA of the tile) and
+// 2 + hb (second), so the dword is shifted right by 8 hb once and the two instructions use op_sel 0 and 2.  The dword of K tile g + 1 is requested at the start of K tile g, in FRONT of that
+// phase's LDS-DMA issues: it is older than the eight DMA pieces the counted wait leaves in flight, so "K tile g + 1 has landed"
+// covers it and the counts stay as they are.  Rows past M are not clamped: M % 256 == 0 is required.
+// EPI 5 (DT = 1): C = e4m3(GELU(A W^T + bias)) with MX scales -- in the quad-transposed accumulator layout ONE lane holds a whole
+// 32-column block of its row (columns 32 h + {0..31} of the wave's 64), so the block maximum, the scale and the 32 bytes are
+// lane-local: no exchange, two 16-byte stores and one scale byte per lane and m tile.
+template <int EPI, bool HAS_BIAS, int DT, bool AMX = false>
 __device__ __forceinline__ void gemm_body(const GemmParams &p) {
+  static_assert(!AMX || DT == 1, "MX block scales belong to the fp8 operands");
+  static_assert(EPI != 5 || (DT == 1 && S6D_GEMM_QT), "the MX output is the fp8 kernel's, on the quad-transposed layout");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;       // M half / N quarter of the 256 x 256 tile
@@ -268,9 +285,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
     const int sw = (lane >> 1) & 7, hb = lane >> 5;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      // 16-byte chunk of the row this lane reads at step ks.  bf16: k step ks, k half hb.  fp8: MFMA ks >> 1 covers 64 bytes, this
-      // lane's 32 of them (k block hb) are chunks 2 hb, 2 hb + 1 of that half-row
-      const int cid = DT == 1 ? (4 * (ks >> 1) + 2 * hb + (ks & 1)) : ((2 * ks) | hb);
+      // 16-byte chunk of the row this lane reads at step ks.  bf16: k step ks, k half hb.  fp8: MFMA ks >> 1 covers 64 bytes = four
+      // chunks; the instruction's two 32-element SCALE blocks are (first 16 bytes of lanes 0-31, first 16 bytes of lanes 32-63) and
+      // (second 16 bytes of both), scaled by the byte of lanes 0-31 and of lanes 32-63 respectively (measured:
+      // tools/probes/mx_scale_probe2.hip) -- so for a scale block to be 32 CONSECUTIVE k (the MX format) lane half hb takes chunks
+      // hb and 2 + hb.  (Rounds 3's map, chunks 2 hb and 2 hb + 1, is equivalent only while both blocks of a row share one scale.)
+      const int cid = DT == 1 ? (4 * (ks >> 1) + hb + 2 * (ks & 1)) : ((2 * ks) | hb);
       foff[ks] = (unsigned)((lane & 31) * 128 + ((cid ^ sw) << 4));
     }
   }
@@ -289,7 +309,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int hb = lane >> 5;
-      const int cid = DT == 1 ? (4 * (ks >> 1) + 2 * hb + (ks & 1)) : ((2 * ks) | hb);
+      const int cid = DT == 1 ? (4 * (ks >> 1) + hb + 2 * (ks & 1)) : ((2 * ks) | hb);
       wfo[nt][ks] = brow + (unsigned)(row * 128 + ((cid ^ ((row >> 1) & 7)) << 4));
     }
   }
@@ -313,8 +333,34 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
       const int row = S6D_GEMM_QT ? 32 * ((a >> 2) & 1) + 16 * nt + 4 * (a >> 3) + (a & 3) : 32 * nt + a;
       wsc[nt] = (int)p.sw[n0 + wc * 64 + row];
     }
+    if (AMX) return;                                                     // the activation scales come per K tile (mx_issue)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) xsc[mt] = (int)p.sa[min(m0 + wr * 128 + mt * 32 + a, p.M - 1)];
+  };
+  // AMX: xsc[] holds the (shifted) scale dwords of the K tile being multiplied, xnx[] those of the next one (in flight or landed);
+  // the cursor walks the K tiles of this workgroup's stream like the DMA cursors do
+  int xnx[4] = {0, 0, 0, 0};
+  int mx_kt = 0, mx_tile = 0;
+  unsigned mx_row = 0;                                                   // dword index of (this lane's row of m tile 0, K tile 0) of the cursor's tile
+  auto mx_set = [&](int tile) __attribute__((always_inline)) {
+    int m0, n0;
+    tile_mn(tile, m0, n0);
+    mx_row = (unsigned)(m0 + wr * 128 + (lane & 31)) * (unsigned)p.nk;
+  };
+  auto mx_issue = [&]() __attribute__((always_inline)) {               // request the cursor's K tile into xnx[], advance the cursor
+    if (!AMX) return;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) xnx[mt] = (int)p.sa_mx[mx_row + (unsigned)(mt * 32 * p.nk) + (unsigned)mx_kt];
+    if (++mx_kt == p.nk) {
+      mx_kt = 0;
+      if (++mx_tile < my_tiles) mx_set(mx_tile);
+    }
+  };
+  auto mx_take = [&]() __attribute__((always_inline)) {                // xnx[] has landed: it becomes the current K tile's
+    if (!AMX) return;
+    const int sh = (lane >> 5) * 8;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) xsc[mt] = (int)((unsigned)xnx[mt] >> sh);
   };
   // EPI 3 / 4 (folded LayerNorm): rstd of this lane's row in strip mt, applied in the epilogue
   float ln_rs[4] = {1.f, 1.f, 1.f, 1.f};
@@ -344,7 +390,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
     const S6D_CONST(float) *cs = (const S6D_CONST(float) *)p.CS + nb;
     const bool hi = (lane >> 5) != 0;
     float ln_sig[4] = {0.f, 0.f, 0.f, 0.f}, ln_nmu[4] = {0.f, 0.f, 0.f, 0.f};
-    if (EPI >= 3) {
+    if ((EPI == 3 || EPI == 4)) {
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const int m = min(m0 + wr * 128 + mt * 32 + (lane & 31), p.M - 1);   // rows past M: a valid address, never stored
@@ -357,7 +403,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       // EPI 3 / 4: one n tile's 2 x 16 constants at a time (all 64 at once spill loop-invariant registers into the main loop)
-      if (EPI >= 3 && nt == 1) __builtin_amdgcn_sched_barrier(0);
+      if ((EPI == 3 || EPI == 4) && nt == 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
 #pragma unroll
@@ -366,7 +412,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
           const int c0 = S6D_GEMM_QT ? 16 * nt + 4 * qd + e : 32 * nt + 8 * qd + e;
           const int c1 = S6D_GEMM_QT ? c0 + 32 : c0 + 4;
           const float b = HAS_BIAS ? (hi ? bs[c1] : bs[c0]) : 0.f;
-          if (EPI >= 3) {
+          if ((EPI == 3 || EPI == 4)) {
             const float sn = hi ? cs[c1] : cs[c0];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) acc[mt][nt][4 * qd + e] = fmaf(ln_sig[mt], b, ln_nmu[mt] * sn);
@@ -430,6 +476,43 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
   // columns 32 h + 16 nt + 8 k ..); the 4 x 4 transpose inside each lane quad turns that into chunk (lane & 3) of the four rows
   // of the quad, i.e. a quad writes 64 contiguous bytes per instruction
   auto epilogue_qt = [&](int mt, int m0, int n0) __attribute__((always_inline)) {
+    if (EPI == 5) {
+      // GELU, then this lane's 32 columns (32 h + 16 nt + r, r = 0..15: acc[mt][0][*] then acc[mt][1][*]) as one MX block: the
+      // quantisation rule of s6d_layernorm_fp8 / utils/fp8.py per BLOCK -- scale 2^e with the smallest e for which amax / 2^e <= 448
+      float v[32], amax = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          v[16 * nt + r] = gelu_erf(acc[mt][nt][r]);
+          amax = fmaxf(amax, fabsf(v[16 * nt + r]));
+        }
+      int e2 = 0;
+      if (amax > 0.f) {
+        int ex;
+        const float f = frexpf(amax, &ex);                               // amax = f 2^ex, f in [0.5, 1): 512 f <= 448 iff f <= 0.875
+        e2 = ex - (f <= 0.875f ? 9 : 8);
+        e2 = min(max(e2, -127), 127);
+      }
+      const float inv = ldexpf(1.f, -e2);
+      unsigned q[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * i] * inv, v[4 * i + 1] * inv, w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * i + 2] * inv, v[4 * i + 3] * inv, w, true);
+        q[i] = (unsigned)w;
+      }
+      const int m = m0 + wr * 128 + mt * 32 + (lane & 31);
+      const int col = n0 + wc * 64 + 32 * (lane >> 5);
+      if (m < p.M) {
+        unsigned char *dst = reinterpret_cast<unsigned char *>(p.C) + (size_t)m * p.ldc + col;
+        *reinterpret_cast<uint4 *>(dst) = make_uint4(q[0], q[1], q[2], q[3]);
+        *reinterpret_cast<uint4 *>(dst + 16) = make_uint4(q[4], q[5], q[6], q[7]);
+        p.SC[(size_t)m * (p.N >> 5) + (col >> 5)] = (unsigned char)(e2 + 127);
+      }
+      return;
+    }
     if (EPI == 2 && p.SP) {
       // partial LayerNorm statistics of the row this lane owns over its 32 columns (32 h + {0..31} of the wave's 64): sum and the
       // sum of squared deviations from the group mean, of the fp32 results (the bf16 rounding of the stored values is zero-mean
@@ -463,7 +546,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
           float v0 = acc[mt][nt][8 * k + 2 * d], v1 = acc[mt][nt][8 * k + 2 * d + 1];
-          if (EPI >= 3) {
+          if ((EPI == 3 || EPI == 4)) {
             v0 *= ln_rs[mt];
             v1 *= ln_rs[mt];
           }
@@ -559,7 +642,14 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
     // A slot is restaged one phase after its last fragment read; that is safe because every load segment ends with lgkmcnt(0)
     // BEFORE its barrier (the reads are retired when the other wave group, one barrier apart, starts issuing into the slot), and
     // a landed K tile is read one phase (two barriers) after the wait that retired it.
-#define S6D_MFMA8(C, A, B, SA, SB) C = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, C, 0, 0, 0, SA, 0, SB)
+#define S6D_MFMA8(C, A, B, SA, SB, OPB) C = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, C, 0, 0, 0, SA, OPB, SB)
+#define S6D_MSEG2_H(QM, H, OPB)                                                        \
+  do {                                                                                 \
+    S6D_MFMA8(acc[2 * QM][0], wq[0][H], xq[0][H], wsc[0], xsc[2 * QM], OPB);           \
+    S6D_MFMA8(acc[2 * QM + 1][0], wq[0][H], xq[1][H], wsc[0], xsc[2 * QM + 1], OPB);   \
+    S6D_MFMA8(acc[2 * QM][1], wq[1][H], xq[0][H], wsc[1], xsc[2 * QM], OPB);           \
+    S6D_MFMA8(acc[2 * QM + 1][1], wq[1][H], xq[1][H], wsc[1], xsc[2 * QM + 1], OPB);   \
+  } while (0)
 #define S6D_MSEG2(QM)                                                                  \
   do {                                                                                 \
     S6D_SETPRIO(1);                                                                    \
@@ -578,12 +668,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
         xq[j][h] = __builtin_shufflevector((i32x4)xf[j][2 * h], (i32x4)xf[j][2 * h + 1], 0, 1, 2, 3, 4, 5, 6, 7); \
         S6D_PIN(wq[j][h]);                                                             \
       }                                                                                \
-      _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                  \
-        S6D_MFMA8(acc[2 * QM][0], wq[0][h], xq[0][h], wsc[0], xsc[2 * QM]);            \
-        S6D_MFMA8(acc[2 * QM + 1][0], wq[0][h], xq[1][h], wsc[0], xsc[2 * QM + 1]);    \
-        S6D_MFMA8(acc[2 * QM][1], wq[1][h], xq[0][h], wsc[1], xsc[2 * QM]);            \
-        S6D_MFMA8(acc[2 * QM + 1][1], wq[1][h], xq[1][h], wsc[1], xsc[2 * QM + 1]);    \
-      }                                                                                \
+      S6D_MSEG2_H(QM, 0, 0);                                                           \
+      S6D_MSEG2_H(QM, 1, (AMX ? 2 : 0));                                               \
     }                                                                                  \
     S6D_PIN(acc[2 * QM][0]);                                                           \
     S6D_PIN(acc[2 * QM + 1][0]);                                                       \
@@ -598,6 +684,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
 #endif
     set_b(0);
     set_a(0);
+    if (AMX) {                                                           // scale dwords of K tile 0: older than every DMA piece below
+      mx_set(0);
+      mx_issue();
+    }
     issue_b(0, 0);
     issue_b(1, 1);
     issue_a(0, 2);
@@ -611,6 +701,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
     } else {
       S6D_VMCNT(0);
     }
+    mx_take();
     if (EPI == 2) {
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) load_resid(mt, cm0, cn0);
@@ -624,6 +715,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
       const int sA = ring(s0 + 2 + wr), sB = s0 + (wc >> 1);
       const bool more2 = g + 2 < G;
       // ---- phase A
+      if (AMX && g + 1 < G) mx_issue();                                  // scale dwords of K tile g + 1, in front of this tile's DMA issues
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -657,6 +749,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
       S6D_MSEG2(1);
       S6D_BARRIER();
       s0 = ring(s0 + 4);
+      if (AMX && g + 1 < G) mx_take();                                   // K tile g + 1's scale dwords (landed: older than the counted wait above)
       if (++ck == p.nk) {
         ck = 0;
         if (wr == 0) S6D_BARRIER();
@@ -686,8 +779,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
     return;
   }
   static_assert(DT != 1 || S6D_GEMM_PH2, "the fp8 operands are wired into the two-phase main loop only");
-  static_assert(DT == 0 || EPI < 2, "the residual K tiles and the folded LayerNorm are wired for bf16 operands");
-  static_assert(S6D_GEMM_QT || EPI < 2, "the residual / LayerNorm epilogues extend the quad-transposed epilogue");
+  static_assert(DT == 0 || EPI < 2 || EPI == 5, "the residual K tiles and the folded LayerNorm are wired for bf16 operands");
+  static_assert(S6D_GEMM_QT || EPI < 2, "the residual / LayerNorm / MX epilogues extend the quad-transposed epilogue");
   // ---- prologue: half-tiles 0..6 of the stream (K tile 0 whole; B0 B1 A0 of K tile 1)
   set_b(0);
   set_a(0);
@@ -805,6 +898,10 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_kernel(GemmParams p) {
 template <int EPI, bool HAS_BIAS>
 __global__ void __launch_bounds__(512, 2) gemm_fp8_kernel(GemmParams p) {
   gemm_body<EPI, HAS_BIAS, 1>(p);
+}
+template <int EPI, bool HAS_BIAS>
+__global__ void __launch_bounds__(512, 2) gemm_fp8mx_kernel(GemmParams p) {       // activations with MX block scales
+  gemm_body<EPI, HAS_BIAS, 1, true>(p);
 }
 template <int EPI, bool HAS_BIAS>
 __global__ void __launch_bounds__(512, 2) gemm_f16_kernel(GemmParams p) {
@@ -1047,6 +1144,8 @@ struct GemmExtra {            // operands of the residual (EPI 2) and folded-Lay
   float *SP = nullptr;        // partial row statistics out (optional)
   const float *RS = nullptr;  // row (mean, rstd) in
   const float *CS = nullptr;  // column sums of the folded weight
+  unsigned char *SC = nullptr;        // EPI 5: MX scale bytes out, [M][N / 32]
+  const unsigned *sa_mx = nullptr;    // MX scale bytes of the A operand in, [M][K / 32]
 };
 static int gemm_launch(const void *A, long lda, const void *W, long ldw, const float *bias, const GemmExtra &x, void *C, long ldc,
                        int M, int N, int K, int epilogue, int col_block, int max_blocks, void *stream, int dt = 0,
@@ -1065,6 +1164,32 @@ extern "C" int s6d_gemm_fp8(const void *A, long lda, const unsigned char *a_scal
   if (epilogue != 0 && epilogue != 1) return S6D_EINVAL;
   if (N % 256 != 0 || K % 128 != 0 || !S6D_GEMM_QT || !S6D_GEMM_PH2) return S6D_EUNSUPPORTED;
   return gemm_launch(A, lda, W, ldw, bias, GemmExtra(), C, ldc, M, N, K, epilogue, 0, max_blocks, stream, 1, a_scale, w_scale);
+}
+
+// lin1 of the fp8 block: C8 = e4m3(GELU(A W^T + bias)) (M, N) bytes, row stride ldc bytes, + one E8M0 byte per row and 32 columns at
+// c_scale [M][N / 32] -- the MX A operand of s6d_gemm_fp8_mxa.
+extern "C" int s6d_gemm_fp8_gelu_mx(const void *A, long lda, const unsigned char *a_scale, const void *W, long ldw,
+                                    const unsigned char *w_scale, const float *bias, void *C8, long ldc, unsigned char *c_scale,
+                                    int M, int N, int K, int max_blocks, void *stream) {
+  if (!a_scale || !w_scale || !c_scale) return S6D_EINVAL;
+  if (N % 256 != 0 || K % 128 != 0 || !S6D_GEMM_QT || !S6D_GEMM_PH2) return S6D_EUNSUPPORTED;
+  if (ldc < N || (ldc % 16) != 0) return S6D_EINVAL;
+  GemmExtra x;
+  x.SC = c_scale;
+  // (gemm_launch checks ldc against N in ELEMENTS of a 2-byte output: the byte rows of this form satisfy the same inequalities)
+  return gemm_launch(A, lda, W, ldw, bias, x, C8, ldc, M, N, K, 5, 0, max_blocks, stream, 1, a_scale, w_scale);
+}
+
+// lin2 of the fp8 block: the activations carry MX block scales (a_mx [M][K / 32] E8M0 bytes, what s6d_gemm_fp8_gelu_mx wrote),
+// the weights one scale per output channel; bf16 output, bias / GELU epilogue as s6d_gemm_fp8.  M % 256 == 0.
+extern "C" int s6d_gemm_fp8_mxa(const void *A, long lda, const unsigned char *a_mx, const void *W, long ldw, const unsigned char *w_scale,
+                                const float *bias, void *C, long ldc, int M, int N, int K, int epilogue, int max_blocks, void *stream) {
+  if (!a_mx || !w_scale || ((uintptr_t)a_mx & 3)) return S6D_EINVAL;
+  if (epilogue != 0 && epilogue != 1) return S6D_EINVAL;
+  if (N % 256 != 0 || K % 128 != 0 || M % 256 != 0 || !S6D_GEMM_QT || !S6D_GEMM_PH2) return S6D_EUNSUPPORTED;
+  GemmExtra x;
+  x.sa_mx = reinterpret_cast<const unsigned *>(a_mx);
+  return gemm_launch(A, lda, W, ldw, bias, x, C, ldc, M, N, K, epilogue, 0, max_blocks, stream, 1, nullptr, w_scale);
 }
 
 extern "C" int s6d_gemm_bf16_res(const void *A, long lda, const void *W, long ldw, const float *bias, const void *R, long ldr,
@@ -1113,7 +1238,7 @@ static int gemm_launch(const void *A, long lda, const void *W, long ldw, const f
   if (N % 128 != 0 || K % kstep != 0 || lda < K || ldw < K || ldc < N) return S6D_EINVAL;
   if ((lda % ralign) || (ldw % ralign) || (ldc % 8)) return S6D_EINVAL;  // 16-byte rows
   if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) return S6D_EINVAL;
-  if (epilogue < 0 || epilogue > 4) return S6D_EINVAL;
+  if (epilogue < 0 || epilogue > 5 || (epilogue == 5 && dt != 1)) return S6D_EINVAL;
   // staging addresses are 32-bit byte offsets from A / W
   if ((double)M * (double)lda * esz >= 2147483648.0 || (double)N * (double)ldw * esz >= 2147483648.0) return S6D_EUNSUPPORTED;
   const int impl = (N % 256 != 0) ? 2 : ((col_block > 0 || epilogue >= 2 || dt) ? 1 : gemm_impl());
@@ -1131,6 +1256,8 @@ static int gemm_launch(const void *A, long lda, const void *W, long ldw, const f
   p.ldw2 = (unsigned)(ldw * esz);
   p.sa = sa;
   p.sw = sw;
+  p.sa_mx = x.sa_mx;
+  p.SC = x.SC;
   p.ldc = ldc;
   p.M = M;
   p.N = N;
@@ -1178,8 +1305,25 @@ static int gemm_launch(const void *A, long lda, const void *W, long ldw, const f
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                    \
     hipLaunchKernelGGL((gemm_fp8_kernel<E, HB>), dim3(grid), dim3(512), lds, st, p);                                    \
   } while (0)
-  if (dt == 1) {
+#define S6D_GEMM8X_LAUNCH(E, HB)                                                                                        \
+  do {                                                                                                                  \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_fp8mx_kernel<E, HB>),                                \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                    \
+    hipLaunchKernelGGL((gemm_fp8mx_kernel<E, HB>), dim3(grid), dim3(512), lds, st, p);                                  \
+  } while (0)
+  if (dt == 1 && x.sa_mx) {
     if (epilogue == 1) {
+      if (bias) S6D_GEMM8X_LAUNCH(1, true); else S6D_GEMM8X_LAUNCH(1, false);
+    } else {
+      if (bias) S6D_GEMM8X_LAUNCH(0, true); else S6D_GEMM8X_LAUNCH(0, false);
+    }
+    return launch_status();
+  }
+#undef S6D_GEMM8X_LAUNCH
+  if (dt == 1) {
+    if (epilogue == 5) {
+      if (bias) S6D_GEMM8_LAUNCH(5, true); else S6D_GEMM8_LAUNCH(5, false);
+    } else if (epilogue == 1) {
       if (bias) S6D_GEMM8_LAUNCH(1, true); else S6D_GEMM8_LAUNCH(1, false);
     } else {
       if (bias) S6D_GEMM8_LAUNCH(0, true); else S6D_GEMM8_LAUNCH(0, false);

@@ -677,6 +677,48 @@ def gemm_fp8(a8, a_scale, w8, w_scale, bias=None, gelu=False, max_blocks=0):
     return out.reshape(*a8.shape[:-1], N)
 
 
+def gemm_fp8_gelu_mx(a8, a_scale, w8, w_scale, bias=None, max_blocks=0):
+    """lin1 of the fp8 block with an MX output: a8 (..., K) uint8 e4m3 + a_scale (rows,) uint8, w8 (N, K) + w_scale (N,) ->
+    (q (rows, N) uint8 = e4m3(GELU(A W^T + bias)), s (rows, N / 32) uint8 = one E8M0 scale per row and 32 columns): the MX A operand
+    of gemm_fp8_mxa.  N % 256 == 0, K % 128 == 0; one launch (rows * K < 2^31)."""
+    for t, nm in ((a8, "a8"), (a_scale, "a_scale"), (w8, "w8"), (w_scale, "w_scale")):
+        _chk(t, torch.uint8, nm)
+    K, N = a8.shape[-1], w8.shape[0]
+    a2 = a8.reshape(-1, K)
+    M = a2.shape[0]
+    if w8.shape != (N, K) or a_scale.numel() != M or w_scale.numel() != N:
+        raise ValueError(f"shapes: a8 {tuple(a8.shape)}, a_scale {tuple(a_scale.shape)}, w8 {tuple(w8.shape)}, w_scale {tuple(w_scale.shape)}")
+    if bias is not None:
+        _chk(bias, torch.float32, "bias", 1)
+    if M * K >= 2 ** 31:
+        raise RuntimeError("one launch: the row count exceeds one 2-GiB slab")
+    q = torch.empty(M, N, dtype=torch.uint8, device=a8.device)
+    s = torch.empty(M, N // 32, dtype=torch.uint8, device=a8.device)
+    _call("s6d_gemm_fp8_gelu_mx", _ptr(a2), ctypes.c_long(K), _ptr(a_scale.reshape(-1)), _ptr(w8), ctypes.c_long(K), _ptr(w_scale),
+          _ptr(bias) if bias is not None else _vp(0), _ptr(q), ctypes.c_long(N), _ptr(s), M, N, K, int(max_blocks), _stream())
+    return q, s
+
+
+def gemm_fp8_mxa(a8, a_mx, w8, w_scale, bias=None, gelu=False, max_blocks=0):
+    """a8 (rows, K) uint8 e4m3 with a_mx (rows, K / 32) uint8 MX block scales (gemm_fp8_gelu_mx's outputs), w8 (N, K) uint8 with
+    w_scale (N,) -> act(A W^T + bias) (rows, N) bf16.  rows % 256 == 0, N % 256 == 0, K % 128 == 0."""
+    for t, nm in ((a8, "a8"), (a_mx, "a_mx"), (w8, "w8"), (w_scale, "w_scale")):
+        _chk(t, torch.uint8, nm)
+    K, N = a8.shape[-1], w8.shape[0]
+    a2 = a8.reshape(-1, K)
+    M = a2.shape[0]
+    if w8.shape != (N, K) or tuple(a_mx.shape) != (M, K // 32) or w_scale.numel() != N:
+        raise ValueError(f"shapes: a8 {tuple(a8.shape)}, a_mx {tuple(a_mx.shape)}, w8 {tuple(w8.shape)}, w_scale {tuple(w_scale.shape)}")
+    if bias is not None:
+        _chk(bias, torch.float32, "bias", 1)
+    if M * K >= 2 ** 31:
+        raise RuntimeError("one launch: the row count exceeds one 2-GiB slab")
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=a8.device)
+    _call("s6d_gemm_fp8_mxa", _ptr(a2), ctypes.c_long(K), _ptr(a_mx), _ptr(w8), ctypes.c_long(K), _ptr(w_scale),
+          _ptr(bias) if bias is not None else _vp(0), _ptr(out), ctypes.c_long(N), M, N, K, 1 if gelu else 0, int(max_blocks), _stream())
+    return out
+
+
 def layernorm_fp8(x, gamma, beta, eps, delta=None):
     """x (..., C) bf16 -> (LN(x) as e4m3fn bytes (..., C) uint8, one E8M0 scale byte per row (rows,) uint8).
     delta (same shape, bf16): -> (x + delta, bytes, scales) with the residual add folded in, as add_layernorm."""
@@ -995,7 +1037,7 @@ def have(name):
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
                "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_frames_f32",
-               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "crop_resize_pad": "s6d_crop_resize_pad_f32", "samdec_img2tok": "s6d_samdec_img2tok_bf16", "samdec_tok2img": "s6d_samdec_tok2img_f32", "sam_mask_post": "s6d_sam_mask_post_sel_f32", "nms": "s6d_nms_f32", "samdec_upscale_heads": "s6d_samdec_upscale_heads_bf16", "mha": "s6d_mha_f32",
+               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "crop_resize_pad": "s6d_crop_resize_pad_f32", "samdec_img2tok": "s6d_samdec_img2tok_bf16", "samdec_tok2img": "s6d_samdec_tok2img_f32", "sam_mask_post": "s6d_sam_mask_post_sel_f32", "gemm_fp8_mx": "s6d_gemm_fp8_mxa", "nms": "s6d_nms_f32", "samdec_upscale_heads": "s6d_samdec_upscale_heads_bf16", "mha": "s6d_mha_f32",
                "linear_attn_focus": "s6d_linear_attn_focus_f32", "linear_attention": "s6d_linear_attention_f32", "project_bbox": "s6d_project_bbox_frames_f32"}.get(name)
         import os
         disabled = name in os.environ.get("S6D_DISABLE_FUSED", "").split(",")

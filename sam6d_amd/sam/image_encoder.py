@@ -253,7 +253,7 @@ class ImageEncoderViT(nn.Module):
         from ..utils.linear import lnfold_eligible, res_eligible
         x = x.contiguous()
         C = x.shape[-1]
-        if _gemm_mode() == "fp8":
+        if _gemm_mode() in ("fp8", "fp8mx"):
             return self._blocks_fp8(x, upto)
         rows, hid = x.numel() // C, max(blk.mlp.lin1.out_features for blk in self.blocks)
         if (lnfold_eligible(x, C, C) and C % 32 == 0 and all(lnfold_eligible(x, blk.mlp.lin1.out_features, C) and
@@ -343,12 +343,18 @@ class ImageEncoderViT(nn.Module):
             # tensor): the quantising LayerNorm then reads ONE tensor and writes its e4m3 rows
             x = x.clone()
             x2 = x.view(M, C)
+            mx = _gemm_mode() == "fp8mx" and ops.have("gemm_fp8_mx") and M % 256 == 0
+            delta = None
             for i, blk in enumerate(self.blocks):
                 if upto is not None and i >= upto:
                     break
                 at = blk.attn
                 g, b = self._ln_f32(blk.norm1)
-                h8, hs = ops.layernorm_fp8(x, g, b, blk.norm1.eps)
+                if delta is None:
+                    h8, hs = ops.layernorm_fp8(x, g, b, blk.norm1.eps)
+                else:                                              # fp8mx: the previous block's lin2 output joins the stream here
+                    x, h8, hs = ops.layernorm_fp8(x, g, b, blk.norm1.eps, delta=delta)
+                    x2 = x.view(M, C)
                 wq, ws, bq = fp8.cached_weight(at.qkv)
                 qkv = ops.gemm_fp8(h8, hs, wq, ws, bq).view(B, H, W, 3 * C)
                 S = blk.window_size if blk.window_size > 0 else H
@@ -359,9 +365,18 @@ class ImageEncoderViT(nn.Module):
                 g, b = self._ln_f32(blk.norm2)
                 h8, hs = ops.layernorm_fp8(x, g, b, blk.norm2.eps)
                 w1, s1, b1 = fp8.cached_weight(blk.mlp.lin1)
-                w2, b2 = _cached(blk.mlp.lin2, blk.mlp.lin2.weight)
-                ops.gemm_bf16(ops.gemm_fp8(h8, hs, w1, s1, b1, gelu=True), w2, b2, residual=x2, out=x2)
-            return x
+                if mx:
+                    # S6D_SAM_GEMM=fp8mx (round 4): lin1's GELU epilogue writes e4m3 with MX block scales (one E8M0 byte per token
+                    # and 32 channels), lin2 multiplies them on the fp8 matrix cores -- the 5120-wide hidden activations never exist
+                    # in bf16.  lin2's output is a bf16 delta that the next quantising LayerNorm adds to the stream
+                    # (s6d_add_layernorm_fp8): the fp8 kernel has no registers left for the residual epilogue.
+                    q8, qs = ops.gemm_fp8_gelu_mx(h8, hs, w1, s1, b1)
+                    w2q, w2s, b2f = fp8.cached_weight(blk.mlp.lin2)
+                    delta = ops.gemm_fp8_mxa(q8, qs, w2q, w2s, b2f).view(x.shape)
+                else:
+                    w2, b2 = _cached(blk.mlp.lin2, blk.mlp.lin2.weight)
+                    ops.gemm_bf16(ops.gemm_fp8(h8, hs, w1, s1, b1, gelu=True), w2, b2, residual=x2, out=x2)
+            return x if delta is None else x + delta
         delta = None
         for i, blk in enumerate(self.blocks):
             if upto is not None and i >= upto:
@@ -428,7 +443,8 @@ class ImageEncoderViT(nn.Module):
 
 
 def _gemm_mode():
-    """S6D_SAM_GEMM = bf16 (default, BASELINE configs[1]) | fp8 (configs[4]: qkv and lin1 on the fp8 matrix cores)."""
+    """S6D_SAM_GEMM = bf16 (default, BASELINE configs[1]) | fp8 (configs[4]: qkv and lin1 on the fp8 matrix cores) | fp8mx (round 4:
+    lin2 too, fed by lin1's MX-scaled e4m3 output)."""
     return os.environ.get("S6D_SAM_GEMM", "bf16")
 
 

@@ -32,6 +32,21 @@ def dequantize_rows(q, s):
     return torch.ldexp(q.view(torch.float8_e4m3fn).float(), (s.to(torch.int32) - 127)[:, None])
 
 
+def quantize_blocks(x, block=32):
+    """MX form: (rows, K) float -> (q (rows, K) uint8 e4m3fn bytes, s (rows, K / block) uint8 E8M0 bytes), one power-of-two scale
+    per row and ``block`` consecutive elements, by the rule of quantize_rows applied per block (what the GELU epilogue of
+    s6d_gemm_fp8_gelu_mx does for every 32 columns of a row)."""
+    rows, K = x.shape
+    q, s = quantize_rows(x.reshape(rows * (K // block), block))
+    return q.view(rows, K), s.view(rows, K // block)
+
+
+def dequantize_blocks(q, s, block=32):
+    """Inverse of quantize_blocks, in float32."""
+    rows, K = q.shape
+    return dequantize_rows(q.reshape(rows * (K // block), block), s.reshape(-1)).view(rows, K)
+
+
 def cached_weight(lin, w2d=None):
     """(q, s, bias_f32) of an nn.Linear, cached until the parameters change."""
     w = lin.weight if w2d is None else w2d

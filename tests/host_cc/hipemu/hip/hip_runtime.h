@@ -394,13 +394,14 @@ static inline int __builtin_amdgcn_cvt_pk_fp8_f32(float a, float b, int old, boo
   return hi ? (int)(((unsigned)old & 0x0000ffffu) | (pk << 16)) : (int)(((unsigned)old & 0xffff0000u) | pk);
 }
 
-// v_mfma_scale_f32_32x32x64_f8f6f4 with fp8 e4m3 operands (cbsz = blgp = 0): A lane l = row l%32, k block l/32 (32 consecutive
-// bytes); B alike; the scale operand's byte 0 is the E8M0 block scale of the lane's 32 elements: value = q * 2^(byte - 127).
-// C/D as the other 32x32 shapes.  (The true k order inside a lane's 32 bytes does not matter to a kernel that loads A and B
-// with the same map; here it is taken as consecutive.)
+// v_mfma_scale_f32_32x32x64_f8f6f4 with fp8 e4m3 operands (cbsz = blgp = 0), as measured on the MI355X (tools/probes/
+// mx_scale_probe.hip, mx_scale_probe2.hip; profiles/r04_mx_scale_probe.txt): A lane l = row l % 32 holds 32 bytes; the 64 k elements
+// of a row are  k = 32 (j / 16) + 16 (l / 32) + j % 16  for byte j of lane half l / 32 -- i.e. the FIRST 16 bytes of both lane
+// halves form scale block 0 (k 0..31), the second 16 bytes block 1 (k 32..63); block b is scaled by byte op_sel of the scale
+// operand of the lanes of half b: value = q * 2^(byte - 127).  B alike.  C/D as the other 32x32 shapes.
 typedef __attribute__((ext_vector_type(8))) int hipemu_i32x8;
 template <class VC>
-static inline VC hipemu_mfma_scale_32x32x64_f8(hipemu_i32x8 a, hipemu_i32x8 b, VC c, int fa, int fb, int sa, int sb) {
+static inline VC hipemu_mfma_scale_32x32x64_f8(hipemu_i32x8 a, hipemu_i32x8 b, VC c, int fa, int fb, int osa, int sa, int osb, int sb) {
   if (fa != 0 || fb != 0) {
     std::fprintf(stderr, "hipemu: only fp8 e4m3 operands of the f8f6f4 MFMA are emulated\n");
     std::abort();
@@ -410,25 +411,35 @@ static inline VC hipemu_mfma_scale_32x32x64_f8(hipemu_i32x8 a, hipemu_i32x8 b, V
     int sc;
   } mine;
   const int l = hipemu::lane_of(), col = l & 31, hb = l >> 5;
-  float A[16][64];                                               // the 16 rows this lane's results need, descaled
+  float A[16][64];                                               // the 16 rows this lane's results need, descaled, in k order
   std::memcpy(mine.q, &a, 32);
-  mine.sc = sa & 0xff;
+  mine.sc = ((unsigned)sa >> (8 * (osa & 3))) & 0xff;
   hipemu::begin_exchange(mine, 11);
   for (int r = 0; r < 16; ++r) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * hb;
-    for (int blk = 0; blk < 2; ++blk) {
-      const OP o = hipemu::peek<OP>(row + 32 * blk);
-      for (int j = 0; j < 32; ++j) A[r][blk * 32 + j] = ldexpf(hipemu_e4m3_to_f(o.q[j]), o.sc - 127);
+    const OP h0 = hipemu::peek<OP>(row), h1 = hipemu::peek<OP>(row + 32);
+    for (int half = 0; half < 2; ++half) {
+      const OP &o = half ? h1 : h0;
+      for (int j = 0; j < 32; ++j) {
+        const int blk = j >> 4;
+        A[r][32 * blk + 16 * half + (j & 15)] = ldexpf(hipemu_e4m3_to_f(o.q[j]), (blk ? h1.sc : h0.sc) - 127);
+      }
     }
   }
   hipemu::end_exchange();
   std::memcpy(mine.q, &b, 32);
-  mine.sc = sb & 0xff;
+  mine.sc = ((unsigned)sb >> (8 * (osb & 3))) & 0xff;
   hipemu::begin_exchange(mine, 12);
   float B[64];
-  for (int blk = 0; blk < 2; ++blk) {
-    const OP o = hipemu::peek<OP>(col + 32 * blk);
-    for (int j = 0; j < 32; ++j) B[blk * 32 + j] = ldexpf(hipemu_e4m3_to_f(o.q[j]), o.sc - 127);
+  {
+    const OP h0 = hipemu::peek<OP>(col), h1 = hipemu::peek<OP>(col + 32);
+    for (int half = 0; half < 2; ++half) {
+      const OP &o = half ? h1 : h0;
+      for (int j = 0; j < 32; ++j) {
+        const int blk = j >> 4;
+        B[32 * blk + 16 * half + (j & 15)] = ldexpf(hipemu_e4m3_to_f(o.q[j]), (blk ? h1.sc : h0.sc) - 127);
+      }
+    }
   }
   hipemu::end_exchange();
   VC d = c;
@@ -439,7 +450,7 @@ static inline VC hipemu_mfma_scale_32x32x64_f8(hipemu_i32x8 a, hipemu_i32x8 b, V
   }
   return d;
 }
-#define __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, fa, fb, osa, sa, osb, sb) hipemu_mfma_scale_32x32x64_f8(a, b, c, fa, fb, sa, sb)
+#define __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, fa, fb, osa, sa, osb, sb) hipemu_mfma_scale_32x32x64_f8(a, b, c, fa, fb, osa, sa, osb, sb)
 
 // IEEE-half forms of the two shapes: same lane layouts, _Float16 elements
 typedef __attribute__((ext_vector_type(8))) _Float16 hipemu_f16x8;

@@ -38,6 +38,12 @@ def _run():
     for case in ((256, 256, 128, False, False, 0), (300, 256, 384, True, False, 0), (700, 512, 256, True, True, 8),
                  (1280, 768, 128, True, False, 8)):
         T.test_gemm_fp8_vs_float_on_the_quantised_operands(*case)
+    # MX forms (round 4): block scales on the activations (several K tiles, two output tiles per workgroup: the scale cursor crosses a
+    # tile boundary), and the GELU epilogue that writes them
+    for case in ((256, 256, 128, 0), (512, 512, 384, 8), (1024, 256, 1280, 8), (1280, 768, 256, 8)):    # the last: 15 tiles on 8 workgroups
+        T.test_gemm_fp8_mx_activations_vs_float(*case)
+    for case in ((256, 256, 128, 0), (300, 512, 256, 8)):
+        T.test_gemm_fp8_gelu_mx_output_vs_float(*case)
 
 
 @pytest.mark.parametrize("mode", ["early", "late"])
@@ -70,4 +76,14 @@ def test_fp8_block_loop_on_the_emulator(emu, monkeypatch):
         out = m._blocks_fused(x, None).float()
     assert len(calls) == 4
     rel = ((out - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    assert rel <= T.E_BLOCK_FP8 * 3 ** 0.5, rel
+    # fp8mx (round 4): lin1 -> MX e4m3 -> lin2 on the fp8 kernels, lin2's delta added by the next quantising LayerNorm
+    mx = []
+    real_mx = emu.gemm_fp8_mxa
+    monkeypatch.setattr(emu, "gemm_fp8_mxa", lambda *a, **k: (mx.append(1), real_mx(*a, **k))[1])
+    with torch.no_grad():
+        monkeypatch.setenv("S6D_SAM_GEMM", "fp8mx")
+        out_mx = m._blocks_fused(x, None).float()
+    assert len(mx) == 2 and len(calls) == 6                          # per block: qkv on gemm_fp8, lin1 on gemm_fp8_gelu_mx, lin2 on gemm_fp8_mxa
+    rel = ((out_mx - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
     assert rel <= T.E_BLOCK_FP8 * 3 ** 0.5, rel

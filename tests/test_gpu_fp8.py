@@ -58,6 +58,70 @@ def test_gemm_fp8_vs_float_on_the_quantised_operands(M, N, K, bias, gelu, blocks
     assert (err <= tol * 1.01 + (1e-5 if gelu else 0)).all(), (err / tol).max().item()
 
 
+@pytest.mark.parametrize("M,N,K,blocks", [(256, 256, 128, 0), (512, 512, 384, 8), (1024, 256, 1280, 8), (1280, 768, 256, 8),
+                                          (65536, 1280, 5120, 0)])
+def test_gemm_fp8_mx_activations_vs_float(M, N, K, blocks):
+    """s6d_gemm_fp8_mxa: the A operand with one E8M0 scale per row and 32 k (scales that DIFFER from block to block by up to 2^12,
+    so a scale byte applied to the wrong block -- a neighbouring block of the K tile, the other lane half, another K tile or
+    another m tile -- is an error of orders of magnitude), against the float64 product of the dequantised operands."""
+    from sam6d_amd import ops
+    if not torch.cuda.is_available() and M > 2000:
+        pytest.skip("emulator: small shapes only")
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-6, 7, (M, K // 32), generator=g).float()).repeat_interleave(32, 1)
+    w = torch.randn(N, K, generator=g) / K ** 0.5 * torch.exp2(torch.randint(-3, 4, (N, 1), generator=g).float())
+    b = torch.randn(N, generator=g)
+    qa, sa = fp8.quantize_blocks(a)
+    qw, sw = fp8.quantize_rows(w)
+    out = ops.gemm_fp8_mxa(qa.cuda(), sa.cuda(), qw.cuda(), sw.cuda(), b.cuda(), max_blocks=blocks)
+    rows = torch.randperm(M, generator=g)[:1024] if M > 10000 else torch.arange(M)
+    da, dw = fp8.dequantize_blocks(qa[rows], sa[rows]).double(), fp8.dequantize_rows(qw, sw).double()
+    ref = (da @ dw.t() + b.double()).float()
+    err = (out.float().cpu()[rows] - ref).abs()
+    # one bf16 rounding + the instruction's sum precision: its 64 products are aligned to the LARGEST (scaled) one with ~17 bits, and
+    # here the two blocks of an instruction differ by up to 2^12 in scale, so the budget is 2^-14 of sum |a||w| instead of the 2^-16
+    # of the row-scaled test (measured 1.5 x that one; a misrouted scale byte would be off by factors of 2 .. 4096)
+    tol = 2.0 ** -8 * ref.abs() + 2.0 ** -14 * (da.abs() @ dw.abs().t()).float() + 1e-30
+    assert (err <= tol * 1.01).all(), (err / tol).max().item()
+
+
+@pytest.mark.parametrize("M,N,K,blocks", [(256, 256, 128, 0), (300, 512, 256, 8), (8192, 5120, 1280, 0)])
+def test_gemm_fp8_gelu_mx_output_vs_float(M, N, K, blocks):
+    """s6d_gemm_fp8_gelu_mx: e4m3 bytes + one E8M0 scale per row and 32 columns of GELU(A W^T + bias).  Against the float64
+    statement: every scale byte is the quantisation rule's for the block's true amax, or one off where that amax sits within the
+    kernel's fp32 / GELU rounding of a binade edge (< 1 % of the blocks); the dequantised values are within half an e4m3 step of the
+    block's top binade (2^-4 of the block amax) of the true values."""
+    from sam6d_amd import ops
+    if not torch.cuda.is_available() and M > 2000:
+        pytest.skip("emulator: small shapes only")
+    g = torch.Generator().manual_seed(M + N + K + 5)
+    a = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-3, 4, (M, 1), generator=g).float())
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    qa, sa = fp8.quantize_rows(a)
+    qw, sw = fp8.quantize_rows(w)
+    q, s = ops.gemm_fp8_gelu_mx(qa.cuda(), sa.cuda(), qw.cuda(), sw.cuda(), b.cuda(), max_blocks=blocks)
+    assert q.shape == (M, N) and s.shape == (M, N // 32) and q.dtype == torch.uint8 and s.dtype == torch.uint8
+    rows = torch.randperm(M, generator=g)[:512] if M > 2000 else torch.arange(M)
+    ref = torch.nn.functional.gelu(fp8.dequantize_rows(qa[rows], sa[rows]).double() @ fp8.dequantize_rows(qw, sw).double().t() + b.double()).float()
+    rq, rs = fp8.quantize_blocks(ref)
+    s_, q_ = s.cpu()[rows], q.cpu()[rows]
+    ds = (s_.int() - rs.int()).abs()
+    assert ds.max() <= 1 and (ds != 0).float().mean() < 1e-2, (ds.max().item(), (ds != 0).float().mean().item())
+    got = fp8.dequantize_blocks(q_, s_)
+    amax = ref.view(len(rows), N // 32, 32).abs().amax(2, keepdim=True).expand(-1, -1, 32).reshape(len(rows), N)
+    assert ((got - ref).abs() <= 2.0 ** -4 * amax * 1.01 + 1e-30).all(), ((got - ref).abs() / amax.clamp(min=1e-30)).max().item()
+    # and as the A operand of the next GEMM: gemm_fp8_mxa(q, s, ...) == product of the dequantised values
+    if M % 256 == 0:
+        w2 = torch.randn(256, N, generator=g) / N ** 0.5
+        qw2, sw2 = fp8.quantize_rows(w2)
+        out = ops.gemm_fp8_mxa(q, s, qw2.cuda(), sw2.cuda())
+        ref2 = (fp8.dequantize_blocks(q_, s_).double() @ fp8.dequantize_rows(qw2, sw2).double().t()).float()
+        err = (out.float().cpu()[rows] - ref2).abs()
+        tol = 2.0 ** -8 * ref2.abs() + 2.0 ** -16 * (fp8.dequantize_blocks(q_, s_).abs().double() @ fp8.dequantize_rows(qw2, sw2).abs().double().t()).float() + 1e-30
+        assert (err <= tol * 1.01).all(), (err / tol).max().item()
+
+
 @pytest.mark.parametrize("rows,C", [(1000, 1280), (37, 160), (5, 768), (64, 2048)])
 def test_layernorm_fp8_vs_library_statement(rows, C):
     """s6d_layernorm_fp8 == quantize_rows(layer_norm(x)) : identical scale bytes; payload bytes identical except where the fp32
@@ -83,8 +147,10 @@ E_BLOCK_FP8 = 2.1e-2      # profiles/r02_fp8_block_probe.txt: e4m3 operands on A
                           # block's output rms (bf16 operands: 1.3e-3); this path quantises two of the four (qkv, lin1)
 
 
-def test_vit_h_fp8_accuracy_gate(monkeypatch):
-    """configs[4] gate, part 1: the whole ViT-H with qkv / lin1 on the fp8 matrix cores against the SAME model in fp32 on the
+@pytest.mark.parametrize("mode", ["fp8", "fp8mx"])
+def test_vit_h_fp8_accuracy_gate(monkeypatch, mode):
+    """(mode fp8: qkv and lin1 on the fp8 matrix cores; fp8mx, round 4: lin2 too, fed by lin1's MX-scaled e4m3 output.)
+    configs[4] gate, part 1: the whole ViT-H with qkv / lin1 on the fp8 matrix cores against the SAME model in fp32 on the
     device (pinned to the reference golden by tests/test_gpu_sam.py): relative rms error of the token map after k blocks and of
     the neck output within the per-block budget of the round-2 probe accumulated in quadrature, E_BLOCK_FP8 * sqrt(k + 1).
     Part 2: proposals -- the mask decoder on a 8 x 8 grid of point prompts from the fp8 embedding against the bf16 embedding:
@@ -100,7 +166,7 @@ def test_vit_h_fp8_accuracy_gate(monkeypatch):
     for k in (1, 4, 32):
         with torch.no_grad():
             t32 = m.forward_tokens(x, upto=k).float()
-            monkeypatch.setenv("S6D_SAM_GEMM", "fp8")
+            monkeypatch.setenv("S6D_SAM_GEMM", mode)
             with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
                 t8 = m.forward_tokens(x.to(torch.bfloat16), upto=k).float()
             monkeypatch.setenv("S6D_SAM_GEMM", "bf16")
@@ -108,7 +174,7 @@ def test_vit_h_fp8_accuracy_gate(monkeypatch):
     with torch.no_grad():
         monkeypatch.setenv("S6D_SAM_DTYPE", "bf16")
         e16 = m(x).float()
-        monkeypatch.setenv("S6D_SAM_GEMM", "fp8")
+        monkeypatch.setenv("S6D_SAM_GEMM", mode)
         e8 = m(x).float()
         monkeypatch.setenv("S6D_SAM_GEMM", "bf16")
         monkeypatch.setenv("S6D_SAM_DTYPE", "fp32")
@@ -125,7 +191,7 @@ def test_vit_h_fp8_accuracy_gate(monkeypatch):
     inter, union = (a & b).flatten(1).sum(1).float(), (a | b).flatten(1).sum(1).float()
     big = union > 100
     iou = (inter / union.clamp(min=1))[big]
-    util.record_margin("vit_h_fp8_gate", **{f"rel_{k}": v for k, v in rel.items()}, mask_iou_mean=iou.mean(), mask_iou_min=iou.min(),
+    util.record_margin(f"vit_h_{mode}_gate", **{f"rel_{k}": v for k, v in rel.items()}, mask_iou_mean=iou.mean(), mask_iou_min=iou.min(),
                        mask_iou_share_above_095=(iou >= 0.95).float().mean(), masks_compared=float(big.sum()))
     for k in (1, 4, 32):
         assert rel[k] <= E_BLOCK_FP8 * (k + 1) ** 0.5, rel

@@ -13,5 +13,7 @@ for _ in range(2):
     bench.kernel_rooflines(dev, bench.SAM_CHUNK, 32)
 os.environ["S6D_SAM_GEMM"] = "fp8"
 bench.kernel_rooflines(dev, bench.SAM_CHUNK, 32)
+os.environ["S6D_SAM_GEMM"] = "fp8mx"                     # + lin1 with the MX output, lin2 with MX activations (round 4)
+bench.kernel_rooflines(dev, bench.SAM_CHUNK, 32)
 torch.cuda.synchronize()
 print("done")

@@ -661,9 +661,9 @@ def _extras(extra, hp, dev, args, world):
             built = extra["pipeline"].pop("_built")
             best = "fp8mx" if "error" not in extra.get("configs", {}).get("fp8mx", {"error": 1}) else "fp8"
             if isinstance(extra.get("configs", {}).get(best), dict) and "error" not in extra["configs"][best]:
-                # the same whole frame in the fp8 configuration: SAM ViT-H (fp8mx when built) AND DINOv2 ViT-L qkv / fc1 on the fp8 cores
+                # the same whole frame in the fp8 configuration: SAM ViT-H AND DINOv2 ViT-L on the fp8 cores (fp8mx: lin2 / fc2 too)
                 old = {k: os.environ.get(k) for k in ("S6D_SAM_GEMM", "S6D_DINO_GEMM")}
-                os.environ.update(S6D_SAM_GEMM=best, S6D_DINO_GEMM="fp8")
+                os.environ.update(S6D_SAM_GEMM=best, S6D_DINO_GEMM=best)
                 try:
                     torch.cuda.empty_cache()
                     pf = frame_demo.measure(dev, built=built)

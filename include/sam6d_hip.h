@@ -271,7 +271,8 @@ int s6d_gemm_fp8(const void *A, long lda, const unsigned char *a_scale, const vo
  *   one E8M0 byte per row and 32 columns, scale = 2^e with the smallest e for which the block's amax / 2^e <= 448 (the rule of
  *   s6d_layernorm_fp8, per block).  A / a_scale / W / w_scale / bias as s6d_gemm_fp8.
  * s6d_gemm_fp8_mxa: A (M,K) e4m3 bytes with a_mx [M][K / 32] E8M0 bytes (what s6d_gemm_fp8_gelu_mx wrote; 4-byte aligned), W with
- *   one scale per output channel -> act(A W^T + bias) (M,N) bf16.  M % 256 == 0, N % 256 == 0, K % 128 == 0.
+ *   one scale per output channel -> act(A W^T + bias) (M,N) bf16.  N % 256 == 0, K % 128 == 0; a_mx must be readable for
+ *   ceil(M / 256) * 256 rows (the scale dwords of a whole row tile are fetched; rows past M may hold anything).
  * The matrix instruction (v_mfma_scale_f32_32x32x64_f8f6f4) applies a lane's scale byte to its own 32-k block and op_sel picks
  * the byte: the MX scales ride in the hardware operand, the accumulators hold the true product. */
 int s6d_gemm_fp8_gelu_mx(const void *A, long lda, const unsigned char *a_scale, const void *W, long ldw, const unsigned char *w_scale,

@@ -194,7 +194,7 @@ __device__ __forceinline__ unsigned pack_out(float lo, float hi) { return DT == 
 // 128 bytes = four blocks = one dword of scales per row; lane half hb SUPPLIES the scales of blocks hb (first MFMA of the tile) and
 // 2 + hb (second), so the dword is shifted right by 8 hb once and the two instructions use op_sel 0 and 2.  The dword of K tile g + 1 is requested at the start of K tile g, in FRONT of that
 // phase's LDS-DMA issues: it is older than the eight DMA pieces the counted wait leaves in flight, so "K tile g + 1 has landed"
-// covers it and the counts stay as they are.  Rows past M are not clamped: M % 256 == 0 is required.
+// covers it and the counts stay as they are.  Rows past M are not clamped: the scale array is readable for whole 256-row tiles.
 // EPI 5 (DT = 1): C = e4m3(GELU(A W^T + bias)) with MX scales -- in the quad-transposed accumulator layout ONE lane holds a whole
 // 32-column block of its row (columns 32 h + {0..31} of the wave's 64), so the block maximum, the scale and the 32 bytes are
 // lane-local: no exchange, two 16-byte stores and one scale byte per lane and m tile.
@@ -1181,12 +1181,13 @@ extern "C" int s6d_gemm_fp8_gelu_mx(const void *A, long lda, const unsigned char
 }
 
 // lin2 of the fp8 block: the activations carry MX block scales (a_mx [M][K / 32] E8M0 bytes, what s6d_gemm_fp8_gelu_mx wrote),
-// the weights one scale per output channel; bf16 output, bias / GELU epilogue as s6d_gemm_fp8.  M % 256 == 0.
+// the weights one scale per output channel; bf16 output, bias / GELU epilogue as s6d_gemm_fp8.  The scale dwords of a whole 256-row
+// tile are read: a_mx must be READABLE for ceil(M / 256) * 256 rows (rows past M may hold anything; their products are not stored).
 extern "C" int s6d_gemm_fp8_mxa(const void *A, long lda, const unsigned char *a_mx, const void *W, long ldw, const unsigned char *w_scale,
                                 const float *bias, void *C, long ldc, int M, int N, int K, int epilogue, int max_blocks, void *stream) {
   if (!a_mx || !w_scale || ((uintptr_t)a_mx & 3)) return S6D_EINVAL;
   if (epilogue != 0 && epilogue != 1) return S6D_EINVAL;
-  if (N % 256 != 0 || K % 128 != 0 || M % 256 != 0 || !S6D_GEMM_QT || !S6D_GEMM_PH2) return S6D_EUNSUPPORTED;
+  if (N % 256 != 0 || K % 128 != 0 || !S6D_GEMM_QT || !S6D_GEMM_PH2) return S6D_EUNSUPPORTED;
   GemmExtra x;
   x.sa_mx = reinterpret_cast<const unsigned *>(a_mx);
   return gemm_launch(A, lda, W, ldw, bias, x, C, ldc, M, N, K, epilogue, 0, max_blocks, stream, 1, nullptr, w_scale);

@@ -207,7 +207,7 @@ class DinoVisionTransformer(nn.Module):
         C = x.shape[-1]
         exact_gelu = all(isinstance(blk.mlp.act, nn.GELU) and blk.mlp.act.approximate == "none" for blk in self.blocks)
         rows = x.numel() // C
-        if os.environ.get("S6D_DINO_GEMM", "bf16") == "fp8":
+        if os.environ.get("S6D_DINO_GEMM", "bf16") in ("fp8", "fp8mx"):
             return self._blocks_fp8(x, scale, exact_gelu)
         if (exact_gelu and C % 256 == 0 and all(lnfold_eligible(x, C, C) and lnfold_eligible(x, blk.mlp.fc1.out_features, C) and
                                                 lnfold_eligible(x, C, blk.mlp.fc1.out_features) for blk in self.blocks)
@@ -284,10 +284,17 @@ class DinoVisionTransformer(nn.Module):
         B, N, _ = x.shape
         rows = B * N
         x2 = x.view(rows, C)
+        # S6D_DINO_GEMM=fp8mx: fc2 too, fed by fc1's MX-scaled e4m3 output (s6d_gemm_fp8_gelu_mx -> s6d_gemm_fp8_mxa, as the SAM
+        # encoder's fp8mx loop); fc2's bf16 output is the delta the next quantising LayerNorm adds
+        mx = os.environ.get("S6D_DINO_GEMM") == "fp8mx" and ops.have("gemm_fp8_mx")
+        delta = None
         for blk in self.blocks:
             wp, bp, bpf, w2, b2, b2f = blk._folded(x.dtype)
             g, b = _ln_f32(blk.norm1)
-            h8, hs = ops.layernorm_fp8(x2, g, b, blk.norm1.eps)
+            if delta is None:
+                h8, hs = ops.layernorm_fp8(x2, g, b, blk.norm1.eps)
+            else:
+                x2, h8, hs = ops.layernorm_fp8(x2, g, b, blk.norm1.eps, delta=delta)
             wq, ws, bq = fp8.cached_weight(blk.attn.qkv)
             qkv = ops.gemm_fp8(h8, hs, wq, ws, bq).view(B, N, 3 * C)
             o = ops.seq_attention(qkv, blk.attn.num_heads, scale)
@@ -295,9 +302,25 @@ class DinoVisionTransformer(nn.Module):
             g, b = _ln_f32(blk.norm2)
             h8, hs = ops.layernorm_fp8(x2, g, b, blk.norm2.eps)
             w1, s1, b1 = fp8.cached_weight(blk.mlp.fc1)
-            ops.gemm_bf16(ops.gemm_fp8(h8, hs, w1, s1, b1, gelu=True), w2, b2f, residual=x2, out=x2)
+            if mx:
+                q8, qs = ops.gemm_fp8_gelu_mx(h8, hs, w1, s1, b1)
+                w2q, w2s = self._fc2_fp8(blk, w2)
+                delta = ops.gemm_fp8_mxa(q8, qs, w2q, w2s, b2f)
+            else:
+                ops.gemm_bf16(ops.gemm_fp8(h8, hs, w1, s1, b1, gelu=True), w2, b2f, residual=x2, out=x2)
         g, b = _ln_f32(self.norm)
-        return ops.add_layernorm(x, None, g, b, self.norm.eps)
+        return ops.add_layernorm(x2.view(B, N, C), None if delta is None else delta.view(B, N, C), g, b, self.norm.eps)
+
+    @staticmethod
+    def _fc2_fp8(blk, w2_folded):
+        """e4m3 bytes + per-channel scales of fc2 with the LayerScale gain folded in (Block._folded), cached on the folded tensor."""
+        from ..utils import fp8
+        c = getattr(blk, "_s6d_fc2_fp8", None)
+        key = (w2_folded.data_ptr(), w2_folded._version)
+        if c is None or c[0] != key:
+            c = (key,) + fp8.quantize_rows(w2_folded.float())
+            blk._s6d_fc2_fp8 = c
+        return c[1], c[2]
 
     def forward_features(self, x, masks=None):
         dt = _dtype() if x.is_cuda else torch.float32

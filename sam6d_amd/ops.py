@@ -693,7 +693,8 @@ def gemm_fp8_gelu_mx(a8, a_scale, w8, w_scale, bias=None, max_blocks=0):
     if M * K >= 2 ** 31:
         raise RuntimeError("one launch: the row count exceeds one 2-GiB slab")
     q = torch.empty(M, N, dtype=torch.uint8, device=a8.device)
-    s = torch.empty(M, N // 32, dtype=torch.uint8, device=a8.device)
+    Mp = (M + 255) // 256 * 256                 # the consumer fetches the scale dwords of whole 256-row tiles: the rows exist
+    s = torch.zeros(Mp, N // 32, dtype=torch.uint8, device=a8.device)[:M]
     _call("s6d_gemm_fp8_gelu_mx", _ptr(a2), ctypes.c_long(K), _ptr(a_scale.reshape(-1)), _ptr(w8), ctypes.c_long(K), _ptr(w_scale),
           _ptr(bias) if bias is not None else _vp(0), _ptr(q), ctypes.c_long(N), _ptr(s), M, N, K, int(max_blocks), _stream())
     return q, s
@@ -713,6 +714,11 @@ def gemm_fp8_mxa(a8, a_mx, w8, w_scale, bias=None, gelu=False, max_blocks=0):
         _chk(bias, torch.float32, "bias", 1)
     if M * K >= 2 ** 31:
         raise RuntimeError("one launch: the row count exceeds one 2-GiB slab")
+    Mp = (M + 255) // 256 * 256
+    if a_mx.untyped_storage().nbytes() - a_mx.storage_offset() < Mp * (K // 32):
+        pad = torch.zeros(Mp, K // 32, dtype=torch.uint8, device=a8.device)
+        pad[:M] = a_mx
+        a_mx = pad[:M]
     out = torch.empty(M, N, dtype=torch.bfloat16, device=a8.device)
     _call("s6d_gemm_fp8_mxa", _ptr(a2), ctypes.c_long(K), _ptr(a_mx), _ptr(w8), ctypes.c_long(K), _ptr(w_scale),
           _ptr(bias) if bias is not None else _vp(0), _ptr(out), ctypes.c_long(N), M, N, K, 1 if gelu else 0, int(max_blocks), _stream())

@@ -199,8 +199,10 @@ def test_vit_h_fp8_accuracy_gate(monkeypatch, mode):
     assert iou.mean() >= 0.95, (iou.mean().item(), iou.min().item())
 
 
-def test_vit_l14_fp8_accuracy_gate(monkeypatch):
-    """configs[4] for the descriptor ViT (round 4, S6D_DINO_GEMM=fp8): qkv / fc1 of every DINOv2 block on the fp8 matrix cores.
+@pytest.mark.parametrize("mode", ["fp8", "fp8mx"])
+def test_vit_l14_fp8_accuracy_gate(monkeypatch, mode):
+    """configs[4] for the descriptor ViT (round 4, S6D_DINO_GEMM=fp8): qkv / fc1 of every DINOv2 block on the fp8 matrix cores
+    (fp8mx: fc2 too, on fc1's MX-scaled e4m3 output; 255 x 257 token rows: the MX scale rows are padded to whole row tiles).
     Part 1: the residual stream after 24 blocks against the SAME model in fp32 within the per-block fp8 budget in quadrature.
     Part 2, at the level of DECISIONS, on the proposals of tests/golden/frame_e2e.npz: descriptors' cosine to the fp32 ones, and
     what the scoring stage makes of them -- the selection and the object decision must not move; template flips and the final
@@ -223,7 +225,7 @@ def test_vit_l14_fp8_accuracy_gate(monkeypatch):
     boxes = torch.cat([torch.from_numpy(g["sam_boxes"]).float(), fi["boxes"]]).cuda()
     rgbs, _ = o._crops(fi["rgb"], masks, boxes, True, True)
     out = {}
-    for name, env in (("fp32", dict(S6D_DINO_DTYPE="fp32", S6D_DINO_GEMM="bf16")), ("fp8", dict(S6D_DINO_DTYPE="bf16", S6D_DINO_GEMM="fp8"))):
+    for name, env in (("fp32", dict(S6D_DINO_DTYPE="fp32", S6D_DINO_GEMM="bf16")), ("fp8", dict(S6D_DINO_DTYPE="bf16", S6D_DINO_GEMM=mode))):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         with torch.no_grad():
@@ -240,10 +242,10 @@ def test_vit_l14_fp8_accuracy_gate(monkeypatch):
     obj = (r32["pred_obj"][:n] != r8["pred_obj"][:n]).float().mean().item() if same_sel else 1.0
     tpl = (r32["best_template"][:n] != r8["best_template"][:n]).float().mean().item() if same_sel else 1.0
     dfin = (r32["final"][:n] - r8["final"][:n]).abs().max().item() if same_sel else float("nan")
-    util.record_margin("vit_l14_fp8_gate", stream_rel_24=rel, cls_cos_min=cos.min().item(), same_sel=same_sel, pred_obj_flip_rate=obj,
+    util.record_margin(f"vit_l14_{mode}_gate", stream_rel_24=rel, cls_cos_min=cos.min().item(), same_sel=same_sel, pred_obj_flip_rate=obj,
                        best_template_flip_rate=tpl, final_score_diff_max=dfin)
-    # measured in round 4 (profiles/r04_parity_margins_fp8_dino.jsonl): stream 3.3e-2 off after 24 blocks, cosine >= 0.9981, the same 26
-    # proposals selected, no object and no template decision flipped, final scores within 1.3e-3
+    # measured in round 4 (profiles/r04_parity_margins_fp8_dino.jsonl): fp8 -- stream 3.3e-2 off after 24 blocks, cosine >= 0.9980; fp8mx --
+    # 4.0e-2, >= 0.9969; both: the same 26 proposals selected, no object and no template decision flipped, final scores within 1.5e-3
     assert rel <= E_BLOCK_FP8 * 25 ** 0.5, rel
-    assert cos.min() > 0.996 and same_sel and obj == 0.0, (cos.min().item(), same_sel, obj)
+    assert cos.min() > (0.996 if mode == "fp8" else 0.994) and same_sel and obj == 0.0, (cos.min().item(), same_sel, obj)
     assert tpl <= 1 / 26 + 1e-9 and dfin < 3e-3, (tpl, dfin)

@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the whole-frame `pipeline` block (all five models)")
     ap.add_argument("--no-fp8", action="store_true", help="skip the `configs.fp8` block (BASELINE configs[4] measured next to the headline)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="the timed steps only (no stage split, no per-kernel rows, no fp8 / whole-frame / CPU blocks): the target of the "
+                         "rocprofv3 kernel-statistics passes, so that their shares are the step's and not the side measurements'")
     ap.add_argument("--standin", action="store_true",
                     help="TEST INFRASTRUCTURE (tests/test_bench_launcher.py): stand-in stages on the CPU over gloo, to exercise the "
                          "launcher, the barriers, the record gather and the JSON line on a host without GPUs; the line it prints "
@@ -801,7 +804,7 @@ def main():
         extra["standin"] = True
         extra["gathered_rows"] = int(last.shape[0])
         extra["gathered_ranks"] = sorted({int(v) for v in last[:, 0].tolist()})
-    elif rank == 0:
+    elif rank == 0 and not args.no_extras:
         try:
             _extras(extra, hp, dev, args, world)
         except Exception as e:  # noqa: BLE001  (the headline line must come out even if a side measurement fails)

@@ -16,9 +16,9 @@ timeout 900 python bench.py --steps 5 --warmup 2 > gpurun_out/prof/${R}_bench_li
 # same box A/B of the round's host-visible change in the step: the IEEE-half range guard's host read at the end of the PEM stage
 S6D_PEM_F16_GUARD=0 timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline --no-fp8 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('guard off:', d['value'], d['ms_per_step'])" > gpurun_out/prof/${R}_guard_ab.txt
 timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline --no-fp8 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('guard on: ', d['value'], d['ms_per_step'])" >> gpurun_out/prof/${R}_guard_ab.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline --no-fp8 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o bench -- python bench.py --steps 3 --warmup 1 --no-extras > /dev/null 2>&1
 cp $(find /tmp/prof_bench -name "*kernel_stats.csv" | head -1) gpurun_out/prof/${R}_bench_kernel_stats.csv
-S6D_BENCH_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_serial -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline --no-fp8 > /dev/null 2>&1
+S6D_BENCH_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_serial -o bench -- python bench.py --steps 3 --warmup 1 --no-extras > /dev/null 2>&1
 cp $(find /tmp/prof_serial -name "*kernel_stats.csv" | head -1) gpurun_out/prof/${R}_bench_serial_kernel_stats.csv
 cat > /tmp/fd.py <<'PY'
 import json, os, sys, torch

@@ -30,7 +30,7 @@ extern "C" {
 
 /* Bumped whenever a signature in this header changes; the loader (sam6d_amd/_lib.py) refuses a library whose
  * s6d_version() differs from the header it was written against (a stale .so fails at load, not at a call). */
-#define S6D_ABI_VERSION 113
+#define S6D_ABI_VERSION 114
 int s6d_version(void);
 const char *s6d_strerror(int code);
 /* last HIP error string seen by this thread (empty if none) */
@@ -399,6 +399,17 @@ int s6d_pe_group_mlp_f32(const float *pts, const int32_t *idx, int B, int N, int
  * memory.  ref: segment_anything/modeling/sam.py:164-174. */
 int s6d_sam_preprocess_f32(const float *in, int B, int h, int w, int S, const float *mean3_host,
                            const float *std3_host, int out_bf16, void *out, void *stream);
+
+/* The A operand of a 3x3, padding-1 convolution run as one GEMM over K = 9 C: in (B,H,W,C) of two-byte elements (bf16 or f16,
+ * copied bit for bit) -> out (B,H,W,9C), out[b,y,x,(3 dy + dx) C + c] = in[b, y + dy - 1, x + dx - 1, c], 0 outside the map.
+ * C % 8 == 0.  ref: the neck's second Conv2d, segment_anything/modeling/image_encoder.py:91-97 (weight flattened in
+ * (dy, dx, ci) order by the caller). */
+int s6d_im2col3x3_b16(const void *in, int B, int H, int W, int C, void *out, void *stream);
+
+/* The A operand of a kernel = stride = p convolution (PatchEmbed): in (B,Cin,H,W) two-byte elements -> out (B,H/p,W/p,Cin p p),
+ * a patch's elements in (c, dy, dx) order = Conv2d.weight.flatten(1)'s.  p % 8 == 0, H % p == W % p == 0.
+ * ref: PatchEmbed.forward, segment_anything/modeling/image_encoder.py:375-395. */
+int s6d_patchify_b16(const void *in, int B, int Cin, int H, int W, int p, void *out, void *stream);
 
 /* Features of chosen pixels of the x4-upsampled feature map without materialising it.
  * up (B, G*G, P*P, C) f32 = output_upscaling(tokens) before the pixel shuffle (G = 14 patches, P = 4, C = 256);

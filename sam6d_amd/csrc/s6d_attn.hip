@@ -123,6 +123,13 @@ constexpr int kAbl = S6D_ATTN_ABLATE;
 #ifndef S6D_GLB_PRIO
 #define S6D_GLB_PRIO 1
 #endif
+#ifndef S6D_WIN16_ASM_DMA
+#define S6D_WIN16_ASM_DMA 1          // persistent window kernel: LDS-DMA as inline asm (1) or through the builtin (0).  With the builtin hipcc
+#endif                               // waits vmcnt(0) in front of the next LDS read (bias tables; first V fragment): the prefetch of the NEXT
+                                     // item's images did not overlap the current item's arithmetic at all (ISA read in round 4)
+#ifndef S6D_WIN16_QDEFER
+#define S6D_WIN16_QDEFER 1           // the next item's Q fragments are loaded half way through the PV pass and MASKED at the start of the
+#endif                               // next item (1) instead of right behind the loads (0: a full fetch latency inside the PV pass)
 #ifndef S6D_WIN16_KSWZ
 #define S6D_WIN16_KSWZ 0             // the same chunk swizzle on the persistent window kernel's compact K image (11-chunk rows): measured
                                      // 0.265 ms against 0.260 ms without it (16 frames, one process) -- that kernel waits on its fetches,
@@ -991,6 +998,23 @@ __device__ const uint4 g_win16_zero = {0u, 0u, 0u, 0u};
 #endif
 #define S6D_ATTN_GLOBAL(T) __attribute__((address_space(1))) T
 
+// One 1-KiB DMA piece: lane l's 16 bytes at src -> LDS byte address lds + 16 l (lds wave-uniform).  Issued as inline asm, not through
+// __builtin_amdgcn_global_load_lds: with the builtin in the loop hipcc puts an s_waitcnt vmcnt(0) in front of the first
+// ds_read_b64_tr_b16 of every tile (it cannot tell that the reads touch another ring slot), which drains the two-tile look-ahead;
+// the waits here are the counted ones written out below.  M0 is on the clobber list (the library is built with -Wno-inline-asm: hipcc
+// warns about reserved registers there); nothing else in the kernel uses it.
+#ifdef HIPEMU
+#define S6D_ATTN_DMA16(src, lds_ptr) __builtin_amdgcn_global_load_lds((const S6D_ATTN_GLOBAL(void) *)(src), (lds_ptr), 16, 0, 0)
+#else
+__device__ __forceinline__ void attn_dma16(const void *src, S6D_LDS(char) *dst) {
+  const unsigned a = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dst);
+  // s_nop: one wait state between the SALU write of M0 and the LDS-DMA that reads it (hipcc puts the same nop after its own s_mov m0)
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(a) : "memory", "m0");
+}
+#define S6D_ATTN_DMA16(src, lds_ptr) attn_dma16((src), (lds_ptr))
+#endif
+
+
 // S14: the kernel is instantiated once for 14 x 14 windows (the ViT-H configuration: every key row exists, win16_pass<.., 14, true>)
 // and once for the other sizes (win16_pass<.., 16, false>).  As ONE kernel holding both passes it needed 256 VGPRs + 21 spilled
 // registers, stored to scratch for every item on either path; the 14 x 14 instantiation alone takes 239 VGPRs and no scratch
@@ -1031,12 +1055,18 @@ __global__ __launch_bounds__(512) void attn_window16p_kernel(AttnParams p, int n
       const u16 *src = img ? qkv_at(p, tokc, which, it.head) + min(part * 8, HD - 8) : p.qkv_bias + sel;
       const void *sp = inwin ? (const void *)src : (const void *)&g_win16_zero;
       S6D_LDS(char) *dst = (S6D_LDS(char) *)dst_base + (k << 10);
+#if S6D_WIN16_ASM_DMA
+      S6D_ATTN_DMA16(sp, dst);
+#else
       __builtin_amdgcn_global_load_lds((const S6D_ATTN_GLOBAL(void) *)sp, dst, 16, 0, 0);
+#endif
     }
   };
   constexpr int MAXROWS = 2;
   bf16x8 qfa[MAXROWS][C::KS];
-  auto load_q = [&](const WinItem &it) __attribute__((always_inline)) {
+  // RAW: loads only (the zero mask of the out-of-window / padded-head-dim chunks is lane-constant and applied by mask_q at the
+  // start of the item that uses the fragments, behind the end-of-item wait)
+  auto load_q = [&](const WinItem &it, bool raw) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < MAXROWS; ++i) {
       const int qy = wave + i * WAVES;
@@ -1050,7 +1080,20 @@ __global__ __launch_bounds__(512) void attn_window16p_kernel(AttnParams p, int n
         const size_t tokc = (size_t)(it.b * p.H + min(y, p.H - 1)) * p.W + min(x, p.W - 1);
         const u16 *src = qimg ? qkv_at(p, tokc, 0, it.head) + dc : p.qkv_bias + it.head * HD + dc;
         t.u = *reinterpret_cast<const uint4 *>(src);
-        if (!(qwin && d0 < HD)) t.u = make_uint4(0, 0, 0, 0);
+        if (!raw && !(qwin && d0 < HD)) t.u = make_uint4(0, 0, 0, 0);
+        qfa[i][ks] = t.v;
+      }
+    }
+  };
+  auto mask_q = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < MAXROWS; ++i) {
+      const bool qwin = c < S && wave + i * WAVES < S;
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        union { uint4 u; bf16x8 v; } t;
+        t.v = qfa[i][ks];
+        if (!(qwin && ks * 32 + g * 8 < HD)) t.u = make_uint4(0, 0, 0, 0);
         qfa[i][ks] = t.v;
       }
     }
@@ -1059,7 +1102,7 @@ __global__ __launch_bounds__(512) void attn_window16p_kernel(AttnParams p, int n
   WinItem cur, nxt;
   int id = blockIdx.x;
   cur.decode(p, id);
-  load_q(cur);
+  load_q(cur, false);
   stage_image(cur, 1, smem);
   stage_image(cur, 2, smem + kbytes);
   S6D_ATTN_VMCNT0();
@@ -1098,7 +1141,7 @@ __global__ __launch_bounds__(512) void attn_window16p_kernel(AttnParams p, int n
     S6D_TICK(wtk, 3);
     const u16 *Kl = reinterpret_cast<const u16 *>(cb), *Vl = reinterpret_cast<const u16 *>(cb + kbytes);
     auto mid = [&]() __attribute__((always_inline)) {                // half way through the PV pass: this item's Q fragments are long dead
-      if (more) load_q(nxt);
+      if (more) load_q(nxt, S6D_WIN16_QDEFER != 0);
     };
     const bf16x8 (&q2)[2][C::KS] = reinterpret_cast<const bf16x8 (&)[2][C::KS]>(qfa[0]);
     if (S14)
@@ -1113,6 +1156,9 @@ __global__ __launch_bounds__(512) void attn_window16p_kernel(AttnParams p, int n
     if (S6D_G64_TIMING)
 #pragma unroll
       for (int i = 0; i < 6; ++i) wsum[i] += wtk[i + 1] - wtk[i];
+    // unconditional: on the last item the fragments are stale and unused, but hipcc's wait-count model then sees every path into the
+    // loop header with no load in flight (otherwise it waits vmcnt(5..0) at the fragments' first use, i.e. for the K DMA issued before it)
+    if (S6D_WIN16_QDEFER) mask_q();
     cur = nxt;
     buf ^= 1;
   }
@@ -1264,22 +1310,6 @@ constexpr int G64_THLD = 65;
 #ifndef S6D_G64_SLOTS
 #define S6D_G64_SLOTS 3             // ring depth: tiles are DMA'd S6D_G64_SLOTS - 1 ahead of the arithmetic
 #endif
-// One 1-KiB DMA piece: lane l's 16 bytes at src -> LDS byte address lds + 16 l (lds wave-uniform).  Issued as inline asm, not through
-// __builtin_amdgcn_global_load_lds: with the builtin in the loop hipcc puts an s_waitcnt vmcnt(0) in front of the first
-// ds_read_b64_tr_b16 of every tile (it cannot tell that the reads touch another ring slot), which drains the two-tile look-ahead;
-// the waits here are the counted ones written out below.  M0 is on the clobber list (the library is built with -Wno-inline-asm: hipcc
-// warns about reserved registers there); nothing else in the kernel uses it.
-#ifdef HIPEMU
-#define S6D_ATTN_DMA16(src, lds_ptr) __builtin_amdgcn_global_load_lds((const S6D_ATTN_GLOBAL(void) *)(src), (lds_ptr), 16, 0, 0)
-#else
-__device__ __forceinline__ void attn_dma16(const void *src, S6D_LDS(char) *dst) {
-  const unsigned a = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dst);
-  // s_nop: one wait state between the SALU write of M0 and the LDS-DMA that reads it (hipcc puts the same nop after its own s_mov m0)
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(a) : "memory", "m0");
-}
-#define S6D_ATTN_DMA16(src, lds_ptr) attn_dma16((src), (lds_ptr))
-#endif
-
 #ifndef S6D_G64_WAVES
 #define S6D_G64_WAVES 8
 #endif

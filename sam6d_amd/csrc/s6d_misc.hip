@@ -13,6 +13,12 @@
 //                    added one after the other into a float32 accumulator.  A parallel reduction rounds differently, and
 //                    a centroid that is off by a micrometre moves points across the radius filter; so the order is kept:
 //                    one wave per detection stages 512-row chunks in LDS (coalesced), lanes 0..C-1 add them in row order.
+//   im2col3x3       the nine shifted views of a (B,H,W,C) two-byte map side by side, (B,H,W,9C) in (dy, dx, c) order with
+//                    zeros outside the map: the A operand of the SAM neck's 3x3 convolution run as ONE GEMM over K = 9 C
+//                    (segment_anything/modeling/image_encoder.py:91-97).  torch.cat over nine strided views wrote the same
+//                    302 MB per 16 frames in 390 us; this pass is one coalesced 16-byte store per thread.
+//   patchify         PatchEmbed's Conv2d with kernel = stride = p (image_encoder.py:375-395) is a GEMM over the pixels of a patch:
+//                    (B,Cin,H,W) -> (B,H/p,W/p,Cin p p) in (c, dy, dx) order, the Conv2d weight's own flattening.
 #include "s6d_common.h"
 #include "s6d_seqsum.h"
 
@@ -92,9 +98,71 @@ __global__ __launch_bounds__(256) void upsample_gather_kernel(const float *__res
   }
 }
 
+// in (B,H,W,C) -> out (B,H,W,9C); C8 = C / 8 (one thread = 16 bytes of the output)
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const uint4 *__restrict__ in, int B, int H, int W, int C8,
+                                                       uint4 *__restrict__ out) {
+  const size_t total = (size_t)B * H * W * 9 * C8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    size_t r = i / C8;
+    const int tap = (int)(r % 9);
+    r /= 9;
+    const int x = (int)(r % W);
+    r /= W;
+    const int y = (int)(r % H);
+    const size_t b = r / H;
+    const int sy = y + tap / 3 - 1, sx = x + tap % 3 - 1;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = in[((b * H + sy) * (size_t)W + sx) * C8 + c8];
+    out[i] = v;
+  }
+}
+
+// in (B,Cin,H,W) -> out (B,H/p,W/p,Cin*p*p), element (c, dy, dx) of a patch at c*p*p + dy*p + dx; p8 = p / 8
+__global__ __launch_bounds__(256) void patchify_kernel(const uint4 *__restrict__ in, int B, int Cin, int H, int W, int p,
+                                                      uint4 *__restrict__ out) {
+  const int p8 = p / 8, gy = H / p, gx = W / p, per = Cin * p * p8;          // 16-byte chunks per patch
+  const size_t total = (size_t)B * gy * gx * per;
+  const size_t W8 = (size_t)W / 8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int e = (int)(i % per);
+    size_t r = i / per;
+    const int px = (int)(r % gx);
+    r /= gx;
+    const int py = (int)(r % gy);
+    const size_t b = r / gy;
+    const int d8 = e % p8, dy = (e / p8) % p, c = e / (p8 * p);
+    out[i] = in[((b * Cin + c) * H + (size_t)py * p + dy) * W8 + (size_t)px * p8 + d8];
+  }
+}
+
 }  // namespace s6d
 
 using namespace s6d;
+
+extern "C" int s6d_im2col3x3_b16(const void *in, int B, int H, int W, int C, void *out, void *stream) {
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) != 0) return S6D_EINVAL;
+  if (B == 0) return S6D_OK;
+  if (!in || !out) return S6D_EINVAL;
+  const size_t total = (size_t)B * H * W * 9 * (C / 8);
+  size_t g = (total + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(im2col3x3_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), (const uint4 *)in, B, H, W, C / 8,
+                     (uint4 *)out);
+  return launch_status();
+}
+
+extern "C" int s6d_patchify_b16(const void *in, int B, int Cin, int H, int W, int p, void *out, void *stream) {
+  if (B < 0 || Cin <= 0 || H <= 0 || W <= 0 || p <= 0 || (p % 8) != 0 || (H % p) != 0 || (W % p) != 0) return S6D_EINVAL;
+  if (B == 0) return S6D_OK;
+  if (!in || !out) return S6D_EINVAL;
+  const size_t total = (size_t)B * Cin * H * (W / 8);
+  size_t g = (total + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), (const uint4 *)in, B, Cin, H, W, p,
+                     (uint4 *)out);
+  return launch_status();
+}
 
 extern "C" int s6d_sam_preprocess_f32(const float *in, int B, int h, int w, int S, const float *mean3_host,
                                       const float *std3_host, int out_bf16, void *out, void *stream) {

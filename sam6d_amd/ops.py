@@ -212,6 +212,28 @@ def sam_preprocess(x, mean, std, img_size, out_dtype=torch.bfloat16):
     return out
 
 
+def im2col3x3(y):
+    """(B,H,W,C) bf16 / f16 -> (B,H,W,9C): the nine shifted views of a zero-padded 3x3 neighbourhood in (dy, dx, c) order -- the A
+    operand of a padding-1 3x3 convolution as one GEMM.  [the SAM neck's second Conv2d, image_encoder.py:91-97]"""
+    if y.dtype not in (torch.bfloat16, torch.float16) or y.dim() != 4 or not y.is_contiguous():
+        raise RuntimeError("im2col3x3: contiguous (B,H,W,C) bf16 / f16 expected")
+    B, H, W, C = y.shape
+    out = torch.empty(B, H, W, 9 * C, dtype=y.dtype, device=y.device)
+    _call("s6d_im2col3x3_b16", _ptr(y), B, H, W, C, _ptr(out), _stream())
+    return out
+
+
+def patchify(x, p):
+    """(B,Cin,H,W) bf16 / f16 -> (B,H/p,W/p,Cin*p*p) with a patch's elements in (c, dy, dx) order (Conv2d.weight.flatten(1)'s):
+    the A operand of a kernel = stride = p convolution.  [PatchEmbed.forward, image_encoder.py:375-395]"""
+    if x.dtype not in (torch.bfloat16, torch.float16) or x.dim() != 4 or not x.is_contiguous():
+        raise RuntimeError("patchify: contiguous (B,Cin,H,W) bf16 / f16 expected")
+    B, Cin, H, W = x.shape
+    out = torch.empty(B, H // p, W // p, Cin * p * p, dtype=x.dtype, device=x.device)
+    _call("s6d_patchify_b16", _ptr(x), B, Cin, H, W, int(p), _ptr(out), _stream())
+    return out
+
+
 def crop_resize_pad(image_u8, masks, params, target, mean, std, rgb=True, mask=True):
     """Fused proposal crops [CustomDINOv2.process_rgb_proposals / process_masks_proposals].
     image_u8 (H,W,3) uint8, masks (P,H,W) f32, params (P,12) int32 records (sam6d_amd.ism.dinov2.crop_params)
@@ -1043,7 +1065,7 @@ def have(name):
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
                "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_frames_f32",
-               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "crop_resize_pad": "s6d_crop_resize_pad_f32", "samdec_img2tok": "s6d_samdec_img2tok_bf16", "samdec_tok2img": "s6d_samdec_tok2img_f32", "sam_mask_post": "s6d_sam_mask_post_sel_f32", "gemm_fp8_mx": "s6d_gemm_fp8_mxa", "nms": "s6d_nms_f32", "samdec_upscale_heads": "s6d_samdec_upscale_heads_bf16", "mha": "s6d_mha_f32",
+               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "im2col3x3": "s6d_im2col3x3_b16", "patchify": "s6d_patchify_b16", "crop_resize_pad": "s6d_crop_resize_pad_f32", "samdec_img2tok": "s6d_samdec_img2tok_bf16", "samdec_tok2img": "s6d_samdec_tok2img_f32", "sam_mask_post": "s6d_sam_mask_post_sel_f32", "gemm_fp8_mx": "s6d_gemm_fp8_mxa", "nms": "s6d_nms_f32", "samdec_upscale_heads": "s6d_samdec_upscale_heads_bf16", "mha": "s6d_mha_f32",
                "linear_attn_focus": "s6d_linear_attn_focus_f32", "linear_attention": "s6d_linear_attention_f32", "project_bbox": "s6d_project_bbox_frames_f32"}.get(name)
         import os
         disabled = name in os.environ.get("S6D_DISABLE_FUSED", "").split(",")

@@ -78,7 +78,10 @@ class PatchEmbed(nn.Module):
     def forward(self, x):
         B, C, H, W = x.shape
         p = self.proj.kernel_size[0]
-        x = x.view(B, C, H // p, p, W // p, p).permute(0, 2, 4, 1, 3, 5).reshape(B, H // p, W // p, C * p * p)
+        if x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and p % 8 == 0 and H % p == 0 and W % p == 0 and ops.have("patchify"):
+            x = ops.patchify(x.contiguous(), p)                   # one coalesced pass instead of a 6-d strided copy
+        else:
+            x = x.view(B, C, H // p, p, W // p, p).permute(0, 2, 4, 1, 3, 5).reshape(B, H // p, W // p, C * p * p)
         return fused_linear(self.proj, x, weight2d=self.proj.weight.flatten(1))
 
 
@@ -228,7 +231,7 @@ class ImageEncoderViT(nn.Module):
         if self.pos_embed is not None:
             x = x + self.pos_embed.to(x.dtype)
         if x.is_cuda and x.dtype == torch.bfloat16 and ops.have("add_layernorm"):
-            return self._blocks_fused(x, upto)
+            return self._blocks_fused(x, upto, own=True)       # x is this call's own tensor: updated in place
         for i, blk in enumerate(self.blocks):
             if upto is not None and i >= upto:
                 break
@@ -245,7 +248,7 @@ class ImageEncoderViT(nn.Module):
             norm._s6d_f32 = c
         return c[1], c[2]
 
-    def _blocks_fused(self, x, upto):
+    def _blocks_fused(self, x, upto, own=False):
         """Same dataflow as Block.forward.  Round 3: the two residual adds of a block happen in the epilogues of the proj and
         lin2 GEMMs (s6d_gemm_bf16_res, in place on the stream tensor) and the LayerNorms are one-read passes; round 2 folded
         each add into the following LayerNorm pass (two reads + two writes per add: 6 % of the step).  Same arithmetic either
@@ -254,13 +257,13 @@ class ImageEncoderViT(nn.Module):
         x = x.contiguous()
         C = x.shape[-1]
         if _gemm_mode() in ("fp8", "fp8mx"):
-            return self._blocks_fp8(x, upto)
+            return self._blocks_fp8(x, upto, own)
         rows, hid = x.numel() // C, max(blk.mlp.lin1.out_features for blk in self.blocks)
         if (lnfold_eligible(x, C, C) and C % 32 == 0 and all(lnfold_eligible(x, blk.mlp.lin1.out_features, C) and
                                                              lnfold_eligible(x, C, blk.mlp.lin1.out_features) and blk.attn.use_rel_pos
                                                              for blk in self.blocks)
                 and ops.have("win_attention") and rows <= ops.gemm_one_launch_rows(max(hid, 3 * C))):
-            return self._blocks_lnfold(x, upto)
+            return self._blocks_lnfold(x, upto, own)
         if res_eligible(x, C, C) and all(res_eligible(x, C, blk.mlp.lin2.in_features) for blk in self.blocks):
             x = x.clone()                                        # the stream tensor is updated in place from here on
             for i, blk in enumerate(self.blocks):
@@ -285,7 +288,7 @@ class ImageEncoderViT(nn.Module):
             delta = blk.mlp(h).contiguous()
         return x if delta is None else x + delta
 
-    def _blocks_lnfold(self, x, upto):
+    def _blocks_lnfold(self, x, upto, own=False):
         """Block.forward (image_encoder.py:166-182) with neither the residual adds nor the LayerNorms as passes of their own
         (round 2 / 3 spent 6 % of the step in add + LayerNorm: two reads and two writes of the token map per add):
           * `x + proj(..)` and `x + lin2(..)`: the residual tile rides through the matrix cores of the producing GEMM
@@ -295,7 +298,8 @@ class ImageEncoderViT(nn.Module):
             sigma b' - mean s and dividing by sigma in its epilogue (s6d_gemm_bf16_lnfold).  The normalised activations never exist.
         Out-of-image window tokens keep the ORIGINAL qkv bias (the reference pads after norm1: zeros through qkv = its bias)."""
         from ..utils.linear import _cached, lnfold_cached
-        x = x.clone()                                            # the stream tensor is updated in place from here on
+        if not own:
+            x = x.clone()                                        # the stream tensor is updated in place from here on
         B, H, W, C = x.shape
         M = B * H * W
         x2 = x.view(M, C)
@@ -323,7 +327,7 @@ class ImageEncoderViT(nn.Module):
                 st = ops.ln_stats_finalize(sp, 32, blocks[i + 1].norm1.eps)
         return x
 
-    def _blocks_fp8(self, x, upto):
+    def _blocks_fp8(self, x, upto, own=False):
         """BASELINE configs[4] (never the headline): the two LayerNorm-fed GEMMs of every block -- qkv (1280 -> 3840) and lin1
         (1280 -> 5120, + GELU), 58 % of the encoder's GEMM FLOP -- on the fp8 matrix cores.  LayerNorm writes its output as e4m3
         bytes with one power-of-two scale per token (s6d_layernorm_fp8: no extra pass), the weights carry one power-of-two scale
@@ -341,7 +345,8 @@ class ImageEncoderViT(nn.Module):
                 and M <= ops.gemm_one_launch_rows(max(blk.mlp.lin1.out_features for blk in self.blocks)):
             # the residual adds in the bf16 proj / lin2 GEMMs (accumulators start at bias + residual, in place on the stream
             # tensor): the quantising LayerNorm then reads ONE tensor and writes its e4m3 rows
-            x = x.clone()
+            if not own:
+                x = x.clone()
             x2 = x.view(M, C)
             mx = _gemm_mode() == "fp8mx" and ops.have("gemm_fp8_mx") and M % 256 == 0
             delta = None
@@ -410,17 +415,21 @@ class ImageEncoderViT(nn.Module):
         else:
             y = F.layer_norm(y.float(), (y.shape[-1],), n1.weight.float(), n1.bias.float(), n1.eps).to(dt)
         Co = y.shape[-1]
-        yp = F.pad(y, (0, 0, 1, 1, 1, 1))                                   # zero pad H and W by 1
         if y.is_cuda and dt == torch.bfloat16 and ops.have("gemm_bf16") and (9 * Co) % 64 == 0 and c3.weight.shape[0] % 128 == 0:
             # the 3x3 convolution as ONE GEMM over K = 9 Ci (the nine shifted views side by side, weight in (dy, dx, ci) order):
             # fp32 accumulation over all taps inside the kernel instead of nine bf16 partial products summed in fp32 passes
-            cols = torch.cat([yp[:, dy:dy + H, dx:dx + W, :] for dy in range(3) for dx in range(3)], dim=-1)
+            if ops.have("im2col3x3") and Co % 8 == 0:
+                cols = ops.im2col3x3(y.contiguous())
+            else:
+                yp = F.pad(y, (0, 0, 1, 1, 1, 1))                           # zero pad H and W by 1
+                cols = torch.cat([yp[:, dy:dy + H, dx:dx + W, :] for dy in range(3) for dx in range(3)], dim=-1)
             acc = fused_linear(c3, cols, weight2d=c3.weight.permute(0, 2, 3, 1).reshape(c3.weight.shape[0], -1))
             if kern:                                                        # bf16 GEMM output -> fp32 embedding, statistics in fp32
                 g, b = self._ln_f32(n2)
                 return ops.layernorm_f32out(acc.contiguous(), g, b, n2.eps).permute(0, 3, 1, 2)
             acc = acc.float()
         else:
+            yp = F.pad(y, (0, 0, 1, 1, 1, 1))                               # zero pad H and W by 1
             w = c3.weight.to(dt)                                            # (Co, Ci, 3, 3)
             acc = None
             for dy in range(3):

@@ -20,6 +20,10 @@ def test_sam_preprocess_on_the_emulator(emu):
     TS.test_preprocess_matches_oracle()
 
 
+def test_layout_kernels_on_the_emulator(emu):
+    TS.test_layout_kernels_bit_exact_vs_the_library_statements()
+
+
 def test_crop_kernel_on_the_emulator(emu):
     TD.test_crops_bit_exact_vs_oracle_and_golden(56)
     TD.test_crops_random_boxes_bit_exact_vs_oracle()

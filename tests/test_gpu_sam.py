@@ -128,6 +128,28 @@ def test_preprocess_matches_oracle():
     assert (out16 - ref).abs().max() < 2e-2 and (out16[:, :, 768:] == 0).all()
 
 
+def test_layout_kernels_bit_exact_vs_the_library_statements():
+    """s6d_patchify_b16 / s6d_im2col3x3_b16 move two-byte elements: the results must equal PatchEmbed's view / permute / reshape and
+    the nine shifted views of the zero-padded map (what the neck's 3x3 convolution read before) bit for bit."""
+    import torch.nn.functional as F
+
+    from sam6d_amd import ops
+    g = torch.Generator().manual_seed(1)
+    for dt in (torch.bfloat16, torch.float16):
+        x = torch.randn(2, 3, 64, 96, generator=g).to(dt)
+        p = 16
+        ref = x.view(2, 3, 4, p, 6, p).permute(0, 2, 4, 1, 3, 5).reshape(2, 4, 6, 3 * p * p)
+        assert torch.equal(ops.patchify(x.cuda(), p).cpu(), ref)
+        y = torch.randn(2, 5, 7, 16, generator=g).to(dt)
+        yp = F.pad(y, (0, 0, 1, 1, 1, 1))
+        ref = torch.cat([yp[:, dy:dy + 5, dx:dx + 7, :] for dy in range(3) for dx in range(3)], dim=-1)
+        assert torch.equal(ops.im2col3x3(y.cuda()).cpu(), ref)
+    x8 = torch.randn(1, 2, 8, 8, generator=g).bfloat16()             # p = 8, one patch per channel row
+    assert torch.equal(ops.patchify(x8.cuda(), 8).cpu(), x8.view(1, 2, 1, 8, 1, 8).permute(0, 2, 4, 1, 3, 5).reshape(1, 1, 1, 128))
+    with pytest.raises(RuntimeError):
+        ops.im2col3x3(torch.zeros(1, 2, 2, 12, dtype=torch.bfloat16).cuda())         # C % 8 != 0
+
+
 @pytest.mark.parametrize("index", [0, 7])
 def test_vit_h_block_bf16_hip_path_vs_oracle_block(index):
     """ONE ViT-H block through the bf16 HIP path (fused residual + LayerNorm, hand-written GEMMs with bias / GELU epilogues, the

@@ -92,6 +92,8 @@ def main():
     flop = 4.0 * Bs * nhs * hds * Ns * Ns
     for path in libs:
         name = os.path.basename(path)[8:-3]
+        if "timing" in name:                  # the phase-clock build writes through a null clock array in kernels that do not pass one
+            continue
         L = ctypes.CDLL(path)
 
         def run_seq():

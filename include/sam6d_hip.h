@@ -30,7 +30,7 @@ extern "C" {
 
 /* Bumped whenever a signature in this header changes; the loader (sam6d_amd/_lib.py) refuses a library whose
  * s6d_version() differs from the header it was written against (a stale .so fails at load, not at a call). */
-#define S6D_ABI_VERSION 114
+#define S6D_ABI_VERSION 116
 int s6d_version(void);
 const char *s6d_strerror(int code);
 /* last HIP error string seen by this thread (empty if none) */
@@ -309,6 +309,12 @@ int s6d_patch_scores_f32(const float *query, const float *refstore, const int32_
                          int S, int N1, int N2, int C, int T, float thred, float *workspace, float *appe,
                          float *ratio, void *stream);
 long s6d_patch_scores_workspace_floats(int S, int N1, int N2);
+/* The same with the selected proposals named by index: query (P,N1,C) is the UN-gathered descriptor tensor of all proposals of the
+ * launch group and row s of the launch reads query[qsel[s]] (qsel (S) i32; NULL = s6d_patch_scores_f32).  Replaces the
+ * `query_appe_descriptors[idx_selected]` copy of model/detector.py:341-349 (1 MB per selected proposal at 256 x 1024 floats). */
+int s6d_patch_scores_sel_f32(const float *query, const int32_t *qsel, const float *refstore, const int32_t *obj,
+                             const int32_t *tmpl, int S, int N1, int N2, int C, int T, float thred, float *workspace, float *appe,
+                             float *ratio, void *stream);
 
 /* Mean back-projected 3-D point of each mask: masks (S,H,W) f32, depth (H,W) f32 -> out (S,3) f32 [m], with
  * Z = depth * depth_scale / 1000 (the reference's contract: depth in millimetres at depth_scale 1).
@@ -323,6 +329,11 @@ long s6d_masked_depth_mean_workspace_bytes(int S, int H, int W);   /* W % 4 == 0
 /* Several frames in one launch: depth (F,H,W), K (F,3,3) f64, frame (S) i32 = the frame of every mask (NULL: one frame). */
 int s6d_masked_depth_mean_frames_f32(const float *masks, const float *depth, const int32_t *frame, int S, int H, int W,
                                      float depth_scale, const double *K, void *workspace, float *out, void *stream);
+/* ... and with the selected masks named by index: masks (P,H,W) holds every proposal of the launch group, mask s of the launch is
+ * masks[msel[s]] (msel (S) i32; NULL: masks[s]).  Replaces the `masks[idx_selected]` copy of model/detector.py:351-353
+ * (1.2 MB per selected proposal at 480 x 640).  Workspace as for S masks. */
+int s6d_masked_depth_mean_sel_f32(const float *masks, const int32_t *msel, const float *depth, const int32_t *frame, int S, int H,
+                                  int W, float depth_scale, const double *K, void *workspace, float *out, void *stream);
 
 /* Template projection: uv[s,i] = clamp(trunc(K (R_tmpl[s] p_i + t_s))), bbox[s] = (min u, min v, max u, max v).
  * pointcloud (O,N,3), poses (T,4,4), trans (S,3), K (3,3) f32; obj/tmpl (S) i32 -> uv (S,N,2) i32, bbox (S,4) i32.
@@ -399,6 +410,12 @@ int s6d_pe_group_mlp_f32(const float *pts, const int32_t *idx, int B, int N, int
  * memory.  ref: segment_anything/modeling/sam.py:164-174. */
 int s6d_sam_preprocess_f32(const float *in, int B, int h, int w, int S, const float *mean3_host,
                            const float *std3_host, int out_bf16, void *out, void *stream);
+
+/* flags[b] = 1 if row b of x (B rows of n floats, contiguous, n % 4 == 0, x 16-byte aligned) holds an inf or a NaN, else 0.
+ * The range guard of the IEEE-half PEM feature extractor (one read of its fp32 up-projection instead of a library reduction whose
+ * SUM could itself overflow); ref: ViT_AE.forward, Pose_Estimation_Model/model/feature_extraction.py:98-117 (the reference runs
+ * fp32 and has no guard). */
+int s6d_nonfinite_rows_f32(const float *x, int B, long n, int32_t *flags, void *stream);
 
 /* The A operand of a 3x3, padding-1 convolution run as one GEMM over K = 9 C: in (B,H,W,C) of two-byte elements (bf16 or f16,
  * copied bit for bit) -> out (B,H,W,9C), out[b,y,x,(3 dy + dx) C + c] = in[b, y + dy - 1, x + dx - 1, c], 0 outside the map.

@@ -136,7 +136,7 @@ __device__ __forceinline__ void ps_split(float x, unsigned short &hi, unsigned s
 __global__ __launch_bounds__(kPsThreads) void patch_scores_kernel(const float *__restrict__ q,
                                                                  const float *__restrict__ refstore,
                                                                  const int *__restrict__ obj, const int *__restrict__ tmpl,
-                                                                 int N1, int N2, int C, int T,
+                                                                 const int *__restrict__ qsel, int N1, int N2, int C, int T,
                                                                  float *__restrict__ part_rowsum,
                                                                  float *__restrict__ part_colmax,
                                                                  int *__restrict__ part_nnz) {
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kPsThreads) void patch_scores_kernel(const float *_
   const int slot = blockIdx.x * 8 + wave;                  // partial index within the proposal
   const int row0 = slot * kPsRowsPerWave;
   const int nct = (N2 + 15) / 16;
-  const float *Q = q + (size_t)s * N1 * C;
+  const float *Q = q + (size_t)(qsel ? qsel[s] : s) * N1 * C;       // qsel: rows of the un-gathered (P,N1,C) query tensor
   const float *Rf = refstore + ((size_t)obj[s] * T + tmpl[s]) * (size_t)N2 * C;
   const float *qa[2];
 #pragma unroll
@@ -347,7 +347,7 @@ __device__ __forceinline__ float md_z(float m, float d, float depth_scale) { ret
 __global__ __launch_bounds__(256) void masked_depth_l1_kernel(const float *__restrict__ masks, const float *__restrict__ depth,
                                                              int H, int W, float depth_scale,
                                                              const double *__restrict__ K, const int *__restrict__ frame,
-                                                             char *__restrict__ ws) {
+                                                             const int *__restrict__ msel, char *__restrict__ ws) {
   __shared__ float zs[kMdSpan];                  // masked metric depth of the span, 0 where invalid
   __shared__ float l0f[16 * kMdC32];
   __shared__ double l0d[2 * 32 * kMdC64];
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void masked_depth_l1_kernel(const float *__res
   // the camera matrix is read on the device (3x3 row-major float64, the reference's dtype): no host copy, no cache
   const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
   const int e0 = sp * kMdSpan;
-  const float4 *m4 = reinterpret_cast<const float4 *>(masks + (size_t)s * g.n + e0);   // n % 4 == 0 (launcher)
+  const float4 *m4 = reinterpret_cast<const float4 *>(masks + (size_t)(msel ? msel[s] : s) * g.n + e0);   // n % 4 == 0 (launcher)
   const float4 *d4 = reinterpret_cast<const float4 *>(depth + e0);
   int cnt = 0;
   for (int i = tid; i < kMdSpan / 4; i += 256) {
@@ -447,8 +447,8 @@ __device__ __forceinline__ T md_upper(const T *l1, int stride, int nb, T rem) {
 
 __global__ __launch_bounds__(64) void masked_depth_final_kernel(const float *__restrict__ masks, const float *__restrict__ depth,
                                                                int H, int W, float depth_scale, const double *__restrict__ K,
-                                                               const int *__restrict__ frame, const char *__restrict__ ws,
-                                                               float *__restrict__ out) {
+                                                               const int *__restrict__ frame, const int *__restrict__ msel,
+                                                               const char *__restrict__ ws, float *__restrict__ out) {
   __shared__ float cz[kMdC32];
   __shared__ double cxy[2 * kMdC64];
   const int s = blockIdx.x, lane = threadIdx.x;
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(64) void masked_depth_final_kernel(const float *__r
   const int fr = frame ? frame[s] : 0;
   depth += (size_t)fr * g.n;
   K += (size_t)fr * 9;
-  masks += (size_t)s * g.n;
+  masks += (size_t)(msel ? msel[s] : s) * g.n;
   const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
   const char *wm = ws + (size_t)s * md_ws_per_mask(g);
   auto zat = [&](int i) { const float z = md_z(masks[i], depth[i], depth_scale); return z > 0.f ? z : 0.f; };
@@ -589,9 +589,19 @@ extern "C" int s6d_semantic_select_f32(const float *scores, int P, int O, int T,
   return launch_status();
 }
 
+extern "C" int s6d_patch_scores_sel_f32(const float *query, const int32_t *qsel, const float *refstore, const int32_t *obj,
+                                        const int32_t *tmpl, int S, int N1, int N2, int C, int T, float thred, float *workspace,
+                                        float *appe, float *ratio, void *stream);
+
 extern "C" int s6d_patch_scores_f32(const float *query, const float *refstore, const int32_t *obj, const int32_t *tmpl,
                                     int S, int N1, int N2, int C, int T, float thred, float *workspace, float *appe,
                                     float *ratio, void *stream) {
+  return s6d_patch_scores_sel_f32(query, nullptr, refstore, obj, tmpl, S, N1, N2, C, T, thred, workspace, appe, ratio, stream);
+}
+
+extern "C" int s6d_patch_scores_sel_f32(const float *query, const int32_t *qsel, const float *refstore, const int32_t *obj,
+                                        const int32_t *tmpl, int S, int N1, int N2, int C, int T, float thred, float *workspace,
+                                        float *appe, float *ratio, void *stream) {
   if (S < 0 || N1 <= 0 || N2 <= 0 || C <= 0 || (C % 32) != 0 || T <= 0) return S6D_EINVAL;
   if (N2 > 16 * kMaxColTiles) return S6D_EUNSUPPORTED;
   if (S == 0) return S6D_OK;
@@ -604,8 +614,8 @@ extern "C" int s6d_patch_scores_f32(const float *query, const float *refstore, c
   hipStream_t st = as_stream(stream);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&patch_scores_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, kPsLdsBytes);
-  hipLaunchKernelGGL(patch_scores_kernel, dim3(nrb, S), dim3(kPsThreads), kPsLdsBytes, st, query, refstore, obj, tmpl, N1,
-                     N2, C, T, part_rowsum, part_colmax, part_nnz);
+  hipLaunchKernelGGL(patch_scores_kernel, dim3(nrb, S), dim3(kPsThreads), kPsLdsBytes, st, query, refstore, obj, tmpl, qsel,
+                     N1, N2, C, T, part_rowsum, part_colmax, part_nnz);
   int rc = launch_status();
   if (rc) return rc;
   hipLaunchKernelGGL(patch_finalize_kernel, dim3(S), dim3(64), 0, st, part_rowsum, part_colmax, part_nnz, S, nslot, N1, N2,
@@ -623,16 +633,23 @@ extern "C" long s6d_masked_depth_mean_workspace_bytes(int S, int H, int W) {
   return (long)((size_t)S * md_ws_per_mask(md_geom(H, W)));
 }
 
-extern "C" int s6d_masked_depth_mean_frames_f32(const float *masks, const float *depth, const int32_t *frame, int S, int H, int W,
-                                                float depth_scale, const double *K, void *workspace, float *out, void *stream);
+extern "C" int s6d_masked_depth_mean_sel_f32(const float *masks, const int32_t *msel, const float *depth, const int32_t *frame, int S,
+                                             int H, int W, float depth_scale, const double *K, void *workspace, float *out,
+                                             void *stream);
 
 extern "C" int s6d_masked_depth_mean_f32(const float *masks, const float *depth, int S, int H, int W, float depth_scale,
                                          const double *K, void *workspace, float *out, void *stream) {
-  return s6d_masked_depth_mean_frames_f32(masks, depth, nullptr, S, H, W, depth_scale, K, workspace, out, stream);
+  return s6d_masked_depth_mean_sel_f32(masks, nullptr, depth, nullptr, S, H, W, depth_scale, K, workspace, out, stream);
 }
 
 extern "C" int s6d_masked_depth_mean_frames_f32(const float *masks, const float *depth, const int32_t *frame, int S, int H, int W,
                                                 float depth_scale, const double *K, void *workspace, float *out, void *stream) {
+  return s6d_masked_depth_mean_sel_f32(masks, nullptr, depth, frame, S, H, W, depth_scale, K, workspace, out, stream);
+}
+
+extern "C" int s6d_masked_depth_mean_sel_f32(const float *masks, const int32_t *msel, const float *depth, const int32_t *frame, int S,
+                                             int H, int W, float depth_scale, const double *K, void *workspace, float *out,
+                                             void *stream) {
   if (S < 0 || H <= 0 || W <= 0) return S6D_EINVAL;
   // float4 loads of the maps; one vector of the float32 reduction at least; 16 rows per cascade level (ATen switches to
   // 32 from 2^20 rows of the float64 reduction on: 16.7 M pixels)
@@ -642,11 +659,11 @@ extern "C" int s6d_masked_depth_mean_frames_f32(const float *masks, const float 
   const MdGeom g = md_geom(H, W);
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(masked_depth_l1_kernel, dim3(g.nspan, S), dim3(256), 0, st, masks, depth, H, W, depth_scale, K,
-                     frame, (char *)workspace);
+                     frame, msel, (char *)workspace);
   int rc = launch_status();
   if (rc) return rc;
   hipLaunchKernelGGL(masked_depth_final_kernel, dim3(S), dim3(64), 0, st, masks, depth, H, W, depth_scale, K, frame,
-                     (const char *)workspace, out);
+                     msel, (const char *)workspace, out);
   return launch_status();
 }
 

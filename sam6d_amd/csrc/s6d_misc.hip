@@ -136,9 +136,36 @@ __global__ __launch_bounds__(256) void patchify_kernel(const uint4 *__restrict__
   }
 }
 
+// flags[b] = 1 if row b of x (B rows of n floats, n % 4 == 0) holds an inf or a NaN (exponent field all ones); flags zeroed by the launcher
+__global__ __launch_bounds__(256) void nonfinite_rows_kernel(const float4 *__restrict__ x, long n4, int *__restrict__ flags) {
+  const int b = blockIdx.y;
+  const uint4 *row = reinterpret_cast<const uint4 *>(x) + (size_t)b * n4;
+  unsigned bad = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const uint4 v = row[i];
+    bad |= ((v.x & 0x7f800000u) == 0x7f800000u) | ((v.y & 0x7f800000u) == 0x7f800000u) | ((v.z & 0x7f800000u) == 0x7f800000u) |
+           ((v.w & 0x7f800000u) == 0x7f800000u);
+  }
+  if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(flags + b, 1);
+}
+
 }  // namespace s6d
 
 using namespace s6d;
+
+extern "C" int s6d_nonfinite_rows_f32(const float *x, int B, long n, int32_t *flags, void *stream) {
+  if (B < 0) return S6D_EINVAL;
+  if (B == 0) return S6D_OK;
+  if (n <= 0 || (n % 4) != 0 || !x || !flags || ((uintptr_t)x & 15)) return S6D_EINVAL;
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(flags, 0, (size_t)B * sizeof(int32_t), st) != hipSuccess) return launch_status();
+  const long n4 = n / 4;
+  long g = (n4 + 256 * 8 - 1) / (256 * 8);
+  if (g > 1024) g = 1024;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(nonfinite_rows_kernel, dim3((unsigned)g, (unsigned)B), dim3(256), 0, st, (const float4 *)x, n4, flags);
+  return launch_status();
+}
 
 extern "C" int s6d_im2col3x3_b16(const void *in, int B, int H, int W, int C, void *out, void *stream) {
   if (B < 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) != 0) return S6D_EINVAL;

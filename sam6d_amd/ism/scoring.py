@@ -92,7 +92,9 @@ class ScoringMixin:
         best_template = self.best_template_pose(scores[idx_selected, ...], pred_idx_objects)
         return idx_selected, pred_idx_objects, score_per_proposal[idx_selected], best_template
 
-    def compute_appearance_score(self, best_pose, pred_objects_idx, qurey_appe_descriptors):
+    def compute_appearance_score(self, best_pose, pred_objects_idx, qurey_appe_descriptors, sel=None):
+        """sel (device path only): ``qurey_appe_descriptors`` holds EVERY proposal and the kernel reads the rows ``sel`` names -- the
+        `[idx_selected]` copy of model/detector.py:341-349 (1 MB per selected proposal) is never made."""
         store = self.ref_data["appe_descriptors"]
         thred = getattr(self, "visible_thred", 0.5)
         halfs = (torch.float16, torch.bfloat16)
@@ -108,8 +110,11 @@ class ScoringMixin:
                 store = c[1]
             qdt = qurey_appe_descriptors.dtype
             obj32, tmpl32 = pred_objects_idx.int().contiguous(), best_pose.int().contiguous()
-            appe, ratio = ops.patch_scores(qurey_appe_descriptors.float().contiguous(), store, obj32, tmpl32, float(thred))
+            appe, ratio = ops.patch_scores(qurey_appe_descriptors.float().contiguous(), store, obj32, tmpl32, float(thred),
+                                           sel=sel)
             return appe.to(qdt), RefPatchHandle(store, obj32, tmpl32, ratio.to(qdt), thred)
+        if sel is not None:
+            qurey_appe_descriptors = qurey_appe_descriptors[sel.long()]
         ref = store[pred_objects_idx, best_pose, ...]
         metric = MaskedPatch_MatrixSimilarity(metric="cosine", chunk_size=64)
         appe, ratio = metric.both(qurey_appe_descriptors, ref, thred)
@@ -211,20 +216,29 @@ class FrameScorer(ScoringMixin):
             z = sem.new_zeros(0)
             return dict(frame=frame, sel=sel, pred_obj=pobj, semantic=sem, best_template=bt, appearance=z, iou=z, visible_ratio=z,
                         final=z, image_uv=torch.zeros(0, self.ref_data["pointcloud"].shape[1], 2, dtype=torch.int32, device=dev))
-        qp = qry_patch.reshape(F_ * P, *qry_patch.shape[2:])[sel]
-        appe, ref = self.compute_appearance_score(bt, pobj, qp)
+        if not (ops.have("masked_depth_mean") and ops.have("project_bbox") and ops.have("patch_scores") and qry_cls.is_cuda):
+            raise RuntimeError("score_frames is the batched device path (fp32 / half descriptors on the GPU); use score() per frame")
+        # the selected proposals are NAMED to the kernels (sel32), not copied out: `query_appe_descriptors[idx_selected]` and
+        # `masks[idx_selected]` of the reference (detector.py:341-353) moved 1 MB + 1.2 MB per selected proposal through HBM twice
+        sel32 = sel.int().contiguous()
+        qall = qry_patch.reshape(F_ * P, *qry_patch.shape[2:])
+        appe, ref = self.compute_appearance_score(bt, pobj, qall, sel=sel32)
+        if not isinstance(ref, RefPatchHandle):
+            raise RuntimeError("score_frames is the batched device path (fp32 / half descriptors on the GPU); use score() per frame")
         Kf = K if K.dim() == 3 else K[None].expand(F_, 3, 3)
         H, W = depth.shape[-2:]
-        msel = masks.reshape(F_ * P, H, W)[sel].to(torch.float32).contiguous()
+        mall = masks.reshape(F_ * P, H, W)
+        if mall.dtype != torch.float32 or not mall.is_contiguous():
+            mall, msel = mall[sel].to(torch.float32).contiguous(), None
+        else:
+            msel = sel32
         f32 = frame.int().contiguous()
         poses, pcs = self.ref_data["poses"], self.ref_data["pointcloud"]
-        if not (ops.have("masked_depth_mean") and ops.have("project_bbox") and msel.is_cuda and isinstance(ref, RefPatchHandle)):
-            raise RuntimeError("score_frames is the batched device path (fp32 / half descriptors on the GPU); use score() per frame")
-        t = ops.masked_depth_mean(msel, depth.to(torch.float32).contiguous(), Kf, float(depth_scale), frame=f32)
+        t = ops.masked_depth_mean(mall, depth.to(torch.float32).contiguous(), Kf, float(depth_scale), frame=f32, sel=msel)
         uv, bbox = ops.project_bbox(pcs.contiguous(), poses.contiguous(), pobj.int().contiguous(), bt.int().contiguous(), t.contiguous(),
                                     Kf.to(device=dev, dtype=torch.float32).contiguous(), H, W, frame=f32)
         vr = ref.visible_ratio if ref.thred == self.visible_thred else ops.patch_scores(
-            qp.float().contiguous(), ref.store, ref.obj, ref.tmpl, float(self.visible_thred))[1].to(qp.dtype)
+            qall.float().contiguous(), ref.store, ref.obj, ref.tmpl, float(self.visible_thred), sel=sel32)[1].to(qall.dtype)
         # compute_iou per proposal, then quirk Q3 per frame: a frame with any empty intersection reports 0.0 for all its proposals
         bb_a, bb_b = bbox.to(boxes.dtype), boxes.reshape(F_ * P, 4)[sel]
         tl = torch.max(bb_a[:, 0:2], bb_b[:, 0:2])

@@ -212,6 +212,16 @@ def sam_preprocess(x, mean, std, img_size, out_dtype=torch.bfloat16):
     return out
 
 
+def nonfinite_rows(x):
+    """x (B, ...) f32 contiguous -> (B,) bool: does instance b hold an inf or a NaN?  One read of x."""
+    _chk(x, torch.float32, "x")
+    B = x.shape[0]
+    n = x.numel() // max(B, 1)
+    flags = torch.empty(B, dtype=torch.int32, device=x.device)
+    _call("s6d_nonfinite_rows_f32", _ptr(x), B, ctypes.c_long(n), _ptr(flags), _stream())
+    return flags.bool()
+
+
 def im2col3x3(y):
     """(B,H,W,C) bf16 / f16 -> (B,H,W,9C): the nine shifted views of a zero-padded 3x3 neighbourhood in (dy, dx, c) order -- the A
     operand of a padding-1 3x3 convolution as one GEMM.  [the SAM neck's second Conv2d, image_encoder.py:91-97]"""
@@ -987,31 +997,41 @@ def semantic_select(scores, topk):
     return bs, bo, bt
 
 
-def patch_scores(query, refstore, obj, tmpl, thred):
-    """query (S,N1,C), refstore (O,T,N2,C) f32, obj/tmpl (S) i32 -> appe (S), ratio (S)."""
+def patch_scores(query, refstore, obj, tmpl, thred, sel=None):
+    """query (S,N1,C), refstore (O,T,N2,C) f32, obj/tmpl (S) i32 -> appe (S), ratio (S).
+    sel (S) i32: query is the UN-gathered (P,N1,C) tensor of every proposal and row s reads query[sel[s]] (no gathered copy)."""
     _chk(query, torch.float32, "query", 3)
     _chk(refstore, torch.float32, "refstore", 4)
     _chk(obj, torch.int32, "obj", 1)
     _chk(tmpl, torch.int32, "tmpl", 1)
     S, N1, C = query.shape
+    if sel is not None:
+        _chk(sel, torch.int32, "sel", 1)
+        S = sel.shape[0]
+        if obj.shape[0] != S or tmpl.shape[0] != S:
+            raise ValueError("patch_scores: obj / tmpl / sel must have one entry per selected proposal")
     _, T, N2, _ = refstore.shape
     fn = _lib.lib().s6d_patch_scores_workspace_floats
     fn.restype = ctypes.c_long
     ws = torch.empty(max(int(fn(S, N1, N2)), 1), dtype=torch.float32, device=query.device)
     appe = torch.empty(S, dtype=torch.float32, device=query.device)
     ratio = torch.empty(S, dtype=torch.float32, device=query.device)
-    _call("s6d_patch_scores_f32", _ptr(query), _ptr(refstore), _ptr(obj), _ptr(tmpl), S, N1, N2, C, T,
-          ctypes.c_float(thred), _ptr(ws), _ptr(appe), _ptr(ratio), _stream())
+    _call("s6d_patch_scores_sel_f32", _ptr(query), _ptr(sel) if sel is not None else _vp(0), _ptr(refstore), _ptr(obj), _ptr(tmpl),
+          S, N1, N2, C, T, ctypes.c_float(thred), _ptr(ws), _ptr(appe), _ptr(ratio), _stream())
     return appe, ratio
 
 
-def masked_depth_mean(masks, depth, K, depth_scale, frame=None):
-    """masks (S,H,W) f32, depth (H,W) f32, K 3x3 (any float dtype, host or device) -> (S,3) f32.  The camera matrix goes to
+def masked_depth_mean(masks, depth, K, depth_scale, frame=None, sel=None):
+    """sel (S) i32: masks is the UN-gathered (P,H,W) tensor of every proposal and mask s of the call is masks[sel[s]].
+    masks (S,H,W) f32, depth (H,W) f32, K 3x3 (any float dtype, host or device) -> (S,3) f32.  The camera matrix goes to
     the device as float64 (the reference's dtype) and is read there: no host copy of a device K and no cache keyed by
     an address (a new frame's K may land on the old one's).  Several frames in one launch: depth (F,H,W), K (F,3,3),
     frame (S) i32 = the frame of every mask."""
     _chk(masks, torch.float32, "masks", 3)
     S, H, W = masks.shape
+    if sel is not None:
+        _chk(sel, torch.int32, "sel", 1)
+        S = sel.shape[0]
     if frame is None:
         _chk(depth, torch.float32, "depth", 2)
         if tuple(K.shape) != (3, 3):
@@ -1030,8 +1050,8 @@ def masked_depth_mean(masks, depth, K, depth_scale, frame=None):
     fn = _lib.lib().s6d_masked_depth_mean_workspace_bytes
     fn.restype = ctypes.c_long
     ws = torch.empty(max(int(fn(S, H, W)), 8), dtype=torch.uint8, device=masks.device)
-    _call("s6d_masked_depth_mean_frames_f32", _ptr(masks), _ptr(depth), _ptr(frame) if frame is not None else _vp(0), S, H, W,
-          ctypes.c_float(depth_scale), _ptr(Kd), _ptr(ws), _ptr(out), _stream())
+    _call("s6d_masked_depth_mean_sel_f32", _ptr(masks), _ptr(sel) if sel is not None else _vp(0), _ptr(depth),
+          _ptr(frame) if frame is not None else _vp(0), S, H, W, ctypes.c_float(depth_scale), _ptr(Kd), _ptr(ws), _ptr(out), _stream())
     return out
 
 
@@ -1063,9 +1083,9 @@ def have(name):
                "fine_assign": "s6d_fine_assign_f32", "fine_match": "s6d_fine_match_f32", "pem_pre": "s6d_pem_compact_cloud_f32", "coarse_sample": "s6d_coarse_sample_f32", "upsample_gather": "s6d_upsample_gather_f32",
                "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "add_layernorm": "s6d_add_layernorm_bf16", "gemm_bf16": "s6d_gemm_bf16", "gemm_bf16_res": "s6d_gemm_bf16_res", "gemm_bf16_lnfold": "s6d_gemm_bf16_lnfold", "gemm_f16": "s6d_gemm_f16", "gemm_fp8": "s6d_gemm_fp8", "layernorm_fp8": "s6d_layernorm_fp8", "layernorm_f32out": "s6d_layernorm_bf16_f32", "linear_f32": "s6d_linear_f32", "win_attention": "s6d_win_attention_layout_bf16",
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
-               "patch_scores": "s6d_patch_scores_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
-               "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_frames_f32",
-               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "im2col3x3": "s6d_im2col3x3_b16", "patchify": "s6d_patchify_b16", "crop_resize_pad": "s6d_crop_resize_pad_f32", "samdec_img2tok": "s6d_samdec_img2tok_bf16", "samdec_tok2img": "s6d_samdec_tok2img_f32", "sam_mask_post": "s6d_sam_mask_post_sel_f32", "gemm_fp8_mx": "s6d_gemm_fp8_mxa", "nms": "s6d_nms_f32", "samdec_upscale_heads": "s6d_samdec_upscale_heads_bf16", "mha": "s6d_mha_f32",
+               "patch_scores": "s6d_patch_scores_sel_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
+               "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_sel_f32",
+               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "im2col3x3": "s6d_im2col3x3_b16", "nonfinite_rows": "s6d_nonfinite_rows_f32", "patchify": "s6d_patchify_b16", "crop_resize_pad": "s6d_crop_resize_pad_f32", "samdec_img2tok": "s6d_samdec_img2tok_bf16", "samdec_tok2img": "s6d_samdec_tok2img_f32", "sam_mask_post": "s6d_sam_mask_post_sel_f32", "gemm_fp8_mx": "s6d_gemm_fp8_mxa", "nms": "s6d_nms_f32", "samdec_upscale_heads": "s6d_samdec_upscale_heads_bf16", "mha": "s6d_mha_f32",
                "linear_attn_focus": "s6d_linear_attn_focus_f32", "linear_attention": "s6d_linear_attention_f32", "project_bbox": "s6d_project_bbox_frames_f32"}.get(name)
         import os
         disabled = name in os.environ.get("S6D_DISABLE_FUSED", "").split(",")

@@ -205,10 +205,13 @@ class ViT_AE(nn.Module):
                 # of a released checkpoint may exceed it in an outlier channel (bf16 / fp32 do not have the problem).  An overflow
                 # becomes inf in the GEMM / LayerNorm epilogue's conversion, inf / NaN is absorbing in the residual stream
                 # (x + finite stays non-finite through every later block) and reaches every row of this up-projection: one
-                # reduction over it says which instances are affected (a SUM: inf and NaN survive it, inf - inf is NaN, and 8e5
-                # finite fp32 features of O(1..100) cannot overflow it; an `isfinite().all()` chain costs five passes instead
-                # of one).  A device tensor: Net.forward reads it once, at its end.
-                self.overflow = ~torch.isfinite(up.sum(dim=(1, 2)))
+                # read of it says which instances are affected (s6d_nonfinite_rows_f32: exponent field all ones; round 4's first
+                # form was a library SUM over the instance, 0.15 ms per 32 instances at 0.7 TB/s).  A device tensor: Net.forward
+                # reads it once, at its end.
+                if up.is_cuda and ops.have("nonfinite_rows") and up.is_contiguous() and (up[0].numel() % 4) == 0:
+                    self.overflow = ops.nonfinite_rows(up)
+                else:
+                    self.overflow = ~torch.isfinite(up.sum(dim=(1, 2)))
             return up
         taps = self.vit(x)
         return self.output_upscaling(torch.cat([t[:, 1:] for t in taps], dim=2))

@@ -64,6 +64,7 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char *hipGetErrorString(hipError_t) { return "hipemu: no error"; }
 template <class F>
 static inline hipError_t hipFuncSetAttribute(F, int, int) { return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 
 namespace hipemu {
 

@@ -221,6 +221,25 @@ def test_real_example_frame_through_preprocessing_and_net(net):
     assert dR.max() <= R_TOL and dt <= T_TOL_M, (dR, dt)
 
 
+def test_nonfinite_rows_kernel_flags_exactly_the_rows_with_inf_or_nan():
+    """s6d_nonfinite_rows_f32 (the range guard's one read of the up-projection): rows with an inf or a NaN anywhere -- first element,
+    last element, a single one in 800 k -- are flagged and no other; large FINITE values (whose library SUM would overflow to inf,
+    a false alarm of round 4's first form) are not."""
+    from sam6d_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(6, 196, 64, generator=g)
+    x[1, 0, 0] = float("inf")
+    x[2, -1, -1] = float("nan")
+    x[3, 100, 7] = float("-inf")
+    x[4] = 3.0e38                                      # finite; the sum of the row is inf in fp32
+    out = ops.nonfinite_rows(x.cuda()).cpu()
+    assert out.tolist() == [False, True, True, True, False, False]
+    assert ops.nonfinite_rows(torch.zeros(0, 8).cuda()).shape == (0,)
+    big = torch.zeros(2, 802816)
+    big[1, 777777] = float("nan")
+    assert ops.nonfinite_rows(big.cuda()).cpu().tolist() == [False, True]
+
+
 def test_fp16_extractor_range_guard_reruns_overflowing_instances_in_fp32(net, monkeypatch):
     """VERDICT r3 missing #7: the IEEE-half ViT-B has the range 65504; a released checkpoint with an outlier channel must not turn
     the pose into NaN silently.  An outlier of 1e5 is planted in one channel of the residual stream (fc2 bias of block 3): every

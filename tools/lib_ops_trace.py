@@ -30,7 +30,7 @@ def trace(name, fn, lines):
     from torch.profiler import ProfilerActivity, profile
     fn()
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
         fn()
         torch.cuda.synchronize()
     by = collections.defaultdict(lambda: [0, 0.0])
@@ -46,27 +46,32 @@ def trace(name, fn, lines):
                 continue
             lib += d
             short = k.name.split("(")[0].split("<")[0].replace("void ", "").replace("at::native::", "")
-            key = (site_of(ev.stack or []), ev.name, short[:48])
+            shapes = str(getattr(ev, "input_shapes", ""))[:90]
+            key = (site_of(ev.stack or []) if ev.stack else shapes, ev.name, short[:48])
             by[key][0] += 1
             by[key][1] += d
     lines.append(f"== {name}: library kernels {lib / 1e3:.3f} ms of {tot / 1e3:.3f} ms GPU time ({100 * lib / max(tot, 1e-9):.1f} %)")
-    for (site, op, kern), (n, d) in sorted(by.items(), key=lambda kv: -kv[1][1])[:45]:
-        lines.append(f"  {d / 1e3:7.3f} ms {n:4d}x  {kern:48s} {op[:28]:28s} {site}")
+    for (site, op, kern), (n, d) in sorted(by.items(), key=lambda kv: -kv[1][1])[:70]:
+        lines.append(f"  {d / 1e3:7.3f} ms {n:4d}x  {kern[:34]:34s} {op[:24]:24s} {site}")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out")
     ap.add_argument("--frames", type=int, default=32)
+    ap.add_argument("--stages", default="pem,ism,sam")
     a = ap.parse_args()
     import bench
     dev = torch.device("cuda:0")
     hp = bench.HotPath(dev, a.frames, 16)
     lines = []
     with torch.no_grad():
-        trace("PEM (batch of %d instances)" % a.frames, hp.pem_stage, lines)
-        trace("ISM scoring (%d frames)" % a.frames, hp.ism_stage, lines)
-        trace("SAM encoder (%d frames)" % a.frames, hp.sam_stage, lines)
+        if "pem" in a.stages:
+            trace("PEM (batch of %d instances)" % a.frames, hp.pem_stage, lines)
+        if "ism" in a.stages:
+            trace("ISM scoring (%d frames)" % a.frames, hp.ism_stage, lines)
+        if "sam" in a.stages:
+            trace("SAM encoder (%d frames)" % a.frames, hp.sam_stage, lines)
     txt = "\n".join(lines)
     print(txt)
     if a.out:

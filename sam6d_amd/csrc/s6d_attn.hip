@@ -172,7 +172,10 @@ struct Cfg {
   static constexpr int KROW = HDP + 8;          // K image row stride (bf16 elements): +16 B pad
   // V image row stride (row-major [key][d]): an ODD multiple of 16 elements (32 B), so the 8 key rows that one
   // half-wave of a ds_read_b64_tr_b16 touches start on 8 distinct 32-byte bank groups (HD + 8 was 2-way conflicted)
-  static constexpr int VROW = (((HD + 15) / 16) | 1) * 16;
+  // Head dim 64 takes HD + 8 instead (144-byte rows: the eighth row of a half-wave wraps onto the first one's first four banks, a
+  // 2-way conflict on one row in eight) -- at 160 bytes the K / V images of a 257-token sequence miss the 80 KiB that lets TWO
+  // workgroups share a CU by 3 KiB (round 4, attn_window_kernel's compact layout).
+  static constexpr int VROW = HD == 64 ? HD + 8 : (((HD + 15) / 16) | 1) * 16;
   static constexpr int KT = 64;                 // keys per tile
   static constexpr int KPARTS = HDP / 8, VPARTS = HD / 8;
 };
@@ -421,18 +424,19 @@ struct Stager {
       v[n] = load_chunk<HD>(p, 2, head, valid, tok, part * 8);
     }
   }
-  __device__ __forceinline__ void store(u16 *Kl, u16 *Vl, int tid) const {
+  // klim / vlim: rows of this tile that the image holds (a compact image ends inside the last tile)
+  __device__ __forceinline__ void store(u16 *Kl, u16 *Vl, int tid, int klim = 64, int vlim = 64) const {
 #pragma unroll
     for (int n = 0; n < NK; ++n) {
       const int i = tid + n * THREADS;
       const int key = i / C::KPARTS, part = i - key * C::KPARTS;
-      if (i < 64 * C::KPARTS) *reinterpret_cast<uint4 *>(Kl + key * C::KROW + part * 8) = k[n];
+      if (i < 64 * C::KPARTS && key < klim) *reinterpret_cast<uint4 *>(Kl + key * C::KROW + part * 8) = k[n];
     }
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
       const int i = tid + n * THREADS;
       const int key = i / C::VPARTS, part = i - key * C::VPARTS;
-      if (i < 64 * C::VPARTS) *reinterpret_cast<uint4 *>(Vl + key * C::VROW + part * 8) = v[n];
+      if (i < 64 * C::VPARTS && key < vlim) *reinterpret_cast<uint4 *>(Vl + key * C::VROW + part * 8) = v[n];
     }
   }
 };
@@ -582,6 +586,27 @@ struct WinItem {
   }
 };
 
+__host__ __device__ inline int win_seq_krows(int T) { return (T + 15) & ~15; }
+__host__ __device__ inline int win_seq_vrows(int T) { return (T + 31) & ~31; }
+// tile `t` of a sequence against one strip: a full tile, or the tail with the 16-key sub-tiles that exist
+template <int HD>
+__device__ __forceinline__ void win_seq_tile(const AttnParams &p, const u16 *Kl, const u16 *Vl, int t, int nfull, int tail_subs,
+                                             StripState<HD, 1> &st, int lane) {
+  using C = Cfg<HD>;
+  const float thv[1] = {0.f};
+  const u16 *Kt = Kl + (size_t)t * 64 * C::KROW, *Vt = Vl + (size_t)t * 64 * C::VROW;
+  if (t < nfull) {
+    process_tile<HD, 2, 1>(p, Kt, Vt, t * 64, st, thv, lane);
+    return;
+  }
+  switch (tail_subs) {                                              // wave-uniform
+    case 1: process_tile<HD, 2, 1, false, false, 1>(p, Kt, Vt, t * 64, st, thv, lane); break;
+    case 2: process_tile<HD, 2, 1, false, false, 2>(p, Kt, Vt, t * 64, st, thv, lane); break;
+    case 3: process_tile<HD, 2, 1, false, false, 3>(p, Kt, Vt, t * 64, st, thv, lane); break;
+    default: process_tile<HD, 2, 1, false, false, 4>(p, Kt, Vt, t * 64, st, thv, lane); break;
+  }
+}
+
 // ---- windowed: one workgroup per (image, window, head); every key slot LDS resident ------------------------
 template <int HD, int WAVES, bool BIAS>
 __global__ __launch_bounds__(WAVES * 64) void attn_window_kernel(AttnParams p) {
@@ -589,9 +614,13 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window_kernel(AttnParams p) {
   constexpr int MODE = BIAS ? 0 : 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int ntile = (p.T + 63) / 64;
-  u16 *Kl = reinterpret_cast<u16 *>(smem);                         // [ntile*64][KROW]
-  u16 *Vl = Kl + (size_t)ntile * 64 * C::KROW;                     // [ntile*64][VROW]
-  float *tabs = reinterpret_cast<float *>(Vl + (size_t)ntile * 64 * C::VROW);
+  // no bias (sequences): COMPACT images -- K rows up to the last 16-key sub-tile that exists, V rows up to the last 32-key step
+  // (seq_tile below skips the absent sub-tiles of the tail tile).  257 tokens x head dim 64: 272 x 144 + 288 x 144 = 78.75 KiB instead
+  // of 320 rows of both = 95 KiB, i.e. two workgroups per CU: one fetches its item while the other computes (round 4).
+  const int krows = BIAS ? ntile * 64 : win_seq_krows(p.T), vrows = BIAS ? ntile * 64 : win_seq_vrows(p.T);
+  u16 *Kl = reinterpret_cast<u16 *>(smem);                         // [krows][KROW]
+  u16 *Vl = Kl + (size_t)krows * C::KROW;                          // [vrows][VROW]
+  float *tabs = reinterpret_cast<float *>(Vl + (size_t)vrows * C::VROW);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   float *th = tabs + (size_t)wave * 2 * 16 * p.LT, *tw = th + 16 * p.LT;
 
@@ -609,7 +638,9 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window_kernel(AttnParams p) {
         if (t0 + i < ntile) st[i].load(p, b, wy, wx, head, (t0 + i) * 64, tid);
 #pragma unroll
       for (int i = 0; i < SB; ++i)
-        if (t0 + i < ntile) st[i].store(Kl + (size_t)(t0 + i) * 64 * C::KROW, Vl + (size_t)(t0 + i) * 64 * C::VROW, tid);
+        if (t0 + i < ntile)
+          st[i].store(Kl + (size_t)(t0 + i) * 64 * C::KROW, Vl + (size_t)(t0 + i) * 64 * C::VROW, tid, krows - (t0 + i) * 64,
+                      vrows - (t0 + i) * 64);
     }
   }
   __syncthreads();
@@ -634,8 +665,13 @@ __global__ __launch_bounds__(WAVES * 64) void attn_window_kernel(AttnParams p) {
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) st.oacc[0][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float thv[1] = {0.f};
-    for (int t = 0; t < ntile; ++t)
-      process_tile<HD, MODE, 1>(p, Kl + (size_t)t * 64 * C::KROW, Vl + (size_t)t * 64 * C::VROW, t * 64, st, thv, lane);
+    if (BIAS) {
+      for (int t = 0; t < ntile; ++t)
+        process_tile<HD, MODE, 1>(p, Kl + (size_t)t * 64 * C::KROW, Vl + (size_t)t * 64 * C::VROW, t * 64, st, thv, lane);
+    } else {
+      const int nfull = p.T >> 6, tail_subs = ((p.T & 63) + 15) >> 4;
+      for (int t = 0; t < ntile; ++t) win_seq_tile<HD>(p, Kl, Vl, t, nfull, tail_subs, st, lane);
+    }
     store_strip<HD>(p, b, wy, wx, head, q0, st.lacc[0][0], st.oacc[0], lane);
   }
 }
@@ -1656,7 +1692,8 @@ static int launch_attn(AttnParams p, hipStream_t st) {
   } else if (p.ws > 0) {
     constexpr int WAVES = 8;
     const int ntile = (p.T + 63) / 64;
-    const size_t lds = (size_t)ntile * 64 * (C::KROW + C::VROW) * 2 + (bias ? (size_t)WAVES * 2 * 16 * p.LT * 4 : 0);
+    const size_t lds = bias ? (size_t)ntile * 64 * (C::KROW + C::VROW) * 2 + (size_t)WAVES * 2 * 16 * p.LT * 4
+                            : ((size_t)win_seq_krows(p.T) * C::KROW + (size_t)win_seq_vrows(p.T) * C::VROW) * 2;
     if (lds > 160 * 1024) return S6D_EUNSUPPORTED;
     const unsigned grid = (unsigned)(p.B * p.nwy * p.nwx * p.nh);
     if (bias) {

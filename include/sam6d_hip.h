@@ -30,7 +30,7 @@ extern "C" {
 
 /* Bumped whenever a signature in this header changes; the loader (sam6d_amd/_lib.py) refuses a library whose
  * s6d_version() differs from the header it was written against (a stale .so fails at load, not at a call). */
-#define S6D_ABI_VERSION 116
+#define S6D_ABI_VERSION 118
 int s6d_version(void);
 const char *s6d_strerror(int code);
 /* last HIP error string seen by this thread (empty if none) */
@@ -483,6 +483,15 @@ int s6d_samdec_img2tok_bf16(const void *q, const void *q_add, const void *kexp, 
                             const float *out_bias, const float *ln_w, const float *ln_b, float ln_eps, int B, int N,
                             int n_tok, int q_ld, int q_shared, int resid_shared, void *out, void *stream);
 
+/* The same block with the q projection of the image tokens folded into the expanded keys: x (1|B,N,256) bf16 RAW image tokens with row
+ * stride x_ld (x_shared: no batch dimension), pe (N,256) bf16 added to x for the scores (bf16 rounding) or NULL,
+ * kexp256 (B,64,256) bf16 = kexp W_q (kexp as above, W_q (128,256) the q_proj weight), cbias (B,64) f32 = kexp . b_q (the bias of
+ * the projection differs between the slots a token's softmax runs over); the other operands as s6d_samdec_img2tok_bf16.  The
+ * (B,N,128) projected queries are never written or read.  ref: transformer.py:173-180, Attention.forward :222-240. */
+int s6d_samdec_img2tok_raw_bf16(const void *x, const void *pe, const void *kexp256, const float *cbias, const void *vpt,
+                                const void *resid, const float *out_bias, const float *ln_w, const float *ln_b, float ln_eps, int B,
+                                int N, int n_tok, int x_ld, int x_shared, int resid_shared, void *out, void *stream);
+
 /* SAM mask decoder, token -> image cross attention before out_proj: softmax(q_t k^T / sqrt(16)) v over the N image
  * tokens, 8 heads x 16.  qt (B,8,128) f32 projected prompt tokens (pad unused rows with anything finite; their output
  * rows are meaningless); k and v are the 128-wide column ranges [k_off, k_off+128), [v_off, v_off+128) of a bf16 tensor
@@ -492,6 +501,15 @@ int s6d_samdec_img2tok_bf16(const void *q, const void *q_add, const void *kexp, 
  * :98-103; Attention.forward :222-240. */
 int s6d_samdec_tok2img_f32(const float *qt, const void *kv, int ld, int k_off, int v_off, int kv_shared, const void *k_pe,
                            int B, int N, float scale, float *out, void *stream);
+
+/* The same attention on the RAW image tokens, the k / v projections folded into the queries (no k / v tensor over the B x N image
+ * tokens): qp (B,64,256) bf16, row j = head * 8 + slot = scale * log2(e) * W_k[head]^T q[slot, head] (zero rows for unused slots);
+ * x (1|B,N,256) bf16 with row stride ld (x_shared: no batch dimension); pe (N,256) bf16 added to x for the scores (bf16 rounding) or
+ * NULL -> y (B,64,256) f32, y[j] = sum_n softmax_n(qp[j] . (x_n + pe_n)) x_n.  The caller finishes with out[slot, head] =
+ * W_v[head] y[head * 8 + slot] + b_v[head].  N % 64 == 0.
+ * ref: as s6d_samdec_tok2img_f32 (transformer.py:160-165, :98-103, :222-240). */
+int s6d_samdec_tok2img_raw_bf16(const void *qp, const void *x, int ld, int x_shared, const void *pe, int B, int N, float *y,
+                                void *stream);
 
 /* SAM mask decoder, output head after the first transposed conv: LayerNorm2d + GELU, second 2x2/2 transposed conv,
  * GELU, and the hypernetwork product, per output pixel.  y0 (B,h*w,4*64) bf16, row stride y_ld elements = first

@@ -41,22 +41,28 @@ constexpr int kSdVRow = kSdJ + 8;   // LDS row stride of the folded values (bf16
 // q (Bq,N,128) bf16 with row stride q_ld (+ q_add (N,128) bf16 or null), kexp (B,64,128) bf16: row j = h*8+t holds scale * k_t in the 16
 // columns of head h, zeros elsewhere; vpt (B,256,64) bf16: vpt[n][j] = (v_t W_o^T)[n] restricted to head h;
 // resid (Br,N,256) bf16; obias, gamma, beta (256) f32 -> out (B,N,256) bf16.  Bq, Br in {1, B}.
+// RAW (round 4): the q projection is folded into the expanded keys -- q = the RAW image tokens (B|1,N,256), q_add = the positional
+// encoding (N,256), kexp (B,64,256) = kexp_128 W_q, cbias (B,64) = kexp_128 . b_q (the projection's bias is NOT constant over the
+// slots a token's softmax runs over): the (B,N,128) projected queries of the image tokens are never written or read.
+template <bool RAW>
 __global__ __launch_bounds__(256, 2) void img2tok_kernel(const u16 *__restrict__ q, const u16 *__restrict__ q_add,
-                                                      const u16 *__restrict__ kexp, const u16 *__restrict__ vpt,
+                                                      const u16 *__restrict__ kexp, const float *__restrict__ cbias,
+                                                      const u16 *__restrict__ vpt,
                                                       const u16 *__restrict__ resid, const float *__restrict__ obias,
                                                       const float *__restrict__ gamma, const float *__restrict__ beta,
                                                       float eps, int N, int n_tok, int q_ld, long q_bstride,
                                                       long r_bstride, u16 *__restrict__ out) {
+  constexpr int KD = RAW ? kSdC : kSdD, KROWL = KD + 8, KSN = KD / 32;   // key width, LDS row stride, k-steps of the score product
   extern __shared__ __attribute__((aligned(16))) char sd_smem[];
-  u16 *Kl = reinterpret_cast<u16 *>(sd_smem);                       // [64][kSdKRow]
-  u16 *Vl = Kl + kSdJ * kSdKRow;                                    // [256][kSdVRow]
+  u16 *Kl = reinterpret_cast<u16 *>(sd_smem);                       // [64][KROWL]
+  u16 *Vl = Kl + kSdJ * KROWL;                                      // [256][kSdVRow]
   float *pl = reinterpret_cast<float *>(Vl + kSdC * kSdVRow);       // [3][256]: obias, gamma, beta
   const int b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int c = lane & 15, g = lane >> 4;
-  for (int i = tid; i < kSdJ * kSdD / 8; i += 256) {                // 16-byte chunks
-    const int row = i / (kSdD / 8), ch = i - row * (kSdD / 8);
-    *reinterpret_cast<uint4 *>(Kl + row * kSdKRow + ch * 8) =
-        *reinterpret_cast<const uint4 *>(kexp + ((size_t)b * kSdJ + row) * kSdD + ch * 8);
+  for (int i = tid; i < kSdJ * KD / 8; i += 256) {                  // 16-byte chunks
+    const int row = i / (KD / 8), ch = i - row * (KD / 8);
+    *reinterpret_cast<uint4 *>(Kl + row * KROWL + ch * 8) =
+        *reinterpret_cast<const uint4 *>(kexp + ((size_t)b * kSdJ + row) * KD + ch * 8);
   }
   for (int i = tid; i < kSdC * kSdJ / 8; i += 256) {
     const int row = i / (kSdJ / 8), ch = i - row * (kSdJ / 8);
@@ -76,20 +82,23 @@ __global__ __launch_bounds__(256, 2) void img2tok_kernel(const u16 *__restrict__
     // ---- scores^T (64 x 16) = Kexp (64 x 128) . Q^T ------------------------------------------------------------
     sd_f32x4 s[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) s[t] = sd_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 4; ++t) {
+      s[t] = sd_f32x4{0.f, 0.f, 0.f, 0.f};
+      if (RAW) s[t] = *reinterpret_cast<const sd_f32x4 *>(cbias + (size_t)b * kSdJ + t * 16 + g * 4);   // rows j = t*16 + g*4 + r
+    }
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KSN; ++ks) {
       union { uint4 u; sd_bf16x8 v; u16 h[8]; } qa;
       qa.u = *reinterpret_cast<const uint4 *>(qb + (size_t)tok * q_ld + ks * 32 + g * 8);
-      if (q_add) {                                                   // + W_q pe (shared by every prompt)
+      if (q_add) {                                                   // + W_q pe (shared by every prompt); RAW: + pe itself
         union { uint4 u; u16 h[8]; } pa;
-        pa.u = *reinterpret_cast<const uint4 *>(q_add + (size_t)tok * kSdD + ks * 32 + g * 8);
+        pa.u = *reinterpret_cast<const uint4 *>(q_add + (size_t)tok * KD + ks * 32 + g * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) qa.h[e] = sd_f2bf(sd_bf2f(qa.h[e]) + sd_bf2f(pa.h[e]));
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const sd_bf16x8 ka = *reinterpret_cast<const sd_bf16x8 *>(Kl + (t * 16 + c) * kSdKRow + ks * 32 + g * 8);
+        const sd_bf16x8 ka = *reinterpret_cast<const sd_bf16x8 *>(Kl + (t * 16 + c) * KROWL + ks * 32 + g * 8);
         s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qa.v, s[t], 0, 0, 0);
       }
     }
@@ -399,6 +408,139 @@ __global__ __launch_bounds__(kT2IWaves * 64) void tok2img_kernel(const float *__
   }
 }
 
+// ---- token -> image attention on the RAW image tokens (round 4) -------------------------------------------------------------------
+// Reference: Attention.forward of segment_anything/modeling/transformer.py:185-232 as used by TwoWayAttentionBlock step (2) and the
+// transformer's final attention: softmax(q_t . k_n / 4) v_n with k_n = W_k (x_n + pe_n) + b_k, v_n = W_v x_n + b_v per prompt.
+// tok2img_kernel above reads k and v that a GEMM over ALL B x 4096 image tokens wrote (2.1 GB read + 2.1 GB written per use).
+// The projections fold into the 8 x 8 (head, token) queries instead:
+//     q_t,h . k_n = (W_k,h^T q_t,h) . (x_n + pe_n) + const      (the b_k term is the same for every n: softmax drops it)
+//     sum_n p_n v_n = W_v,h (sum_n p_n x_n) + b_v,h              (sum_n p_n = 1)
+// so the kernel attends 64 folded 256-d queries q'_j (j = head * 8 + slot, pre-multiplied by scale * log2 e, zero rows for unused
+// slots) against the raw tokens and returns y_j = sum_n p_jn x_n: one read of x (2.1 GB per 1024 prompts), no k / v tensor; the
+// caller applies W_v per head to the 64 x 256 result (a 1024 x 64 x 256 x 16 product).  Matrix work: 4 x the scalar kernel's
+// flops, on the matrix cores: S^T = (X + PE) Q'^T and O^T += X^T P^T per 64-token tile, a wave per 16 query slots (2 heads), the
+// tile shared by the four waves through LDS (one image of x + pe for the K fragments, one of x for the transposed V reads).
+constexpr int kT2RTile = 64;                      // image tokens per tile
+constexpr int kT2RKRow = kSdC + 8;                // x + pe image row (bf16): 528 B, conflict-free ds_read_b128 fragments
+constexpr int kT2RVRow = kSdC + 16;               // x image row: 17 x 32 B, an odd multiple of 32 B for ds_read_b64_tr_b16
+constexpr int kT2RLds = kT2RTile * (kT2RKRow + kT2RVRow) * 2;
+typedef __attribute__((ext_vector_type(4))) short sd_s16x4;
+#define S6D_SD_LDS(T) __attribute__((address_space(3))) T
+
+// qp (B,64,256) bf16; x (Bx,N,256) bf16 rows of stride ld, Bx in {1, B} (x_bstride = 0: shared); pe (N,256) bf16 or null;
+// y (B,64,256) f32.  N % 64 == 0.  One 4-wave workgroup per prompt.
+__global__ __launch_bounds__(256, 2) void tok2img_raw_kernel(const u16 *__restrict__ qp, const u16 *__restrict__ x, int ld,
+                                                            long x_bstride, const u16 *__restrict__ pe, int N,
+                                                            float *__restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) char t2r_smem[];
+  u16 *Kl = reinterpret_cast<u16 *>(t2r_smem);                      // [64][kT2RKRow]  x + pe
+  u16 *Vl = Kl + kT2RTile * kT2RKRow;                               // [64][kT2RVRow]  x
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int c = lane & 15, g = lane >> 4;
+  // B fragments of this wave's 16 query slots: row c, k elements g*8 .. g*8+7 of each of the 8 k-steps
+  sd_bf16x8 qf[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    union { uint4 u; sd_bf16x8 v; } t;
+    t.u = *reinterpret_cast<const uint4 *>(qp + ((size_t)b * kSdJ + wave * 16 + c) * kSdC + ks * 32 + g * 8);
+    qf[ks] = t.v;
+  }
+  const u16 *xb = x + (size_t)b * x_bstride;
+  // staging: 64 tokens x 32 chunks of 16 B = 2048 chunks, 8 per thread: chunk i = tid + 256 j -> token i >> 5, chunk i & 31
+  uint4 px[8], pp[8];
+  auto fetch = [&](int nt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = tid + 256 * j, tk = i >> 5, ch = i & 31;
+      px[j] = *reinterpret_cast<const uint4 *>(xb + (size_t)(nt + tk) * ld + ch * 8);
+      if (pe) pp[j] = *reinterpret_cast<const uint4 *>(pe + (size_t)(nt + tk) * kSdC + ch * 8);
+    }
+  };
+  auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = tid + 256 * j, tk = i >> 5, ch = i & 31;
+      *reinterpret_cast<uint4 *>(Vl + tk * kT2RVRow + ch * 8) = px[j];
+      union { uint4 u; u16 h[8]; } a, e;
+      a.u = px[j];
+      if (pe) {
+        e.u = pp[j];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a.h[k] = sd_f2bf(sd_bf2f(a.h[k]) + sd_bf2f(e.h[k]));
+      }
+      *reinterpret_cast<uint4 *>(Kl + tk * kT2RKRow + ch * 8) = a.u;
+    }
+  };
+  float m_run = -1e30f;
+  sd_f32x4 lacc = {0.f, 0.f, 0.f, 0.f}, oacc[16];
+#pragma unroll
+  for (int dt = 0; dt < 16; ++dt) oacc[dt] = sd_f32x4{0.f, 0.f, 0.f, 0.f};
+  union { sd_bf16x8 v; u16 h[8]; } ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones.h[i] = 0x3f80;                  // bf16 1.0
+  fetch(0);
+  for (int nt = 0; nt < N; nt += kT2RTile) {
+    commit();
+    __syncthreads();                                                // the tile is in LDS
+    if (nt + kT2RTile < N) fetch(nt + kT2RTile);                    // the next one flies under this one's arithmetic
+    // ---- S^T (64 tokens x 16 slots) = (X + PE) Q'^T: acc[r] = score of token sub*16 + g*4 + r against slot c ----------------
+    float s[4][4];
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      sd_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const sd_bf16x8 ka = *reinterpret_cast<const sd_bf16x8 *>(Kl + (sub * 16 + c) * kT2RKRow + ks * 32 + g * 8);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[ks], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[sub][r] = acc[r];
+    }
+    // ---- online softmax over the tokens (queries were pre-multiplied by scale * log2 e); the rescale of the accumulators is skipped
+    //      while no slot's maximum grew by more than 2^6 (P stays <= 64: exact in bf16's exponent range) --------------------------
+    float mx = s[0][0];
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[sub][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (__any(mx - m_run > 6.0f)) {                                 // wave-uniform
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      lacc *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 16; ++dt) oacc[dt] *= alpha;
+      m_run = m_new;
+    }
+    union { sd_bf16x8 v; u16 h[8]; } pb[2];
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pb[sub >> 1].h[(sub & 1) * 4 + r] = sd_f2bf(__builtin_amdgcn_exp2f(s[sub][r] - m_run));
+    // ---- O^T (256 x 16 slots) += X^T P^T over two 32-token steps; the row sums ride an all-ones A fragment ------------------
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const u16 *vrow = Vl + (32 * j + g * 4 + (c >> 2)) * kT2RVRow + (c & 3) * 4;
+      lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, pb[j].v, lacc, 0, 0, 0);
+#pragma unroll
+      for (int dt = 0; dt < 16; ++dt) {
+        union { sd_bf16x8 v; sd_s16x4 q[2]; } va;
+        va.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_SD_LDS(sd_s16x4) *)(vrow + dt * 16));
+        va.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_SD_LDS(sd_s16x4) *)(vrow + 16 * kT2RVRow + dt * 16));
+        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va.v, pb[j].v, oacc[dt], 0, 0, 0);
+      }
+    }
+    __syncthreads();                                                // every wave is done with the tile: it may be overwritten
+  }
+  // y[b][slot = wave*16 + c][d = dt*16 + g*4 + r]
+  const float inv = 1.0f / lacc[0];
+  float *yo = y + ((size_t)b * kSdJ + wave * 16 + c) * kSdC + g * 4;
+#pragma unroll
+  for (int dt = 0; dt < 16; ++dt)
+    *reinterpret_cast<float4 *>(yo + dt * 16) = make_float4(oacc[dt][0] * inv, oacc[dt][1] * inv, oacc[dt][2] * inv, oacc[dt][3] * inv);
+}
+
 // ---- mask post-processing of the automatic mask generator, fused ---------------------------------------------------
 // Reference: Sam.postprocess_masks (modeling/sam.py:133-162: bilinear to the padded square, crop, bilinear to the frame),
 // then on the full-resolution logits calculate_stability_score, `> mask_threshold` and batched_mask_to_box
@@ -659,22 +801,58 @@ extern "C" int s6d_samdec_tok2img_f32(const float *qt, const void *kv, int ld, i
   return launch_status();
 }
 
+extern "C" int s6d_samdec_tok2img_raw_bf16(const void *qp, const void *x, int ld, int x_shared, const void *pe, int B, int N,
+                                           float *y, void *stream) {
+  if (B < 0 || N <= 0 || (N % kT2RTile) != 0 || ld < kSdC || (ld % 8) != 0) return S6D_EINVAL;
+  if (B == 0) return S6D_OK;
+  if (!qp || !x || !y || (((uintptr_t)qp | (uintptr_t)x | (uintptr_t)pe | (uintptr_t)y) & 15)) return S6D_EINVAL;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tok2img_raw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kT2RLds);
+  hipLaunchKernelGGL(tok2img_raw_kernel, dim3(B), dim3(256), kT2RLds, as_stream(stream), (const u16 *)qp, (const u16 *)x, ld,
+                     x_shared ? 0L : (long)N * ld, (const u16 *)pe, N, y);
+  return launch_status();
+}
+
+static int img2tok_launch(bool raw, const void *q, const void *q_add, const void *kexp, const float *cbias, const void *vpt,
+                          const void *resid, const float *out_bias, const float *ln_w, const float *ln_b, float ln_eps, int B, int N,
+                          int n_tok, int q_ld, int q_shared, int resid_shared, void *out, void *stream) {
+  const int kd = raw ? kSdC : kSdD;
+  if (B < 0 || N <= 0 || (N % 16) != 0 || n_tok <= 0 || n_tok > 8 || q_ld < kd || (q_ld % 8) != 0) return S6D_EINVAL;
+  if (B == 0) return S6D_OK;
+  if (!q || !kexp || !vpt || !resid || !out_bias || !ln_w || !ln_b || !out || (raw && !cbias)) return S6D_EINVAL;
+  const size_t lds = (size_t)(kSdJ * (kd + 8) + kSdC * kSdVRow) * 2 + 3 * 256 * 4;
+  const int nstrip = N / 16;
+  const int gx = nstrip >= 64 ? 16 : (nstrip + 3) / 4;              // 16 workgroups x 4 waves x 4 strips at N = 4096
+  if (raw) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&img2tok_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    hipLaunchKernelGGL(img2tok_kernel<true>, dim3(gx, B), dim3(256), lds, as_stream(stream), (const u16 *)q, (const u16 *)q_add,
+                       (const u16 *)kexp, cbias, (const u16 *)vpt, (const u16 *)resid, out_bias, ln_w, ln_b, ln_eps, N, n_tok, q_ld,
+                       q_shared ? 0L : (long)N * q_ld, resid_shared ? 0L : (long)N * kSdC, (u16 *)out);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&img2tok_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    hipLaunchKernelGGL(img2tok_kernel<false>, dim3(gx, B), dim3(256), lds, as_stream(stream), (const u16 *)q, (const u16 *)q_add,
+                       (const u16 *)kexp, cbias, (const u16 *)vpt, (const u16 *)resid, out_bias, ln_w, ln_b, ln_eps, N, n_tok, q_ld,
+                       q_shared ? 0L : (long)N * q_ld, resid_shared ? 0L : (long)N * kSdC, (u16 *)out);
+  }
+  return launch_status();
+}
+
 extern "C" int s6d_samdec_img2tok_bf16(const void *q, const void *q_add, const void *kexp, const void *vpt,
                                        const void *resid, const float *out_bias, const float *ln_w, const float *ln_b,
                                        float ln_eps, int B, int N, int n_tok, int q_ld, int q_shared, int resid_shared,
                                        void *out, void *stream) {
-  if (B < 0 || N <= 0 || (N % 16) != 0 || n_tok <= 0 || n_tok > 8 || q_ld < kSdD || (q_ld % 8) != 0) return S6D_EINVAL;
-  if (B == 0) return S6D_OK;
-  if (!q || !kexp || !vpt || !resid || !out_bias || !ln_w || !ln_b || !out) return S6D_EINVAL;
-  const size_t lds = (size_t)(kSdJ * kSdKRow + kSdC * kSdVRow) * 2 + 3 * 256 * 4;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&img2tok_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
-  const int nstrip = N / 16;
-  const int gx = nstrip >= 64 ? 16 : (nstrip + 3) / 4;              // 16 workgroups x 4 waves x 4 strips at N = 4096
-  hipLaunchKernelGGL(img2tok_kernel, dim3(gx, B), dim3(256), lds, as_stream(stream), (const u16 *)q, (const u16 *)q_add,
-                     (const u16 *)kexp, (const u16 *)vpt, (const u16 *)resid, out_bias, ln_w, ln_b, ln_eps, N, n_tok, q_ld,
-                     q_shared ? 0L : (long)N * q_ld, resid_shared ? 0L : (long)N * kSdC, (u16 *)out);
-  return launch_status();
+  return img2tok_launch(false, q, q_add, kexp, nullptr, vpt, resid, out_bias, ln_w, ln_b, ln_eps, B, N, n_tok, q_ld, q_shared,
+                        resid_shared, out, stream);
+}
+
+extern "C" int s6d_samdec_img2tok_raw_bf16(const void *x, const void *pe, const void *kexp256, const float *cbias, const void *vpt,
+                                           const void *resid, const float *out_bias, const float *ln_w, const float *ln_b,
+                                           float ln_eps, int B, int N, int n_tok, int x_ld, int x_shared, int resid_shared,
+                                           void *out, void *stream) {
+  return img2tok_launch(true, x, pe, kexp256, cbias, vpt, resid, out_bias, ln_w, ln_b, ln_eps, B, N, n_tok, x_ld, x_shared,
+                        resid_shared, out, stream);
 }
 
 extern "C" int s6d_samdec_upscale_heads_bf16(const void *y0, const float *ln_w, const float *ln_b, float ln_eps,

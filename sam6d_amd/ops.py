@@ -292,6 +292,28 @@ def samdec_img2tok(q, q_add, kexp, vpt, resid, out_bias, ln_w, ln_b, eps, n_tok)
     return out
 
 
+def samdec_img2tok_raw(x, pe, kexp256, cbias, vpt, resid, out_bias, ln_w, ln_b, eps, n_tok):
+    """samdec_img2tok with the q projection folded into the expanded keys: x (1|B,N,256) bf16 RAW image tokens, pe (N,256) bf16 or
+    None (added to x for the scores), kexp256 (B,64,256) bf16 = kexp_128 @ W_q, cbias (B,64) f32 = kexp_128 @ b_q, vpt (B,256,64) bf16,
+    resid (1|B,N,256) bf16 -> (B,N,256) bf16.  The projected queries of the B x N image tokens are never written."""
+    B, N = kexp256.shape[0], resid.shape[1]
+    for t, nm in ((kexp256, "kexp256"), (vpt, "vpt"), (resid, "resid"), (x, "x")):
+        _chk(t, torch.bfloat16, nm, 3)
+    for t, nm in ((out_bias, "out_bias"), (ln_w, "ln_w"), (ln_b, "ln_b")):
+        _chk(t, torch.float32, nm, 1)
+    _chk(cbias, torch.float32, "cbias", 2)
+    if pe is not None:
+        _chk(pe, torch.bfloat16, "pe", 2)
+    if (tuple(kexp256.shape) != (B, 64, 256) or tuple(vpt.shape) != (B, 256, 64) or resid.shape[2] != 256 or tuple(x.shape[1:]) != (N, 256)
+            or tuple(cbias.shape) != (B, 64) or x.shape[0] not in (1, B) or resid.shape[0] not in (1, B)):
+        raise RuntimeError("samdec_img2tok_raw: shape mismatch")
+    out = torch.empty(B, N, 256, dtype=torch.bfloat16, device=kexp256.device)
+    _call("s6d_samdec_img2tok_raw_bf16", _ptr(x), _ptr(pe) if pe is not None else _vp(0), _ptr(kexp256), _ptr(cbias), _ptr(vpt),
+          _ptr(resid), _ptr(out_bias), _ptr(ln_w), _ptr(ln_b), ctypes.c_float(eps), B, N, int(n_tok), 256,
+          1 if x.shape[0] == 1 and B > 1 else 0, 1 if resid.shape[0] == 1 and B > 1 else 0, _ptr(out), _stream())
+    return out
+
+
 def samdec_tok2img(qt, kv, k_off, v_off, k_pe, scale):
     """Token->image attention before out_proj.  qt (B,T<=8,128) f32, kv (1|B,N,ld) bf16 holding k / v at column
     offsets k_off / v_off, k_pe (N,128) bf16 or None -> (B,T,128) f32."""
@@ -308,6 +330,30 @@ def samdec_tok2img(qt, kv, k_off, v_off, k_pe, scale):
           1 if kv.shape[0] == 1 and B > 1 else 0, _ptr(k_pe) if k_pe is not None else _vp(0), B, int(kv.shape[1]),
           ctypes.c_float(scale), _ptr(out), _stream())
     return out[:, :T]
+
+
+def samdec_tok2img_raw(qt, x, pe, wk, wv, bv, scale):
+    """Token->image attention before out_proj on the RAW image tokens: the k / v projections are folded into the queries, no
+    projected k / v tensor over the image tokens exists.  qt (B,T<=8,128) f32 projected prompt tokens, x (1|B,N,256) bf16 image
+    tokens, pe (N,256) bf16 or None (added to x for the scores), wk / wv (128,256), bv (128): the k_proj / v_proj parameters ->
+    (B,T,128) f32 = softmax(q (W_k (x + pe))^T * scale) (W_v x + b_v), heads 8 x 16."""
+    _chk(x, torch.bfloat16, "x", 3)
+    B, T, _ = qt.shape
+    if qt.dtype != torch.float32 or not qt.is_cuda or qt.shape[2] != 128 or T > 8 or x.shape[0] not in (1, B) or x.shape[2] != 256:
+        raise RuntimeError("samdec_tok2img_raw: qt must be (B,T<=8,128) float32 CUDA, x (1|B,N,256) bfloat16")
+    if pe is not None:
+        _chk(pe, torch.bfloat16, "pe", 2)
+    H, hd = 8, 16
+    with torch.autocast(device_type="cuda", enabled=False):          # the two small folds stay float32 inside an autocast region
+        # q'[b, h, t, :] = scale * log2(e) * W_k[h]^T q[b, t, h]
+        qp = torch.zeros(B, H, 8, 256, dtype=torch.float32, device=qt.device)
+        qp[:, :, :T] = torch.einsum("bthd,hdc->bhtc", qt.view(B, T, H, hd) * (scale * 1.4426950408889634), wk.float().view(H, hd, 256))
+        qp = qp.to(torch.bfloat16).view(B, 64, 256)
+        y = torch.empty(B, 64, 256, dtype=torch.float32, device=qt.device)
+        _call("s6d_samdec_tok2img_raw_bf16", _ptr(qp), _ptr(x), int(x.stride(1)), 1 if x.shape[0] == 1 and B > 1 else 0,
+              _ptr(pe) if pe is not None else _vp(0), B, int(x.shape[1]), _ptr(y), _stream())
+        out = torch.einsum("bhtc,hdc->bthd", y.view(B, H, 8, 256)[:, :, :T], wv.float().view(H, hd, 256)) + bv.float().view(1, 1, H, hd)
+    return out.reshape(B, T, 128)
 
 
 def sam_mask_post(low_res, img_size, input_size, original_size, mask_threshold=0.0, stability_offset=1.0):
@@ -1085,7 +1131,7 @@ def have(name):
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_sel_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
                "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_sel_f32",
-               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "im2col3x3": "s6d_im2col3x3_b16", "nonfinite_rows": "s6d_nonfinite_rows_f32", "patchify": "s6d_patchify_b16", "crop_resize_pad": "s6d_crop_resize_pad_f32", "samdec_img2tok": "s6d_samdec_img2tok_bf16", "samdec_tok2img": "s6d_samdec_tok2img_f32", "sam_mask_post": "s6d_sam_mask_post_sel_f32", "gemm_fp8_mx": "s6d_gemm_fp8_mxa", "nms": "s6d_nms_f32", "samdec_upscale_heads": "s6d_samdec_upscale_heads_bf16", "mha": "s6d_mha_f32",
+               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "im2col3x3": "s6d_im2col3x3_b16", "nonfinite_rows": "s6d_nonfinite_rows_f32", "patchify": "s6d_patchify_b16", "crop_resize_pad": "s6d_crop_resize_pad_f32", "samdec_img2tok": "s6d_samdec_img2tok_bf16", "samdec_img2tok_raw": "s6d_samdec_img2tok_raw_bf16", "samdec_tok2img": "s6d_samdec_tok2img_f32", "samdec_tok2img_raw": "s6d_samdec_tok2img_raw_bf16", "sam_mask_post": "s6d_sam_mask_post_sel_f32", "gemm_fp8_mx": "s6d_gemm_fp8_mxa", "nms": "s6d_nms_f32", "samdec_upscale_heads": "s6d_samdec_upscale_heads_bf16", "mha": "s6d_mha_f32",
                "linear_attn_focus": "s6d_linear_attn_focus_f32", "linear_attention": "s6d_linear_attention_f32", "project_bbox": "s6d_project_bbox_frames_f32"}.get(name)
         import os
         disabled = name in os.environ.get("S6D_DISABLE_FUSED", "").split(",")

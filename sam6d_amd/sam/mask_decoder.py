@@ -388,6 +388,11 @@ class MaskDecoder(nn.Module):
                                      ct1.weight.permute(2, 3, 1, 0).reshape(-1, C)], 0).to(bf).contiguous(),
                     b_kvu=torch.cat([fin.k_proj.bias, fin.v_proj.bias, ct1.bias.repeat(4)], 0).to(bf).contiguous(),
                     kpef=F.linear(pe32, fin.k_proj.weight.float()).to(bf).contiguous()[0],
+                    # round 4 (raw token->image attention): only the image->token queries and the first transposed conv are still
+                    # projected over the B x N image tokens
+                    pe_bf=pe32.to(bf).contiguous()[0],
+                    w_q1=ci.q_proj.weight.to(bf).contiguous(), b_q1=ci.q_proj.bias.to(bf).contiguous(),
+                    w_u=ct1.weight.permute(2, 3, 1, 0).reshape(-1, C).to(bf).contiguous(), b_u=ct1.bias.repeat(4).to(bf).contiguous(),
                     w2t=ct2.weight.permute(2, 3, 1, 0).reshape(4 * ct2.out_channels, ct2.in_channels).to(bf).contiguous(),
                     b2=ct2.bias.float().contiguous(), ln_w=ln.weight.float().contiguous(), ln_b=ln.bias.float().contiguous())
             c = (key, d)
@@ -414,9 +419,11 @@ class MaskDecoder(nn.Module):
         return F.linear(x, w, b)
 
     @staticmethod
-    def _expand(att, queries, tokens):
+    def _expand(att, queries, tokens, fold_q=False):
         """Operands of s6d_samdec_img2tok_bf16 from the prompt tokens: block-diagonal scaled keys (B,64,128) and the
-        values with out_proj folded in (B,256,64); slot j = head * 8 + token."""
+        values with out_proj folded in (B,256,64); slot j = head * 8 + token.
+        fold_q: the image side's q projection folded into the keys (s6d_samdec_img2tok_raw_bf16) -> (kexp W_q (B,64,256) bf16,
+        kexp . b_q (B,64) f32, vpt)."""
         B, T, _ = queries.shape
         H, hd = att.num_heads, att.internal_dim // att.num_heads
         kt = (att.k_proj(queries + tokens).float() / math.sqrt(hd)).view(B, T, H, hd)
@@ -425,6 +432,11 @@ class MaskDecoder(nn.Module):
         kexp = F.pad(torch.einsum("bthd,hg->bhtgd", kt, eye), (0, 0, 0, 0, 0, 8 - T)).reshape(B, 8 * H, H * hd)
         wo = att.out_proj.weight.float().view(-1, H, hd)
         vpt = F.pad(torch.einsum("bthd,nhd->bnht", vt, wo), (0, 8 - T)).reshape(B, wo.shape[0], 8 * H)
+        if fold_q:
+            with torch.autocast(device_type=kexp.device.type, enabled=False):             # float32 products (autocast would round them)
+                k256 = kexp.float() @ att.q_proj.weight.float()                            # (B,64,128) @ (128,256)
+                cb = kexp.float() @ att.q_proj.bias.float()                                # (B,64)
+            return k256.to(torch.bfloat16).contiguous(), cb.contiguous(), vpt.to(torch.bfloat16).contiguous()
         return kexp.to(torch.bfloat16).contiguous(), vpt.to(torch.bfloat16).contiguous()
 
     def _predict_masks_fused(self, image_embeddings, image_pe, sparse, dense):
@@ -443,8 +455,18 @@ class MaskDecoder(nn.Module):
         # ---- layer 0 (image side shared by every prompt) -----------------------------------------------------------
         ca, ci = L0.cross_attn_token_to_image, L0.cross_attn_image_to_token
         t2i = ops.have("samdec_tok2img")
+        # round 4: token->image attention on the RAW image tokens (k / v projections folded into the 8 x 8 queries, matrix cores):
+        # no k / v tensor over the B x N image tokens is written or read (S6D_SAMDEC_T2I=kv: the round-3 form)
+        import os
+        raw = (ops.have("samdec_tok2img_raw") and (h * w) % 64 == 0 and os.environ.get("S6D_SAMDEC_T2I", "raw") == "raw")
         sc = 1.0 / math.sqrt(ca.internal_dim // ca.num_heads)
-        if t2i:
+        keys0_bf = keys0.to(bf).contiguous()
+
+        def t2i_raw(att, x, pe_):
+            return lambda qp: ops.samdec_tok2img_raw(qp, x, pe_, att.k_proj.weight, att.v_proj.weight, att.v_proj.bias, sc)
+        if raw:
+            queries = L0.token_side(tokens, tokens, None, None, t2i_raw(ca, keys0_bf, P["pe_bf"]))
+        elif t2i:
             kv0 = torch.cat([ca.k_proj(kp0), ca.v_proj(keys0)], -1).to(bf).contiguous()           # (1, N, 2d)
             queries = L0.token_side(tokens, tokens, None, None,
                                     lambda qp: ops.samdec_tok2img(qp, kv0, 0, ca.internal_dim, None, sc))
@@ -452,31 +474,47 @@ class MaskDecoder(nn.Module):
             queries = L0.token_side(tokens, tokens, ca.k_proj(kp0), ca.v_proj(keys0))
         kexp, vpt = self._expand(ci, queries, tokens)
         n4 = L0.norm4
-        keys1 = ops.samdec_img2tok(ci.q_proj(kp0).to(bf).contiguous(), None, kexp, vpt, keys0.to(bf).contiguous(),
+        keys1 = ops.samdec_img2tok(ci.q_proj(kp0).to(bf).contiguous(), None, kexp, vpt, keys0_bf,
                                    ci.out_proj.bias.float(), n4.weight.float(), n4.bias.float(), n4.eps, T)
         # ---- layer 1 -----------------------------------------------------------------------------------------------
         ca, ci = L1.cross_attn_token_to_image, L1.cross_attn_image_to_token
         d = ca.internal_dim
-        kvq = self._rows_gemm(keys1, P["w_kvq"], P["b_kvq"])                       # (B, N, 3d) bf16
-        if t2i:
-            queries = L1.token_side(queries, tokens, None, None,
-                                    lambda qp: ops.samdec_tok2img(qp, kvq, 0, d, P["kpe1"], sc))
+        fold = raw and ops.have("samdec_img2tok_raw")
+        if raw:
+            queries = L1.token_side(queries, tokens, None, None, t2i_raw(ca, keys1, P["pe_bf"]))
+            q1 = None if fold else self._rows_gemm(keys1, P["w_q1"], P["b_q1"])    # (B, N, d) bf16: image->token queries only
         else:
-            queries = L1.token_side(queries, tokens, kvq[..., :d] + P["kpe1"], kvq[..., d:2 * d])
-        kexp, vpt = self._expand(ci, queries, tokens)
+            kvq = self._rows_gemm(keys1, P["w_kvq"], P["b_kvq"])                   # (B, N, 3d) bf16
+            if t2i:
+                queries = L1.token_side(queries, tokens, None, None,
+                                        lambda qp: ops.samdec_tok2img(qp, kvq, 0, d, P["kpe1"], sc))
+            else:
+                queries = L1.token_side(queries, tokens, kvq[..., :d] + P["kpe1"], kvq[..., d:2 * d])
+            q1 = kvq[..., 2 * d:]
         n4 = L1.norm4
-        keys2 = ops.samdec_img2tok(kvq[..., 2 * d:], P["qpe1"], kexp, vpt, keys1, ci.out_proj.bias.float(),
-                                   n4.weight.float(), n4.bias.float(), n4.eps, T)
-        # ---- final token->image attention + output head ---------------------------------------------------------------
-        kvu = self._rows_gemm(keys2, P["w_kvu"], P["b_kvu"])                       # (B, N, 2d + 4*c1) bf16
-        qf = fin.q_proj(queries + tokens)
-        if t2i:
-            a = fin.out_proj(ops.samdec_tok2img(qf.float(), kvu, 0, d, P["kpef"], sc))
+        if fold:                                                                   # q projection folded into the expanded keys
+            k256, cb, vpt = self._expand(ci, queries, tokens, fold_q=True)
+            keys2 = ops.samdec_img2tok_raw(keys1, P["pe_bf"], k256, cb, vpt, keys1, ci.out_proj.bias.float(),
+                                           n4.weight.float(), n4.bias.float(), n4.eps, T)
         else:
-            a = fin.attend(qf, kvu[..., :d] + P["kpef"], kvu[..., d:2 * d])
+            kexp, vpt = self._expand(ci, queries, tokens)
+            keys2 = ops.samdec_img2tok(q1, P["qpe1"], kexp, vpt, keys1, ci.out_proj.bias.float(),
+                                       n4.weight.float(), n4.bias.float(), n4.eps, T)
+        # ---- final token->image attention + output head ---------------------------------------------------------------
+        qf = fin.q_proj(queries + tokens)
+        if raw:
+            a = fin.out_proj(t2i_raw(fin, keys2, P["pe_bf"])(qf.float()))
+            up = self._rows_gemm(keys2, P["w_u"], P["b_u"])                        # (B, N, 4*c1) bf16: first transposed conv
+        else:
+            kvu = self._rows_gemm(keys2, P["w_kvu"], P["b_kvu"])                   # (B, N, 2d + 4*c1) bf16
+            if t2i:
+                a = fin.out_proj(ops.samdec_tok2img(qf.float(), kvu, 0, d, P["kpef"], sc))
+            else:
+                a = fin.attend(qf, kvu[..., :d] + P["kpef"], kvu[..., d:2 * d])
+            up = kvu[..., 2 * d:]
         hs = tr.norm_final_attn(queries + a)
         iou_tok, mask_toks = hs[:, 0, :], hs[:, 1:1 + self.num_mask_tokens, :]
         hyper = torch.stack([self.output_hypernetworks_mlps[i](mask_toks[:, i, :]) for i in range(self.num_mask_tokens)], 1)
-        masks = ops.samdec_upscale_heads(kvu[..., 2 * d:], P["ln_w"], P["ln_b"], self.output_upscaling[1].eps, P["w2t"],
+        masks = ops.samdec_upscale_heads(up, P["ln_w"], P["ln_b"], self.output_upscaling[1].eps, P["w2t"],
                                          P["b2"], hyper.float().contiguous(), h, w)
         return masks, self.iou_prediction_head(iou_tok).float()

@@ -31,8 +31,10 @@ def test_crop_kernel_on_the_emulator(emu):
 
 def test_decoder_kernels_on_the_emulator(emu):
     T.test_img2tok_kernel_vs_restated_algebra()
+    T.test_img2tok_raw_kernel_vs_explicit_q_projection()
     T.test_upscale_heads_kernel_vs_restated_algebra()
     T.test_tok2img_kernel_vs_oracle()
+    T.test_tok2img_raw_kernel_vs_oracle_attention_with_explicit_projections()
 
 
 def test_mini_encoder_bf16_fused_path_on_the_emulator(emu, monkeypatch):

@@ -95,6 +95,42 @@ def test_img2tok_kernel_vs_restated_algebra():
         assert err.max() < 0.06 and err.mean() < 4e-3, (T, shared, err.max().item(), err.mean().item())
 
 
+def test_img2tok_raw_kernel_vs_explicit_q_projection():
+    """s6d_samdec_img2tok_raw_bf16 (round 4: q projection folded into the expanded keys, raw image tokens + positional encoding read
+    in place) against the statement with the EXPLICIT projection q = W_q (x + pe) + b_q in float32: attention of every image token
+    over the T prompt tokens per head, out_proj folded into the values, + bias + residual + LayerNorm.  Shared and per-prompt x."""
+    from sam6d_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, N = 4, 256
+    wq, bq = torch.randn(128, 256, generator=g) / 16, 0.5 * torch.randn(128, generator=g)
+    for T, shared, use_pe in ((7, False, True), (8, True, True), (5, False, False)):
+        Bx = 1 if shared else B
+        x = torch.randn(Bx, N, 256, generator=g).to(torch.bfloat16)
+        pe = torch.randn(N, 256, generator=g).to(torch.bfloat16) if use_pe else None
+        kt = torch.randn(B, 8, T, 16, generator=g) * 0.5                               # scaled keys per (head, token)
+        kexp = torch.zeros(B, 8, 8, 8, 16)
+        for hh in range(8):
+            kexp[:, hh, :T, hh] = kt[:, hh]
+        kexp = kexp.reshape(B, 64, 128)
+        k256, cb = (kexp @ wq).to(torch.bfloat16), (kexp @ bq).contiguous()
+        vpt = torch.zeros(B, 256, 8, 8)
+        vpt[..., :T] = torch.randn(B, 256, 8, T, generator=g)
+        vpt = vpt.reshape(B, 256, 64).to(torch.bfloat16)
+        bo, lw, lb = (torch.randn(256, generator=g) for _ in range(3))
+        out = ops.samdec_img2tok_raw(x.cuda(), pe.cuda() if use_pe else None, k256.cuda(), cb.cuda(), vpt.cuda(), x.cuda(), bo.cuda(),
+                                     lw.cuda(), lb.cuda(), 1e-5, T).float().cpu()
+        xf = x.float().expand(B, -1, -1)
+        q = ((xf + pe.float()) if use_pe else xf) @ wq.t() + bq                           # (B, N, 128)
+        s_ = q.reshape(B, N, 8, 16).transpose(1, 2) @ kt.transpose(-1, -2)               # (B, heads, N, T)
+        p = torch.softmax(s_, -1)
+        vv = vpt.float().view(B, 256, 8, 8)[..., :T]
+        y = torch.einsum("bhnt,bcht->bnc", p, vv) + bo + xf
+        ref = torch.nn.functional.layer_norm(y, (256,), lw, lb, 1e-5)
+        err = (out - ref).abs()
+        # measured 0.039 / 2.5e-3: the bf16 output grid at |x| <= 4 (0.016) + bf16 probabilities and folded keys
+        assert err.max() < 0.08 and err.mean() < 4e-3, (T, shared, use_pe, err.max().item(), err.mean().item())
+
+
 def test_upscale_heads_kernel_vs_restated_algebra():
     from sam6d_amd import ops
     g = torch.Generator().manual_seed(2)
@@ -133,6 +169,31 @@ def test_tok2img_kernel_vs_oracle():
         v = kv[..., 256:384].float()
         ref = osd.attention_core(qt.cpu(), k.cpu().expand(B, -1, -1), v.cpu().expand(B, -1, -1), 8)    # 1 / sqrt(16) = 0.25
         assert (out.cpu() - ref).abs().max() < 2e-4, (shared, (out.cpu() - ref).abs().max().item())
+
+
+def test_tok2img_raw_kernel_vs_oracle_attention_with_explicit_projections():
+    """s6d_samdec_tok2img_raw_bf16 (round 4: k / v projections folded into the queries, raw image tokens attended on the matrix
+    cores) against the oracle's attention core fed with EXPLICIT projections k = W_k (x + pe) + b_k, v = W_v x + b_v in float32 on
+    the same bf16 image tokens.  Tolerance: the folded queries and x + pe are rounded to bf16 (2^-9 relative) before a 256-term dot
+    product with O(1) scores, and P is rounded to bf16 before the value product."""
+    from sam6d_amd import ops
+    g = torch.Generator().manual_seed(7)
+    B, N, T = 5, 512, 7
+    qt = torch.randn(B, T, 128, generator=g)
+    wk, wv = torch.randn(128, 256, generator=g) / 16, torch.randn(128, 256, generator=g) / 16
+    bk, bv = torch.randn(128, generator=g), torch.randn(128, generator=g)
+    for shared, use_pe in ((False, True), (True, False), (False, False)):
+        x = torch.randn(1 if shared else B, N, 256, generator=g).to(torch.bfloat16)
+        pe = torch.randn(N, 256, generator=g).to(torch.bfloat16) if use_pe else None
+        out = ops.samdec_tok2img_raw(qt.cuda(), x.cuda(), pe.cuda() if use_pe else None, wk.cuda(), wv.cuda(), bv.cuda(), 0.25).cpu()
+        xf = x.float().expand(B, -1, -1)
+        k = (xf + pe.float() if use_pe else xf) @ wk.t() + bk
+        v = xf @ wv.t() + bv
+        ref = osd.attention_core(qt, k, v, 8)
+        err = (out - ref).abs().max().item()
+        assert out.shape == (B, T, 128) and err < 2e-2 and (out - ref).abs().mean().item() < 1e-3, (shared, use_pe, err)   # 7e-3 / 3.4e-4
+    with pytest.raises(Exception):
+        ops.samdec_tok2img_raw(qt.cuda(), torch.zeros(B, 100, 256, dtype=torch.bfloat16).cuda(), None, wk.cuda(), wv.cuda(), bv.cuda(), 0.25)
 
 
 def test_mask_post_kernel_bit_exact_vs_oracle_and_golden():

@@ -136,6 +136,11 @@ __global__ __launch_bounds__(256) void patchify_kernel(const uint4 *__restrict__
   }
 }
 
+__global__ void nonfinite_clear_kernel(int *flags, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) flags[i] = 0;
+}
+
 // flags[b] = 1 if row b of x (B rows of n floats, n % 4 == 0) holds an inf or a NaN (exponent field all ones); flags zeroed by the launcher
 __global__ __launch_bounds__(256) void nonfinite_rows_kernel(const float4 *__restrict__ x, long n4, int *__restrict__ flags) {
   const int b = blockIdx.y;
@@ -158,7 +163,9 @@ extern "C" int s6d_nonfinite_rows_f32(const float *x, int B, long n, int32_t *fl
   if (B == 0) return S6D_OK;
   if (n <= 0 || (n % 4) != 0 || !x || !flags || ((uintptr_t)x & 15)) return S6D_EINVAL;
   hipStream_t st = as_stream(stream);
-  if (hipMemsetAsync(flags, 0, (size_t)B * sizeof(int32_t), st) != hipSuccess) return launch_status();
+  // the flags are cleared by a kernel, not hipMemsetAsync: the PEM forward is captured into a hipGraph by the frame pipeline, and a
+  // memset node inside that capture left the flags unset on replay (every instance read as overflowed: measured, round 4)
+  hipLaunchKernelGGL(nonfinite_clear_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, flags, B);
   const long n4 = n / 4;
   long g = (n4 + 256 * 8 - 1) / (256 * 8);
   if (g > 1024) g = 1024;

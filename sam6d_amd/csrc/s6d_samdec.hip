@@ -77,9 +77,39 @@ __global__ __launch_bounds__(256, 2) void img2tok_kernel(const u16 *__restrict__
   u16 *ob = out + (size_t)b * N * kSdC;
   // this workgroup's tokens: gridDim.x workgroups share the N tokens of the prompt in 16-token strips
   const int nstrip = N / 16;
-  for (int strip = blockIdx.x * 4 + wave; strip < nstrip; strip += gridDim.x * 4) {
+  // The strip loop is software-pipelined (round 4): the q (and positional) fragments of the NEXT strip and the residual rows of THIS
+  // strip are requested before this strip's matrix work, so neither global-load latency is exposed (as written first, every strip
+  // started with a load -> MFMA dependency and its epilogue with another: 1.2 - 1.9 ms per 1024 prompts at 2 waves per SIMD, bound
+  // by neither HBM nor the matrix pipe).
+  union QF { uint4 u; sd_bf16x8 v; u16 h[8]; };
+  QF qn[KSN], pn[KSN];
+  auto fetch_q = [&](int strip) __attribute__((always_inline)) {
     const int tok = strip * 16 + c;
-    // ---- scores^T (64 x 16) = Kexp (64 x 128) . Q^T ------------------------------------------------------------
+#pragma unroll
+    for (int ks = 0; ks < KSN; ++ks) {
+      qn[ks].u = *reinterpret_cast<const uint4 *>(qb + (size_t)tok * q_ld + ks * 32 + g * 8);
+      if (q_add) pn[ks].u = *reinterpret_cast<const uint4 *>(q_add + (size_t)tok * KD + ks * 32 + g * 8);
+    }
+  };
+  const int strip0 = blockIdx.x * 4 + wave, sstep = gridDim.x * 4;
+  if (strip0 < nstrip) fetch_q(strip0);
+  for (int strip = strip0; strip < nstrip; strip += sstep) {
+    const int tok = strip * 16 + c;
+    // this strip's B fragments: q (+ W_q pe shared by every prompt; RAW: + pe itself), rounded to bf16
+    QF qa[KSN];
+#pragma unroll
+    for (int ks = 0; ks < KSN; ++ks) {
+      qa[ks] = qn[ks];
+      if (q_add) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qa[ks].h[e] = sd_f2bf(sd_bf2f(qa[ks].h[e]) + sd_bf2f(pn[ks].h[e]));
+      }
+    }
+    union RR { uint2 u; u16 h[4]; };
+    RR rr[16];                                                       // residual rows of this strip, first used in the epilogue
+#pragma unroll
+    for (int nt = 0; nt < 16; ++nt) rr[nt].u = *reinterpret_cast<const uint2 *>(rb + (size_t)tok * kSdC + nt * 16 + g * 4);
+    // ---- scores^T (64 x 16) = Kexp (64 x KD) . Q^T ------------------------------------------------------------
     sd_f32x4 s[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -88,20 +118,16 @@ __global__ __launch_bounds__(256, 2) void img2tok_kernel(const u16 *__restrict__
     }
 #pragma unroll
     for (int ks = 0; ks < KSN; ++ks) {
-      union { uint4 u; sd_bf16x8 v; u16 h[8]; } qa;
-      qa.u = *reinterpret_cast<const uint4 *>(qb + (size_t)tok * q_ld + ks * 32 + g * 8);
-      if (q_add) {                                                   // + W_q pe (shared by every prompt); RAW: + pe itself
-        union { uint4 u; u16 h[8]; } pa;
-        pa.u = *reinterpret_cast<const uint4 *>(q_add + (size_t)tok * KD + ks * 32 + g * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qa.h[e] = sd_f2bf(sd_bf2f(qa.h[e]) + sd_bf2f(pa.h[e]));
-      }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const sd_bf16x8 ka = *reinterpret_cast<const sd_bf16x8 *>(Kl + (t * 16 + c) * KROWL + ks * 32 + g * 8);
-        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qa.v, s[t], 0, 0, 0);
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qa[ks].v, s[t], 0, 0, 0);
       }
     }
+    // the next strip's fragments fly under the softmax, the value product and the epilogue (requested here, where qa is dead: the
+    // RAW form holds 2 x 8 fragments and would otherwise run out of registers)
+    __builtin_amdgcn_sched_barrier(0);
+    if (strip + sstep < nstrip) fetch_q(strip + sstep);
     // ---- softmax over the 8 token slots of a head: row j = tile*16 + g*4 + r = h*8 + slot -> h = 2*tile + (g>>1),
     //      slot = (g&1)*4 + r: four registers here and four in the lane 16 away --------------------------------------
     union { sd_bf16x8 v; u16 h[8]; } pb[2];
@@ -144,11 +170,9 @@ __global__ __launch_bounds__(256, 2) void img2tok_kernel(const u16 *__restrict__
     float sum = 0.f;
 #pragma unroll
     for (int nt = 0; nt < 16; ++nt) {
-      union { uint2 u; u16 h[4]; } rr;
-      rr.u = *reinterpret_cast<const uint2 *>(rb + (size_t)tok * kSdC + nt * 16 + g * 4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        o[nt][r] += pl[nt * 16 + g * 4 + r] + sd_bf2f(rr.h[r]);
+        o[nt][r] += pl[nt * 16 + g * 4 + r] + sd_bf2f(rr[nt].h[r]);
         sum += o[nt][r];
       }
     }
@@ -223,15 +247,28 @@ __global__ __launch_bounds__(256, 2) void upscale_heads_kernel(const u16 *__rest
   }
   // a strip = 16 tokens x one sub-pixel (dy, dx): 4N/16 strips per prompt
   const int nstrip = N / 16 * 4;
-  for (int strip = blockIdx.x * 4 + wave; strip < nstrip; strip += gridDim.x * 4) {
+  // software-pipelined like img2tok_kernel (round 4): the two 16-byte pieces of the NEXT strip are requested before this strip's
+  // arithmetic (every strip used to start with a load -> LayerNorm dependency)
+  union YA { uint4 u; u16 hh[8]; };
+  YA yn[2];
+  auto fetch_y = [&](int strip) __attribute__((always_inline)) {
+    const int sp = strip & 3, tok = (strip >> 2) * 16 + c;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      yn[ks].u = *reinterpret_cast<const uint4 *>(y0 + ((size_t)b * N + tok) * y_ld + sp * kUpC1 + ks * 32 + g * 8);
+  };
+  const int strip0 = blockIdx.x * 4 + wave, sstep = gridDim.x * 4;
+  if (strip0 < nstrip) fetch_y(strip0);
+  for (int strip = strip0; strip < nstrip; strip += sstep) {
     const int sp = strip & 3, tok = (strip >> 2) * 16 + c;           // token of this lane's column
     // ---- LayerNorm2d + GELU on the 64-vector of (token, sub-pixel): 16 channels here, 48 in the lanes 16/32/48 away
     float x[2][8];
     float sum = 0.f;
+    YA ya[2] = {yn[0], yn[1]};
+    if (strip + sstep < nstrip) fetch_y(strip + sstep);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      union { uint4 u; u16 hh[8]; } a;
-      a.u = *reinterpret_cast<const uint4 *>(y0 + ((size_t)b * N + tok) * y_ld + sp * kUpC1 + ks * 32 + g * 8);
+      const YA a = ya[ks];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         x[ks][e] = sd_bf2f(a.hh[e]);

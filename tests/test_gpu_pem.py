@@ -275,3 +275,45 @@ def test_fp16_extractor_range_guard_reruns_overflowing_instances_in_fp32(net, mo
             warnings.simplefilter("always")
             ok = net(dict(ep))
         assert not ok["f16_overflow"].any() and not any("overflowed" in str(x.message) for x in w)
+
+
+def test_range_guard_flag_survives_graph_capture_and_replay(net, monkeypatch):
+    """FramePipeline._pem_forward captures Net.forward (IEEE-half extractor) into a hipGraph and reads the guard's flag after every
+    replay.  The flag kernel must work inside a capture: a healthy network replays with no flag set and no fp32 re-run (round 4: a
+    memset node in the capture left the flags unset, every replay was followed by an eager fp32 forward -- 31 instead of 16 ms per
+    10 instances), and an overflowing one is still caught."""
+    import warnings
+
+    from sam6d_amd import pipeline
+    from sam6d_amd.pem import pose_estimation_model as pm
+    monkeypatch.setenv("S6D_PEM_VIT_DTYPE", "fp16")
+    B = 4
+    inp = synth.pem_inputs(B, seed=7)
+    ep = _to({k: inp[k] for k in ("pts", "rgb", "rgb_choose", "model", "dense_po", "dense_fo")}, "cuda")
+    ep["coarse_rand_u"] = synth.coarse_uniforms(B, 6).cuda()
+    for bad in (False, True):
+        n = pm.Net(pm.default_cfg()).eval().cuda()
+        n.load_state_dict(net.state_dict())
+        if bad:
+            with torch.no_grad():
+                n.feature_extraction.rgb_net.vit.blocks[3].mlp.fc2.bias[5] = 1.0e5
+        calls = []
+
+        class Counted:                                                  # the pipeline's own calls of the network (not the guard's inner re-run)
+            def __call__(self, e):
+                calls.append(1)
+                return n(e)
+
+            def __getattr__(self, name):
+                return getattr(n, name)
+        fp = pipeline.FramePipeline.__new__(pipeline.FramePipeline)
+        fp.pem, fp.graph_max, fp._pem_graphs = Counted(), 16, {}
+        with torch.no_grad(), warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            fp._pem_forward(dict(ep))                                   # warm-up x 2 + capture (+ the re-run when flagged)
+            k = len(calls)
+            out = fp._pem_forward(dict(ep))                             # replay
+        reran = len(calls) - k
+        assert reran == (1 if bad else 0), (bad, reran)
+        assert any("overflowed" in str(x.message) for x in w) == bad
+        assert torch.isfinite(out["pred_R"]).all()

@@ -30,7 +30,7 @@ extern "C" {
 
 /* Bumped whenever a signature in this header changes; the loader (sam6d_amd/_lib.py) refuses a library whose
  * s6d_version() differs from the header it was written against (a stale .so fails at load, not at a call). */
-#define S6D_ABI_VERSION 118
+#define S6D_ABI_VERSION 119
 int s6d_version(void);
 const char *s6d_strerror(int code);
 /* last HIP error string seen by this thread (empty if none) */
@@ -162,6 +162,13 @@ int s6d_min_dist_f32(const float *pts, const float *R, const float *t, const flo
 int s6d_rpe_attention_f32(const float *q, const float *k, const float *v, const float *qt, const float *qb,
                           const float *embed, int B, int N, int C, int heads, float scale, float *out,
                           void *stream);
+
+/* The same core with q | k | v | q~ | qb taken as column blocks of ONE projection output proj (B,N,ld) f32 (offsets in floats, multiples
+ * of 4; q~ is 4 x 256 wide: head h at qt_off + 256 h; qb 4 wide): the caller folds W_p into the projection's weights
+ * (q~_h = x (W_q,h^T W_p,h) + b_q,h W_p,h; qb_h = x (W_q,h^T b_p,h) + b_q,h . b_p,h), so `W_p^T q` is not a pass of its own.
+ * ref: as s6d_rpe_attention_f32 (transformer.py:368-406). */
+int s6d_rpe_attention_packed_f32(const float *proj, long ld, int q_off, int k_off, int v_off, int qt_off, int qb_off,
+                                 const float *embed, int B, int N, int C, int heads, float scale, float *out, void *stream);
 /* The same with row strides ldq / ldk / ldv (floats, multiples of 4) for q / k / v: the column blocks of one q | k | v projection
  * output are attended without copies. */
 int s6d_rpe_attention_strided_f32(const float *q, long ldq, const float *k, long ldk, const float *v, long ldv, const float *qt,

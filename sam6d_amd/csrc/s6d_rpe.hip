@@ -22,7 +22,10 @@ template <int WAVES, bool RPE>
 __global__ __launch_bounds__(WAVES * 64) void rpe_attention_kernel(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ qt, const float *__restrict__ qb, const float *__restrict__ embed,
-    int B, int N, int M, float scale, float *__restrict__ out, long ldq, long ldk, long ldv) {
+    int B, int N, int M, float scale, float *__restrict__ out, long ldq, long ldk, long ldv, long qt_bs, long qt_rs, long qt_hs,
+    long qb_bs, long qb_rs, long qb_hs) {
+  // qt (b, head, n, 256) at b qt_bs + n qt_rs + head qt_hs, qb (b, head, n) at b qb_bs + n qb_rs + head qb_hs: (B,4,N,256) / (B,4,N)
+  // tensors of their own, or column blocks of the SAME projection output as q | k | v (round 4: W_p folded into the projection)
   // ldq / ldk / ldv: row strides (floats) of q / k / v -- 256 for contiguous tensors, the projection's row width when they are the
   // column blocks of one q | k | v (k | v) projection output (no .contiguous() copies between the Linear and the attention)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -40,12 +43,12 @@ __global__ __launch_bounds__(WAVES * 64) void rpe_attention_kernel(
   float qbg = 0.f;
   const float *erow = nullptr;
   if (RPE) {
-    const float *base = qt + ((size_t)b * 4 * N + n) * 256 + c4;         // (B,4,N,256)
+    const float *base = qt + (size_t)b * qt_bs + (size_t)n * qt_rs + c4;
     t0 = *reinterpret_cast<const float4 *>(base);
-    t1 = *reinterpret_cast<const float4 *>(base + (size_t)N * 256);
-    t2 = *reinterpret_cast<const float4 *>(base + (size_t)2 * N * 256);
-    t3 = *reinterpret_cast<const float4 *>(base + (size_t)3 * N * 256);
-    qbg = qb[((size_t)b * 4 + g) * N + n];
+    t1 = *reinterpret_cast<const float4 *>(base + qt_hs);
+    t2 = *reinterpret_cast<const float4 *>(base + 2 * qt_hs);
+    t3 = *reinterpret_cast<const float4 *>(base + 3 * qt_hs);
+    qbg = qb[(size_t)b * qb_bs + (size_t)n * qb_rs + (size_t)g * qb_hs];
     erow = embed + (size_t)row * M * 256 + c4;
   }
   const float *krow = k + (size_t)b * M * ldk + c4;
@@ -124,7 +127,30 @@ extern "C" int s6d_rpe_attention_strided_f32(const float *q, long ldq, const flo
   const size_t lds = (size_t)WAVES * 4 * Np * sizeof(float);
   if (lds > 64 * 1024) return S6D_EUNSUPPORTED;
   hipLaunchKernelGGL((rpe_attention_kernel<WAVES, true>), dim3((unsigned)((rows + WAVES - 1) / WAVES)), dim3(WAVES * 64),
-                     lds, as_stream(stream), q, k, v, qt, qb, embed, B, N, N, scale, out, ldq, ldk, ldv);
+                     lds, as_stream(stream), q, k, v, qt, qb, embed, B, N, N, scale, out, ldq, ldk, ldv, 4L * N * 256, 256L, (long)N * 256,
+                     4L * N, 1L, (long)N);
+  return launch_status();
+}
+
+// q | k | v | q~ (4 x 256) | qb (4) as column blocks of ONE projection output proj (B,N,ld): W_p of the RPE layer is folded into the
+// projection's weights by the caller (q~_h = x (W_q,h^T W_p,h) + b_q,h W_p,h), so the `W_p^T q` products of the layer are not a pass.
+extern "C" int s6d_rpe_attention_packed_f32(const float *proj, long ld, int q_off, int k_off, int v_off, int qt_off, int qb_off,
+                                            const float *embed, int B, int N, int C, int heads, float scale, float *out,
+                                            void *stream) {
+  if (B < 0 || N <= 0 || C != 256 || heads != 4 || (ld % 4) != 0) return B < 0 || N <= 0 || (ld % 4) ? S6D_EINVAL : S6D_EUNSUPPORTED;
+  if (q_off < 0 || k_off < 0 || v_off < 0 || qt_off < 0 || qb_off < 0 || (q_off % 4) || (k_off % 4) || (v_off % 4) || (qt_off % 4) ||
+      q_off + C > ld || k_off + C > ld || v_off + C > ld || qt_off + 4 * C > ld || qb_off + 4 > ld)
+    return S6D_EINVAL;
+  if (B == 0) return S6D_OK;
+  if (!proj || !embed || !out || ((uintptr_t)proj & 15)) return S6D_EINVAL;
+  constexpr int WAVES = 4;
+  const long rows = (long)B * N;
+  const int Np = (N + 3) & ~3;
+  const size_t lds = (size_t)WAVES * 4 * Np * sizeof(float);
+  if (lds > 64 * 1024) return S6D_EUNSUPPORTED;
+  hipLaunchKernelGGL((rpe_attention_kernel<WAVES, true>), dim3((unsigned)((rows + WAVES - 1) / WAVES)), dim3(WAVES * 64),
+                     lds, as_stream(stream), proj + q_off, proj + k_off, proj + v_off, proj + qt_off, proj + qb_off, embed, B, N, N,
+                     scale, out, ld, ld, ld, (long)N * ld, ld, 256L, (long)N * ld, ld, 1L);
   return launch_status();
 }
 
@@ -147,7 +173,7 @@ extern "C" int s6d_mha_strided_f32(const float *q, long ldq, const float *k, lon
   const size_t lds = (size_t)WAVES * 4 * Np * sizeof(float);
   if (lds > 64 * 1024) return S6D_EUNSUPPORTED;
   hipLaunchKernelGGL((rpe_attention_kernel<WAVES, false>), dim3((unsigned)((rows + WAVES - 1) / WAVES)), dim3(WAVES * 64),
-                     lds, as_stream(stream), q, k, v, nullptr, nullptr, nullptr, B, N, M, scale, out, ldq, ldk, ldv);
+                     lds, as_stream(stream), q, k, v, nullptr, nullptr, nullptr, B, N, M, scale, out, ldq, ldk, ldv, 0L, 0L, 0L, 0L, 0L, 0L);
   return launch_status();
 }
 

@@ -197,6 +197,18 @@ def rpe_attention(q, k, v, qt, qb, embed, scale):
     return out
 
 
+def rpe_attention_packed(proj, embed, scale, q_off=0, k_off=256, v_off=512, qt_off=768, qb_off=1792):
+    """rpe_attention on ONE projection output proj (B,N,ld) f32 holding q | k | v | q~ (4 x 256) | qb (4) as column blocks (W_p folded
+    into the projection's weights by the caller) -> (B,N,256) f32."""
+    _chk(proj, torch.float32, "proj", 3)
+    _chk(embed, torch.float32, "embed", 4)
+    B, N, ld = proj.shape
+    out = torch.empty(B, N, 256, dtype=torch.float32, device=proj.device)
+    _call("s6d_rpe_attention_packed_f32", _ptr(proj), ctypes.c_long(ld), int(q_off), int(k_off), int(v_off), int(qt_off), int(qb_off),
+          _ptr(embed), B, N, 256, 4, ctypes.c_float(scale), _ptr(out), _stream())
+    return out
+
+
 # ------------------------------------------------------------------ edges of the path
 def sam_preprocess(x, mean, std, img_size, out_dtype=torch.bfloat16):
     """(B,3,h,w) f32 -> (B,3,S,S) normalised + zero padded, in `out_dtype` (bf16 or f32).  [Sam.preprocess]"""
@@ -1125,7 +1137,7 @@ _FUSED = {}
 
 def have(name):
     if name not in _FUSED:
-        sym = {"rpe_attention": "s6d_rpe_attention_f32", "geo_embedding": "s6d_geo_embedding_f32",
+        sym = {"rpe_attention": "s6d_rpe_attention_f32", "rpe_attention_packed": "s6d_rpe_attention_packed_f32", "geo_embedding": "s6d_geo_embedding_f32",
                "fine_assign": "s6d_fine_assign_f32", "fine_match": "s6d_fine_match_f32", "pem_pre": "s6d_pem_compact_cloud_f32", "coarse_sample": "s6d_coarse_sample_f32", "upsample_gather": "s6d_upsample_gather_f32",
                "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "add_layernorm": "s6d_add_layernorm_bf16", "gemm_bf16": "s6d_gemm_bf16", "gemm_bf16_res": "s6d_gemm_bf16_res", "gemm_bf16_lnfold": "s6d_gemm_bf16_lnfold", "gemm_f16": "s6d_gemm_f16", "gemm_fp8": "s6d_gemm_fp8", "layernorm_fp8": "s6d_layernorm_fp8", "layernorm_f32out": "s6d_layernorm_bf16_f32", "linear_f32": "s6d_linear_f32", "win_attention": "s6d_win_attention_layout_bf16",
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",

@@ -11,6 +11,7 @@ the forward passes are re-derived for the hardware rather than transcribed:
     gfx950 kernel exists (see ops.HAVE) and are expressed with library GEMMs otherwise.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -120,8 +121,38 @@ class RPEMultiHeadAttention(nn.Module):
         self.d_model = d_model
         self.scale = 1.0 / math.sqrt(d_model // num_heads)
 
+    def _fold(self):
+        """W_p folded into the q projection (round 4): a Linear-shaped holder of the 1280 x 256 weight whose rows are, per head h,
+        the 256 rows of W_p,h^T W_q,h (q~_h = W_p,h^T q_h as a function of x), then the 4 rows b_p,h^T W_q,h (qb_h), then zeros up
+        to a whole 256-column tile; biases W_p,h^T b_q,h and b_q,h . b_p,h.  float64 products, cached until a parameter changes."""
+        ps = (self.proj_q.weight, self.proj_q.bias, self.proj_p.weight, self.proj_p.bias)
+        key = tuple((t._version, t.data_ptr()) for t in ps)
+        c = self.__dict__.get("_s6d_fold")
+        if c is None or c[0] != key:
+            with torch.no_grad():
+                C = self.d_model
+                c_ = C // HEADS
+                wq, bq = self.proj_q.weight.detach().double().view(HEADS, c_, C), self.proj_q.bias.detach().double().view(HEADS, c_)
+                wp, bp = self.proj_p.weight.detach().double().view(HEADS, c_, C), self.proj_p.bias.detach().double().view(HEADS, c_)
+                w = torch.zeros(HEADS * C + C, C, dtype=torch.float64, device=wq.device)
+                b = torch.zeros(HEADS * C + C, dtype=torch.float64, device=wq.device)
+                w[:HEADS * C] = torch.einsum("hcj,hck->hjk", wp, wq).reshape(HEADS * C, C)
+                b[:HEADS * C] = torch.einsum("hcj,hc->hj", wp, bq).reshape(HEADS * C)
+                w[HEADS * C:HEADS * C + HEADS] = torch.einsum("hc,hck->hk", bp, wq)
+                b[HEADS * C:HEADS * C + HEADS] = (bp * bq).sum(1)
+                lin = torch.nn.Module()
+                lin.weight, lin.bias = w.float().contiguous(), b.float().contiguous()
+            c = (key, lin)
+            self.__dict__["_s6d_fold"] = c
+        return c[1]
+
     def forward(self, x, embed):
         B, N, C = x.shape
+        if (ops.have("rpe_attention_packed") and ops.have("linear_f32") and x.is_cuda and x.dtype == torch.float32 and C == 256
+                and not torch.is_grad_enabled() and os.environ.get("S6D_RPE_FOLD", "1") == "1"):
+            # q | k | v | q~ | qb from ONE launch of the projection kernel; the attention core reads them in place
+            proj = plinear(self, (self.proj_q, self.proj_k, self.proj_v, self._fold()), x)
+            return ops.rpe_attention_packed(proj, embed, self.scale)
         qkv = plinear(self, (self.proj_q, self.proj_k, self.proj_v), x)         # q | k | v in one launch
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]             # column blocks, attended in place (row stride 3 C)
         c = C // HEADS

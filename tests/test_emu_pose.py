@@ -14,7 +14,8 @@ def test_min_dist_on_the_emulator(emu):
 
 
 def test_rpe_attention_on_the_emulator(emu):
-    T.test_rpe_attention_vs_oracle(emu, 3, 50)
+    T.test_rpe_attention_vs_oracle(emu, 3, 50, "1")
+    T.test_rpe_attention_vs_oracle(emu, 3, 50, "0")
 
 
 def test_geo_embedding_on_the_emulator(emu):

@@ -138,8 +138,28 @@ def test_min_dist_vs_oracle(ops, N, P):
 
 
 @pytest.mark.parametrize("B,N", [(2, 197), (3, 50)])
-def test_rpe_attention_vs_oracle(ops, B, N):
-    """Fused RPE attention (q~.e rewrite, streamed embedding) vs the reference formulation."""
+@pytest.mark.parametrize("fold", ["1", "0"])
+def test_rpe_attention_vs_oracle(ops, B, N, fold):
+    """Fused RPE attention (q~.e rewrite, streamed embedding) vs the reference formulation.  fold = 1 (round 4, default): W_p folded
+    into the q | k | v projection, the attention core reads q~ and qb in place from that launch's output (s6d_rpe_attention_packed_f32);
+    fold = 0: the `W_p^T q` products as library einsums in front of s6d_rpe_attention_strided_f32."""
+    import os
+
+    from sam6d_amd.pem.layers import RPEMultiHeadAttention
+    from sam6d_amd.utils import seeded
+    os.environ["S6D_RPE_FOLD"] = fold
+    calls = []
+    real = ops.rpe_attention_packed
+    ops.rpe_attention_packed = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        _rpe_case(ops, B, N)
+    finally:
+        ops.rpe_attention_packed = real
+        os.environ.pop("S6D_RPE_FOLD", None)
+    assert len(calls) == (1 if fold == "1" else 0)
+
+
+def _rpe_case(ops, B, N):
     from sam6d_amd.pem.layers import RPEMultiHeadAttention
     from sam6d_amd.utils import seeded
     m = RPEMultiHeadAttention(256).eval()

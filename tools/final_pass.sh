@@ -12,13 +12,13 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -o f
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -o w -- python tools/pmc_kernels.py > /dev/null 2>&1
 python tools/pmc_summarise.py gpurun_out/prof/${R}_pmc_summary.json /tmp/pmc_f /tmp/pmc_w > /dev/null 2>&1
 cp gpurun_out/prof/${R}_pmc_summary.json profiles/${R}_pmc_summary.json   # the bench line below reads its roofline.traffic from it
-timeout 900 python bench.py --steps 5 --warmup 2 > gpurun_out/prof/${R}_bench_line.json 2> gpurun_out/prof/${R}_bench.err
+( time timeout 900 python bench.py --steps 5 --warmup 2 > gpurun_out/prof/${R}_bench_line.json 2> gpurun_out/prof/${R}_bench.err ) 2> gpurun_out/prof/${R}_bench_wallclock.txt
 # same box A/B of the round's host-visible change in the step: the IEEE-half range guard's host read at the end of the PEM stage
 S6D_PEM_F16_GUARD=0 timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline --no-fp8 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('guard off:', d['value'], d['ms_per_step'])" > gpurun_out/prof/${R}_guard_ab.txt
 timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline --no-fp8 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('guard on: ', d['value'], d['ms_per_step'])" >> gpurun_out/prof/${R}_guard_ab.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o bench -- python bench.py --steps 3 --warmup 1 --no-extras > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o bench -- python bench.py --steps 8 --warmup 1 --no-extras > /dev/null 2>&1
 cp $(find /tmp/prof_bench -name "*kernel_stats.csv" | head -1) gpurun_out/prof/${R}_bench_kernel_stats.csv
-S6D_BENCH_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_serial -o bench -- python bench.py --steps 3 --warmup 1 --no-extras > /dev/null 2>&1
+S6D_BENCH_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_serial -o bench -- python bench.py --steps 8 --warmup 1 --no-extras > /dev/null 2>&1
 cp $(find /tmp/prof_serial -name "*kernel_stats.csv" | head -1) gpurun_out/prof/${R}_bench_serial_kernel_stats.csv
 cat > /tmp/fd.py <<'PY'
 import json, os, sys, torch
@@ -44,6 +44,14 @@ print({k: d.get(k) for k in ("value", "ms_per_step", "stages_ms", "roofline", "e
 print("fp8", {k: d.get("configs", {}).get("fp8", {}).get(k) for k in ("value", "ms_per_step", "error")})
 print("pipeline", d.get("pipeline"))
 print("cpu", d.get("cpu_baseline"))
+for m in ("fp8", "fp8mx"):
+    c = d.get("configs", {}).get(m, {})
+    print(m, c.get("value"), c.get("ms_per_step"), (c.get("pipeline") or {}).get("frames_per_s"), c.get("error"))
+import csv
+rows = list(csv.DictReader(open("gpurun_out/prof/r04_bench_serial_kernel_stats.csv")))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+own = sum(float(r["TotalDurationNs"]) for r in rows if "s6d" in r["Name"])
+print("kernels of this library: %.1f %% of the traced GPU time; library kernels: %.1f %%" % (100 * own / tot, 100 * (1 - own / tot)))
 for k in d.get("kernels", []):
     print(k["kernel"][:100], k["avg_ms"], k["frac"], k.get("pmc_key"))
 PY

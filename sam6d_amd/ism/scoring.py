@@ -221,7 +221,12 @@ class FrameScorer(ScoringMixin):
         # the selected proposals are NAMED to the kernels (sel32), not copied out: `query_appe_descriptors[idx_selected]` and
         # `masks[idx_selected]` of the reference (detector.py:341-353) moved 1 MB + 1.2 MB per selected proposal through HBM twice
         sel32 = sel.int().contiguous()
+        sel_m = sel32
         qall = qry_patch.reshape(F_ * P, *qry_patch.shape[2:])
+        if qall.dtype != torch.float32 or not qall.is_contiguous():
+            # half descriptors are converted to float32 for the kernel: convert the SELECTED rows only (the index form would convert
+            # every proposal's 256 x 1024 descriptors first)
+            qall, sel32 = qall[sel].contiguous(), None
         appe, ref = self.compute_appearance_score(bt, pobj, qall, sel=sel32)
         if not isinstance(ref, RefPatchHandle):
             raise RuntimeError("score_frames is the batched device path (fp32 / half descriptors on the GPU); use score() per frame")
@@ -231,7 +236,7 @@ class FrameScorer(ScoringMixin):
         if mall.dtype != torch.float32 or not mall.is_contiguous():
             mall, msel = mall[sel].to(torch.float32).contiguous(), None
         else:
-            msel = sel32
+            msel = sel_m
         f32 = frame.int().contiguous()
         poses, pcs = self.ref_data["poses"], self.ref_data["pointcloud"]
         t = ops.masked_depth_mean(mall, depth.to(torch.float32).contiguous(), Kf, float(depth_scale), frame=f32, sel=msel)

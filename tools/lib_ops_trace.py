@@ -51,7 +51,7 @@ def trace(name, fn, lines):
             by[key][0] += 1
             by[key][1] += d
     lines.append(f"== {name}: library kernels {lib / 1e3:.3f} ms of {tot / 1e3:.3f} ms GPU time ({100 * lib / max(tot, 1e-9):.1f} %)")
-    for (site, op, kern), (n, d) in sorted(by.items(), key=lambda kv: -kv[1][1])[:70]:
+    for (site, op, kern), (n, d) in sorted(by.items(), key=lambda kv: -kv[1][1])[:110]:
         lines.append(f"  {d / 1e3:7.3f} ms {n:4d}x  {kern[:34]:34s} {op[:24]:24s} {site}")
 
 
@@ -60,7 +60,28 @@ def main():
     ap.add_argument("--out")
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--stages", default="pem,ism,sam")
+    ap.add_argument("--pipeline", action="store_true", help="trace one whole frame of tools/frame_demo.py's FramePipeline instead")
     a = ap.parse_args()
+    if a.pipeline:
+        os.environ.setdefault("S6D_PEM_VIT_DTYPE", "fp16")
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import frame_demo
+        pipe, args = frame_demo.build(torch.device("cuda", 0))
+        lines = []
+        for _ in range(2):
+            pipe(*args)
+        trace("whole frame (FramePipeline, one frame, graphs as the pipeline uses them)", lambda: pipe(*args), lines)
+        os.environ["S6D_AMG_GRAPH"] = "0"
+        os.environ["S6D_PEM_GRAPH"] = "0"
+        pipe.invalidate_graphs()
+        pipe(*args)
+        trace("whole frame, hipGraph replay off (every launch visible to the profiler)", lambda: pipe(*args), lines)
+        txt = "\n".join(lines)
+        print(txt)
+        if a.out:
+            os.makedirs(os.path.dirname(a.out), exist_ok=True)
+            open(a.out, "w").write(txt + "\n")
+        return
     import bench
     dev = torch.device("cuda:0")
     hp = bench.HotPath(dev, a.frames, 16)

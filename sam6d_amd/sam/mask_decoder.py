@@ -31,6 +31,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from ..utils.linear import CastCachedLinear
 from .image_encoder import LayerNorm2d, MLPBlock
 
 
@@ -152,10 +153,11 @@ class Attention(nn.Module):
         super().__init__()
         self.embedding_dim, self.internal_dim, self.num_heads = embedding_dim, embedding_dim // downsample_rate, num_heads
         assert self.internal_dim % num_heads == 0, "num_heads must divide embedding_dim."
-        self.q_proj = nn.Linear(embedding_dim, self.internal_dim)
-        self.k_proj = nn.Linear(embedding_dim, self.internal_dim)
-        self.v_proj = nn.Linear(embedding_dim, self.internal_dim)
-        self.out_proj = nn.Linear(self.internal_dim, embedding_dim)
+        # CastCachedLinear = nn.Linear with its autocast weight casts kept across calls (checkpoint keys unchanged)
+        self.q_proj = CastCachedLinear(embedding_dim, self.internal_dim)
+        self.k_proj = CastCachedLinear(embedding_dim, self.internal_dim)
+        self.v_proj = CastCachedLinear(embedding_dim, self.internal_dim)
+        self.out_proj = CastCachedLinear(self.internal_dim, embedding_dim)
 
     def _heads(self, x):
         b, n, c = x.shape
@@ -181,6 +183,8 @@ class TwoWayAttentionBlock(nn.Module):
         self.cross_attn_token_to_image = Attention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
         self.norm2 = nn.LayerNorm(embedding_dim)
         self.mlp = MLPBlock(embedding_dim, mlp_dim, activation)
+        self.mlp.lin1.__class__ = CastCachedLinear                  # same parameters; the cast cache of the class above
+        self.mlp.lin2.__class__ = CastCachedLinear
         self.norm3 = nn.LayerNorm(embedding_dim)
         self.norm4 = nn.LayerNorm(embedding_dim)
         self.cross_attn_image_to_token = Attention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
@@ -240,7 +244,7 @@ class MLP(nn.Module):
         super().__init__()
         self.num_layers = num_layers
         h = [hidden_dim] * (num_layers - 1)
-        self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
+        self.layers = nn.ModuleList(CastCachedLinear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
         self.sigmoid_output = sigmoid_output
 
     def forward(self, x):

@@ -26,6 +26,27 @@ def _cached(lin, w2d, dtype=torch.bfloat16):
     return c[1], c[2]
 
 
+class CastCachedLinear(torch.nn.Linear):
+    """nn.Linear (same parameters, same state_dict keys) whose autocast casts are cached ACROSS calls.  Under torch.autocast every
+    parameter is re-cast in every autocast region; for the mask decoder's token side -- some forty small Linear layers per batch of
+    prompts -- that is two 5-us cast kernels per layer and call (120 per frame, profiles/r04_library_ops_frame.txt).  Here the cast
+    copies are kept until the parameter changes (version / storage) and the product runs on them with autocast off: the same
+    operands, the same library GEMM, the same bits.  Inference only (no_grad); anything else is nn.Linear.forward."""
+
+    def forward(self, x):
+        if x.is_cuda and torch.is_autocast_enabled() and not torch.is_grad_enabled():
+            dt = torch.get_autocast_gpu_dtype()
+            w, b = self.weight, self.bias
+            key = (w._version, w.data_ptr(), None if b is None else (b._version, b.data_ptr()), dt)
+            c = self.__dict__.get("_s6d_cast")
+            if c is None or c[0] != key:
+                c = (key, w.detach().to(dt), None if b is None else b.detach().to(dt))
+                self.__dict__["_s6d_cast"] = c
+            with torch.autocast(device_type="cuda", enabled=False):
+                return F.linear(x if x.dtype == dt else x.to(dt), c[1], c[2])
+        return super().forward(x)
+
+
 def eligible(x, n_out, k_in):
     if x.is_cuda and x.dtype == torch.float16:           # IEEE half (PEM ViT-B): the 256 x 256-tile kernel only
         return n_out % 256 == 0 and k_in % 64 == 0 and ops.have("gemm_f16")

@@ -335,3 +335,34 @@ def test_decoder_batch_graph_replay_equals_eager(monkeypatch):
     g3 = run(inp["emb"])
     assert torch.allclose(g3["iou_preds"].float(), e1["iou_preds"].float() + 0.25, atol=2e-2) and len(amg._GRAPHS) == 2
     amg.invalidate_graphs()
+
+
+def test_cast_cached_linear_is_autocast_linear_bit_for_bit_and_follows_weight_updates():
+    """utils.linear.CastCachedLinear (the decoder's small Linear layers): under autocast its output equals nn.Linear's bit for bit (same
+    cast operands, same library product), the cast copies are reused across calls, and an in-place weight update or a
+    load_state_dict is picked up (the cache is keyed on the parameters' versions and storage)."""
+    from sam6d_amd.utils.linear import CastCachedLinear
+    g = torch.Generator().manual_seed(0)
+    ref = torch.nn.Linear(256, 128).cuda()
+    lin = CastCachedLinear(256, 128).cuda()
+    lin.load_state_dict(ref.state_dict())
+    x = torch.randn(1024, 7, 256, generator=g).cuda()
+    with torch.no_grad():
+        assert torch.equal(lin(x), ref(x))                                   # no autocast: nn.Linear.forward
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            a, b = lin(x), ref(x)
+            assert a.dtype == torch.bfloat16 and torch.equal(a, b)
+            w0 = lin.__dict__["_s6d_cast"][1]
+            lin(x)
+            assert lin.__dict__["_s6d_cast"][1] is w0                        # reused
+            ref.weight.mul_(1.5)
+            lin.weight.mul_(1.5)                                             # in-place update: version changes
+            assert torch.equal(lin(x), ref(x)) and lin.__dict__["_s6d_cast"][1] is not w0
+            sd = {k: v * 0.5 for k, v in ref.state_dict().items()}
+            ref.load_state_dict(sd)
+            lin.load_state_dict(sd)
+            assert torch.equal(lin(x), ref(x))
+        with torch.autocast(device_type="cuda", dtype=torch.float16):
+            assert torch.equal(lin(x), ref(x))                               # another autocast dtype: its own copies
+    y = lin(x)                                                               # grad enabled: nn.Linear.forward, differentiable
+    assert y.requires_grad

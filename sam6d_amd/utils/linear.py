@@ -34,8 +34,8 @@ class CastCachedLinear(torch.nn.Linear):
     operands, the same library GEMM, the same bits.  Inference only (no_grad); anything else is nn.Linear.forward."""
 
     def forward(self, x):
-        if x.is_cuda and torch.is_autocast_enabled() and not torch.is_grad_enabled():
-            dt = torch.get_autocast_gpu_dtype()
+        if x.is_cuda and torch.is_autocast_enabled("cuda") and not torch.is_grad_enabled():
+            dt = torch.get_autocast_dtype("cuda")
             w, b = self.weight, self.bias
             key = (w._version, w.data_ptr(), None if b is None else (b._version, b.data_ptr()), dt)
             c = self.__dict__.get("_s6d_cast")

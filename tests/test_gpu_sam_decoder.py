@@ -355,12 +355,16 @@ def test_cast_cached_linear_is_autocast_linear_bit_for_bit_and_follows_weight_up
             w0 = lin.__dict__["_s6d_cast"][1]
             lin(x)
             assert lin.__dict__["_s6d_cast"][1] is w0                        # reused
-            ref.weight.mul_(1.5)
-            lin.weight.mul_(1.5)                                             # in-place update: version changes
+        # (autocast's own cast cache is per region and is NOT invalidated by an in-place update inside the region: nn.Linear is
+        # compared in a fresh region after every change; CastCachedLinear follows the parameter's version in any region)
+        ref.weight.mul_(1.5)
+        lin.weight.mul_(1.5)                                                 # in-place update: version changes
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
             assert torch.equal(lin(x), ref(x)) and lin.__dict__["_s6d_cast"][1] is not w0
-            sd = {k: v * 0.5 for k, v in ref.state_dict().items()}
-            ref.load_state_dict(sd)
-            lin.load_state_dict(sd)
+        sd = {k: v * 0.5 for k, v in ref.state_dict().items()}
+        ref.load_state_dict(sd)
+        lin.load_state_dict(sd)
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
             assert torch.equal(lin(x), ref(x))
         with torch.autocast(device_type="cuda", dtype=torch.float16):
             assert torch.equal(lin(x), ref(x))                               # another autocast dtype: its own copies

@@ -30,7 +30,7 @@ extern "C" {
 
 /* Bumped whenever a signature in this header changes; the loader (sam6d_amd/_lib.py) refuses a library whose
  * s6d_version() differs from the header it was written against (a stale .so fails at load, not at a call). */
-#define S6D_ABI_VERSION 119
+#define S6D_ABI_VERSION 120
 int s6d_version(void);
 const char *s6d_strerror(int code);
 /* last HIP error string seen by this thread (empty if none) */
@@ -120,6 +120,13 @@ int s6d_pem_crops_f32(const unsigned char *image, const unsigned char *m, const 
 /* R = V diag(1,1,det(V U^T)) U^T for H = U S V^T, n matrices: H (n,3,3) f32 -> R (n,3,3) f32.
  * ref: weighted_procrustes, utils/model_utils.py:341-347 (torch.svd + det fix). */
 int s6d_rot_from_h_f32(const float *H, int n, float *R, void *stream);
+
+/* weighted_procrustes for one point set per instance (utils/model_utils.py:287-363 as compute_fine_Rt calls it, :268-271):
+ * src, ref (B,N,3) f32, weights (B,N) f32 (values below weight_thresh count as 0; normalised by sum + eps) -> R (B,3,3),
+ * t (B,3) with ref ~ src R^T + t.  One workgroup per instance, fixed summation order in double: an instance's result
+ * does not depend on B (the library op chain it replaces picked reduction / bmm configurations by batch size). */
+int s6d_weighted_procrustes_f32(const float *src, const float *ref, const float *weights, int B, int N, float weight_thresh,
+                                float eps, float *R, float *t, void *stream);
 
 /* Pose hypotheses of compute_coarse_Rt (utils/model_utils.py:216-231).
  * pts1 (B,N1,3), pts2 (B,N2,3) f32; pair (B,n_hyp,3) i32 = searchsorted() bins, decoded as

@@ -913,10 +913,224 @@ def gen_frame_e2e():
     print("size", os.path.getsize(os.path.join(OUT, "frame_e2e.npz")))
 
 
+def _e2e_query_proposals(g):
+    """The proposals the scoring half of frame_e2e.npz scored: SAM's (stored bit-packed) followed by the ten depth windows."""
+    from tests import util as tutil
+    fi = tutil.frame_inputs(dict(FRAME_CASE, P=10))
+    K = g["sam_boxes"].shape[0]
+    sam_masks = torch.from_numpy(np.unpackbits(g["sam_masks"], axis=1)[:, :480 * 640].reshape(K, 480, 640).astype(np.float32))
+    return fi, torch.cat([sam_masks, fi["masks"]]), torch.cat([torch.from_numpy(g["sam_boxes"]).long(), fi["boxes"].long()])
+
+
+def gen_frame_e2e_ism(tmp):
+    """Stage 1 of the pose half (ISM process): the REFERENCE's statements after the final score, on the reference's own scores
+    stored in frame_e2e.npz -- two flows:
+      bop    detector.py:349-352,383-400 (test_step): Detections.remove_very_small_detections -> [descriptors / scores: stored]
+             -> filter -> add_attribute(scores / object_ids = pred_idx_objects) -> apply_nms_per_object_id(0.25) -> to_numpy ->
+             save_to_file -> convert_npz_to_json;
+      custom run_inference_custom.py:161-205 (demo.sh): no size filter, no NMS; object_ids keep the predicted objects (the
+             script's zeros_like is its single-object special case: this case scores three objects).
+    torchvision is not installable: box_area / nms are supplied as in gen_detections_ops (the NMS boundary stays unpinned)."""
+    import importlib
+    import json
+    from tests import util as tutil
+    from . import sam_decoder as od
+    rh.ism()
+    mu = importlib.import_module("model.utils")
+    mu.box_area = lambda b: (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    mu.torchvision.ops.nms = od.nms
+    pc = tutil.E2E_POSE_CASE
+    g = np.load(os.path.join(OUT, "frame_e2e.npz"))
+    fi, q_masks, q_boxes = _e2e_query_proposals(g)
+    sel, final, pobj = torch.from_numpy(g["sel"]), torch.from_numpy(g["final"]), torch.from_numpy(g["pred_obj"])
+    for flow in ("bop", "custom"):
+        det = mu.Detections({"masks": q_masks.clone(), "boxes": q_boxes.clone()})
+        if flow == "bop":
+            n0 = len(det)
+            det.remove_very_small_detections(types.SimpleNamespace(min_box_size=pc["min_box_size"], min_mask_size=pc["min_mask_size"]))
+            assert len(det) == n0, "the stored scores were computed on the unfiltered proposal list"
+        det.filter(sel)
+        det.add_attribute("scores", final.clone())
+        det.add_attribute("object_ids", pobj.clone())
+        if flow == "bop":
+            det.apply_nms_per_object_id(nms_thresh=pc["nms_thresh"])
+        det.to_numpy()
+        path = os.path.join(tmp, "det_" + flow)
+        det.save_to_file(pc["scene_id"], pc["frame_id"], 0.0, path, pc["dataset"] if flow == "bop" else "Custom", return_results=False)
+        recs = mu.convert_npz_to_json(idx=0, list_npz_paths=[path + ".npz"])
+        json.dump(recs, open(path + ".json", "w"))
+        print("frame_e2e_pose/ism", flow, len(recs), "detections, scores", [round(r["score"], 4) for r in recs])
+
+
+def gen_frame_e2e_pem(tmp):
+    """Stage 2 of the pose half (PEM process): template onboarding through the REFERENCE Net.feature_extraction.get_obj_feats
+    (test_bop.py:117-119), the score threshold (bop_test_dataset.py:84 / run_inference_custom.py:169-171), the reference's rle
+    decoder, the per-detection loop (oracle/pem_pre.py with injected sampling keys; one radius per detection = its object's,
+    bop_test_dataset.py:125), per-object template rows (test_bop.py:143-147), the REFERENCE Net in one batch with the generator
+    seeded (run_inference_custom.py:281-285), and the reference's two result writers executed from its files.  Detections are
+    taken best-first (stable), the order sam6d_amd.pipeline.FramePipeline hands them on: a row of the batch does not depend on
+    its neighbours in the reference either, the order only fixes which row of the injected randoms an instance consumes."""
+    import copy
+    import json
+    import time
+    from tests import util as tutil
+    from . import pem_pre as opre
+    du = rh.pem_data_utils()
+    ns = rh.pem()
+    pc = tutil.E2E_POSE_CASE
+    pin = tutil.e2e_pose_inputs(pc)
+    fi = pin["fi"]
+    net = ns.pose_estimation_model.Net(rh.pem_cfg().model).eval()
+    seeded.load_seeded(net, pc["pem_weight_seed"])
+    pem_dir = os.path.join(rh.REF_ROOT, "SAM-6D", "Pose_Estimation_Model")
+    rec = {}
+    with torch.no_grad():
+        dense_po, dense_fo = net.feature_extraction.get_obj_feats(pin["tem_rgb"], pin["tem_pts"], pin["tem_choose"])
+    rec["dense_po"] = dense_po.numpy()
+    for k in ("gt_R", "gt_t", "tem_obj_pts", "tem_v1"):                          # frozen: see tests/util.e2e_pose_inputs
+        rec[k] = pin[k].numpy()
+    rec["dense_fo_sum"], rec["dense_fo_smp"] = digest(dense_fo, 101)
+    depth = fi["depth_mm"].numpy() * np.float32(fi["depth_scale"]) / np.float32(1000.0)
+    for flow in ("bop", "custom"):
+        dets_ = json.load(open(os.path.join(tmp, "det_" + flow + ".json")))
+        order = sorted(range(len(dets_)), key=lambda i: -dets_[i]["score"])                 # stable: ties keep file order
+        dets = [dets_[i] for i in order if dets_[i]["score"] > pc["det_score_thresh"]]
+        masks = np.stack([du.rle_to_binary_mask(d["segmentation"]) for d in dets]).astype(bool)
+        obj = np.array([d["category_id"] - 1 for d in dets])
+        obs = opre.preprocess_frame(fi["rgb"], depth, fi["K"].numpy(), masks, pin["radius"].numpy()[obj], keys=pin["keys"].numpy()[:len(dets)])
+        kept = obs["kept"]
+        M = len(kept)
+        o = torch.from_numpy(obj[kept])
+        ep = dict(pts=torch.from_numpy(obs["pts"]), rgb=torch.from_numpy(obs["rgb"]), rgb_choose=torch.from_numpy(obs["rgb_choose"]),
+                  model=pin["model"][o].contiguous(), dense_po=dense_po[o].contiguous(), dense_fo=dense_fo[o].contiguous())
+        t0 = time.time()
+        with torch.no_grad():
+            torch.manual_seed(pc["rand_seed"])
+            out = net(dict(ep))
+        print("frame_e2e_pose/pem", flow, "reference Net on", M, "instances:", round(time.time() - t0, 1), "s")
+        # ---- conditioning of the reference ITSELF.  compute_coarse_Rt (model_utils.py:187-246) draws 6000 hypotheses through a
+        # searchsorted on a float32 cumsum of 38 416 weights, keeps 300 by a topk and picks one by an arg-max: three discontinuous
+        # steps.  On unrelated features (seeded weights) near-ties exist, and the SAME torch code then answers differently on
+        # another CPU (seen: the oracle's restatement on the GPU box's host against this container's).  Measured implementation
+        # noise at the similarity matrix (product vs oracle, tools/probes/e2e_diag2.py): rms 1e-5 on values of rms 3.  The reference's
+        # own compute_coarse_Rt is therefore called again 48 times per instance on its own inputs with that noise ADDED to the matrix
+        # (the generator re-seeded to the same uniforms each time); an instance whose coarse pose moves in any trial cannot be held
+        # to the bar by anybody: marked unstable, stored, reported by the tests instead of asserted.  The whole Net is also re-run
+        # three times on inputs moved by 1e-5 x rms (colour crop, template features) for the continuous part.
+        cap = {}
+        cpm = ns.coarse_point_matching
+        real_coarse = cpm.compute_coarse_Rt
+
+        def spy(atten, pts1, pts2, *a, **k):
+            cap.update(atten=atten.clone(), pts1=pts1.clone(), pts2=pts2.clone(), a=a, k=k)
+            return real_coarse(atten, pts1, pts2, *a, **k)
+        cpm.compute_coarse_Rt = spy
+        try:
+            with torch.no_grad():
+                torch.manual_seed(pc["rand_seed"])
+                chk = net(dict(ep))
+        finally:
+            cpm.compute_coarse_Rt = real_coarse
+        assert torch.equal(chk["pred_R"], out["pred_R"])
+        stable = np.ones(M, bool)
+        coarse_move = np.zeros(M, np.float32)
+        rms = cap["atten"].pow(2).mean().sqrt()
+        for trial in range(48):
+            gq = torch.Generator().manual_seed(700 + trial)
+            # even trials: noise on the similarity matrix; odd trials: the sparse points moved by float32 rounding-level relative
+            # noise (2e-7) -- hypotheses from triplets with a repeated or collinear point have a rank-deficient 3 x 3 covariance
+            # whose SVD completion is arbitrary (it follows the LAPACK build / CPU), they fit their own three points perfectly, so
+            # they survive the topk, and on junk features one of them can win the arg-max
+            noisy, q1, q2 = cap["atten"], cap["pts1"], cap["pts2"]
+            if trial % 2 == 0:
+                noisy = noisy + 1e-5 * torch.randn(noisy.shape, generator=gq)
+            else:
+                q1 = q1 * (1 + 2e-7 * torch.randn(q1.shape, generator=gq))
+                q2 = q2 * (1 + 2e-7 * torch.randn(q2.shape, generator=gq))
+            with torch.no_grad():
+                torch.manual_seed(pc["rand_seed"])
+                R2, t2 = real_coarse(noisy, q1, q2, *cap["a"], **cap["k"])
+            d = (R2 - out["init_R"]).flatten(1).norm(dim=1).numpy()
+            coarse_move = np.maximum(coarse_move, d)
+        stable &= coarse_move <= 1e-4
+        print("  coarse pose movement under 1e-5 noise on the similarity matrix (rms", float(rms), ") / 2e-7 relative on the points, max over 48 trials:",
+              coarse_move.round(4).tolist())
+        move = np.zeros((3, M), np.float32)
+        for trial in range(3):
+            gq = torch.Generator().manual_seed(900 + trial)
+            ep2 = dict(ep)
+            for k in ("rgb", "dense_fo"):
+                ep2[k] = ep[k] + 1e-5 * ep[k].pow(2).mean().sqrt() * torch.randn(ep[k].shape, generator=gq)
+            with torch.no_grad():
+                torch.manual_seed(pc["rand_seed"])
+                o2 = net(ep2)
+            dR2 = (o2["pred_R"] - out["pred_R"]).flatten(1).norm(dim=1).numpy()
+            dt2 = (o2["pred_t"] - out["pred_t"]).norm(dim=1).numpy() * 1e3
+            move[trial] = dR2
+            stable &= (dR2 <= 1e-3) & (dt2 <= 1e-3)
+        print("  reference pose movement under 1e-5 x rms additive input noise (max dR over three trials):", move.max(0).round(6).tolist(), "stable", stable.tolist())
+        sub = [dets[i] for i in kept.tolist()]
+        det_score = torch.FloatTensor([d["score"] for d in sub])
+        p = flow + "_"
+        # test_bop.py:155-181 (csv) and run_inference_custom.py:290-307 (json), executed from the reference's files
+        src = _ref_statements(os.path.join(pem_dir, "test_bop.py"), "pred_Rs = torch.cat(pred_Rs", "image_time = time.time() - end")
+        src2 = _ref_statements(os.path.join(pem_dir, "test_bop.py"), "# write results", "lines.append(line)")
+        env = dict(torch=torch, time=time, end=time.time(), pred_Rs=[out["pred_R"]], pred_Ts=[out["pred_t"]], pred_scores=[out["pred_pose_score"]],
+                   data=dict(score=det_score.reshape(1, M, 1), scene_id=torch.tensor([pc["scene_id"]]), img_id=torch.tensor([pc["frame_id"]]),
+                             seg_time=torch.tensor([0.0]), obj_id=torch.tensor([d["category_id"] for d in sub]).reshape(1, M)),
+                   n_instance=M, lines=[])
+        exec(src, env)
+        env["image_time"] = 0.0
+        exec(src2, env)
+        src3 = _ref_statements(os.path.join(pem_dir, "run_inference_custom.py"), "if 'pred_pose_score' in out.keys():", "json.dump(detections, f)")
+        env3 = dict(out=dict({k: v.clone() for k, v in out.items() if torch.is_tensor(v)}, score=det_score),
+                    detections=copy.deepcopy(sub), json=json, os=os, np=np, torch=torch, cfg=types.SimpleNamespace(output_dir=os.path.join(tmp, flow)), open=open)
+        os.makedirs(os.path.join(tmp, flow, "sam6d_results"), exist_ok=True)
+        exec(src3, env3)
+        rec.update({p + "ism_json": np.array(json.dumps(dets_)), p + "order": np.array(order), p + "n_thresh": np.array(len(dets)), p + "kept_pre": kept,
+                    p + "obj": obj[kept], p + "pts": obs["pts"], p + "rgb_choose": obs["rgb_choose"], p + "bbox": obs["bbox"],
+                    p + "pred_R": out["pred_R"].numpy(), p + "pred_t": out["pred_t"].numpy(), p + "pred_pose_score": out["pred_pose_score"].numpy(),
+                    p + "init_R": out["init_R"].numpy(), p + "init_t": out["init_t"].numpy(), p + "stable": stable, p + "ref_move_dR": move, p + "ref_coarse_move": coarse_move,
+                    p + "csv": np.array("".join(env["lines"])),
+                    p + "pem_json": np.array(open(os.path.join(tmp, flow, "sam6d_results", "detection_pem.json")).read())})
+        rec[p + "rgb_sum"], rec[p + "rgb_smp"] = digest(torch.from_numpy(obs["rgb"]), 4099)
+        # known answers: a detection whose mask IS the window its object was made from (tests/util.e2e_pose_inputs) observes that
+        # object at the seeded pose
+        kat = np.full(M, -1)
+        for j, i in enumerate(kept.tolist()):
+            for oo, wnd in enumerate(pc["base_windows"]):
+                if obj[i] == oo and np.array_equal(masks[i], fi["masks"].numpy()[wnd] > 0):
+                    kat[j] = oo
+        rec[p + "kat_obj"] = kat
+        for j in np.nonzero(kat >= 0)[0]:
+            oo = kat[j]
+            print("  known answer: instance", j, "object", oo, "|R - R0|", float((out["pred_R"][j] - pin["gt_R"][oo]).norm()),
+                  "|t - t0| mm", float((out["pred_t"][j] - pin["gt_t"][oo]).norm() * 1e3), "pose score", float(out["pred_pose_score"][j]))
+        print("  thresholded", len(dets), "of", len(dets_), "-> PEM kept", kept.tolist(), "objects", obj[kept].tolist())
+        print("  pose score", out["pred_pose_score"].numpy().round(4).tolist())
+        print("  t (m)", out["pred_t"].numpy().round(4).tolist())
+    rec["case"] = np.array(str(pc))
+    np.savez_compressed(os.path.join(OUT, "frame_e2e_pose.npz"), **rec)
+    print("frame_e2e_pose.npz", os.path.getsize(os.path.join(OUT, "frame_e2e_pose.npz")), "bytes")
+
+
+def gen_frame_e2e_pose():
+    """tests/golden/frame_e2e_pose.npz -- the pose half of the pixels-to-pose golden: continues
+    frame_e2e.npz (reference SAM + DINOv2 + scoring on the Example frame) through the reference's hand-off, the PEM's score
+    threshold, pre-processing, onboarding and Net to R, t, pose score, BOP csv lines and detection_pem.json.  Two processes, as
+    the two reference trees own the same top-level module names."""
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(OUT))
+    with tempfile.TemporaryDirectory() as tmp:
+        for stage in ("frame_e2e_ism", "frame_e2e_pem"):
+            subprocess.check_call([sys.executable, "-m", "oracle.gen_golden", stage, tmp], cwd=root)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    if sys.argv[1] in ("frame_ism", "frame_pem"):
-        {"frame_ism": gen_frame_ism, "frame_pem": gen_frame_pem}[sys.argv[1]](sys.argv[2])
+    if sys.argv[1] in ("frame_ism", "frame_pem", "frame_e2e_ism", "frame_e2e_pem"):
+        {"frame_ism": gen_frame_ism, "frame_pem": gen_frame_pem, "frame_e2e_ism": gen_frame_e2e_ism, "frame_e2e_pem": gen_frame_e2e_pem}[sys.argv[1]](sys.argv[2])
         sys.exit(0)
-    {"frame": gen_frame, "frame_e2e": gen_frame_e2e, "pem": gen_pem, "pem_b32": gen_pem_b32, "pem_wc": gen_pem_wc, "example": gen_example, "sam": gen_sam, "ism": gen_ism, "dinov2": gen_dinov2, "sam_decoder": gen_sam_decoder, "handoff": gen_handoff, "pem_pre": gen_pem_pre, "pem_results": gen_pem_results, "detections_ops": gen_detections_ops, "sam_transforms": gen_sam_transforms, "sam_state_dict": gen_sam_state_dict}[sys.argv[1]]()
+    {"frame": gen_frame, "frame_e2e": gen_frame_e2e, "frame_e2e_pose": gen_frame_e2e_pose, "pem": gen_pem, "pem_b32": gen_pem_b32, "pem_wc": gen_pem_wc, "example": gen_example, "sam": gen_sam, "ism": gen_ism, "dinov2": gen_dinov2, "sam_decoder": gen_sam_decoder, "handoff": gen_handoff, "pem_pre": gen_pem_pre, "pem_results": gen_pem_results, "detections_ops": gen_detections_ops, "sam_transforms": gen_sam_transforms, "sam_state_dict": gen_sam_state_dict}[sys.argv[1]]()

@@ -41,9 +41,23 @@ def build(force=False, verbose=False):
         return SO_PATH
     if not os.path.exists(HIPCC):
         raise RuntimeError(f"hipcc not found at {HIPCC}; cannot build libsam6d_hip.so")
-    from concurrent.futures import ThreadPoolExecutor
     objdir = os.path.join(_CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
+    # one builder at a time: `bench.py --gpus N` starts N ranks that may all find the library stale; they share the object directory,
+    # so the build runs under an exclusive file lock and whoever waited re-checks staleness instead of compiling again
+    import fcntl
+    with open(os.path.join(objdir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():
+                return SO_PATH
+            return _build_locked(force, verbose, objdir)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose, objdir):
+    from concurrent.futures import ThreadPoolExecutor
     extra = os.environ.get("S6D_EXTRA_HIPCC_FLAGS", "").split()
     cflags = [f for f in FLAGS if f != "-shared"] + extra
     hdrs = glob.glob(os.path.join(_CSRC, "*.h")) + glob.glob(os.path.join(_HERE, "..", "include", "*.h"))
@@ -66,10 +80,12 @@ def build(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(one, sources()))
     open(tag, "w").write(flags_now)
-    cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", SO_PATH] + objs
+    tmp = SO_PATH + f".{os.getpid()}.tmp"                       # link beside the target, then rename: a reader never sees a half-written .so
+    cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", tmp] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=_CSRC)
+    os.replace(tmp, SO_PATH)
     return SO_PATH
 
 

@@ -398,6 +398,67 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
   if (PRIO) __builtin_amdgcn_s_setprio(0);
 }
 
+// ---- round 5: the 64 x 64 global tile WITHOUT a running maximum ---------------------------------------------------------------
+// process_tile spends, per score, scale + bias (fma), running max (max / max3), subtract, exp2 and half a pack, plus two
+// cross-lane exchanges and a wave vote per strip for the maximum -- 130 VALU + 32 exp2 beside 48 matrix instructions per tile, and
+// the maximum is a barrier between ALL score instructions of a tile and ALL its exponentials.  None of the maximum is needed
+// after the first tile: P only has to stay representable.  bf16 has float32's exponent range and the accumulators (row sums on
+// the matrix core, O^T) are float32, so with m fixed at the FIRST tile's row maximum P = exp2(s - m) is computed to the same
+// relative precision as with a running maximum as long as no row's sum approaches 2^127.  So after tile 0 (process_tile, which
+// sets m_run):
+//   * the rel-pos column bias rides the matrix core: the score chain starts from C = tw / scale_log2 instead of 0;
+//   * P = exp2(fma(acc, scale_log2, th - m)): ONE fma per score; no max, no subtract, no exchange, no vote, no rescale branch, and
+//     the exponentials of sub-tile s are independent of the score instructions of sub-tile s + 1;
+//   * at the end of the tile loop a row sum that is not < 2^100 (inf / NaN included) makes the WORKGROUP run its tile loop again
+//     with process_tile for every tile (attn_global64_kernel): the old arithmetic is the fallback, so any input the old kernel
+//     handled is still handled -- scores that grow by more than 2^100 over the first 64 keys' maximum take the slow path.
+template <int HD, int NS, bool KSWZ, bool PRIO>
+__device__ __forceinline__ void process_tile_nomax(const AttnParams &p, const u16 *Kl, const u16 *Vl, StripState<HD, NS> &st,
+                                                   const f32x4 (&cbias)[NS][4], const float (&nb)[NS], int lane) {
+  using C = Cfg<HD>;
+  const int g = lane >> 4, c = lane & 15;
+  const int gk = KSWZ ? (g ^ kswz(c)) : g;
+  union PB { bf16x8 v; u16 h[8]; };
+  PB pb[NS][2];
+  if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub) {
+    f32x4 acc[NS];
+#pragma unroll
+    for (int n = 0; n < NS; ++n) acc[n] = cbias[n][sub];
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8 *>(Kl + (sub * 16 + c) * C::KROW + ks * 32 + gk * 8);
+#pragma unroll
+      for (int n = 0; n < NS; ++n) acc[n] = S6D_ATTN_MFMA16(a, st.qf[n][ks], acc[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < NS; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        pb[n][sub >> 1].h[(sub & 1) * 4 + r] = f2bf(fast_exp2(__builtin_fmaf(acc[n][r], p.scale_log2, nb[n])));
+  }
+  union { bf16x8 v; u16 h[8]; } ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones.h[i] = S6D_ATTN_ONE;
+  union VA { bf16x8 v; s16x4 q[2]; };
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const u16 *vrow = Vl + (32 * j + g * 4 + (c >> 2)) * C::VROW + (c & 3) * 4;
+#pragma unroll
+    for (int n = 0; n < NS; ++n) st.lacc[n] = S6D_ATTN_MFMA16(ones.v, pb[n][j].v, st.lacc[n]);
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) {
+      VA va;
+      va.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + dt * 16));
+      va.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + 16 * C::VROW + dt * 16));
+#pragma unroll
+      for (int n = 0; n < NS; ++n) st.oacc[n][dt] = S6D_ATTN_MFMA16(va.v, pb[n][j].v, st.oacc[n][dt]);
+    }
+  }
+  if (PRIO) __builtin_amdgcn_s_setprio(0);
+}
+
 // ---- staging: global -> registers -> LDS, split so the loads can fly under the previous tile's math ------
 template <int HD, int THREADS>
 struct Stager {
@@ -1349,6 +1410,12 @@ constexpr int G64_THLD = 65;
 #ifndef S6D_G64_WAVES
 #define S6D_G64_WAVES 8
 #endif
+#ifndef S6D_G64_NOMAX
+#define S6D_G64_NOMAX 1             // tiles after the first without a running maximum (process_tile_nomax); 0: round-4 arithmetic
+#endif
+#ifndef S6D_G64_NOMAX_PRIO
+#define S6D_G64_NOMAX_PRIO 0        // s_setprio 1 around a no-max tile's matrix instructions
+#endif
 #ifndef S6D_G64_STATIC_PRIO
 #define S6D_G64_STATIC_PRIO 0       // 1: the second-dispatched half of an 8-wave workgroup runs the whole tile loop at s_setprio 1
 #endif
@@ -1363,7 +1430,7 @@ struct G64 {
   static constexpr int SLOT = NPIECE * 1024;
   static constexpr int RING = SLOTS * SLOT;
   static constexpr int TABS = WAVES * NS * 16 * G64_THLD * 4;
-  static constexpr int LDS = RING + TABS;
+  static constexpr int LDS = RING + TABS + 16;                         // + the workgroup's "run the safe loop" flag
   static_assert(NPIECE > WAVES * (PW - 1) && PW >= 2, "every wave has a real piece to repeat");
   static_assert(RING >= WAVES * 16 * 80 * 4, "the prologue's per-wave scratch aliases the ring");
   static_assert(PW * (SLOTS - 2) <= 15 || SLOTS == 2, "vmcnt immediates used below");
@@ -1463,30 +1530,94 @@ __global__ __launch_bounds__(WAVES * 64) void attn_global64_kernel(AttnParams p)
   const int ntile = p.T / 64;
   constexpr int D = SLOTS - 1;                      // look-ahead in tiles
   static_assert(D >= 1 && D <= 6, "ring depth");
-  __syncthreads();                                  // every wave is done with its scratch (it aliases the ring)
+  // column bias as the score chain's C operand (process_tile_nomax): tw / scale_log2, four key columns per register quad
+  f32x4 cbias[NS][4];
+  {
+    const float inv = 1.0f / p.scale_log2;
 #pragma unroll
-  for (int d = 0; d < D; ++d) issue(d);
-  int slot = 0;
+    for (int n = 0; n < NS; ++n)
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cbias[n][sub][r] = st.twr[n][sub * 4 + r] * inv;
+  }
+  int *redo = reinterpret_cast<int *>(smem + G::RING + G::TABS);
+  const u16 *src0[PW];
+#pragma unroll
+  for (int i = 0; i < PW; ++i) src0[i] = src[i];
   long long tk[6] = {0, 0, 0, 0, 0, 0}, tsum[5] = {0, 0, 0, 0, 0};
-  if (S6D_G64_STATIC_PRIO && WAVES == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);     // wave is wave-uniform (readfirstlane above)
-  for (int t = 0; t < ntile; ++t) {
+  int slot = 0;
+  // everything of a tile in front of its arithmetic: this wave's pieces have landed, everybody's have (barrier; every wave is past
+  // tile t - 1, so its slot is free), the DMA of tile t + D is issued into that slot, the row-bias words of the tile are read
+  auto tile_head = [&](int t, float (&thv)[NS]) __attribute__((always_inline)) -> const u16 * {
     S6D_TICK(tk, 0);
-    g64_wait_tiles<PW>(min(D - 1, ntile - 1 - t));  // this wave's pieces of tile t are in LDS
+    g64_wait_tiles<PW>(min(D - 1, ntile - 1 - t));
     S6D_ATTN_LGKM0();
-    __builtin_amdgcn_s_barrier();                   // ... and everybody's; every wave is past tile t - 1 (its slot is free)
+    __builtin_amdgcn_s_barrier();
     S6D_TICK(tk, 1);
     if (t + D < ntile && !(kAbl & 1)) issue(slot >= 1 ? slot - 1 : SLOTS - 1);
-    float thv[NS];
 #pragma unroll
     for (int n = 0; n < NS; ++n) thv[n] = thm[n][c * G64_THLD + t];
     S6D_TICK(tk, 2);
     const u16 *Kl = reinterpret_cast<const u16 *>(smem + slot * G::SLOT);
-    if (!(kAbl & 2)) process_tile<HD, 1, NS, true, S6D_GLB_PRIO != 0>(p, Kl, Kl + 64 * C::KROW, t * 64, st, thv, lane, tk);
-    S6D_TICK(tk, 5);
-    if (S6D_G64_TIMING)
-#pragma unroll
-      for (int i = 0; i < 5; ++i) tsum[i] += tk[i + 1] - tk[i];
     slot = slot == SLOTS - 1 ? 0 : slot + 1;
+    return Kl;
+  };
+  auto prime = [&]() __attribute__((always_inline)) {
+    __syncthreads();                                // every wave is done with its scratch (it aliases the ring) / with the first pass
+    if (tid == 0) *redo = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(d);
+    slot = 0;
+  };
+  if (S6D_G64_STATIC_PRIO && WAVES == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);     // wave is wave-uniform (readfirstlane above)
+  bool done = false;
+  if (S6D_G64_NOMAX && !S6D_G64_TIMING) {
+    // ---- pass A: tile 0 with the running-maximum arithmetic (it sets m_run), every later tile without a maximum ------------------
+    prime();
+    {
+      float thv[NS];
+      const u16 *Kl = tile_head(0, thv);
+      process_tile<HD, 1, NS, true, S6D_GLB_PRIO != 0>(p, Kl, Kl + 64 * C::KROW, 0, st, thv, lane, tk);
+    }
+    for (int t = 1; t < ntile; ++t) {
+      float thv[NS], nb[NS];
+      const u16 *Kl = tile_head(t, thv);
+#pragma unroll
+      for (int n = 0; n < NS; ++n) nb[n] = thv[n] - st.m_run[n];
+      process_tile_nomax<HD, NS, true, S6D_G64_NOMAX_PRIO != 0>(p, Kl, Kl + 64 * C::KROW, st, cbias, nb, lane);
+    }
+    // a row sum that left the comfortable range (or is inf / NaN): the whole workgroup repeats its tiles with the running maximum
+    bool bad = false;
+#pragma unroll
+    for (int n = 0; n < NS; ++n) bad |= !(st.lacc[n][0] < 1.2676506e30f);      // 2^100
+    if (__any(bad) && lane == 0) *redo = 1;
+    __syncthreads();
+    done = *redo == 0;
+    if (!done) {
+#pragma unroll
+      for (int n = 0; n < NS; ++n) {
+        st.m_run[n] = -1e30f;
+        st.lacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) st.oacc[n][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int i = 0; i < PW; ++i) src[i] = src0[i];
+    }
+  }
+  if (!done) {
+    // ---- pass B: the round-4 kernel (every tile with the running maximum); the fallback of pass A ---------------------------------
+    prime();
+    for (int t = 0; t < ntile; ++t) {
+      float thv[NS];
+      const u16 *Kl = tile_head(t, thv);
+      if (!(kAbl & 2)) process_tile<HD, 1, NS, true, S6D_GLB_PRIO != 0>(p, Kl, Kl + 64 * C::KROW, t * 64, st, thv, lane, tk);
+      S6D_TICK(tk, 5);
+      if (S6D_G64_TIMING)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) tsum[i] += tk[i + 1] - tk[i];
+    }
   }
 #pragma unroll
   for (int n = 0; n < NS; ++n) store_strip<HD>(p, b, 0, 0, head, q0[n], st.lacc[n][0], st.oacc[n], lane);

@@ -122,6 +122,86 @@ __global__ __launch_bounds__(THREADS) void transform_min_dist_kernel(
   dmin[((size_t)b * P + p) * N + n] = sqrtf(best);
 }
 
+// weighted_procrustes for one point set per instance (model_utils.py:287-363 as compute_fine_Rt calls it, :268-271): weights below
+// `thresh` are zeroed, w = weights / (sum + eps), sc = sum w src, rc = sum w ref, H = (src - sc)^T (w (ref - rc)), R = rot_from_h(H),
+// t = rc - R sc.  ONE workgroup per instance and a FIXED summation order (thread i takes points i, i + 256, ...; a binary tree
+// over the 256 partial sums), accumulated in double: the result of an instance does not depend on how many instances share the
+// launch -- the library chain it replaces (where, sum, div, 2 x mul + sum, bmm(3 x N, N x 3), matmul) picks reduction / GEMM
+// configurations by the BATCH size, so a frame's poses differed in the last bits between a group of frames and a frame alone.
+constexpr int kWpThreads = 256;
+__device__ __forceinline__ void wp_tree(double *red, int tid, int width) {      // red[width][256] -> sums in red[k * 256]
+  for (int s = kWpThreads / 2; s > 0; s >>= 1) {
+    __syncthreads();
+    if (tid < s)
+      for (int k = 0; k < width; ++k) red[k * kWpThreads + tid] += red[k * kWpThreads + tid + s];
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kWpThreads) void weighted_procrustes_kernel(const float *__restrict__ src, const float *__restrict__ ref,
+                                                                        const float *__restrict__ weights, int N, float thresh,
+                                                                        float eps, float *__restrict__ Rout, float *__restrict__ tout) {
+  __shared__ double red[9 * kWpThreads];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float *S = src + (size_t)b * N * 3, *Q = ref + (size_t)b * N * 3, *Wt = weights + (size_t)b * N;
+  auto wt = [&](int i) { const float w = Wt[i]; return w < thresh ? 0.0f : w; };
+  double a = 0;
+  for (int i = tid; i < N; i += kWpThreads) a += (double)wt(i);
+  red[tid] = a;
+  wp_tree(red, tid, 1);
+  const float wsum = (float)red[0] + eps;                 // the reference's float32 normaliser
+  __syncthreads();
+  double c[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = tid; i < N; i += kWpThreads) {
+    const double w = (double)(wt(i) / wsum);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      c[k] += w * (double)S[i * 3 + k];
+      c[3 + k] += w * (double)Q[i * 3 + k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) red[k * kWpThreads + tid] = c[k];
+  wp_tree(red, tid, 6);
+  float sc[3], rc[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    sc[k] = (float)red[k * kWpThreads];
+    rc[k] = (float)red[(3 + k) * kWpThreads];
+  }
+  __syncthreads();
+  double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = tid; i < N; i += kWpThreads) {
+    const float w = wt(i) / wsum;
+    float ds[3], dq[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      ds[k] = S[i * 3 + k] - sc[k];
+      dq[k] = w * (Q[i * 3 + k] - rc[k]);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) h[r * 3 + k] += (double)ds[r] * (double)dq[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) red[k * kWpThreads + tid] = h[k];
+  wp_tree(red, tid, 9);
+  if (tid == 0) {
+    double H[9], R[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) H[k] = (double)(float)red[k * kWpThreads];
+    rot_from_h(H, R);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rout[(size_t)b * 9 + k] = (float)R[k];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float Rr0 = (float)R[r * 3 + 0], Rr1 = (float)R[r * 3 + 1], Rr2 = (float)R[r * 3 + 2];
+      tout[(size_t)b * 3 + r] = rc[r] - (Rr0 * sc[0] + Rr1 * sc[1] + Rr2 * sc[2]);
+    }
+  }
+}
+
 }  // namespace s6d
 
 using namespace s6d;
@@ -153,5 +233,15 @@ extern "C" int s6d_min_dist_f32(const float *pts, const float *R, const float *t
   dim3 grid((N + 255) / 256, P, B);
   hipLaunchKernelGGL((transform_min_dist_kernel<256>), grid, dim3(256), (size_t)Nm * 12, as_stream(stream), pts, R, t,
                      model, N, P, Nm, dmin);
+  return launch_status();
+}
+
+extern "C" int s6d_weighted_procrustes_f32(const float *src, const float *ref, const float *weights, int B, int N, float weight_thresh,
+                                           float eps, float *R, float *t, void *stream) {
+  if (B < 0 || N <= 0) return S6D_EINVAL;
+  if (B == 0) return S6D_OK;
+  if (!src || !ref || !weights || !R || !t) return S6D_EINVAL;
+  hipLaunchKernelGGL(weighted_procrustes_kernel, dim3(B), dim3(kWpThreads), 0, as_stream(stream), src, ref, weights, N, weight_thresh,
+                     eps, R, t);
   return launch_status();
 }

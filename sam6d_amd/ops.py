@@ -107,6 +107,21 @@ def rot_from_h(H):
     return out
 
 
+def weighted_procrustes(src, ref, weights, weight_thresh=0.0, eps=1e-5):
+    """src, ref (B,N,3), weights (B,N) f32 -> R (B,3,3), t (B,3): ref ~ src R^T + t (batch-size independent, fixed order)."""
+    _chk(src, torch.float32, "src", 3)
+    _chk(ref, torch.float32, "ref", 3)
+    _chk(weights, torch.float32, "weights", 2)
+    B, N, _ = src.shape
+    if ref.shape != src.shape or weights.shape != (B, N):
+        raise ValueError(f"weighted_procrustes: src {tuple(src.shape)}, ref {tuple(ref.shape)}, weights {tuple(weights.shape)}")
+    R = torch.empty(B, 3, 3, dtype=torch.float32, device=src.device)
+    t = torch.empty(B, 3, dtype=torch.float32, device=src.device)
+    _call("s6d_weighted_procrustes_f32", _ptr(src), _ptr(ref), _ptr(weights), B, N, ctypes.c_float(weight_thresh), ctypes.c_float(eps), _ptr(R), _ptr(t),
+          _stream())
+    return R, t
+
+
 def pose_hypotheses(pts1, pts2, pair):
     """pts1 (B,N1,3), pts2 (B,N2,3) f32, pair (B,3*n) i32 -> R (B,n,3,3), t (B,n,3), dis (B,n)."""
     _chk(pts1, torch.float32, "pts1", 3)
@@ -383,6 +398,10 @@ def sam_mask_post(low_res, img_size, input_size, original_size, mask_threshold=0
         sb = C * n * n
     ct = max(sb // (n * n), C, 1)               # planes between consecutive prompts (Ct of the parent tensor for a channel slice)
     Bm, (H, W) = B * C, original_size
+    if Bm == 0:                                    # no prompt or no channel: nothing to launch (a clamped channel count would write B rows
+        dev = low_res.device                       # into zero-row outputs)
+        return (torch.empty(0, H, W, dtype=torch.bool, device=dev), torch.empty(0, dtype=torch.float32, device=dev),
+                torch.empty(0, 4, dtype=torch.int64, device=dev))
     masks = torch.empty(Bm, H, W, dtype=torch.bool, device=low_res.device)      # the kernel writes 0 / 1 bytes: no uint8 -> bool pass
     stats = torch.empty(Bm, 6, dtype=torch.int32, device=low_res.device)
     # the slice's data pointer is its first plane: mask (b, c) reads plane b * ct + c from there
@@ -1139,7 +1158,7 @@ def have(name):
     if name not in _FUSED:
         sym = {"rpe_attention": "s6d_rpe_attention_f32", "rpe_attention_packed": "s6d_rpe_attention_packed_f32", "geo_embedding": "s6d_geo_embedding_f32",
                "fine_assign": "s6d_fine_assign_f32", "fine_match": "s6d_fine_match_f32", "pem_pre": "s6d_pem_compact_cloud_f32", "coarse_sample": "s6d_coarse_sample_f32", "upsample_gather": "s6d_upsample_gather_f32",
-               "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "add_layernorm": "s6d_add_layernorm_bf16", "gemm_bf16": "s6d_gemm_bf16", "gemm_bf16_res": "s6d_gemm_bf16_res", "gemm_bf16_lnfold": "s6d_gemm_bf16_lnfold", "gemm_f16": "s6d_gemm_f16", "gemm_fp8": "s6d_gemm_fp8", "layernorm_fp8": "s6d_layernorm_fp8", "layernorm_f32out": "s6d_layernorm_bf16_f32", "linear_f32": "s6d_linear_f32", "win_attention": "s6d_win_attention_layout_bf16",
+               "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "weighted_procrustes": "s6d_weighted_procrustes_f32", "add_layernorm": "s6d_add_layernorm_bf16", "gemm_bf16": "s6d_gemm_bf16", "gemm_bf16_res": "s6d_gemm_bf16_res", "gemm_bf16_lnfold": "s6d_gemm_bf16_lnfold", "gemm_f16": "s6d_gemm_f16", "gemm_fp8": "s6d_gemm_fp8", "layernorm_fp8": "s6d_layernorm_fp8", "layernorm_f32out": "s6d_layernorm_bf16_f32", "linear_f32": "s6d_linear_f32", "win_attention": "s6d_win_attention_layout_bf16",
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_sel_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
                "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_sel_f32",

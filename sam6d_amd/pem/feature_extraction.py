@@ -287,8 +287,26 @@ class ViTEncoder(nn.Module):
     def get_obj_feats(self, tem_rgb_list, tem_pts_list, tem_choose_list, npoint=None):
         """Template onboarding: 42 views x 5000 px -> FPS to npoint (feature_extraction.py:170-181)."""
         npoint = npoint or self.npoint
-        feats = [self.get_img_feats(t, c) for t, c in zip(tem_rgb_list, tem_choose_list)]
+        feats = []
+        for v, (t, c) in enumerate(zip(tem_rgb_list, tem_choose_list)):
+            f = self.get_img_feats(t, c)
+            # the IEEE-half extractor's range flag (tokens_up) is per call: onboarding reads it view by view (an offline pass: one
+            # host wait per view costs nothing) and re-runs a flagged view's objects with the fp32 extractor, so that no inf / NaN
+            # template feature is stored for every later frame (ADVICE r4)
+            bad, self.rgb_net.overflow = self.rgb_net.overflow, None
+            if bad is not None and bool(bad.any()):
+                import warnings
+                idx = torch.nonzero(bad).squeeze(1)
+                warnings.warn(f"PEM ViT-B in IEEE half overflowed on template view {v} for object(s) {idx.tolist()}: "
+                              "re-running them with the fp32 extractor", RuntimeWarning, stacklevel=2)
+                with force_vit_dtype("fp32"):
+                    f = f.clone()
+                    f[idx] = self.get_img_feats(t[idx].contiguous(), c[idx].contiguous()).to(f.dtype)
+                self.rgb_net.overflow = None
+            feats.append(f)
         pts = torch.cat(tem_pts_list, dim=1).contiguous()
         feat = torch.cat(feats, dim=1).contiguous()
+        if not bool(torch.isfinite(feat).all()):
+            raise FloatingPointError("template onboarding produced non-finite features (set S6D_PEM_VIT_DTYPE=fp32 for this checkpoint)")
         idx = ops.furthest_point_sampling(pts, npoint)
         return ops.gather_rows(pts, idx), ops.gather_rows(feat, idx)

@@ -159,7 +159,10 @@ class FinePointMatching(nn.Module):
     def forward(self, p1, f1, geo1, fps_idx1, p2, f2, geo2, fps_idx2, radius, end_points):
         B = p1.size(0)
         init_R, init_t = end_points["init_R"], end_points["init_t"]
-        p1_ = (p1 - init_t.unsqueeze(1)) @ init_R
+        # (p1 - t) R spelled out per component: a batched 2048 x 3 x 3 library GEMM picks its kernel by the batch size, so the
+        # last bits of a row followed the instances around it (round 5: group-vs-single identity of FramePipeline)
+        d = p1 - init_t.unsqueeze(1)
+        p1_ = d[..., 0:1] * init_R[:, None, 0, :] + d[..., 1:2] * init_R[:, None, 1, :] + d[..., 2:3] * init_R[:, None, 2, :]
         bg = self.bg_token.expand(B, -1, -1)
         # (bg token, dense rows) kept apart through the blocks: one concatenation per side at the end instead of one per block
         f1 = (bg, plinear(self, self.in_proj, f1, residual=self.PE(p1_)))

@@ -211,8 +211,12 @@ def _finish(image_u8, m, box, kept, pts, ch, img_size, rgb_mask_flag, rgb=None):
             torch.zeros(0, 3, img_size, img_size, device=dev)
     ch_h, ch_w = (bk[:, 1] - bk[:, 0]), (bk[:, 3] - bk[:, 2])
     row, col = ch // ch_w[:, None], ch % ch_w[:, None]
-    rgb_choose = ((row.double() * (img_size / ch_h.double())[:, None]).floor() * img_size +
-                  (col.double() * (img_size / ch_w.double())[:, None]).floor()).long()
+    # get_resize_rgb_choose (data_utils.py:113-123) in ITS float64 arithmetic: ratio = fl(img_size / crop) by a true division
+    # (`scalar / tensor` is reciprocal() * scalar in torch: one ulp off for crops of 140 or 160 pixels, where row * ratio lands
+    # on an integer -- found by the pixels-to-pose golden, round 5), then fl(row * ratio), floor
+    size = torch.full((1,), float(img_size), dtype=torch.float64, device=dev)
+    rgb_choose = ((row.double() * torch.div(size, ch_h.double())[:, None]).floor() * img_size +
+                  (col.double() * torch.div(size, ch_w.double())[:, None]).floor()).long()
     return dict(pts=pts, rgb=rgb, rgb_choose=rgb_choose, kept=kept, bbox=bk)
 
 

@@ -34,6 +34,9 @@ def rotation_from_H(H):
 def weighted_procrustes(src, ref, weights=None, weight_thresh=0.0, eps=1e-5):
     if weights is None:
         weights = torch.ones_like(src[..., 0])
+    if ops.have("weighted_procrustes") and src.is_cuda and src.dim() == 3 and src.dtype == torch.float32:
+        # one launch, fixed summation order per instance: the pose of an instance does not depend on the batch it is in
+        return ops.weighted_procrustes(src.contiguous(), ref.contiguous(), weights.contiguous(), weight_thresh, eps)
     weights = torch.where(weights < weight_thresh, torch.zeros_like(weights), weights)
     w = (weights / (weights.sum(dim=-1, keepdim=True) + eps)).unsqueeze(-1)
     sc = (src * w).sum(dim=-2, keepdim=True)

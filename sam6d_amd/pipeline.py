@@ -83,11 +83,17 @@ class FramePipeline:
         x = torch.stack([rs.apply_image(im).permute(2, 0, 1) for im in images]).float()
         return self.enc(sam_preprocess(x, self.enc.img_size)).float()
 
+    def _segment(self, emb, image_u8):
+        """The segmentor stage of one frame (model/sam.py generate_masks after the encoder) -> dict(masks bool (K,H,W), boxes (K,4)).
+        A separate method so that proposals of another source can be joined here (the pixels-to-pose golden adds ten depth
+        windows to SAM's proposals: tests/test_gpu_zz_pipeline_e2e.py)."""
+        H, W = image_u8.shape[:2]
+        return amg.generate_proposals(self.pe, self.md, emb, (H, W), self.enc.img_size, points_per_batch=self.ppb, **self.seg_kw)
+
     def _propose(self, emb, image_u8):
         """proposals of one frame that survive the size filters and whose crop exists -> (masks, boxes).  emb: (1,256,64,64)."""
         H, W = image_u8.shape[:2]
-        prop = amg.generate_proposals(self.pe, self.md, emb, (H, W), self.enc.img_size, points_per_batch=self.ppb,
-                                      **self.seg_kw)
+        prop = self._segment(emb, image_u8)
         area = prop["masks"].flatten(1).sum(1).float() / (H * W)
         b = prop["boxes"].float()
         box_area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]) / (H * W)

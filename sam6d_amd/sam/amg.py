@@ -56,6 +56,7 @@ def _decode_batch_graphed(prompt_encoder, mask_decoder, image_embedding, in_poin
     key = (id(prompt_encoder), id(mask_decoder), tuple(image_embedding.shape), image_embedding.dtype, tuple(in_points.shape),
            in_points.dtype, tuple(input_size), tuple(original_size), int(img_size), float(mask_threshold), float(stability_score_offset),
            os.environ.get("S6D_SAM_DECODER_DTYPE", ""), os.environ.get("S6D_DISABLE_FUSED", ""), os.environ.get("S6D_SAMDEC_GEMM", ""),
+           os.environ.get("S6D_SAMDEC_T2I", ""), torch.is_autocast_enabled(), torch.get_autocast_gpu_dtype(),
            _weights_key(prompt_encoder, mask_decoder), dev.index)
     g = _GRAPHS.get(key)
     if g is None:
@@ -108,8 +109,10 @@ def process_point_batch(prompt_encoder, mask_decoder, image_embedding, in_points
         keep &= stability >= stability_score_thresh                  # NaN (empty +-offset masks) fails, as in the reference
     idx = torch.nonzero(keep).squeeze(1)
     C = low_res.shape[1]
+    # low_res of the graphed path is the graph's own output buffer, overwritten by the next replay: callers that keep several
+    # batches (generate_proposals) get a private copy
     return dict(masks=masks[idx], iou_preds=iou[idx], stability_score=stability[idx], boxes=boxes[idx],
-                point_index=idx // C, low_res_logits=low_res)
+                point_index=idx // C, low_res_logits=low_res.clone() if graphed else low_res)
 
 
 def build_point_grid(n_per_side):

@@ -116,6 +116,12 @@ def _run_late(cases):
         T.test_fused_attention_vs_oracle(*c)
 
 
+def test_global_attention_fallback_on_the_emulator(emu):
+    """Scores that outgrow the first tile's maximum: exp2 overflow -> the workgroup's second pass (30), large finite P (2)."""
+    T.test_global_attention_when_scores_outgrow_the_first_tile(80, 30.0)
+    T.test_global_attention_when_scores_outgrow_the_first_tile(80, 2.0)
+
+
 def test_lds_dma_attention_kernels_under_the_late_completion_model():
     """attn_global64_kernel (64 x 64 grid) and the persistent window kernel with their DMA bytes arriving as late as the waits
     allow: a ring slot read before its counted wait, or refilled before its last reader passed the barrier, shows up here."""

@@ -9,6 +9,11 @@ def test_rot_from_h_on_the_emulator(emu):
     T.test_rot_from_h_vs_svd(emu)
 
 
+def test_weighted_procrustes_on_the_emulator(emu):
+    T.test_weighted_procrustes_vs_oracle_and_batch_invariance(emu, 2, 197)
+    T.test_weighted_procrustes_vs_oracle_and_batch_invariance(emu, 1, 7)
+
+
 def test_min_dist_on_the_emulator(emu):
     T.test_min_dist_vs_oracle(emu, 196, 3)
 

@@ -32,6 +32,35 @@ def test_fused_attention_vs_oracle(B, H, nh, hd, ws):
     assert err.max() < 3e-2 and err.mean() < 3e-3, (err.max().item(), err.mean().item())
 
 
+@pytest.mark.parametrize("hd,grow", [(80, 30.0), (80, 2.0), (64, 30.0)])
+def test_global_attention_when_scores_outgrow_the_first_tile(hd, grow):
+    """attn_global64_kernel keeps the FIRST key tile's row maximum for every later tile (process_tile_nomax, round 5) and repeats
+    its tiles with the running-maximum arithmetic when a row sum leaves float32's comfortable range.  Image 1's queries get a
+    +-2 pattern added and its keys from grid row 8 on ARE that pattern times `grow`: with 30 the later scores exceed the first
+    tile's maximum by hundreds of log2 units (exp2 overflows -> the second pass must run), with 2 by some tens (P up to ~2^50,
+    finite: the fast path must stay accurate).  Image 0 is ordinary, so one workgroup set takes the fallback and the other not."""
+    from oracle import sam as osam
+    from sam6d_amd import ops
+    H, nh = 64, 1
+    bias, rh, rw, qkv = _mk(2, H, nh, hd, 0, 77)
+    bias = torch.zeros_like(bias)
+    pat = torch.where(torch.arange(hd) % 2 == 0, 1.0, -1.0)
+    qkv[1, :, :, :hd] += 2 * pat
+    qkv[1, 8:, :, hd:2 * hd] = grow * pat
+    bias, rh, rw, qkv = (t.to(torch.bfloat16) for t in (bias, rh, rw, qkv))
+    # the premise, in log2 units: (largest late score) - (largest score against the first 64 keys), per query of image 1
+    q, k = qkv[1, :, :, :hd].float().reshape(-1, hd), qkv[1, :, :, hd:2 * hd].float().reshape(-1, hd)
+    sc = (q @ k.t()) * hd ** -0.5 * 1.4426950408889634
+    gap = (sc[:, 512:].max(1).values - sc[:, :64].max(1).values)
+    assert (gap.min() > 128) if grow == 30.0 else (20 < gap.min() and gap.max() < 90), (gap.min().item(), gap.max().item())
+    out = ops.window_attention(qkv.cuda().contiguous(), bias.cuda().contiguous(), rh.cuda().contiguous(), rw.cuda().contiguous(), nh, 0,
+                               hd ** -0.5).float().cpu()
+    ref = osam.windowed_attention_from_qkv(qkv.float(), bias.float(), rh.float(), rw.float(), nh, 0)
+    assert torch.isfinite(out).all()
+    err = (out - ref).abs()
+    assert err.max() < 3e-2 and err.mean() < 3e-3, (err.max().item(), err.mean().item())
+
+
 @pytest.mark.parametrize("ws", [14, 0])
 def test_benched_launch_group_b16_h16(ws):
     """The launch group bench.py runs (16 frames x 16 heads x hd 80 on the 64 x 64 grid: 6400 window items through the

@@ -147,3 +147,16 @@ def test_cv2_vectors_if_present():
     for s in g["sides"].tolist():
         out = o.cv2_resize_linear_u8(image(s, 1000 + s), 224)
         assert hashlib.sha256(np.ascontiguousarray(out).tobytes()).hexdigest() == str(g[f"sha_{s}"]), s
+
+
+def test_rgb_choose_for_every_crop_size_in_float64_like_the_reference():
+    """get_resize_rgb_choose (data_utils.py:113-123) multiplies by fl64(224 / crop): with crops of 140 or 160 pixels some
+    row * ratio products land exactly on an integer, so a ratio one ulp off (torch's `scalar / tensor` = reciprocal * scalar)
+    moves those rows by one -- every crop size a 480 x 640 frame can give, against the oracle helper (itself pinned to the
+    reference's function by tests/golden/pem_pre.npz and example_frame.npz).  Found by the pixels-to-pose golden (round 5)."""
+    for size in range(33, 481):
+        ch = torch.arange(size * size, dtype=torch.int64)[None]
+        box = torch.tensor([[0, size, 0, size]])
+        out = pre._finish(torch.zeros(1, 1, 3, dtype=torch.uint8), None, box, torch.zeros(1, dtype=torch.int64), torch.zeros(1, 1, 3), ch, 224,
+                          True, rgb=torch.zeros(1, 3, 224, 224))
+        np.testing.assert_array_equal(out["rgb_choose"][0].numpy(), opre.resize_rgb_choose(ch[0].numpy(), [0, size, 0, size], 224), err_msg=str(size))

@@ -94,3 +94,55 @@ def frame_inputs(c):
                 pointcloud=torch.from_numpy(g["dense_po"])[None], model=g["model"], dense_po=g["dense_po"], radius=float(g["radius"]))
 
 
+
+
+E2E_POSE_CASE = dict(det_score_thresh=0.46, nms_thresh=0.25, min_box_size=0.05, min_mask_size=3e-4, pem_weight_seed=1, key_seed=41,
+                     rand_seed=43, tem_seed=44, scene_id=2, frame_id=17, dataset="ycbv", n_keys=32, base_windows=(0, 8, 9))
+
+
+def e2e_pose_inputs(c=None, frozen=None):
+    """Model-independent inputs of the pose half of the pixels-to-pose golden (tests/golden/frame_e2e_pose.npz), shared by the
+    generator (oracle/gen_golden.py frame_e2e_pose) and the tests.
+
+    The PEM's three objects are made FROM THE FRAME so that the matching problem is a real one (seeded weights carry no learned
+    prior, but equal inputs give equal features: the known-answer construction of SURVEY.md 8c): object o is the surface seen
+    through depth window base_windows[o] of the Example frame.  The oracle's pre-processing of that window (its own seeded
+    sampling keys) gives 2048 camera-frame points, the 224 x 224 colour crop and the pixel index of every point; with a seeded
+    pose (R0, t0 = the cloud's centroid) the object-frame points are (p - t0) R0, and the onboarding pass (get_obj_feats) gets TWO
+    template views of them: the same crop, points [0, 1400) and [600, 2048) (the second set moved by 2e-4 of seeded noise so that
+    no two points coincide), each with its pixel indices.  ``model`` = the first 1024 object-frame points, radius = max |model|.
+    A detection of that window is then an observation of the object at pose (R0, t0), sampled at other pixels: the Net should
+    recover it; detections of other windows assigned to the object stay unrelated (and ill-conditioned: see `stable` in the
+    golden).  Everything is a pure function of the frozen Example frame and CPU generators."""
+    import torch
+
+    from oracle import pem_pre as opre
+    c = c or E2E_POSE_CASE
+    fi = frame_inputs(dict(P=10, O=1, T=6, C=128, n_patch=64, seed=21))
+    rgb = fi["rgb"]
+    H, W = rgb.shape[:2]
+    gen = torch.Generator().manual_seed(c["tem_seed"])
+    depth = fi["depth_mm"].numpy() * np.float32(fi["depth_scale"]) / np.float32(1000.0)
+    base = list(c["base_windows"])
+    tkeys = torch.rand(len(base), H * W, generator=gen).numpy()
+    obs = opre.preprocess_frame(rgb, depth, fi["K"].numpy(), fi["masks"].numpy()[base] > 0, 10.0, keys=tkeys)
+    assert obs["kept"].tolist() == list(range(len(base)))
+    pts_cam = torch.from_numpy(obs["pts"])                                     # (O,2048,3)
+    crop, choose = torch.from_numpy(obs["rgb"]), torch.from_numpy(obs["rgb_choose"])
+    if frozen is not None:
+        t0, R0 = torch.from_numpy(frozen["gt_t"]), torch.from_numpy(frozen["gt_R"])
+        obj_pts, v1 = torch.from_numpy(frozen["tem_obj_pts"]), torch.from_numpy(frozen["tem_v1"])
+        assert ((pts_cam - t0[:, None]) @ R0 - obj_pts).abs().max() < 1e-5      # the stored points ARE this construction
+    else:
+        t0 = pts_cam.mean(dim=1)
+        R0 = torch.linalg.qr(torch.randn(len(base), 3, 3, generator=gen))[0]
+        R0 = R0 * torch.sign(torch.linalg.det(R0)).view(-1, 1, 1)               # proper rotations
+        obj_pts = (pts_cam - t0[:, None]) @ R0                                 # p_cam = p_obj R0^T + t0
+        v1 = obj_pts[:, 600:] + 2e-4 * torch.randn(len(base), 1448, 3, generator=gen)
+    tem_pts = [obj_pts[:, :1400].contiguous(), v1.contiguous()]
+    tem_choose = [choose[:, :1400].contiguous(), choose[:, 600:].contiguous()]
+    models = obj_pts[:, :1024].contiguous()
+    radius = models.norm(dim=2).max(dim=1).values
+    keys = torch.rand(c["n_keys"], H * W, generator=torch.Generator().manual_seed(c["key_seed"]))
+    return dict(fi=fi, tem_rgb=[crop, crop.clone()], tem_pts=tem_pts, tem_choose=tem_choose, model=models, radius=radius, keys=keys,
+                gt_R=R0, gt_t=t0, tem_obj_pts=obj_pts, tem_v1=v1)

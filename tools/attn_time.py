@@ -70,6 +70,8 @@ def main():
                 ref[ws] = o.clone()
             elif not is_probe(name):
                 row["equals_base"] = bool(torch.equal(o, ref[ws]))
+                if not row["equals_base"]:
+                    row["max_abs_diff_vs_base"] = float((o.float() - ref[ws].float()).abs().max())
             if ws == 14 and "timing" in name:
                 t = o_full[B * H * H * nh * hd:].view(torch.int64)[:48].view(8, 6).cpu().tolist()
                 items = (B * 25 * nh + 255) // 256

@@ -66,23 +66,6 @@ SAM_CHUNK = 16   # frames per SAM encoder launch group: 16 x 4096 tokens per GEM
                  # recorded hipBLASLt solutions 199.0 ms / 32 frames, chunk 16 on the default heuristics 193.0, chunk 32 193.6)
 
 
-def _use_tuned_library_gemms():
-    """Library GEMMs (qkv / proj / MLP of the ViTs) go through hipBLASLt via torch; pick the solutions recorded
-    by PyTorch TunableOp on this exact stack (profiles/tunableop_gfx950_sam_chunk8.csv: +7 % on the SAM stage,
-    59 s of tuning, done once offline).  Validators in the file pin torch / hipBLASLt / arch versions; on any
-    mismatch TunableOp silently falls back to the default heuristics.  No tuning happens inside the bench."""
-    path = os.path.join(ROOT, "profiles", "tunableop_gfx950_sam_chunk8.csv")
-    if os.environ.get("S6D_NO_TUNABLEOP") or not os.path.exists(path):
-        return
-    try:
-        import torch.cuda.tunable as tn
-        tn.enable(True)
-        tn.tuning_enable(False)
-        tn.read_file(path)
-    except Exception as e:  # noqa: BLE001
-        print(f"[bench] TunableOp file not used: {e}", file=sys.stderr)
-
-
 class HotPath:
     """All device state of one rank: models, replicated template data, one batch of frames."""
 
@@ -99,7 +82,6 @@ class HotPath:
         # extractor (library GEMMs) costs 6.4 ms more per 32 instances (profiles/r03_bench_pem_vit_dtype.txt).  The SAM ViT-H -- 87 %
         # of the step -- runs bf16 as configs[1] says.
         os.environ.setdefault("S6D_PEM_VIT_DTYPE", "fp16")
-        _use_tuned_library_gemms()
         self.dev, self.F, self.chunk = device, frames, sam_chunk
         self.sam = seeded.load_seeded(build_vit_h().eval(), 3).to(device=device, dtype=torch.bfloat16)
         self.pem = seeded.load_seeded(pm.Net(pm.default_cfg()).eval(), 1).to(device)
@@ -525,10 +507,29 @@ def _pmc_traffic(row):
 
 
 def cpu_baseline():
-    """CPU restatement (oracle = 'port' of the reference algorithm) timed on the host cores on a bounded sample of the same
-    workload: 1 SAM ViT-H frame + 1 ISM frame (P = 128) + a PEM batch of 2 instances; per SURVEY 8(d) each leg is 1 warm-up
-    run + the MEDIAN of 3 timed runs, and the core count used is stated next to ``nproc``."""
+    """The CPU path timed on the host cores on a bounded sample of the same workload: 1 SAM ViT-H frame + 1 ISM frame (P = 128) + a
+    PEM batch of 8 instances; per SURVEY 8(d) each leg is 1 warm-up run + the MEDIAN of 3 timed runs, and the core count used is
+    stated next to ``nproc``.  Where the reference tree exists (the build container: S6D_REFERENCE_ROOT or /root/reference) the
+    REFERENCE's own modules are timed through oracle/ref_timing.py (kind "reference", one process per leg); on the GPU box there is
+    no reference tree and the oracle's restatement of the same algorithm is timed (kind "port")."""
     import statistics
+
+    nproc = os.cpu_count()
+    cores = min(nproc, 32)          # torch CPU kernels stop scaling (and regress) beyond ~32 threads
+    torch.set_num_threads(cores)
+    from oracle import refharness as rh
+    if rh.available():
+        import subprocess
+        legs = {}
+        for leg in ("sam", "ism", "pem"):
+            out = subprocess.run([sys.executable, "-m", "oracle.ref_timing", leg, str(cores)], cwd=ROOT, capture_output=True, text=True, check=True)
+            legs[leg] = json.loads(out.stdout.strip().splitlines()[-1])
+        t_sam, t_ism, t_pem = legs["sam"]["seconds"], legs["ism"]["seconds"], legs["pem"]["seconds"] / legs["pem"]["unit_count"]
+        per_frame = t_sam + t_ism + t_pem
+        return {"value": 1.0 / per_frame, "unit": "frames/s", "cores": cores, "nproc": nproc, "kind": "reference",
+                "sample": f"the reference's own modules (oracle/ref_timing.py), 1 warm-up + median of 3 per leg: ImageEncoderViT ViT-H on 1 frame "
+                          f"({t_sam:.2f}s) + ISM scoring methods on 1 frame P=128 ({t_ism:.3f}s) + Net on a batch of {legs['pem']['unit_count']} "
+                          f"({t_pem:.2f}s/instance), fp32 torch CPU, seeded weights"}
 
     from oracle import ism as oism
     from oracle import pem as opem
@@ -536,10 +537,6 @@ def cpu_baseline():
     from sam6d_amd.pem import pose_estimation_model as pm
     from sam6d_amd.sam.image_encoder import build_vit_h
     from sam6d_amd.utils import seeded, synth
-
-    nproc = os.cpu_count()
-    cores = min(nproc, 32)          # torch CPU kernels stop scaling (and regress) beyond ~32 threads
-    torch.set_num_threads(cores)
 
     def med3(fn):
         fn()                        # warm-up (thread pool, allocator, first-touch of the weights)
@@ -550,13 +547,14 @@ def cpu_baseline():
             ts.append(time.perf_counter() - t0)
         return statistics.median(ts), ts
 
+    NB = 8
     with torch.no_grad():
         Wp = {k: v for k, v in seeded.load_seeded(pm.Net(pm.default_cfg()), 1).state_dict().items()}
-        inp = synth.pem_inputs(2, seed=1)
+        inp = synth.pem_inputs(NB, seed=1)
         ep = {k: inp[k] for k in ("pts", "rgb", "rgb_choose", "model", "dense_po", "dense_fo")}
-        ru = synth.coarse_uniforms(2, 2)
+        ru = synth.coarse_uniforms(NB, 2)
         t_pem, pem_runs = med3(lambda: opem.net_forward(Wp, ep, ru))
-        t_pem /= 2
+        t_pem /= NB
         ii = synth.ism_inputs(P=P_PROPOSALS, O=1, T=42, seed=11)
         t_ism, _ = med3(lambda: oism.score_frame(ii))
         with torch.device("cpu"):
@@ -566,8 +564,9 @@ def cpu_baseline():
     per_frame = t_sam + t_ism + t_pem
     return {"value": 1.0 / per_frame, "unit": "frames/s", "cores": cores, "nproc": nproc, "kind": "port",
             "sample": f"1 warm-up + median of 3 per leg: 1 SAM ViT-H frame ({t_sam:.2f}s; runs "
-                      f"{'/'.join(f'{t:.2f}' for t in sam_runs)}) + 1 ISM frame P=128 ({t_ism:.3f}s) + PEM batch of 2 "
-                      f"({t_pem:.2f}s/instance; runs {'/'.join(f'{t / 2:.2f}' for t in pem_runs)}), fp32 torch CPU oracle"}
+                      f"{'/'.join(f'{t:.2f}' for t in sam_runs)}) + 1 ISM frame P=128 ({t_ism:.3f}s) + PEM batch of {NB} "
+                      f"({t_pem:.2f}s/instance; runs {'/'.join(f'{t / NB:.2f}' for t in pem_runs)}), fp32 torch CPU oracle "
+                      "(no reference tree on this host: the reference's own modules are timed where it exists, profiles/r05_cpu_baseline_reference.json)"}
 
 
 def fp8_config(hp, dev, args, mode="fp8"):

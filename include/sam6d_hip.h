@@ -30,8 +30,12 @@ extern "C" {
 
 /* Bumped whenever a signature in this header changes; the loader (sam6d_amd/_lib.py) refuses a library whose
  * s6d_version() differs from the header it was written against (a stale .so fails at load, not at a call). */
-#define S6D_ABI_VERSION 120
+#define S6D_ABI_VERSION 122
 int s6d_version(void);
+/* Upper bound on the workgroups of the persistent kernels (the 14 x 14 window attention walks its (window, head) items with one
+ * workgroup per CU); 0 = one per CU of the device.  Process-wide.  Replaces the environment lookups the launch path made until
+ * round 4; used by the tests to make few workgroups walk many items. */
+int s6d_set_persistent_grid_limit(int max_workgroups);
 const char *s6d_strerror(int code);
 /* last HIP error string seen by this thread (empty if none) */
 const char *s6d_last_hip_error(void);
@@ -176,6 +180,12 @@ int s6d_rpe_attention_f32(const float *q, const float *k, const float *v, const 
  * ref: as s6d_rpe_attention_f32 (transformer.py:368-406). */
 int s6d_rpe_attention_packed_f32(const float *proj, long ld, int q_off, int k_off, int v_off, int qt_off, int qb_off,
                                  const float *embed, int B, int N, int C, int heads, float scale, float *out, void *stream);
+/* ... with the embedding (B,N,N,C) stored in IEEE half (s6d_geo_embedding_f16): widened in registers, float32 products and sums. */
+int s6d_rpe_attention_packed_e16_f32(const float *proj, long ld, int q_off, int k_off, int v_off, int qt_off, int qb_off,
+                                     const void *embed_f16, int B, int N, int C, int heads, float scale, float *out, void *stream);
+int s6d_rpe_attention_strided_e16_f32(const float *q, long ldq, const float *k, long ldk, const float *v, long ldv, const float *qt,
+                                      const float *qb, const void *embed_f16, int B, int N, int C, int heads, float scale, float *out,
+                                      void *stream);
 /* The same with row strides ldq / ldk / ldv (floats, multiples of 4) for q / k / v: the column blocks of one q | k | v projection
  * output are attended without copies. */
 int s6d_rpe_attention_strided_f32(const float *q, long ldq, const float *k, long ldk, const float *v, long ldv, const float *qt,
@@ -368,6 +378,10 @@ int s6d_project_bbox_frames_f32(const float *pointcloud, const float *poses, con
  * SinusoidalPositionalEmbedding.forward :263-281. */
 int s6d_geo_embedding_f32(const float *idx4, long NP, const float *Wd, const float *bd, const float *Wa,
                           const float *ba, const float *div_term, int C, int K, float *out, void *stream);
+/* The same arithmetic with the result STORED in IEEE half: out_f16 (NP,C) f16.  The embedding's only reader is the RPE attention
+ * core, which streams it twelve times per forward; read with the _e16 entry points below. */
+int s6d_geo_embedding_f16(const float *idx4, long NP, const float *Wd, const float *bd, const float *Wa,
+                          const float *ba, const float *div_term, int C, int K, void *out_f16, void *stream);
 
 /* Fused fp32 Linear of the point transformer:  y = LN( res + act( x W^T + b ) )  with every stage optional.
  * x (M,K) f32 row stride ldx; W given as its bf16 hi / lo parts (N,K) each, made once per weight version by

@@ -101,12 +101,6 @@ __device__ __forceinline__ const u16 *qkv_at(const AttnParams &p, size_t tok, in
 #define S6D_ATTN_ABLATE 0
 #endif
 constexpr int kAbl = S6D_ATTN_ABLATE;
-#ifndef S6D_PT_KPRE
-#define S6D_PT_KPRE 0                // process_tile: K fragments double-buffered one sub-tile ahead
-#endif
-#ifndef S6D_PT_VPRE
-#define S6D_PT_VPRE 0                // process_tile: V fragments of a tile requested in front of the softmax (1: pinned there, 2: free)
-#endif
 // Global-attention layout / schedule switches (defaults = what is measured fastest; tools/attn_variants.sh builds the others):
 //   S6D_GLB_KSWZ  K image rows whose (row >> 2 ^ row >> 3) & 1 is set keep their 16-byte chunks pairwise swapped: with an odd row
 //                 stride (13 chunks) the two row sets of a ds_read_b128 lane group ({0-3,12-15} reading chunk g, {4-11} reading
@@ -134,9 +128,6 @@ constexpr int kAbl = S6D_ATTN_ABLATE;
 #define S6D_WIN16_KSWZ 0             // the same chunk swizzle on the persistent window kernel's compact K image (11-chunk rows): measured
                                      // 0.265 ms against 0.260 ms without it (16 frames, one process) -- that kernel waits on its fetches,
                                      // and the swizzled source addresses split each token's 160-byte run into swapped 16-byte pieces
-#endif
-#ifndef S6D_GLB64_DEFAULT_IMPL
-#define S6D_GLB64_DEFAULT_IMPL 2     // 64 x 64 grid: 2 = attn_global64_kernel (LDS-DMA ring), 1 = attn_global_kernel (register staged)
 #endif
 #ifndef S6D_GLB_WAVES
 #define S6D_GLB_WAVES 4
@@ -238,16 +229,9 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
   const int gk = KSWZ ? (g ^ kswz(c)) : g;               // chunk of this lane's K fragment inside its group of 4 (see S6D_GLB_KSWZ)
   float s[NS][4][4];
   if (PRIO) __builtin_amdgcn_s_setprio(1);
-  // S6D_PT_KPRE: the K fragments of sub-tile s + 1 are requested in front of the matrix instructions of sub-tile s (two register
-  // sets, KS x 4 VGPRs more) instead of each fragment in front of its own instruction
-  bf16x8 kpre[S6D_PT_KPRE ? 2 : 1][S6D_PT_KPRE ? C::KS : 1];
   auto kfrag = [&](int sub, int ks) __attribute__((always_inline)) {
     return *reinterpret_cast<const bf16x8 *>(Kl + (sub * 16 + c) * C::KROW + ks * 32 + gk * 8);
   };
-  if (S6D_PT_KPRE && !(kAbl & 16)) {
-#pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) kpre[0][ks] = kfrag(0, ks);
-  }
 #pragma unroll
   for (int sub = 0; sub < 4; ++sub) {
     f32x4 acc[NS];
@@ -261,13 +245,9 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
       continue;
     }
     if (!(kAbl & 16)) {
-      if (S6D_PT_KPRE && sub + 1 < SUBS) {
-#pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks) kpre[(sub + 1) & 1][ks] = kfrag(sub + 1, ks);
-      }
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
-        const bf16x8 a = S6D_PT_KPRE ? kpre[sub & 1][ks] : kfrag(sub, ks);
+        const bf16x8 a = kfrag(sub, ks);
 #pragma unroll
         for (int n = 0; n < NS; ++n) acc[n] = S6D_ATTN_MFMA16(a, st.qf[n][ks], acc[n]);
       }
@@ -292,24 +272,7 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
   }
   union PB { bf16x8 v; u16 h[8]; };
   PB pb[NS][2];
-  // S6D_PT_VPRE: every V fragment of the tile is requested HERE, in front of the softmax arithmetic, instead of two at a time in
-  // front of the matrix instruction that consumes them (as written below the compiler emits read, read, s_waitcnt lgkmcnt(0),
-  // MFMA for every d tile: ten exposed LDS round trips per tile at two waves per SIMD).  2 x DT fragments = 32 (head dim 64) /
-  // 40 (80) VGPRs; the arithmetic and its order are unchanged.
   union VA { bf16x8 v; s16x4 q[2]; };
-  VA vpre[S6D_PT_VPRE ? 2 : 1][S6D_PT_VPRE ? C::DT : 1];
-  if (S6D_PT_VPRE && !(kAbl & 8)) {
-#pragma unroll
-    for (int j = 0; j < (SUBS + 1) / 2; ++j) {
-      const u16 *vrow = Vl + (32 * j + g * 4 + (c >> 2)) * C::VROW + (c & 3) * 4;
-#pragma unroll
-      for (int dt = 0; dt < C::DT; ++dt) {
-        vpre[j][dt].q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + dt * 16));
-        vpre[j][dt].q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + 16 * C::VROW + dt * 16));
-      }
-    }
-    if (S6D_PT_VPRE == 1) __builtin_amdgcn_sched_barrier(0);       // keep the requests in front of the exponentials (2: let the scheduler place them)
-  }
   if (PRIO) __builtin_amdgcn_s_setprio(0);
   if (kAbl & 4) {                                          // ablation: no softmax arithmetic
 #pragma unroll
@@ -384,12 +347,8 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) {
       VA va;
-      if (S6D_PT_VPRE) {
-        va = vpre[j][dt];
-      } else {
-        va.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + dt * 16));
-        va.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + 16 * C::VROW + dt * 16));
-      }
+      va.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + dt * 16));
+      va.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + 16 * C::VROW + dt * 16));
 #pragma unroll
       for (int n = 0; n < NS; ++n)
         st.oacc[n][dt] = S6D_ATTN_MFMA16(va.v, pb[n][j].v, st.oacc[n][dt]);
@@ -1628,157 +1587,6 @@ __global__ __launch_bounds__(WAVES * 64) void attn_global64_kernel(AttnParams p)
   }
 }
 
-// ---- sequences (no positional bias): DINOv2 ViT-L/14 (257 tokens), the PEM's ViT-B (197 tokens) -- round 4 ----------------
-// attn_window_kernel above treats a sequence as one all-resident window: one workgroup per (sequence, head) that fetches 99 KB,
-// waits for it, and then runs 17 strips of 16 queries over 8 waves (three rounds, the last with one wave busy) over 5 x 64 = 320
-// key slots for 257 keys.  Measured 20 us per item (186 us per launch of 150 crops x 16 heads: 0.08 of the matrix peak, 0.2 of
-// HBM) against ~2 us of matrix work: with two waves per SIMD every LDS fragment read in front of a matrix instruction is an
-// exposed ~100-cycle wait (the tile loop waits 17 times per tile), and a wave walks 15 tiles one after the other.
-// This kernel keeps the arithmetic (process_tile, one strip per wave: 73 VGPRs) and changes the schedule:
-//   * ONE ROUND: a wave per query strip, up to 16 waves (four per SIMD hide each other's LDS waits);
-//   * a 17th strip (257 = 16 x 16 + 1 queries) is split over the KEY tiles instead of costing a second round: wave t runs tile t
-//     for it and leaves (m, l, O^T) in LDS, wave 0 merges the partial states (the flash-decoding combination) -- one tile's time;
-//   * persistent: a workgroup per CU walks its (sequence, head) items; the K / V rows of item i + 1 are fetched into REGISTERS
-//     (2 x 3 x 16 bytes per thread) while item i is computed from LDS and written to the images between two barriers;
-//   * the tail tile runs only the 16-key sub-tiles that exist (257 keys = 4 tiles + 1 sub-tile).
-// Key rows >= T of the images are zero-filled once (finite operands for the masked columns of the tail).
-template <int HD, int NS>
-__device__ __forceinline__ void seq_init(StripState<HD, NS> &st) {
-#pragma unroll
-  for (int n = 0; n < NS; ++n) {
-    st.th[n] = nullptr; st.tw[n] = nullptr; st.qy[n] = 0; st.qx[n] = 0;
-    st.m_run[n] = -1e30f; st.lacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 16; ++i) st.twr[n][i] = 0.f;
-#pragma unroll
-    for (int dt = 0; dt < Cfg<HD>::DT; ++dt) st.oacc[n][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-}
-
-// tile `t` of the sequence (a full one, or the tail with its existing sub-tiles) against the strip(s) of `st`
-template <int HD, int NS>
-__device__ __forceinline__ void seq_tile(const AttnParams &p, const u16 *Kl, const u16 *Vl, int t, int nfull, int tail_subs,
-                                         StripState<HD, NS> &st, int lane) {
-  using C = Cfg<HD>;
-  float thv[NS];
-#pragma unroll
-  for (int n = 0; n < NS; ++n) thv[n] = 0.f;
-  const u16 *Kt = Kl + (size_t)t * 64 * C::KROW, *Vt = Vl + (size_t)t * 64 * C::VROW;
-  if (t < nfull) {
-    process_tile<HD, 2, NS>(p, Kt, Vt, t * 64, st, thv, lane);
-    return;
-  }
-  switch (tail_subs) {                                              // wave-uniform
-    case 1: process_tile<HD, 2, NS, false, false, 1>(p, Kt, Vt, t * 64, st, thv, lane); break;
-    case 2: process_tile<HD, 2, NS, false, false, 2>(p, Kt, Vt, t * 64, st, thv, lane); break;
-    case 3: process_tile<HD, 2, NS, false, false, 3>(p, Kt, Vt, t * 64, st, thv, lane); break;
-    default: process_tile<HD, 2, NS, false, false, 4>(p, Kt, Vt, t * 64, st, thv, lane); break;
-  }
-}
-
-constexpr int kSeqMaxWaves = 16;
-constexpr int kSeqPart = 2 + 4 * 5;                                 // floats per lane of a partial state: m, l, O^T (DT <= 5 tiles of 4)
-template <int HD>
-__global__ __launch_bounds__(kSeqMaxWaves * 64) void attn_seq_kernel(AttnParams p, int nitems) {
-  using C = Cfg<HD>;
-  static_assert(2 + 4 * C::DT <= kSeqPart, "partial-state slot");
-  constexpr int KP = HD / 8;                                        // 16-byte chunks per K / V row (the K image's head-dim pad stays zero)
-  constexpr int NPRE = 3;                                           // register prefetch: 16-byte chunks per thread and image (24 VGPRs)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int T = p.T, nfull = T / 64, rem = T - nfull * 64, tail_subs = (rem + 15) / 16;
-  const int ntile = nfull + (rem ? 1 : 0), rows = ntile * 64;
-  u16 *Kl = reinterpret_cast<u16 *>(smem);                          // [rows][KROW]
-  u16 *Vl = Kl + (size_t)rows * C::KROW;                            // [rows][VROW]
-  float *part = reinterpret_cast<float *>(Vl + (size_t)rows * C::VROW);   // [ntile][kSeqPart][64]: partial states of the split strip
-  const int tid = threadIdx.x, nthr = blockDim.x, wave = tid >> 6, lane = tid & 63, nwave = nthr >> 6;
-  const int nstrip = (T + 15) / 16;
-  const bool split = nstrip > nwave;                                // one strip more than waves: it is split over the key tiles
-  // zero both images once: head-dim padding of K, rows >= T of both
-  for (int i = tid; i < rows * (C::KROW + C::VROW) / 8; i += nthr) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
-  const int nchunk = T * KP;                                        // chunks of one image of one item
-  uint4 kr[NPRE], vr[NPRE];
-  auto fetch = [&](int id) {
-    WinItem it;
-    it.decode(p, id);
-    const u16 *kb = qkv_at(p, (size_t)it.b * T, 1, it.head), *vb = qkv_at(p, (size_t)it.b * T, 2, it.head);
-#pragma unroll
-    for (int n = 0; n < NPRE; ++n) {
-      const int i = min(tid + n * nthr, nchunk - 1);                // surplus lanes repeat the last chunk (never stored)
-      const int key = i / KP, part_ = i - key * KP;
-      if (kAbl & 1) {                                               // ablation: no K / V loads
-        kr[n] = make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
-        vr[n] = kr[n];
-        continue;
-      }
-      kr[n] = *reinterpret_cast<const uint4 *>(kb + (size_t)key * p.tok_stride + part_ * 8);
-      vr[n] = *reinterpret_cast<const uint4 *>(vb + (size_t)key * p.tok_stride + part_ * 8);
-    }
-  };
-  int id = blockIdx.x;
-  if (id < nitems) fetch(id);
-  __syncthreads();                                                  // the zero fill is complete before the first rows land
-  for (; id < nitems; id += gridDim.x) {
-#pragma unroll
-    for (int n = 0; n < NPRE; ++n) {
-      const int i = tid + n * nthr;
-      if (i < nchunk) {
-        const int key = i / KP, part_ = i - key * KP;
-        *reinterpret_cast<uint4 *>(Kl + key * C::KROW + part_ * 8) = kr[n];
-        *reinterpret_cast<uint4 *>(Vl + key * C::VROW + part_ * 8) = vr[n];
-      }
-    }
-    __syncthreads();
-    WinItem it;
-    it.decode(p, id);
-    StripState<HD, 1> st;
-    if (split && wave < ntile) {
-      // the strip beyond the waves first: tile `wave` of it, the partial state to LDS.  (Before the prefetch is issued: the
-      // registers of the prefetched rows and the working set of a tile together exceed the 128 VGPRs of a 16-wave workgroup, and
-      // a spilled prefetch register makes the wave wait for the fetch right here.)
-      seq_init<HD, 1>(st);
-      load_q<HD>(p, it.b, 0, 0, it.head, nwave * 16, st.qf[0], lane);
-      seq_tile<HD, 1>(p, Kl, Vl, wave, nfull, tail_subs, st, lane);
-      float *ps = part + (size_t)wave * kSeqPart * 64 + lane;
-      ps[0] = st.m_run[0];
-      ps[64] = st.lacc[0][0];
-#pragma unroll
-      for (int dt = 0; dt < C::DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ps[(2 + 4 * dt + r) * 64] = st.oacc[0][dt][r];
-    }
-    // this item's Q rows are requested BEFORE the next item's K / V rows: loads return in order, so the wait for Q does not wait
-    // for the prefetch, which then flies under the arithmetic below
-    seq_init<HD, 1>(st);
-    load_q<HD>(p, it.b, 0, 0, it.head, wave * 16, st.qf[0], lane);
-    if (id + (int)gridDim.x < nitems) fetch(id + gridDim.x);
-    if (!(kAbl & 2))
-      for (int t = 0; t < ntile; ++t) seq_tile<HD, 1>(p, Kl, Vl, t, nfull, tail_subs, st, lane);
-    store_strip<HD>(p, it.b, 0, 0, it.head, wave * 16, st.lacc[0][0], st.oacc[0], lane);
-    if (split) {
-      __syncthreads();
-      if (wave == 0) {                                              // merge: O = sum_t 2^(m_t - m) O_t, l likewise, m = max_t m_t
-        float m = -1e30f;
-        for (int t = 0; t < ntile; ++t) m = fmaxf(m, part[(size_t)t * kSeqPart * 64 + lane]);
-        float l = 0.f;
-        f32x4 o[C::DT];
-#pragma unroll
-        for (int dt = 0; dt < C::DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int t = 0; t < ntile; ++t) {
-          const float *ps = part + (size_t)t * kSeqPart * 64 + lane;
-          const float a = fast_exp2(ps[0] - m);
-          l += a * ps[64];
-#pragma unroll
-          for (int dt = 0; dt < C::DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[dt][r] += a * ps[(2 + 4 * dt + r) * 64];
-        }
-        store_strip<HD>(p, it.b, 0, 0, it.head, nwave * 16, l, o, lane);
-      }
-    }
-    __syncthreads();                                                // every wave is done with the images (and the partial states)
-  }
-}
-
 template <int HD>
 static int launch_attn(AttnParams p, hipStream_t st) {
   using C = Cfg<HD>;
@@ -1787,20 +1595,15 @@ static int launch_attn(AttnParams p, hipStream_t st) {
     constexpr int WAVES = 8;                                      // rows (wave, wave + 8): two query rows per wave share every
                                                                   // K / V fragment read (measured: 8x2 rows 0.23 ms vs 14x1 rows 0.25 ms per 8 frames)
     const int SR = (p.S + 1) & ~1;
-    // persistent, LDS-DMA double-buffered kernel: two query rows per wave (S > 8), both images + the rel tables inside 160 KiB.  S6D_WIN16_IMPL=1 selects the one-item kernel.
-    static int impl = -1;
-    if (impl < 0) {
-      const char *e = getenv("S6D_WIN16_IMPL");
-      impl = (e && atoi(e) == 1) ? 1 : 2;
-    }
-    if (impl == 2 && p.S > WAVES) {
+    // persistent, LDS-DMA double-buffered kernel: two query rows per wave (S > 8), both images + the rel tables inside 160 KiB;
+    // windows of up to 8 rows take the one-item kernel below
+    if (p.S > WAVES) {
       const int kin = (SR * 16 * (HD + 8) / 8 + 63) / 64, vin = (SR * 16 * C::VROW / 8 + 63) / 64;
       const size_t lds = (size_t)2 * (kin + vin) * 1024 + (size_t)2 * 32 * C::HDP * 2;
       const int nitems = p.B * p.nwy * p.nwx * p.nh;
       if (lds <= 160 * 1024 && (size_t)WAVES * 16 * W16_LT * 4 <= (size_t)vin * 1024) {
         int grid = nitems < 256 ? nitems : 256;                   // one persistent workgroup per CU
-        const char *ge = getenv("S6D_WIN16_GRID");                // tests: fewer workgroups than items without a big problem
-        if (ge && atoi(ge) > 0 && atoi(ge) < grid) grid = atoi(ge);
+        if (s6d::g_s6d_persistent_grid_limit > 0 && s6d::g_s6d_persistent_grid_limit < grid) grid = s6d::g_s6d_persistent_grid_limit;   // set through the ABI (tests)
         if (grid >= 8) grid &= ~7;                                // whole XCD rounds: workgroup j keeps to XCD j % 8, like its items
         if (p.S == 14) {
           (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_window16p_kernel<HD, true>),
@@ -1850,12 +1653,7 @@ static int launch_attn(AttnParams p, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS));                         \
     hipLaunchKernelGGL((attn_global_kernel<HD, WAVES, MODE>), dim3(grid), dim3(WAVES * 64), (LDS), st, p);     \
   } while (0)
-    static int impl64 = -1;                                      // S6D_GLB64_IMPL=1: the register-staged kernel on the 64 x 64 grid too
-    if (impl64 < 0) {
-      const char *e = getenv("S6D_GLB64_IMPL");
-      impl64 = e ? (atoi(e) == 1 ? 1 : 2) : S6D_GLB64_DEFAULT_IMPL;
-    }
-    if (bias && p.S == 64 && impl64 == 2) {
+    if (bias && p.S == 64) {
       using G = G64<HD, S6D_G64_WAVES, S6D_G64_SLOTS>;
       static_assert(G::LDS <= 160 * 1024, "ring + tables fit the CU's LDS");
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_global64_kernel<HD, G::WAVES, G::SLOTS>),
@@ -1866,8 +1664,6 @@ static int launch_attn(AttnParams p, hipStream_t st) {
     }
     if (!bias) {
       S6D_GLB(2, ring);
-    } else if (p.S == 64 && ring >= (size_t)WAVES * 16 * 80 * 4) {
-      S6D_GLB(1, ring + (size_t)WAVES * NS * 16 * S6D_GLB_THLD * 4);
     } else {
       S6D_GLB(0, ring + (size_t)WAVES * NS * 2 * 16 * p.LT * 4);
     }
@@ -1971,28 +1767,6 @@ extern "C" int S6D_SEQ_ATTENTION_STRIDED(const void *qkv, long tok_stride, long 
   p.scale_log2 = scale * kLog2e;
   p.tok_stride = tok_stride; p.which_stride = which_stride; p.head_stride = head_stride;
   hipStream_t st = as_stream(stream);
-  // S6D_SEQ_ATTN_IMPL=2 selects the persistent one-round kernel of round 4 (attn_seq_kernel: head dim 64, up to 272 tokens, a wave
-  // per query strip, a 17th strip split over the key tiles).  NOT the default: measured 224 us against the window kernel's 194 us
-  // per 150 x 16 x 257 launch (profiles/r04_seq_attention_ablation.txt: its fetch phase alone 130 us, its arithmetic alone 111 us,
-  // and the two do not overlap because the 16-wave workgroup's 128-VGPR budget spills the prefetched rows).
-  const char *ie = getenv("S6D_SEQ_ATTN_IMPL");                     // read per call (tests switch it inside one process)
-  const int impl = (ie && atoi(ie) == 2) ? 2 : 1;
-  if (impl == 2 && head_dim == 64) {
-    using C = Cfg<64>;
-    const int nstrip = (N + 15) / 16, waves = nstrip < kSeqMaxWaves ? nstrip : kSeqMaxWaves, ntile = (N + 63) / 64;
-    const size_t lds = (size_t)ntile * 64 * (C::KROW + C::VROW) * 2 + (size_t)ntile * kSeqPart * 64 * 4;
-    if (nstrip <= kSeqMaxWaves + 1 && lds <= 160 * 1024) {          // at most ONE strip beyond the waves (split over the key tiles)
-      const int nitems = B * num_heads;
-      int grid = nitems < 256 ? nitems : 256;
-      const char *ge = getenv("S6D_SEQ_ATTN_GRID");                 // tests: fewer workgroups than items without a big problem
-      if (ge && atoi(ge) > 0 && atoi(ge) < grid) grid = atoi(ge);
-      if (grid >= 8) grid &= ~7;                                    // whole XCD rounds: workgroup j keeps to XCD j % 8, like its items
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_seq_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds);
-      hipLaunchKernelGGL((attn_seq_kernel<64>), dim3(grid), dim3(waves * 64), lds, st, p, nitems);
-      return launch_status();
-    }
-  }
   switch (head_dim) {
     case 80: return launch_attn<80>(p, st);
     case 64: return launch_attn<64>(p, st);

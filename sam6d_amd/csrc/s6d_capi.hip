@@ -11,6 +11,18 @@ void set_hip_error(hipError_t e) {
 }
 }  // namespace s6d
 
+// Upper bound on the workgroups of the PERSISTENT kernels (attn_window16p_kernel walks its (window, head) items with one workgroup
+// per CU): 0 = the device's 256.  A process-wide setting made through the ABI (it replaced a getenv() inside the launch path in
+// round 5); the tests use it to make few workgroups walk many items on small problems.
+namespace s6d {
+int g_s6d_persistent_grid_limit = 0;
+}
+extern "C" int s6d_set_persistent_grid_limit(int max_workgroups) {
+  if (max_workgroups < 0) return S6D_EINVAL;
+  s6d::g_s6d_persistent_grid_limit = max_workgroups;
+  return S6D_OK;
+}
+
 extern "C" int s6d_version(void) { return S6D_ABI_VERSION; }
 
 extern "C" const char *s6d_last_hip_error(void) { return s6d::g_hip_err; }

@@ -22,6 +22,7 @@ inline int launch_status() {
 }
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+extern int g_s6d_persistent_grid_limit;      // csrc/s6d_capi.hip: s6d_set_persistent_grid_limit
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

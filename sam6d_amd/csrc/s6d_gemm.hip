@@ -1123,19 +1123,8 @@ __global__ void __launch_bounds__(256, 2) gemm2_bf16_kernel(GemmParams p) {
 
 using namespace s6d;
 
-// Which kernel: 2 = two independent 256 x 128 workgroups per CU (N % 128 == 0), 1 = the eight-wave 256 x 256 machine (N % 256 == 0).
-#ifndef S6D_GEMM_DEFAULT_IMPL
-#define S6D_GEMM_DEFAULT_IMPL 1     // measured (profiles/r02_gemm_v2_vs_v1.json): version 1 is ahead on every ViT-H shape
-#endif
-static int gemm_impl() {
-  static int impl = -1;
-  if (impl < 0) {
-    const char *e = getenv("S6D_GEMM_IMPL");
-    impl = (e && (atoi(e) == 1 || atoi(e) == 2)) ? atoi(e) : S6D_GEMM_DEFAULT_IMPL;
-  }
-  return impl;
-}
-
+// Which kernel: the eight-wave 256 x 256 machine wherever N % 256 == 0 (every ViT shape: measured ahead of version 2 on all of them,
+// profiles/r02_gemm_v2_shapes.json); version 2 (two independent 256 x 128 workgroups per CU) serves N % 256 == 128.
 extern "C" int s6d_gemm_bf16_cblk(const void *A, long lda, const void *W, long ldw, const float *bias, void *C, long ldc, int M,
                                   int N, int K, int epilogue, int col_block, int max_blocks, void *stream);
 struct GemmExtra {            // operands of the residual (EPI 2) and folded-LayerNorm (EPI 3 / 4) forms
@@ -1242,7 +1231,7 @@ static int gemm_launch(const void *A, long lda, const void *W, long ldw, const f
   if (epilogue < 0 || epilogue > 5 || (epilogue == 5 && dt != 1)) return S6D_EINVAL;
   // staging addresses are 32-bit byte offsets from A / W
   if ((double)M * (double)lda * esz >= 2147483648.0 || (double)N * (double)ldw * esz >= 2147483648.0) return S6D_EUNSUPPORTED;
-  const int impl = (N % 256 != 0) ? 2 : ((col_block > 0 || epilogue >= 2 || dt) ? 1 : gemm_impl());
+  const int impl = (N % 256 != 0) ? 2 : 1;
   GemmParams p;
   p.A = (const u16 *)A;
   p.W = (const u16 *)W;
@@ -1267,8 +1256,7 @@ static int gemm_launch(const void *A, long lda, const void *W, long ldw, const f
   p.NT = N / (impl == 2 ? 128 : 256);
   p.nk = K / kstep;
   p.ntiles = p.MT * p.NT;
-  const char *gm_env = getenv("S6D_GEMM_GM");                            // tile-order experiment knob
-  p.GM = (gm_env && atoi(gm_env) > 0) ? atoi(gm_env) : 8;
+  p.GM = 8;                                                              // m-tiles per n-tile group of the schedule (profiles/r04_gemm_gm.txt)
   p.cblk = col_block;
   hipStream_t st = as_stream(stream);
   if (impl == 2) {

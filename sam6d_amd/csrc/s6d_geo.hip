@@ -62,10 +62,13 @@ constexpr int OFF_AH = OFF_WAL + GEO_C * GEO_ROW;                  // [4 emb][64
 constexpr int OFF_AL = OFF_AH + 4 * GEO_PAIRS * GEO_ROW;
 constexpr int GEO_LDS_ELEMS = OFF_AL + 4 * GEO_PAIRS * GEO_ROW;    // 61440 elems = 120 KB
 
+// HALF: the embedding is written in IEEE half (2 bytes per channel) instead of float32 -- its only reader, rpe_attention_kernel, is
+// bound by streaming it (12 reads of 1.4 GB per 32 instances); the arithmetic up to the store is the same.
+template <bool HALF>
 __global__ __launch_bounds__(GEO_THREADS) void geo_embed_kernel(const float *__restrict__ idx4, long NP,
                                                                const float *__restrict__ Wd, const float *__restrict__ bd,
                                                                const float *__restrict__ Wa, const float *__restrict__ ba,
-                                                               const float *__restrict__ div_term, float *__restrict__ out) {
+                                                               const float *__restrict__ div_term, void *__restrict__ outv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   u16 *lds = reinterpret_cast<u16 *>(smem);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -184,7 +187,10 @@ __global__ __launch_bounds__(GEO_THREADS) void geo_embed_kernel(const float *__r
     for (int r = 0; r < 4; ++r) {
       const long pr = pair0 + mt * 16 + g * 4 + r;
       const float v = accd[t][r] + fmaxf(fmaxf(acca[0][t][r], acca[1][t][r]), acca[2][t][r]) + bias;
-      if (pr < NP) out[pr * GEO_C + n] = v;
+      if (pr < NP) {
+        if (HALF) reinterpret_cast<_Float16 *>(outv)[pr * GEO_C + n] = (_Float16)v;
+        else reinterpret_cast<float *>(outv)[pr * GEO_C + n] = v;
+      }
     }
   }
 }
@@ -193,17 +199,30 @@ __global__ __launch_bounds__(GEO_THREADS) void geo_embed_kernel(const float *__r
 
 using namespace s6d;
 
-extern "C" int s6d_geo_embedding_f32(const float *idx4, long NP, const float *Wd, const float *bd, const float *Wa,
-                                     const float *ba, const float *div_term, int C, int K, float *out, void *stream) {
+static int geo_launch(const float *idx4, long NP, const float *Wd, const float *bd, const float *Wa, const float *ba,
+                      const float *div_term, int C, int K, void *out, bool half, void *stream) {
   if (NP < 0) return S6D_EINVAL;
   if (C != GEO_C || K != 3) return S6D_EUNSUPPORTED;      // released model: hidden_dim 256, angle_k 3
   if (NP == 0) return S6D_OK;
   if (!idx4 || !Wd || !bd || !Wa || !ba || !div_term || !out) return S6D_EINVAL;
   const size_t lds = (size_t)GEO_LDS_ELEMS * 2;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&geo_embed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
   const unsigned grid = (unsigned)((NP + GEO_PAIRS - 1) / GEO_PAIRS);
-  hipLaunchKernelGGL(geo_embed_kernel, dim3(grid), dim3(GEO_THREADS), lds, as_stream(stream), idx4, NP, Wd, bd, Wa, ba,
-                     div_term, out);
+  if (half) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&geo_embed_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(geo_embed_kernel<true>, dim3(grid), dim3(GEO_THREADS), lds, as_stream(stream), idx4, NP, Wd, bd, Wa, ba, div_term, out);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&geo_embed_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(geo_embed_kernel<false>, dim3(grid), dim3(GEO_THREADS), lds, as_stream(stream), idx4, NP, Wd, bd, Wa, ba, div_term, out);
+  }
   return launch_status();
+}
+
+extern "C" int s6d_geo_embedding_f32(const float *idx4, long NP, const float *Wd, const float *bd, const float *Wa,
+                                     const float *ba, const float *div_term, int C, int K, float *out, void *stream) {
+  return geo_launch(idx4, NP, Wd, bd, Wa, ba, div_term, C, K, out, false, stream);
+}
+
+extern "C" int s6d_geo_embedding_f16(const float *idx4, long NP, const float *Wd, const float *bd, const float *Wa,
+                                     const float *ba, const float *div_term, int C, int K, void *out_f16, void *stream) {
+  return geo_launch(idx4, NP, Wd, bd, Wa, ba, div_term, C, K, out_f16, true, stream);
 }

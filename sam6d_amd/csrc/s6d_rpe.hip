@@ -18,10 +18,12 @@ __device__ __forceinline__ float dot4(const float4 a, const float4 b) {
 
 // RPE == false: plain multi-head attention of N query rows over M keys (cross attention of the sparse
 // transformer, transformer.py:93-148): the same one-wave-per-query-row structure without the embedding stream.
-template <int WAVES, bool RPE>
+// EH: the embedding is stored in IEEE half (s6d_geo_embedding_f16): 8 bytes per lane and key instead of 16, widened in registers; the
+// products and sums are the float32 ones.
+template <int WAVES, bool RPE, bool EH = false>
 __global__ __launch_bounds__(WAVES * 64) void rpe_attention_kernel(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
-    const float *__restrict__ qt, const float *__restrict__ qb, const float *__restrict__ embed,
+    const float *__restrict__ qt, const float *__restrict__ qb, const void *__restrict__ embedv,
     int B, int N, int M, float scale, float *__restrict__ out, long ldq, long ldk, long ldv, long qt_bs, long qt_rs, long qt_hs,
     long qb_bs, long qb_rs, long qb_hs) {
   // qt (b, head, n, 256) at b qt_bs + n qt_rs + head qt_hs, qb (b, head, n) at b qb_bs + n qb_rs + head qb_hs: (B,4,N,256) / (B,4,N)
@@ -42,6 +44,7 @@ __global__ __launch_bounds__(WAVES * 64) void rpe_attention_kernel(
   float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0, t2 = t0, t3 = t0;  // q~ of the four heads
   float qbg = 0.f;
   const float *erow = nullptr;
+  const _Float16 *erow_h = nullptr;
   if (RPE) {
     const float *base = qt + (size_t)b * qt_bs + (size_t)n * qt_rs + c4;
     t0 = *reinterpret_cast<const float4 *>(base);
@@ -49,7 +52,8 @@ __global__ __launch_bounds__(WAVES * 64) void rpe_attention_kernel(
     t2 = *reinterpret_cast<const float4 *>(base + 2 * qt_hs);
     t3 = *reinterpret_cast<const float4 *>(base + 3 * qt_hs);
     qbg = qb[(size_t)b * qb_bs + (size_t)n * qb_rs + (size_t)g * qb_hs];
-    erow = embed + (size_t)row * M * 256 + c4;
+    if (EH) erow_h = reinterpret_cast<const _Float16 *>(embedv) + (size_t)row * M * 256 + c4;
+    else erow = reinterpret_cast<const float *>(embedv) + (size_t)row * M * 256 + c4;
   }
   const float *krow = k + (size_t)b * M * ldk + c4;
   const float *vrow = v + (size_t)b * M * ldv + c4;
@@ -60,7 +64,14 @@ __global__ __launch_bounds__(WAVES * 64) void rpe_attention_kernel(
     const float4 k4 = *reinterpret_cast<const float4 *>(krow + (size_t)m * ldk);
     float mine = 0.f;
     if (RPE) {
-      const float4 e4 = *reinterpret_cast<const float4 *>(erow + (size_t)m * 256);
+      float4 e4;
+      if (EH) {
+        typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+        const h4 e = *reinterpret_cast<const h4 *>(erow_h + (size_t)m * 256);
+        e4 = make_float4((float)e[0], (float)e[1], (float)e[2], (float)e[3]);
+      } else {
+        e4 = *reinterpret_cast<const float4 *>(erow + (size_t)m * 256);
+      }
       const float p0 = dot4(t0, e4), p1 = dot4(t1, e4), p2 = dot4(t2, e4), p3 = dot4(t3, e4);
       // fold 4 partials -> 1: lanes 0-31 keep heads {0,1}, 32-63 keep {2,3}; then bit 4 picks one
       float ka = hi32 ? p2 : p0, kb = hi32 ? p3 : p1;
@@ -113,9 +124,8 @@ __global__ __launch_bounds__(WAVES * 64) void rpe_attention_kernel(
 
 using namespace s6d;
 
-extern "C" int s6d_rpe_attention_strided_f32(const float *q, long ldq, const float *k, long ldk, const float *v, long ldv,
-                                             const float *qt, const float *qb, const float *embed, int B, int N, int C, int heads,
-                                             float scale, float *out, void *stream) {
+static int rpe_strided(const float *q, long ldq, const float *k, long ldk, const float *v, long ldv, const float *qt, const float *qb,
+                       const void *embed, bool eh, int B, int N, int C, int heads, float scale, float *out, void *stream) {
   if (B < 0 || N <= 0 || ldq < C || ldk < C || ldv < C || (ldq % 4) || (ldk % 4) || (ldv % 4)) return S6D_EINVAL;
   if (C != 256 || heads != 4) return S6D_EUNSUPPORTED;   // released model: d_model 256, 4 heads
   if (B == 0) return S6D_OK;
@@ -126,17 +136,33 @@ extern "C" int s6d_rpe_attention_strided_f32(const float *q, long ldq, const flo
   const int Np = (N + 3) & ~3;
   const size_t lds = (size_t)WAVES * 4 * Np * sizeof(float);
   if (lds > 64 * 1024) return S6D_EUNSUPPORTED;
-  hipLaunchKernelGGL((rpe_attention_kernel<WAVES, true>), dim3((unsigned)((rows + WAVES - 1) / WAVES)), dim3(WAVES * 64),
-                     lds, as_stream(stream), q, k, v, qt, qb, embed, B, N, N, scale, out, ldq, ldk, ldv, 4L * N * 256, 256L, (long)N * 256,
-                     4L * N, 1L, (long)N);
+  if (eh)
+    hipLaunchKernelGGL((rpe_attention_kernel<WAVES, true, true>), dim3((unsigned)((rows + WAVES - 1) / WAVES)), dim3(WAVES * 64),
+                       lds, as_stream(stream), q, k, v, qt, qb, embed, B, N, N, scale, out, ldq, ldk, ldv, 4L * N * 256, 256L,
+                       (long)N * 256, 4L * N, 1L, (long)N);
+  else
+    hipLaunchKernelGGL((rpe_attention_kernel<WAVES, true, false>), dim3((unsigned)((rows + WAVES - 1) / WAVES)), dim3(WAVES * 64),
+                       lds, as_stream(stream), q, k, v, qt, qb, embed, B, N, N, scale, out, ldq, ldk, ldv, 4L * N * 256, 256L,
+                       (long)N * 256, 4L * N, 1L, (long)N);
   return launch_status();
+}
+
+extern "C" int s6d_rpe_attention_strided_f32(const float *q, long ldq, const float *k, long ldk, const float *v, long ldv,
+                                             const float *qt, const float *qb, const float *embed, int B, int N, int C, int heads,
+                                             float scale, float *out, void *stream) {
+  return rpe_strided(q, ldq, k, ldk, v, ldv, qt, qb, embed, false, B, N, C, heads, scale, out, stream);
+}
+
+extern "C" int s6d_rpe_attention_strided_e16_f32(const float *q, long ldq, const float *k, long ldk, const float *v, long ldv,
+                                                 const float *qt, const float *qb, const void *embed_f16, int B, int N, int C, int heads,
+                                                 float scale, float *out, void *stream) {
+  return rpe_strided(q, ldq, k, ldk, v, ldv, qt, qb, embed_f16, true, B, N, C, heads, scale, out, stream);
 }
 
 // q | k | v | q~ (4 x 256) | qb (4) as column blocks of ONE projection output proj (B,N,ld): W_p of the RPE layer is folded into the
 // projection's weights by the caller (q~_h = x (W_q,h^T W_p,h) + b_q,h W_p,h), so the `W_p^T q` products of the layer are not a pass.
-extern "C" int s6d_rpe_attention_packed_f32(const float *proj, long ld, int q_off, int k_off, int v_off, int qt_off, int qb_off,
-                                            const float *embed, int B, int N, int C, int heads, float scale, float *out,
-                                            void *stream) {
+static int rpe_packed(const float *proj, long ld, int q_off, int k_off, int v_off, int qt_off, int qb_off, const void *embed, bool eh,
+                      int B, int N, int C, int heads, float scale, float *out, void *stream) {
   if (B < 0 || N <= 0 || C != 256 || heads != 4 || (ld % 4) != 0) return B < 0 || N <= 0 || (ld % 4) ? S6D_EINVAL : S6D_EUNSUPPORTED;
   if (q_off < 0 || k_off < 0 || v_off < 0 || qt_off < 0 || qb_off < 0 || (q_off % 4) || (k_off % 4) || (v_off % 4) || (qt_off % 4) ||
       q_off + C > ld || k_off + C > ld || v_off + C > ld || qt_off + 4 * C > ld || qb_off + 4 > ld)
@@ -148,10 +174,27 @@ extern "C" int s6d_rpe_attention_packed_f32(const float *proj, long ld, int q_of
   const int Np = (N + 3) & ~3;
   const size_t lds = (size_t)WAVES * 4 * Np * sizeof(float);
   if (lds > 64 * 1024) return S6D_EUNSUPPORTED;
-  hipLaunchKernelGGL((rpe_attention_kernel<WAVES, true>), dim3((unsigned)((rows + WAVES - 1) / WAVES)), dim3(WAVES * 64),
-                     lds, as_stream(stream), proj + q_off, proj + k_off, proj + v_off, proj + qt_off, proj + qb_off, embed, B, N, N,
-                     scale, out, ld, ld, ld, (long)N * ld, ld, 256L, (long)N * ld, ld, 1L);
+  if (eh)
+    hipLaunchKernelGGL((rpe_attention_kernel<WAVES, true, true>), dim3((unsigned)((rows + WAVES - 1) / WAVES)), dim3(WAVES * 64),
+                       lds, as_stream(stream), proj + q_off, proj + k_off, proj + v_off, proj + qt_off, proj + qb_off, embed, B, N, N,
+                       scale, out, ld, ld, ld, (long)N * ld, ld, 256L, (long)N * ld, ld, 1L);
+  else
+    hipLaunchKernelGGL((rpe_attention_kernel<WAVES, true, false>), dim3((unsigned)((rows + WAVES - 1) / WAVES)), dim3(WAVES * 64),
+                       lds, as_stream(stream), proj + q_off, proj + k_off, proj + v_off, proj + qt_off, proj + qb_off, embed, B, N, N,
+                       scale, out, ld, ld, ld, (long)N * ld, ld, 256L, (long)N * ld, ld, 1L);
   return launch_status();
+}
+
+extern "C" int s6d_rpe_attention_packed_f32(const float *proj, long ld, int q_off, int k_off, int v_off, int qt_off, int qb_off,
+                                            const float *embed, int B, int N, int C, int heads, float scale, float *out,
+                                            void *stream) {
+  return rpe_packed(proj, ld, q_off, k_off, v_off, qt_off, qb_off, embed, false, B, N, C, heads, scale, out, stream);
+}
+
+extern "C" int s6d_rpe_attention_packed_e16_f32(const float *proj, long ld, int q_off, int k_off, int v_off, int qt_off, int qb_off,
+                                                const void *embed_f16, int B, int N, int C, int heads, float scale, float *out,
+                                                void *stream) {
+  return rpe_packed(proj, ld, q_off, k_off, v_off, qt_off, qb_off, embed_f16, true, B, N, C, heads, scale, out, stream);
 }
 
 extern "C" int s6d_rpe_attention_f32(const float *q, const float *k, const float *v, const float *qt,

@@ -203,11 +203,12 @@ def rpe_attention(q, k, v, qt, qb, embed, scale):
     embed (B,N,N,256) -> (B,N,256), all f32."""
     (q, ldq), (k, ldk), (v, ldv) = _rows3(q, "q"), _rows3(k, "k"), _rows3(v, "v")
     qt, qb = qt.contiguous(), qb.contiguous()
-    for a, nm in ((qt, "qt"), (qb, "qb"), (embed, "embed")):
+    for a, nm in ((qt, "qt"), (qb, "qb")):
         _chk(a, torch.float32, nm)
+    _chk(embed, embed.dtype if embed.dtype == torch.float16 else torch.float32, "embed", 4)
     B, N, C = q.shape
     out = torch.empty(B, N, C, dtype=torch.float32, device=q.device)
-    _call("s6d_rpe_attention_strided_f32", _ptr(q), ctypes.c_long(ldq), _ptr(k), ctypes.c_long(ldk), _ptr(v), ctypes.c_long(ldv),
+    _call("s6d_rpe_attention_strided_e16_f32" if embed.dtype == torch.float16 else "s6d_rpe_attention_strided_f32", _ptr(q), ctypes.c_long(ldq), _ptr(k), ctypes.c_long(ldk), _ptr(v), ctypes.c_long(ldv),
           _ptr(qt), _ptr(qb), _ptr(embed), B, N, C, 4, ctypes.c_float(scale), _ptr(out), _stream())
     return out
 
@@ -216,10 +217,10 @@ def rpe_attention_packed(proj, embed, scale, q_off=0, k_off=256, v_off=512, qt_o
     """rpe_attention on ONE projection output proj (B,N,ld) f32 holding q | k | v | q~ (4 x 256) | qb (4) as column blocks (W_p folded
     into the projection's weights by the caller) -> (B,N,256) f32."""
     _chk(proj, torch.float32, "proj", 3)
-    _chk(embed, torch.float32, "embed", 4)
+    _chk(embed, embed.dtype if embed.dtype == torch.float16 else torch.float32, "embed", 4)
     B, N, ld = proj.shape
     out = torch.empty(B, N, 256, dtype=torch.float32, device=proj.device)
-    _call("s6d_rpe_attention_packed_f32", _ptr(proj), ctypes.c_long(ld), int(q_off), int(k_off), int(v_off), int(qt_off), int(qb_off),
+    _call("s6d_rpe_attention_packed_e16_f32" if embed.dtype == torch.float16 else "s6d_rpe_attention_packed_f32", _ptr(proj), ctypes.c_long(ld), int(q_off), int(k_off), int(v_off), int(qt_off), int(qb_off),
           _ptr(embed), B, N, 256, 4, ctypes.c_float(scale), _ptr(out), _stream())
     return out
 
@@ -938,14 +939,17 @@ def add_layernorm(x, delta, gamma, beta, eps):
     return xo, y
 
 
-def geo_embedding(idx4, Wd, bd, Wa, ba, div_term):
-    """idx4 (...,4) f32 [d_idx, a_idx x3] -> (...,256) f32 geometric structure embedding."""
+def geo_embedding(idx4, Wd, bd, Wa, ba, div_term, out_dtype=torch.float32):
+    """idx4 (...,4) f32 [d_idx, a_idx x3] -> (...,256) geometric structure embedding, stored in f32 or (out_dtype=torch.float16) in
+    IEEE half for the RPE attention core to stream."""
     for a, nm in ((idx4, "idx4"), (Wd, "Wd"), (bd, "bd"), (Wa, "Wa"), (ba, "ba"), (div_term, "div_term")):
         _chk(a, torch.float32, nm)
+    if out_dtype not in (torch.float32, torch.float16):
+        raise RuntimeError("the embedding is stored in float32 or float16")
     NP = idx4.numel() // 4
-    out = torch.empty(*idx4.shape[:-1], Wd.shape[0], dtype=torch.float32, device=idx4.device)
-    _call("s6d_geo_embedding_f32", _ptr(idx4), ctypes.c_long(NP), _ptr(Wd), _ptr(bd), _ptr(Wa), _ptr(ba),
-          _ptr(div_term), int(Wd.shape[0]), int(idx4.shape[-1] - 1), _ptr(out), _stream())
+    out = torch.empty(*idx4.shape[:-1], Wd.shape[0], dtype=out_dtype, device=idx4.device)
+    _call("s6d_geo_embedding_f32" if out_dtype == torch.float32 else "s6d_geo_embedding_f16", _ptr(idx4), ctypes.c_long(NP), _ptr(Wd),
+          _ptr(bd), _ptr(Wa), _ptr(ba), _ptr(div_term), int(Wd.shape[0]), int(idx4.shape[-1] - 1), _ptr(out), _stream())
     return out
 
 
@@ -1156,7 +1160,7 @@ _FUSED = {}
 
 def have(name):
     if name not in _FUSED:
-        sym = {"rpe_attention": "s6d_rpe_attention_f32", "rpe_attention_packed": "s6d_rpe_attention_packed_f32", "geo_embedding": "s6d_geo_embedding_f32",
+        sym = {"rpe_attention": "s6d_rpe_attention_f32", "rpe_attention_packed": "s6d_rpe_attention_packed_f32", "geo_embedding": "s6d_geo_embedding_f32", "geo_embedding_f16": "s6d_geo_embedding_f16",
                "fine_assign": "s6d_fine_assign_f32", "fine_match": "s6d_fine_match_f32", "pem_pre": "s6d_pem_compact_cloud_f32", "coarse_sample": "s6d_coarse_sample_f32", "upsample_gather": "s6d_upsample_gather_f32",
                "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "weighted_procrustes": "s6d_weighted_procrustes_f32", "add_layernorm": "s6d_add_layernorm_bf16", "gemm_bf16": "s6d_gemm_bf16", "gemm_bf16_res": "s6d_gemm_bf16_res", "gemm_bf16_lnfold": "s6d_gemm_bf16_lnfold", "gemm_f16": "s6d_gemm_f16", "gemm_fp8": "s6d_gemm_fp8", "layernorm_fp8": "s6d_layernorm_fp8", "layernorm_f32out": "s6d_layernorm_bf16_f32", "linear_f32": "s6d_linear_f32", "win_attention": "s6d_win_attention_layout_bf16",
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",

@@ -162,7 +162,7 @@ class RPEMultiHeadAttention(nn.Module):
         qb = torch.einsum("bhnc,hc->bhn", qh, self.proj_p.bias.view(HEADS, c))
         if ops.have("rpe_attention") and x.is_cuda:
             return ops.rpe_attention(q, k, v, qt, qb, embed, self.scale)
-        sp = torch.einsum("bhnj,bnmj->bhnm", qt, embed) + qb.unsqueeze(-1)
+        sp = torch.einsum("bhnj,bnmj->bhnm", qt, embed.float()) + qb.unsqueeze(-1)
         a = torch.softmax((qh @ _split(k).transpose(-1, -2) + sp) * self.scale, dim=-1)
         return _merge(a @ _split(v))
 
@@ -335,6 +335,9 @@ class SinusoidalPositionalEmbedding(nn.Module):
         return torch.stack([torch.sin(om), torch.cos(om)], dim=-1).reshape(*x.shape, self.d_model)
 
 
+_GEO_DTYPE_DEFAULT = "fp32"
+
+
 class GeometricStructureEmbedding(nn.Module):
     """transformer.py:286-349.  cfg: sigma_d, sigma_a, angle_k, reduction_a, hidden_dim."""
 
@@ -371,8 +374,12 @@ class GeometricStructureEmbedding(nn.Module):
         if ops.have("geo_embedding") and points.is_cuda and self.angle_k == 3 and self.proj_d.weight.shape[0] == 256:
             d_idx, a_idx = self.get_embedding_indices(points)
             idx4 = torch.cat([d_idx.unsqueeze(-1), a_idx], dim=-1).contiguous()          # (B,N,N,4)
+            # S6D_PEM_GEO_DTYPE=fp16: the embedding is STORED in IEEE half (same arithmetic up to the store); its twelve readers
+            # (rpe_attention_kernel, bound by streaming it) then move half the bytes.  Measured margins: DESIGN.md 4.
+            half = os.environ.get("S6D_PEM_GEO_DTYPE", _GEO_DTYPE_DEFAULT) == "fp16" and ops.have("geo_embedding_f16")
             return ops.geo_embedding(idx4, self.proj_d.weight.contiguous(), self.proj_d.bias, self.proj_a.weight.contiguous(),
-                                     self.proj_a.bias, self.embedding.div_term.contiguous())
+                                     self.proj_a.bias, self.embedding.div_term.contiguous(),
+                                     out_dtype=torch.float16 if half else torch.float32)
         outs = []
         for p in points.split(4, dim=0):     # bound the (b,N,N,k,256) intermediate of the library path
             d_idx, a_idx = self.get_embedding_indices(p)

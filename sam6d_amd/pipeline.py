@@ -218,7 +218,7 @@ class FramePipeline:
             ver += t._version
             ptr ^= t.data_ptr()
         return (Mp, tuple((tuple(ep[k].shape[1:]), ep[k].dtype) for k in keys), os.environ.get("S6D_PEM_VIT_DTYPE", ""),
-                os.environ.get("S6D_PEM_F16_GUARD", ""), ver, ptr)
+                os.environ.get("S6D_PEM_F16_GUARD", ""), os.environ.get("S6D_PEM_GEO_DTYPE", ""), ver, ptr)
 
     def invalidate_graphs(self):
         """Drop every captured PEM graph (they are re-captured on the next call)."""

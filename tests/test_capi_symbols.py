@@ -77,7 +77,7 @@ def test_every_entry_point_refuses_null_operands():
              "int": lambda: ctypes.c_int(16)}
     rcs = {}
     for name, args in protos:
-        if args.strip() == "void":
+        if args.strip() == "void" or "*" not in args:          # no operand to refuse (s6d_version, s6d_set_persistent_grid_limit)
             continue
         vals = []
         for a in (x.strip() for x in args.split(",")):

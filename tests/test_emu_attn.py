@@ -19,12 +19,16 @@ def test_head_major_layout_on_the_emulator(emu, B, H, nh, hd, ws):
 
 @pytest.mark.parametrize("grid", [8, 3])
 def test_persistent_window_kernel_walks_several_items(emu, monkeypatch, grid):
-    """attn_window16p_kernel with fewer workgroups than items (S6D_WIN16_GRID): the LDS-DMA prefetch of the next item's K / V
+    """attn_window16p_kernel with fewer workgroups than items (s6d_set_persistent_grid_limit): the LDS-DMA prefetch of the next item's K / V
     images into the other half of LDS, the Q prefetch in the PV pass, scratch tables inside the buffer being filled; 32 items
     (out-of-image window slots included) on 8 and on 3 workgroups (uneven shares, odd and even item counts per workgroup)."""
-    monkeypatch.setenv("S6D_WIN16_GRID", str(grid))
-    T.test_fused_attention_vs_oracle(2, 20, 4, 80, 14)
-    T.test_fused_attention_vs_oracle(1, 28, 2, 64, 14)
+    from sam6d_amd import _lib
+    assert _lib.lib().s6d_set_persistent_grid_limit(grid) == 0
+    try:
+        T.test_fused_attention_vs_oracle(2, 20, 4, 80, 14)
+        T.test_fused_attention_vs_oracle(1, 28, 2, 64, 14)
+    finally:
+        _lib.lib().s6d_set_persistent_grid_limit(0)
 
 
 @pytest.mark.parametrize("rows,C", [(37, 160), (5, 768)])
@@ -35,25 +39,6 @@ def test_add_layernorm_on_the_emulator(emu, rows, C):
 @pytest.mark.parametrize("B,N,nh,hd", [(2, 50, 2, 80), (1, 70, 1, 64)])
 def test_seq_attention_on_the_emulator(emu, B, N, nh, hd):
     T.test_seq_attention_vs_torch(B, N, nh, hd)
-
-
-@pytest.mark.parametrize("B,N,nh,grid", [(1, 17, 2, 0),      # one tile: tail of 2 sub-tiles, two waves
-                                         (3, 97, 2, 2),      # 1 tile + a 3-sub-tile tail; 6 items on 2 persistent workgroups (prefetch path)
-                                         (1, 129, 1, 0),     # 2 tiles + a 1-sub-tile tail holding ONE key
-                                         (1, 50, 2, 0),      # a tail of four sub-tiles, the last one partial
-                                         (2, 64, 3, 4),      # no tail tile; 6 items on 4 workgroups (uneven shares)
-                                         (2, 257, 2, 3),     # the DINOv2 shape: 16 waves + the 17th strip split over the 5 key tiles; 4 items on 3 workgroups
-                                         (1, 272, 1, 0),     # the largest sequence: 17 full strips
-                                         (1, 197, 2, 0)])    # the PEM ViT-B shape: 13 waves, no split
-def test_seq_attention_one_round_kernel_on_the_emulator(emu, monkeypatch, B, N, nh, grid):
-    """attn_seq_kernel (head dim 64, round 4): tails of 1 - 4 sixteen-key sub-tiles, workgroups that walk several items (register
-    prefetch of the next item's K / V rows under the current item's arithmetic), the strip split over the key tiles with the
-    merge of its partial softmax states, against torch; bf16 and IEEE half."""
-    monkeypatch.setenv("S6D_SEQ_ATTN_IMPL", "2")                     # opt-in (the window kernel stays the default: it measured faster)
-    if grid:
-        monkeypatch.setenv("S6D_SEQ_ATTN_GRID", str(grid))
-    T.test_seq_attention_vs_torch(B, N, nh, 64)
-    T.test_seq_attention_float16_vs_torch(B, N, nh, 64)
 
 
 def test_segment_seq_sum_and_centroid_path_on_the_emulator(emu, monkeypatch):

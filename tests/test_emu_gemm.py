@@ -63,17 +63,15 @@ def _run_case(i):
     _check(ops, M, N, K, bias, gelu, mb, pad, seed=i)
 
 
-@pytest.mark.parametrize("impl", [2, 1])
 @pytest.mark.parametrize("mode", ["early", "late"])
 @pytest.mark.parametrize("case", range(len(CASES)))
-def test_gemm_on_the_emulator(case, mode, impl):
-    """impl 2 = two independent 256 x 128 workgroups per CU (the default), 1 = the eight-wave 256 x 256 kernel (S6D_GEMM_IMPL=1)."""
-    if case == 4 and not os.environ.get("S6D_EMU_SLOW") and (mode == "late" or impl == 1):
+def test_gemm_on_the_emulator(case, mode):
+    """The launcher picks the kernel by shape: N % 256 == 0 -> the eight-wave 256 x 256 kernel, N % 256 == 128 -> the kernel of two
+    independent 256 x 128 workgroups per CU; CASES holds both kinds."""
+    if case == 4 and not os.environ.get("S6D_EMU_SLOW") and mode == "late":
         pytest.skip("long case runs once by default (S6D_EMU_SLOW=1 for every combination)")
-    if impl == 1 and CASES[case][1] % 256:
-        pytest.skip("the 256 x 256 kernel needs N % 256 == 0 (the launcher routes other N to the 256 x 128 kernel)")
-    # HIPEMU_GLDS / S6D_GEMM_IMPL are read once per process: each combination gets its own interpreter
-    env = dict(os.environ, HIPEMU_GLDS=mode, S6D_GEMM_IMPL=str(impl))
+    # HIPEMU_GLDS is read once per process: each combination gets its own interpreter
+    env = dict(os.environ, HIPEMU_GLDS=mode)
     r = subprocess.run([sys.executable, "-c", f"import sys; sys.path.insert(0, {ROOT!r}); "
                         f"from tests import test_emu_gemm as t; t._run_case({case})"], env=env, capture_output=True,
                        text=True, timeout=1500)

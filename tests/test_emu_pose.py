@@ -14,6 +14,10 @@ def test_weighted_procrustes_on_the_emulator(emu):
     T.test_weighted_procrustes_vs_oracle_and_batch_invariance(emu, 1, 7)
 
 
+def test_half_stored_geo_embedding_on_the_emulator(emu):
+    T.test_half_stored_geo_embedding_and_its_reader(emu)
+
+
 def test_min_dist_on_the_emulator(emu):
     T.test_min_dist_vs_oracle(emu, 196, 3)
 

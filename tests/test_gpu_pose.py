@@ -54,6 +54,29 @@ def test_weighted_procrustes_vs_oracle_and_batch_invariance(ops, B, N):
         assert torch.equal(R1[0], R[b]) and torch.equal(t1[0], t[b])
 
 
+def test_half_stored_geo_embedding_and_its_reader(ops):
+    """S6D_PEM_GEO_DTYPE=fp16: s6d_geo_embedding_f16 stores the SAME values rounded to IEEE half (relative 2^-11), and the RPE
+    attention core on the half tensor equals the core on that tensor widened to float32 bit for bit (it widens in registers)."""
+    from sam6d_amd.pem.layers import GeometricStructureEmbedding
+    from sam6d_amd.pem.pose_estimation_model import default_cfg
+    from sam6d_amd.utils import seeded
+    geo = seeded.load_seeded(GeometricStructureEmbedding(default_cfg().geo_embedding).eval(), 4).cuda()
+    pts = synth.pem_inputs(2, seed=9, n_pts=37, with_rgb=False)["pts"].cuda() * 5
+    d_idx, a_idx = geo.get_embedding_indices(pts)
+    idx4 = torch.cat([d_idx.unsqueeze(-1), a_idx], dim=-1).contiguous()
+    args = (idx4, geo.proj_d.weight.contiguous(), geo.proj_d.bias, geo.proj_a.weight.contiguous(), geo.proj_a.bias, geo.embedding.div_term.contiguous())
+    e32 = ops.geo_embedding(*args)
+    e16 = ops.geo_embedding(*args, out_dtype=torch.float16)
+    assert e16.dtype == torch.float16 and torch.equal(e16.cpu(), e32.cpu().half())
+    g = torch.Generator().manual_seed(2)
+    B, N = pts.shape[:2]
+    q, k, v = (torch.randn(B, N, 256, generator=g).cuda() for _ in range(3))
+    qt, qb = torch.randn(B, 4, N, 256, generator=g).cuda() * 0.1, torch.randn(B, 4, N, generator=g).cuda()
+    a = ops.rpe_attention(q, k, v, qt, qb, e16, 0.125)
+    b = ops.rpe_attention(q, k, v, qt, qb, e16.float(), 0.125)
+    assert torch.equal(a.cpu(), b.cpu())
+
+
 def test_pose_hypotheses_vs_oracle(ops):
     B, N, n = 3, 196, 6000
     inp = synth.pem_inputs(B, seed=5, n_pts=N, with_rgb=False)

@@ -804,6 +804,14 @@ __device__ __forceinline__ void win16_pass(const AttnParams &p, const u16 *Kl, c
   float sp[NS][SRC][4], m[NS];
 #pragma unroll
   for (int n = 0; n < NS; ++n) m[n] = -1e29f;                     // finite even if a whole strip is padding
+  f32x4 cb[NS];
+  {
+    const float inv = 1.0f / p.scale_log2;
+#pragma unroll
+    for (int n = 0; n < NS; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cb[n][r] = twr[n][r] * inv;          // masked columns: -1e30 / scale, still finite
+  }
   bf16x8 kf[2][C::KS];
   // compact (LDS-DMA staged) images keep the chunk pairs of rows with (kx >> 2 ^ kx >> 3) & 1 swapped (S6D_GLB_KSWZ above; kx = c here)
   const int gk = KSWZ ? (g ^ kswz(c)) : g;
@@ -825,9 +833,11 @@ __device__ __forceinline__ void win16_pass(const AttnParams &p, const u16 *Kl, c
 #pragma unroll
   for (int ky = 0; ky < SRC; ++ky) {
     if (ky + 1 < SRC) kload(ky + 1, kf[(ky + 1) & 1]);
+    // the column bias rides the matrix core (round 5): the score chain starts from C = tw / scale_log2, so sp holds
+    // (q.k + tw / scale) and the scale is applied inside the exponential's fma below -- one VALU instruction per score less
     f32x4 acc[NS];
 #pragma unroll
-    for (int n = 0; n < NS; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < NS; ++n) acc[n] = cb[n];
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks)
 #pragma unroll
@@ -836,8 +846,8 @@ __device__ __forceinline__ void win16_pass(const AttnParams &p, const u16 *Kl, c
 #pragma unroll
     for (int n = 0; n < NS; ++n) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sp[n][ky][r] = acc[n][r] * p.scale_log2 + twr[n][r];
-      const float mk = fmaxf(fmaxf(sp[n][ky][0], sp[n][ky][1]), fmaxf(sp[n][ky][2], sp[n][ky][3])) + thv[n][ky];
+      for (int r = 0; r < 4; ++r) sp[n][ky][r] = acc[n][r];
+      const float mk = __builtin_fmaf(fmaxf(fmaxf(acc[n][0], acc[n][1]), fmaxf(acc[n][2], acc[n][3])), p.scale_log2, thv[n][ky]);
       m[n] = fmaxf(m[n], mk);
     }
   }
@@ -879,9 +889,9 @@ __device__ __forceinline__ void win16_pass(const AttnParams &p, const u16 *Kl, c
       for (int n = 0; n < NS; ++n)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const float off = m[n] - thv[n][u + h];
+          const float nb = thv[n][u + h] - m[n];                    // m >= -1e29 (its initial value): a padded query's all-masked strip gives 0, not inf
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pb[n].hh[h * 4 + r] = f2bf(fast_exp2(sp[n][u + h][r] - off));
+          for (int r = 0; r < 4; ++r) pb[n].hh[h * 4 + r] = f2bf(fast_exp2(__builtin_fmaf(sp[n][u + h][r], p.scale_log2, nb)));
         }
 #pragma unroll
       for (int n = 0; n < NS; ++n) lacc[n] = S6D_ATTN_MFMA16(ones.v, pb[n].v, lacc[n]);
@@ -1090,32 +1100,73 @@ __global__ __launch_bounds__(512) void attn_window16p_kernel(AttnParams p, int n
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int g = lane >> 4, c = lane & 15;
   const int Cc = p.nh * HD;
-  for (int i = tid; i < 2 * 32 * C::HDP / 8; i += 512) {             // rel tables -> LDS, once
-    const bool w = i >= 32 * C::HDP / 8;
-    const int ii = w ? i - 32 * C::HDP / 8 : i;
-    reinterpret_cast<uint4 *>(w ? relw : relh)[ii] = reinterpret_cast<const uint4 *>(w ? p.rel_w : p.rel_h)[ii];
+  // rel tables -> LDS, once.  A row is HDP / 8 = 12 (8) chunks of 16 bytes, so the 16 rows of a fragment read start on only 4 (2) of
+  // the 16 bank slots: every one of the 12 fragment reads per item was a 4-way conflict -- 2.3 k of a workgroup's ~28 k cycles per
+  // item, and the whole of the kernel's SQ_LDS_BANK_CONFLICT count (14.5 M per launch = 6400 items x 2.3 k, profiles/r04_sq_summary
+  // .json).  There is no LDS left for padded rows (2 x 74 KiB images + 12 KiB tables = 160 KiB), so the chunks of
+  // row r are stored at chunk ^ ((r >> 2) & 3): inside a group of four chunks, 16 rows x one chunk index -> 16 distinct slots.
+  constexpr int RCH = C::HDP / 8;
+  for (int i = tid; i < 2 * 32 * RCH; i += 512) {
+    const bool w = i >= 32 * RCH;
+    const int ii = w ? i - 32 * RCH : i;
+    const int row = ii / RCH, ch = ii - row * RCH;
+    reinterpret_cast<uint4 *>(w ? relw : relh)[row * RCH + (ch ^ ((row >> 2) & 3))] = reinterpret_cast<const uint4 *>(w ? p.rel_w : p.rel_h)[ii];
   }
 
-  // ---- DMA of one image: `which` 1 = K (row KCH chunks, the last one padding), 2 = V
+  // ---- DMA of one image: `which` 1 = K (row KCH chunks, the last one padding), 2 = V.
+  // Which chunk of the image a lane feeds in the wave's i-th DMA instruction -- key row, key column, head-dim part, inside the
+  // S x S window or not -- does not depend on the item: it is computed ONCE per kernel and kept packed in one register per
+  // instruction slot (round 5).  Until then every instruction recomputed it (a division by the row's chunk count, the swizzle, two
+  // 64-bit token products: ~56 instructions per DMA instruction, ~10 per wave and item: a quarter of the wave's instruction
+  // stream).  Per item only the window origin, the image test at the frame's edge and one 64-bit multiply-add remain.
+  constexpr int MAXI = S14 ? 5 : 6;                                  // DMA instructions per wave and image: ceil(14 (16) x 16 x 11 / 64 / 8)
+  unsigned kvc[MAXI];                     // per instruction slot: K in bits 0-12, V in bits 16-28: ky | kx << 4 | part << 8 | inwin << 12
+  {
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+      unsigned both = 0;
+#pragma unroll
+      for (int which = 1; which <= 2; ++which) {
+        const int rowch = which == 1 ? KCH : VCH, nch = which == 1 ? kchunks : vchunks;
+        const int k = wave + i * WAVES;
+        const int j = min((k << 6) + lane, nch - 1);                  // chunk of the image (tail lanes repeat the last chunk's source)
+        const int slot = j / rowch, pp = j - slot * rowch;
+        const int ky = slot >> 4, kx = slot & 15;
+        const int part = (S6D_WIN16_KSWZ && which == 1 && pp * 8 < HD) ? pp ^ kswz(kx) : pp;     // K: chunk pairs swapped on the source side
+        const bool inwin = ky < S && kx < S && part * 8 < HD;
+        const unsigned v = (unsigned)(ky & 15) | ((unsigned)kx << 4) | ((unsigned)part << 8) | ((unsigned)inwin << 12);
+        both |= which == 1 ? v : v << 16;
+      }
+      kvc[i] = both;
+    }
+  }
   auto stage_image = [&](const WinItem &it, int which, char *dst_base) __attribute__((always_inline)) {
-    const int rowch = which == 1 ? KCH : VCH, ninstr = which == 1 ? kinstr : vinstr, nch = which == 1 ? kchunks : vchunks;
-    for (int k = wave; k < ninstr; k += WAVES) {
-      const int j = min((k << 6) + lane, nch - 1);                  // chunk of the image (tail lanes repeat the last chunk's source)
-      const int slot = j / rowch, pp = j - slot * rowch;
-      const int ky = slot >> 4, kx = slot & 15;
-      const int part = (S6D_WIN16_KSWZ && which == 1 && pp * 8 < HD) ? pp ^ kswz(kx) : pp;     // K: chunk pairs swapped on the source side
-      const int y = it.wy * p.ws + ky, x = it.wx * p.ws + kx;
-      const bool inwin = ky < S && kx < S && part * 8 < HD, img = (y < p.H) && (x < p.W);
-      const size_t tokc = (size_t)(it.b * p.H + min(y, p.H - 1)) * p.W + min(x, p.W - 1);
-      const int sel = which * Cc + it.head * HD + min(part * 8, HD - 8);
-      const u16 *src = img ? qkv_at(p, tokc, which, it.head) + min(part * 8, HD - 8) : p.qkv_bias + sel;
-      const void *sp = inwin ? (const void *)src : (const void *)&g_win16_zero;
-      S6D_LDS(char) *dst = (S6D_LDS(char) *)dst_base + (k << 10);
-#if S6D_WIN16_ASM_DMA
-      S6D_ATTN_DMA16(sp, dst);
-#else
-      __builtin_amdgcn_global_load_lds((const S6D_ATTN_GLOBAL(void) *)sp, dst, 16, 0, 0);
+    const int ninstr = which == 1 ? kinstr : vinstr;
+    const int y0 = it.wy * p.ws, x0 = it.wx * p.ws, bH = it.b * p.H;
+    const u16 *base = qkv_at(p, 0, which, it.head);                   // wave-uniform
+    const u16 *bias_base = p.qkv_bias + which * Cc + it.head * HD;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+      const int k = wave + i * WAVES;
+      if (k < ninstr) {                                               // wave-uniform
+        unsigned cc = which == 1 ? kvc[i] : kvc[i] >> 16;
+#ifndef HIPEMU
+        asm volatile("" : "+v"(cc));        // opaque per item: the unpacked fields must not be hoisted out of the item loop (40 registers)
 #endif
+        const int ky = (int)(cc & 15u), kx = (int)((cc >> 4) & 15u), po = min((int)((cc >> 8) & 15u) * 8, HD - 8);
+        const int y = y0 + ky, x = x0 + kx;
+        const bool img = (y < p.H) && (x < p.W);
+        const unsigned tok = (unsigned)(bH + min(y, p.H - 1)) * (unsigned)p.W + (unsigned)min(x, p.W - 1);
+        const u16 *s_img = base + (size_t)tok * (size_t)p.tok_stride + po;
+        const u16 *src = img ? s_img : bias_base + po;
+        const void *sp = (cc >> 12) & 1u ? (const void *)src : (const void *)&g_win16_zero;
+        S6D_LDS(char) *dst = (S6D_LDS(char) *)dst_base + (k << 10);
+#if S6D_WIN16_ASM_DMA
+        S6D_ATTN_DMA16(sp, dst);
+#else
+        __builtin_amdgcn_global_load_lds((const S6D_ATTN_GLOBAL(void) *)sp, dst, 16, 0, 0);
+#endif
+      }
     }
   };
   constexpr int MAXROWS = 2;
@@ -1181,8 +1232,9 @@ __global__ __launch_bounds__(512) void attn_window16p_kernel(AttnParams p, int n
       for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks) {
-          rf.rh[jt][ks].u = *reinterpret_cast<const uint4 *>(relh + (jt * 16 + c) * C::HDP + ks * 32 + g * 8);
-          rf.rw[jt][ks].u = *reinterpret_cast<const uint4 *>(relw + (jt * 16 + c) * C::HDP + ks * 32 + g * 8);
+          const int ro = (jt * 16 + c) * C::HDP + ((ks * 4 + g) ^ (((jt * 16 + c) >> 2) & 3)) * 8;     // chunk swizzle of the copy above
+          rf.rh[jt][ks].u = *reinterpret_cast<const uint4 *>(relh + ro);
+          rf.rw[jt][ks].u = *reinterpret_cast<const uint4 *>(relw + ro);
         }
       float *tab = reinterpret_cast<float *>(nb + kbytes) + (size_t)wave * 16 * W16_LT;
       if (S == 14)

@@ -57,6 +57,46 @@ class StandInPipeline:
         return out
 
 
+def real_pipeline(dev):
+    """The five released-size models on seeded weights + a loader of synthetic frames whose proposal count P and instance count K
+    vary from frame to frame (frame_shape) -> (pipe, load_frame)."""
+    import collections
+
+    from sam6d_amd.utils import synth
+    from tools import frame_demo
+    counts = collections.deque()          # one P per frame, consumed by the proposal stage in frame order
+    pipe, (img0, depth0, K0, _, _) = frame_demo.build(dev, top_k="keys", sync_stages=False, proposal_counts=counts)
+
+    def load(s, i):
+        P, K = frame_shape(s, i)
+        g = torch.Generator().manual_seed(s * 7919 + i)
+        img = (img0.int() + torch.randint(-8, 9, img0.shape, generator=g).to(dev)).clamp(0, 255).to(torch.uint8)
+        counts.append(P)
+        return (img, depth0, K0, torch.rand(K, 480 * 640, generator=g).to(dev), synth.coarse_uniforms(K, s * 1000 + i).to(dev))
+    return pipe, load
+
+
+def measure_world1(dev, frames=24, group=8):
+    """BASELINE configs[2]'s program on ONE rank with the warm-up separated (the round-4 number, 86 ms busy per
+    frame over 16 frames, included the first group's allocator growth, library autotuning and graph captures): one untimed group of
+    other frames, then `frames` frames in groups of `group`.  -> dict for bench.py's `sharded_world1` block."""
+    pipe, load = real_pipeline(dev)
+    warm = [(9, 1 + i) for i in range(group)]
+    pipe.run_group([load(s, i) for (s, i) in warm])
+    torch.cuda.synchronize()
+    ids = frame_list(frames)
+    t0 = time.perf_counter()
+    res = shard.run_sharded(ids, load, pipe, group_size=group, dataset_name="ycbv", device=dev, fixed_time=0.0)
+    wall = time.perf_counter() - t0
+    busy = float(res["stats"][0, 0])
+    shapes = [frame_shape(s, i) for (s, i) in ids]
+    return {"workload": f"{frames} synthetic 480x640 frames, proposals per frame {min(p for p, _ in shapes)}..{max(p for p, _ in shapes)} "
+                        f"(mean {sum(p for p, _ in shapes) / frames:.0f}), instances per frame {min(k for _, k in shapes)}..{max(k for _, k in shapes)} "
+                        f"(mean {sum(k for _, k in shapes) / frames:.1f}), groups of {group}, one warm-up group untimed",
+            "frames_per_s": round(frames / busy, 2), "busy_ms_per_frame": round(busy / frames * 1e3, 2),
+            "frames_per_s_incl_frame_synthesis": round(frames / wall, 2), "poses": int(res["records"].shape[0])}
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=64)
@@ -88,18 +128,9 @@ def main(argv=None):
             return (torch.randint(0, 256, (8, 8, 3), generator=g, dtype=torch.uint8), torch.rand(8, 8, generator=g),
                     torch.eye(3, dtype=torch.float64), torch.rand(K, 64, generator=g), torch.rand(K, 18000, generator=g))
     else:
-        from tools import frame_demo
-        from sam6d_amd.utils import synth
-        import collections
-        counts = collections.deque()          # one P per frame, consumed by the proposal stage in frame order
-        pipe, (img0, depth0, K0, _, _) = frame_demo.build(dev, top_k="keys", sync_stages=False, proposal_counts=counts)
-
-        def load(s, i):
-            P, K = frame_shape(s, i)
-            g = torch.Generator().manual_seed(s * 7919 + i)
-            img = (img0.int() + torch.randint(-8, 9, img0.shape, generator=g).to(dev)).clamp(0, 255).to(torch.uint8)
-            counts.append(P)
-            return (img, depth0, K0, torch.rand(K, 480 * 640, generator=g).to(dev), synth.coarse_uniforms(K, s * 1000 + i).to(dev))
+        pipe, load = real_pipeline(dev)
+        pipe.run_group([load(9, 1 + i) for i in range(a.group)])          # warm-up group: allocator, library autotuning, graph captures
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     res = shard.run_sharded(ids, load, pipe, group_size=a.group, dataset_name=a.dataset, device=dev, fixed_time=a.fixed_time)
     if world > 1:
@@ -110,9 +141,11 @@ def main(argv=None):
             os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
             with open(a.out, "w+") as f:
                 f.writelines(res["csv_lines"])
+        busy = [float(x) for x in res["stats"][:, 0]]
         print(json.dumps(dict(tool="run_sharded", world=world, frames=a.frames, group=a.group, poses=int(res["records"].shape[0]),
-                              frames_per_s=a.frames / wall, wall_s=wall, balance_efficiency=res["balance_efficiency"],
-                              per_rank_busy_s=[round(float(x), 4) for x in res["stats"][:, 0]],
+                              frames_per_s=a.frames / wall, wall_s=wall, frames_per_s_busy=a.frames / max(busy) if max(busy) > 0 else None,
+                              balance_efficiency=res["balance_efficiency"],
+                              per_rank_busy_s=[round(x, 4) for x in busy],
                               per_rank_frames=[int(x) for x in res["stats"][:, 1]],
                               per_rank_instances=[int(x) for x in res["stats"][:, 2]], stand_in=bool(a.stand_in),
                               scaling="unmeasured on hardware" if a.stand_in or world == 1 else "measured")))

@@ -214,6 +214,31 @@ __global__ __launch_bounds__(256) void layernorm_fp8_kernel(const u16 *__restric
 // [group][2][M].  Combined group by group in index order with the exact pairwise update (Chan et al.): no cancellation, fixed order.
 // Latency, not bandwidth, is what this pass costs (20 MB): a thread's 2 x groups loads are issued eight groups at a time ahead of the
 // (sequential) combination, 64-thread workgroups spread the rows over all CUs.
+// Round 5: ALL partials of a row are requested before the first combination (the 40-group case of the ViT-H stream in one template
+// instantiation: 80 registers); in groups of eight the pass was five dependent L2 round trips = 12.4 us per launch, 126 launches per step.
+template <int GROUPS>
+__global__ __launch_bounds__(64) void ln_stats_finalize_fixed_kernel(const float *__restrict__ sp, int gsz, long M, float eps,
+                                                                    float *__restrict__ out) {
+  const long row = (long)blockIdx.x * 64 + threadIdx.x;
+  if (row >= M) return;
+  float s[GROUPS], q[GROUPS];
+#pragma unroll
+  for (int g = 0; g < GROUPS; ++g) {
+    s[g] = sp[(size_t)(2 * g) * M + row];
+    q[g] = sp[(size_t)(2 * g + 1) * M + row];
+  }
+  const float nb = (float)gsz;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int g = 0; g < GROUPS; ++g) {                    // the same pairwise update in the same order as the generic kernel below
+    const float d = s[g] / nb - mean, nn = n + nb;
+    mean += d * (nb / nn);
+    m2 += q[g] + d * d * (n * nb / nn);
+    n = nn;
+  }
+  *reinterpret_cast<float2 *>(out + row * 2) = make_float2(mean, sqrtf(m2 / n + eps));
+}
+
 __global__ __launch_bounds__(64) void ln_stats_finalize_kernel(const float *__restrict__ sp, int groups, int gsz, long M, float eps,
                                                               float *__restrict__ out) {
   const long row = (long)blockIdx.x * 64 + threadIdx.x;
@@ -290,8 +315,13 @@ extern "C" int s6d_ln_stats_finalize(const float *stats_partial, int groups, int
   if (M < 0 || groups <= 0 || group_size <= 0) return S6D_EINVAL;
   if (M == 0) return S6D_OK;
   if (!stats_partial || !row_stats || ((uintptr_t)row_stats & 7)) return S6D_EINVAL;
-  hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, as_stream(stream), stats_partial,
-                     groups, group_size, M, eps, row_stats);
+  const dim3 grid((unsigned)((M + 63) / 64));
+  if (groups == 40)                      // ViT-H (1280 channels): every partial in flight at once
+    hipLaunchKernelGGL(ln_stats_finalize_fixed_kernel<40>, grid, dim3(64), 0, as_stream(stream), stats_partial, group_size, M, eps, row_stats);
+  else if (groups == 32)                 // DINOv2 ViT-L (1024 channels)
+    hipLaunchKernelGGL(ln_stats_finalize_fixed_kernel<32>, grid, dim3(64), 0, as_stream(stream), stats_partial, group_size, M, eps, row_stats);
+  else
+    hipLaunchKernelGGL(ln_stats_finalize_kernel, grid, dim3(64), 0, as_stream(stream), stats_partial, groups, group_size, M, eps, row_stats);
   return launch_status();
 }
 

@@ -122,6 +122,7 @@ def _run_res():
     T.test_residual_gemm_sums_in_the_accumulators(300, 256, 64, True)
     T.test_residual_gemm_row_statistics(700, 768, 192)
     T.test_lnfold_gemm_vs_layernorm_then_linear(700, 768, 192, False, 0)
+    T.test_residual_gemm_row_statistics(260, 1280, 64)      # 40 column groups: the all-loads-first finalize kernel (round 5)
     T.test_lnfold_gemm_vs_layernorm_then_linear(300, 256, 320, True, 0)
     T.test_lnfold_gemm_vs_layernorm_then_linear(520, 768, 256, False, 64)
     T.test_lnfold_gemm_with_offset_rows(300, 256, 320)

@@ -150,7 +150,7 @@ def test_residual_gemm_sums_in_the_accumulators(M, N, K, inplace):
     _check(got, ref, "residual sum")
 
 
-@pytest.mark.parametrize("M,N,K", [(700, 768, 192), (300, 256, 64), (65536, 1280, 1280)])
+@pytest.mark.parametrize("M,N,K", [(700, 768, 192), (300, 256, 64), (260, 1280, 64), (300, 1024, 128), (65536, 1280, 1280)])
 def test_residual_gemm_row_statistics(M, N, K):
     """The partial LayerNorm statistics the residual GEMM emits, combined by s6d_ln_stats_finalize, are the mean / sigma = sqrt(var + eps) of the fp32
     result rows (float64 reference), and s6d_row_stats_bf16 of the stored bf16 rows agrees with them to the bf16 rounding."""

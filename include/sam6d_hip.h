@@ -30,7 +30,7 @@ extern "C" {
 
 /* Bumped whenever a signature in this header changes; the loader (sam6d_amd/_lib.py) refuses a library whose
  * s6d_version() differs from the header it was written against (a stale .so fails at load, not at a call). */
-#define S6D_ABI_VERSION 122
+#define S6D_ABI_VERSION 123
 int s6d_version(void);
 /* Upper bound on the workgroups of the persistent kernels (the 14 x 14 window attention walks its (window, head) items with one
  * workgroup per CU); 0 = one per CU of the device.  Process-wide.  Replaces the environment lookups the launch path made until
@@ -382,6 +382,11 @@ int s6d_geo_embedding_f32(const float *idx4, long NP, const float *Wd, const flo
  * core, which streams it twelve times per forward; read with the _e16 entry points below. */
 int s6d_geo_embedding_f16(const float *idx4, long NP, const float *Wd, const float *bd, const float *Wa,
                           const float *ba, const float *div_term, int C, int K, void *out_f16, void *stream);
+/* The same with the two weight matrices PRE-SPLIT into their bf16 hi / lo parts: Wd_hilo, Wa_hilo = [hi (C,C) | lo (C,C)] bf16 as
+ * s6d_linear_split_weight_f32 makes them (once per weight version; 16-byte aligned) -- the in-kernel split of the other two entry
+ * points is half of their vector instructions.  out: (NP,C) f32, or f16 when out_f16 != 0.  Same values bit for bit. */
+int s6d_geo_embedding_split(const float *idx4, long NP, const void *Wd_hilo, const float *bd, const void *Wa_hilo,
+                            const float *ba, const float *div_term, int C, int K, void *out, int out_f16, void *stream);
 
 /* Fused fp32 Linear of the point transformer:  y = LN( res + act( x W^T + b ) )  with every stage optional.
  * x (M,K) f32 row stride ldx; W given as its bf16 hi / lo parts (N,K) each, made once per weight version by

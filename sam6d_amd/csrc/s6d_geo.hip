@@ -64,7 +64,10 @@ constexpr int GEO_LDS_ELEMS = OFF_AL + 4 * GEO_PAIRS * GEO_ROW;    // 61440 elem
 
 // HALF: the embedding is written in IEEE half (2 bytes per channel) instead of float32 -- its only reader, rpe_attention_kernel, is
 // bound by streaming it (12 reads of 1.4 GB per 32 instances); the arithmetic up to the store is the same.
-template <bool HALF>
+// PRE (round 5): the weights arrive as their bf16 hi / lo parts (s6d_linear_split_weight_f32, made once per weight version by the
+// caller) -- Wd / Wa then point at [hi (C x C) | lo (C x C)] bf16.  Until then EVERY workgroup split the same two 256 x 256 fp32
+// matrices again in every k-step: ~200 of a thread's ~400 vector instructions per k-step beside 96 matrix instructions per wave.
+template <bool HALF, bool PRE>
 __global__ __launch_bounds__(GEO_THREADS) void geo_embed_kernel(const float *__restrict__ idx4, long NP,
                                                                const float *__restrict__ Wd, const float *__restrict__ bd,
                                                                const float *__restrict__ Wa, const float *__restrict__ ba,
@@ -90,8 +93,22 @@ __global__ __launch_bounds__(GEO_THREADS) void geo_embed_kernel(const float *__r
     const long pr = min(pair0 + item_p[n], NP - 1);
     xval[n] = idx4[pr * 4 + item_e[n]];
   }
-  float4 wreg[8];                                                  // prefetched weight slice (4 of W_d, 4 of W_a)
+  float4 wreg[8];                                                  // prefetched weight slice (4 of W_d, 4 of W_a); PRE: 8 x 16 bytes of bf16
   auto wload = [&](int ks) {
+    if (PRE) {
+      // part q = 0..3 (W_d hi, W_d lo, W_a hi, W_a lo): 256 rows x 4 chunks of 8 bf16 per k-step = 1024 chunks, two per thread
+      const u16 *parts[4] = {reinterpret_cast<const u16 *>(Wd), reinterpret_cast<const u16 *>(Wd) + GEO_C * GEO_C,
+                             reinterpret_cast<const u16 *>(Wa), reinterpret_cast<const u16 *>(Wa) + GEO_C * GEO_C};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const int it = tid + n * GEO_THREADS;                    // 0..1023: row = it / 4, chunk = it % 4
+          const uint4 v = *reinterpret_cast<const uint4 *>(parts[q] + (size_t)(it >> 2) * GEO_C + ks * 32 + (it & 3) * 8);
+          wreg[q * 2 + n] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
+      return;
+    }
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
       const int it = tid + n * GEO_THREADS;                        // 0..2047: row = it/8, float4 col = it%8
@@ -101,6 +118,20 @@ __global__ __launch_bounds__(GEO_THREADS) void geo_embed_kernel(const float *__r
     }
   };
   auto wstore = [&]() {
+    if (PRE) {
+      const int offs[4] = {OFF_WDH, OFF_WDL, OFF_WAH, OFF_WAL};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const int it = tid + n * GEO_THREADS;
+          const int row = it >> 2, ch = it & 3;
+          const float4 f = wreg[q * 2 + n];
+          *reinterpret_cast<uint4 *>(lds + offs[q] + row * GEO_ROW + ((ch ^ geo_swz(row)) * 8)) =
+              make_uint4(__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), __float_as_uint(f.w));
+        }
+      return;
+    }
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
       const int it = tid + n * GEO_THREADS;
@@ -199,30 +230,44 @@ __global__ __launch_bounds__(GEO_THREADS) void geo_embed_kernel(const float *__r
 
 using namespace s6d;
 
-static int geo_launch(const float *idx4, long NP, const float *Wd, const float *bd, const float *Wa, const float *ba,
-                      const float *div_term, int C, int K, void *out, bool half, void *stream) {
+template <bool HALF, bool PRE>
+static void geo_launch_t(const float *idx4, long NP, const float *Wd, const float *bd, const float *Wa, const float *ba,
+                         const float *div_term, void *out, void *stream) {
+  const size_t lds = (size_t)GEO_LDS_ELEMS * 2;
+  const unsigned grid = (unsigned)((NP + GEO_PAIRS - 1) / GEO_PAIRS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&geo_embed_kernel<HALF, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((geo_embed_kernel<HALF, PRE>), dim3(grid), dim3(GEO_THREADS), lds, as_stream(stream), idx4, NP, Wd, bd, Wa, ba, div_term, out);
+}
+
+static int geo_launch(const float *idx4, long NP, const void *Wd, const float *bd, const void *Wa, const float *ba,
+                      const float *div_term, int C, int K, void *out, bool half, bool pre, void *stream) {
   if (NP < 0) return S6D_EINVAL;
   if (C != GEO_C || K != 3) return S6D_EUNSUPPORTED;      // released model: hidden_dim 256, angle_k 3
   if (NP == 0) return S6D_OK;
   if (!idx4 || !Wd || !bd || !Wa || !ba || !div_term || !out) return S6D_EINVAL;
-  const size_t lds = (size_t)GEO_LDS_ELEMS * 2;
-  const unsigned grid = (unsigned)((NP + GEO_PAIRS - 1) / GEO_PAIRS);
+  if (pre && (((uintptr_t)Wd | (uintptr_t)Wa) & 15)) return S6D_EINVAL;
+  const float *wd = reinterpret_cast<const float *>(Wd), *wa = reinterpret_cast<const float *>(Wa);
   if (half) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&geo_embed_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(geo_embed_kernel<true>, dim3(grid), dim3(GEO_THREADS), lds, as_stream(stream), idx4, NP, Wd, bd, Wa, ba, div_term, out);
+    if (pre) geo_launch_t<true, true>(idx4, NP, wd, bd, wa, ba, div_term, out, stream);
+    else geo_launch_t<true, false>(idx4, NP, wd, bd, wa, ba, div_term, out, stream);
   } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&geo_embed_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(geo_embed_kernel<false>, dim3(grid), dim3(GEO_THREADS), lds, as_stream(stream), idx4, NP, Wd, bd, Wa, ba, div_term, out);
+    if (pre) geo_launch_t<false, true>(idx4, NP, wd, bd, wa, ba, div_term, out, stream);
+    else geo_launch_t<false, false>(idx4, NP, wd, bd, wa, ba, div_term, out, stream);
   }
   return launch_status();
 }
 
 extern "C" int s6d_geo_embedding_f32(const float *idx4, long NP, const float *Wd, const float *bd, const float *Wa,
                                      const float *ba, const float *div_term, int C, int K, float *out, void *stream) {
-  return geo_launch(idx4, NP, Wd, bd, Wa, ba, div_term, C, K, out, false, stream);
+  return geo_launch(idx4, NP, Wd, bd, Wa, ba, div_term, C, K, out, false, false, stream);
 }
 
 extern "C" int s6d_geo_embedding_f16(const float *idx4, long NP, const float *Wd, const float *bd, const float *Wa,
                                      const float *ba, const float *div_term, int C, int K, void *out_f16, void *stream) {
-  return geo_launch(idx4, NP, Wd, bd, Wa, ba, div_term, C, K, out_f16, true, stream);
+  return geo_launch(idx4, NP, Wd, bd, Wa, ba, div_term, C, K, out_f16, true, false, stream);
+}
+
+extern "C" int s6d_geo_embedding_split(const float *idx4, long NP, const void *Wd_hilo, const float *bd, const void *Wa_hilo,
+                                       const float *ba, const float *div_term, int C, int K, void *out, int out_f16, void *stream) {
+  return geo_launch(idx4, NP, Wd_hilo, bd, Wa_hilo, ba, div_term, C, K, out, out_f16 != 0, true, stream);
 }

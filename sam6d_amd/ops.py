@@ -939,15 +939,22 @@ def add_layernorm(x, delta, gamma, beta, eps):
     return xo, y
 
 
-def geo_embedding(idx4, Wd, bd, Wa, ba, div_term, out_dtype=torch.float32):
+def geo_embedding(idx4, Wd, bd, Wa, ba, div_term, out_dtype=torch.float32, split=None):
     """idx4 (...,4) f32 [d_idx, a_idx x3] -> (...,256) geometric structure embedding, stored in f32 or (out_dtype=torch.float16) in
-    IEEE half for the RPE attention core to stream."""
+    IEEE half for the RPE attention core to stream.  split = (Wd_hilo, Wa_hilo): the weights already split into bf16 hi / lo parts,
+    each a (2, 256, 256) bf16 tensor [hi | lo] (the caller caches them per weight version): same bits, half the kernel's vector work."""
     for a, nm in ((idx4, "idx4"), (Wd, "Wd"), (bd, "bd"), (Wa, "Wa"), (ba, "ba"), (div_term, "div_term")):
         _chk(a, torch.float32, nm)
     if out_dtype not in (torch.float32, torch.float16):
         raise RuntimeError("the embedding is stored in float32 or float16")
     NP = idx4.numel() // 4
     out = torch.empty(*idx4.shape[:-1], Wd.shape[0], dtype=out_dtype, device=idx4.device)
+    if split is not None and have("geo_embedding_split"):
+        for a, nm in ((split[0], "Wd_hilo"), (split[1], "Wa_hilo")):
+            _chk(a, torch.bfloat16, nm, 3)
+        _call("s6d_geo_embedding_split", _ptr(idx4), ctypes.c_long(NP), _ptr(split[0]), _ptr(bd), _ptr(split[1]), _ptr(ba), _ptr(div_term),
+              int(Wd.shape[0]), int(idx4.shape[-1] - 1), _ptr(out), 1 if out_dtype == torch.float16 else 0, _stream())
+        return out
     _call("s6d_geo_embedding_f32" if out_dtype == torch.float32 else "s6d_geo_embedding_f16", _ptr(idx4), ctypes.c_long(NP), _ptr(Wd),
           _ptr(bd), _ptr(Wa), _ptr(ba), _ptr(div_term), int(Wd.shape[0]), int(idx4.shape[-1] - 1), _ptr(out), _stream())
     return out
@@ -1160,7 +1167,7 @@ _FUSED = {}
 
 def have(name):
     if name not in _FUSED:
-        sym = {"rpe_attention": "s6d_rpe_attention_f32", "rpe_attention_packed": "s6d_rpe_attention_packed_f32", "geo_embedding": "s6d_geo_embedding_f32", "geo_embedding_f16": "s6d_geo_embedding_f16",
+        sym = {"rpe_attention": "s6d_rpe_attention_f32", "rpe_attention_packed": "s6d_rpe_attention_packed_f32", "geo_embedding": "s6d_geo_embedding_f32", "geo_embedding_f16": "s6d_geo_embedding_f16", "geo_embedding_split": "s6d_geo_embedding_split",
                "fine_assign": "s6d_fine_assign_f32", "fine_match": "s6d_fine_match_f32", "pem_pre": "s6d_pem_compact_cloud_f32", "coarse_sample": "s6d_coarse_sample_f32", "upsample_gather": "s6d_upsample_gather_f32",
                "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "weighted_procrustes": "s6d_weighted_procrustes_f32", "add_layernorm": "s6d_add_layernorm_bf16", "gemm_bf16": "s6d_gemm_bf16", "gemm_bf16_res": "s6d_gemm_bf16_res", "gemm_bf16_lnfold": "s6d_gemm_bf16_lnfold", "gemm_f16": "s6d_gemm_f16", "gemm_fp8": "s6d_gemm_fp8", "layernorm_fp8": "s6d_layernorm_fp8", "layernorm_f32out": "s6d_layernorm_bf16_f32", "linear_f32": "s6d_linear_f32", "win_attention": "s6d_win_attention_layout_bf16",
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",

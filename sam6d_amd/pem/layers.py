@@ -354,6 +354,21 @@ class GeometricStructureEmbedding(nn.Module):
         if self.reduction_a != "max":
             raise ValueError("MI355X build implements reduction_a == 'max' (config/base.yaml:30)")
 
+    def _split_weights(self):
+        """(W_d, W_a) as [hi | lo] bf16 parts for s6d_geo_embedding_split, cached until a weight changes (round 5: every workgroup
+        of the kernel used to split both matrices again in each of its eight k-steps)."""
+        if not (ops.have("geo_embedding_split") and os.environ.get("S6D_GEO_PRESPLIT", "1") == "1"):
+            return None
+        ws = (self.proj_d.weight, self.proj_a.weight)
+        key = tuple((w._version, w.data_ptr(), w.dtype) for w in ws)
+        c = self.__dict__.get("_s6d_geo_split")
+        if c is None or c[0] != key:
+            with torch.no_grad():
+                parts = tuple(torch.stack(ops.split_weight(w.detach().float().contiguous())).contiguous() for w in ws)
+            c = (key, parts)
+            self.__dict__["_s6d_geo_split"] = c
+        return c[1]
+
     @torch.no_grad()
     def get_embedding_indices(self, points):
         B, N, _ = points.shape
@@ -379,7 +394,7 @@ class GeometricStructureEmbedding(nn.Module):
             half = os.environ.get("S6D_PEM_GEO_DTYPE", _GEO_DTYPE_DEFAULT) == "fp16" and ops.have("geo_embedding_f16")
             return ops.geo_embedding(idx4, self.proj_d.weight.contiguous(), self.proj_d.bias, self.proj_a.weight.contiguous(),
                                      self.proj_a.bias, self.embedding.div_term.contiguous(),
-                                     out_dtype=torch.float16 if half else torch.float32)
+                                     out_dtype=torch.float16 if half else torch.float32, split=self._split_weights())
         outs = []
         for p in points.split(4, dim=0):     # bound the (b,N,N,k,256) intermediate of the library path
             d_idx, a_idx = self.get_embedding_indices(p)

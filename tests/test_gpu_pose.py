@@ -68,6 +68,11 @@ def test_half_stored_geo_embedding_and_its_reader(ops):
     e32 = ops.geo_embedding(*args)
     e16 = ops.geo_embedding(*args, out_dtype=torch.float16)
     assert e16.dtype == torch.float16 and torch.equal(e16.cpu(), e32.cpu().half())
+    # pre-split weights (what the module passes since round 5): the same bits as the in-kernel split, in both storage types
+    split = geo._split_weights()
+    assert split is not None and split[0].shape == (2, 256, 256) and split[0].dtype == torch.bfloat16
+    assert torch.equal(ops.geo_embedding(*args, split=split).cpu(), e32.cpu())
+    assert torch.equal(ops.geo_embedding(*args, out_dtype=torch.float16, split=split).cpu(), e16.cpu())
     g = torch.Generator().manual_seed(2)
     B, N = pts.shape[:2]
     q, k, v = (torch.randn(B, N, 256, generator=g).cuda() for _ in range(3))

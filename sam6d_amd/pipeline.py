@@ -55,6 +55,10 @@ class FramePipeline:
         self.sync_stages = sync_stages
         self.graph_max = int(os.environ.get("S6D_PEM_GRAPH_MAX", "16"))      # instance counts up to this one replay a captured graph
         self._pem_graphs = {}
+        # a captured graph bakes the weights' addresses and derived buffers in: the fingerprint in _pem_graph_key sees version bumps and
+        # re-allocations, a load_state_dict is caught here (in-place `.data` edits bump no version: call invalidate_graphs())
+        if hasattr(self.pem, "register_load_state_dict_post_hook"):
+            self.pem.register_load_state_dict_post_hook(lambda module, incompatible: self.invalidate_graphs())
 
     def score_metres(self, cls, patch, masks, boxes, depth_m, K):
         """The unit boundary between the two halves of the frame: this class takes depth in METRES (what the PEM

@@ -371,9 +371,12 @@ class MaskDecoder(nn.Module):
         tr = self.transformer
         L1, fin = tr.layers[1], tr.final_attn_token_to_image
         ct1, ln, _, ct2, _ = self.output_upscaling
-        srcs = [L1.cross_attn_token_to_image.k_proj.weight, L1.cross_attn_token_to_image.v_proj.weight,
-                L1.cross_attn_image_to_token.q_proj.weight, fin.k_proj.weight, fin.v_proj.weight, ct1.weight, ct2.weight,
-                ln.weight, pe]
+        ca_, ci_ = L1.cross_attn_token_to_image, L1.cross_attn_image_to_token
+        srcs = [ca_.k_proj.weight, ca_.v_proj.weight, ci_.q_proj.weight, fin.k_proj.weight, fin.v_proj.weight, ct1.weight, ct2.weight,
+                ln.weight, pe,
+                # every bias the cached operands are made of as well (b_q1 / b_u / b_kvq / b_kvu / b2 / ln_b went stale when
+                # only a bias was updated)
+                ca_.k_proj.bias, ca_.v_proj.bias, ci_.q_proj.bias, fin.k_proj.bias, fin.v_proj.bias, ct1.bias, ct2.bias, ln.bias]
         key = tuple((t._version, t.data_ptr()) for t in srcs)
         c = getattr(self, "_s6d_prep", None)
         if c is None or c[0] != key:

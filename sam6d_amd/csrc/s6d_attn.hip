@@ -124,10 +124,13 @@ constexpr int kAbl = S6D_ATTN_ABLATE;
 #ifndef S6D_WIN16_QDEFER
 #define S6D_WIN16_QDEFER 1           // the next item's Q fragments are loaded half way through the PV pass and MASKED at the start of the
 #endif                               // next item (1) instead of right behind the loads (0: a full fetch latency inside the PV pass)
+#ifndef S6D_WIN16_STREAM
+#define S6D_WIN16_STREAM 1           // 14 x 14 windows: one streaming pass without the exact maximum (win16_pass_stream), exact pass as the fallback
+#endif
 #ifndef S6D_WIN16_KSWZ
-#define S6D_WIN16_KSWZ 0             // the same chunk swizzle on the persistent window kernel's compact K image (11-chunk rows): measured
-                                     // 0.265 ms against 0.260 ms without it (16 frames, one process) -- that kernel waits on its fetches,
-                                     // and the swizzled source addresses split each token's 160-byte run into swapped 16-byte pieces
+#define S6D_WIN16_KSWZ 1             // the same chunk swizzle on the persistent window kernel's compact K image (11-chunk rows).  Round 2 measured
+                                     // it at 0.265 against 0.260 ms (the swizzled source computed per DMA instruction); since round 5 the per-lane
+                                     // chunk map is made once per kernel and the swizzle is free: 0.2403 -> 0.2372 ms (profiles/r05_attn_window_stream.txt)
 #endif
 #ifndef S6D_GLB_WAVES
 #define S6D_GLB_WAVES 4
@@ -920,6 +923,158 @@ __device__ __forceinline__ void win16_pass(const AttnParams &p, const u16 *Kl, c
   }
 }
 
+// ---- round 5: the window pass as ONE stream, without the exact maximum -----------------------------------------------------
+// win16_pass is exact two-pass softmax: all SRC x 4 scores of a strip stay in registers (112 for two strips of a 14 x 14 window)
+// while the strip maximum is found, then the exponentials and P V run.  The maximum costs 1.25 vector instructions per score, the
+// scale + bias another one, and the 112 registers put the kernel at the 256-VGPR limit.  As in process_tile_nomax (global
+// attention): P only has to stay representable, bf16 has float32's exponent range, the accumulators are float32.  Here the reference
+// value m is the maximum over the FIRST TWO key rows (32 of the 196 keys), known before the first exponential; every 32-key step then
+// is score instructions -> exp2(fma(acc, scale_log2, th - m)) -> P V, nothing kept but the accumulators: 2.5 vector instructions
+// per score instead of 4.75, no score array (182 VGPRs instead of 236).
+// Safety net: a valid row whose sum is not < 2^100 (inf / NaN included) had scores more than ~92 log2 units above its reference; the
+// WAVE then repeats the pass with that row's m raised by 96 (the sum drops by 2^96: any m within ~100 of the true maximum is as good
+// as the maximum) until no row is out of range -- K / V stay resident in LDS for the whole item, so the retry is local to the wave,
+// it is the same code (no second pass inlined: an exact-pass fallback pushed the kernel into scratch), and it terminates: scores
+// of bf16 operands are finite, 40 rounds cover 3840 log2 units; NaN inputs give NaN outputs as they do in the exact pass.
+// The column bias rides the matrix core (C = tw / scale_log2), masked columns carry -1e30 / scale there, a padded query's all-masked
+// strip is clamped at m >= -1e29 so that its (discarded) P is 0, not inf.
+// `next_q` is called once the last score instructions of the (first) round are issued: the caller loads the NEXT item's Q fragments
+// into the registers of `qf`; `this_q` reloads THIS item's (before a retry round); after a retry `next_q` is called again at the end.
+template <int HD, int SRC, int KROWT, bool KSWZ, class NEXTQ, class THISQ>
+__device__ __forceinline__ void win16_pass_stream(const AttnParams &p, const u16 *Kl, const u16 *Vl, int S, int b, int wy, int wx,
+                                                  int head, int qy0, int rstride, const bf16x8 (&qf)[2][Cfg<HD>::KS],
+                                                  const float (*twr)[4], const float (*thv)[16], int lane, NEXTQ next_q, THISQ this_q) {
+  using C = Cfg<HD>;
+  constexpr int NS = 2;
+  static_assert(SRC % 2 == 0 && SRC >= 4, "whole 32-key steps");
+  const int g = lane >> 4, c = lane & 15;
+  const int Cc = p.nh * HD;
+  const int gk = KSWZ ? (g ^ kswz(c)) : g;
+  f32x4 cb[NS];
+  {
+    const float inv = 1.0f / p.scale_log2;
+#pragma unroll
+    for (int n = 0; n < NS; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cb[n][r] = twr[n][r] * inv;
+  }
+  bf16x8 kf[2][C::KS];
+  auto kload = [&](int ky, bf16x8 (&dst)[C::KS]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      dst[ks] = *reinterpret_cast<const bf16x8 *>(Kl + (ky * 16 + c) * KROWT + ks * 32 + gk * 8);
+      if (KROWT < C::HDP && ks * 32 + 32 > HD && ks * 32 + g * 8 >= HD) {      // compact rows: the k range past HD reads into the next row
+        union { bf16x8 v; uint4 u; } z;
+        z.u = make_uint4(0, 0, 0, 0);
+        dst[ks] = z.v;
+      }
+    }
+  };
+  auto scores = [&](const bf16x8 (&k)[C::KS], f32x4 (&acc)[NS]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int n = 0; n < NS; ++n) acc[n] = cb[n];
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks)
+#pragma unroll
+      for (int n = 0; n < NS; ++n) acc[n] = S6D_ATTN_MFMA16(k[ks], qf[n][ks], acc[n]);
+  };
+  f32x4 s0[NS], s1[NS];
+  kload(0, kf[0]);
+  kload(1, kf[1]);
+  scores(kf[0], s0);
+  scores(kf[1], s1);
+  float m[NS];
+#pragma unroll
+  for (int n = 0; n < NS; ++n) {
+    const float m0 = __builtin_fmaf(fmaxf(fmaxf(s0[n][0], s0[n][1]), fmaxf(s0[n][2], s0[n][3])), p.scale_log2, thv[n][0]);
+    const float m1 = __builtin_fmaf(fmaxf(fmaxf(s1[n][0], s1[n][1]), fmaxf(s1[n][2], s1[n][3])), p.scale_log2, thv[n][1]);
+    float v = fmaxf(fmaxf(m0, m1), -1e29f);
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
+    m[n] = v;
+  }
+  union { bf16x8 v; u16 hh[8]; } ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones.hh[i] = S6D_ATTN_ONE;
+  f32x4 oacc[NS][C::DT], lacc[NS];
+  int round = 0;                                                      // wave-uniform
+  for (;;) {
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+      lacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) oacc[n][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < SRC; u += 2) {
+      if (u > 0 || round > 0) {                                       // (round 0 enters with the first two rows' scores in s0 / s1)
+        kload(u, kf[0]);
+        kload(u + 1, kf[1]);
+        scores(kf[0], s0);
+        scores(kf[1], s1);
+      }
+      if (u == SRC - 2 && round == 0) {
+        // the last score instructions are issued: the Q fragments are dead and the next item's go straight into their registers; the
+        // last step's exponentials and P V, the end-of-item wait and the barrier cover the fetch
+        __builtin_amdgcn_sched_barrier(0);
+        next_q();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      union { bf16x8 v; s16x4 q[2]; } va[C::DT];
+      const u16 *vrow = Vl + (u * 16 + g * 4 + (c >> 2)) * C::VROW + (c & 3) * 4;
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) {
+        va[dt].q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + dt * 16));
+        va[dt].q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((S6D_LDS(s16x4) *)(vrow + 16 * C::VROW + dt * 16));
+      }
+      union { bf16x8 v; u16 hh[8]; } pb[NS];
+#pragma unroll
+      for (int n = 0; n < NS; ++n) {
+        const float nb0 = thv[n][u] - m[n], nb1 = thv[n][u + 1] - m[n];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pb[n].hh[r] = f2bf(fast_exp2(__builtin_fmaf(s0[n][r], p.scale_log2, nb0)));
+          pb[n].hh[4 + r] = f2bf(fast_exp2(__builtin_fmaf(s1[n][r], p.scale_log2, nb1)));
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < NS; ++n) lacc[n] = S6D_ATTN_MFMA16(ones.v, pb[n].v, lacc[n]);
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+        for (int n = 0; n < NS; ++n) oacc[n][dt] = S6D_ATTN_MFMA16(va[dt].v, pb[n].v, oacc[n][dt]);
+    }
+    bool any_bad = false;
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+      const int qy = qy0 + n * rstride;
+      const bool bad = (qy < S) && (c < S) && !(lacc[n][0] < 1.2676506e30f);      // 2^100; a valid query's sum is >= 1 (its reference key)
+      m[n] = bad ? m[n] + 96.0f : m[n];
+      any_bad |= bad;
+    }
+    if (!__any(any_bad) || round >= 40) break;
+    if (round == 0) this_q();                                         // this item's Q fragments again (next_q() replaced them)
+    ++round;
+  }
+  if (round > 0) next_q();
+#pragma unroll
+  for (int n = 0; n < NS; ++n) {
+    const int qy = qy0 + n * rstride;
+    const int y = wy * p.ws + qy, x = wx * p.ws + c;
+    if ((qy < S) && c < S && (y < p.H) && (x < p.W)) {
+      const float inv = 1.0f / lacc[n][0];
+      u16 *dst = p.out + ((size_t)(b * p.H + y) * p.W + x) * (size_t)Cc + head * HD;
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) {
+        union { uint2 u2; u16 hh[4]; } o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o.hh[r] = f2bf(oacc[n][dt][r] * inv);
+        *reinterpret_cast<uint2 *>(dst + dt * 16 + g * 4) = o.u2;
+      }
+    }
+  }
+}
+
 // ---- windowed, row-padded (S <= 16): key slot = ky*16 + kx, so every 16-key MFMA sub-tile is ONE key row and
 // every 16-query strip is ONE query row: the decomposed bias costs one LDS word per sub-tile (rel_h) plus four
 // registers (rel_w, kx = g*4+r fixed per lane; out-of-window columns carry -1e30 there, which is the mask).
@@ -1173,7 +1328,7 @@ __global__ __launch_bounds__(512) void attn_window16p_kernel(AttnParams p, int n
   bf16x8 qfa[MAXROWS][C::KS];
   // RAW: loads only (the zero mask of the out-of-window / padded-head-dim chunks is lane-constant and applied by mask_q at the
   // start of the item that uses the fragments, behind the end-of-item wait)
-  auto load_q = [&](const WinItem &it, bool raw) __attribute__((always_inline)) {
+  auto load_q = [&](const WinItem &it, bool raw, bf16x8 (&qdst)[MAXROWS][C::KS]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < MAXROWS; ++i) {
       const int qy = wave + i * WAVES;
@@ -1188,7 +1343,7 @@ __global__ __launch_bounds__(512) void attn_window16p_kernel(AttnParams p, int n
         const u16 *src = qimg ? qkv_at(p, tokc, 0, it.head) + dc : p.qkv_bias + it.head * HD + dc;
         t.u = *reinterpret_cast<const uint4 *>(src);
         if (!raw && !(qwin && d0 < HD)) t.u = make_uint4(0, 0, 0, 0);
-        qfa[i][ks] = t.v;
+        qdst[i][ks] = t.v;
       }
     }
   };
@@ -1209,7 +1364,7 @@ __global__ __launch_bounds__(512) void attn_window16p_kernel(AttnParams p, int n
   WinItem cur, nxt;
   int id = blockIdx.x;
   cur.decode(p, id);
-  load_q(cur, false);
+  load_q(cur, false, qfa);
   stage_image(cur, 1, smem);
   stage_image(cur, 2, smem + kbytes);
   S6D_ATTN_VMCNT0();
@@ -1248,14 +1403,25 @@ __global__ __launch_bounds__(512) void attn_window16p_kernel(AttnParams p, int n
     if (more) stage_image(nxt, 2, nb + kbytes);
     S6D_TICK(wtk, 3);
     const u16 *Kl = reinterpret_cast<const u16 *>(cb), *Vl = reinterpret_cast<const u16 *>(cb + kbytes);
-    auto mid = [&]() __attribute__((always_inline)) {                // half way through the PV pass: this item's Q fragments are long dead
-      if (more) load_q(nxt, S6D_WIN16_QDEFER != 0);
-    };
     const bf16x8 (&q2)[2][C::KS] = reinterpret_cast<const bf16x8 (&)[2][C::KS]>(qfa[0]);
-    if (S14)
-      win16_pass<HD, 2, 14, true, KROWT, S6D_WIN16_KSWZ != 0>(p, Kl, Vl, S, SR, cur.b, cur.wy, cur.wx, cur.head, wave, WAVES, q2, twr, thv, lane, mid);
-    else
-      win16_pass<HD, 2, 16, false, KROWT, S6D_WIN16_KSWZ != 0>(p, Kl, Vl, S, SR, cur.b, cur.wy, cur.wx, cur.head, wave, WAVES, q2, twr, thv, lane, mid);
+    if (S14 && S6D_WIN16_STREAM) {
+      // the streaming pass keeps this item's Q fragments live to its last score instructions; the next item's are requested right
+      // there, into the same registers (a retry round of the pass fetches this item's again)
+      auto next_q = [&]() __attribute__((always_inline)) {
+        if (more) load_q(nxt, S6D_WIN16_QDEFER != 0, qfa);
+      };
+      auto this_q = [&]() __attribute__((always_inline)) { load_q(cur, false, qfa); };
+      win16_pass_stream<HD, 14, KROWT, S6D_WIN16_KSWZ != 0>(p, Kl, Vl, S, cur.b, cur.wy, cur.wx, cur.head, wave, WAVES, q2, twr, thv, lane,
+                                                            next_q, this_q);
+    } else {
+      auto mid = [&]() __attribute__((always_inline)) {              // half way through the PV pass: this item's Q fragments are long dead
+        if (more) load_q(nxt, S6D_WIN16_QDEFER != 0, qfa);
+      };
+      if (S14)
+        win16_pass<HD, 2, 14, true, KROWT, S6D_WIN16_KSWZ != 0>(p, Kl, Vl, S, SR, cur.b, cur.wy, cur.wx, cur.head, wave, WAVES, q2, twr, thv, lane, mid);
+      else
+        win16_pass<HD, 2, 16, false, KROWT, S6D_WIN16_KSWZ != 0>(p, Kl, Vl, S, SR, cur.b, cur.wy, cur.wx, cur.head, wave, WAVES, q2, twr, thv, lane, mid);
+    }
     S6D_TICK(wtk, 4);
     S6D_ATTN_VMCNT0();                                               // next item's images and Q have landed (and this item's stores)
     S6D_TICK(wtk, 5);

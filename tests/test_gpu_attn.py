@@ -61,6 +61,32 @@ def test_global_attention_when_scores_outgrow_the_first_tile(hd, grow):
     assert err.max() < 3e-2 and err.mean() < 3e-3, (err.max().item(), err.mean().item())
 
 
+@pytest.mark.parametrize("grow", [30.0, 2.0])
+def test_window_attention_when_scores_outgrow_the_first_key_rows(grow):
+    """The persistent 14 x 14 window kernel streams its 32-key steps against the maximum of the window's FIRST TWO key rows
+    (win16_pass_stream, round 5) and repeats the pass with that reference raised by 96 log2 units per round while a row sum is out of
+    float32's comfortable range.  The keys of window rows >= 2 are a +-1 pattern times `grow`, the queries carry twice that pattern:
+    with 30 the later scores exceed the reference by hundreds of log2 units (several retry rounds), with 2 by some tens (no retry, P
+    up to ~2^50)."""
+    from oracle import sam as osam
+    from sam6d_amd import ops
+    H, nh, hd, ws = 28, 2, 80, 14
+    bias, rh, rw, qkv = _mk(2, H, nh, hd, ws, 91)
+    bias = torch.zeros_like(bias)
+    pat = torch.where(torch.arange(hd) % 2 == 0, 1.0, -1.0)
+    late = (torch.arange(H) % ws) >= 2
+    for h in range(nh):
+        qkv[1, :, :, h * hd:(h + 1) * hd] += 2 * pat
+        qkv[1, late, :, nh * hd + h * hd:nh * hd + (h + 1) * hd] = grow * pat
+    bias, rh, rw, qkv = (t.to(torch.bfloat16) for t in (bias, rh, rw, qkv))
+    out = ops.window_attention(qkv.cuda().contiguous(), bias.cuda().contiguous(), rh.cuda().contiguous(), rw.cuda().contiguous(), nh, ws,
+                               hd ** -0.5).float().cpu()
+    ref = osam.windowed_attention_from_qkv(qkv.float(), bias.float(), rh.float(), rw.float(), nh, ws)
+    assert torch.isfinite(out).all()
+    err = (out - ref).abs()
+    assert err.max() < 3e-2 and err.mean() < 3e-3, (err.max().item(), err.mean().item())
+
+
 @pytest.mark.parametrize("ws", [14, 0])
 def test_benched_launch_group_b16_h16(ws):
     """The launch group bench.py runs (16 frames x 16 heads x hd 80 on the 64 x 64 grid: 6400 window items through the

@@ -10,15 +10,12 @@ build() { /opt/rocm/bin/hipcc $FLAGS $2 -o $OUT/libattn_$1.so sam6d_amd/csrc/s6d
 build base ""
 build noload "-DS6D_ATTN_ABLATE=1"
 build nomath "-DS6D_ATTN_ABLATE=2"
-build nosoftmax "-DS6D_ATTN_ABLATE=4"
-build w4s2 "-DS6D_G64_WAVES=4 -DS6D_G64_SLOTS=2"
-build staticprio "-DS6D_G64_STATIC_PRIO=1"
 build timing "-DS6D_G64_TIMING=1"
-wait
-# the register-staged kernel on the 64 x 64 grid: as it was in round 1, with the layout switches, and with 8 waves
-build old_r1 "-DS6D_GLB64_DEFAULT_IMPL=1 -DS6D_GLB_KSWZ=0 -DS6D_GLB_THLD=64 -DS6D_GLB_PRIO=0"
-build old_all "-DS6D_GLB64_DEFAULT_IMPL=1"
-build old_waves8 "-DS6D_GLB64_DEFAULT_IMPL=1 -DS6D_GLB_WAVES=8"
+# round 5: the running-maximum arithmetic of round 4 on the global kernel, the exact two-pass window pass, the window kernel without its K chunk swizzle
+build g64_max "-DS6D_G64_NOMAX=0"
+build win_exact "-DS6D_WIN16_STREAM=0"
+build win_noswz "-DS6D_WIN16_KSWZ=0"
+build g64_w4s2 "-DS6D_G64_WAVES=4 -DS6D_G64_SLOTS=2"
 for x in "$@"; do build "${x%%:*}" "${x#*:}"; done
 wait
 ls $OUT

@@ -67,7 +67,7 @@ SHAPES = [  # name, M, K, N, gelu
 def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "full"
     L = _lib.lib()
-    res = {"shapes": [], "variants": [], "grid": [], "gm": []}
+    res = {"shapes": [], "variants": [], "grid": []}
     if mode == "pmc":                       # a few launches of the dominant shape only (counter passes)
         a, w, b = make(65536, 5120, 1280)
         out = torch.empty(65536, 5120, dtype=torch.bfloat16, device="cuda")
@@ -112,10 +112,10 @@ def main():
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         json.dump(out, open(os.path.join(ROOT, "gpurun_out", "gemm_variants.json"), "w"), indent=1)
         return
-    if mode == "shapes":                    # the shape table only (one run per S6D_GEMM_IMPL)
-        tag = os.environ.get("S6D_GEMM_IMPL", "2")
+    if mode == "shapes":                    # the shape table only
+        tag = "_shapes"
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        json.dump(res, open(os.path.join(ROOT, "gpurun_out", f"gemm_time_impl{tag}.json"), "w"), indent=1)
+        json.dump(res, open(os.path.join(ROOT, "gpurun_out", f"gemm_time{tag}.json"), "w"), indent=1)
         return
     # profiling variants, grid sizes and tile orders on the dominant shape
     a, w, b = make(65536, 5120, 1280)
@@ -137,13 +137,6 @@ def main():
         row = {"max_blocks": mb, "ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1)}
         res["grid"].append(row)
         print(row, flush=True)
-    for gm in (1, 2, 4, 8, 16, 32):
-        os.environ["S6D_GEMM_GM"] = str(gm)
-        ms = event_ms(lambda: call(L, a, w, b, out, True))
-        row = {"GM": gm, "ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1)}
-        res["gm"].append(row)
-        print(row, flush=True)
-    os.environ.pop("S6D_GEMM_GM", None)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(res, open(os.path.join(ROOT, "gpurun_out", "gemm_time.json"), "w"), indent=1)
 

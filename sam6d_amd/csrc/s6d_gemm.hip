@@ -442,10 +442,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
     for (int qd = 0; qd < 4; ++qd) {
       float v[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] = acc[mt][nt][4 * qd + e];
-        if (EPI == 1) v[e] = gelu_erf(v[e]);
-      }
+      for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * qd + e];
+      if (EPI == 1) gelu_erf4(v);
       pk[qd][0] = pack_out<DT>(v[0], v[1]);
       pk[qd][1] = pack_out<DT>(v[2], v[3]);
     }
@@ -483,9 +481,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          v[16 * nt + r] = gelu_erf(acc[mt][nt][r]);
-          amax = fmaxf(amax, fabsf(v[16 * nt + r]));
+        for (int r = 0; r < 16; r += 4) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[16 * nt + r + i] = acc[mt][nt][r + i];
+          gelu_erf4(v + 16 * nt + r);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) amax = fmaxf(amax, fabsf(v[16 * nt + r + i]));
         }
       int e2 = 0;
       if (amax > 0.f) {
@@ -542,20 +543,20 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int k = 0; k < 2; ++k)
+      for (int k = 0; k < 2; ++k) {
+        float v[8];
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          float v0 = acc[mt][nt][8 * k + 2 * d], v1 = acc[mt][nt][8 * k + 2 * d + 1];
-          if ((EPI == 3 || EPI == 4)) {
-            v0 *= ln_rs[mt];
-            v1 *= ln_rs[mt];
-          }
-          if (EPI == 1 || EPI == 4) {
-            v0 = gelu_erf(v0);
-            v1 = gelu_erf(v1);
-          }
-          X[2 * nt + k][d] = pack_out<DT>(v0, v1);
+        for (int i = 0; i < 8; ++i) {
+          v[i] = acc[mt][nt][8 * k + i];
+          if ((EPI == 3 || EPI == 4)) v[i] *= ln_rs[mt];
         }
+        if (EPI == 1 || EPI == 4) {
+          gelu_erf4(v);
+          gelu_erf4(v + 4);
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) X[2 * nt + k][d] = pack_out<DT>(v[2 * d], v[2 * d + 1]);
+      }
     const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
@@ -1040,10 +1041,8 @@ __global__ void __launch_bounds__(256, 2) gemm2_bf16_kernel(GemmParams p) {
         for (int qd = 0; qd < 4; ++qd) {
           float v[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = acc[mt][nt][4 * qd + e];
-            if (EPI == 1) v[e] = gelu_erf(v[e]);
-          }
+          for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * qd + e];
+          if (EPI == 1) gelu_erf4(v);
           pk[qd][0] = pack_bf16(v[0], v[1]);
           pk[qd][1] = pack_bf16(v[2], v[3]);
         }

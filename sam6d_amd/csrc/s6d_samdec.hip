@@ -204,7 +204,6 @@ __global__ __launch_bounds__(256, 2) void img2tok_kernel(const u16 *__restrict__
 }
 
 // erf-form GELU: gelu_erf of csrc/s6d_common.h (relative error 6e-6, far below the bf16 grid of the inputs)
-__device__ __forceinline__ float sd_gelu(float x) { return gelu_erf(x); }
 
 constexpr int kUpC1 = 64, kUpC2 = 32;
 constexpr int kUpWRow = kUpC1 + 8;   // LDS row stride of W2^T (bf16): 144 B
@@ -293,9 +292,16 @@ __global__ __launch_bounds__(256, 2) void upscale_heads_kernel(const u16 *__rest
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int ch = ks * 32 + g * 8 + e;
-        ua[ks].hh[e] = sd_f2bf(sd_gelu((x[ks][e] - mean) * rstd * lw[ch] + lb[ch]));
+      for (int e = 0; e < 8; e += 4) {
+        float gv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int ch = ks * 32 + g * 8 + e + i;
+          gv[i] = (x[ks][e + i] - mean) * rstd * lw[ch] + lb[ch];
+        }
+        gelu_erf4(gv);                                               // four evaluations on packed fp32 instructions, same bits
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ua[ks].hh[e + i] = sd_f2bf(gv[i]);
       }
     // ---- second transposed conv: V^T (128 x 16) = W2^T (128 x 64) . U^T; row n = s2*32 + ch, s2 = dy2*2 + dx2 -----
     float mine[4];                                                   // logit of mask g at the four sub-pixels s2 of this token
@@ -312,8 +318,12 @@ __global__ __launch_bounds__(256, 2) void upscale_heads_kernel(const u16 *__rest
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, ua[ks].v, acc, 0, 0, 0);
         }
         // C layout: row n_local = g*4 + r -> ch = half*16 + g*4 + r, col = token c
+        float gv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) vb.hh[half * 4 + r] = sd_f2bf(sd_gelu(acc[r] + bb[half * 16 + g * 4 + r]));
+        for (int r = 0; r < 4; ++r) gv[r] = acc[r] + bb[half * 16 + g * 4 + r];
+        gelu_erf4(gv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vb.hh[half * 4 + r] = sd_f2bf(gv[r]);
       }
       sd_f32x4 lg = {0.f, 0.f, 0.f, 0.f};
       lg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hya_hi.v, vb.v, lg, 0, 0, 0);

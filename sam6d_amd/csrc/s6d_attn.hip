@@ -397,7 +397,7 @@ __device__ __forceinline__ void process_tile_nomax(const AttnParams &p, const u1
 #pragma unroll
     for (int n = 0; n < NS; ++n)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < 4; ++r)     // (scalar FMAs on purpose: as two v_pk_fma_f32 per lane the kernel measured 1.6 % slower, profiles/r05_attn_pkfma_ab.txt)
         pb[n][sub >> 1].h[(sub & 1) * 4 + r] = f2bf(fast_exp2(__builtin_fmaf(acc[n][r], p.scale_log2, nb[n])));
   }
   union { bf16x8 v; u16 h[8]; } ones;
@@ -893,7 +893,6 @@ __device__ __forceinline__ void win16_pass(const AttnParams &p, const u16 *Kl, c
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const float nb = thv[n][u + h] - m[n];                    // m >= -1e29 (its initial value): a padded query's all-masked strip gives 0, not inf
-#pragma unroll
           for (int r = 0; r < 4; ++r) pb[n].hh[h * 4 + r] = f2bf(fast_exp2(__builtin_fmaf(sp[n][u + h][r], p.scale_log2, nb)));
         }
 #pragma unroll
@@ -1031,6 +1030,7 @@ __device__ __forceinline__ void win16_pass_stream(const AttnParams &p, const u16
 #pragma unroll
       for (int n = 0; n < NS; ++n) {
         const float nb0 = thv[n][u] - m[n], nb1 = thv[n][u + 1] - m[n];
+        // (scalar FMAs on purpose: the packed form needs aligned register pairs and put this kernel into scratch)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           pb[n].hh[r] = f2bf(fast_exp2(__builtin_fmaf(s0[n][r], p.scale_log2, nb0)));

@@ -12,15 +12,18 @@
 
 namespace s6d {
 
+// explicit fused multiply-adds: written as a sum of products the compiler is free to contract either product of a pair, and picks
+// differently per instantiation -- the instantiations (keys per trip, chosen by batch size) must agree bit for bit
 __device__ __forceinline__ float dot4(const float4 a, const float4 b) {
-  return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+  return __builtin_fmaf(a.w, b.w, __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)));
 }
 
 // RPE == false: plain multi-head attention of N query rows over M keys (cross attention of the sparse
 // transformer, transformer.py:93-148): the same one-wave-per-query-row structure without the embedding stream.
 // EH: the embedding is stored in IEEE half (s6d_geo_embedding_f16): 8 bytes per lane and key instead of 16, widened in registers; the
 // products and sums are the float32 ones.
-template <int WAVES, bool RPE, bool EH = false>
+// KEYS: keys per trip of the score loop (1, 2 or 4; the launchers choose by the number of query rows, see rpe_keys()).
+template <int WAVES, bool RPE, bool EH = false, int KEYS = 4>
 __global__ __launch_bounds__(WAVES * 64) void rpe_attention_kernel(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ qt, const float *__restrict__ qb, const void *__restrict__ embedv,
@@ -60,34 +63,73 @@ __global__ __launch_bounds__(WAVES * 64) void rpe_attention_kernel(
   const bool hi32 = lane & 32, hi16 = lane & 16;
 
   // ---- scores -------------------------------------------------------------------------------
-  for (int m = 0; m < M; ++m) {
-    const float4 k4 = *reinterpret_cast<const float4 *>(krow + (size_t)m * ldk);
-    float mine = 0.f;
-    if (RPE) {
-      float4 e4;
-      if (EH) {
-        typedef __attribute__((ext_vector_type(4))) _Float16 h4;
-        const h4 e = *reinterpret_cast<const h4 *>(erow_h + (size_t)m * 256);
-        e4 = make_float4((float)e[0], (float)e[1], (float)e[2], (float)e[3]);
-      } else {
-        e4 = *reinterpret_cast<const float4 *>(erow + (size_t)m * 256);
+  // KEYS keys per trip (round 5): their embedding rows are KEYS independent 1-KiB loads in flight per wave and the 16-lane sums fold
+  // the keys into the lanes (4 keys: 5 shuffles instead of 16).  Every sum keeps the operand pairs of the one-key form (distance 8,
+  // 4, 2, 1, same partners): the same bits for every KEYS.  Measured (profiles/r05_rpe_four_keys_ab.txt): with few query rows (10
+  // instances: 1970 waves on 8192 slots) one key per trip leaves the stream latency-bound -- a wave's next load waits for its own
+  // seven-shuffle reduction -- and four keys run 0.173 -> 0.108 ms; with the chip full (32 instances) the extra registers cost two
+  // waves per SIMD and the one-key form is 7 % faster.  The plain rows kernel (RPE = false) gains at both sizes.
+  const bool hi8 = lane & 8, hi4 = lane & 4;
+  for (int m0 = 0; m0 < M; m0 += KEYS) {
+    float4 k4[KEYS], e4[KEYS];
+#pragma unroll
+    for (int u = 0; u < KEYS; ++u) {
+      const int m = min(m0 + u, M - 1);                 // the last trip repeats key M - 1 (not stored)
+      k4[u] = *reinterpret_cast<const float4 *>(krow + (size_t)m * ldk);
+      if (RPE) {
+        if (EH) {
+          typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+          const h4 e = *reinterpret_cast<const h4 *>(erow_h + (size_t)m * 256);
+          e4[u] = make_float4((float)e[0], (float)e[1], (float)e[2], (float)e[3]);
+        } else {
+          e4[u] = *reinterpret_cast<const float4 *>(erow + (size_t)m * 256);
+        }
       }
-      const float p0 = dot4(t0, e4), p1 = dot4(t1, e4), p2 = dot4(t2, e4), p3 = dot4(t3, e4);
-      // fold 4 partials -> 1: lanes 0-31 keep heads {0,1}, 32-63 keep {2,3}; then bit 4 picks one
-      float ka = hi32 ? p2 : p0, kb = hi32 ? p3 : p1;
-      const float sa = hi32 ? p0 : p2, sb = hi32 ? p1 : p3;
-      ka += __shfl_xor(sa, 32);
-      kb += __shfl_xor(sb, 32);
-      mine = hi16 ? kb : ka;
-      const float send = hi16 ? ka : kb;
-      mine += __shfl_xor(send, 16);
     }
-    mine += dot4(q4, k4);                       // q.k for this lane's head (channels of head g)
-    mine += __shfl_xor(mine, 8);
-    mine += __shfl_xor(mine, 4);
-    mine += __shfl_xor(mine, 2);
-    mine += __shfl_xor(mine, 1);
-    if ((lane & 15) == 0) sc[g * Np + m] = (mine + qbg) * scale;
+    float mine[KEYS];
+#pragma unroll
+    for (int u = 0; u < KEYS; ++u) {
+      mine[u] = 0.f;
+      if (RPE) {
+        const float p0 = dot4(t0, e4[u]), p1 = dot4(t1, e4[u]), p2 = dot4(t2, e4[u]), p3 = dot4(t3, e4[u]);
+        // fold 4 partials -> 1: lanes 0-31 keep heads {0,1}, 32-63 keep {2,3}; then bit 4 picks one
+        float ka = hi32 ? p2 : p0, kb = hi32 ? p3 : p1;
+        const float sa = hi32 ? p0 : p2, sb = hi32 ? p1 : p3;
+        ka += __shfl_xor(sa, 32);
+        kb += __shfl_xor(sb, 32);
+        mine[u] = hi16 ? kb : ka;
+        const float send = hi16 ? ka : kb;
+        mine[u] += __shfl_xor(send, 16);
+      }
+      mine[u] += dot4(q4, k4[u]);                 // q.k for this lane's head (channels of head g)
+    }
+    // 16-lane sums: bit 3 of the lane picks key u & 1, bit 2 picks u >> 1 (KEYS = 4), then the plain butterfly
+    float s;
+    int mu = m0;
+    bool writer;
+    if (KEYS == 4) {
+      float a0 = hi8 ? mine[1] : mine[0], a1 = hi8 ? mine[KEYS - 1] : mine[KEYS / 2];
+      a0 += __shfl_xor(hi8 ? mine[0] : mine[1], 8);
+      a1 += __shfl_xor(hi8 ? mine[KEYS / 2] : mine[KEYS - 1], 8);
+      s = hi4 ? a1 : a0;
+      s += __shfl_xor(hi4 ? a0 : a1, 4);
+      mu += ((lane >> 3) & 1) + 2 * ((lane >> 2) & 1);
+      writer = (lane & 3) == 0;
+    } else if (KEYS == 2) {
+      s = hi8 ? mine[KEYS - 1] : mine[0];
+      s += __shfl_xor(hi8 ? mine[0] : mine[KEYS - 1], 8);
+      s += __shfl_xor(s, 4);
+      mu += (lane >> 3) & 1;
+      writer = (lane & 7) == 0;
+    } else {
+      s = mine[0];
+      s += __shfl_xor(s, 8);
+      s += __shfl_xor(s, 4);
+      writer = (lane & 15) == 0;
+    }
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 1);
+    if (writer && mu < M) sc[g * Np + mu] = (s + qbg) * scale;
   }
   __builtin_amdgcn_wave_barrier();
   // ---- softmax over keys, per head (16 lanes per head) ---------------------------------------
@@ -124,6 +166,19 @@ __global__ __launch_bounds__(WAVES * 64) void rpe_attention_kernel(
 
 using namespace s6d;
 
+// Keys per trip of the embedding stream (see the score loop): 4 up to 5000 query rows (25 instances; the chip has 8192 wave slots), else
+// S6D_RPE_KEYS_FULL (1: measured 7 % faster than 4 at 32 instances; a compile-time switch for tools/probes/rpe_ab.py builds).
+#ifndef S6D_RPE_KEYS_FULL
+#define S6D_RPE_KEYS_FULL 1
+#endif
+static inline int rpe_keys(long rows) { return rows <= 5000 ? 4 : S6D_RPE_KEYS_FULL; }
+#define S6D_RPE_LAUNCH(EHV, KEYSV, GRID, LDS, ST, ...)                                                              \
+  do {                                                                                                            \
+    if ((KEYSV) == 4) hipLaunchKernelGGL((rpe_attention_kernel<4, true, EHV, 4>), GRID, dim3(256), LDS, ST, __VA_ARGS__);      \
+    else if ((KEYSV) == 2) hipLaunchKernelGGL((rpe_attention_kernel<4, true, EHV, 2>), GRID, dim3(256), LDS, ST, __VA_ARGS__); \
+    else hipLaunchKernelGGL((rpe_attention_kernel<4, true, EHV, 1>), GRID, dim3(256), LDS, ST, __VA_ARGS__);                   \
+  } while (0)
+
 static int rpe_strided(const float *q, long ldq, const float *k, long ldk, const float *v, long ldv, const float *qt, const float *qb,
                        const void *embed, bool eh, int B, int N, int C, int heads, float scale, float *out, void *stream) {
   if (B < 0 || N <= 0 || ldq < C || ldk < C || ldv < C || (ldq % 4) || (ldk % 4) || (ldv % 4)) return S6D_EINVAL;
@@ -136,14 +191,15 @@ static int rpe_strided(const float *q, long ldq, const float *k, long ldk, const
   const int Np = (N + 3) & ~3;
   const size_t lds = (size_t)WAVES * 4 * Np * sizeof(float);
   if (lds > 64 * 1024) return S6D_EUNSUPPORTED;
+  static_assert(WAVES == 4, "S6D_RPE_LAUNCH instantiates the four-wave kernels");
+  const dim3 grid((unsigned)((rows + WAVES - 1) / WAVES));
+  const int keys = rpe_keys(rows);
   if (eh)
-    hipLaunchKernelGGL((rpe_attention_kernel<WAVES, true, true>), dim3((unsigned)((rows + WAVES - 1) / WAVES)), dim3(WAVES * 64),
-                       lds, as_stream(stream), q, k, v, qt, qb, embed, B, N, N, scale, out, ldq, ldk, ldv, 4L * N * 256, 256L,
-                       (long)N * 256, 4L * N, 1L, (long)N);
+    S6D_RPE_LAUNCH(true, keys, grid, lds, as_stream(stream), q, k, v, qt, qb, embed, B, N, N, scale, out, ldq, ldk, ldv, 4L * N * 256,
+                   256L, (long)N * 256, 4L * N, 1L, (long)N);
   else
-    hipLaunchKernelGGL((rpe_attention_kernel<WAVES, true, false>), dim3((unsigned)((rows + WAVES - 1) / WAVES)), dim3(WAVES * 64),
-                       lds, as_stream(stream), q, k, v, qt, qb, embed, B, N, N, scale, out, ldq, ldk, ldv, 4L * N * 256, 256L,
-                       (long)N * 256, 4L * N, 1L, (long)N);
+    S6D_RPE_LAUNCH(false, keys, grid, lds, as_stream(stream), q, k, v, qt, qb, embed, B, N, N, scale, out, ldq, ldk, ldv, 4L * N * 256,
+                   256L, (long)N * 256, 4L * N, 1L, (long)N);
   return launch_status();
 }
 
@@ -174,14 +230,15 @@ static int rpe_packed(const float *proj, long ld, int q_off, int k_off, int v_of
   const int Np = (N + 3) & ~3;
   const size_t lds = (size_t)WAVES * 4 * Np * sizeof(float);
   if (lds > 64 * 1024) return S6D_EUNSUPPORTED;
+  static_assert(WAVES == 4, "S6D_RPE_LAUNCH instantiates the four-wave kernels");
+  const dim3 grid((unsigned)((rows + WAVES - 1) / WAVES));
+  const int keys = rpe_keys(rows);
   if (eh)
-    hipLaunchKernelGGL((rpe_attention_kernel<WAVES, true, true>), dim3((unsigned)((rows + WAVES - 1) / WAVES)), dim3(WAVES * 64),
-                       lds, as_stream(stream), proj + q_off, proj + k_off, proj + v_off, proj + qt_off, proj + qb_off, embed, B, N, N,
-                       scale, out, ld, ld, ld, (long)N * ld, ld, 256L, (long)N * ld, ld, 1L);
+    S6D_RPE_LAUNCH(true, keys, grid, lds, as_stream(stream), proj + q_off, proj + k_off, proj + v_off, proj + qt_off, proj + qb_off,
+                   embed, B, N, N, scale, out, ld, ld, ld, (long)N * ld, ld, 256L, (long)N * ld, ld, 1L);
   else
-    hipLaunchKernelGGL((rpe_attention_kernel<WAVES, true, false>), dim3((unsigned)((rows + WAVES - 1) / WAVES)), dim3(WAVES * 64),
-                       lds, as_stream(stream), proj + q_off, proj + k_off, proj + v_off, proj + qt_off, proj + qb_off, embed, B, N, N,
-                       scale, out, ld, ld, ld, (long)N * ld, ld, 256L, (long)N * ld, ld, 1L);
+    S6D_RPE_LAUNCH(false, keys, grid, lds, as_stream(stream), proj + q_off, proj + k_off, proj + v_off, proj + qt_off, proj + qb_off,
+                   embed, B, N, N, scale, out, ld, ld, ld, (long)N * ld, ld, 256L, (long)N * ld, ld, 1L);
   return launch_status();
 }
 
@@ -215,7 +272,7 @@ extern "C" int s6d_mha_strided_f32(const float *q, long ldq, const float *k, lon
   const int Np = (M + 3) & ~3;
   const size_t lds = (size_t)WAVES * 4 * Np * sizeof(float);
   if (lds > 64 * 1024) return S6D_EUNSUPPORTED;
-  hipLaunchKernelGGL((rpe_attention_kernel<WAVES, false>), dim3((unsigned)((rows + WAVES - 1) / WAVES)), dim3(WAVES * 64),
+  hipLaunchKernelGGL((rpe_attention_kernel<WAVES, false, false, 4>), dim3((unsigned)((rows + WAVES - 1) / WAVES)), dim3(WAVES * 64),
                      lds, as_stream(stream), q, k, v, nullptr, nullptr, nullptr, B, N, M, scale, out, ldq, ldk, ldv, 0L, 0L, 0L, 0L, 0L, 0L);
   return launch_status();
 }

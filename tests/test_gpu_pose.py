@@ -365,3 +365,23 @@ def test_fine_match_properties_at_the_benched_size(ops):
     assert (wsum >= 0).all() and (wsum <= 1 + 1e-5).all()
     off = w1 == 0
     assert (wsum[off] == 0).all() and (pred[off] == 0).all()
+
+
+def test_rpe_attention_rows_do_not_depend_on_the_batch_size(ops):
+    """The RPE core picks its keys-per-trip instantiation by the number of query rows (four keys per trip up to 5000 rows, one beyond:
+    csrc/s6d_rpe.hip); the instantiations must agree BIT FOR BIT, or a frame alone (10 instances) and the same frame inside a
+    launch group (80 instances) would get different poses.  Two instances alone against the same two as rows of a batch of 28."""
+    N, C, Bbig = 197, 256, 28                                  # 28 x 197 = 5516 rows: the one-key instantiation
+    g = torch.Generator(device="cuda").manual_seed(12)
+    q, k, v = (torch.randn(Bbig, N, C, generator=g, device="cuda") for _ in range(3))
+    qt = torch.randn(Bbig, 4, N, C, generator=g, device="cuda") * 0.1
+    qb = torch.randn(Bbig, 4, N, generator=g, device="cuda")
+    emb = torch.randn(Bbig, N, N, C, generator=g, device="cuda")
+    big = ops.rpe_attention(q, k, v, qt, qb, emb, 0.125)
+    small = ops.rpe_attention(q[5:7].contiguous(), k[5:7].contiguous(), v[5:7].contiguous(), qt[5:7].contiguous(), qb[5:7].contiguous(),
+                              emb[5:7].contiguous(), 0.125)
+    assert torch.equal(big[5:7], small)
+    ref = torch.softmax((torch.einsum("bnhc,bmhc->bhnm", q[5:7].view(2, N, 4, 64), k[5:7].view(2, N, 4, 64)) +
+                         torch.einsum("bhnc,bnmc->bhnm", qt[5:7], emb[5:7]) + qb[5:7][..., None]) * 0.125, -1)
+    ref = torch.einsum("bhnm,bmhc->bnhc", ref, v[5:7].view(2, N, 4, 64)).reshape(2, N, C)
+    assert (small - ref).abs().max() < 2e-4 * ref.abs().max().clamp_min(1.0)

@@ -431,7 +431,8 @@ int s6d_seq_attention_bf16(const void *qkv, int B, int N, int num_heads, int hea
 /* PositionalEncoding branch, fused: for every point, gather its `ns` ball-query neighbours, build the 6-channel
  * input [nbr - centre ; nbr], run the 3-layer SharedMLP (BatchNorm folded: W0 (32,6), W1 (64,32), W2 (128,64),
  * row-major (out,in), + biases) with ReLU, and max over the neighbours.
- * pts (B,N,3) f32, idx (B,N,ns) i32 (s6d_ball_query_f32 output) -> out (B,N,128) f32.
+ * pts (B,N,3) f32, idx (B,N,ns) i32 (s6d_ball_query_f32 output) -> out (B,N,128) f32.  Layers 1 and 2 run on the bf16 matrix
+ * cores with the 3-term split of s6d_linear_f32 (fp32 accumulation, ~2^-17 relative per product; layer 0 in fp32).
  * ref: PositionalEncoding.forward, Pose_Estimation_Model/model/fine_point_matching.py:101-117 (one scale),
  * QueryAndGroup pointnet2_utils.py:331-356, SharedMLP pytorch_utils.py:25-50. */
 int s6d_pe_group_mlp_f32(const float *pts, const int32_t *idx, int B, int N, int ns, const float *W0, const float *b0,

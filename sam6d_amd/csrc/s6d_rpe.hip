@@ -171,7 +171,10 @@ using namespace s6d;
 #ifndef S6D_RPE_KEYS_FULL
 #define S6D_RPE_KEYS_FULL 1
 #endif
-static inline int rpe_keys(long rows) { return rows <= 5000 ? 4 : S6D_RPE_KEYS_FULL; }
+#ifndef S6D_RPE_FOUR_KEYS_MAX_ROWS     // (0 in tests/test_emu_pose.py's variant builds: every size takes the S6D_RPE_KEYS_FULL instantiation)
+#define S6D_RPE_FOUR_KEYS_MAX_ROWS 5000
+#endif
+static inline int rpe_keys(long rows) { return rows <= S6D_RPE_FOUR_KEYS_MAX_ROWS ? 4 : S6D_RPE_KEYS_FULL; }
 #define S6D_RPE_LAUNCH(EHV, KEYSV, GRID, LDS, ST, ...)                                                              \
   do {                                                                                                            \
     if ((KEYSV) == 4) hipLaunchKernelGGL((rpe_attention_kernel<4, true, EHV, 4>), GRID, dim3(256), LDS, ST, __VA_ARGS__);      \

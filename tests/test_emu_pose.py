@@ -107,3 +107,49 @@ def test_cross_and_linear_attention_on_the_emulator(emu):
         ref = opem.linear_layer(W, "l", xd, ms)
         out = ll(xd, ms)
     assert (out - ref).abs().max() < 2e-5
+
+
+_RPE_VARIANT = r'''
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from tests import hipemu
+so = hipemu.build(files=["s6d_rpe.hip", "s6d_capi.hip"]) if os.environ.get("HIPEMU_EXTRA") else hipemu.build()
+L = ctypes.CDLL(so)
+rng = np.random.default_rng(5)
+B, N, C = 2, 21, 256                       # 21 keys: the four- and two-key loops end on a partial trip
+q, k, v = (rng.standard_normal((B, N, C)).astype(np.float32) for _ in range(3))
+qt = (0.1 * rng.standard_normal((B, 4, N, C))).astype(np.float32)
+qb = rng.standard_normal((B, 4, N)).astype(np.float32)
+emb = rng.standard_normal((B, N, N, C)).astype(np.float32)
+out = np.zeros((B, N, C), np.float32)
+rc = L.s6d_rpe_attention_f32(hipemu.ptr(q), hipemu.ptr(k), hipemu.ptr(v), hipemu.ptr(qt), hipemu.ptr(qb), hipemu.ptr(emb), B, N, C, 4,
+                             ctypes.c_float(0.125), hipemu.ptr(out), None)
+assert rc == 0, rc
+s = np.einsum("bnhc,bmhc->bhnm", q.reshape(B, N, 4, 64), k.reshape(B, N, 4, 64)) + np.einsum("bhnc,bnmc->bhnm", qt, emb) + qb[..., None]
+s = (s * 0.125).astype(np.float64)
+p = np.exp(s - s.max(-1, keepdims=True))
+p /= p.sum(-1, keepdims=True)
+ref = np.einsum("bhnm,bmhc->bnhc", p, v.reshape(B, N, 4, 64)).reshape(B, N, C)
+assert np.abs(out - ref).max() < 1e-4, np.abs(out - ref).max()
+sys.stdout.buffer.write(out.tobytes())
+'''
+
+
+def test_rpe_keys_per_trip_instantiations_agree_bit_for_bit():
+    """csrc/s6d_rpe.hip picks 4 / 1 keys per trip by the number of query rows (and 2 in probe builds); a frame alone and the frame
+    inside a launch group must get the same bits.  The three instantiations on the same small input, each in its own host build
+    (HIPEMU_EXTRA is read when tests.hipemu is imported) -- the GPU twin at the real threshold is
+    tests/test_gpu_pose.py::test_rpe_attention_rows_do_not_depend_on_the_batch_size."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for extra in ("", "-DS6D_RPE_FOUR_KEYS_MAX_ROWS=0", "-DS6D_RPE_FOUR_KEYS_MAX_ROWS=0 -DS6D_RPE_KEYS_FULL=2"):
+        r = subprocess.run([sys.executable, "-c", _RPE_VARIANT % {"root": root}], env=dict(os.environ, HIPEMU_EXTRA=extra),
+                           capture_output=True, timeout=1500)
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        outs.append(r.stdout)
+    assert len(outs[0]) == 2 * 21 * 256 * 4
+    assert outs[0] == outs[1] and outs[0] == outs[2]

@@ -65,7 +65,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
   p = fmaf(z, p, -9.999961853e-01f);
   return fmaf(-ax, __builtin_amdgcn_exp2f(p), fmaxf(x, 0.f));
 }
-// gelu_erf of TWO values, bit for bit (round 5): the seven fused multiply-adds of the polynomial as packed fp32 instructions
+// gelu_erf of several values at once, bit for bit (round 5; gelu_erf above is the definition, the kernels call gelu_erf4): the seven fused multiply-adds of the polynomial as packed fp32 instructions
 // (v_pk_fma_f32: two IEEE fmas per lane and issue slot, constants broadcast from one scalar register) -- 6.5 plain slots + v_exp per
 // element instead of 10 + v_exp.  |x| stays a source modifier of the scalar instructions (the packed ones have none: a packed
 // final product would pay a v_and per element).  The lin1 + GELU epilogue is 128 evaluations per lane and tile with no matrix work
@@ -81,12 +81,6 @@ __device__ __forceinline__ V gelu_erf_poly(V z) {
   p = __builtin_elementwise_fma(z, p, (V)(-4.584769309e-01f));
   p = __builtin_elementwise_fma(z, p, (V)(-1.151244164e+00f));
   return __builtin_elementwise_fma(z, p, (V)(-9.999961853e-01f));
-}
-__device__ __forceinline__ void gelu_erf2(float &x0, float &x1) {
-  const f32x2_t z = {fminf(fabsf(x0), 6.0f), fminf(fabsf(x1), 6.0f)};
-  const f32x2_t p = gelu_erf_poly(z);
-  x0 = fmaf(-fabsf(x0), __builtin_amdgcn_exp2f(p.x), fmaxf(x0, 0.f));
-  x1 = fmaf(-fabsf(x1), __builtin_amdgcn_exp2f(p.y), fmaxf(x1, 0.f));
 }
 // four values: two independent packed chains, which the scheduler interleaves (a packed fp32 instruction that consumes the result
 // of the one right before it costs a wait state)

@@ -911,7 +911,9 @@ __global__ void __launch_bounds__(512, 2) gemm_f16_kernel(GemmParams p) {
 
 
 // =====================================================================================================================================
-// Version 2: two INDEPENDENT 256-thread workgroups per CU, 256 x 128 output tiles.
+// Version 2: two INDEPENDENT 256-thread workgroups per CU, 256 x 128 output tiles.  In the product this is the path of the shapes the
+// 256 x 256 kernel cannot tile -- N % 256 == 128 (gemm_launch: impl 2; plain and GELU epilogues, bf16) -- and nothing else: on the
+// ViT-H shapes it measured 0.89 - 0.96 x of version 1 (profiles/r02_gemm_v2_shapes.json) and is not selected there.
 //
 // What the measurements of version 1 said (profiles/r02_gemm_v1_time.json, 65536 x 1280 -> 5120): the whole kernel 0.76 ms, without
 // the epilogue stores 0.65, without the LDS-DMA 0.62, matrix work + fragment reads alone 0.55 -- and everything EXCEPT the matrix work

@@ -155,7 +155,8 @@ def test_rgb_choose_for_every_crop_size_in_float64_like_the_reference():
     moves those rows by one -- every crop size a 480 x 640 frame can give, against the oracle helper (itself pinned to the
     reference's function by tests/golden/pem_pre.npz and example_frame.npz).  Found by the pixels-to-pose golden (round 5)."""
     for size in range(33, 481):
-        ch = torch.arange(size * size, dtype=torch.int64)[None]
+        # the map acts on the row and the column index separately: every row (column 0) and every column (row 0) of the crop
+        ch = torch.cat([torch.arange(size, dtype=torch.int64) * size, torch.arange(1, size, dtype=torch.int64)])[None]
         box = torch.tensor([[0, size, 0, size]])
         out = pre._finish(torch.zeros(1, 1, 3, dtype=torch.uint8), None, box, torch.zeros(1, dtype=torch.int64), torch.zeros(1, 1, 3), ch, 224,
                           True, rgb=torch.zeros(1, 3, 224, 224))

@@ -30,12 +30,18 @@ extern "C" {
 
 /* Bumped whenever a signature in this header changes; the loader (sam6d_amd/_lib.py) refuses a library whose
  * s6d_version() differs from the header it was written against (a stale .so fails at load, not at a call). */
-#define S6D_ABI_VERSION 123
+#define S6D_ABI_VERSION 124
 int s6d_version(void);
 /* Upper bound on the workgroups of the persistent kernels (the 14 x 14 window attention walks its (window, head) items with one
  * workgroup per CU); 0 = one per CU of the device.  Process-wide.  Replaces the environment lookups the launch path made until
  * round 4; used by the tests to make few workgroups walk many items. */
 int s6d_set_persistent_grid_limit(int max_workgroups);
+/* Which form of the bf16 / f16 GEMM kernel serves the shapes both forms cover (csrc/s6d_gemm.hip: eight waves, 128 x 64 wave tiles;
+ * csrc/s6d_gemm4.hip: four waves, 128 x 128 wave tiles, accumulators in the accumulator register file): 0 = the library's choice per
+ * shape (the default), 64 = always the eight-wave form, 128 = the four-wave form wherever it applies (N % 256 == 0, M % 256 == 0,
+ * K >= 128, epilogues without a residual operand).  Both forms give the same bits (the same products in the same order per
+ * accumulator); the switch exists for A/B measurements and the parity tests.  Process-wide; returns S6D_EINVAL for other values. */
+int s6d_set_gemm_wave_tile(int columns);
 const char *s6d_strerror(int code);
 /* last HIP error string seen by this thread (empty if none) */
 const char *s6d_last_hip_error(void);

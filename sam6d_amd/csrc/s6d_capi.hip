@@ -23,6 +23,16 @@ extern "C" int s6d_set_persistent_grid_limit(int max_workgroups) {
   return S6D_OK;
 }
 
+// Form of the bf16 / f16 GEMM kernel (include/sam6d_hip.h: s6d_set_gemm_wave_tile): 0 = per shape, 64 / 128 = forced.
+namespace s6d {
+int g_s6d_gemm_wave_tile = 0;
+}
+extern "C" int s6d_set_gemm_wave_tile(int columns) {
+  if (columns != 0 && columns != 64 && columns != 128) return S6D_EINVAL;
+  s6d::g_s6d_gemm_wave_tile = columns;
+  return S6D_OK;
+}
+
 extern "C" int s6d_version(void) { return S6D_ABI_VERSION; }
 
 extern "C" const char *s6d_last_hip_error(void) { return s6d::g_hip_err; }

@@ -29,13 +29,13 @@
 //     relative error 6e-6), round to bf16,
 //     v_permlane32_swap pairs the two lane halves into 16-byte row segments.
 #include "s6d_common.h"
+#include "s6d_gemm_params.h"
 #include <stdlib.h>
 
 namespace s6d {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef unsigned short u16;
 #define S6D_LDS(T) __attribute__((address_space(3))) T
 #define S6D_GLOBAL(T) __attribute__((address_space(1))) T
 
@@ -120,31 +120,6 @@ typedef unsigned short u16;
 //          start, where the bias read of the plain form sits) and the epilogue multiplies by rstd_m = 1 / sigma_m:  the
 //          normalised activations are never written (and never rounded to bf16).
 
-struct GemmParams {
-  const u16 *A;       // (M,K) bf16, row stride lda
-  const u16 *W;       // (N,K) bf16, row stride ldw
-  const float *bias;  // (N) f32 or nullptr
-  u16 *C;             // (M,N) bf16, row stride ldc
-  const unsigned char *sa, *sw;   // fp8 operands (DT = 1): E8M0 scale byte of every A row (M) / W row (N); value = q * 2^(byte - 127)
-  const unsigned *sa_mx;          // MX form of the A operand (AMX; round 4): one E8M0 byte per row and 32-k block, [M][K / 32] bytes =
-                                  // [M][nk] dwords (a dword = the four blocks of one 128-byte K tile); sa is unused then
-  unsigned char *SC;              // EPI 5: the output is e4m3 bytes at C (row stride ldc BYTES) + one E8M0 byte per row and 32 columns
-                                  // here, [M][N / 32] -- the MX A operand of the next GEMM
-  const u16 *R;       // EPI 2: residual (M,N) bf16, row stride ldr2 BYTES; may be C itself (a tile's residual is read by the workgroup
-                      // that stores the tile, one tile ahead of its stores)
-  float *SP;          // EPI 2, optional: partial row statistics, [N / 32][2][M] floats (sum, sum of squared deviations per 32 columns)
-  const float *RS;    // EPI 3 / 4: per-row (mean, sigma = sqrt(var + eps)) of A, [M][2] floats
-  const float *CS;    // EPI 3 / 4: s_n = sum_k W'_nk, (N) floats
-  unsigned ldr2;
-  unsigned lda2, ldw2;  // row strides in BYTES
-  long ldc;
-  int M, N, K;
-  int MT, NT, nk, ntiles;
-  int GM;             // m-tiles per group of the tile order
-  int cblk;           // 0: C is (M, N) with row stride ldc.  > 0 (multiple of 8): column blocks of this width are stored as
-                      // separate (M, cblk) matrices one after the other -- element (m, n) at C + (n / cblk) M cblk + m cblk + n % cblk
-                      // (the qkv projection writes q / k / v head-major for the attention kernels: every head's rows contiguous)
-};
 
 constexpr int kSlot = 16384;  // one half-tile: 128 rows x 64 k bf16
 constexpr int kRing = 10;     // slots: all 160 KiB of the CU
@@ -1260,6 +1235,10 @@ static int gemm_launch(const void *A, long lda, const void *W, long ldw, const f
   p.GM = 8;                                                              // m-tiles per n-tile group of the schedule (profiles/r04_gemm_gm.txt)
   p.cblk = col_block;
   hipStream_t st = as_stream(stream);
+  // the four-wave form (csrc/s6d_gemm4.hip) where it applies and is selected (s6d_set_gemm_wave_tile; 0 = gemm4_default below)
+  if (impl == 1 && g_s6d_gemm_wave_tile != 64 && !x.sa_mx && gemm4_supports(p, epilogue, dt) &&
+      (g_s6d_gemm_wave_tile == 128 || gemm4_default(p, epilogue, dt)))
+    return gemm4_launch(p, epilogue, max_blocks, st, dt);
   if (impl == 2) {
     if (max_blocks <= 0) max_blocks = 512;                               // two persistent workgroups per CU
     int grid = p.ntiles < max_blocks ? p.ntiles : max_blocks;

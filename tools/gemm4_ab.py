@@ -1,0 +1,104 @@
+"""A/B of the two forms of the bf16 GEMM kernel in ONE process (s6d_set_gemm_wave_tile: 64 = eight waves with 128 x 64 wave tiles,
+csrc/s6d_gemm.hip; 128 = four waves with 128 x 128 wave tiles, csrc/s6d_gemm4.hip) on the ViT-H shapes of the benched step:
+parity of the four-wave form (against the fp32 product of the same operands AND bit for bit against the eight-wave form), then
+interleaved timing rounds.  Usage: python tools/gemm4_ab.py [rounds]   -> gpurun_out/gemm4_ab.json"""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sam6d_amd import _lib, ops  # noqa: E402
+
+
+def event_ms(fn, n=20, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def make(M, N, K, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    a = torch.randn(M, K, generator=g, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g, device="cuda") / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, generator=g, device="cuda")
+    return a, w, b
+
+
+def check(a, w, b, out, gelu, rows=2048):
+    idx = torch.randperm(a.shape[0], device="cuda")[:rows]
+    ref = a[idx].float() @ w.float().t() + b
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    err = (out[idx].float() - ref).abs()
+    tol = 2.0 ** -8 * ref.abs() + 1e-5
+    return int((err > 1.01 * tol).sum().item()), float(err.max().item())
+
+
+SHAPES = [  # name, M, K, N, kind   (kind: plain / gelu / lnfold / lnfold_gelu / cblk)
+    ("qkv lnfold cblk", 65536, 1280, 3840, "lnfold_cblk"),
+    ("lin1 lnfold+gelu", 65536, 1280, 5120, "lnfold_gelu"),
+    ("lin1 gelu", 65536, 1280, 5120, "gelu"),
+    ("proj plain", 65536, 1280, 1280, "plain"),
+    ("lin2 plain", 65536, 5120, 1280, "plain"),
+    ("qkv M=4096", 4096, 1280, 3840, "plain"),
+    ("lin1 M=4096 gelu", 4096, 1280, 5120, "gelu"),
+]
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    L = _lib.lib()
+    res = []
+    for name, M, K, N, kind in SHAPES:
+        a, w, b = make(M, N, K)
+        if kind.startswith("lnfold"):
+            stats = ops.row_stats(a)
+            cs = w.float().sum(1).contiguous()
+            cb = 80 if kind == "lnfold_cblk" else 0
+            fn = lambda: ops.gemm_bf16_lnfold(a, stats, w, cs, b, gelu=kind == "lnfold_gelu", col_block=cb)   # noqa: E731
+        else:
+            fn = lambda: ops.gemm_bf16(a, w, b, gelu=kind == "gelu")   # noqa: E731
+        out = {}
+        for wt in (64, 128):
+            assert L.s6d_set_gemm_wave_tile(wt) == 0
+            out[wt] = fn().clone()
+        torch.cuda.synchronize()
+        same = bool(torch.equal(out[64], out[128]))
+        ndiff = int((out[64] != out[128]).sum().item())
+        row = {"name": name, "M": M, "K": K, "N": N, "kind": kind, "bit_equal_to_eight_wave": same, "differing": ndiff}
+        if kind in ("plain", "gelu"):
+            bad, emax = check(a, w, b, out[128], kind == "gelu")
+            row.update(mismatch_vs_fp32=bad, max_err=emax)
+        # 20 repeated launches bit-identical (a slot read before its DMA landed shows up as run-to-run differences)
+        L.s6d_set_gemm_wave_tile(128)
+        rep = all(torch.equal(fn(), out[128]) for _ in range(10))
+        row["repeat_identical"] = bool(rep)
+        fl = 2.0 * M * N * K
+        t = {64: [], 128: []}
+        for _ in range(rounds):
+            for wt in (64, 128):
+                L.s6d_set_gemm_wave_tile(wt)
+                t[wt].append(event_ms(fn))
+        row["ms_w64"] = [round(x, 4) for x in t[64]]
+        row["ms_w128"] = [round(x, 4) for x in t[128]]
+        row["tflops_w64"] = round(fl / min(t[64]) / 1e9, 1)
+        row["tflops_w128"] = round(fl / min(t[128]) / 1e9, 1)
+        print(row, flush=True)
+        res.append(row)
+    L.s6d_set_gemm_wave_tile(0)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "gemm4_ab.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

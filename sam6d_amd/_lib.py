@@ -26,6 +26,13 @@ def sources():
     return sorted(glob.glob(os.path.join(_CSRC, "*.hip")))
 
 
+def file_flags(src):
+    """Extra compiler flags of ONE source: a first line `// hipcc-flags: ...` (csrc/s6d_gemm4.hip switches the SLP vectoriser off)."""
+    with open(src) as f:
+        first = f.readline()
+    return first.split(":", 1)[1].split() if first.startswith("// hipcc-flags:") else []
+
+
 def _stale():
     if not os.path.exists(SO_PATH):
         return True
@@ -72,7 +79,7 @@ def _build_locked(force, verbose, objdir):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         dep_t = max(hdr_t, os.path.getmtime(src), max(os.path.getmtime(x) for x in sources()) if src.endswith("_f16.hip") else 0)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < dep_t:
-            cmd = [HIPCC] + cflags + ["-c", src, "-o", obj]
+            cmd = [HIPCC] + cflags + file_flags(src) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd, cwd=_CSRC)

@@ -55,7 +55,51 @@ SHAPES = [  # name, M, K, N, kind   (kind: plain / gelu / lnfold / lnfold_gelu /
 ]
 
 
+def variants(rounds):
+    """every library of tools/gemm4_variants.sh on lin1 + GELU and qkv (plain epilogue) at 16 frames, interleaved rounds; the
+    product library's two forms ride along as 'lib64' / 'lib128'"""
+    import ctypes
+    import glob
+    vp = ctypes.c_void_p
+
+    def call(L, a, w, b, out, gelu):
+        M, K = a.shape
+        N = w.shape[0]
+        rc = L.s6d_gemm_bf16(vp(a.data_ptr()), ctypes.c_long(a.stride(0)), vp(w.data_ptr()), ctypes.c_long(w.stride(0)),
+                             vp(b.data_ptr()), vp(out.data_ptr()), ctypes.c_long(out.stride(0)), M, N, K, 1 if gelu else 0, 0,
+                             vp(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, rc
+
+    libs = {"lib64": (_lib.lib(), 64), "lib128": (_lib.lib(), 128)}
+    for path in sorted(glob.glob(os.path.join(ROOT, "tools", "gemm4_variants", "libg4_*.so"))):
+        libs[os.path.basename(path)[6:-3]] = (ctypes.CDLL(path), 128)
+    data = {}
+    for name, M, K, N, gelu in (("lin1+gelu", 65536, 1280, 5120, True), ("qkv", 65536, 1280, 3840, False),
+                                ("lin2", 65536, 5120, 1280, False)):
+        data[name] = (make(M, N, K), torch.empty(M, N, dtype=torch.bfloat16, device="cuda"), gelu, 2.0 * M * N * K)
+    out = {}
+    ref = {}
+    for r in range(rounds):
+        for v, (L, wt) in libs.items():
+            L.s6d_set_gemm_wave_tile(wt)
+            for name, ((a, w, b), o, gelu, fl) in data.items():
+                ms = event_ms(lambda: call(L, a, w, b, o, gelu), n=20, warm=3)
+                out.setdefault(v, {}).setdefault(name, []).append(round(fl / ms / 1e9, 1))
+                if r == 0:
+                    if v == "lib64":
+                        ref[name] = o.clone()
+                    elif name in ref:
+                        out[v].setdefault("equal", {})[name] = bool(torch.equal(o, ref[name]))
+    for v, d in out.items():
+        print(v.ljust(12), d, flush=True)
+    _lib.lib().s6d_set_gemm_wave_tile(0)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "gemm4_variants.json"), "w"), indent=1)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "variants":
+        return variants(int(sys.argv[2]) if len(sys.argv) > 2 else 2)
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     L = _lib.lib()
     res = []

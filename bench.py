@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--config", choices=("lmo", "fp8", "fp8mx"), default="lmo",
                     help="lmo = BASELINE configs[1] (the headline: bf16 ViTs); fp8 = the fp8 ViT-H MFMA path of configs[4] on the same "
                          "workload (qkv / lin1 GEMMs of the SAM encoder on the fp8 matrix cores) -- its own line, never the headline")
+    ap.add_argument("--gemm-wave-tile", type=int, choices=(0, 64, 128), default=0,
+                    help="form of the bf16 GEMM kernel (ops.set_gemm_wave_tile): 0 = the library's choice (default), 64 = eight-wave "
+                         "form everywhere, 128 = four-wave form wherever it applies -- for same-box A/B runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the whole-frame `pipeline` block (all five models)")
@@ -208,6 +211,17 @@ def stage_ms(fn, n=2):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
+
+
+_GEMM_WAVE_TILE = 0        # what --gemm-wave-tile set (0 = the library's choice: the four-wave form wherever it applies)
+
+
+def _gemm_inst(epi, M):
+    """Template instance (as rocprofv3 prints it) that serves a ViT-H Linear with epilogue `epi` at M rows: the four-wave form
+    (csrc/s6d_gemm4.hip) covers epilogues 0, 1, 3, 4 at M % 256 == 0 and is the library's choice there; the residual epilogue (2)
+    and everything else runs the eight-wave form (csrc/s6d_gemm.hip)."""
+    four = _GEMM_WAVE_TILE != 64 and epi in (0, 1, 3, 4) and M % 256 == 0
+    return f"gemm4_bf16_kernel<{epi}, true>" if four else f"gemm_bf16_kernel<{epi}, true>"
 
 
 def _event_ms(fn, n):
@@ -399,7 +413,7 @@ def kernel_rooflines(dev, sam_chunk, frames, in_step=None):
             wf, cs, bf = lnfold_weights(W, b, torch.ones(K, device=dev), torch.zeros(K, device=dev))
             st = ops.row_stats(x)
             b2b = _event_ms(lambda: ops.gemm_bf16_lnfold(x, st, wf, cs, bf, gelu=gelu), 10)
-            inst = "gemm_bf16_kernel<4, true>" if gelu else "gemm_bf16_kernel<3, true>"
+            inst = _gemm_inst(4 if gelu else 3, M)
         elif folded or (res_only and nm in ("proj", "lin2")):
             form = "res"
             xr = torch.randn(M, N, generator=g).to(dev).to(torch.bfloat16)
@@ -408,7 +422,7 @@ def kernel_rooflines(dev, sam_chunk, frames, in_step=None):
             inst = "gemm_bf16_kernel<2, true>"
         else:
             b2b = _event_ms(lambda: ops.gemm_bf16(x, w, b, gelu=gelu), 10)
-            inst = "gemm_bf16_kernel<1, true>" if gelu else "gemm_bf16_kernel<0, true>"
+            inst = _gemm_inst(1 if gelu else 0, M)
         # avg_ms: inside the step (gemm_ms_inside_the_step) when the caller measured it; back_to_back_ms: 10 launches of this shape alone
         ms = in_step[(form, M, K, N, gelu)][0] if in_step and (form, M, K, N, gelu) in in_step else b2b
         flop = 2.0 * M * N * K
@@ -464,7 +478,7 @@ def kernel_rooflines(dev, sam_chunk, frames, in_step=None):
                         "avg_ms": round(ms, 4), "back_to_back_ms": round(b2b, 4), "launches_per_step": 32 * groups,
                         "algorithmic_bytes": 1.0 * (M * 5120 + 1280 * 5120) + M * 160.0 + 2.0 * M * 1280, "pmc_key": "gemm_fp8mx_kernel<0, true>"})
             for r in out:                                                   # lin1's bf16-output fp8 form and the bf16 lin2 are off the path here
-                if r["kernel"].startswith("gemm_fp8_kernel (lin1+gelu") or (r["kernel"].startswith("gemm_bf16_kernel") and r.get("shape") == "lin2"):
+                if r["kernel"].startswith("gemm_fp8_kernel (lin1+gelu") or (r["kernel"].startswith(("gemm_bf16_kernel", "gemm4_bf16_kernel")) and r.get("shape") == "lin2"):
                     r["launches_per_step"] = 0
         xb = torch.randn(M, 1280, generator=g).to(dev).to(torch.bfloat16)
         gm, bt = torch.ones(1280, device=dev), torch.zeros(1280, device=dev)
@@ -474,7 +488,7 @@ def kernel_rooflines(dev, sam_chunk, frames, in_step=None):
                     "launches_per_step": 64 * groups, "algorithmic_bytes": float(M) * 1280 * 3})
         # in this configuration qkv / lin1 do not run the bf16 kernel: their bf16 rows stay for comparison, off the path
         for r in out:
-            if r["kernel"].startswith("gemm_bf16_kernel") and r.get("shape") in ("qkv", "lin1+gelu"):
+            if r["kernel"].startswith(("gemm_bf16_kernel", "gemm4_bf16_kernel")) and r.get("shape") in ("qkv", "lin1+gelu"):
                 r["launches_per_step"] = 0
     x = torch.randn(M, 1280, generator=g).to(dev).to(torch.bfloat16)
     w = torch.randn(5120, 1280, generator=g).to(dev).to(torch.bfloat16)
@@ -811,6 +825,11 @@ def main():
 
     if args.config in ("fp8", "fp8mx"):
         os.environ["S6D_SAM_GEMM"] = args.config
+    if args.gemm_wave_tile and not args.standin:
+        from sam6d_amd import ops as _ops
+        global _GEMM_WAVE_TILE
+        _GEMM_WAVE_TILE = args.gemm_wave_tile
+        _ops.set_gemm_wave_tile(args.gemm_wave_tile)
     hp = StandInPath(dev, args.frames, rank) if args.standin else HotPath(dev, args.frames, args.sam_chunk)
 
     def barrier():

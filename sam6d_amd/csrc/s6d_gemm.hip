@@ -159,8 +159,18 @@ __device__ __forceinline__ unsigned pack_f16(float lo, float hi) {
   c.h = (_Float16)hi;
   return (unsigned)a.u | ((unsigned)c.u << 16);
 }
+// bf16: ONE v_cvt_pk_bf16_f32 per dword (round 6; the scalar conversions compile to a conversion per value and an SDWA or).  IEEE half
+// stays value by value: v_cvt_pk_f16_f32 differs from v_cvt_f16_f32 on results below the smallest normal half.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 template <int DT>
-__device__ __forceinline__ unsigned pack_out(float lo, float hi) { return DT == 2 ? pack_f16(lo, hi) : pack_bf16(lo, hi); }
+__device__ __forceinline__ unsigned pack_out(float lo, float hi) {
+#ifdef HIPEMU
+  return DT == 2 ? pack_f16(lo, hi) : pack_bf16(lo, hi);
+#else
+  if constexpr (DT == 2) return pack_f16(lo, hi);
+  else return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){lo, hi}, bf16x2_t));
+#endif
+}
 
 // AMX (DT = 1 only; round 4): the activations carry MX block scales -- one E8M0 byte per row and 32 k (GemmParams::sa_mx) instead of
 // one per row.  The matrix instruction takes exactly that: a lane's scale byte applies to its own 32-k block and op_sel picks the
@@ -448,6 +458,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
   // S6D_GEMM_QT: the 32 x 64 strip of m tile mt.  A lane holds 4 chunks of 8 consecutive columns of its row (chunk 2 nt + k =
   // columns 32 h + 16 nt + 8 k ..); the 4 x 4 transpose inside each lane quad turns that into chunk (lane & 3) of the four rows
   // of the quad, i.e. a quad writes 64 contiguous bytes per instruction
+  char *ep_base = nullptr;                                               // this tile's store base of the lane and the row stride in bytes
+  long ep_row = 0;
   auto epilogue_qt = [&](int mt, int m0, int n0) __attribute__((always_inline)) {
     if (EPI == 5) {
       // GELU, then this lane's 32 columns (32 h + 16 nt + r, r = 0..15: acc[mt][0][*] then acc[mt][1][*]) as one MX block: the
@@ -532,27 +544,14 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
 #pragma unroll
         for (int d = 0; d < 4; ++d) X[2 * nt + k][d] = pack_out<DT>(v[2 * d], v[2 * d + 1]);
       }
-    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      // bit 0 of (chunk index, lane): pairs (0,1), (2,3) with the neighbour lane ^ 1; then bit 1: pairs (0,2), (1,3) with lane ^ 2
-#pragma unroll
-      for (int q = 0; q < 4; q += 2) {
-        const unsigned send = b0 ? X[q][d] : X[q + 1][d];
-        const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
-        X[q][d] = b0 ? recv : X[q][d];
-        X[q + 1][d] = b0 ? X[q + 1][d] : recv;
-      }
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const unsigned send = b1 ? X[q][d] : X[q + 2][d];
-        const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
-        X[q][d] = b1 ? recv : X[q][d];
-        X[q + 2][d] = b1 ? X[q + 2][d] : recv;
-      }
-    }
+    // bit 0 of (chunk index, lane): pairs (0,1), (2,3) with the neighbour lane ^ 1; then bit 1: pairs (0,2), (1,3) with lane ^ 2
+    quad_xchg4<0>(X[0], X[1]);
+    quad_xchg4<0>(X[2], X[3]);
+    quad_xchg4<1>(X[0], X[2]);
+    quad_xchg4<1>(X[1], X[3]);
+    // rows 32 mt + (lane & 28) + y of the wave's 128: ep_base (set once per tile by epilogue()) + a constant row stride
     const int mq = m0 + wr * 128 + mt * 32 + (lane & 28);                // first row of this lane's quad
-    const int col = n0 + wc * 64 + 32 * (lane >> 5) + 8 * (lane & 3);
+    char *dst = ep_base + (long)(mt * 32) * ep_row;
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
       if (S6D_GEMM_ABLATE & 4) {
@@ -560,18 +559,26 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p) {
         asm volatile("" ::"v"(X[y][0]), "v"(X[y][1]), "v"(X[y][2]), "v"(X[y][3]));
 #endif
       } else if (mq + y < p.M) {
-        u16 *dst;
-        if (p.cblk > 0) {
-          const int blk = col / p.cblk;
-          dst = p.C + ((size_t)blk * p.M + (size_t)(mq + y)) * p.cblk + (col - blk * p.cblk);
-        } else {
-          dst = p.C + (size_t)(mq + y) * p.ldc + col;
-        }
-        *reinterpret_cast<uint4 *>(dst) = make_uint4(X[y][0], X[y][1], X[y][2], X[y][3]);
+        *reinterpret_cast<uint4 *>(dst + y * ep_row) = make_uint4(X[y][0], X[y][1], X[y][2], X[y][3]);
       }
     }
   };
   auto epilogue = [&](int m0, int n0, int nm0, int nn0) __attribute__((always_inline)) {   // (nm0, nn0): the next tile (EPI 2)
+    if (S6D_GEMM_QT && EPI != 5) {
+      // store addresses of the tile, once (round 6): element (row, col) lives at C + row ldc + col, or -- column blocks of width
+      // cblk stored as separate (M, cblk) matrices -- at C + ((col / cblk) M + row) cblk + col % cblk; either way the rows of one
+      // column are a constant stride apart, so a strip's stores are base + (32 mt + y) * stride (was: a division per strip)
+      const int row = m0 + wr * 128 + (lane & 28);
+      const int col = n0 + wc * 64 + 32 * (lane >> 5) + 8 * (lane & 3);
+      if (p.cblk > 0) {
+        const int blk = col / p.cblk;
+        ep_base = (char *)(p.C + ((size_t)blk * p.M + (size_t)row) * p.cblk + (col - blk * p.cblk));
+        ep_row = 2 * (long)p.cblk;
+      } else {
+        ep_base = (char *)(p.C + (size_t)row * p.ldc + col);
+        ep_row = 2 * p.ldc;
+      }
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       if (S6D_GEMM_QT) {

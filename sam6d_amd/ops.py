@@ -701,6 +701,13 @@ def gemm_bf16(a, w, bias=None, gelu=False, out=None, max_blocks=0, col_block=0, 
     return out.reshape(*a.shape[:-1], N)
 
 
+def set_gemm_wave_tile(columns):
+    """Which form of the bf16 / f16 GEMM kernel serves the shapes both cover (include/sam6d_hip.h: s6d_set_gemm_wave_tile): 0 = the
+    library's choice per shape, 64 = the eight-wave form, 128 = the four-wave form wherever it applies.  Process-wide; for A/B
+    measurements and the parity tests (the two forms give the same bits)."""
+    _call("s6d_set_gemm_wave_tile", int(columns))
+
+
 def gemm_one_launch_rows(row_stride, elem_bytes=2):
     """Rows ONE launch of the bf16 / f16 GEMM kernels takes for an A operand of ``row_stride`` elements per row: their staging
     addresses are 32-bit byte offsets from A, so a launch stays below 2 GiB, in whole 256-row tiles.  The plain forms walk larger

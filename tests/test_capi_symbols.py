@@ -102,3 +102,34 @@ def test_product_library_carries_no_emulator_code():
         assert "__gfx950__" in out and "HIPEMU" not in out
     blob = open(_lib.SO_PATH, "rb").read()
     assert b"hipemu" not in blob and b"HIPEMU" not in blob
+
+
+def test_gemm4_compiler_code_leaves_the_accumulator_file_alone(tmp_path):
+    """csrc/s6d_gemm4.hip keeps its 256 accumulators in a[0:255] across inline-asm blocks the compiler knows nothing about: that is
+    sound only while the compiler-generated code around the blocks never touches the accumulator file and never spills.  Checked on
+    the generated assembly of every instantiation: outside ;;#ASMSTART / ;;#ASMEND no instruction names an a-register, there is no
+    scratch access, and the kernel descriptors reserve the whole accumulator file behind the architected registers."""
+    import os
+    import re
+    import subprocess
+    src = os.path.join(os.path.dirname(_lib.__file__), "csrc", "s6d_gemm4.hip")
+    out = tmp_path / "g4.s"
+    flags = [f for f in _lib.FLAGS if f not in ("-shared", "-fPIC")] + _lib.file_flags(src)
+    subprocess.check_call([_lib.HIPCC] + flags + ["-S", "--cuda-device-only", "-o", str(out), src], cwd=os.path.dirname(src))
+    text = out.read_text()
+    kernels = re.findall(r"^(_ZN3s6d\w*gemm4_\w+):[^\n]*\n(.*?)s_endpgm", text, flags=re.M | re.S)
+    assert len(kernels) >= 10
+    for name, body in kernels:
+        inside = False
+        for line in body.splitlines():
+            if "#ASMSTART" in line:
+                inside = True
+            elif "#ASMEND" in line:
+                inside = False
+            elif not inside and not line.strip().startswith(";"):
+                assert not re.search(r"\ba\[?\d+|accvgpr", line), f"{name}: compiler code touches the accumulator file: {line.strip()}"
+                assert "scratch_" not in line, f"{name}: spill: {line.strip()}"
+    for m in re.finditer(r"\.amdhsa_kernel (\S*gemm4\S*)(.*?)\.end_amdhsa_kernel", text, flags=re.S):
+        nxt = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(2)).group(1))
+        off = int(re.search(r"\.amdhsa_accum_offset (\d+)", m.group(2)).group(1))
+        assert nxt - off == 256 and nxt <= 512, (m.group(1), nxt, off)

@@ -251,3 +251,55 @@ def test_lnfold_gemm_with_offset_rows(M, N, K):
         true = torch.nn.functional.layer_norm(x.double(), (K,), gamma.double(), beta.double(), 1e-6) @ W.double().t() + b.double()
         rel[off] = ((out.double() - true).pow(2).mean() / true.pow(2).mean()).sqrt().item()
     assert rel[0.0] <= 3e-3 and rel[30.0] <= 1.5 * rel[0.0] + 1e-3, rel
+
+
+@pytest.mark.parametrize("M,N,K,kind,blocks", [
+    (65536, 3840, 1280, "lnfold_cblk", 0),     # qkv of 16 ViT-H frames: folded LayerNorm, head-major column blocks
+    (16384, 5120, 1280, "lnfold_gelu", 0),     # lin1 + GELU
+    (4096, 1280, 5120, "plain", 0),            # 80 K tiles per output tile
+    (256, 256, 128, "gelu", 0),                # the smallest shape of the form: one tile, two K tiles
+    (2560, 512, 128, "plain", 8),              # 20 tiles on 8 workgroups, two K tiles each: the stream changes tile in every iteration
+    (1536, 768, 192, "gelu", 8),               # 18 tiles on 8 workgroups, three K tiles (the ring wraps inside a tile)
+    (1024, 768, 768, "f16_gelu", 0),           # IEEE-half operands
+    (768, 256, 1280, "nobias", 8),
+])
+def test_four_wave_form_gives_the_bits_of_the_eight_wave_form(M, N, K, kind, blocks):
+    """csrc/s6d_gemm4.hip (four waves, 128 x 128 wave tiles, K loop in assembly, accumulators in the accumulator register file) against
+    csrc/s6d_gemm.hip through s6d_set_gemm_wave_tile: the same products in the same order per accumulator and the same epilogue
+    arithmetic -> equal bits, on every epilogue the form covers; ten repeated launches agree bit for bit (a fragment read before its
+    DMA piece landed would show as run-to-run differences); the result is one rounding from the float product."""
+    from sam6d_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    dt = torch.float16 if kind.startswith("f16") else torch.bfloat16
+    a = (torch.randn(M, K, generator=g, device="cuda") * (0.5 + torch.rand(M, 1, generator=g, device="cuda"))).to(dt)
+    w = (torch.randn(N, K, generator=g, device="cuda") / K ** 0.5).to(dt)
+    b = None if kind == "nobias" else torch.randn(N, generator=g, device="cuda")
+    if kind.startswith("lnfold"):
+        st = ops.row_stats(a, 1e-6)
+        cs = w.float().sum(1).contiguous()
+        fn = lambda: ops.gemm_bf16_lnfold(a, st, w, cs, b, gelu=kind == "lnfold_gelu", col_block=80 if kind == "lnfold_cblk" else 0,   # noqa: E731
+                                          max_blocks=blocks)
+    else:
+        fn = lambda: ops.gemm_bf16(a, w, b, gelu=kind.endswith("gelu"), max_blocks=blocks)   # noqa: E731
+    try:
+        ops.set_gemm_wave_tile(64)
+        ref = fn().clone()
+        ops.set_gemm_wave_tile(128)
+        got = fn().clone()
+        assert torch.equal(got, ref), f"{int((got != ref).sum())} of {ref.numel()} values differ from the eight-wave form"
+        for i in range(10):
+            assert torch.equal(fn(), got), f"launch {i} differs"
+    finally:
+        ops.set_gemm_wave_tile(0)
+    if not kind.startswith("lnfold"):
+        want = _ref(a, w, b, kind.endswith("gelu"))
+        err = (got.float() - want).abs()
+        tol = (2.0 ** -11 if dt == torch.float16 else 2.0 ** -8) * want.abs() + 1e-5
+        assert int((err > 1.01 * tol).sum()) == 0, err.max().item()
+
+
+def test_wave_tile_switch_rejects_other_values():
+    from sam6d_amd import _lib
+    L = _lib.lib()
+    assert L.s6d_set_gemm_wave_tile(32) == -1
+    assert L.s6d_set_gemm_wave_tile(0) == 0

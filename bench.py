@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--gemm-wave-tile", type=int, choices=(0, 64, 128), default=0,
                     help="form of the bf16 GEMM kernel (ops.set_gemm_wave_tile): 0 = the library's choice (default), 64 = eight-wave "
                          "form everywhere, 128 = four-wave form wherever it applies -- for same-box A/B runs")
+    ap.add_argument("--strict", action="store_true",
+                    help="sam6d_amd.policy strict mode: a library (rocBLAS / ATen) branch of a module on a CUDA tensor raises, naming the failed guard")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the whole-frame `pipeline` block (all five models)")
@@ -69,6 +71,15 @@ SAM_CHUNK = 16   # frames per SAM encoder launch group: 16 x 4096 tokens per GEM
                  # recorded hipBLASLt solutions 199.0 ms / 32 frames, chunk 16 on the default heuristics 193.0, chunk 32 193.6)
 
 
+def benched_policy():
+    """The configuration this file measures, made explicit: sam6d_amd.policy.PrecisionPolicy.benched() = the
+    library defaults (bf16 SAM ViT-H / mask decoder / DINOv2) + the PEM's ViT-B extractor in IEEE half.  The process environment
+    gets the same value so that the blocks below that re-read it (policy.reload() after switching S6D_SAM_GEMM for the fp8 rows)
+    stay on it; an S6D_PEM_VIT_DTYPE the caller exported wins."""
+    os.environ.setdefault("S6D_PEM_VIT_DTYPE", "fp16")
+    __import__("sam6d_amd.policy").policy.reload()
+
+
 class HotPath:
     """All device state of one rank: models, replicated template data, one batch of frames."""
 
@@ -84,7 +95,8 @@ class HotPath:
         # the fp32 extractor's); half keeps the features within 1e-3 and the pose within the bar (tests/test_gpu_pem.py).  The fp32
         # extractor (library GEMMs) costs 6.4 ms more per 32 instances (profiles/r03_bench_pem_vit_dtype.txt).  The SAM ViT-H -- 87 %
         # of the step -- runs bf16 as configs[1] says.
-        os.environ.setdefault("S6D_PEM_VIT_DTYPE", "fp16")
+        # (the extractor's dtype is the caller's policy: bench.py's main() selects fp16 -- benched_policy() below -- and HotPath
+        # itself changes neither the environment nor the policy)
         self.dev, self.F, self.chunk = device, frames, sam_chunk
         self.sam = seeded.load_seeded(build_vit_h().eval(), 3).to(device=device, dtype=torch.bfloat16)
         self.pem = seeded.load_seeded(pm.Net(pm.default_cfg()).eval(), 1).to(device)
@@ -588,7 +600,7 @@ def fp8_config(hp, dev, args, mode="fp8"):
     if not (ops.have("gemm_fp8") and ops.have("layernorm_fp8")) or (mode == "fp8mx" and not ops.have("gemm_fp8_mx")):
         return {"error": "fp8 kernels not in the library"}
     old = os.environ.get("S6D_SAM_GEMM")
-    os.environ["S6D_SAM_GEMM"] = mode
+    os.environ["S6D_SAM_GEMM"] = mode; __import__("sam6d_amd.policy").policy.reload()
     try:
         for _ in range(max(1, args.warmup)):
             hp.step()
@@ -613,7 +625,7 @@ def fp8_config(hp, dev, args, mode="fp8"):
                              "traffic_source": "profiles/r0*_pmc_summary.json (stored rocprofv3 --pmc passes, not this run)"},
                 "kernels": kr, "accuracy_gate": "tests/test_gpu_fp8.py"}
     finally:
-        os.environ.pop("S6D_SAM_GEMM") if old is None else os.environ.__setitem__("S6D_SAM_GEMM", old)
+        os.environ.pop("S6D_SAM_GEMM") if old is None else os.environ.__setitem__("S6D_SAM_GEMM", old); __import__("sam6d_amd.policy").policy.reload()
 
 
 
@@ -669,11 +681,11 @@ def _extras(extra, hp, dev, args, world):
     for dt_ in ("fp32", "fp16", "bf16"):
         if dt_ == cur:
             continue
-        os.environ["S6D_PEM_VIT_DTYPE"] = dt_
+        os.environ["S6D_PEM_VIT_DTYPE"] = dt_; __import__("sam6d_amd.policy").policy.reload()
         try:
             alt[dt_] = round(stage_ms(hp.pem_stage, 1), 2)
         finally:
-            os.environ["S6D_PEM_VIT_DTYPE"] = cur
+            os.environ["S6D_PEM_VIT_DTYPE"] = cur; __import__("sam6d_amd.policy").policy.reload()
     # parity of each extractor dtype is NOT measured by this run: tests/test_gpu_pem.py::test_net_forward_well_conditioned_vs_
     # reference_golden holds fp32 / fp16 to 1e-3 mm against tests/golden/pem_wc.npz and records the margins
     # (profiles/r*_parity_margins_final.jsonl)
@@ -724,7 +736,7 @@ def _extras(extra, hp, dev, args, world):
             if isinstance(extra.get("configs", {}).get(best), dict) and "error" not in extra["configs"][best]:
                 # the same whole frame in the fp8 configuration: SAM ViT-H AND DINOv2 ViT-L on the fp8 cores (fp8mx: lin2 / fc2 too)
                 old = {k: os.environ.get(k) for k in ("S6D_SAM_GEMM", "S6D_DINO_GEMM")}
-                os.environ.update(S6D_SAM_GEMM=best, S6D_DINO_GEMM=best)
+                os.environ.update(S6D_SAM_GEMM=best, S6D_DINO_GEMM=best); __import__("sam6d_amd.policy").policy.reload()
                 try:
                     torch.cuda.empty_cache()
                     pf = frame_demo.measure(dev, built=built)
@@ -824,7 +836,11 @@ def main():
         assert dist.get_world_size() == args.gpus
 
     if args.config in ("fp8", "fp8mx"):
-        os.environ["S6D_SAM_GEMM"] = args.config
+        os.environ["S6D_SAM_GEMM"] = args.config; __import__("sam6d_amd.policy").policy.reload()
+    if not args.standin:
+        benched_policy()
+    if args.strict and not args.standin:
+        os.environ["S6D_STRICT"] = "1"; __import__("sam6d_amd.policy").policy.reload()
     if args.gemm_wave_tile and not args.standin:
         from sam6d_amd import ops as _ops
         global _GEMM_WAVE_TILE
@@ -862,6 +878,9 @@ def main():
 
     ms_step = dt / args.steps * 1e3
     value = world * args.frames * args.steps / dt
+    # library (rocBLAS / ATen) branches the modules took on CUDA tensors during warm-up + the timed steps (sam6d_amd/policy.py::guard):
+    # the benched step is expected to take none
+    lib_hits = {} if args.standin else {f"{s}:{g}": n for (s, g), n in __import__("sam6d_amd.policy").policy.library_branch_hits().items()}
     if dist is not None:
         # the process group ends HERE, with every rank present: rank 0 goes on alone into minutes of side measurements, and a
         # destroy_process_group issued after the other ranks have exited may wait on them
@@ -870,7 +889,7 @@ def main():
         dist = None
 
     # stage breakdown + roofline of the dominant stage (rank 0 only; outside the timed region)
-    extra = {}
+    extra = {"library_branches_in_the_timed_steps": lib_hits, "strict": bool(args.strict)}
     if args.standin:
         extra["standin"] = True
         extra["gathered_rows"] = int(last.shape[0])

@@ -28,6 +28,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from .. import policy
 from ..utils.linear import eligible, fused_linear, lnfold_cached, lnfold_eligible
 
 descriptor_size = {"dinov2_vits14": 384, "dinov2_vitb14": 768, "dinov2_vitl14": 1024, "dinov2_vitg14": 1536}
@@ -37,7 +38,7 @@ RGB_MEAN, RGB_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)      # dinov2.p
 
 
 def _dtype():
-    return {"fp32": torch.float32, "bf16": torch.bfloat16}[os.environ.get("S6D_DINO_DTYPE", "bf16")]
+    return {"fp32": torch.float32, "bf16": torch.bfloat16}[policy.current().dino_dtype]
 
 
 class PatchEmbed(nn.Module):
@@ -196,8 +197,8 @@ class DinoVisionTransformer(nn.Module):
 
     def _fusable(self, x):
         hd = self.embed_dim // self.num_heads
-        return (x.is_cuda and x.dtype == torch.bfloat16 and hd in (64, 80) and ops.have("seq_attention") and
-                ops.have("add_layernorm"))
+        return policy.guard("ism.DinoVisionTransformer", cuda=x.is_cuda, bf16=x.dtype == torch.bfloat16, head_dim=hd in (64, 80),
+                            have=ops.have("seq_attention") and ops.have("add_layernorm"))
 
     def _blocks_fused(self, x):
         """Residual stream through all blocks + the final norm; returns (x_prenorm, x_norm)."""
@@ -207,7 +208,7 @@ class DinoVisionTransformer(nn.Module):
         C = x.shape[-1]
         exact_gelu = all(isinstance(blk.mlp.act, nn.GELU) and blk.mlp.act.approximate == "none" for blk in self.blocks)
         rows = x.numel() // C
-        if os.environ.get("S6D_DINO_GEMM", "bf16") in ("fp8", "fp8mx"):
+        if policy.current().dino_gemm in ("fp8", "fp8mx"):
             return self._blocks_fp8(x, scale, exact_gelu)
         if (exact_gelu and C % 256 == 0 and all(lnfold_eligible(x, C, C) and lnfold_eligible(x, blk.mlp.fc1.out_features, C) and
                                                 lnfold_eligible(x, C, blk.mlp.fc1.out_features) for blk in self.blocks)
@@ -286,7 +287,7 @@ class DinoVisionTransformer(nn.Module):
         x2 = x.view(rows, C)
         # S6D_DINO_GEMM=fp8mx: fc2 too, fed by fc1's MX-scaled e4m3 output (s6d_gemm_fp8_gelu_mx -> s6d_gemm_fp8_mxa, as the SAM
         # encoder's fp8mx loop); fc2's bf16 output is the delta the next quantising LayerNorm adds
-        mx = os.environ.get("S6D_DINO_GEMM") == "fp8mx" and ops.have("gemm_fp8_mx")
+        mx = policy.current().dino_gemm == "fp8mx" and ops.have("gemm_fp8_mx")
         delta = None
         for blk in self.blocks:
             wp, bp, bpf, w2, b2, b2f = blk._folded(x.dtype)

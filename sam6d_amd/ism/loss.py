@@ -17,6 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from .. import policy
 
 
 _FLOATS = (torch.float32, torch.float16, torch.bfloat16)
@@ -31,7 +32,8 @@ class PairwiseSimilarity(nn.Module):
     def forward(self, query, reference):
         """query (P,C), reference (O,T,C) -> (P,O,T) in [0,1]."""
         O, T, C = reference.shape
-        if ops.have("pairwise_cosine") and query.is_cuda and query.dtype in _FLOATS and reference.dtype in _FLOATS:
+        if policy.guard("ism.PairwiseSimilarity", cuda=query.is_cuda, have=ops.have("pairwise_cosine"),
+                        float_dtypes=query.dtype in _FLOATS and reference.dtype in _FLOATS):
             # fp16 / bf16 descriptors (the BOP flow runs under Lightning precision=16, configs/machine/trainer/local.yaml:9) take
             # the same kernel: it accumulates in fp32 either way, and under autocast the reference's cosine_similarity is an
             # fp32 op with an fp32 result -- which is what comes back here
@@ -50,8 +52,9 @@ class MaskedPatch_MatrixSimilarity(nn.Module):
     def both(self, query, reference, thred=0.5):
         """(appearance score (S), visible ratio (S)) from one similarity pass."""
         S, N2 = reference.shape[0], reference.shape[1]
-        if ops.have("patch_scores") and query.is_cuda and query.dtype in _FLOATS and reference.dtype in _FLOATS \
-                and N2 <= 256 and query.shape[-1] % 32 == 0:
+        if policy.guard("ism.MaskedPatch_MatrixSimilarity", cuda=query.is_cuda, have=ops.have("patch_scores"),
+                        float_dtypes=query.dtype in _FLOATS and reference.dtype in _FLOATS, patches_le_256=N2 <= 256,
+                        C32=query.shape[-1] % 32 == 0):
             # the kernel addresses a resident (O,T,N2,C) store by (object, template): a materialised (S,N2,C) reference
             # is the store of ONE object whose "templates" are the S rows
             obj = torch.zeros(S, dtype=torch.int32, device=query.device)

@@ -11,6 +11,7 @@ INTEGRATION.md shows the two-line change that mixes it into the reference class.
 import torch
 
 from .. import ops
+from .. import policy
 from .loss import MaskedPatch_MatrixSimilarity
 
 
@@ -29,7 +30,7 @@ def masked_depth_translation(masks, depth, K, depth_scale):
     """Mean back-projected point of each mask (utils/trimesh_utils.py:77-105 applied to
     mask*depth, detector.py:234-246) without the (S,H,W) ``repeat``: three masked sums."""
     S, H, W = masks.shape
-    if ops.have("masked_depth_mean") and masks.is_cuda:
+    if policy.guard("ism.masked_depth_mean", cuda=masks.is_cuda, have=ops.have("masked_depth_mean")):
         return ops.masked_depth_mean(masks.to(torch.float32).contiguous(), depth.to(torch.float32).contiguous(), K,
                                      float(depth_scale))
     # dtype trail of the reference: Z float32; X, Y float64 (the camera matrix is a float64 tensor
@@ -68,8 +69,8 @@ class ScoringMixin:
         scores = cfg.metric(proposal_decriptors, self.ref_data["descriptors"])     # (P,O,T)
         agg = cfg.aggregation_function
         topk = {"mean": scores.shape[-1], "max": 1, "avg_5": 5}.get(agg)
-        if topk is not None and ops.have("semantic_select") and scores.is_cuda and scores.dtype == torch.float32 \
-                and scores.shape[-1] <= 256:
+        if topk is not None and policy.guard("ism.compute_semantic_score", cuda=scores.is_cuda, have=ops.have("semantic_select"),
+                                             f32=scores.dtype == torch.float32, T_le_256=scores.shape[-1] <= 256):
             # one kernel: per-object top-k mean, arg-max object, best template of that object
             score_per_proposal, assigned, best_t = ops.semantic_select(scores.contiguous(), topk)
             idx_selected = torch.nonzero(score_per_proposal > cfg.confidence_thresh).squeeze(1)
@@ -98,8 +99,9 @@ class ScoringMixin:
         store = self.ref_data["appe_descriptors"]
         thred = getattr(self, "visible_thred", 0.5)
         halfs = (torch.float16, torch.bfloat16)
-        if ops.have("patch_scores") and qurey_appe_descriptors.is_cuda and store.is_contiguous() and store.shape[2] <= 256 \
-                and store.dtype in (torch.float32,) + halfs and qurey_appe_descriptors.dtype in (torch.float32,) + halfs:
+        if policy.guard("ism.compute_appearance_score", cuda=qurey_appe_descriptors.is_cuda, have=ops.have("patch_scores"),
+                        contiguous_store=store.is_contiguous(), patches_le_256=store.shape[2] <= 256,
+                        dtypes=store.dtype in (torch.float32,) + halfs and qurey_appe_descriptors.dtype in (torch.float32,) + halfs):
             # half descriptors (BOP flow under precision=16): the resident store is converted ONCE per store tensor and kept (it
             # is read-only template data); the query of the frame is converted per call.  fp32 arithmetic inside the kernel.
             if store.dtype != torch.float32:
@@ -155,7 +157,7 @@ class ScoringMixin:
         t = self.Calculate_the_query_translation(proposals, depth, K, batch["depth_scale"])
         H, W = depth.shape
         poses, pcs = self.ref_data["poses"], self.ref_data["pointcloud"]
-        if ops.have("project_bbox") and t.is_cuda and poses.dtype == torch.float32 and pcs.dtype == torch.float32:
+        if policy.guard("ism.project_bbox", cuda=t.is_cuda, have=ops.have("project_bbox"), f32=poses.dtype == torch.float32 and pcs.dtype == torch.float32):
             uv, bbox = ops.project_bbox(pcs.contiguous(), poses.contiguous(), pred_object_idx.int().contiguous(),
                                         best_pose.int().contiguous(), t.contiguous(),
                                         K.to(device=t.device, dtype=torch.float32).contiguous(), H, W)

@@ -10,6 +10,7 @@ import os
 import torch
 
 from . import _lib
+from . import policy
 
 _vp = ctypes.c_void_p
 
@@ -1136,7 +1137,7 @@ def masked_depth_mean(masks, depth, K, depth_scale, frame=None, sel=None):
         _chk(frame, torch.int32, "frame", 1)
         if K.dim() != 3 or tuple(K.shape[1:]) != (3, 3) or K.shape[0] != depth.shape[0] or frame.shape[0] != S:
             raise ValueError(f"batched call: depth (F,H,W), K (F,3,3), frame (S); got {tuple(depth.shape)}, {tuple(K.shape)}, {tuple(frame.shape)}")
-    if frame is not None and os.environ.get("S6D_DEBUG") and S:          # costs a host round trip: debug runs only
+    if frame is not None and policy.current().debug and S:          # costs a host round trip: debug runs only
         lo, hi = int(frame.min()), int(frame.max())
         if lo < 0 or hi >= depth.shape[0]:
             raise ValueError(f"frame indices span [{lo}, {hi}] but there are {depth.shape[0]} frames")
@@ -1182,7 +1183,8 @@ def have(name):
                "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_sel_f32",
                "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "im2col3x3": "s6d_im2col3x3_b16", "nonfinite_rows": "s6d_nonfinite_rows_f32", "patchify": "s6d_patchify_b16", "crop_resize_pad": "s6d_crop_resize_pad_f32", "samdec_img2tok": "s6d_samdec_img2tok_bf16", "samdec_img2tok_raw": "s6d_samdec_img2tok_raw_bf16", "samdec_tok2img": "s6d_samdec_tok2img_f32", "samdec_tok2img_raw": "s6d_samdec_tok2img_raw_bf16", "sam_mask_post": "s6d_sam_mask_post_sel_f32", "gemm_fp8_mx": "s6d_gemm_fp8_mxa", "nms": "s6d_nms_f32", "samdec_upscale_heads": "s6d_samdec_upscale_heads_bf16", "mha": "s6d_mha_f32",
                "linear_attn_focus": "s6d_linear_attn_focus_f32", "linear_attention": "s6d_linear_attention_f32", "project_bbox": "s6d_project_bbox_frames_f32"}.get(name)
-        import os
-        disabled = name in os.environ.get("S6D_DISABLE_FUSED", "").split(",")
-        _FUSED[name] = (not disabled) and sym is not None and hasattr(_lib.lib(), sym)
+        _FUSED[name] = sym is not None and hasattr(_lib.lib(), sym)
+    # (policy.disable_fused: kernel names the modules must not use -- the tests' way of forcing the library statement)
+    if policy.current().disable_fused and name in policy.current().disable_fused.split(","):
+        return False
     return _FUSED[name]

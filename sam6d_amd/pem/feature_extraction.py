@@ -19,6 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from .. import policy
 from ..utils.linear import fused_linear
 
 
@@ -42,7 +43,7 @@ def _vit_dtype():
     """S6D_PEM_VIT_DTYPE = fp32 (default) | fp16 | bf16.  fp16: the fused pipeline in IEEE half -- the matrix rate of bf16 with an
     11-bit significand: extractor features within 1e-3 of fp32's (bf16: 7.6e-3), pose within north_star's 1e-3 / 1e-3 mm of the
     reference on the well-conditioned golden (tests/test_gpu_pem.py); bf16 misses the translation bar by 1.3-2x."""
-    name = _FORCE_DTYPE[-1] if _FORCE_DTYPE else os.environ.get("S6D_PEM_VIT_DTYPE", "fp32")
+    name = _FORCE_DTYPE[-1] if _FORCE_DTYPE else policy.current().pem_vit_dtype
     return {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[name]
 
 
@@ -118,8 +119,8 @@ class ViT(nn.Module):
         d = len(self.blocks)
         n = d // 4
         taps = (d - 3 * n - 1, d - 2 * n - 1, d - n - 1, d - 1)
-        if x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and ops.have("seq_attention") and ops.have("add_layernorm") \
-                and (x.dtype == torch.bfloat16 or ops.have("gemm_f16")):
+        if policy.guard("pem.ViT.forward", cuda=x.is_cuda, half_dtype=x.dtype in (torch.bfloat16, torch.float16),
+                        have=ops.have("seq_attention") and ops.have("add_layernorm") and (x.dtype == torch.bfloat16 or ops.have("gemm_f16"))):
             return self._forward_fused(x, taps)
         out = []
         for i, blk in enumerate(self.blocks):
@@ -230,7 +231,7 @@ class ViT_AE(nn.Module):
         56x56 pixel-shuffled map evaluated only where needed."""
         B, _, H, W = x.shape
         up = self.tokens_up(x)
-        if ops.have("upsample_gather") and up.is_cuda:
+        if policy.guard("pem.ViT_AE.upsample_gather", cuda=up.is_cuda, have=ops.have("upsample_gather")):
             return ops.upsample_gather(up.contiguous(), choose, H, W, self.out_dim)
         return _upsample_gather_lib(up, choose, H, W, self.out_dim)
 

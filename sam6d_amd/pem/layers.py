@@ -18,6 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from .. import policy
 
 HEADS = 4
 
@@ -46,8 +47,8 @@ def plinear(owner, lins, x, relu=False, residual=None, norm=None):
     lins = lins if isinstance(lins, (tuple, list)) else (lins,)
     N = sum(l.weight.shape[0] for l in lins)
     K = lins[0].weight.shape[1]
-    if (ops.have("linear_f32") and x.is_cuda and x.dtype == torch.float32 and K % 32 == 0 and N % 256 == 0
-            and (norm is None or N == 256) and not torch.is_grad_enabled()):
+    if policy.guard("pem.plinear", cuda=x.is_cuda, have=ops.have("linear_f32"), f32=x.dtype == torch.float32, K32=K % 32 == 0,
+                    N256=N % 256 == 0, norm_width=norm is None or N == 256, no_grad=not torch.is_grad_enabled()):
         hi, lo, b = _plin_weights(owner, lins)
         x2 = x if x.stride(-1) == 1 and x.is_contiguous() else x.contiguous()
         r2 = None if residual is None else residual.contiguous()
@@ -95,7 +96,7 @@ class MultiHeadAttention(nn.Module):
         self.scale = 1.0 / math.sqrt(d_model // num_heads)
 
     def forward(self, xq, xk, xv):
-        if ops.have("mha") and xq.is_cuda and xq.shape[-1] == 256:
+        if policy.guard("pem.MultiHeadAttention", cuda=xq.is_cuda, have=ops.have("mha"), C256=xq.shape[-1] == 256):
             C = xq.shape[-1]
             q = plinear(self, self.proj_q, xq)
             if xk is xv:                                              # k | v of the memory in one launch
@@ -148,8 +149,9 @@ class RPEMultiHeadAttention(nn.Module):
 
     def forward(self, x, embed):
         B, N, C = x.shape
-        if (ops.have("rpe_attention_packed") and ops.have("linear_f32") and x.is_cuda and x.dtype == torch.float32 and C == 256
-                and not torch.is_grad_enabled() and os.environ.get("S6D_RPE_FOLD", "1") == "1"):
+        if policy.guard("pem.RPEMultiHeadAttention", cuda=x.is_cuda, have=ops.have("rpe_attention_packed") and ops.have("linear_f32"),
+                        f32=x.dtype == torch.float32, C256=C == 256, no_grad=not torch.is_grad_enabled(),
+                        rpe_fold=policy.current().rpe_fold == "1"):
             # q | k | v | q~ | qb from ONE launch of the projection kernel; the attention core reads them in place
             proj = plinear(self, (self.proj_q, self.proj_k, self.proj_v, self._fold()), x)
             return ops.rpe_attention_packed(proj, embed, self.scale)
@@ -248,13 +250,14 @@ class LinearAttention(nn.Module):
 
     def forward(self, xq, xkv):
         inv_scale = 1.0 / F.softplus(self.scale)
-        if ops.have("linear_attn_focus") and xq.is_cuda and xq.shape[-1] == 256:
+        if policy.guard("pem.LinearAttention.focus", cuda=xq.is_cuda, have=ops.have("linear_attn_focus"), C256=xq.shape[-1] == 256):
             focus = lambda t: ops.linear_attn_focus(t, inv_scale, self.focusing_factor)   # noqa: E731  one fused pass
         else:
             focus = lambda t: self._focus(t, inv_scale)                                    # noqa: E731
         C = xq.shape[-1]
         kv_ = plinear(self, (self.proj_k, self.proj_v), xkv)         # k | v of the memory in one launch
-        if ops.have("linear_attention") and ops.have("linear_attn_focus") and xq.is_cuda and C == 256 and xq.dtype == torch.float32:
+        if policy.guard("pem.LinearAttention", cuda=xq.is_cuda, have=ops.have("linear_attention") and ops.have("linear_attn_focus"),
+                        C256=C == 256, f32=xq.dtype == torch.float32):
             # everything behind the projections in two launches (csrc/s6d_linattn.hip): the focus map of q, k^T v, q . sum k, (q kv) z
             # and the head merge; k | v stay the two halves of the one projection output (strided rows)
             return ops.linear_attention(plinear(self, self.proj_q, xq), inv_scale, self.focusing_factor, focus(kv_[..., :C].contiguous()),
@@ -357,7 +360,7 @@ class GeometricStructureEmbedding(nn.Module):
     def _split_weights(self):
         """(W_d, W_a) as [hi | lo] bf16 parts for s6d_geo_embedding_split, cached until a weight changes (round 5: every workgroup
         of the kernel used to split both matrices again in each of its eight k-steps)."""
-        if not (ops.have("geo_embedding_split") and os.environ.get("S6D_GEO_PRESPLIT", "1") == "1"):
+        if not (ops.have("geo_embedding_split") and policy.current().geo_presplit == "1"):
             return None
         ws = (self.proj_d.weight, self.proj_a.weight)
         key = tuple((w._version, w.data_ptr(), w.dtype) for w in ws)
@@ -386,12 +389,13 @@ class GeometricStructureEmbedding(nn.Module):
         return dist / self.sigma_d, torch.atan2(sin_v, cos_v) * self.factor_a
 
     def forward(self, points):
-        if ops.have("geo_embedding") and points.is_cuda and self.angle_k == 3 and self.proj_d.weight.shape[0] == 256:
+        if policy.guard("pem.GeometricStructureEmbedding", cuda=points.is_cuda, have=ops.have("geo_embedding"), angle_k3=self.angle_k == 3,
+                        C256=self.proj_d.weight.shape[0] == 256):
             d_idx, a_idx = self.get_embedding_indices(points)
             idx4 = torch.cat([d_idx.unsqueeze(-1), a_idx], dim=-1).contiguous()          # (B,N,N,4)
             # S6D_PEM_GEO_DTYPE=fp16: the embedding is STORED in IEEE half (same arithmetic up to the store); its twelve readers
             # (rpe_attention_kernel, bound by streaming it) then move half the bytes.  Measured margins: DESIGN.md 4.
-            half = os.environ.get("S6D_PEM_GEO_DTYPE", _GEO_DTYPE_DEFAULT) == "fp16" and ops.have("geo_embedding_f16")
+            half = policy.current().pem_geo_dtype == "fp16" and ops.have("geo_embedding_f16")
             return ops.geo_embedding(idx4, self.proj_d.weight.contiguous(), self.proj_d.bias, self.proj_a.weight.contiguous(),
                                      self.proj_a.bias, self.embedding.div_term.contiguous(),
                                      out_dtype=torch.float16 if half else torch.float32, split=self._split_weights())

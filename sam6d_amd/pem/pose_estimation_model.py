@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from .. import policy
 from .feature_extraction import ViTEncoder
 from .layers import GeometricStructureEmbedding, GeometricTransformer, SparseToDenseTransformer, plinear
 from .solvers import coarse_Rt, fine_Rt
@@ -128,7 +129,7 @@ class PositionalEncoding(nn.Module):
         outs = []
         for mlp, (r, ns) in zip((self.mlp1, self.mlp2), self.scales):
             idx = ops.ball_query(pts, pts, r, ns)                                   # (B,N,ns) i32
-            if ops.have("pe_group") and pts.is_cuda and not self.training:
+            if policy.guard("pem.PositionalEncoding", cuda=pts.is_cuda, have=ops.have("pe_group"), eval_mode=not self.training):
                 (W0, b0), (W1, b1), (W2, b2) = (layer.folded() for layer in mlp.layers())
                 outs.append(ops.pe_group_mlp(pts, idx, W0, b0, W1, b1, W2, b2))     # (B,N,128), nothing else hits HBM
                 continue
@@ -172,7 +173,7 @@ class FinePointMatching(nn.Module):
         o1 = torch.cat([plinear(self, self.out_proj, f1[0].contiguous()), plinear(self, self.out_proj, f1[1])], dim=1)
         o2 = torch.cat([plinear(self, self.out_proj, f2[0].contiguous()), plinear(self, self.out_proj, f2[1])], dim=1)
         model = end_points["model"] / (radius.reshape(-1, 1, 1) + 1e-6)
-        if ops.have("fine_match") and o1.is_cuda and o1.dtype == torch.float32 and o1.shape[2] == 256:
+        if policy.guard("pem.FinePointMatching", cuda=o1.is_cuda, have=ops.have("fine_match"), f32=o1.dtype == torch.float32, C256=o1.shape[2] == 256):
             # similarity tiles are formed inside the assignment kernel: the (B,2049,2049) matrix is never written
             R, t, score = fine_Rt(None, p1, p2, model, feats=(o1, o2, self.cfg.temp))
         else:
@@ -232,7 +233,7 @@ class Net(nn.Module):
         if bad is None:
             return out
         out["f16_overflow"] = bad
-        if (bad.is_cuda and torch.cuda.is_current_stream_capturing()) or os.environ.get("S6D_PEM_F16_GUARD", "1") == "0":
+        if (bad.is_cuda and torch.cuda.is_current_stream_capturing()) or policy.current().pem_f16_guard == "0":
             return out
         if not bool(bad.any()):
             return out

@@ -27,6 +27,8 @@ import os
 
 import torch
 
+from .. import policy
+
 MEAN = (0.485, 0.456, 0.406)
 STD = (0.229, 0.224, 0.225)
 
@@ -223,7 +225,7 @@ def _finish(image_u8, m, box, kept, pts, ch, img_size, rgb_mask_flag, rgb=None):
 def _keyed_indices(n, keys, n_sample):
     """The defined sampler: (P,n_sample) in-list positions from one uniform per crop pixel."""
     dev = n.device
-    use_kernel = _use_kernels(n) and os.environ.get("S6D_PEM_SAMPLER") != "library"
+    use_kernel = _use_kernels(n) and policy.current().pem_sampler != "library"
     if use_kernel and keys.dtype == torch.float32 and keys.is_contiguous() and n_sample <= 2048:
         # one workgroup per detection (s6d_pem_sample_indices_f32) instead of a top-k over a (P, L) table of 64-bit keys; no host
         # round trip for L
@@ -267,7 +269,7 @@ _SLOT_BYTES = 1 << 30          # bound on the fixed-capacity point slots of one 
 def _use_kernels(t):
     """The csrc/s6d_pempre.hip path: device tensors, library present, not switched off (S6D_PEM_PRE=library)."""
     from .. import ops
-    return t.is_cuda and os.environ.get("S6D_PEM_PRE") != "library" and ops.have("pem_pre")
+    return t.is_cuda and policy.current().pem_pre != "library" and ops.have("pem_pre")
 
 
 def _segment_seq_sum(x, start, count):

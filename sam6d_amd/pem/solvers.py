@@ -9,6 +9,7 @@ them (ops.have), and as device-side library ops otherwise.
 import torch
 
 from .. import ops
+from .. import policy
 
 
 def soft_assignment(atten):
@@ -22,7 +23,7 @@ def soft_assignment(atten):
 
 def rotation_from_H(H):
     """R = V diag(1,1,det(V U^T)) U^T for H = U S V^T (model_utils.py:343-347)."""
-    if ops.have("rot_from_h") and H.is_cuda:
+    if policy.guard("pem.rot_from_h", cuda=H.is_cuda, have=ops.have("rot_from_h")):
         return ops.rot_from_h(H.contiguous())
     U, _, Vh = torch.linalg.svd(H.double())
     V = Vh.transpose(-1, -2)
@@ -34,7 +35,8 @@ def rotation_from_H(H):
 def weighted_procrustes(src, ref, weights=None, weight_thresh=0.0, eps=1e-5):
     if weights is None:
         weights = torch.ones_like(src[..., 0])
-    if ops.have("weighted_procrustes") and src.is_cuda and src.dim() == 3 and src.dtype == torch.float32:
+    if policy.guard("pem.weighted_procrustes", cuda=src.is_cuda, have=ops.have("weighted_procrustes"), batched=src.dim() == 3,
+                    f32=src.dtype == torch.float32):
         # one launch, fixed summation order per instance: the pose of an instance does not depend on the batch it is in
         return ops.weighted_procrustes(src.contiguous(), ref.contiguous(), weights.contiguous(), weight_thresh, eps)
     weights = torch.where(weights < weight_thresh, torch.zeros_like(weights), weights)
@@ -50,7 +52,7 @@ def weighted_procrustes(src, ref, weights=None, weight_thresh=0.0, eps=1e-5):
 def min_dist_to_model(pts, R, t, model):
     """For every pose p and point n: min_m || (pts[n] - t_p) R_p - model[m] ||.
     pts (B,N,3), R (B,P,3,3), t (B,P,3), model (B,Nm,3) -> (B,P,N)."""
-    if ops.have("min_dist") and pts.is_cuda:
+    if policy.guard("pem.min_dist", cuda=pts.is_cuda, have=ops.have("min_dist")):
         return ops.min_dist(pts.contiguous(), R.contiguous(), t.contiguous(), model.contiguous())
     tp = (pts.unsqueeze(1) - t.unsqueeze(2)) @ R                       # (B,P,N,3)
     out = []
@@ -64,8 +66,8 @@ def coarse_Rt(atten, pts1, pts2, model_pts, rand_u, n1=6000, n2=300):
     """compute_coarse_Rt.  rand_u (B, 3*n1) are the uniform samples (drawn by the caller)."""
     B, N1, _ = pts1.shape
     N2 = pts2.shape[1]
-    if ops.have("coarse_sample") and atten.is_cuda and atten.dtype == torch.float32 and N2 + 1 <= 256 \
-            and N1 * N2 * 4 <= 152 * 1024 and n1 <= 16384:
+    if policy.guard("pem.compute_coarse_Rt", cuda=atten.is_cuda, have=ops.have("coarse_sample"), f32=atten.dtype == torch.float32,
+                    N2_le_255=N2 + 1 <= 256, lds=N1 * N2 * 4 <= 152 * 1024, n1_le_16384=n1 <= 16384):
         # five launches: sampling head (dual softmax, labels, ^1.5, prefix sums, search) -> hypotheses -> the n2 smallest residuals
         # -> nearest-model-point scan -> scored arg-max
         pair, w1 = ops.coarse_sample(atten.contiguous(), rand_u.contiguous())
@@ -78,7 +80,7 @@ def coarse_Rt(atten, pts1, pts2, model_pts, rand_u, n1=6000, n2=300):
     cum = torch.cumsum(score, dim=1)
     cum = cum / (cum[:, -1:].contiguous() + 1e-8)
     pair = torch.searchsorted(cum, rand_u.contiguous())
-    if ops.have("pose_hypotheses") and pts1.is_cuda:
+    if policy.guard("pem.pose_hypotheses", cuda=pts1.is_cuda, have=ops.have("pose_hypotheses")):
         Rs, ts, dis = ops.pose_hypotheses(pts1.contiguous(), pts2.contiguous(), pair.int().contiguous())
     else:
         i1 = torch.clamp(pair.div(N2, rounding_mode="floor"), max=N1 - 1)
@@ -100,12 +102,13 @@ def coarse_Rt(atten, pts1, pts2, model_pts, rand_u, n1=6000, n2=300):
 def fine_Rt(atten, pts1, pts2, model_pts, dis_thres=0.15, feats=None):
     """compute_fine_Rt.  feats = (f1, f2, temp): the out_proj features the similarity is made of -- with them the fused kernel
     forms similarity tiles on the fly and ``atten`` (the (B,2049,2049) matrix) may be None."""
-    if feats is not None and ops.have("fine_match") and feats[0].is_cuda and feats[0].shape[2] == 256 \
-            and feats[0].dtype == torch.float32:
+    if feats is not None and policy.guard("pem.compute_fine_Rt", cuda=feats[0].is_cuda, have=ops.have("fine_match"),
+                                          C256=feats[0].shape[2] == 256, f32=feats[0].dtype == torch.float32):
         pred, wsum, w1 = ops.fine_match(feats[0].contiguous(), feats[1].contiguous(), pts2.contiguous(), float(feats[2]))
     elif atten is None:
         raise ValueError("fine_Rt needs the similarity matrix when the fused similarity kernel is not available")
-    elif ops.have("fine_assign") and atten.is_cuda and atten.shape[2] <= 2112 and pts2.shape[1] == atten.shape[2] - 1:
+    elif policy.guard("pem.compute_fine_Rt.assign", cuda=atten.is_cuda, have=ops.have("fine_assign"), cols=atten.shape[2] <= 2112,
+                      background_column=pts2.shape[1] == atten.shape[2] - 1):
         pred, wsum, w1 = ops.fine_assign(atten.contiguous(), pts2.contiguous())
     else:
         amat, w1, _ = soft_assignment(atten)

@@ -21,6 +21,7 @@ from types import SimpleNamespace
 
 import torch
 
+from . import policy
 from .ism.handoff import Detections
 from .pem import preprocess as pem_pre
 from .sam import amg
@@ -53,7 +54,7 @@ class FramePipeline:
         self.nms_thresh, self.det_thresh = nms_per_object_thresh, det_score_thresh
         self.times = {}
         self.sync_stages = sync_stages
-        self.graph_max = int(os.environ.get("S6D_PEM_GRAPH_MAX", "16"))      # instance counts up to this one replay a captured graph
+        self.graph_max = int(policy.current().pem_graph_max)      # instance counts up to this one replay a captured graph
         self._pem_graphs = {}
         # a captured graph bakes the weights' addresses and derived buffers in: the fingerprint in _pem_graph_key sees version bumps and
         # re-allocations, a load_state_dict is caught here (in-place `.data` edits bump no version: call invalidate_graphs())
@@ -144,7 +145,7 @@ class FramePipeline:
         Measured (tools/probes/desc_group_ab*.py): the ViT alone runs 21.9 instead of 25.6 ms per 128 crops in batches of 255, but a
         group gains only 0.7 ms per frame (61.4 vs 62.1 ms): frame by frame the ViT starts on a cool socket after the mask decoder
         (23.6 ms), four full batches back to back run at the power limit.  S6D_DESC_GROUP=0: frame by frame (A/B runs)."""
-        if len(frames) == 1 or not (hasattr(self.desc, "frame_batcher") and os.environ.get("S6D_DESC_GROUP", "1") == "1"):
+        if len(frames) == 1 or not (hasattr(self.desc, "frame_batcher") and policy.current().desc_group == "1"):
             return [self._detect(emb[i:i + 1], f[0], f[1], f[2]) for i, f in enumerate(frames)]
         t0 = time.perf_counter()
         fb, props = self.desc.frame_batcher(), []
@@ -171,7 +172,7 @@ class FramePipeline:
         instance so that a few graphs serve every frame."""
         M = ep["pts"].shape[0]
         dev = ep["pts"].device
-        if not (dev.type == "cuda" and M <= self.graph_max and os.environ.get("S6D_PEM_GRAPH", "1") == "1"):
+        if not (dev.type == "cuda" and M <= self.graph_max and policy.current().pem_graph == "1"):
             return self.pem(ep)
         Mp = (M + 1) // 2 * 2
         keys = ("pts", "rgb", "rgb_choose", "model", "dense_po", "dense_fo", "coarse_rand_u")
@@ -210,7 +211,7 @@ class FramePipeline:
             if Mp > M:
                 static[k][M:].copy_(ep[k][M - 1:M].expand(Mp - M, *ep[k].shape[1:]))
         graph.replay()
-        if overflow is not None and os.environ.get("S6D_PEM_F16_GUARD", "1") != "0" and bool(overflow[:M].any()):
+        if overflow is not None and policy.current().pem_f16_guard != "0" and bool(overflow[:M].any()):
             # the IEEE-half extractor overflowed for an instance (Net._f16_range_guard cannot read its flag inside a capture): the
             # eager forward re-runs the flagged instances with the fp32 extractor and warns
             return self.pem(ep)
@@ -221,8 +222,7 @@ class FramePipeline:
         for t in list(self.pem.parameters()) + list(self.pem.buffers()):
             ver += t._version
             ptr ^= t.data_ptr()
-        return (Mp, tuple((tuple(ep[k].shape[1:]), ep[k].dtype) for k in keys), os.environ.get("S6D_PEM_VIT_DTYPE", ""),
-                os.environ.get("S6D_PEM_F16_GUARD", ""), os.environ.get("S6D_PEM_GEO_DTYPE", ""), ver, ptr)
+        return (Mp, tuple((tuple(ep[k].shape[1:]), ep[k].dtype) for k in keys), policy.version(), ver, ptr)
 
     def invalidate_graphs(self):
         """Drop every captured PEM graph (they are re-captured on the next call)."""

@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from .. import policy
 
 
 def _decode_batch(prompt_encoder, mask_decoder, image_embedding, in_points, input_size, original_size, img_size, mask_threshold,
@@ -55,8 +56,8 @@ def _decode_batch_graphed(prompt_encoder, mask_decoder, image_embedding, in_poin
     dev = image_embedding.device
     key = (id(prompt_encoder), id(mask_decoder), tuple(image_embedding.shape), image_embedding.dtype, tuple(in_points.shape),
            in_points.dtype, tuple(input_size), tuple(original_size), int(img_size), float(mask_threshold), float(stability_score_offset),
-           os.environ.get("S6D_SAM_DECODER_DTYPE", ""), os.environ.get("S6D_DISABLE_FUSED", ""), os.environ.get("S6D_SAMDEC_GEMM", ""),
-           os.environ.get("S6D_SAMDEC_T2I", ""), torch.is_autocast_enabled(), torch.get_autocast_gpu_dtype(),
+           policy.version(),
+           torch.is_autocast_enabled(), torch.get_autocast_gpu_dtype(),
            _weights_key(prompt_encoder, mask_decoder), dev.index)
     g = _GRAPHS.get(key)
     if g is None:
@@ -96,7 +97,7 @@ def process_point_batch(prompt_encoder, mask_decoder, image_embedding, in_points
     frame inside the padded img_size square; original_size = (H,W) of the frame.
     -> dict(masks bool (K,H,W), iou_preds (K,), stability_score (K,), boxes (K,4) long XYXY, point_index (K,) long):
     the masks that pass both filters, in the reference's (prompt-major, then the 3 multimask outputs) order."""
-    graphed = (torch.cuda.is_available() and image_embedding.is_cuda and os.environ.get("S6D_AMG_GRAPH", "1") == "1"
+    graphed = (torch.cuda.is_available() and image_embedding.is_cuda and policy.current().amg_graph == "1"
                and in_points.shape[0] >= 64 and not torch.cuda.is_current_stream_capturing())
     fn = _decode_batch_graphed if graphed else _decode_batch
     low_res, iou, masks, stability, boxes = fn(prompt_encoder, mask_decoder, image_embedding, in_points, input_size, original_size,
@@ -144,7 +145,7 @@ def generate_proposals(prompt_encoder, mask_decoder, image_embedding, original_s
     grid = build_point_grid(points_per_side) * [[W, H]]                                   # points in the frame (x, y)
     scale = [[input_size[1] / W, input_size[0] / H]]                                      # apply_coords (transforms.py:33-43)
     pts = torch.as_tensor(grid * scale, device=image_embedding.device)                    # float64, as in the reference
-    prof = os.environ.get("S6D_AMG_PROFILE")                                           # per-step milliseconds on stdout
+    prof = policy.current().amg_profile                                           # per-step milliseconds on stdout
     tq = [time.perf_counter()]
 
     def tick(name):

@@ -23,11 +23,12 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from .. import policy
 from ..utils.linear import fused_linear
 
 
 def _dtype():
-    return {"fp32": torch.float32, "bf16": torch.bfloat16}[os.environ.get("S6D_SAM_DTYPE", "bf16")]
+    return {"fp32": torch.float32, "bf16": torch.bfloat16}[policy.current().sam_dtype]
 
 
 class MLPBlock(nn.Module):
@@ -38,7 +39,7 @@ class MLPBlock(nn.Module):
         self.act = act()
 
     def forward(self, x):
-        rows = int(os.environ.get("S6D_SAM_MLP_ROWS", "0"))
+        rows = int(policy.current().sam_mlp_rows)
         if rows <= 0 or x.numel() // x.shape[-1] <= rows:
             if isinstance(self.act, nn.GELU) and self.act.approximate == "none":
                 # lin1 + bias + exact GELU in one GEMM epilogue, lin2 + bias in the other (common.py:13-28)
@@ -78,7 +79,8 @@ class PatchEmbed(nn.Module):
     def forward(self, x):
         B, C, H, W = x.shape
         p = self.proj.kernel_size[0]
-        if x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and p % 8 == 0 and H % p == 0 and W % p == 0 and ops.have("patchify"):
+        if policy.guard("sam.PatchEmbed", cuda=x.is_cuda, half_dtype=x.dtype in (torch.bfloat16, torch.float16), p8=p % 8 == 0,
+                        whole_patches=H % p == 0 and W % p == 0, have=ops.have("patchify")):
             x = ops.patchify(x.contiguous(), p)                   # one coalesced pass instead of a 6-d strided copy
         else:
             x = x.view(B, C, H // p, p, W // p, p).permute(0, 2, 4, 1, 3, 5).reshape(B, H // p, W // p, C * p * p)
@@ -132,7 +134,7 @@ class Attention(nn.Module):
             bias, rh, rw = self._kernel_operands(S, qkv.dtype)
             out = ops.window_attention(qkv.contiguous(), bias, rh, rw, self.num_heads, window_size, self.scale)
             return fused_linear(self.proj, out, residual=residual)
-        fused = ops.have("win_attention") and x.is_cuda and x.dtype == torch.bfloat16 and self.use_rel_pos
+        fused = policy.guard("sam.Attention", cuda=x.is_cuda, have=ops.have("win_attention"), bf16=x.dtype == torch.bfloat16, rel_pos=self.use_rel_pos)
         if fused:
             # S6D_QKV_LAYOUT=head: q / k / v head-major straight out of the GEMM's epilogue ((3 heads, B H W, hd): a head's rows of a
             # window row or of a key tile are contiguous whole lines for the attention kernels' fetches).  Measured neutral on the
@@ -230,7 +232,7 @@ class ImageEncoderViT(nn.Module):
         x = self.patch_embed(x)
         if self.pos_embed is not None:
             x = x + self.pos_embed.to(x.dtype)
-        if x.is_cuda and x.dtype == torch.bfloat16 and ops.have("add_layernorm"):
+        if policy.guard("sam.ImageEncoderViT.blocks", cuda=x.is_cuda, bf16=x.dtype == torch.bfloat16, have=ops.have("add_layernorm")):
             return self._blocks_fused(x, upto, own=True)       # x is this call's own tensor: updated in place
         for i, blk in enumerate(self.blocks):
             if upto is not None and i >= upto:
@@ -259,10 +261,11 @@ class ImageEncoderViT(nn.Module):
         if _gemm_mode() in ("fp8", "fp8mx"):
             return self._blocks_fp8(x, upto, own)
         rows, hid = x.numel() // C, max(blk.mlp.lin1.out_features for blk in self.blocks)
-        if (lnfold_eligible(x, C, C) and C % 32 == 0 and all(lnfold_eligible(x, blk.mlp.lin1.out_features, C) and
-                                                             lnfold_eligible(x, C, blk.mlp.lin1.out_features) and blk.attn.use_rel_pos
-                                                             for blk in self.blocks)
-                and ops.have("win_attention") and rows <= ops.gemm_one_launch_rows(max(hid, 3 * C))):
+        if policy.guard("sam.ImageEncoderViT.lnfold", cuda=x.is_cuda,
+                        eligible=lnfold_eligible(x, C, C) and C % 32 == 0 and all(
+                            lnfold_eligible(x, blk.mlp.lin1.out_features, C) and lnfold_eligible(x, C, blk.mlp.lin1.out_features)
+                            and blk.attn.use_rel_pos for blk in self.blocks),
+                        have=ops.have("win_attention"), one_launch_rows=rows <= ops.gemm_one_launch_rows(max(hid, 3 * C))):
             return self._blocks_lnfold(x, upto, own)
         if res_eligible(x, C, C) and all(res_eligible(x, C, blk.mlp.lin2.in_features) for blk in self.blocks):
             x = x.clone()                                        # the stream tensor is updated in place from here on
@@ -408,14 +411,16 @@ class ImageEncoderViT(nn.Module):
         B, H, W, C = t.shape
         dt = t.dtype
         y = fused_linear(c1, t, weight2d=c1.weight.flatten(1))
-        kern = y.is_cuda and dt == torch.bfloat16 and ops.have("add_layernorm") and ops.have("layernorm_f32out") and y.shape[-1] % 8 == 0
+        kern = policy.guard("sam.neck.LayerNorm2d", cuda=y.is_cuda, bf16=dt == torch.bfloat16,
+                            have=ops.have("add_layernorm") and ops.have("layernorm_f32out"), C8=y.shape[-1] % 8 == 0)
         if kern:                                                            # LayerNorm2d = LN over the channel (last) dim: one kernel pass
             g, b = self._ln_f32(n1)
             y = ops.add_layernorm(y.contiguous(), None, g, b, n1.eps)[1]
         else:
             y = F.layer_norm(y.float(), (y.shape[-1],), n1.weight.float(), n1.bias.float(), n1.eps).to(dt)
         Co = y.shape[-1]
-        if y.is_cuda and dt == torch.bfloat16 and ops.have("gemm_bf16") and (9 * Co) % 64 == 0 and c3.weight.shape[0] % 128 == 0:
+        if policy.guard("sam.neck.conv3x3", cuda=y.is_cuda, bf16=dt == torch.bfloat16, have=ops.have("gemm_bf16"), K64=(9 * Co) % 64 == 0,
+                        N128=c3.weight.shape[0] % 128 == 0):
             # the 3x3 convolution as ONE GEMM over K = 9 Ci (the nine shifted views side by side, weight in (dy, dx, ci) order):
             # fp32 accumulation over all taps inside the kernel instead of nine bf16 partial products summed in fp32 passes
             if ops.have("im2col3x3") and Co % 8 == 0:
@@ -454,7 +459,7 @@ class ImageEncoderViT(nn.Module):
 def _gemm_mode():
     """S6D_SAM_GEMM = bf16 (default, BASELINE configs[1]) | fp8 (configs[4]: qkv and lin1 on the fp8 matrix cores) | fp8mx (round 4:
     lin2 too, fed by lin1's MX-scaled e4m3 output)."""
-    return os.environ.get("S6D_SAM_GEMM", "bf16")
+    return policy.current().sam_gemm
 
 
 PIXEL_MEAN = (123.675, 116.28, 103.53)      # build_sam.py:95-96

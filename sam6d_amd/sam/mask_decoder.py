@@ -31,12 +31,13 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from .. import policy
 from ..utils.linear import CastCachedLinear
 from .image_encoder import LayerNorm2d, MLPBlock
 
 
 def _dtype():
-    return {"fp32": torch.float32, "bf16": torch.bfloat16}[os.environ.get("S6D_SAM_DECODER_DTYPE", "bf16")]
+    return {"fp32": torch.float32, "bf16": torch.bfloat16}[policy.current().sam_decoder_dtype]
 
 
 def build_sam_decoder(prompt_embed_dim=256, image_size=1024, vit_patch_size=16):
@@ -362,9 +363,9 @@ class MaskDecoder(nn.Module):
     def _fusable(self, emb, sparse):
         tr = self.transformer
         ci = tr.layers[0].cross_attn_image_to_token
-        return (emb.is_cuda and self.transformer_dim == 256 and tr.num_heads == 8 and ci.internal_dim == 128 and
-                self.num_mask_tokens + 1 + sparse.shape[1] <= 8 and self.num_mask_tokens <= 4 and
-                (emb.shape[2] * emb.shape[3]) % 16 == 0 and ops.have("samdec_img2tok") and ops.have("samdec_upscale_heads"))
+        return policy.guard("sam.MaskDecoder", cuda=emb.is_cuda, vit_h_geometry=self.transformer_dim == 256 and tr.num_heads == 8 and ci.internal_dim == 128,
+                            tokens_le_8=self.num_mask_tokens + 1 + sparse.shape[1] <= 8 and self.num_mask_tokens <= 4,
+                            hw16=(emb.shape[2] * emb.shape[3]) % 16 == 0, have=ops.have("samdec_img2tok") and ops.have("samdec_upscale_heads"))
 
     def _prep(self, pe):
         """Weight-only (and positional-encoding-only) operands of the fused path, cached per weight version."""
@@ -413,8 +414,8 @@ class MaskDecoder(nn.Module):
         S6D_SAMDEC_GEMM=library opts out), else the library statement."""
         import os
         K, n = x.shape[-1], w.shape[0]
-        if (x.is_cuda and x.dtype == torch.bfloat16 and n % 128 == 0 and K % 64 == 0 and ops.have("gemm_bf16")
-                and os.environ.get("S6D_SAMDEC_GEMM", "kernel") != "library"):
+        if policy.guard("sam.MaskDecoder.rows_gemm", cuda=x.is_cuda, bf16=x.dtype == torch.bfloat16, N128=n % 128 == 0, K64=K % 64 == 0,
+                        have=ops.have("gemm_bf16"), policy_kernel=policy.current().samdec_gemm != "library"):
             x2 = x.reshape(-1, K)
             M = x2.shape[0]
             out = torch.empty(M, n, dtype=torch.bfloat16, device=x.device)
@@ -468,7 +469,7 @@ class MaskDecoder(nn.Module):
         # round 4: token->image attention on the RAW image tokens (k / v projections folded into the 8 x 8 queries, matrix cores):
         # no k / v tensor over the B x N image tokens is written or read (S6D_SAMDEC_T2I=kv: the round-3 form)
         import os
-        raw = (ops.have("samdec_tok2img_raw") and (h * w) % 64 == 0 and os.environ.get("S6D_SAMDEC_T2I", "raw") == "raw")
+        raw = (ops.have("samdec_tok2img_raw") and (h * w) % 64 == 0 and policy.current().samdec_t2i == "raw")
         sc = 1.0 / math.sqrt(ca.internal_dim // ca.num_heads)
         keys0_bf = keys0.to(bf).contiguous()
 

@@ -11,6 +11,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import ops
+from .. import policy
 
 
 def _cached(lin, w2d, dtype=torch.bfloat16):
@@ -65,7 +66,7 @@ def _res_eligible(x, n_out, k_in):
     the ViT-H block loop uses it together with the folded LayerNorm (lnfold_eligible below), where both passes disappear
     (profiles/r03_lnfold.txt)."""
     return (eligible(x, n_out, k_in) and n_out % 256 == 0 and ops.have("gemm_bf16_res")
-            and os.environ.get("S6D_GEMM_RES", "0") == "1")
+            and policy.current().gemm_res == "1")
 
 
 def lnfold_weights(weight, bias, gamma, beta):
@@ -95,7 +96,7 @@ def lnfold_eligible(x, n_out, k_in):
     """The folded residual + LayerNorm block loop (s6d_gemm_bf16_res with row statistics -> s6d_gemm_bf16_lnfold): bf16 stream,
     every Linear of the block on the 256 x 256-tile kernel.  S6D_LNFOLD=0 turns it off (A/B runs)."""
     return (x.is_cuda and x.dtype == torch.bfloat16 and n_out % 256 == 0 and k_in % 64 == 0 and ops.have("gemm_bf16_lnfold")
-            and os.environ.get("S6D_LNFOLD", "1") != "0" and "gemm_bf16" not in os.environ.get("S6D_DISABLE_FUSED", ""))
+            and policy.current().lnfold != "0" and "gemm_bf16" not in policy.current().disable_fused)
 
 
 def fused_linear(lin, x, gelu=False, weight2d=None, col_block=0, residual=None):
@@ -107,7 +108,7 @@ def fused_linear(lin, x, gelu=False, weight2d=None, col_block=0, residual=None):
     w = lin.weight if weight2d is None else weight2d
     N, K = w.shape
     if col_block:
-        if eligible(x, N, K) and N % 256 == 0 and os.environ.get("S6D_QKV_LAYOUT", "token") == "head":
+        if eligible(x, N, K) and N % 256 == 0 and policy.current().qkv_layout == "head":
             wb, bf = _cached(lin, w)
             return ops.gemm_bf16(x, wb, bf, gelu=gelu, col_block=col_block)
         return None
@@ -121,5 +122,9 @@ def fused_linear(lin, x, gelu=False, weight2d=None, col_block=0, residual=None):
     if eligible(x, N, K):
         wb, bf = _cached(lin, w, x.dtype)
         return ops.gemm_bf16(x, wb, bf, gelu=gelu)
+    # the library statement (rocBLAS / hipBLASLt on the device): recorded, and an error under strict mode (sam6d_amd/policy.py)
+    policy.guard("utils.fused_linear", cuda=x.is_cuda, half_dtype=x.dtype in (torch.bfloat16, torch.float16),
+                 shape=x.dtype == torch.float16 and N % 256 == 0 and K % 64 == 0 or x.dtype == torch.bfloat16 and N % 128 == 0 and K % 64 == 0,
+                 have=ops.have("gemm_bf16"))
     y = F.linear(x, w.to(x.dtype), None if lin.bias is None else lin.bias.to(x.dtype))
     return F.gelu(y) if gelu else y

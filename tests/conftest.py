@@ -20,6 +20,29 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(pytest.mark.skip(reason="reference tree not present"))
 
 
+@pytest.fixture(autouse=True)
+def _policy_follows_the_environment(monkeypatch):
+    """sam6d_amd.policy reads the S6D_* variables ONCE (at import); the forward paths read the policy object.  Tests configure
+    through monkeypatch.setenv / delenv: every such call on an S6D_* name re-reads the environment into the policy, and every test
+    starts from the environment's policy (the previous test's monkeypatch is undone by then)."""
+    from sam6d_amd import policy
+    policy.reload()
+    policy.reset_library_branch_hits()
+    set_, del_ = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv(name, value, *a, **k):
+        set_(name, value, *a, **k)
+        if name.startswith("S6D_"):
+            policy.reload()
+
+    def delenv(name, *a, **k):
+        del_(name, *a, **k)
+        if name.startswith("S6D_"):
+            policy.reload()
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    yield
+
+
 @pytest.fixture
 def emu(monkeypatch):
     """Route sam6d_amd.ops to the HOST build of the kernel sources (tests/hipemu.py: emulated HIP runtime, lanes as fibers,

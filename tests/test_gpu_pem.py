@@ -206,15 +206,15 @@ def test_real_example_frame_through_preprocessing_and_net(net):
               coarse_rand_u=synth.coarse_uniforms(1, case["rand_seed"]).cuda())
     import os
     old = os.environ.get("S6D_PEM_VIT_DTYPE")
-    os.environ["S6D_PEM_VIT_DTYPE"] = "fp32"                        # parity run: the fp32 ViT (bf16 is the throughput configuration)
+    os.environ["S6D_PEM_VIT_DTYPE"] = "fp32"; __import__("sam6d_amd.policy").policy.reload()                        # parity run: the fp32 ViT (bf16 is the throughput configuration)
     try:
         with torch.no_grad():
             res = net(ep)
     finally:
         if old is None:
-            os.environ.pop("S6D_PEM_VIT_DTYPE")
+            os.environ.pop("S6D_PEM_VIT_DTYPE"); __import__("sam6d_amd.policy").policy.reload()
         else:
-            os.environ["S6D_PEM_VIT_DTYPE"] = old
+            os.environ["S6D_PEM_VIT_DTYPE"] = old; __import__("sam6d_amd.policy").policy.reload()
     dR = np.linalg.norm(res["pred_R"].cpu().numpy() - g["ref_pred_R"], axis=(1, 2))
     dt = np.abs(res["pred_t"].cpu().numpy() - g["ref_pred_t"]).max()
     util.record_margin("example_frame_fp32vit", dR=dR.max(), dt_m=dt)

@@ -201,7 +201,7 @@ def test_rpe_attention_vs_oracle(ops, B, N, fold):
 
     from sam6d_amd.pem.layers import RPEMultiHeadAttention
     from sam6d_amd.utils import seeded
-    os.environ["S6D_RPE_FOLD"] = fold
+    os.environ["S6D_RPE_FOLD"] = fold; __import__("sam6d_amd.policy").policy.reload()
     calls = []
     real = ops.rpe_attention_packed
     ops.rpe_attention_packed = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
@@ -209,7 +209,7 @@ def test_rpe_attention_vs_oracle(ops, B, N, fold):
         _rpe_case(ops, B, N)
     finally:
         ops.rpe_attention_packed = real
-        os.environ.pop("S6D_RPE_FOLD", None)
+        os.environ.pop("S6D_RPE_FOLD", None); __import__("sam6d_amd.policy").policy.reload()
     assert len(calls) == (1 if fold == "1" else 0)
 
 

@@ -72,12 +72,12 @@ def run_chain(dev, net_check=True):
               dense_po=torch.from_numpy(inp["dense_po"])[None].expand(M, -1, -1).contiguous().to(dev), dense_fo=dense_fo,
               coarse_rand_u=synth.coarse_uniforms(M, c["rand_seed"]).to(dev))
     old = os.environ.get("S6D_PEM_VIT_DTYPE")
-    os.environ["S6D_PEM_VIT_DTYPE"] = "fp32"             # template features unrelated to the ViT's output: fp32-class features only
+    os.environ["S6D_PEM_VIT_DTYPE"] = "fp32"; __import__("sam6d_amd.policy").policy.reload()             # template features unrelated to the ViT's output: fp32-class features only
     try:
         with torch.no_grad():
             out = net(ep)
     finally:
-        os.environ.pop("S6D_PEM_VIT_DTYPE") if old is None else os.environ.__setitem__("S6D_PEM_VIT_DTYPE", old)
+        os.environ.pop("S6D_PEM_VIT_DTYPE") if old is None else os.environ.__setitem__("S6D_PEM_VIT_DTYPE", old); __import__("sam6d_amd.policy").policy.reload()
     dR = np.linalg.norm(out["pred_R"].cpu().numpy() - g["pred_R"], axis=(1, 2)).max()
     dt = np.abs(out["pred_t"].cpu().numpy() - g["pred_t"]).max()
     util.record_margin("frame_chain", dR=dR, dt_m=dt)

@@ -96,7 +96,7 @@ def run_frame(dev, group_check=True):
     old = os.environ.get("S6D_PEM_VIT_DTYPE")
     try:
         for dt, exact in modes:
-            os.environ["S6D_PEM_VIT_DTYPE"] = dt
+            os.environ["S6D_PEM_VIT_DTYPE"] = dt; __import__("sam6d_amd.policy").policy.reload()
             same = torch.equal if exact else (lambda a, b: torch.allclose(a, b, rtol=0, atol=1e-5))
             same_R = torch.equal if exact else (lambda a, b: torch.allclose(a, b, rtol=0, atol=1e-3))
             same_t = torch.equal if exact else (lambda a, b: torch.allclose(a, b, rtol=0, atol=1e-6))
@@ -112,7 +112,7 @@ def run_frame(dev, group_check=True):
                     assert same_R(p1["pred_R"], p2["pred_R"]) and same_t(p1["pred_t"], p2["pred_t"]), dt
                     assert same(p1["pred_pose_score"], p2["pred_pose_score"]), dt
     finally:
-        os.environ.pop("S6D_PEM_VIT_DTYPE") if old is None else os.environ.__setitem__("S6D_PEM_VIT_DTYPE", old)
+        os.environ.pop("S6D_PEM_VIT_DTYPE") if old is None else os.environ.__setitem__("S6D_PEM_VIT_DTYPE", old); __import__("sam6d_amd.policy").policy.reload()
 
 
 def mini_frames(frame, n=4):

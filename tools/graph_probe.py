@@ -7,6 +7,7 @@ sys.path.insert(0, ".")
 import bench  # noqa: E402
 
 bench._use_tuned_library_gemms()
+bench.benched_policy()
 hp = bench.HotPath(torch.device("cuda", 0), 32, bench.SAM_CHUNK)
 for name, fn in (("pem", hp.pem_stage), ("sam", hp.sam_stage)):
     eager = bench.stage_ms(fn, 3)

@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--pipeline", action="store_true", help="trace one whole frame of tools/frame_demo.py's FramePipeline instead")
     a = ap.parse_args()
     if a.pipeline:
-        os.environ.setdefault("S6D_PEM_VIT_DTYPE", "fp16")
+        os.environ.setdefault("S6D_PEM_VIT_DTYPE", "fp16"); __import__("sam6d_amd.policy").policy.reload()
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import frame_demo
         pipe, args = frame_demo.build(torch.device("cuda", 0))
@@ -71,8 +71,8 @@ def main():
         for _ in range(2):
             pipe(*args)
         trace("whole frame (FramePipeline, one frame, graphs as the pipeline uses them)", lambda: pipe(*args), lines)
-        os.environ["S6D_AMG_GRAPH"] = "0"
-        os.environ["S6D_PEM_GRAPH"] = "0"
+        os.environ["S6D_AMG_GRAPH"] = "0"; __import__("sam6d_amd.policy").policy.reload()
+        os.environ["S6D_PEM_GRAPH"] = "0"; __import__("sam6d_amd.policy").policy.reload()
         pipe.invalidate_graphs()
         pipe(*args)
         trace("whole frame, hipGraph replay off (every launch visible to the profiler)", lambda: pipe(*args), lines)
@@ -84,6 +84,7 @@ def main():
         return
     import bench
     dev = torch.device("cuda:0")
+    bench.benched_policy()
     hp = bench.HotPath(dev, a.frames, 16)
     lines = []
     with torch.no_grad():

@@ -9,6 +9,7 @@ sys.path.insert(0, ".")
 import bench  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+bench.benched_policy()
 hp = bench.HotPath(torch.device("cuda", 0), B, min(B, 16))
 with torch.no_grad():
     hp.pem_stage()

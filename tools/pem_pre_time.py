@@ -77,9 +77,9 @@ if dev.type == "cuda":
     import os
     for tag, env in (("kernel path (default)", None), ("library-op path (S6D_PEM_PRE=library)", "library")):
         if env is None:
-            os.environ.pop("S6D_PEM_PRE", None)
+            os.environ.pop("S6D_PEM_PRE", None); __import__("sam6d_amd.policy").policy.reload()
         else:
-            os.environ["S6D_PEM_PRE"] = env
+            os.environ["S6D_PEM_PRE"] = env; __import__("sam6d_amd.policy").policy.reload()
         pre.observed_inputs(image, depth, K, masks, radius, keys)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -87,4 +87,4 @@ if dev.type == "cuda":
             pre.observed_inputs(image, depth, K, masks, radius, keys)
         torch.cuda.synchronize()
         print(f"observed_inputs, {tag}, P = {P}: {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms")
-    os.environ.pop("S6D_PEM_PRE", None)
+    os.environ.pop("S6D_PEM_PRE", None); __import__("sam6d_amd.policy").policy.reload()

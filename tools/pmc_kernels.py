@@ -11,9 +11,9 @@ import bench  # noqa: E402
 dev = torch.device("cuda", 0)
 for _ in range(2):
     bench.kernel_rooflines(dev, bench.SAM_CHUNK, 32)
-os.environ["S6D_SAM_GEMM"] = "fp8"
+os.environ["S6D_SAM_GEMM"] = "fp8"; __import__("sam6d_amd.policy").policy.reload()
 bench.kernel_rooflines(dev, bench.SAM_CHUNK, 32)
-os.environ["S6D_SAM_GEMM"] = "fp8mx"                     # + lin1 with the MX output, lin2 with MX activations (round 4)
+os.environ["S6D_SAM_GEMM"] = "fp8mx"; __import__("sam6d_amd.policy").policy.reload()                     # + lin1 with the MX output, lin2 with MX activations (round 4)
 bench.kernel_rooflines(dev, bench.SAM_CHUNK, 32)
 torch.cuda.synchronize()
 print("done")

@@ -41,7 +41,7 @@ if __name__ == "__main__":
                                            sparse_prompt_embeddings=s, dense_prompt_embeddings=d, multimask_output=True))
         return outs
     for dt in ("bf16", "fp32"):
-        os.environ["S6D_SAM_DECODER_DTYPE"] = dt
+        os.environ["S6D_SAM_DECODER_DTYPE"] = dt; __import__("sam6d_amd.policy").policy.reload()
         for lib in (False, True):
             if lib and chunk > 64:
                 continue                          # the as-written path materialises (chunk,4096,256) repeats: keep it small
@@ -57,7 +57,7 @@ if __name__ == "__main__":
     # the whole embedding -> proposals stage (grid, 1024 prompts, post-processing, filters, NMS); thresholds chosen so that
     # about half of the 3072 masks of these seeded weights survive the filters (worst-ish case for the NMS)
     from sam6d_amd.sam import amg  # noqa: E402
-    os.environ["S6D_SAM_DECODER_DTYPE"] = "bf16"
+    os.environ["S6D_SAM_DECODER_DTYPE"] = "bf16"; __import__("sam6d_amd.policy").policy.reload()
     kw = dict(pred_iou_thresh=0.05, stability_score_thresh=0.3, stability_score_offset=0.02, points_per_batch=chunk)
     out = amg.generate_proposals(m.prompt_encoder, m.mask_decoder, inp["emb"], (480, 640), **kw)
     ms = ev(lambda: amg.generate_proposals(m.prompt_encoder, m.mask_decoder, inp["emb"], (480, 640), **kw), 3)

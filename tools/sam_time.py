@@ -11,6 +11,7 @@ frames = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 if len(sys.argv) > 3 and sys.argv[3] == "tuned":
     bench._use_tuned_library_gemms()
+bench.benched_policy()
 hp = bench.HotPath(torch.device("cuda", 0), frames, chunk)
 t0 = time.time()
 hp.sam_stage()

@@ -203,11 +203,29 @@ def test_vit_h_fp8_accuracy_gate(monkeypatch, mode):
     # (lin2 in fp8 as well: rel 6.9e-2, min 0.889, 65 % of the masks above 0.95) does not meet the share bound and is therefore an
     # opt-in mode held to the mean only.
     assert iou.mean() >= 0.95, (iou.mean().item(), iou.min().item())
+    _FP8_GATE[mode] = dict(min=iou.min().item(), share=(iou >= 0.95).float().mean().item())
     if mode == "fp8":
+        # FINAL bounds (round 6: they are not the bars first written down -- 0.80 / 0.93 -- and are not presented as such: those
+        # stay below as test_vit_h_fp8_original_bars, expected to fail, so the relaxation is visible in every run's report).
         # share: the verdict's 0.80; three boxes of the pool gave 0.823 / 0.818 / 0.802 for the same seeded inputs (the bf16 decoder's
         # library GEMMs are chosen per box), i.e. 158 ... 154 of 192 masks -- the bound leaves six masks of slack and still separates
         # the modes (fp8mx: 0.63 ... 0.66)
         assert iou.min() >= 0.90 and (iou >= 0.95).float().mean() >= 0.77, (iou.min().item(), (iou >= 0.95).float().mean().item())
+
+
+_FP8_GATE = {}
+
+
+@pytest.mark.xfail(reason="the bars first written for configs[4] (min mask IoU >= 0.93, share of masks above 0.95 >= 0.80): fp8 measures "
+                          "0.91 / 0.80-0.82 -- the min bar is not met, the share bar is met on some boxes only; the asserted gate "
+                          "(test_vit_h_fp8_accuracy_gate) is the relaxed 0.90 / 0.77, stated as such", strict=False)
+def test_vit_h_fp8_original_bars():
+    """Runs after test_vit_h_fp8_accuracy_gate[fp8] (same module, collection order) and judges ITS measurement against the bars as
+    first written: ADVICE r5 -- keep the original bars visible instead of presenting the relaxed numbers as pre-registered."""
+    if "fp8" not in _FP8_GATE:
+        pytest.skip("test_vit_h_fp8_accuracy_gate[fp8] did not run")
+    m = _FP8_GATE["fp8"]
+    assert m["min"] >= 0.93 and m["share"] >= 0.80, m
 
 
 @pytest.mark.parametrize("mode", ["fp8", "fp8mx"])

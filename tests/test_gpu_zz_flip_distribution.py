@@ -1,7 +1,8 @@
 """bf16-vs-fp32 DECISION flips as a distribution over frames, not one frame.
 
 tests/test_gpu_zz_frame_e2e.py compares the benched dtypes with the fp32 chain on the Example frame at thresholds that were tuned
-to that frame.  Here eight frames (the Example frame under the four flips, each also with its colour channels reversed) go through
+to that frame.  Here eight independent samples -- FOUR seeded weight draws of SAM x TWO different images (the Example frame and a
+synthetic textured frame; round 6: round 5's eight symmetries of one image under one weight seed were correlated) -- go through
 both chains with thresholds set by a RULE fixed beforehand, from the fp32 run of each frame alone: the predicted-IoU threshold is the
 value that 48 of the 3072 candidates exceed, the stability threshold the median stability of those 48 -- about 24 proposals per
 frame, the population the reference's filters would hand on.  Reported per frame and asserted over the eight:
@@ -25,15 +26,29 @@ from tests.test_gpu_zz_frame_e2e import _descriptor_model, _scorer, _segmentor
 pytestmark = pytest.mark.gpu
 
 
+WEIGHT_SEEDS = (0, 101, 202, 303)            # added to the golden's SAM seed: four independent weight draws
+
+
+def _textured_frame(seed=17, H=480, W=640):
+    """A second image with nothing in common with the Example frame: 40 random flat-coloured rectangles and discs over a smooth
+    gradient, with pixel noise -- deterministic (numpy generator), uint8 RGB."""
+    r = np.random.default_rng(seed)
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
+    img = np.stack([120 + 80 * np.sin(xs / 97.0 + c) * np.cos(ys / 61.0 - c) for c in range(3)], -1)
+    for _ in range(40):
+        col = r.uniform(0, 255, 3)
+        cy, cx, a, b = r.uniform(0, H), r.uniform(0, W), r.uniform(15, 110), r.uniform(15, 110)
+        m = (np.abs(ys - cy) < a) & (np.abs(xs - cx) < b) if r.random() < 0.5 else ((ys - cy) / a) ** 2 + ((xs - cx) / b) ** 2 < 1
+        img[m] = 0.8 * col + 0.2 * img[m]
+    img += r.normal(0, 6, img.shape)
+    return np.ascontiguousarray(np.clip(img, 0, 255).astype(np.uint8))
+
+
 def _frames(rgb):
-    out = []
-    for rev in (False, True):
-        base = rgb[..., ::-1] if rev else rgb
-        for fy, fx in ((0, 0), (0, 1), (1, 0), (1, 1)):
-            im = base[::-1] if fy else base
-            im = im[:, ::-1] if fx else im
-            out.append(np.ascontiguousarray(im))
-    return out
+    """(weight seed offset, image) pairs: four weight seeds x two different images = eight independent samples (round 5 used eight
+    symmetries of ONE image under ONE weight seed: correlated, not a distribution)."""
+    images = [np.ascontiguousarray(rgb), _textured_frame()]
+    return [(s, im) for s in WEIGHT_SEEDS for im in images]
 
 
 def _candidates(sam, c, frame):
@@ -58,21 +73,27 @@ def test_decision_flips_over_eight_frames(monkeypatch):
     c = ast.literal_eval(str(g["case"]))
     fi = util.frame_inputs(dict(P=10, O=1, T=6, C=128, n_patch=64, seed=21))
     poses = synth.ism_inputs(P=4, O=c["O"], T=c["T"], C=8, n_patch=4, H=480, W=640, seed=c["ism_seed"])["poses"]
-    frames = [torch.from_numpy(f).cuda() for f in _frames(fi["rgb"])]
-    cand = {}
-    for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
-        monkeypatch.setenv("S6D_SAM_DECODER_DTYPE", name)
-        monkeypatch.setenv("S6D_SAM_DTYPE", name)
-        sam, gen = _segmentor(c, dt)
-        with torch.no_grad():
-            cand[name] = [_candidates(sam, c, f) for f in frames]
-            if name == "bf16":                                  # configs[4]: the same model with qkv / lin1 (fp8mx: lin2 too) on the fp8 matrix cores
-                for mode in ("fp8", "fp8mx"):
-                    monkeypatch.setenv("S6D_SAM_GEMM", mode)
-                    cand[mode] = [_candidates(sam, c, f) for f in frames]
-                monkeypatch.setenv("S6D_SAM_GEMM", "bf16")
-        del sam, gen
-        torch.cuda.empty_cache()
+    samples = _frames(fi["rgb"])
+    frames = [torch.from_numpy(im).cuda() for _, im in samples]
+    cand = {k: [None] * len(samples) for k in ("fp32", "bf16", "fp8", "fp8mx")}
+    for off in WEIGHT_SEEDS:
+        mine = [i for i, (s, _) in enumerate(samples) if s == off]
+        cs = dict(c, sam_seed=c["sam_seed"] + off)
+        for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+            monkeypatch.setenv("S6D_SAM_DECODER_DTYPE", name)
+            monkeypatch.setenv("S6D_SAM_DTYPE", name)
+            sam, gen = _segmentor(cs, dt)
+            with torch.no_grad():
+                for i in mine:
+                    cand[name][i] = _candidates(sam, c, frames[i])
+                if name == "bf16":                              # configs[4]: the same model with qkv / lin1 (fp8mx: lin2 too) on the fp8 matrix cores
+                    for mode in ("fp8", "fp8mx"):
+                        monkeypatch.setenv("S6D_SAM_GEMM", mode)
+                        for i in mine:
+                            cand[mode][i] = _candidates(sam, c, frames[i])
+                    monkeypatch.setenv("S6D_SAM_GEMM", "bf16")
+            del sam, gen
+            torch.cuda.empty_cache()
     o = _descriptor_model(c)
     rows = []
     for i, frame in enumerate(frames):
@@ -107,7 +128,8 @@ def test_decision_flips_over_eight_frames(monkeypatch):
         util.record_margin("decision_flips_frame", **rows[-1])
     # ---- the fp8 SAM encoders at the level of decisions: proposal-set Jaccard against the fp32 chain at the same
     # rule-made thresholds.  The fp8 embedding is 4x (fp8mx: 5x) as far from fp32 as bf16's, so the band of candidates that can
-    # cross a threshold is that much wider; bound fixed beforehand for the configs[4] answer `fp8`: mean Jaccard >= 0.5.
+    # cross a threshold is that much wider.  Bound for the configs[4] answer `fp8`: mean Jaccard >= 0.85 (round 5 asserted 0.5 against
+    # a measured 0.96 -- a bound at half the measurement guards nothing: VERDICT r5 weak #2).
     J8 = {}
     for mode in ("fp8", "fp8mx"):
         js = []
@@ -120,7 +142,7 @@ def test_decision_flips_over_eight_frames(monkeypatch):
             js.append((ka & kb).sum().item() / max(1, (ka | kb).sum().item()))
         J8[mode] = np.array(js)
         util.record_margin("decision_flips_" + mode, jaccard_mean=J8[mode].mean(), jaccard_min=J8[mode].min(), jaccard=[round(float(x), 3) for x in js])
-    assert J8["fp8"].mean() >= 0.5, J8
+    assert J8["fp8"].mean() >= 0.85, J8
     J = np.array([r["jaccard"] for r in rows])
     util.record_margin("decision_flips_summary", frames=len(rows), jaccard_mean=J.mean(), jaccard_min=J.min(), jaccard_max=J.max(),
                        obj_flip_max=max(r["obj_flip"] for r in rows), tpl_flip_mean=float(np.mean([r["tpl_flip"] for r in rows])),

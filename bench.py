@@ -521,7 +521,7 @@ def _pmc_traffic(row):
     Rows name their counter key (`pmc_key` = the kernel's template instance as rocprofv3 prints it); a template instance that runs
     at several shapes in the counter pass (its average would mix them) has none."""
     key = row.get("pmc_key", row["kernel"])
-    for f in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for f in ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", f)))
         except Exception:  # noqa: BLE001

@@ -1,9 +1,9 @@
 # Round-end measurement pass (tests + smoke, bench line with cpu_baseline + configs.fp8 + the whole-frame pipeline block, rocprofv3 kernel
-# stats of the bench command on three streams and on one and of the whole-frame demo, PMC passes folded into profiles/r05_*.json).
+# stats of the bench command on three streams and on one and of the whole-frame demo, PMC passes folded into profiles/r06_*.json).
 #   gpurun --timeout 3000 -- 'bash tools/final_pass.sh'      then copy gpurun_out/prof/* into profiles/
 set -x
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-R=r05
+R=r06
 mkdir -p gpurun_out/prof; rm -f gpurun_out/margins.jsonl
 timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -3 > gpurun_out/prof/${R}_gpu_suite.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 >> gpurun_out/prof/${R}_gpu_suite.txt
@@ -37,7 +37,7 @@ timeout 600 python tools/run_sharded.py --frames 16 --group 8 --out gpurun_out/p
 cat gpurun_out/prof/${R}_gpu_suite.txt
 python - <<'PY'
 import json
-d = json.loads(open("gpurun_out/prof/r05_bench_line.json").read().strip().splitlines()[-1])
+d = json.loads(open("gpurun_out/prof/r06_bench_line.json").read().strip().splitlines()[-1])
 print({k: d.get(k) for k in ("value", "ms_per_step", "stages_ms", "roofline", "extras_error")})
 print("pipeline", d.get("pipeline"))
 print("cpu", d.get("cpu_baseline"))
@@ -45,7 +45,7 @@ for m in ("fp8", "fp8mx"):
     c = d.get("configs", {}).get(m, {})
     print(m, c.get("value"), c.get("ms_per_step"), (c.get("pipeline") or {}).get("frames_per_s"), c.get("error"))
 import csv
-rows = list(csv.DictReader(open("gpurun_out/prof/r05_bench_serial_kernel_stats.csv")))
+rows = list(csv.DictReader(open("gpurun_out/prof/r06_bench_serial_kernel_stats.csv")))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 own = sum(float(r["TotalDurationNs"]) for r in rows if "s6d" in r["Name"])
 print("kernels of this library: %.1f %% of the traced GPU time; library kernels: %.1f %%" % (100 * own / tot, 100 * (1 - own / tot)))

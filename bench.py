@@ -587,8 +587,23 @@ def cpu_baseline():
             Ws = {k: v for k, v in seeded.load_seeded(build_vit_h(), 3).state_dict().items()}
         x = synth.sam_input(1, 5, 1024)
         t_sam, sam_runs = med3(lambda: osam.encoder_forward(Ws, x, osam.VIT_H))
+    # SURVEY 8d says "all host cores (count stated)": the dominant leg (the ViT-H frame, > 85 % of the per-frame time) is timed once
+    # more on ALL hardware threads, so that the choice of 32 is a measurement in the line, not a claim
+    all_cores = None
+    if nproc > cores:
+        torch.set_num_threads(nproc)
+        with torch.no_grad():
+            osam.encoder_forward(Ws, x, osam.VIT_H)
+            t0 = time.perf_counter()
+            osam.encoder_forward(Ws, x, osam.VIT_H)
+            t_all = time.perf_counter() - t0
+        torch.set_num_threads(cores)
+        all_cores = {"threads": nproc, "sam_frame_s": round(t_all, 2), "sam_frame_s_at_cores": round(t_sam, 2),
+                     "faster": "all" if t_all < t_sam else f"{cores} threads"}
+        if t_all < t_sam:                                       # the faster setting is the baseline
+            t_sam, cores = t_all, nproc
     per_frame = t_sam + t_ism + t_pem
-    return {"value": 1.0 / per_frame, "unit": "frames/s", "cores": cores, "nproc": nproc, "kind": "port",
+    return {"value": 1.0 / per_frame, "unit": "frames/s", "cores": cores, "nproc": nproc, "kind": "port", "all_cores_check": all_cores,
             "sample": f"1 warm-up + median of 3 per leg: 1 SAM ViT-H frame ({t_sam:.2f}s; runs "
                       f"{'/'.join(f'{t:.2f}' for t in sam_runs)}) + 1 ISM frame P=128 ({t_ism:.3f}s) + PEM batch of {NB} "
                       f"({t_pem:.2f}s/instance; runs {'/'.join(f'{t / NB:.2f}' for t in pem_runs)}), fp32 torch CPU oracle "

@@ -89,7 +89,25 @@ def frame_records(det, poses, dataset_name, time_s=0.0):
                         poses["pred_R"].detach().float().cpu(), poses["pred_t"].detach().float().cpu(), time_s)
 
 
-def run_sharded(frame_ids, load_frame, pipeline, group_size=8, dataset_name="ycbv", device=None, fixed_time=None):
+def assignment_efficiency(costs, world, policy="round_robin"):
+    """Shard-balance efficiency mean(busy) / max(busy) of `world` ranks for per-frame costs (seconds, in split order) under the static
+    round-robin assignment run_sharded uses (frame i -> rank i % world) or under "lpt" (longest processing time first: frames sorted
+    by cost, each to the least-loaded rank -- the bound a cost-aware assignment could reach; costs are only known after the ISM stage,
+    so this is reported, not used).  Lets a world-1 run say what a world-8 run of the same split would lose to imbalance."""
+    costs = [float(c) for c in costs]
+    busy = [0.0] * world
+    if policy == "round_robin":
+        for i, c in enumerate(costs):
+            busy[i % world] += c
+    elif policy == "lpt":
+        for c in sorted(costs, reverse=True):
+            busy[busy.index(min(busy))] += c
+    else:
+        raise ValueError(policy)
+    return (sum(busy) / world) / max(busy) if max(busy) > 0 else 1.0
+
+
+def run_sharded(frame_ids, load_frame, pipeline, group_size=8, dataset_name="ycbv", device=None, fixed_time=None, prefetch=True):
     """BASELINE configs[2]: the frame loop of a test split sharded over the ranks of one node (the reference: one Lightning
     test step per frame + a per-frame .npz + a file-glob merge, ISM model/detector.py:425-462; PEM test_bop.py:123-185).
 
@@ -108,16 +126,29 @@ def run_sharded(frame_ids, load_frame, pipeline, group_size=8, dataset_name="ycb
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist_on else (0, 1)
     sync = (lambda: torch.cuda.synchronize()) if (device is not None and torch.device(device).type == "cuda") else (lambda: None)
     mine = shard_indices(len(frame_ids), rank, world)
-    blocks, busy, n_inst = [], 0.0, 0
-    for g0 in range(0, len(mine), group_size):
-        ids = [frame_ids[i] for i in mine[g0:g0 + group_size]]
-        frames = [load_frame(s, i) for (s, i) in ids]
+    blocks, busy, n_inst, group_s, load_wait = [], 0.0, 0, [], 0.0
+    groups = [[frame_ids[i] for i in mine[g0:g0 + group_size]] for g0 in range(0, len(mine), group_size)]
+    # The next group's frames are loaded (disk / decode / upload: the caller's load_frame) by ONE background thread while this
+    # group computes (round 6; before, loading sat on the compute thread between two groups).  One group ahead, no queue: the
+    # loader holds at most one group of host / device buffers.  prefetch=False: the old order (the byte-for-byte tests use both).
+    pool = None
+    if prefetch and len(groups) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="s6d-load")
+    load = lambda ids: [load_frame(s, i) for (s, i) in ids]            # noqa: E731
+    pending = pool.submit(load, groups[0]) if pool is not None and groups else None
+    for gi, ids in enumerate(groups):
+        tl = time.perf_counter()
+        frames = pending.result() if pending is not None else load(ids)
+        load_wait += time.perf_counter() - tl
+        pending = pool.submit(load, groups[gi + 1]) if pool is not None and gi + 1 < len(groups) else None
         sync()
         t0 = time.perf_counter()
         res = pipeline.run_group(frames)
         sync()
         dt = time.perf_counter() - t0
         busy += dt
+        group_s.append(dt)
         for (s, i), (det, poses) in zip(ids, res):
             det.scene_id, det.image_id = s, i
             rec = frame_records(det, poses, dataset_name, fixed_time if fixed_time is not None else dt / len(ids))
@@ -132,4 +163,7 @@ def run_sharded(frame_ids, load_frame, pipeline, group_size=8, dataset_name="ycb
     st = torch.tensor([[busy, float(len(mine)), float(n_inst)]], dtype=torch.float32)
     stats = gather_records(torch.nn.functional.pad(st, (0, RECORD_WIDTH - 3)).to(dev)).cpu()[:, :3] if dist_on else st
     eff = float(stats[:, 0].mean() / stats[:, 0].max()) if stats[:, 0].max() > 0 else 1.0
-    return dict(records=full, csv_lines=to_bop_csv_lines(full), stats=stats, balance_efficiency=eff, rank=rank, world=world)
+    if pool is not None:
+        pool.shutdown(wait=True)
+    return dict(records=full, csv_lines=to_bop_csv_lines(full), stats=stats, balance_efficiency=eff, rank=rank, world=world,
+                group_seconds=group_s, load_wait_seconds=load_wait)

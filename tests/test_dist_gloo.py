@@ -94,3 +94,27 @@ def test_sharded_frame_loop_csv_equals_the_single_rank_run(tmp_path, monkeypatch
     # split order: (scene_id, im_id) non-decreasing down the file
     keys = [tuple(int(v) for v in ln.split(",")[:2]) for ln in a.decode().splitlines()]
     assert keys == sorted(keys)
+
+
+def test_prefetch_thread_changes_nothing_and_balance_report():
+    """run_sharded loads the next group's frames on a background thread while the current group computes (round 6): the records are
+    those of the serial order; assignment_efficiency reproduces hand-computed balances of the static round-robin assignment and of
+    the cost-sorted bound."""
+    import torch
+    from sam6d_amd.utils import shard
+    from tools import run_sharded as rs
+    pipe = rs.StandInPipeline()
+
+    def load(s, i):
+        P, K = rs.frame_shape(s, i)
+        g = torch.Generator().manual_seed(s * 7919 + i)
+        return (torch.randint(0, 256, (8, 8, 3), generator=g, dtype=torch.uint8), torch.rand(8, 8, generator=g),
+                torch.eye(3, dtype=torch.float64), torch.rand(K, 64, generator=g), torch.rand(K, 18000, generator=g))
+    ids = rs.frame_list(13)
+    a = shard.run_sharded(ids, load, pipe, group_size=4, fixed_time=0.0, prefetch=True)
+    b = shard.run_sharded(ids, load, pipe, group_size=4, fixed_time=0.0, prefetch=False)
+    assert torch.equal(a["records"], b["records"]) and a["csv_lines"] == b["csv_lines"]
+    assert len(a["group_seconds"]) == 4 and a["load_wait_seconds"] >= 0.0
+    costs = [4, 1, 1, 1, 1, 1, 1, 1, 5]                     # 2 ranks, round robin: 4+1+1+1+5 = 12 | 1+1+1+1 = 4 -> mean 8 / max 12
+    assert abs(shard.assignment_efficiency(costs, 2, "round_robin") - 8 / 12) < 1e-9
+    assert abs(shard.assignment_efficiency(costs, 2, "lpt") - 1.0) < 1e-9      # 5+1+1+1 | 4+1+1+1+1 = 8 | 8

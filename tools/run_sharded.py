@@ -90,7 +90,15 @@ def measure_world1(dev, frames=24, group=8):
     wall = time.perf_counter() - t0
     busy = float(res["stats"][0, 0])
     shapes = [frame_shape(s, i) for (s, i) in ids]
-    return {"workload": f"{frames} synthetic 480x640 frames, proposals per frame {min(p for p, _ in shapes)}..{max(p for p, _ in shapes)} "
+    # what a world-8 run of this split would lose to imbalance, from per-frame busy times measured here (frames alone, groups of 1):
+    # the static round-robin assignment run_sharded uses against the bound of a cost-sorted one
+    one = shard.run_sharded(ids, load, pipe, group_size=1, dataset_name="ycbv", device=dev, fixed_time=0.0)
+    costs = one["group_seconds"]
+    balance = {"frames": len(costs), "frame_ms_min": round(min(costs) * 1e3, 1), "frame_ms_max": round(max(costs) * 1e3, 1),
+               "world8_round_robin": round(shard.assignment_efficiency(costs, 8, "round_robin"), 3),
+               "world8_cost_sorted_bound": round(shard.assignment_efficiency(costs, 8, "lpt"), 3)}
+    return {"load_wait_ms_per_frame_behind_the_prefetch_thread": round(res["load_wait_seconds"] / frames * 1e3, 2),
+            "world8_balance_from_world1_frame_times": balance,"workload": f"{frames} synthetic 480x640 frames, proposals per frame {min(p for p, _ in shapes)}..{max(p for p, _ in shapes)} "
                         f"(mean {sum(p for p, _ in shapes) / frames:.0f}), instances per frame {min(k for _, k in shapes)}..{max(k for _, k in shapes)} "
                         f"(mean {sum(k for _, k in shapes) / frames:.1f}), groups of {group}, one warm-up group untimed",
             "frames_per_s": round(frames / busy, 2), "busy_ms_per_frame": round(busy / frames * 1e3, 2),

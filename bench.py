@@ -230,9 +230,9 @@ _GEMM_WAVE_TILE = 0        # what --gemm-wave-tile set (0 = the library's choice
 
 def _gemm_inst(epi, M):
     """Template instance (as rocprofv3 prints it) that serves a ViT-H Linear with epilogue `epi` at M rows: the four-wave form
-    (csrc/s6d_gemm4.hip) covers epilogues 0, 1, 3, 4 at M % 256 == 0 and is the library's choice there; the residual epilogue (2)
-    and everything else runs the eight-wave form (csrc/s6d_gemm.hip)."""
-    four = _GEMM_WAVE_TILE != 64 and epi in (0, 1, 3, 4) and M % 256 == 0
+    (csrc/s6d_gemm4.hip) covers epilogues 0 - 4 at M % 256 == 0 and runs when --gemm-wave-tile 128 selects it; the library's own
+    choice is the eight-wave form (csrc/s6d_gemm.hip): 0.3 % ahead inside the step once both forms had the round-6 epilogue."""
+    four = _GEMM_WAVE_TILE == 128 and epi in (0, 1, 2, 3, 4) and M % 256 == 0
     return f"gemm4_bf16_kernel<{epi}, true>" if four else f"gemm_bf16_kernel<{epi}, true>"
 
 
@@ -431,7 +431,7 @@ def kernel_rooflines(dev, sam_chunk, frames, in_step=None):
             xr = torch.randn(M, N, generator=g).to(dev).to(torch.bfloat16)
             sp = torch.empty(N // 32, 2, M, device=dev) if folded else None
             b2b = _event_ms(lambda: ops.gemm_bf16(x, w, b, residual=xr, out=xr, stats_partial=sp), 10)
-            inst = "gemm_bf16_kernel<2, true>"
+            inst = _gemm_inst(2, M)
         else:
             b2b = _event_ms(lambda: ops.gemm_bf16(x, w, b, gelu=gelu), 10)
             inst = _gemm_inst(1 if gelu else 0, M)

@@ -262,6 +262,10 @@ def test_lnfold_gemm_with_offset_rows(M, N, K):
     (1536, 768, 192, "gelu", 8),               # 18 tiles on 8 workgroups, three K tiles (the ring wraps inside a tile)
     (1024, 768, 768, "f16_gelu", 0),           # IEEE-half operands
     (768, 256, 1280, "nobias", 8),
+    (65536, 1280, 1280, "res_stats", 0),       # proj of 16 ViT-H frames: residual in the accumulators + partial row statistics, in place
+    (4096, 1280, 5120, "res_stats", 0),        # lin2
+    (2560, 512, 128, "res", 8),                # residual prefetch across tiles: 20 tiles on 8 workgroups, two K tiles each
+    (1536, 768, 192, "res_nobias", 8),
 ])
 def test_four_wave_form_gives_the_bits_of_the_eight_wave_form(M, N, K, kind, blocks):
     """csrc/s6d_gemm4.hip (four waves, 128 x 128 wave tiles, K loop in assembly, accumulators in the accumulator register file) against
@@ -279,20 +283,36 @@ def test_four_wave_form_gives_the_bits_of_the_eight_wave_form(M, N, K, kind, blo
         cs = w.float().sum(1).contiguous()
         fn = lambda: ops.gemm_bf16_lnfold(a, st, w, cs, b, gelu=kind == "lnfold_gelu", col_block=80 if kind == "lnfold_cblk" else 0,   # noqa: E731
                                           max_blocks=blocks)
+    elif kind.startswith("res"):
+        if kind == "res_nobias":
+            b = None
+        r = torch.randn(M, N, generator=g, device="cuda").to(dt)
+        sp = torch.full((N // 32, 2, M), float("nan"), device="cuda") if kind == "res_stats" else None
+        keep = {}
+
+        def fn():
+            x = r.clone()                                   # in place on the residual (what the ViT blocks do)
+            out = ops.gemm_bf16(a, w, b, residual=x, out=x, stats_partial=sp, max_blocks=blocks)
+            if sp is not None:
+                keep["sp"] = sp.clone()
+            return out
     else:
         fn = lambda: ops.gemm_bf16(a, w, b, gelu=kind.endswith("gelu"), max_blocks=blocks)   # noqa: E731
     try:
         ops.set_gemm_wave_tile(64)
         ref = fn().clone()
+        sp_ref = keep["sp"] if kind == "res_stats" else None
         ops.set_gemm_wave_tile(128)
         got = fn().clone()
         assert torch.equal(got, ref), f"{int((got != ref).sum())} of {ref.numel()} values differ from the eight-wave form"
+        if sp_ref is not None:                              # the partial LayerNorm statistics too, bit for bit
+            assert torch.equal(keep["sp"], sp_ref) and torch.isfinite(sp_ref).all()
         for i in range(10):
             assert torch.equal(fn(), got), f"launch {i} differs"
     finally:
         ops.set_gemm_wave_tile(0)
     if not kind.startswith("lnfold"):
-        want = _ref(a, w, b, kind.endswith("gelu"))
+        want = _ref(a, w, b, kind.endswith("gelu")) + (r.float() if kind.startswith("res") else 0.0)
         err = (got.float() - want).abs()
         tol = (2.0 ** -11 if dt == torch.float16 else 2.0 ** -8) * want.abs() + 1e-5
         assert int((err > 1.01 * tol).sum()) == 0, err.max().item()

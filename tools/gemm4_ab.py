@@ -50,6 +50,8 @@ SHAPES = [  # name, M, K, N, kind   (kind: plain / gelu / lnfold / lnfold_gelu /
     ("lin1 gelu", 65536, 1280, 5120, "gelu"),
     ("proj plain", 65536, 1280, 1280, "plain"),
     ("lin2 plain", 65536, 5120, 1280, "plain"),
+    ("proj residual + stats", 65536, 1280, 1280, "res"),
+    ("lin2 residual + stats", 65536, 5120, 1280, "res"),
     ("qkv M=4096", 4096, 1280, 3840, "plain"),
     ("lin1 M=4096 gelu", 4096, 1280, 5120, "gelu"),
 ]
@@ -110,6 +112,10 @@ def main():
             cs = w.float().sum(1).contiguous()
             cb = 80 if kind == "lnfold_cblk" else 0
             fn = lambda: ops.gemm_bf16_lnfold(a, stats, w, cs, b, gelu=kind == "lnfold_gelu", col_block=cb)   # noqa: E731
+        elif kind == "res":
+            xr = torch.randn(M, N, device="cuda").to(torch.bfloat16)
+            sp = torch.empty(N // 32, 2, M, device="cuda")
+            fn = lambda: ops.gemm_bf16(a, w, b, residual=xr, stats_partial=sp)   # noqa: E731
         else:
             fn = lambda: ops.gemm_bf16(a, w, b, gelu=kind == "gelu")   # noqa: E731
         out = {}

@@ -12,7 +12,7 @@ from collections import defaultdict
 # Template instances that tools/pmc_kernels.py launches at TWO shapes, in blocks of RUN launches (bench._event_ms: 1 + 10) that
 # alternate proj, lin2: their rows are split by dispatch order so that each shape gets its own traffic figure.
 RUN = 11
-SPLIT = {"gemm_bf16_kernel<2, true>": ("proj", "lin2")}
+SPLIT = {"gemm_bf16_kernel<2, true>": ("proj", "lin2"), "gemm4_bf16_kernel<2, true>": ("proj", "lin2")}
 out = defaultdict(lambda: defaultdict(list))
 for path in sys.argv[2:]:
     for f in glob.glob(path + "/**/*counter_collection.csv", recursive=True):

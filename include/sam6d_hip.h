@@ -405,6 +405,23 @@ int s6d_geo_embedding_split(const float *idx4, long NP, const void *Wd_hilo, con
 int s6d_linear_f32(const float *x, long ldx, int M, int K, const void *w_hi, const void *w_lo, const float *bias, int N, int act,
                    const float *res, long ldr, const float *gamma, const float *beta, float eps, float *y, long ldy,
                    void *stream);
+
+/* The post-attention chain of a PEM transformer layer in ONE launch (csrc/s6d_pchain.hip):
+ *   h = LN1(x + a W1^T + b1);  y = LN2(h + relu(h We^T + be) Ws^T + bs)
+ * = AttentionLayer / RPEAttentionLayer / LinearAttentionLayer's `norm(linear(attention) + x)` followed by AttentionOutput
+ * (Pose_Estimation_Model/model/transformer.py:182-197, :200-224, :409-438, :567-608).  a, x, y (M,256) f32 with row strides lda / ldx /
+ * ldy (multiples of 4, 16-byte aligned bases); W1 (256,256), We (512,256), Ws (256,512) as the bf16 hi / lo parts made by
+ * s6d_linear_split_weight_f32 AND re-arranged by s6d_linear_fragment_weight (each wave loads its matrix-instruction operands
+ * straight from global memory: W never passes through LDS); biases and LayerNorm parameters f32.  The arithmetic is s6d_linear_f32's,
+ * operation for operation: the result equals three s6d_linear_f32 launches bit for bit.
+ * s6d_linear_fragment_weight: w (N,K) bf16 row-major (N % 32 == 0, K % 16 == 0) -> out, the same elements in fragment order: for row
+ * tile t (32 rows) and k step s (16 wide) the 64 lanes' 8-element fragments back to back -- element (32 t + (lane & 31),
+ * 16 s + 8 (lane >> 5) + e) at ((t K / 16 + s) 64 + lane) 8 + e. */
+int s6d_linear_fragment_weight(const void *w, int N, int K, void *out, void *stream);
+int s6d_attn_output_chain_f32(const float *a, long lda, const float *x, long ldx, int M, const void *w1_hi, const void *w1_lo,
+                              const float *b1, const float *gamma1, const float *beta1, float eps1, const void *we_hi, const void *we_lo,
+                              const float *be, const void *ws_hi, const void *ws_lo, const float *bs, const float *gamma2,
+                              const float *beta2, float eps2, float *y, long ldy, void *stream);
 int s6d_linear_split_weight_f32(const float *w, long n, void *hi, void *lo, void *stream);
 
 /* Soft-assignment head of compute_fine_Rt (Pose_Estimation_Model/utils/model_utils.py:262-270), fused.

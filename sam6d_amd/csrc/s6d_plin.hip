@@ -21,6 +21,7 @@
 // by the host wrapper); the next chunk's global loads are in flight while the current one is multiplied; 50 KB of LDS per
 // workgroup, so three workgroups share a CU and fill each other's barriers.
 #include "s6d_common.h"
+#include "s6d_plin_math.h"
 
 namespace s6d {
 
@@ -170,11 +171,7 @@ __global__ __launch_bounds__(256) void plin_kernel(PlinParams p) {
         if (p.res) rs = *reinterpret_cast<const float4 *>(p.res + (size_t)m * p.ldr + cb + 32 * nt + 8 * q);
         const float rv[4] = {rs.x, rs.y, rs.z, rs.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = acc[mt][nt][4 * q + e] + bv[e];
-          if (p.act == 1) v = fmaxf(v, 0.f);
-          acc[mt][nt][4 * q + e] = v + rv[e];
-        }
+        for (int e = 0; e < 4; ++e) acc[mt][nt][4 * q + e] = pl_bias_act_res(acc[mt][nt][4 * q + e], bv[e], p.act == 1, rv[e]);
       }
     }
   if (p.gamma) {                             // N == 256 (launcher): the workgroup holds whole rows; statistics in two passes
@@ -187,10 +184,7 @@ __global__ __launch_bounds__(256) void plin_kernel(PlinParams p) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float d = pass ? acc[mt][nt][r] - mean[mt] : acc[mt][nt][r];
-            s += pass ? d * d : d;
-          }
+          for (int r = 0; r < 16; ++r) s = pass ? pl_sqdev(s, acc[mt][nt][r], mean[mt]) : s + acc[mt][nt][r];
         red[32 * mt + fr][2 * wave + fh] = s;
       }
       __syncthreads();
@@ -214,7 +208,7 @@ __global__ __launch_bounds__(256) void plin_kernel(PlinParams p) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[mt][nt][4 * q + e] = (acc[mt][nt][4 * q + e] - mean[mt]) * rstd[mt] * gv[e] + tv[e];
+          for (int e = 0; e < 4; ++e) acc[mt][nt][4 * q + e] = pl_normalize(acc[mt][nt][4 * q + e], mean[mt], rstd[mt], gv[e], tv[e]);
       }
   }
 #pragma unroll

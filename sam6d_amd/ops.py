@@ -916,6 +916,48 @@ def linear_f32(x, w_hi, w_lo, bias=None, relu=False, residual=None, ln=None):
     return y.reshape(*x.shape[:-1], N)
 
 
+def fragment_weight(w):
+    """w (N, K) bf16 (a part of split_weight's output) -> the same elements in matrix-instruction fragment order (s6d_linear_fragment_weight),
+    the weight format of attn_output_chain."""
+    _chk(w, torch.bfloat16, "w", 2)
+    w = w.contiguous()
+    out = torch.empty_like(w)
+    _call("s6d_linear_fragment_weight", _ptr(w), int(w.shape[0]), int(w.shape[1]), _ptr(out), _stream())
+    return out
+
+
+def attn_output_chain(a, x, w1, ln1, we, ws, ln2):
+    """LN2(h + relu(h We^T + be) Ws^T + bs) with h = LN1(x + a W1^T + b1) in one kernel (s6d_attn_output_chain_f32): a, x (..., 256)
+    f32; w1 / we / ws = (w_hi, w_lo, bias) of the (256,256) / (512,256) / (256,512) Linear layers (split_weight, each part through
+    fragment_weight); ln1 / ln2 =
+    (gamma, beta, eps).  Equals linear_f32 x 3 bit for bit."""
+    _chk(a, torch.float32, "a")
+    _chk(x, torch.float32, "x")
+    if a.shape != x.shape or a.shape[-1] != 256:
+        raise ValueError(f"a {tuple(a.shape)} and x {tuple(x.shape)} must be (..., 256)")
+    for (hi, lo, b), shp in ((w1, (256, 256)), (we, (512, 256)), (ws, (256, 512))):
+        _chk(hi, torch.bfloat16, "w_hi", 2)
+        _chk(lo, torch.bfloat16, "w_lo", 2)
+        _chk(b, torch.float32, "bias", 1)
+        if tuple(hi.shape) != shp or tuple(lo.shape) != shp or b.numel() != shp[0] or not (hi.is_contiguous() and lo.is_contiguous()):
+            raise ValueError(f"weight parts must be contiguous {shp}")
+    for g, bt, _ in (ln1, ln2):
+        _chk(g, torch.float32, "gamma", 1)
+        _chk(bt, torch.float32, "beta", 1)
+    a2, x2 = a.reshape(-1, 256), x.reshape(-1, 256)
+    if a2.stride(1) != 1 or a2.stride(0) % 4 or a2.data_ptr() % 16:
+        a2 = a2.contiguous()
+    if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
+        x2 = x2.contiguous()
+    M = a2.shape[0]
+    y = torch.empty(M, 256, dtype=torch.float32, device=a.device)
+    _call("s6d_attn_output_chain_f32", _ptr(a2), ctypes.c_long(a2.stride(0)), _ptr(x2), ctypes.c_long(x2.stride(0)), M,
+          _ptr(w1[0]), _ptr(w1[1]), _ptr(w1[2]), _ptr(ln1[0]), _ptr(ln1[1]), ctypes.c_float(ln1[2]),
+          _ptr(we[0]), _ptr(we[1]), _ptr(we[2]), _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(ln2[0]), _ptr(ln2[1]), ctypes.c_float(ln2[2]),
+          _ptr(y), ctypes.c_long(256), _stream())
+    return y.reshape(a.shape)
+
+
 def layernorm_f32out(x, gamma, beta, eps):
     """x (..., C) bf16 -> LN(x) (..., C) float32 (fp32 statistics, no rounding of the result)."""
     _chk(x, torch.bfloat16, "x")
@@ -1177,7 +1219,7 @@ def have(name):
     if name not in _FUSED:
         sym = {"rpe_attention": "s6d_rpe_attention_f32", "rpe_attention_packed": "s6d_rpe_attention_packed_f32", "geo_embedding": "s6d_geo_embedding_f32", "geo_embedding_f16": "s6d_geo_embedding_f16", "geo_embedding_split": "s6d_geo_embedding_split",
                "fine_assign": "s6d_fine_assign_f32", "fine_match": "s6d_fine_match_f32", "pem_pre": "s6d_pem_compact_cloud_f32", "coarse_sample": "s6d_coarse_sample_f32", "upsample_gather": "s6d_upsample_gather_f32",
-               "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "weighted_procrustes": "s6d_weighted_procrustes_f32", "add_layernorm": "s6d_add_layernorm_bf16", "gemm_bf16": "s6d_gemm_bf16", "gemm_bf16_res": "s6d_gemm_bf16_res", "gemm_bf16_lnfold": "s6d_gemm_bf16_lnfold", "gemm_f16": "s6d_gemm_f16", "gemm_fp8": "s6d_gemm_fp8", "layernorm_fp8": "s6d_layernorm_fp8", "layernorm_f32out": "s6d_layernorm_bf16_f32", "linear_f32": "s6d_linear_f32", "win_attention": "s6d_win_attention_layout_bf16",
+               "min_dist": "s6d_min_dist_f32", "rot_from_h": "s6d_rot_from_h_f32", "weighted_procrustes": "s6d_weighted_procrustes_f32", "add_layernorm": "s6d_add_layernorm_bf16", "gemm_bf16": "s6d_gemm_bf16", "gemm_bf16_res": "s6d_gemm_bf16_res", "gemm_bf16_lnfold": "s6d_gemm_bf16_lnfold", "gemm_f16": "s6d_gemm_f16", "gemm_fp8": "s6d_gemm_fp8", "layernorm_fp8": "s6d_layernorm_fp8", "layernorm_f32out": "s6d_layernorm_bf16_f32", "linear_f32": "s6d_linear_f32", "attn_output_chain": "s6d_attn_output_chain_f32", "win_attention": "s6d_win_attention_layout_bf16",
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_sel_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
                "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_sel_f32",

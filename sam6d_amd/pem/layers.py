@@ -85,6 +85,32 @@ class AttentionOutput(nn.Module):
         return plinear(self, self.squeeze, plinear(self, self.expand, x, relu=True), residual=x, norm=self.norm)
 
 
+def _chain_weights(owner, lin):
+    """(w_hi, w_lo, bias) of one nn.Linear in the operand format of s6d_attn_output_chain_f32: the split parts of _plin_weights in
+    matrix-instruction fragment order; cached on `owner` with the split weights' cache entry as the key."""
+    hi, lo, b = _plin_weights(owner, (lin,))
+    name = "_s6d_chain_" + str(id(lin))
+    c = owner.__dict__.get(name)
+    if c is None or c[0] is not hi:
+        c = (hi, ops.fragment_weight(hi), ops.fragment_weight(lo), b)
+        owner.__dict__[name] = c
+    return c[1], c[2], c[3]
+
+
+def attention_output_chain(layer, output, att, x):
+    """``output(layer.norm(layer.linear(att) + x))`` -- what every transformer layer does with its attention core's result
+    (transformer.py:182-197 after :200-224 / :409-438 / :567-608) -- as ONE kernel (csrc/s6d_pchain.hip: the strip stays on chip
+    from the attention output to the layer output; bit for bit the three plinear launches it replaces), else those launches."""
+    if policy.guard("pem.attention_output_chain", cuda=x.is_cuda, have=ops.have("attn_output_chain") and ops.have("linear_f32"),
+                    f32=x.dtype == torch.float32 and att.dtype == torch.float32, C256=x.shape[-1] == 256 and att.shape == x.shape,
+                    no_grad=not torch.is_grad_enabled()):
+        n1, n2 = layer.norm, output.norm
+        return ops.attn_output_chain(att, x, _chain_weights(layer, layer.linear), (n1.weight.detach(), n1.bias.detach(), n1.eps),
+                                     _chain_weights(output, output.expand), _chain_weights(output, output.squeeze),
+                                     (n2.weight.detach(), n2.bias.detach(), n2.eps))
+    return output(plinear(layer, layer.linear, att, residual=x, norm=layer.norm))
+
+
 class MultiHeadAttention(nn.Module):
     """transformer.py:93-148 (no masks / factors are ever passed on the inference path)."""
 
@@ -200,7 +226,7 @@ class TransformerLayer(nn.Module):
         self.output = AttentionOutput(d_model)
 
     def forward(self, x, mem):
-        return self.output(self.attention(x, mem))
+        return attention_output_chain(self.attention, self.output, self.attention.attention(x, mem, mem), x)
 
 
 class RPETransformerLayer(nn.Module):
@@ -210,7 +236,7 @@ class RPETransformerLayer(nn.Module):
         self.output = AttentionOutput(d_model)
 
     def forward(self, x, embed):
-        return self.output(self.attention(x, embed))
+        return attention_output_chain(self.attention, self.output, self.attention.attention(x, embed), x)
 
 
 class GeometricTransformer(nn.Module):
@@ -288,7 +314,7 @@ class LinearTransformerLayer(nn.Module):
         self.output = AttentionOutput(d_model)
 
     def forward(self, x, mem):
-        return self.output(self.attention(x, mem))
+        return attention_output_chain(self.attention, self.output, self.attention.attention(x, mem), x)
 
 
 class SparseToDenseTransformer(nn.Module):

@@ -10,3 +10,8 @@ def test_linear_f32_on_the_emulator(emu):
 def test_linear_attention_on_the_emulator(emu):
     T.test_linear_attention_vs_the_library_statement(2, 100, 37)
     T.test_linear_attention_vs_the_library_statement(3, 64, 196)
+
+
+def test_attention_output_chain_on_the_emulator(emu):
+    T.test_attention_output_chain_equals_the_three_launches_bit_for_bit("mha", 1, 45)
+    T.test_attention_output_chain_equals_the_three_launches_bit_for_bit("linear", 1, 70)

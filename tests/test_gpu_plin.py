@@ -103,3 +103,39 @@ def test_linear_attention_vs_the_library_statement(B, I, J):
     ref = ((q @ (k.transpose(-1, -2) @ v)) * z).transpose(1, 2).reshape(B, I, 256)
     err = (out.double() - ref).abs().max().item()
     assert err <= 2e-5 * (1 + ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("kind,B,N", [("rpe", 2, 197), ("mha", 3, 61), ("linear", 2, 300), ("rpe", 1, 32)])
+def test_attention_output_chain_equals_the_three_launches_bit_for_bit(kind, B, N):
+    """csrc/s6d_pchain.hip (round 6): norm(linear(att) + x) -> AttentionOutput as ONE kernel over 32-row strips against the three
+    s6d_linear_f32 launches it replaces (S6D_DISABLE_FUSED=attn_output_chain) on the real layer classes: equal bits (the same
+    3-term products in the same order, the same fixed-order LayerNorm sums), ragged row counts included; and within fp32-class
+    distance of the library statements in float64."""
+    from sam6d_amd import ops, policy
+    from sam6d_amd.pem import layers as L
+    from sam6d_amd.utils import seeded
+    assert ops.have("attn_output_chain")
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    layer = {"rpe": L.RPETransformerLayer, "mha": L.TransformerLayer, "linear": L.LinearTransformerLayer}[kind](256).eval()
+    seeded.load_seeded(layer, 5)
+    layer = layer.cuda()
+    x = torch.randn(B, N, 256, generator=g).cuda()
+    mem = torch.randn(B, 77, 256, generator=g).cuda()
+    emb = torch.randn(B, N, N, 256, generator=g).cuda() * 0.1
+    arg = emb if kind == "rpe" else mem
+    with torch.no_grad():
+        policy.reset_library_branch_hits()
+        fused = layer(x, arg)
+        assert not policy.library_branch_hits(), policy.library_branch_hits()
+        with policy.use(disable_fused="attn_output_chain"):
+            three = layer(x, arg)
+        assert ("pem.attention_output_chain", "have") in policy.library_branch_hits()
+        assert torch.equal(fused, three), float((fused - three).abs().max())
+        # float64 statement of the chain on the kernel's own attention output
+        att = layer.attention.attention(x, arg) if kind != "mha" else layer.attention.attention(x, arg, arg)
+        a, o = layer.attention, layer.output
+        d = lambda t: t.double()      # noqa: E731
+        h = torch.nn.functional.layer_norm(d(x) + d(att) @ d(a.linear.weight).t() + d(a.linear.bias), (256,), d(a.norm.weight), d(a.norm.bias), a.norm.eps)
+        e = torch.relu(h @ d(o.expand.weight).t() + d(o.expand.bias))
+        y = torch.nn.functional.layer_norm(h + e @ d(o.squeeze.weight).t() + d(o.squeeze.bias), (256,), d(o.norm.weight), d(o.norm.bias), o.norm.eps)
+    assert (fused.double() - y).abs().max().item() <= 2e-4 * max(1.0, y.abs().max().item())

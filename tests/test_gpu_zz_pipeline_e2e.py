@@ -32,6 +32,13 @@ from tests import util
 
 pytestmark = pytest.mark.gpu
 
+# Unstable instances that are NOT within the bar of a stored reference hypothesis (measured, round 6: bop instance 7 -- rotation within
+# the bar, 5.7e-4, translation not; custom instances 7, 15, 19, 20 -- 9e-4 / 0.053 / 0.050 / 0.047 from the nearest stored
+# continuation: the fine stage on junk features is itself ill-conditioned).  They are held to the LOOSE bound below instead.
+MEMBERSHIP_MISSES = {"bop": 1, "custom": 4}
+LOOSE_DR = 0.08                                     # every instance: within this of a pose the reference itself produces
+
+
 _ENV = ("S6D_SAM_DECODER_DTYPE", "S6D_SAM_DTYPE", "S6D_DINO_DTYPE", "S6D_PEM_VIT_DTYPE")
 
 
@@ -103,6 +110,7 @@ def _golden_flow(gp, flow, pc):
     return dict(ism=best_first, kept=gp[p + "kept_pre"].tolist(), obj=gp[p + "obj"], pts=gp[p + "pts"], rgb_choose=gp[p + "rgb_choose"],
                 R=gp[p + "pred_R"], t=gp[p + "pred_t"], pose_score=gp[p + "pred_pose_score"], stable=gp[p + "stable"].astype(bool),
                 kat_obj=gp[p + "kat_obj"],
+                alt_R=gp[p + "alt_pred_R"], alt_t=gp[p + "alt_pred_t"], alt_score=gp[p + "alt_pred_pose_score"], alt_ok=gp[p + "alt_valid"],
                 csv=_parse_csv(str(gp[p + "csv"]).splitlines()), pem=json.loads(str(gp[p + "pem_json"])))
 
 
@@ -162,9 +170,31 @@ def test_pipeline_fp32_pixels_to_poses_vs_reference_golden(flow, monkeypatch):
     util.record_margin("pipeline_e2e_fp32_" + flow, detections=len(recs), instances=len(want["kept"]), stable_instances=int(st.sum()),
                        dR_max_stable=dR[st].max(), dt_mm_max_stable=dt_mm[st].max(), pose_score_diff_max_stable=dscore[st].max(),
                        dR_unstable=[round(float(x), 6) for x in dR[~st]], masks_not_bit_equal=n_frame_spanning, pixels_differing_max=worst_px)
-    assert st.sum() >= len(st) // 3                       # (7 of 11 and 9 of 22: the rest win the arg-max with a rank-deficient triplet)
-    assert dR[st].max() <= 1e-3 and dt_mm[st].max() <= 1e-3, (dR.tolist(), dt_mm.tolist(), st.tolist())
+    assert (int(st.sum()), len(st)) == {"bop": (7, 11), "custom": (9, 22)}[flow]      # the golden's own count: a regenerated
+    assert dR[st].max() <= 1e-3 and dt_mm[st].max() <= 1e-3, (dR.tolist(), dt_mm.tolist(), st.tolist())   # golden with fewer stable rows fails
     assert dscore[st].max() <= 2e-3, dscore.tolist()                     # a ratio of counted inliers (1 of 2048 points = 5e-4)
+    # ---- the UNSTABLE instances are asserted too (round 6, VERDICT r5 next #2b): MEMBERSHIP.  The generator stores every coarse
+    # hypothesis the reference's own compute_coarse_Rt lands on in 96 noise trials (its similarity matrix moved by 1e-5 / 3e-5, its
+    # points by 2e-7 relative) and the reference Net's continuation of each through the fine stage; the product's pose must be
+    # within the bar of the reference's pose OR of one of those continuations, for all but MEMBERSHIP_MISSES instances; and EVERY
+    # instance must be within LOOSE_DR of one of them -- an instance the product moved anywhere else fails.
+    cand_R = np.concatenate([want["R"][None], want["alt_R"]])
+    cand_t = np.concatenate([want["t"][None], want["alt_t"]])
+    cand_s = np.concatenate([want["pose_score"][None], want["alt_score"]])
+    cand_ok = np.concatenate([np.ones((1, len(st)), bool), want["alt_ok"]])
+    which = np.full(len(st), -1)
+    for j in range(len(st)):
+        for k in range(cand_R.shape[0]):
+            if cand_ok[k, j] and np.linalg.norm(R[j] - cand_R[k, j]) <= 1e-3 and np.linalg.norm(t[j] - cand_t[k, j]) * 1e3 <= 1e-3 \
+                    and abs(float(poses["pred_pose_score"][j]) - cand_s[k, j]) <= 2e-3:
+                which[j] = k
+                break
+    util.record_margin("pipeline_e2e_fp32_membership_" + flow, matched_hypothesis=which.tolist(), alternatives=want["alt_ok"].sum(0).tolist())
+    near = [min(float(np.linalg.norm(R[j] - cand_R[k, j])) for k in range(cand_R.shape[0]) if cand_ok[k, j]) for j in range(len(st))]
+    util.record_margin("pipeline_e2e_fp32_membership_near_" + flow, nearest_dR=[round(x, 5) for x in near])
+    assert (which[st] == 0).all(), (which.tolist(), dR.round(4).tolist())
+    assert (which >= 0).sum() >= len(st) - MEMBERSHIP_MISSES[flow], (which.tolist(), near)
+    assert max(near) <= LOOSE_DR, near              # (a pose moved by a product bug lands ~1 away in the Frobenius norm, not 0.05)
     # ---- known answers: a detection of the window its object was made from recovers the seeded pose as well as the reference does ---
     kat = want["kat_obj"]
     assert (kat >= 0).sum() == 3 and st[kat >= 0].sum() >= 2          # (custom flow: one of the three moves 4.6e-3 in the noise trials)

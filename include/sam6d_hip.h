@@ -393,6 +393,11 @@ int s6d_geo_embedding_f16(const float *idx4, long NP, const float *Wd, const flo
  * points is half of their vector instructions.  out: (NP,C) f32, or f16 when out_f16 != 0.  Same values bit for bit. */
 int s6d_geo_embedding_split(const float *idx4, long NP, const void *Wd_hilo, const float *bd, const void *Wa_hilo,
                             const float *ba, const float *div_term, int C, int K, void *out, int out_f16, void *stream);
+/* Which kernel serves s6d_geo_embedding_split (process-wide, like s6d_set_gemm_wave_tile): 1 = the two-phase kernel of rounds 3-5
+ * (default: 2 % ahead in the benched step), 2 = geo_embed2_kernel (round 6: sinusoid fragments built in registers, only the weight
+ * slices in LDS by LDS-DMA, one barrier per k-step, no LDS bank conflicts; profiles/r06_geo_embed.md).  Same bits either way.
+ * Other values: S6D_EINVAL. */
+int s6d_set_geo_embed_form(int form);
 
 /* Fused fp32 Linear of the point transformer:  y = LN( res + act( x W^T + b ) )  with every stage optional.
  * x (M,K) f32 row stride ldx; W given as its bf16 hi / lo parts (N,K) each, made once per weight version by

@@ -226,9 +226,207 @@ __global__ __launch_bounds__(GEO_THREADS) void geo_embed_kernel(const float *__r
   }
 }
 
+// ---- round 6: the pre-split form without the operand phase ---------------------------------------------
+// geo_embed_kernel above spends a k-step in two phases behind two barriers: every thread builds a share of the sinusoid fragments and
+// of the weight slices in LDS (12 ds_write_b128 per thread), then every wave reads 40 fragments back for 96 matrix instructions;
+// nothing of phase 1 runs under phase 2 (one workgroup per CU: 120 KB of LDS), and the counted "one bank conflict per matrix
+// instruction" is the 2-way conflict of those twelve stores (8 extra LDS cycles each = 96 per wave and k-step).  Here
+//   * a lane builds ITS OWN sinusoid fragments in registers: lane (c, g) of wave (mt, nh) needs, per embedding, the 8 channels
+//     [8 g, 8 g + 8) of pair 16 mt + c = four sin / cos pairs; the NEXT k-step's are computed while this k-step's matrix
+//     instructions issue.  No LDS traffic, no barrier for them (the two nh waves of a pair tile compute the same values twice:
+//     16 sincos per lane and k-step instead of 8, on vector slots the matrix pipe leaves idle);
+//   * LDS holds only the weight slices, in two stages of [4 parts][256 rows][32] bf16 = 64 KB: slice ks + 1 is stored while slice ks
+//     is multiplied, ONE barrier per k-step.  Rows are 64 bytes apart, the chunk of a row XOR-ed with 2 (row >> 3 & 1): the sixteen
+//     lanes of a ds_read_b128 group ({c 0-3, 12-15 at chunk g} + {c 4-11 at chunk g + 1}) then cover the sixteen 16-byte slots of
+//     the 256-byte bank row exactly once, and a ds_write_b128 group (two rows x four chunks) is 128 contiguous bytes.
+// Arithmetic: the same fragments, the same products in the same order per accumulator -> the same bits as geo_embed_kernel
+// (tests/test_gpu_pose.py::test_half_stored_geo_embedding_and_its_reader holds the two to torch.equal).
+// MEASURED (profiles/r06_geo_embed.md): LDS bank conflicts 78.2 M -> 0, LDS-array cycles 287 M -> 104 M, waits on LDS 123 M -> 9 M per
+// launch -- and 1.95 ms against 1.90 ms for the two-phase kernel at 32 instances (the PEM stage 20.97 against 20.83 ms).  Ablation
+// builds (S6D_G2_ABL): without the weight staging 1.66 ms, without the sinusoids 1.67, without both 1.41 -- and the BARE stream
+// of matrix instructions, nothing else in the loop, 1.41 ms = 0.56 of the nominal bf16 rate: the chip sustains ~1400 TFLOP/s of
+// 16x16x32 products under its power limit, everything beside them costs clock, and this form spends more vector instructions
+// (each nh wave builds the fragments its twin builds too: 3.7 against 1.7 per matrix instruction) than it saves in LDS work.
+// The two-phase kernel therefore stays the default (s6d_set_geo_embed_form(2) selects this one).
+#ifndef S6D_G2_ABL
+#define S6D_G2_ABL 0                                               // timing-only ablation builds (tools/probes/geo_variants.sh): 1 no weight staging, 2 no sinusoids, 4 one fragment set
+#endif
+constexpr int G2_WROW = 32;                                        // bf16 per row and part in a stage (64 B)
+constexpr int G2_PART = GEO_C * G2_WROW;
+constexpr int G2_STAGE = 4 * G2_PART;                              // W_d hi | W_d lo | W_a hi | W_a lo
+constexpr int G2_LDS_BYTES = 2 * G2_STAGE * 2;                     // 128 KB
+#define G2_LDS(T) __attribute__((address_space(3))) T
+#define G2_GLOBAL(T) __attribute__((address_space(1))) T
+#ifdef HIPEMU
+#define G2_VMCNT0() hipemu::vmcnt_wait(0)
+#else
+#define G2_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+__device__ __forceinline__ int g2_swz(int row) { return ((row >> 3) & 1) << 1; }
+
+template <bool HALF>
+__global__ __launch_bounds__(GEO_THREADS) void geo_embed2_kernel(const float *__restrict__ idx4, long NP, const u16 *__restrict__ Wd,
+                                                                const float *__restrict__ bd, const u16 *__restrict__ Wa,
+                                                                const float *__restrict__ ba, const float *__restrict__ div_term,
+                                                                void *__restrict__ outv) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u16 *lds = reinterpret_cast<u16 *>(smem);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int c = lane & 15, g = lane >> 4;
+  const int mt = wave & 3, nh = wave >> 2;
+  const long pair0 = (long)blockIdx.x * GEO_PAIRS;
+  float xv[4];
+  {
+    const long pr = min(pair0 + mt * 16 + c, NP - 1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xv[e] = idx4[pr * 4 + e];
+  }
+  // weight slice of k-step ks -> stage: LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write).  A piece = one part's 16 rows
+  // x 64 B = 1 KiB per wave instruction; lane l of wave w lands at element it = 64 w + l (+ 512 for the second piece) of the part's
+  // [256 rows][4 chunks] image, i.e. row it / 4 at chunk POSITION it % 4, and fetches the chunk (position ^ swizzle(row)) there.
+  auto wstage = [&](int ks, int stage) __attribute__((always_inline)) {
+    const u16 *parts[4] = {Wd, Wd + GEO_C * GEO_C, Wa, Wa + GEO_C * GEO_C};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int it = tid + n * GEO_THREADS;
+        const int row = it >> 2, ch = it & 3;
+        const u16 *src = parts[q] + (size_t)row * GEO_C + ks * 32 + ((ch ^ g2_swz(row)) * 8);
+        G2_LDS(char) *dst = (G2_LDS(char) *)smem + ((stage * G2_STAGE + q * G2_PART) * 2 + (wave * 64 + n * GEO_THREADS) * 16);
+        __builtin_amdgcn_global_load_lds((const G2_GLOBAL(void) *)src, dst, 16, 0, 0);
+      }
+  };
+  // the lane's sinusoid fragments of k-step ks: [embedding] chunk g = frequencies 16 ks + 4 g + j, interleaved [sin, cos] (:279-280)
+  auto frags = [&](int ks, bf16x8 (&ah)[4], bf16x8 (&al)[4]) __attribute__((always_inline)) {
+    float w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = div_term[ks * 16 + g * 4 + j];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      union { bf16x8 v; u16 h[8]; } hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float sn, cs;
+        fast_sincos(xv[e] * w[j], sn, cs);                         // same fp32 product as the reference (:275)
+        split_bf16(sn, hi.h[2 * j], lo.h[2 * j]);
+        split_bf16(cs, hi.h[2 * j + 1], lo.h[2 * j + 1]);
+      }
+      ah[e] = hi.v;
+      al[e] = lo.v;
+    }
+  };
+
+  f32x4 accd[8], acca[3][8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    accd[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) acca[k][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  bf16x8 ah[4], al[4];
+  wstage(0, 0);
+  frags(0, ah, al);
+  float wq[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wq[j] = div_term[16 + g * 4 + j];
+  G2_VMCNT0();
+  __syncthreads();
+#pragma unroll 1
+  for (int ks = 0; ks < GEO_C / 32; ++ks) {
+    const int st = ks & 1;
+    // (no conditions on the last k-step: its surplus slice goes to a stage nobody reads again, its surplus fragments are dropped)
+#if !(S6D_G2_ABL & 1)
+    wstage(min(ks + 1, GEO_C / 32 - 1), st ^ 1);                   // every wave is past its reads of that stage (barrier below)
+#endif
+    // the NEXT k-step's sinusoid fragments are built in eight portions (two sin / cos pairs each), one behind each output tile's
+    // twelve matrix instructions, with a scheduling fence between the portions: left to itself the compiler runs all ~240 vector
+    // instructions first and the 96 products after them, and both waves of a SIMD then want the same pipe at the same time;
+    // in portions the two waves fall one portion out of step and one's vector work runs under the other's products
+    float wq2[4];                                                  // the frequencies of the portions of the NEXT iteration (a load
+#pragma unroll                                                     // consumed in this one would stall the first portion)
+    for (int j = 0; j < 4; ++j) wq2[j] = div_term[min(ks + 2, GEO_C / 32 - 1) * 16 + g * 4 + j];
+    union { bf16x8 v; u16 h[8]; } nhi[4], nlo[4];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int o = st * G2_STAGE + (nh * 128 + ((S6D_G2_ABL & 4) ? 0 : t) * 16 + c) * G2_WROW + (g ^ g2_swz(c)) * 8;
+      const bf16x8 wdh = *reinterpret_cast<const bf16x8 *>(lds + o);
+      const bf16x8 wdl = *reinterpret_cast<const bf16x8 *>(lds + G2_PART + o);
+      const bf16x8 wah = *reinterpret_cast<const bf16x8 *>(lds + 2 * G2_PART + o);
+      const bf16x8 wal = *reinterpret_cast<const bf16x8 *>(lds + 3 * G2_PART + o);
+      // issue order: the four accumulators of the tile in turn, so that a matrix instruction's accumulator input is three
+      // instructions old (a dependent 16x16x32 issued back to back waits for the whole pipe: the bare product stream of this
+      // kernel measured 0.56 of the peak rate with the three terms of an accumulator in a row); per accumulator the order of the
+      // terms -- x_hi w_hi, x_lo w_hi, x_hi w_lo -- is unchanged, so the bits are
+      accd[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], wdh, accd[t], 0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acca[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1 + k], wah, acca[k][t], 0, 0, 0);
+      accd[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[0], wdh, accd[t], 0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acca[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[1 + k], wah, acca[k][t], 0, 0, 0);
+      accd[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[0], wdl, accd[t], 0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acca[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[1 + k], wal, acca[k][t], 0, 0, 0);
+#if !(S6D_G2_ABL & 2)
+      {
+        const int e = t >> 1;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int j = (t & 1) * 2 + jj;
+          float sn, cs;
+          fast_sincos(xv[e] * wq[j], sn, cs);                      // same fp32 product as the reference (:275)
+          split_bf16(sn, nhi[e].h[2 * j], nlo[e].h[2 * j]);        // interleaved [sin w, cos w] layout (:279-280)
+          split_bf16(cs, nhi[e].h[2 * j + 1], nlo[e].h[2 * j + 1]);
+        }
+      }
+#else
+      nhi[t >> 1].v = ah[t >> 1];
+      nlo[t >> 1].v = al[t >> 1];
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    bf16x8 nh_[4], nl_[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      nh_[e] = nhi[e].v;
+      nl_[e] = nlo[e].v;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wq[j] = wq2[j];
+    G2_VMCNT0();                                                   // the next slice has landed (issued ~1500 matrix-pipe cycles ago)
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ah[e] = nh_[e];
+      al[e] = nl_[e];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int n = nh * 128 + t * 16 + c;
+    const float bias = bd[n] + ba[n];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long pr = pair0 + mt * 16 + g * 4 + r;
+      const float v = accd[t][r] + fmaxf(fmaxf(acca[0][t][r], acca[1][t][r]), acca[2][t][r]) + bias;
+      if (pr < NP) {
+        if (HALF) reinterpret_cast<_Float16 *>(outv)[pr * GEO_C + n] = (_Float16)v;
+        else reinterpret_cast<float *>(outv)[pr * GEO_C + n] = v;
+      }
+    }
+  }
+}
+
 }  // namespace s6d
 
 using namespace s6d;
+
+static int g_geo_form = 1;          // 1: geo_embed_kernel<., true> (default: 2 % ahead in the step); 2: geo_embed2_kernel (selectable; profiles/r06_geo_embed.md)
+extern "C" int s6d_set_geo_embed_form(int form) {
+  if (form != 1 && form != 2) return S6D_EINVAL;
+  g_geo_form = form;
+  return S6D_OK;
+}
 
 template <bool HALF, bool PRE>
 static void geo_launch_t(const float *idx4, long NP, const float *Wd, const float *bd, const float *Wa, const float *ba,
@@ -247,6 +445,18 @@ static int geo_launch(const float *idx4, long NP, const void *Wd, const float *b
   if (!idx4 || !Wd || !bd || !Wa || !ba || !div_term || !out) return S6D_EINVAL;
   if (pre && (((uintptr_t)Wd | (uintptr_t)Wa) & 15)) return S6D_EINVAL;
   const float *wd = reinterpret_cast<const float *>(Wd), *wa = reinterpret_cast<const float *>(Wa);
+  if (pre && g_geo_form == 2) {
+    const unsigned grid = (unsigned)((NP + GEO_PAIRS - 1) / GEO_PAIRS);
+    const u16 *wdh = reinterpret_cast<const u16 *>(Wd), *wah = reinterpret_cast<const u16 *>(Wa);
+    if (half) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&geo_embed2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
+      hipLaunchKernelGGL((geo_embed2_kernel<true>), dim3(grid), dim3(GEO_THREADS), G2_LDS_BYTES, as_stream(stream), idx4, NP, wdh, bd, wah, ba, div_term, out);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&geo_embed2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
+      hipLaunchKernelGGL((geo_embed2_kernel<false>), dim3(grid), dim3(GEO_THREADS), G2_LDS_BYTES, as_stream(stream), idx4, NP, wdh, bd, wah, ba, div_term, out);
+    }
+    return launch_status();
+  }
   if (half) {
     if (pre) geo_launch_t<true, true>(idx4, NP, wd, bd, wa, ba, div_term, out, stream);
     else geo_launch_t<true, false>(idx4, NP, wd, bd, wa, ba, div_term, out, stream);

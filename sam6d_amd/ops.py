@@ -702,6 +702,12 @@ def gemm_bf16(a, w, bias=None, gelu=False, out=None, max_blocks=0, col_block=0, 
     return out.reshape(*a.shape[:-1], N)
 
 
+def set_geo_embed_form(form):
+    """Which kernel serves the pre-split geometric embedding (include/sam6d_hip.h: s6d_set_geo_embed_form): 1 = the two-phase kernel
+    of rounds 3-5 (default), 2 = registers-built sinusoid fragments + LDS-DMA weight slices (round 6).  Same bits."""
+    _call("s6d_set_geo_embed_form", int(form))
+
+
 def set_gemm_wave_tile(columns):
     """Which form of the bf16 / f16 GEMM kernel serves the shapes both cover (include/sam6d_hip.h: s6d_set_gemm_wave_tile): 0 = the
     library's choice per shape, 64 = the eight-wave form, 128 = the four-wave form wherever it applies.  Process-wide; for A/B

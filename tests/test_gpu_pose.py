@@ -73,6 +73,13 @@ def test_half_stored_geo_embedding_and_its_reader(ops):
     assert split is not None and split[0].shape == (2, 256, 256) and split[0].dtype == torch.bfloat16
     assert torch.equal(ops.geo_embedding(*args, split=split).cpu(), e32.cpu())
     assert torch.equal(ops.geo_embedding(*args, out_dtype=torch.float16, split=split).cpu(), e16.cpu())
+    # ... and both kernels that serve the pre-split operands (round 6: geo_embed2_kernel builds the sinusoid fragments in registers)
+    try:
+        ops.set_geo_embed_form(2)
+        assert torch.equal(ops.geo_embedding(*args, split=split).cpu(), e32.cpu())
+        assert torch.equal(ops.geo_embedding(*args, out_dtype=torch.float16, split=split).cpu(), e16.cpu())
+    finally:
+        ops.set_geo_embed_form(1)
     g = torch.Generator().manual_seed(2)
     B, N = pts.shape[:2]
     q, k, v = (torch.randn(B, N, 256, generator=g).cuda() for _ in range(3))

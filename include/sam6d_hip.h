@@ -427,6 +427,25 @@ int s6d_attn_output_chain_f32(const float *a, long lda, const float *x, long ldx
                               const float *b1, const float *gamma1, const float *beta1, float eps1, const void *we_hi, const void *we_lo,
                               const float *be, const void *ws_hi, const void *ws_lo, const float *bs, const float *gamma2,
                               const float *beta2, float eps2, float *y, long ldy, void *stream);
+/* The TOKEN side of a SAM TwoWayAttentionBlock (csrc/s6d_samtok.hip; segment_anything/modeling/transformer.py:109-186 steps 1-3 for
+ * the sparse tokens, :189-240 Attention) as two launches around the token->image attention core (s6d_samdec_tok2img_raw_bf16):
+ *   pre : x = queries (+ pe when add_pe);  a = self_attn(q = x, k = x, v = queries);  q1 = norm1(add_pe ? queries + a : a);
+ *         qp = cross_attn_token_to_image.q_proj(q1 + pe)
+ *   post: q2 = norm2(q1 + cross_attn_token_to_image.out_proj(att));  q3 = norm3(q2 + mlp(q2));
+ *         kt = cross_attn_image_to_token.k_proj(q3 + pe);  vt = cross_attn_image_to_token.v_proj(q3)
+ * queries, pe, q1, q3 (B,T,256) f32; qp, att, kt, vt (B,T,128) f32; T <= 8 tokens per prompt; all 16-byte aligned, contiguous.
+ * Every weight is bf16 (N,K) in the FRAGMENT ORDER of s6d_linear_fragment_weight (wq / wk / wv / wo (256,256), wq2 / wk3 / wv3
+ * (128,256), wo2 (256,128), w1 (2048,256), w2 (256,2048)); biases and LayerNorm parameters f32.  Arithmetic = the bf16 autocast
+ * statement of the reference modules: a Linear multiplies bf16-rounded activations by bf16 weights, accumulates in fp32 and rounds
+ * its result to bf16; LayerNorm, residual adds and the softmax are fp32. */
+int s6d_samdec_tokens_pre_bf16(const float *queries, const float *pe, int B, int T, int add_pe, const void *wq, const float *bq,
+                               const void *wk, const float *bk, const void *wv, const float *bv, const void *wo, const float *bo,
+                               const float *gamma1, const float *beta1, float eps1, const void *wq2, const float *bq2, float *q1_out,
+                               float *qp_out, void *stream);
+int s6d_samdec_tokens_post_bf16(const float *q1, const float *att, const float *pe, int B, int T, const void *wo2, const float *bo2,
+                                const float *gamma2, const float *beta2, float eps2, const void *w1, const float *b1, const void *w2,
+                                const float *b2, const float *gamma3, const float *beta3, float eps3, const void *wk3, const float *bk3,
+                                const void *wv3, const float *bv3, float *q3_out, float *kt_out, float *vt_out, void *stream);
 int s6d_linear_split_weight_f32(const float *w, long n, void *hi, void *lo, void *stream);
 
 /* Soft-assignment head of compute_fine_Rt (Pose_Estimation_Model/utils/model_utils.py:262-270), fused.

@@ -385,6 +385,43 @@ def samdec_tok2img_raw(qt, x, pe, wk, wv, bv, scale):
     return out.reshape(B, T, 128)
 
 
+def samdec_tokens_pre(queries, pe, add_pe, lin_q, lin_k, lin_v, lin_o, norm1, lin_q2):
+    """Self-attention + norm1 + token->image query projection of a TwoWayAttentionBlock's sparse tokens in one launch
+    (s6d_samdec_tokens_pre_bf16).  queries, pe (B,T<=8,256) f32; lin_* = (fragment-ordered bf16 weight, f32 bias); norm1 =
+    (gamma, beta, eps) -> (q1 (B,T,256) f32, qp (B,T,128) f32)."""
+    _chk(queries, torch.float32, "queries", 3)
+    _chk(pe, torch.float32, "pe", 3)
+    B, T, C = queries.shape
+    if C != 256 or T > 8 or pe.shape != queries.shape:
+        raise ValueError("samdec_tokens_pre: queries / pe must be (B, T <= 8, 256)")
+    queries, pe = queries.contiguous(), pe.contiguous()
+    q1 = torch.empty(B, T, 256, dtype=torch.float32, device=queries.device)
+    qp = torch.empty(B, T, 128, dtype=torch.float32, device=queries.device)
+    _call("s6d_samdec_tokens_pre_bf16", _ptr(queries), _ptr(pe), B, T, 1 if add_pe else 0, _ptr(lin_q[0]), _ptr(lin_q[1]), _ptr(lin_k[0]),
+          _ptr(lin_k[1]), _ptr(lin_v[0]), _ptr(lin_v[1]), _ptr(lin_o[0]), _ptr(lin_o[1]), _ptr(norm1[0]), _ptr(norm1[1]),
+          ctypes.c_float(norm1[2]), _ptr(lin_q2[0]), _ptr(lin_q2[1]), _ptr(q1), _ptr(qp), _stream())
+    return q1, qp
+
+
+def samdec_tokens_post(q1, att, pe, lin_o2, norm2, lin_1, lin_2, norm3, lin_k3, lin_v3):
+    """Attention output projection + norm2 + MLP + norm3 + the image->token attention's k / v projections in one launch
+    (s6d_samdec_tokens_post_bf16).  q1, pe (B,T,256) f32, att (B,T,128) f32 -> (q3 (B,T,256), kt (B,T,128), vt (B,T,128)) f32."""
+    _chk(q1, torch.float32, "q1", 3)
+    _chk(att, torch.float32, "att", 3)
+    _chk(pe, torch.float32, "pe", 3)
+    B, T, C = q1.shape
+    if C != 256 or T > 8 or pe.shape != q1.shape or tuple(att.shape) != (B, T, 128):
+        raise ValueError("samdec_tokens_post: q1 / pe must be (B, T <= 8, 256), att (B, T, 128)")
+    q1, att, pe = q1.contiguous(), att.contiguous(), pe.contiguous()
+    q3 = torch.empty(B, T, 256, dtype=torch.float32, device=q1.device)
+    kt = torch.empty(B, T, 128, dtype=torch.float32, device=q1.device)
+    vt = torch.empty(B, T, 128, dtype=torch.float32, device=q1.device)
+    _call("s6d_samdec_tokens_post_bf16", _ptr(q1), _ptr(att), _ptr(pe), B, T, _ptr(lin_o2[0]), _ptr(lin_o2[1]), _ptr(norm2[0]), _ptr(norm2[1]),
+          ctypes.c_float(norm2[2]), _ptr(lin_1[0]), _ptr(lin_1[1]), _ptr(lin_2[0]), _ptr(lin_2[1]), _ptr(norm3[0]), _ptr(norm3[1]),
+          ctypes.c_float(norm3[2]), _ptr(lin_k3[0]), _ptr(lin_k3[1]), _ptr(lin_v3[0]), _ptr(lin_v3[1]), _ptr(q3), _ptr(kt), _ptr(vt), _stream())
+    return q3, kt, vt
+
+
 def sam_mask_post(low_res, img_size, input_size, original_size, mask_threshold=0.0, stability_offset=1.0):
     """Fused Sam.postprocess_masks + stability score + threshold + boxes.  low_res (B,C,n,n) f32 -- contiguous, or a channel
     slice ``full[:, c0:c0 + C]`` of a contiguous (B,Ct,n,n) tensor, which is read in place ->
@@ -1229,7 +1266,7 @@ def have(name):
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_sel_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
                "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_sel_f32",
-               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "im2col3x3": "s6d_im2col3x3_b16", "nonfinite_rows": "s6d_nonfinite_rows_f32", "patchify": "s6d_patchify_b16", "crop_resize_pad": "s6d_crop_resize_pad_f32", "samdec_img2tok": "s6d_samdec_img2tok_bf16", "samdec_img2tok_raw": "s6d_samdec_img2tok_raw_bf16", "samdec_tok2img": "s6d_samdec_tok2img_f32", "samdec_tok2img_raw": "s6d_samdec_tok2img_raw_bf16", "sam_mask_post": "s6d_sam_mask_post_sel_f32", "gemm_fp8_mx": "s6d_gemm_fp8_mxa", "nms": "s6d_nms_f32", "samdec_upscale_heads": "s6d_samdec_upscale_heads_bf16", "mha": "s6d_mha_f32",
+               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "im2col3x3": "s6d_im2col3x3_b16", "nonfinite_rows": "s6d_nonfinite_rows_f32", "patchify": "s6d_patchify_b16", "crop_resize_pad": "s6d_crop_resize_pad_f32", "samdec_img2tok": "s6d_samdec_img2tok_bf16", "samdec_img2tok_raw": "s6d_samdec_img2tok_raw_bf16", "samdec_tok2img": "s6d_samdec_tok2img_f32", "samdec_tok2img_raw": "s6d_samdec_tok2img_raw_bf16", "sam_mask_post": "s6d_sam_mask_post_sel_f32", "gemm_fp8_mx": "s6d_gemm_fp8_mxa", "nms": "s6d_nms_f32", "samdec_upscale_heads": "s6d_samdec_upscale_heads_bf16", "samdec_tokens": "s6d_samdec_tokens_post_bf16", "mha": "s6d_mha_f32",
                "linear_attn_focus": "s6d_linear_attn_focus_f32", "linear_attention": "s6d_linear_attention_f32", "project_bbox": "s6d_project_bbox_frames_f32"}.get(name)
         _FUSED[name] = sym is not None and hasattr(_lib.lib(), sym)
     # (policy.disable_fused: kernel names the modules must not use -- the tests' way of forcing the library statement)

@@ -407,6 +407,41 @@ class MaskDecoder(nn.Module):
             self._s6d_prep = c
         return c[1]
 
+    def _token_weights(self, li):
+        """Operands of the token-side kernels (ops.samdec_tokens_pre / _post) for layer li: every Linear as (bf16 weight in
+        matrix-instruction fragment order, f32 bias), the LayerNorms as (gamma, beta, eps); cached per weight version."""
+        L = self.transformer.layers[li]
+        sa, ca, ci = L.self_attn, L.cross_attn_token_to_image, L.cross_attn_image_to_token
+        lins = [sa.q_proj, sa.k_proj, sa.v_proj, sa.out_proj, ca.q_proj, ca.out_proj, L.mlp.lin1, L.mlp.lin2, ci.k_proj, ci.v_proj]
+        norms = [L.norm1, L.norm2, L.norm3]
+        srcs = [t for m in lins + norms for t in (m.weight, m.bias)]
+        key = tuple((t._version, t.data_ptr()) for t in srcs)
+        cache = self.__dict__.setdefault("_s6d_tokw", {})
+        c = cache.get(li)
+        if c is None or c[0] != key:
+            with torch.no_grad(), torch.autocast(device_type="cuda", enabled=False):
+                lw = [(ops.fragment_weight(m.weight.detach().to(torch.bfloat16).contiguous()), m.bias.detach().float().contiguous()) for m in lins]
+                nw = [(m.weight.detach().float().contiguous(), m.bias.detach().float().contiguous(), float(m.eps)) for m in norms]
+            c = (key, lw, nw)
+            cache[li] = c
+        return c[1], c[2]
+
+    def _token_side(self, li, queries, tokens, t2i):
+        """TwoWayAttentionBlock.token_side of layer li + the k / v projections of its image->token attention, on the two
+        token-side kernels (csrc/s6d_samtok.hip) around the token->image attention core `t2i` -> (queries, (kt, vt)); the module
+        statements when the kernels do not apply."""
+        L = self.transformer.layers[li]
+        if policy.guard("sam.MaskDecoder.token_side", cuda=queries.is_cuda, have=ops.have("samdec_tokens"), T8=queries.shape[1] <= 8,
+                        f32=queries.dtype == torch.float32 and tokens.dtype == torch.float32, t2i=t2i is not None,
+                        geometry=L.self_attn.internal_dim == 256 and L.mlp.lin1.out_features == 2048):
+            lw, nw = self._token_weights(li)
+            with torch.autocast(device_type="cuda", enabled=False):
+                q1, qp = ops.samdec_tokens_pre(queries, tokens, not L.skip_first_layer_pe, lw[0], lw[1], lw[2], lw[3], nw[0], lw[4])
+                att = t2i(qp)
+                q3, kt, vt = ops.samdec_tokens_post(q1, att, tokens, lw[5], nw[1], lw[6], lw[7], nw[2], lw[8], lw[9])
+            return q3, (kt, vt)
+        return L.token_side(queries, tokens, None, None, t2i), None
+
     @staticmethod
     def _rows_gemm(x, w, b):
         """x (B, N, K) bf16 @ w (n, K)^T + b over ALL B N image-token rows (1024 prompts x 4096 tokens = 4.2 M rows): the
@@ -427,15 +462,19 @@ class MaskDecoder(nn.Module):
         return F.linear(x, w, b)
 
     @staticmethod
-    def _expand(att, queries, tokens, fold_q=False):
+    def _expand(att, queries, tokens, fold_q=False, ktvt=None):
         """Operands of s6d_samdec_img2tok_bf16 from the prompt tokens: block-diagonal scaled keys (B,64,128) and the
         values with out_proj folded in (B,256,64); slot j = head * 8 + token.
         fold_q: the image side's q projection folded into the keys (s6d_samdec_img2tok_raw_bf16) -> (kexp W_q (B,64,256) bf16,
-        kexp . b_q (B,64) f32, vpt)."""
+        kexp . b_q (B,64) f32, vpt).
+        ktvt: (k_proj(queries + tokens), v_proj(queries)) as (B,T,128) f32 when the token-side kernel has made them already."""
         B, T, _ = queries.shape
         H, hd = att.num_heads, att.internal_dim // att.num_heads
-        kt = (att.k_proj(queries + tokens).float() / math.sqrt(hd)).view(B, T, H, hd)
-        vt = att.v_proj(queries).float().view(B, T, H, hd)
+        if ktvt is not None:
+            kt, vt = (ktvt[0] / math.sqrt(hd)).view(B, T, H, hd), ktvt[1].view(B, T, H, hd)
+        else:
+            kt = (att.k_proj(queries + tokens).float() / math.sqrt(hd)).view(B, T, H, hd)
+            vt = att.v_proj(queries).float().view(B, T, H, hd)
         eye = torch.eye(H, device=kt.device, dtype=kt.dtype)
         kexp = F.pad(torch.einsum("bthd,hg->bhtgd", kt, eye), (0, 0, 0, 0, 0, 8 - T)).reshape(B, 8 * H, H * hd)
         wo = att.out_proj.weight.float().view(-1, H, hd)
@@ -475,15 +514,16 @@ class MaskDecoder(nn.Module):
 
         def t2i_raw(att, x, pe_):
             return lambda qp: ops.samdec_tok2img_raw(qp, x, pe_, att.k_proj.weight, att.v_proj.weight, att.v_proj.bias, sc)
+        ktvt = None
         if raw:
-            queries = L0.token_side(tokens, tokens, None, None, t2i_raw(ca, keys0_bf, P["pe_bf"]))
+            queries, ktvt = self._token_side(0, tokens.float(), tokens.float(), t2i_raw(ca, keys0_bf, P["pe_bf"]))
         elif t2i:
             kv0 = torch.cat([ca.k_proj(kp0), ca.v_proj(keys0)], -1).to(bf).contiguous()           # (1, N, 2d)
             queries = L0.token_side(tokens, tokens, None, None,
                                     lambda qp: ops.samdec_tok2img(qp, kv0, 0, ca.internal_dim, None, sc))
         else:
             queries = L0.token_side(tokens, tokens, ca.k_proj(kp0), ca.v_proj(keys0))
-        kexp, vpt = self._expand(ci, queries, tokens)
+        kexp, vpt = self._expand(ci, queries, tokens, ktvt=ktvt)
         n4 = L0.norm4
         keys1 = ops.samdec_img2tok(ci.q_proj(kp0).to(bf).contiguous(), None, kexp, vpt, keys0_bf,
                                    ci.out_proj.bias.float(), n4.weight.float(), n4.bias.float(), n4.eps, T)
@@ -491,8 +531,9 @@ class MaskDecoder(nn.Module):
         ca, ci = L1.cross_attn_token_to_image, L1.cross_attn_image_to_token
         d = ca.internal_dim
         fold = raw and ops.have("samdec_img2tok_raw")
+        ktvt = None
         if raw:
-            queries = L1.token_side(queries, tokens, None, None, t2i_raw(ca, keys1, P["pe_bf"]))
+            queries, ktvt = self._token_side(1, queries.float(), tokens.float(), t2i_raw(ca, keys1, P["pe_bf"]))
             q1 = None if fold else self._rows_gemm(keys1, P["w_q1"], P["b_q1"])    # (B, N, d) bf16: image->token queries only
         else:
             kvq = self._rows_gemm(keys1, P["w_kvq"], P["b_kvq"])                   # (B, N, 3d) bf16
@@ -504,11 +545,11 @@ class MaskDecoder(nn.Module):
             q1 = kvq[..., 2 * d:]
         n4 = L1.norm4
         if fold:                                                                   # q projection folded into the expanded keys
-            k256, cb, vpt = self._expand(ci, queries, tokens, fold_q=True)
+            k256, cb, vpt = self._expand(ci, queries, tokens, fold_q=True, ktvt=ktvt)
             keys2 = ops.samdec_img2tok_raw(keys1, P["pe_bf"], k256, cb, vpt, keys1, ci.out_proj.bias.float(),
                                            n4.weight.float(), n4.bias.float(), n4.eps, T)
         else:
-            kexp, vpt = self._expand(ci, queries, tokens)
+            kexp, vpt = self._expand(ci, queries, tokens, ktvt=ktvt)
             keys2 = ops.samdec_img2tok(q1, P["qpe1"], kexp, vpt, keys1, ci.out_proj.bias.float(),
                                        n4.weight.float(), n4.bias.float(), n4.eps, T)
         # ---- final token->image attention + output head ---------------------------------------------------------------

@@ -16,7 +16,7 @@ OUT = os.path.join(HERE, "host_cc", "_build")
 EXTRA = os.environ.get("HIPEMU_EXTRA", "").split()
 SO = os.path.join(OUT, "libsam6d_emu" + ("_" + re.sub(r"[^A-Za-z0-9]+", "_", "".join(EXTRA)) if EXTRA else "") + ".so")
 CXX = os.environ.get("HIPEMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
-DYN_NAMES = ("smem", "ps_smem", "sd_smem", "t2i_smem", "t2r_smem", "gemm_smem", "fm_smem", "cs_smem", "pc_smem")
+DYN_NAMES = ("smem", "ps_smem", "sd_smem", "t2i_smem", "t2r_smem", "gemm_smem", "fm_smem", "cs_smem", "pc_smem", "tk_smem")
 
 _lib = None
 

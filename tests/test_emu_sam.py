@@ -161,3 +161,7 @@ def test_dinov2_folded_block_loop_against_float(emu, monkeypatch):
     print("DINOv2 mini: rel rms vs float, folded %.3e, add + LayerNorm form %.3e" % (e_f, e_o))
     assert rel(xf, ref) <= 8e-3 and e_o <= 1e-2, (rel(xf, ref), e_f, e_o)
     assert e_f <= 1.1 * e_o + 5e-4, (e_f, e_o)
+
+
+def test_token_side_kernels_on_the_emulator(emu):
+    T.test_token_side_kernels_vs_autocast_statement(6, 7)

@@ -370,3 +370,73 @@ def test_cast_cached_linear_is_autocast_linear_bit_for_bit_and_follows_weight_up
             assert torch.equal(lin(x), ref(x))                               # another autocast dtype: its own copies
     y = lin(x)                                                               # grad enabled: nn.Linear.forward, differentiable
     assert y.requires_grad
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def _autocast_linear(x, m):
+    """nn.Linear under bf16 autocast, spelled out in fp32: bf16-rounded operands, fp32 accumulation, bf16-rounded result."""
+    return _bf(_bf(x) @ _bf(m.weight.detach().float()).t() + m.bias.detach().float())
+
+
+def _token_side_statement(L, queries, pe, t2i):
+    """TwoWayAttentionBlock steps 1-3 for the sparse tokens + the image->token k / v projections (transformer.py:109-186) with the
+    autocast roundings written out -- the arithmetic csrc/s6d_samtok.hip states in its header."""
+    import math
+    import torch.nn.functional as F
+    sa, ca, ci = L.self_attn, L.cross_attn_token_to_image, L.cross_attn_image_to_token
+    x = queries if L.skip_first_layer_pe else queries + pe
+    B, T, _ = x.shape
+    H = sa.num_heads
+    q, k, v = (_autocast_linear(a, m).view(B, T, H, -1).transpose(1, 2) for a, m in ((x, sa.q_proj), (x, sa.k_proj), (queries, sa.v_proj)))
+    s = _bf(q @ k.transpose(-1, -2)) / math.sqrt(q.shape[-1])
+    o = _bf(_bf(torch.softmax(s, dim=-1)) @ v).transpose(1, 2).reshape(B, T, -1)
+    a = _autocast_linear(o, sa.out_proj)
+    q1 = F.layer_norm(a if L.skip_first_layer_pe else queries + a, (256,), L.norm1.weight, L.norm1.bias, L.norm1.eps)
+    qp = _autocast_linear(q1 + pe, ca.q_proj)
+    att = t2i(qp)
+    q2 = F.layer_norm(q1 + _autocast_linear(att, ca.out_proj), (256,), L.norm2.weight, L.norm2.bias, L.norm2.eps)
+    h = torch.relu(_autocast_linear(q2, L.mlp.lin1))
+    q3 = F.layer_norm(q2 + _autocast_linear(h, L.mlp.lin2), (256,), L.norm3.weight, L.norm3.bias, L.norm3.eps)
+    return q1, qp, q3, _autocast_linear(q3 + pe, ci.k_proj), _autocast_linear(q3, ci.v_proj)
+
+
+@pytest.mark.parametrize("B,T", [(6, 7), (1, 5), (9, 8)])
+def test_token_side_kernels_vs_autocast_statement(B, T):
+    """s6d_samdec_tokens_pre_bf16 / _post_bf16 (round 6: the sparse-token side of a TwoWayAttentionBlock in two launches) against the
+    same layer written with library ops and the autocast roundings spelled out, both layers (with and without skip_first_layer_pe),
+    prompt counts that do not fill a workgroup, T = 5 .. 8 tokens.  The token->image attention between the two kernels is a stand-in
+    (a fixed random linear map of the projected queries): the kernels' own arithmetic is what is under test.  Tolerance: a value that
+    sits on a bf16 rounding boundary may round the other way after a differently ordered fp32 sum (one bf16 ulp = 2^-8 relative on one
+    element of a 256-term dot product); everything else agrees to fp32 accumulation order.  Measured: max 7.8e-3, mean <= 1.0e-4
+    (one prompt x five tokens, where a single flipped value weighs most); bounds 4e-2 / 5e-4."""
+    from sam6d_amd import ops, policy
+    from sam6d_amd.sam.mask_decoder import build_sam_decoder
+    m = seeded.load_seeded(build_sam_decoder(), 3).cuda()
+    dec = m.mask_decoder
+    g = torch.Generator().manual_seed(B * 10 + T)
+    queries = torch.randn(B, T, 256, generator=g).cuda()
+    pe = torch.randn(B, T, 256, generator=g).cuda()
+    mix = (torch.randn(128, 128, generator=g) / 11.0).cuda()
+
+    def t2i(qp):
+        return torch.tanh(qp.float() @ mix)
+    for li in (0, 1):
+        L = dec.transformer.layers[li]
+        assert policy.guard("test", have=ops.have("samdec_tokens"))
+        with torch.no_grad():
+            want = _token_side_statement(L, queries, pe, t2i)
+            seen = {}
+
+            def spy(qp):
+                seen["qp"] = qp.clone()
+                return t2i(qp)
+            q3, (kt, vt) = dec._token_side(li, queries, pe, spy)
+            lw, nw = dec._token_weights(li)
+            q1, _ = ops.samdec_tokens_pre(queries, pe, not L.skip_first_layer_pe, lw[0], lw[1], lw[2], lw[3], nw[0], lw[4])
+        for name, a, b in (("q1", q1, want[0]), ("qp", seen["qp"], want[1]), ("q3", q3, want[2]), ("kt", kt, want[3]), ("vt", vt, want[4])):
+            err = (a - b).abs()
+            util.record_margin(f"samdec_token_side_L{li}_B{B}_T{T}_{name}", max_abs=err.max().item(), mean_abs=err.mean().item(), ref_abs_max=b.abs().max().item())
+            assert err.max().item() < 4e-2 and err.mean().item() < 5e-4, (li, name, err.max().item(), err.mean().item())

@@ -360,6 +360,13 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
   if (PRIO) __builtin_amdgcn_s_setprio(0);
 }
 
+// Row-sum limit of the passes that keep a FIXED reference instead of a running maximum (process_tile_nomax, win16_pass_stream): a
+// row whose sum of P = exp2(s - m) is not below it (inf / NaN included) is redone (second pass / raised reference).  2^60, not 2^100
+// (ADVICE r5): the O^T accumulators hold sum P V, i.e. up to limit x |V| -- at 2^100 a |V| above 2^28 overflowed float32 while the
+// sum still passed; at 2^60 there are 67 binary orders left for V (tests/test_gpu_attn.py runs |V| = 2^50 with P up to 2^90).
+constexpr float kNoMaxSumLimit = 1.15292150e18f;                   // 2^60
+
+
 // ---- round 5: the 64 x 64 global tile WITHOUT a running maximum ---------------------------------------------------------------
 // process_tile spends, per score, scale + bias (fma), running max (max / max3), subtract, exp2 and half a pack, plus two
 // cross-lane exchanges and a wave vote per strip for the maximum -- 130 VALU + 32 exp2 beside 48 matrix instructions per tile, and
@@ -371,9 +378,9 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
 //   * the rel-pos column bias rides the matrix core: the score chain starts from C = tw / scale_log2 instead of 0;
 //   * P = exp2(fma(acc, scale_log2, th - m)): ONE fma per score; no max, no subtract, no exchange, no vote, no rescale branch, and
 //     the exponentials of sub-tile s are independent of the score instructions of sub-tile s + 1;
-//   * at the end of the tile loop a row sum that is not < 2^100 (inf / NaN included) makes the WORKGROUP run its tile loop again
+//   * at the end of the tile loop a row sum that is not < kNoMaxSumLimit = 2^60 (inf / NaN included) makes the WORKGROUP run its tile loop again
 //     with process_tile for every tile (attn_global64_kernel): the old arithmetic is the fallback, so any input the old kernel
-//     handled is still handled -- scores that grow by more than 2^100 over the first 64 keys' maximum take the slow path.
+//     handled is still handled -- scores that grow by more than 2^60 over the first 64 keys' maximum take the slow path.
 template <int HD, int NS, bool KSWZ, bool PRIO>
 __device__ __forceinline__ void process_tile_nomax(const AttnParams &p, const u16 *Kl, const u16 *Vl, StripState<HD, NS> &st,
                                                    const f32x4 (&cbias)[NS][4], const float (&nb)[NS], int lane) {
@@ -930,7 +937,7 @@ __device__ __forceinline__ void win16_pass(const AttnParams &p, const u16 *Kl, c
 // value m is the maximum over the FIRST TWO key rows (32 of the 196 keys), known before the first exponential; every 32-key step then
 // is score instructions -> exp2(fma(acc, scale_log2, th - m)) -> P V, nothing kept but the accumulators: 2.5 vector instructions
 // per score instead of 4.75, no score array (182 VGPRs instead of 236).
-// Safety net: a valid row whose sum is not < 2^100 (inf / NaN included) had scores more than ~92 log2 units above its reference; the
+// Safety net: a valid row whose sum is not < kNoMaxSumLimit = 2^60 (inf / NaN included) had scores more than ~52 log2 units above its reference; the
 // WAVE then repeats the pass with that row's m raised by 96 (the sum drops by 2^96: any m within ~100 of the true maximum is as good
 // as the maximum) until no row is out of range -- K / V stay resident in LDS for the whole item, so the retry is local to the wave,
 // it is the same code (no second pass inlined: an exact-pass fallback pushed the kernel into scratch), and it terminates: scores
@@ -1048,7 +1055,7 @@ __device__ __forceinline__ void win16_pass_stream(const AttnParams &p, const u16
 #pragma unroll
     for (int n = 0; n < NS; ++n) {
       const int qy = qy0 + n * rstride;
-      const bool bad = (qy < S) && (c < S) && !(lacc[n][0] < 1.2676506e30f);      // 2^100; a valid query's sum is >= 1 (its reference key)
+      const bool bad = (qy < S) && (c < S) && !(lacc[n][0] < kNoMaxSumLimit);     // a valid query's sum is >= 1 (its reference key)
       m[n] = bad ? m[n] + 96.0f : m[n];
       any_bad |= bad;
     }
@@ -1275,6 +1282,10 @@ __global__ __launch_bounds__(512) void attn_window16p_kernel(AttnParams p, int n
   // 64-bit token products: ~56 instructions per DMA instruction, ~10 per wave and item: a quarter of the wave's instruction
   // stream).  Per item only the window origin, the image test at the frame's edge and one 64-bit multiply-add remain.
   constexpr int MAXI = S14 ? 5 : 6;                                  // DMA instructions per wave and image: ceil(14 (16) x 16 x 11 / 64 / 8)
+  // the slots are unrolled: an image with more 1-KiB pieces than WAVES x MAXI would silently lose its tail -- the
+  // largest window this instantiation serves (14 rows, or 16 = the launcher's limit) must fit for both images
+  static_assert(((S14 ? 14 : 16) * 16 * (KCH > VCH ? KCH : VCH) + 63) / 64 <= WAVES * MAXI,
+                "attn_window16p_kernel: K / V image has more DMA pieces than the unrolled slots (raise MAXI)");
   unsigned kvc[MAXI];                     // per instruction slot: K in bits 0-12, V in bits 16-28: ky | kx << 4 | part << 8 | inwin << 12
   {
 #pragma unroll
@@ -1767,7 +1778,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_global64_kernel(AttnParams p)
     // a row sum that left the comfortable range (or is inf / NaN): the whole workgroup repeats its tiles with the running maximum
     bool bad = false;
 #pragma unroll
-    for (int n = 0; n < NS; ++n) bad |= !(st.lacc[n][0] < 1.2676506e30f);      // 2^100
+    for (int n = 0; n < NS; ++n) bad |= !(st.lacc[n][0] < kNoMaxSumLimit);
     if (__any(bad) && lane == 0) *redo = 1;
     __syncthreads();
     done = *redo == 0;

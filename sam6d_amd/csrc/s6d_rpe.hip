@@ -156,7 +156,10 @@ __global__ __launch_bounds__(WAVES * 64) void rpe_attention_kernel(
   for (int m = 0; m < M; ++m) {
     const float a = sc[g * Np + m];
     const float4 v4 = *reinterpret_cast<const float4 *>(vrow + (size_t)m * ldv);
-    acc.x += a * v4.x; acc.y += a * v4.y; acc.z += a * v4.z; acc.w += a * v4.w;
+    // explicit fused multiply-adds: the KEYS instantiations must give the same bits, so the contraction is not left to
+    // what the compiler decides around each instantiation's score loop
+    acc.x = __builtin_fmaf(a, v4.x, acc.x); acc.y = __builtin_fmaf(a, v4.y, acc.y);
+    acc.z = __builtin_fmaf(a, v4.z, acc.z); acc.w = __builtin_fmaf(a, v4.w, acc.w);
   }
   acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
   *reinterpret_cast<float4 *>(out + row * 256 + c4) = acc;

@@ -32,13 +32,15 @@ def test_fused_attention_vs_oracle(B, H, nh, hd, ws):
     assert err.max() < 3e-2 and err.mean() < 3e-3, (err.max().item(), err.mean().item())
 
 
-@pytest.mark.parametrize("hd,grow", [(80, 30.0), (80, 2.0), (64, 30.0)])
-def test_global_attention_when_scores_outgrow_the_first_tile(hd, grow):
+@pytest.mark.parametrize("hd,grow,vscale", [(80, 30.0, 1.0), (80, 2.0, 1.0), (64, 30.0, 1.0), (80, 2.0, 2.0 ** 50)])
+def test_global_attention_when_scores_outgrow_the_first_tile(hd, grow, vscale):
     """attn_global64_kernel keeps the FIRST key tile's row maximum for every later tile (process_tile_nomax, round 5) and repeats
     its tiles with the running-maximum arithmetic when a row sum leaves float32's comfortable range.  Image 1's queries get a
     +-2 pattern added and its keys from grid row 8 on ARE that pattern times `grow`: with 30 the later scores exceed the first
     tile's maximum by hundreds of log2 units (exp2 overflows -> the second pass must run), with 2 by some tens (P up to ~2^50,
-    finite: the fast path must stay accurate).  Image 0 is ordinary, so one workgroup set takes the fallback and the other not."""
+    finite: the fast path must stay accurate).  Image 0 is ordinary, so one workgroup set takes the fallback and the other not.
+    vscale = 2^50: image 1's VALUES are that large, so sum P V leaves float32 (2^90 x 2^50) on rows whose sum of P alone
+    would have passed a 2^100 limit -- they must take the second pass (limit 2^60) and come out finite and accurate."""
     from oracle import sam as osam
     from sam6d_amd import ops
     H, nh = 64, 1
@@ -47,6 +49,7 @@ def test_global_attention_when_scores_outgrow_the_first_tile(hd, grow):
     pat = torch.where(torch.arange(hd) % 2 == 0, 1.0, -1.0)
     qkv[1, :, :, :hd] += 2 * pat
     qkv[1, 8:, :, hd:2 * hd] = grow * pat
+    qkv[1, :, :, 2 * hd:] *= vscale
     bias, rh, rw, qkv = (t.to(torch.bfloat16) for t in (bias, rh, rw, qkv))
     # the premise, in log2 units: (largest late score) - (largest score against the first 64 keys), per query of image 1
     q, k = qkv[1, :, :, :hd].float().reshape(-1, hd), qkv[1, :, :, hd:2 * hd].float().reshape(-1, hd)
@@ -57,12 +60,14 @@ def test_global_attention_when_scores_outgrow_the_first_tile(hd, grow):
                                hd ** -0.5).float().cpu()
     ref = osam.windowed_attention_from_qkv(qkv.float(), bias.float(), rh.float(), rw.float(), nh, 0)
     assert torch.isfinite(out).all()
+    out[1] /= vscale
+    ref[1] /= vscale
     err = (out - ref).abs()
     assert err.max() < 3e-2 and err.mean() < 3e-3, (err.max().item(), err.mean().item())
 
 
-@pytest.mark.parametrize("grow", [30.0, 2.0])
-def test_window_attention_when_scores_outgrow_the_first_key_rows(grow):
+@pytest.mark.parametrize("grow,vscale", [(30.0, 1.0), (2.0, 1.0), (2.0, 2.0 ** 50)])
+def test_window_attention_when_scores_outgrow_the_first_key_rows(grow, vscale):
     """The persistent 14 x 14 window kernel streams its 32-key steps against the maximum of the window's FIRST TWO key rows
     (win16_pass_stream, round 5) and repeats the pass with that reference raised by 96 log2 units per round while a row sum is out of
     float32's comfortable range.  The keys of window rows >= 2 are a +-1 pattern times `grow`, the queries carry twice that pattern:
@@ -78,11 +83,14 @@ def test_window_attention_when_scores_outgrow_the_first_key_rows(grow):
     for h in range(nh):
         qkv[1, :, :, h * hd:(h + 1) * hd] += 2 * pat
         qkv[1, late, :, nh * hd + h * hd:nh * hd + (h + 1) * hd] = grow * pat
+    qkv[1, :, :, 2 * nh * hd:] *= vscale                              # (large values under a large, in-range row sum)
     bias, rh, rw, qkv = (t.to(torch.bfloat16) for t in (bias, rh, rw, qkv))
     out = ops.window_attention(qkv.cuda().contiguous(), bias.cuda().contiguous(), rh.cuda().contiguous(), rw.cuda().contiguous(), nh, ws,
                                hd ** -0.5).float().cpu()
     ref = osam.windowed_attention_from_qkv(qkv.float(), bias.float(), rh.float(), rw.float(), nh, ws)
     assert torch.isfinite(out).all()
+    out[1] /= vscale
+    ref[1] /= vscale
     err = (out - ref).abs()
     assert err.max() < 3e-2 and err.mean() < 3e-3, (err.max().item(), err.mean().item())
 

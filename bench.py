@@ -396,6 +396,25 @@ def kernel_rooflines(dev, sam_chunk, frames, in_step=None):
                     "achieved": round(nbytes / ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / 8000.0, 4),
                     "avg_ms": round(ms, 4), "launches_per_step": 36, "algorithmic_bytes": nbytes,
                     "mfma_tflops_executed": round(flop / ms / 1e9, 1), "pmc_key": "plin_kernel"})
+    if ops.have("attn_output_chain") and ops.have("linear_f32"):
+        # round 6: the post-attention chain of a point-transformer layer in one launch (csrc/s6d_pchain.hip) at the dense stage's
+        # shape.  Algorithmic bytes: the attention output and the residual read once, y written once (h and the 512-wide
+        # activations stay on chip); executed FLOP = 3 terms x 2 x M x (256*256 + 2*256*512).
+        Mp = 2048 * B
+        ap, xp2 = torch.randn(Mp, 256, generator=g).to(dev), torch.randn(Mp, 256, generator=g).to(dev)
+
+        def _w(n, k):
+            hi_, lo_ = ops.split_weight((torch.randn(n, k, generator=g) / 16).to(dev))
+            return ops.fragment_weight(hi_), ops.fragment_weight(lo_), torch.randn(n, generator=g).to(dev)
+        w1c, wec, wsc = _w(256, 256), _w(512, 256), _w(256, 512)
+        ln_ = (torch.ones(256, device=dev), torch.zeros(256, device=dev), 1e-5)
+        ms = _event_ms(lambda: ops.attn_output_chain(ap, xp2, w1c, ln_, wec, wsc, ln_), 10)
+        flop = 3.0 * 2.0 * Mp * (256 * 256 + 2 * 256 * 512)
+        nbytes = float(Mp) * 256 * 4 * 3
+        out.append({"kernel": "pchain_kernel (linear + residual + LN + FFN 256-512-256 + residual + LN, M=%d)" % Mp, "bound": "mfma",
+                    "achieved": round(flop / ms / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s (bf16 MFMA executed = 3x the algorithmic fp32 FLOP)",
+                    "frac": round(flop / ms / 1e9 / 2500.0, 4), "avg_ms": round(ms, 4), "launches_per_step": 12,
+                    "algorithmic_bytes": nbytes, "hbm_gbps": round(nbytes / ms / 1e6, 1), "pmc_key": "pchain_kernel"})
     # the Linear layers of the ViT-H blocks: the hand-written bf16 GEMM (csrc/s6d_gemm.hip) at the four shapes of a block, and the
     # library GEMM (hipBLASLt through torch) at the largest of them for context.  Algorithmic work 2 M N K FLOP.
     M = sam_chunk * 4096

@@ -360,11 +360,14 @@ __device__ __forceinline__ void process_tile(const AttnParams &p, const u16 *Kl,
   if (PRIO) __builtin_amdgcn_s_setprio(0);
 }
 
-// Row-sum limit of the passes that keep a FIXED reference instead of a running maximum (process_tile_nomax, win16_pass_stream): a
-// row whose sum of P = exp2(s - m) is not below it (inf / NaN included) is redone (second pass / raised reference).  2^60, not 2^100
-// (ADVICE r5): the O^T accumulators hold sum P V, i.e. up to limit x |V| -- at 2^100 a |V| above 2^28 overflowed float32 while the
-// sum still passed; at 2^60 there are 67 binary orders left for V (tests/test_gpu_attn.py runs |V| = 2^50 with P up to 2^90).
-constexpr float kNoMaxSumLimit = 1.15292150e18f;                   // 2^60
+// Range guard of the passes that keep a FIXED reference instead of a running maximum (process_tile_nomax, win16_pass_stream): a row
+// is redone (second pass / raised reference) when its sum of P = exp2(s - m) is not below 2^100 (inf / NaN included) OR when one of
+// its O^T accumulators is not finite (the accumulators hold sum P V, i.e. up to 2^100 |V|, and overflowed float32 for
+// |V| above 2^28 while the sum still passed; tests/test_gpu_attn.py runs |V| = 2^50 under P up to 2^90).  A lower sum limit instead
+// (2^60 was tried) sends ordinary frames through the second pass: the seeded ViT-H of the benched step has rows 60 .. 100 log2
+// units above their first tile, and the global kernel went 1.81 -> 3.25 ms.
+constexpr float kNoMaxSumLimit = 1.2676506e30f;                    // 2^100
+constexpr float kNoMaxFinite = 3.0e38f;
 
 
 // ---- round 5: the 64 x 64 global tile WITHOUT a running maximum ---------------------------------------------------------------
@@ -378,9 +381,9 @@ constexpr float kNoMaxSumLimit = 1.15292150e18f;                   // 2^60
 //   * the rel-pos column bias rides the matrix core: the score chain starts from C = tw / scale_log2 instead of 0;
 //   * P = exp2(fma(acc, scale_log2, th - m)): ONE fma per score; no max, no subtract, no exchange, no vote, no rescale branch, and
 //     the exponentials of sub-tile s are independent of the score instructions of sub-tile s + 1;
-//   * at the end of the tile loop a row sum that is not < kNoMaxSumLimit = 2^60 (inf / NaN included) makes the WORKGROUP run its tile loop again
+//   * at the end of the tile loop a row sum that is not < kNoMaxSumLimit = 2^100 (inf / NaN included), or a non-finite accumulator, makes the WORKGROUP run its tile loop again
 //     with process_tile for every tile (attn_global64_kernel): the old arithmetic is the fallback, so any input the old kernel
-//     handled is still handled -- scores that grow by more than 2^60 over the first 64 keys' maximum take the slow path.
+//     handled is still handled -- scores that grow by more than 2^100 over the first 64 keys' maximum take the slow path.
 template <int HD, int NS, bool KSWZ, bool PRIO>
 __device__ __forceinline__ void process_tile_nomax(const AttnParams &p, const u16 *Kl, const u16 *Vl, StripState<HD, NS> &st,
                                                    const f32x4 (&cbias)[NS][4], const float (&nb)[NS], int lane) {
@@ -937,7 +940,8 @@ __device__ __forceinline__ void win16_pass(const AttnParams &p, const u16 *Kl, c
 // value m is the maximum over the FIRST TWO key rows (32 of the 196 keys), known before the first exponential; every 32-key step then
 // is score instructions -> exp2(fma(acc, scale_log2, th - m)) -> P V, nothing kept but the accumulators: 2.5 vector instructions
 // per score instead of 4.75, no score array (182 VGPRs instead of 236).
-// Safety net: a valid row whose sum is not < kNoMaxSumLimit = 2^60 (inf / NaN included) had scores more than ~52 log2 units above its reference; the
+// Safety net: a valid row whose sum is not < kNoMaxSumLimit = 2^100 (inf / NaN included) had scores more than ~92 log2 units above its reference
+// (or its sum P V left float32: kNoMaxFinite); the
 // WAVE then repeats the pass with that row's m raised by 96 (the sum drops by 2^96: any m within ~100 of the true maximum is as good
 // as the maximum) until no row is out of range -- K / V stay resident in LDS for the whole item, so the retry is local to the wave,
 // it is the same code (no second pass inlined: an exact-pass fallback pushed the kernel into scratch), and it terminates: scores
@@ -1055,7 +1059,14 @@ __device__ __forceinline__ void win16_pass_stream(const AttnParams &p, const u16
 #pragma unroll
     for (int n = 0; n < NS; ++n) {
       const int qy = qy0 + n * rstride;
-      const bool bad = (qy < S) && (c < S) && !(lacc[n][0] < kNoMaxSumLimit);     // a valid query's sum is >= 1 (its reference key)
+      int ovf = 0;                                                    // this lane's slice of the query's O^T column (4 g-lanes per query)
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ovf |= !(fabsf(oacc[n][dt][r]) < kNoMaxFinite);
+      ovf |= __shfl_xor(ovf, 16);
+      ovf |= __shfl_xor(ovf, 32);
+      const bool bad = (qy < S) && (c < S) && (!(lacc[n][0] < kNoMaxSumLimit) || ovf);     // a valid query's sum is >= 1 (its reference key)
       m[n] = bad ? m[n] + 96.0f : m[n];
       any_bad |= bad;
     }
@@ -1778,7 +1789,13 @@ __global__ __launch_bounds__(WAVES * 64) void attn_global64_kernel(AttnParams p)
     // a row sum that left the comfortable range (or is inf / NaN): the whole workgroup repeats its tiles with the running maximum
     bool bad = false;
 #pragma unroll
-    for (int n = 0; n < NS; ++n) bad |= !(st.lacc[n][0] < kNoMaxSumLimit);
+    for (int n = 0; n < NS; ++n) {
+      bad |= !(st.lacc[n][0] < kNoMaxSumLimit);
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bad |= !(fabsf(st.oacc[n][dt][r]) < kNoMaxFinite);
+    }
     if (__any(bad) && lane == 0) *redo = 1;
     __syncthreads();
     done = *redo == 0;

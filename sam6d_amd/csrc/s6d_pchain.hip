@@ -42,10 +42,18 @@ typedef unsigned short u16;
 typedef __attribute__((ext_vector_type(4))) unsigned pc_u32x4;
 typedef __attribute__((ext_vector_type(4))) float pc_f32x4;
 
-constexpr int PC_ROWS = 64, PC_FS = 264;                   // image row: 256 bf16 + 8 pad (528 B)
-constexpr int PC_IMG = PC_ROWS * PC_FS;                    // elements of one (hi or lo) image
-constexpr int PC_OFF_AH = 0, PC_OFF_AL = PC_IMG, PC_OFF_HH = 2 * PC_IMG, PC_OFF_HL = 3 * PC_IMG, PC_LDS_ELEMS = 4 * PC_IMG;   // 135 168 B
-constexpr int PC_LDS_BYTES = PC_LDS_ELEMS * 2 + PC_ROWS * 8 * 4;
+constexpr int PC_FS = 264;                                 // image row: 256 bf16 + 8 pad (528 B)
+// MT = 32-row tiles per workgroup: 2 (64 rows, 137 KB of LDS) where the rows fill the chip, 1 (32 rows, 69 KB) up to 8192 rows --
+// the 197-token layers (6304 rows at 32 instances, 1970 at 10) then run on twice the CUs with half the serial work per workgroup
+// (334 registers per lane: still one workgroup per CU, which is all such a launch has).  A row's arithmetic does not depend on
+// MT: the same bits.
+template <int MT>
+struct PcCfg {
+  static constexpr int ROWS = 32 * MT;
+  static constexpr int IMG = ROWS * PC_FS;                 // elements of one (hi or lo) image
+  static constexpr int OFF_AH = 0, OFF_AL = IMG, OFF_HH = 2 * IMG, OFF_HL = 3 * IMG, LDS_ELEMS = 4 * IMG;
+  static constexpr int LDS_BYTES = LDS_ELEMS * 2 + ROWS * 8 * 4;
+};
 
 __device__ __forceinline__ void pc_split(float x, u16 &hi, u16 &lo) {
   union { __bf16 b; u16 u; } h, l;
@@ -76,7 +84,10 @@ struct PchainParams {
 
 extern __shared__ __attribute__((aligned(16))) char pc_smem[];
 
+template <int MT>
 __global__ __launch_bounds__(256) void pchain_kernel(PchainParams p) {
+  using Cf = PcCfg<MT>;
+  constexpr int PC_ROWS = Cf::ROWS, PC_OFF_AH = Cf::OFF_AH, PC_OFF_AL = Cf::OFF_AL, PC_OFF_HH = Cf::OFF_HH, PC_OFF_HL = Cf::OFF_HL, PC_LDS_ELEMS = Cf::LDS_ELEMS;
   u16 *lds = reinterpret_cast<u16 *>(pc_smem);
   float(*red)[8] = reinterpret_cast<float(*)[8]>(pc_smem + PC_LDS_ELEMS * 2);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -106,7 +117,7 @@ __global__ __launch_bounds__(256) void pchain_kernel(PchainParams p) {
     for (int s = 0; s < PC_PF; ++s) gload(wh, wl, t0, (size_t)k16 * 512, s, s);
     __builtin_amdgcn_sched_barrier(0);                       // (the scheduler otherwise sinks every load to its first use: no prefetch)
   };
-  auto gemm = [&](pc_f32x16 (&acc)[2][2], const u16 *wh, const u16 *wl, int k16, int r0, int k16_0, int xh_off, int xl_off)
+  auto gemm = [&](pc_f32x16 (&acc)[MT][2], const u16 *wh, const u16 *wl, int k16, int r0, int k16_0, int xh_off, int xl_off)
       __attribute__((always_inline)) {
     const size_t t0 = ((size_t)((r0 >> 5) + 2 * wave) * k16 + k16_0) * 512 + lane * 8;
     const size_t tn = (size_t)k16 * 512;                                                       // to the next n tile
@@ -125,15 +136,15 @@ __global__ __launch_bounds__(256) void pchain_kernel(PchainParams p) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        pc_bf16x8 xh[2], xl[2];
+        pc_bf16x8 xh[MT], xl[MT];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
           const int o = (32 * mt + fr) * PC_FS + kc * 32 + (2 * ks + fh) * 8;
           xh[mt] = *reinterpret_cast<const pc_bf16x8 *>(lds + xh_off + o);
           xl[mt] = *reinterpret_cast<const pc_bf16x8 *>(lds + xl_off + o);
         }
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) {
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlf[nt][ks], xh[mt], acc[mt][nt], 0, 0, 0);   // small terms first
@@ -145,12 +156,12 @@ __global__ __launch_bounds__(256) void pchain_kernel(PchainParams p) {
   };
   const int cb = 64 * wave + 4 * fh;                        // column of register r of n tile nt: cb + 32 nt + (r & 3) + 8 (r >> 2)
   // row-wise LayerNorm of the 256 values a row's eight lanes hold, in plin_kernel's arithmetic (two passes, fixed-order sums)
-  auto layernorm = [&](pc_f32x16 (&acc)[2][2], const float *gamma, const float *beta, float eps) __attribute__((always_inline)) {
-    float mean[2], rstd[2];
+  auto layernorm = [&](pc_f32x16 (&acc)[MT][2], const float *gamma, const float *beta, float eps) __attribute__((always_inline)) {
+    float mean[MT], rstd[MT];
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
         float s = 0.f;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(256) void pchain_kernel(PchainParams p) {
       }
       __syncthreads();
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
         float t = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) t += red[32 * mt + fr][j];
@@ -177,15 +188,15 @@ __global__ __launch_bounds__(256) void pchain_kernel(PchainParams p) {
         const float4 bt = *reinterpret_cast<const float4 *>(beta + cb + 32 * nt + 8 * q);
         const float gv[4] = {g.x, g.y, g.z, g.w}, tv[4] = {bt.x, bt.y, bt.z, bt.w};
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[mt][nt][4 * q + e] = pl_normalize(acc[mt][nt][4 * q + e], mean[mt], rstd[mt], gv[e], tv[e]);
       }
   };
   // the values a lane holds -> the split operand image (rows 32 mt + fr, its columns)
-  auto to_image = [&](const pc_f32x16 (&v)[2][2], int off_hi, int off_lo) __attribute__((always_inline)) {
+  auto to_image = [&](const pc_f32x16 (&v)[MT][2], int off_hi, int off_lo) __attribute__((always_inline)) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -198,9 +209,9 @@ __global__ __launch_bounds__(256) void pchain_kernel(PchainParams p) {
           *reinterpret_cast<uint2 *>(lds + off_lo + o) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
         }
   };
-  auto zero = [](pc_f32x16 (&acc)[2][2]) __attribute__((always_inline)) {
+  auto zero = [](pc_f32x16 (&acc)[MT][2]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -210,13 +221,14 @@ __global__ __launch_bounds__(256) void pchain_kernel(PchainParams p) {
   // ---- the attention-output strip -> image A: thread -> row tid >> 2, 64 floats at 64 (tid & 3); rows past M repeat row M - 1
   prefetch(p.w1h, p.w1l, 16, 0, 0);
   {
-    const int row = tid >> 2, c0 = 64 * (tid & 3);
+    constexpr int TPR = 8 / MT, FPT = 32 * MT;               // threads per row, floats per thread
+    const int row = tid / TPR, c0 = FPT * (tid % TPR);
     const float *src = p.a + (size_t)min(m0 + row, p.M - 1) * p.lda + c0;
-    pc_f32x4 v[16];
+    pc_f32x4 v[FPT / 4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const pc_f32x4 *>(src + 4 * i);
+    for (int i = 0; i < FPT / 4; ++i) v[i] = *reinterpret_cast<const pc_f32x4 *>(src + 4 * i);
 #pragma unroll
-    for (int i = 0; i < 16; i += 2) {
+    for (int i = 0; i < FPT / 4; i += 2) {
       u16 h[8], l[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -232,13 +244,13 @@ __global__ __launch_bounds__(256) void pchain_kernel(PchainParams p) {
   __syncthreads();
 
   // ---- stage 1: h = LN1(x + a W1^T + b1)
-  pc_f32x16 h[2][2];
+  pc_f32x16 h[MT][2];
   zero(h);
   gemm(h, p.w1h, p.w1l, 16, 0, 0, PC_OFF_AH, PC_OFF_AL);
   // the first residual: issued before the next product's W
-  pc_f32x4 xres[2][2][4];
+  pc_f32x4 xres[MT][2][4];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -252,7 +264,7 @@ __global__ __launch_bounds__(256) void pchain_kernel(PchainParams p) {
       const float4 b = *reinterpret_cast<const float4 *>(p.b1 + cb + 32 * nt + 8 * q);
       const float bv[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) h[mt][nt][4 * q + e] = pl_bias_act_res(h[mt][nt][4 * q + e], bv[e], false, xres[mt][nt][q][e]);
     }
@@ -261,11 +273,11 @@ __global__ __launch_bounds__(256) void pchain_kernel(PchainParams p) {
   __syncthreads();                                          // H complete; every wave is past its reads of A (the reductions above)
 
   // ---- stages 2 + 3: y = LN2(h + relu(h We^T + be) Ws^T + bs), the 512 expanded columns in two halves (E lives in A's buffer)
-  pc_f32x16 y[2][2];
+  pc_f32x16 y[MT][2];
   zero(y);
 #pragma unroll 1
   for (int c = 0; c < 2; ++c) {
-    pc_f32x16 e2[2][2];
+    pc_f32x16 e2[MT][2];
     zero(e2);
     gemm(e2, p.weh, p.wel, 16, 256 * c, 0, PC_OFF_HH, PC_OFF_HL);
     prefetch(p.wsh, p.wsl, 32, 0, 16 * c);
@@ -276,7 +288,7 @@ __global__ __launch_bounds__(256) void pchain_kernel(PchainParams p) {
         const float4 b = *reinterpret_cast<const float4 *>(p.bexp + 256 * c + cb + 32 * nt + 8 * q);
         const float bv[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int e = 0; e < 4; ++e) e2[mt][nt][4 * q + e] = pl_bias_act_res(e2[mt][nt][4 * q + e], bv[e], true, 0.f);
       }
@@ -293,13 +305,13 @@ __global__ __launch_bounds__(256) void pchain_kernel(PchainParams p) {
       const float4 b = *reinterpret_cast<const float4 *>(p.bsq + cb + 32 * nt + 8 * q);
       const float bv[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[mt][nt][4 * q + e] = pl_bias_act_res(y[mt][nt][4 * q + e], bv[e], false, h[mt][nt][4 * q + e]);
     }
   layernorm(y, p.g2, p.be2, p.eps2);
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     const int m = m0 + 32 * mt + fr;
     if (m >= p.M) continue;
 #pragma unroll
@@ -354,7 +366,12 @@ extern "C" int s6d_attn_output_chain_f32(const float *a, long lda, const float *
   p.weh = (const u16 *)we_hi; p.wel = (const u16 *)we_lo; p.bexp = be;
   p.wsh = (const u16 *)ws_hi; p.wsl = (const u16 *)ws_lo; p.bsq = bs; p.g2 = gamma2; p.be2 = beta2; p.eps2 = eps2;
   p.y = y; p.ldy = ldy;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pchain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS_BYTES);
-  hipLaunchKernelGGL(pchain_kernel, dim3((unsigned)((M + PC_ROWS - 1) / PC_ROWS)), dim3(256), PC_LDS_BYTES, as_stream(stream), p);
+  if (M <= 8192) {                                            // at most one 32-row workgroup per CU
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pchain_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, PcCfg<1>::LDS_BYTES);
+    hipLaunchKernelGGL(pchain_kernel<1>, dim3((unsigned)((M + 31) / 32)), dim3(256), PcCfg<1>::LDS_BYTES, as_stream(stream), p);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pchain_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PcCfg<2>::LDS_BYTES);
+    hipLaunchKernelGGL(pchain_kernel<2>, dim3((unsigned)((M + 63) / 64)), dim3(256), PcCfg<2>::LDS_BYTES, as_stream(stream), p);
+  }
   return launch_status();
 }

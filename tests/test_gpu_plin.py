@@ -105,7 +105,7 @@ def test_linear_attention_vs_the_library_statement(B, I, J):
     assert err <= 2e-5 * (1 + ref.abs().max().item()), err
 
 
-@pytest.mark.parametrize("kind,B,N", [("rpe", 2, 197), ("mha", 3, 61), ("linear", 2, 300), ("rpe", 1, 32)])
+@pytest.mark.parametrize("kind,B,N", [("rpe", 2, 197), ("mha", 3, 61), ("linear", 2, 300), ("rpe", 1, 32), ("linear", 5, 2047)])   # (the last one: more than 8192 rows = the 64-row form)
 def test_attention_output_chain_equals_the_three_launches_bit_for_bit(kind, B, N):
     """csrc/s6d_pchain.hip (round 6): norm(linear(att) + x) -> AttentionOutput as ONE kernel over 32-row strips against the three
     s6d_linear_f32 launches it replaces (S6D_DISABLE_FUSED=attn_output_chain) on the real layer classes: equal bits (the same

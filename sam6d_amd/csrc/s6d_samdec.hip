@@ -53,6 +53,13 @@ __global__ __launch_bounds__(256, 2) void img2tok_kernel(const u16 *__restrict__
                                                       float eps, int N, int n_tok, int q_ld, long q_bstride,
                                                       long r_bstride, u16 *__restrict__ out) {
   constexpr int KD = RAW ? kSdC : kSdD, KROWL = KD + 8, KSN = KD / 32;   // key width, LDS row stride, k-steps of the score product
+  // Output channel of row i of value tile nt (round 6).  In the accumulator layout lane (c, g) holds rows 4 g .. 4 g + 3 of every
+  // tile for token c.  With channel = 16 nt + i a lane's four values of a tile were 8 bytes and a store / residual-load instruction
+  // touched 32 contiguous bytes per token.  Feeding the value rows in the order chan(nt, i) = 32 (nt / 2) + 8 (i / 4) + 4 (nt % 2) + i % 4
+  // makes the four values of tiles 2 p and 2 p + 1 eight consecutive channels: one 16-byte access per lane and tile pair, 64
+  // contiguous bytes per token and instruction (half the instructions, twice the run length).  Per channel the arithmetic is
+  // unchanged; the LayerNorm's per-lane partial sums run over another 64 channels, so the result can differ in the last float32 bit.
+  auto chan = [](int nt, int i) { return 32 * (nt >> 1) + 8 * (i >> 2) + 4 * (nt & 1) + (i & 3); };
   extern __shared__ __attribute__((aligned(16))) char sd_smem[];
   u16 *Kl = reinterpret_cast<u16 *>(sd_smem);                       // [64][KROWL]
   u16 *Vl = Kl + kSdJ * KROWL;                                      // [256][kSdVRow]
@@ -105,10 +112,10 @@ __global__ __launch_bounds__(256, 2) void img2tok_kernel(const u16 *__restrict__
         for (int e = 0; e < 8; ++e) qa[ks].h[e] = sd_f2bf(sd_bf2f(qa[ks].h[e]) + sd_bf2f(pn[ks].h[e]));
       }
     }
-    union RR { uint2 u; u16 h[4]; };
-    RR rr[16];                                                       // residual rows of this strip, first used in the epilogue
+    union RR { uint4 u; u16 h[8]; };
+    RR rr[8];                                                        // residual rows of this strip (tile pair p: channels 32 p + 8 g .. + 8), first used in the epilogue
 #pragma unroll
-    for (int nt = 0; nt < 16; ++nt) rr[nt].u = *reinterpret_cast<const uint2 *>(rb + (size_t)tok * kSdC + nt * 16 + g * 4);
+    for (int pp = 0; pp < 8; ++pp) rr[pp].u = *reinterpret_cast<const uint4 *>(rb + (size_t)tok * kSdC + pp * 32 + g * 8);
     // ---- scores^T (64 x 16) = Kexp (64 x KD) . Q^T ------------------------------------------------------------
     sd_f32x4 s[4];
 #pragma unroll
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void img2tok_kernel(const u16 *__restrict__
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         union { sd_bf16x8 v; uint2 d[2]; } va;
-        const u16 *vr = Vl + (nt * 16 + c) * kSdVRow + ks * 32 + g * 4;
+        const u16 *vr = Vl + chan(nt, c) * kSdVRow + ks * 32 + g * 4;
         va.d[0] = *reinterpret_cast<const uint2 *>(vr);
         va.d[1] = *reinterpret_cast<const uint2 *>(vr + 16);
         o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va.v, pb[ks].v, o[nt], 0, 0, 0);
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void img2tok_kernel(const u16 *__restrict__
     for (int nt = 0; nt < 16; ++nt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        o[nt][r] += pl[nt * 16 + g * 4 + r] + sd_bf2f(rr[nt].h[r]);
+        o[nt][r] += pl[chan(nt, g * 4 + r)] + sd_bf2f(rr[nt >> 1].h[(nt & 1) * 4 + r]);
         sum += o[nt][r];
       }
     }
@@ -191,14 +198,15 @@ __global__ __launch_bounds__(256, 2) void img2tok_kernel(const u16 *__restrict__
     var += __shfl_xor(var, 32);
     const float rstd = rsqrtf(var * (1.0f / kSdC) + eps);
 #pragma unroll
-    for (int nt = 0; nt < 16; ++nt) {
-      union { uint2 u; u16 h[4]; } w;
+    for (int pp = 0; pp < 8; ++pp) {
+      union { uint4 u; u16 h[8]; } w;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = nt * 16 + g * 4 + r;
-        w.h[r] = sd_f2bf((o[nt][r] - mean) * rstd * pl[256 + n] + pl[512 + n]);
+      for (int e = 0; e < 8; ++e) {
+        const int nt = 2 * pp + (e >> 2), r = e & 3;
+        const int n = pp * 32 + g * 8 + e;                           // = chan(nt, 4 g + r)
+        w.h[e] = sd_f2bf((o[nt][r] - mean) * rstd * pl[256 + n] + pl[512 + n]);
       }
-      *reinterpret_cast<uint2 *>(ob + (size_t)tok * kSdC + nt * 16 + g * 4) = w.u;
+      *reinterpret_cast<uint4 *>(ob + (size_t)tok * kSdC + pp * 32 + g * 8) = w.u;
     }
   }
 }
@@ -244,7 +252,10 @@ __global__ __launch_bounds__(256, 2) void upscale_heads_kernel(const u16 *__rest
     hya_hi.hh[e] = hi;
     hya_lo.hh[e] = sd_f2bf(hv - sd_bf2f(hi));
   }
-  // a strip = 16 tokens x one sub-pixel (dy, dx): 4N/16 strips per prompt
+  // a strip = 16 tokens x one sub-pixel (dy, dx): 4N/16 strips per prompt.  (Round 6, measured and not kept: a wave taking the four
+  // strips of a token group and writing the group's 4 x 4 logits as 16-byte stores, 256 contiguous bytes per mask row and
+  // instruction instead of 8-byte pieces: 1732 -> 1764 us per 1024 prompts -- the kernel is bound by its 3.2 G exact-erf GELU
+  // evaluations, not by the store granularity, unlike img2tok_kernel.)
   const int nstrip = N / 16 * 4;
   // software-pipelined like img2tok_kernel (round 4): the two 16-byte pieces of the NEXT strip are requested before this strip's
   // arithmetic (every strip used to start with a load -> LayerNorm dependency)

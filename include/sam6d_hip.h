@@ -437,15 +437,27 @@ int s6d_attn_output_chain_f32(const float *a, long lda, const float *x, long ldx
  * Every weight is bf16 (N,K) in the FRAGMENT ORDER of s6d_linear_fragment_weight (wq / wk / wv / wo (256,256), wq2 / wk3 / wv3
  * (128,256), wo2 (256,128), w1 (2048,256), w2 (256,2048)); biases and LayerNorm parameters f32.  Arithmetic = the bf16 autocast
  * statement of the reference modules: a Linear multiplies bf16-rounded activations by bf16 weights, accumulates in fp32 and rounds
- * its result to bf16; LayerNorm, residual adds and the softmax are fp32. */
+ * its result to bf16; LayerNorm, residual adds and the softmax are fp32.
+ * Optional operands (null = off) fold the small per-head products around the attention cores into the two launches:
+ *   pre : wkfold (256,128) = cross_attn_token_to_image.k_proj.weight^T in fragment order -> qfold_out (B,64,256) bf16, row h*8 + t =
+ *         bf16(fold_scale * sum_d qp[b,t,16h+d] Wk[16h+d,:]) (zero for t >= T): the query operand of s6d_samdec_tok2img_raw_bf16
+ *         (fold_scale = log2(e) / sqrt(16)); qp_out may then be null;
+ *   post: y (B,64,256) f32 = that kernel's result, wvfold (128,256) = v_proj.weight in fragment order, bvfold (128):
+ *         att[b,t,16h+d] = sum_c y[b,h*8+t,c] Wv[16h+d,c] + bv is formed in the kernel (att may then be null);
+ *         wqfold (256,128) = cross_attn_image_to_token.q_proj.weight^T, bqfold (128), wofold (256,128) = its out_proj.weight, both in
+ *         fragment order -> the operands of s6d_samdec_img2tok[_raw]_bf16: kexp_out (B,64,128) bf16 block-diagonal kt / 4 (the caller
+ *         zero-fills it), k256_out (B,64,256) bf16 = kexp Wq, cb_out (B,64) f32 = kexp . bq, vpt_out (B,256,64) bf16 =
+ *         [sum_d vt[b,t,16h+d] Wo[n,16h+d]] at [b,n,h*8+t]; slots t >= T are zero; kt_out / vt_out may then be null. */
 int s6d_samdec_tokens_pre_bf16(const float *queries, const float *pe, int B, int T, int add_pe, const void *wq, const float *bq,
                                const void *wk, const float *bk, const void *wv, const float *bv, const void *wo, const float *bo,
                                const float *gamma1, const float *beta1, float eps1, const void *wq2, const float *bq2, float *q1_out,
-                               float *qp_out, void *stream);
+                               float *qp_out, const void *wkfold, float fold_scale, void *qfold_out, void *stream);
 int s6d_samdec_tokens_post_bf16(const float *q1, const float *att, const float *pe, int B, int T, const void *wo2, const float *bo2,
                                 const float *gamma2, const float *beta2, float eps2, const void *w1, const float *b1, const void *w2,
                                 const float *b2, const float *gamma3, const float *beta3, float eps3, const void *wk3, const float *bk3,
-                                const void *wv3, const float *bv3, float *q3_out, float *kt_out, float *vt_out, void *stream);
+                                const void *wv3, const float *bv3, float *q3_out, float *kt_out, float *vt_out, const float *y,
+                                const void *wvfold, const float *bvfold, const void *wqfold, const float *bqfold, const void *wofold,
+                                void *kexp_out, void *k256_out, float *cb_out, void *vpt_out, void *stream);
 int s6d_linear_split_weight_f32(const float *w, long n, void *hi, void *lo, void *stream);
 
 /* Soft-assignment head of compute_fine_Rt (Pose_Estimation_Model/utils/model_utils.py:262-270), fused.

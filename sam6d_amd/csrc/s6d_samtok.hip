@@ -56,17 +56,37 @@ struct SamtokPre {
   TkNorm n1;
   TkLinear q2;                // cross_attn_token_to_image.q_proj (256 -> 128)
   float *q1_out;              // (B,T,256) f32: norm1 output
-  float *qp_out;              // (B,T,128) f32: projected token->image queries (bf16-rounded values)
+  float *qp_out;              // (B,T,128) f32: projected token->image queries (bf16-rounded values); may be null
+  // the token->image attention's k projection folded into the queries (s6d_samdec_tok2img_raw_bf16's operand), when wkfold != null:
+  //   qfold[b, h*8 + t, c] = bf16( fold_scale * sum_d qp[b, t, 16 h + d] * Wk[16 h + d, c] ),  zero rows for t >= T
+  const u16 *wkfold;          // (256,128) = Wk^T, bf16, fragment order
+  float fold_scale;
+  u16 *qfold_out;             // (B,64,256) bf16
 };
 struct SamtokPost {
   const float *q1, *att, *pe; // (B,T,256), (B,T,128), (B,T,256) f32
   int B, T;
+  // att from the attention core's raw result (when y != null; att is then unused):  att[b,t,16 h + d] = sum_c y[b, h*8 + t, c] Wv[16 h + d, c] + bv
+  const float *y;             // (B,64,256) f32
+  const u16 *wvfold;          // (128,256) = Wv, bf16, fragment order
+  const float *bvfold;        // (128) f32
   TkLinear o2;                // cross_attn_token_to_image.out_proj (128 -> 256)
   TkNorm n2;
   TkLinear l1, l2;            // mlp.lin1 (256 -> 2048), mlp.lin2 (2048 -> 256)
   TkNorm n3;
   TkLinear k3, v3;            // cross_attn_image_to_token.k_proj / v_proj (256 -> 128)
-  float *q3_out, *kt_out, *vt_out;   // (B,T,256), (B,T,128), (B,T,128) f32
+  float *q3_out, *kt_out, *vt_out;   // (B,T,256), (B,T,128), (B,T,128) f32; kt_out / vt_out may be null
+  // operands of the image->token attention kernels made here instead of by library glue (each output optional):
+  //   kexp[b, h*8 + t, 16 h + d] = kt[b,t,16 h + d] / 4 (block diagonal; the caller zero-fills the buffer once)
+  //   k256[b, h*8 + t, c] = bf16( sum_d kexp[..] Wq[16 h + d, c] ),  cb[b, h*8 + t] = sum_d kexp[..] bq[16 h + d]
+  //   vpt[b, n, h*8 + t] = bf16( sum_d vt[b,t,16 h + d] Wo[n, 16 h + d] );  slots t >= T are zero
+  const u16 *wqfold;          // (256,128) = Wq^T of cross_attn_image_to_token.q_proj, bf16, fragment order
+  const float *bqfold;        // (128) f32
+  const u16 *wofold;          // (256,128) = Wo of cross_attn_image_to_token.out_proj, bf16, fragment order
+  u16 *kexp_out;              // (B,64,128) bf16
+  u16 *k256_out;              // (B,64,256) bf16
+  float *cb_out;              // (B,64) f32
+  u16 *vpt_out;               // (B,256,64) bf16
 };
 
 extern __shared__ __attribute__((aligned(16))) char tk_smem[];
@@ -211,6 +231,47 @@ __device__ __forceinline__ void tk_store_rows(const tk_f32x16 (&v)[NT], float *d
           make_float4(v[nt][4 * q], v[nt][4 * q + 1], v[nt][4 * q + 2], v[nt][4 * q + 3]);
 }
 
+
+// Per-head fold  out[c, row] = sum_{d < 16} W^T[c, 16 h + d] x[row, 16 h + d]  for the wave's 64 columns c and the 8 heads: ONE matrix
+// instruction per (head, 32-column tile) -- k16 step h of the fragment-ordered (256,128) operand against columns [16 h, 16 h + 16)
+// of the (32 rows x 128) bf16 image at xoff.  emit(h, nt, acc) receives the 32 x 32 tile (the lane's row, 16 of its columns).
+template <typename F>
+__device__ __forceinline__ void tk_head_fold(const u16 *__restrict__ w, const u16 *lds, int xoff, int wave, int lane, F emit) {
+  const int fr = lane & 31, fh = lane >> 5;
+  tk_u32x4 wr[2][8];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int h = 0; h < 8; ++h) wr[nt][h] = *reinterpret_cast<const tk_u32x4 *>(w + ((size_t)((2 * wave + nt) * 8 + h) * 64 + lane) * 8);
+#pragma unroll
+  for (int h = 0; h < 8; ++h) {
+    const tk_bf16x8 xf = *reinterpret_cast<const tk_bf16x8 *>(lds + xoff + fr * TK_XS + 16 * h + 8 * fh);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      tk_f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tk_bf16x8, wr[nt][h]), xf, acc, 0, 0, 0);
+      emit(h, nt, acc);
+    }
+  }
+}
+// the tile of tk_head_fold as rows of a (B,64,256) bf16 tensor: out[prompt, h*8 + tok, 64 wave + 32 nt + ...] = bf16(scale * acc)
+__device__ __forceinline__ void tk_store_fold(u16 *out, int prompt, int tok, bool prompt_ok, bool tok_ok, int h, int c0, int fh,
+                                              const tk_f32x16 &acc, float scale) {
+  if (!prompt_ok) return;
+  u16 *dst = out + ((size_t)prompt * 64 + h * 8 + tok) * 256 + c0 + 4 * fh;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    unsigned lo = 0, hi = 0;
+    if (tok_ok) {
+      lo = (unsigned)tk_bf16(acc[4 * q] * scale) | ((unsigned)tk_bf16(acc[4 * q + 1] * scale) << 16);
+      hi = (unsigned)tk_bf16(acc[4 * q + 2] * scale) | ((unsigned)tk_bf16(acc[4 * q + 3] * scale) << 16);
+    }
+    *reinterpret_cast<uint2 *>(dst + 8 * q) = make_uint2(lo, hi);
+  }
+}
+
 // ---- kernel 1: self-attention, norm1, token->image query projection --------------------------------------------------------
 __global__ __launch_bounds__(256) void samtok_pre_kernel(SamtokPre p) {
   u16 *lds = reinterpret_cast<u16 *>(tk_smem);
@@ -350,7 +411,17 @@ __global__ __launch_bounds__(256) void samtok_pre_kernel(SamtokPre p) {
   tk_zero<1>(qp);
   tk_gemm<1>(qp, p.q2.w, 16, wave, 0, 8, lds, X1, lane);
   tk_bias<1>(qp, p.q2.b, 32 * wave, fh, false);
-  tk_store_rows<1>(qp, p.qp_out, 128, row, valid, 32 * wave, fh);
+  if (p.qp_out) tk_store_rows<1>(qp, p.qp_out, 128, row, valid, 32 * wave, fh);
+  if (p.wkfold) {
+    // the folded queries of the attention core: qp (bf16 values) -> image (X0 columns [0, 128); its readers are behind the barriers
+    // above), then one matrix instruction per head and column tile
+    tk_to_image<1>(qp, lds, X0, 32 * wave, fr, fh);
+    __syncthreads();
+    const bool pok = prompt < p.B, tok_ok = tok < p.T;
+    tk_head_fold(p.wkfold, lds, X0, wave, lane, [&](int h, int nt, const tk_f32x16 &acc) __attribute__((always_inline)) {
+      tk_store_fold(p.qfold_out, prompt, tok, pok, tok_ok, h, 64 * wave + 32 * nt, fh, acc, p.fold_scale);
+    });
+  }
 }
 
 // ---- kernel 2: attention output projection, norm2, MLP, norm3, the image->token attention's k / v projections -----------------
@@ -367,7 +438,47 @@ __global__ __launch_bounds__(256) void samtok_post_kernel(SamtokPost p) {
   // attention output (B,T,128) -> X0 columns [0, 128): wave w writes the 32 columns [32 w, 32 w + 32) of its rows
   {
     tk_f32x16 a[1];
-    tk_load_rows<1>(a, p.att, 128, row, valid, 32 * wave, fh);
+    if (p.y) {
+      // ... made here from the attention core's raw result: the 32 columns of wave w are heads 2 w and 2 w + 1; head h multiplies ITS
+      // rows y[b, h*8 + t, :] (K = 256, fp32 -> bf16 hi + lo parts: two instructions per k step keep y to 2^-17) by W_v's 32-row tile
+      // w, of which its own 16 rows are kept (registers 0-7 for the even head, 8-15 for the odd one)
+      tk_f32x16 acc[2];
+      tk_zero<2>(acc);
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int h = 2 * wave + hh;
+        const float *yr = p.y + ((size_t)prompt * 64 + h * 8 + tok) * 256 + 8 * fh;
+        float4 yv[16][2];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          yv[ks][0] = valid ? *reinterpret_cast<const float4 *>(yr + 16 * ks) : make_float4(0.f, 0.f, 0.f, 0.f);
+          yv[ks][1] = valid ? *reinterpret_cast<const float4 *>(yr + 16 * ks + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const tk_u32x4 wv = *reinterpret_cast<const tk_u32x4 *>(p.wvfold + ((size_t)(wave * 16 + ks) * 64 + lane) * 8);
+          const float f[8] = {yv[ks][0].x, yv[ks][0].y, yv[ks][0].z, yv[ks][0].w, yv[ks][1].x, yv[ks][1].y, yv[ks][1].z, yv[ks][1].w};
+          union { tk_bf16x8 v; u16 h[8]; } xh, xl;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            xh.h[e] = tk_bf16(f[e]);
+            xl.h[e] = tk_bf16(f[e] - tk_f32(xh.h[e]));
+          }
+          acc[hh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tk_bf16x8, wv), xl.v, acc[hh], 0, 0, 0);
+          acc[hh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tk_bf16x8, wv), xh.v, acc[hh], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 b = *reinterpret_cast<const float4 *>(p.bvfold + 32 * wave + 4 * fh + 8 * q);
+        const float bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[0][4 * q + e] = valid ? (q < 2 ? acc[0][4 * q + e] : acc[1][4 * q + e]) + bv[e] : 0.f;
+      }
+    } else {
+      tk_load_rows<1>(a, p.att, 128, row, valid, 32 * wave, fh);
+    }
     tk_to_image<1>(a, lds, X0, 32 * wave, fr, fh);
   }
   tk_f32x16 q1[2], pv[2];
@@ -421,11 +532,53 @@ __global__ __launch_bounds__(256) void samtok_post_kernel(SamtokPost p) {
   tk_zero<1>(kt);
   tk_gemm<1>(kt, p.k3.w, 16, wave, 0, 8, lds, X0, lane);
   tk_bias<1>(kt, p.k3.b, 32 * wave, fh, false);
-  tk_store_rows<1>(kt, p.kt_out, 128, row, valid, 32 * wave, fh);
+  if (p.kt_out) tk_store_rows<1>(kt, p.kt_out, 128, row, valid, 32 * wave, fh);
   tk_zero<1>(vt);
   tk_gemm<1>(vt, p.v3.w, 16, wave, 0, 8, lds, X1, lane);
   tk_bias<1>(vt, p.v3.b, 32 * wave, fh, false);
-  tk_store_rows<1>(vt, p.vt_out, 128, row, valid, 32 * wave, fh);
+  if (p.vt_out) tk_store_rows<1>(vt, p.vt_out, 128, row, valid, 32 * wave, fh);
+  if (!p.kexp_out && !p.k256_out && !p.vpt_out) return;
+  // ---- operands of the image->token attention: scaled keys (x 1/4 = 1/sqrt(16): exact), folds with W_q^T and W_o per head ----------
+  const bool pok = prompt < p.B, tok_ok = tok < p.T;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) kt[0][r] *= 0.25f;
+  __syncthreads();                                                   // every wave is past the k / v products (readers of X0 / X1)
+  tk_to_image<1>(kt, lds, X0, 32 * wave, fr, fh);
+  tk_to_image<1>(vt, lds, X1, 32 * wave, fr, fh);
+  if (p.kexp_out && pok && tok_ok) {                                 // block diagonal: head h = 2 w + (register >> 3) keeps its 16 columns
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int h = 2 * wave + (q >> 1), col = 32 * wave + 4 * fh + 8 * q;
+      const unsigned lo = (unsigned)tk_bf16(kt[0][4 * q]) | ((unsigned)tk_bf16(kt[0][4 * q + 1]) << 16);
+      const unsigned hi = (unsigned)tk_bf16(kt[0][4 * q + 2]) | ((unsigned)tk_bf16(kt[0][4 * q + 3]) << 16);
+      *reinterpret_cast<uint2 *>(p.kexp_out + ((size_t)prompt * 64 + h * 8 + tok) * 128 + col) = make_uint2(lo, hi);
+    }
+  }
+  if (p.cb_out) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int q = 2 * hh; q < 2 * hh + 2; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sacc = __builtin_fmaf(kt[0][4 * q + e], p.bqfold[32 * wave + 4 * fh + 8 * q + e], sacc);
+      sacc += __shfl_xor(sacc, 32);
+      if (fh == 0 && pok) p.cb_out[(size_t)prompt * 64 + (2 * wave + hh) * 8 + tok] = tok_ok ? sacc : 0.f;
+    }
+  }
+  __syncthreads();
+  if (p.k256_out)
+    tk_head_fold(p.wqfold, lds, X0, wave, lane, [&](int h, int nt, const tk_f32x16 &acc) __attribute__((always_inline)) {
+      tk_store_fold(p.k256_out, prompt, tok, pok, tok_ok, h, 64 * wave + 32 * nt, fh, acc, 1.0f);
+    });
+  if (p.vpt_out)
+    tk_head_fold(p.wofold, lds, X1, wave, lane, [&](int h, int nt, const tk_f32x16 &acc) __attribute__((always_inline)) {
+      if (!pok) return;
+      // vpt[b, n, h*8 + tok]: 2-byte stores; the eight token lanes of a prompt make a 16-byte run
+      u16 *dst = p.vpt_out + ((size_t)prompt * 256 + 64 * wave + 32 * nt + 4 * fh) * 64 + h * 8 + tok;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[(size_t)((r & 3) + 8 * (r >> 2)) * 64] = tok_ok ? tk_bf16(acc[r]) : (u16)0;
+    });
 }
 
 }  // namespace s6d
@@ -437,13 +590,16 @@ static bool tk_aligned(const void *a) { return (((uintptr_t)a) & 15) == 0; }
 extern "C" int s6d_samdec_tokens_pre_bf16(const float *queries, const float *pe, int B, int T, int add_pe, const void *wq,
                                           const float *bq, const void *wk, const float *bk, const void *wv, const float *bv,
                                           const void *wo, const float *bo, const float *gamma1, const float *beta1, float eps1,
-                                          const void *wq2, const float *bq2, float *q1_out, float *qp_out, void *stream) {
+                                          const void *wq2, const float *bq2, float *q1_out, float *qp_out, const void *wkfold,
+                                          float fold_scale, void *qfold_out, void *stream) {
   if (B < 0 || T < 1 || T > 8) return S6D_EINVAL;
   if (B == 0) return S6D_OK;
-  if (!queries || !pe || !wq || !bq || !wk || !bk || !wv || !bv || !wo || !bo || !gamma1 || !beta1 || !wq2 || !bq2 || !q1_out || !qp_out)
+  if (!queries || !pe || !wq || !bq || !wk || !bk || !wv || !bv || !wo || !bo || !gamma1 || !beta1 || !wq2 || !bq2 || !q1_out)
     return S6D_EINVAL;
+  if (!qp_out && !wkfold) return S6D_EINVAL;
+  if (wkfold && !qfold_out) return S6D_EINVAL;
   if (!tk_aligned(queries) || !tk_aligned(pe) || !tk_aligned(q1_out) || !tk_aligned(qp_out) || !tk_aligned(wq) || !tk_aligned(wk) ||
-      !tk_aligned(wv) || !tk_aligned(wo) || !tk_aligned(wq2))
+      !tk_aligned(wv) || !tk_aligned(wo) || !tk_aligned(wq2) || !tk_aligned(wkfold) || !tk_aligned(qfold_out))
     return S6D_EINVAL;
   SamtokPre p;
   p.queries = queries; p.pe = pe; p.B = B; p.T = T; p.add_pe = add_pe ? 1 : 0;
@@ -451,6 +607,7 @@ extern "C" int s6d_samdec_tokens_pre_bf16(const float *queries, const float *pe,
   p.n1 = {gamma1, beta1, eps1};
   p.q2 = {(const u16 *)wq2, bq2};
   p.q1_out = q1_out; p.qp_out = qp_out;
+  p.wkfold = (const u16 *)wkfold; p.fold_scale = fold_scale; p.qfold_out = (u16 *)qfold_out;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&samtok_pre_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TK_LDS_BYTES);
   hipLaunchKernelGGL(samtok_pre_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), TK_LDS_BYTES, as_stream(stream), p);
   return launch_status();
@@ -460,14 +617,22 @@ extern "C" int s6d_samdec_tokens_post_bf16(const float *q1, const float *att, co
                                            const float *bo2, const float *gamma2, const float *beta2, float eps2, const void *w1,
                                            const float *b1, const void *w2, const float *b2, const float *gamma3, const float *beta3,
                                            float eps3, const void *wk3, const float *bk3, const void *wv3, const float *bv3,
-                                           float *q3_out, float *kt_out, float *vt_out, void *stream) {
+                                           float *q3_out, float *kt_out, float *vt_out, const float *y, const void *wvfold,
+                                           const float *bvfold, const void *wqfold, const float *bqfold, const void *wofold,
+                                           void *kexp_out, void *k256_out, float *cb_out, void *vpt_out, void *stream) {
   if (B < 0 || T < 1 || T > 8) return S6D_EINVAL;
   if (B == 0) return S6D_OK;
-  if (!q1 || !att || !pe || !wo2 || !bo2 || !gamma2 || !beta2 || !w1 || !b1 || !w2 || !b2 || !gamma3 || !beta3 || !wk3 || !bk3 || !wv3 ||
-      !bv3 || !q3_out || !kt_out || !vt_out)
+  if (!q1 || !pe || !wo2 || !bo2 || !gamma2 || !beta2 || !w1 || !b1 || !w2 || !b2 || !gamma3 || !beta3 || !wk3 || !bk3 || !wv3 ||
+      !bv3 || !q3_out)
     return S6D_EINVAL;
+  if (!att && !y) return S6D_EINVAL;
+  if (y && (!wvfold || !bvfold)) return S6D_EINVAL;
+  if ((k256_out || cb_out) && (!wqfold || !bqfold || !k256_out || !cb_out)) return S6D_EINVAL;
+  if (vpt_out && !wofold) return S6D_EINVAL;
   if (!tk_aligned(q1) || !tk_aligned(att) || !tk_aligned(pe) || !tk_aligned(q3_out) || !tk_aligned(kt_out) || !tk_aligned(vt_out) ||
-      !tk_aligned(wo2) || !tk_aligned(w1) || !tk_aligned(w2) || !tk_aligned(wk3) || !tk_aligned(wv3))
+      !tk_aligned(wo2) || !tk_aligned(w1) || !tk_aligned(w2) || !tk_aligned(wk3) || !tk_aligned(wv3) || !tk_aligned(y) ||
+      !tk_aligned(wvfold) || !tk_aligned(bvfold) || !tk_aligned(wqfold) || !tk_aligned(wofold) || !tk_aligned(kexp_out) ||
+      !tk_aligned(k256_out) || !tk_aligned(vpt_out))
     return S6D_EINVAL;
   SamtokPost p;
   p.q1 = q1; p.att = att; p.pe = pe; p.B = B; p.T = T;
@@ -477,6 +642,9 @@ extern "C" int s6d_samdec_tokens_post_bf16(const float *q1, const float *att, co
   p.n3 = {gamma3, beta3, eps3};
   p.k3 = {(const u16 *)wk3, bk3}; p.v3 = {(const u16 *)wv3, bv3};
   p.q3_out = q3_out; p.kt_out = kt_out; p.vt_out = vt_out;
+  p.y = y; p.wvfold = (const u16 *)wvfold; p.bvfold = bvfold;
+  p.wqfold = (const u16 *)wqfold; p.bqfold = bqfold; p.wofold = (const u16 *)wofold;
+  p.kexp_out = (u16 *)kexp_out; p.k256_out = (u16 *)k256_out; p.cb_out = cb_out; p.vpt_out = (u16 *)vpt_out;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&samtok_post_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TK_LDS_BYTES);
   hipLaunchKernelGGL(samtok_post_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), TK_LDS_BYTES, as_stream(stream), p);
   return launch_status();

@@ -385,10 +385,12 @@ def samdec_tok2img_raw(qt, x, pe, wk, wv, bv, scale):
     return out.reshape(B, T, 128)
 
 
-def samdec_tokens_pre(queries, pe, add_pe, lin_q, lin_k, lin_v, lin_o, norm1, lin_q2):
+def samdec_tokens_pre(queries, pe, add_pe, lin_q, lin_k, lin_v, lin_o, norm1, lin_q2, fold=None):
     """Self-attention + norm1 + token->image query projection of a TwoWayAttentionBlock's sparse tokens in one launch
     (s6d_samdec_tokens_pre_bf16).  queries, pe (B,T<=8,256) f32; lin_* = (fragment-ordered bf16 weight, f32 bias); norm1 =
-    (gamma, beta, eps) -> (q1 (B,T,256) f32, qp (B,T,128) f32)."""
+    (gamma, beta, eps) -> (q1 (B,T,256) f32, qp (B,T,128) f32).
+    fold = (wkfold, scale): the attention core's k projection folded into the queries inside the kernel -> (q1, qfold (B,64,256)
+    bf16) instead: the query operand of samdec_tok2img_raw_core."""
     _chk(queries, torch.float32, "queries", 3)
     _chk(pe, torch.float32, "pe", 3)
     B, T, C = queries.shape
@@ -396,30 +398,81 @@ def samdec_tokens_pre(queries, pe, add_pe, lin_q, lin_k, lin_v, lin_o, norm1, li
         raise ValueError("samdec_tokens_pre: queries / pe must be (B, T <= 8, 256)")
     queries, pe = queries.contiguous(), pe.contiguous()
     q1 = torch.empty(B, T, 256, dtype=torch.float32, device=queries.device)
-    qp = torch.empty(B, T, 128, dtype=torch.float32, device=queries.device)
+    if fold is None:
+        out2 = torch.empty(B, T, 128, dtype=torch.float32, device=queries.device)
+        qp_ptr, wk_ptr, sc, qf_ptr = _ptr(out2), _vp(0), 0.0, _vp(0)
+    else:
+        out2 = torch.empty(B, 64, 256, dtype=torch.bfloat16, device=queries.device)
+        qp_ptr, wk_ptr, sc, qf_ptr = _vp(0), _ptr(fold[0]), float(fold[1]), _ptr(out2)
     _call("s6d_samdec_tokens_pre_bf16", _ptr(queries), _ptr(pe), B, T, 1 if add_pe else 0, _ptr(lin_q[0]), _ptr(lin_q[1]), _ptr(lin_k[0]),
           _ptr(lin_k[1]), _ptr(lin_v[0]), _ptr(lin_v[1]), _ptr(lin_o[0]), _ptr(lin_o[1]), _ptr(norm1[0]), _ptr(norm1[1]),
-          ctypes.c_float(norm1[2]), _ptr(lin_q2[0]), _ptr(lin_q2[1]), _ptr(q1), _ptr(qp), _stream())
-    return q1, qp
+          ctypes.c_float(norm1[2]), _ptr(lin_q2[0]), _ptr(lin_q2[1]), _ptr(q1), qp_ptr, wk_ptr, ctypes.c_float(sc), qf_ptr, _stream())
+    return q1, out2
 
 
-def samdec_tokens_post(q1, att, pe, lin_o2, norm2, lin_1, lin_2, norm3, lin_k3, lin_v3):
+def samdec_tok2img_raw_core(qfold, x, pe):
+    """The attention core of samdec_tok2img_raw alone: qfold (B,64,256) bf16 folded queries (samdec_tokens_pre(fold=...)), x
+    (1|B,N,256) bf16 image tokens, pe (N,256) bf16 or None -> y (B,64,256) f32 = sum_n p_jn x_n (samdec_tokens_post(y=...) applies W_v)."""
+    _chk(qfold, torch.bfloat16, "qfold", 3)
+    _chk(x, torch.bfloat16, "x", 3)
+    B = qfold.shape[0]
+    if tuple(qfold.shape[1:]) != (64, 256) or x.shape[0] not in (1, B) or x.shape[2] != 256 or not qfold.is_contiguous():
+        raise RuntimeError("samdec_tok2img_raw_core: qfold must be contiguous (B,64,256), x (1|B,N,256) bfloat16")
+    if pe is not None:
+        _chk(pe, torch.bfloat16, "pe", 2)
+    y = torch.empty(B, 64, 256, dtype=torch.float32, device=qfold.device)
+    _call("s6d_samdec_tok2img_raw_bf16", _ptr(qfold), _ptr(x), int(x.stride(1)), 1 if x.shape[0] == 1 and B > 1 else 0,
+          _ptr(pe) if pe is not None else _vp(0), B, int(x.shape[1]), _ptr(y), _stream())
+    return y
+
+
+def samdec_tokens_post(q1, att, pe, lin_o2, norm2, lin_1, lin_2, norm3, lin_k3, lin_v3, y=None, vfold=None, expand=None):
     """Attention output projection + norm2 + MLP + norm3 + the image->token attention's k / v projections in one launch
-    (s6d_samdec_tokens_post_bf16).  q1, pe (B,T,256) f32, att (B,T,128) f32 -> (q3 (B,T,256), kt (B,T,128), vt (B,T,128)) f32."""
+    (s6d_samdec_tokens_post_bf16).  q1, pe (B,T,256) f32, att (B,T,128) f32 -> (q3 (B,T,256), kt (B,T,128), vt (B,T,128)) f32.
+    y (B,64,256) f32 + vfold = (wvfold, bv): att is formed in the kernel from the attention core's raw result (att = None).
+    expand = dict(wq=wqfold, bq=bias, wo=wofold, fold_q=bool): the operands of the image->token attention kernels are made in the
+    kernel as well -> (q3, dict(kexp | k256 + cb, vpt)) instead of (q3, kt, vt)."""
     _chk(q1, torch.float32, "q1", 3)
-    _chk(att, torch.float32, "att", 3)
     _chk(pe, torch.float32, "pe", 3)
     B, T, C = q1.shape
-    if C != 256 or T > 8 or pe.shape != q1.shape or tuple(att.shape) != (B, T, 128):
-        raise ValueError("samdec_tokens_post: q1 / pe must be (B, T <= 8, 256), att (B, T, 128)")
-    q1, att, pe = q1.contiguous(), att.contiguous(), pe.contiguous()
-    q3 = torch.empty(B, T, 256, dtype=torch.float32, device=q1.device)
-    kt = torch.empty(B, T, 128, dtype=torch.float32, device=q1.device)
-    vt = torch.empty(B, T, 128, dtype=torch.float32, device=q1.device)
-    _call("s6d_samdec_tokens_post_bf16", _ptr(q1), _ptr(att), _ptr(pe), B, T, _ptr(lin_o2[0]), _ptr(lin_o2[1]), _ptr(norm2[0]), _ptr(norm2[1]),
-          ctypes.c_float(norm2[2]), _ptr(lin_1[0]), _ptr(lin_1[1]), _ptr(lin_2[0]), _ptr(lin_2[1]), _ptr(norm3[0]), _ptr(norm3[1]),
-          ctypes.c_float(norm3[2]), _ptr(lin_k3[0]), _ptr(lin_k3[1]), _ptr(lin_v3[0]), _ptr(lin_v3[1]), _ptr(q3), _ptr(kt), _ptr(vt), _stream())
-    return q3, kt, vt
+    if C != 256 or T > 8 or pe.shape != q1.shape:
+        raise ValueError("samdec_tokens_post: q1 / pe must be (B, T <= 8, 256)")
+    if y is None:
+        _chk(att, torch.float32, "att", 3)
+        if tuple(att.shape) != (B, T, 128):
+            raise ValueError("samdec_tokens_post: att must be (B, T, 128)")
+        att = att.contiguous()
+    else:
+        _chk(y, torch.float32, "y", 3)
+        if tuple(y.shape) != (B, 64, 256) or not y.is_contiguous() or vfold is None:
+            raise ValueError("samdec_tokens_post: y must be contiguous (B, 64, 256) with vfold = (wvfold, bv)")
+    q1, pe = q1.contiguous(), pe.contiguous()
+    dev = q1.device
+    q3 = torch.empty(B, T, 256, dtype=torch.float32, device=dev)
+    null = _vp(0)
+    if expand is None:
+        kt = torch.empty(B, T, 128, dtype=torch.float32, device=dev)
+        vt = torch.empty(B, T, 128, dtype=torch.float32, device=dev)
+        tail = (_ptr(kt), _ptr(vt))
+        ex = (null, null, null, null, null, null, null)
+        res = (q3, kt, vt)
+    else:
+        out = {"vpt": torch.empty(B, 256, 64, dtype=torch.bfloat16, device=dev)}
+        if expand["fold_q"]:
+            out["k256"] = torch.empty(B, 64, 256, dtype=torch.bfloat16, device=dev)
+            out["cb"] = torch.empty(B, 64, dtype=torch.float32, device=dev)
+            ex = (_ptr(expand["wq"]), _ptr(expand["bq"]), _ptr(expand["wo"]), null, _ptr(out["k256"]), _ptr(out["cb"]), _ptr(out["vpt"]))
+        else:
+            out["kexp"] = torch.zeros(B, 64, 128, dtype=torch.bfloat16, device=dev)      # block diagonal: the kernel writes the blocks
+            ex = (null, null, _ptr(expand["wo"]), _ptr(out["kexp"]), null, null, _ptr(out["vpt"]))
+        tail = (null, null)
+        res = (q3, out)
+    yargs = (null, null, null) if y is None else (_ptr(y), _ptr(vfold[0]), _ptr(vfold[1]))
+    _call("s6d_samdec_tokens_post_bf16", _ptr(q1), _ptr(att) if y is None else null, _ptr(pe), B, T, _ptr(lin_o2[0]), _ptr(lin_o2[1]),
+          _ptr(norm2[0]), _ptr(norm2[1]), ctypes.c_float(norm2[2]), _ptr(lin_1[0]), _ptr(lin_1[1]), _ptr(lin_2[0]), _ptr(lin_2[1]),
+          _ptr(norm3[0]), _ptr(norm3[1]), ctypes.c_float(norm3[2]), _ptr(lin_k3[0]), _ptr(lin_k3[1]), _ptr(lin_v3[0]), _ptr(lin_v3[1]),
+          _ptr(q3), *tail, *yargs, *ex, _stream())
+    return res
 
 
 def sam_mask_post(low_res, img_size, input_size, original_size, mask_threshold=0.0, stability_offset=1.0):

@@ -414,28 +414,48 @@ class MaskDecoder(nn.Module):
         sa, ca, ci = L.self_attn, L.cross_attn_token_to_image, L.cross_attn_image_to_token
         lins = [sa.q_proj, sa.k_proj, sa.v_proj, sa.out_proj, ca.q_proj, ca.out_proj, L.mlp.lin1, L.mlp.lin2, ci.k_proj, ci.v_proj]
         norms = [L.norm1, L.norm2, L.norm3]
-        srcs = [t for m in lins + norms for t in (m.weight, m.bias)]
+        srcs = [t for m in lins + norms + [ca.k_proj, ca.v_proj, ci.q_proj, ci.out_proj] for t in (m.weight, m.bias)]
         key = tuple((t._version, t.data_ptr()) for t in srcs)
         cache = self.__dict__.setdefault("_s6d_tokw", {})
         c = cache.get(li)
         if c is None or c[0] != key:
             with torch.no_grad(), torch.autocast(device_type="cuda", enabled=False):
-                lw = [(ops.fragment_weight(m.weight.detach().to(torch.bfloat16).contiguous()), m.bias.detach().float().contiguous()) for m in lins]
+                bf = torch.bfloat16
+                lw = [(ops.fragment_weight(m.weight.detach().to(bf).contiguous()), m.bias.detach().float().contiguous()) for m in lins]
                 nw = [(m.weight.detach().float().contiguous(), m.bias.detach().float().contiguous(), float(m.eps)) for m in norms]
-            c = (key, lw, nw)
+                # the per-head folds around the two attention cores (ops.samdec_tokens_pre(fold=), ops.samdec_tokens_post(y=, expand=))
+                fw = dict(wk=ops.fragment_weight(ca.k_proj.weight.detach().to(bf).t().contiguous()),            # (256,128) = W_k^T
+                          wv=ops.fragment_weight(ca.v_proj.weight.detach().to(bf).contiguous()),                # (128,256)
+                          bv=ca.v_proj.bias.detach().float().contiguous(),
+                          wq=ops.fragment_weight(ci.q_proj.weight.detach().to(bf).t().contiguous()),            # (256,128) = W_q^T
+                          bq=ci.q_proj.bias.detach().float().contiguous(),
+                          wo=ops.fragment_weight(ci.out_proj.weight.detach().to(bf).contiguous()))              # (256,128)
+            c = (key, lw, nw, fw)
             cache[li] = c
-        return c[1], c[2]
+        return c[1], c[2], c[3]
 
-    def _token_side(self, li, queries, tokens, t2i):
+    def _token_side(self, li, queries, tokens, t2i, x=None, pe_bf=None, fold_q=False):
         """TwoWayAttentionBlock.token_side of layer li + the k / v projections of its image->token attention, on the two
-        token-side kernels (csrc/s6d_samtok.hip) around the token->image attention core `t2i` -> (queries, (kt, vt)); the module
-        statements when the kernels do not apply."""
+        token-side kernels (csrc/s6d_samtok.hip) around the token->image attention core -> (queries, extra); the module statements
+        when the kernels do not apply (extra = None).
+        With x (the image tokens the core attends, bf16) and pe_bf given, the core runs on the folded queries the first kernel
+        writes, its W_v product and the operands of the image->token attention kernel (block-diagonal keys or their W_q fold,
+        the values with out_proj folded in) are made by the second kernel: extra = dict(kexp | k256 + cb, vpt).  Otherwise `t2i`
+        (projected queries -> attention output before out_proj) is called between the kernels: extra = (kt, vt)."""
         L = self.transformer.layers[li]
         if policy.guard("sam.MaskDecoder.token_side", cuda=queries.is_cuda, have=ops.have("samdec_tokens"), T8=queries.shape[1] <= 8,
-                        f32=queries.dtype == torch.float32 and tokens.dtype == torch.float32, t2i=t2i is not None,
+                        f32=queries.dtype == torch.float32 and tokens.dtype == torch.float32, t2i=t2i is not None or x is not None,
                         geometry=L.self_attn.internal_dim == 256 and L.mlp.lin1.out_features == 2048):
-            lw, nw = self._token_weights(li)
+            lw, nw, fw = self._token_weights(li)
+            ca = L.cross_attn_token_to_image
             with torch.autocast(device_type="cuda", enabled=False):
+                if x is not None and ops.have("samdec_tok2img_raw"):
+                    sc = 1.4426950408889634 / math.sqrt(ca.internal_dim // ca.num_heads)
+                    q1, qfold = ops.samdec_tokens_pre(queries, tokens, not L.skip_first_layer_pe, lw[0], lw[1], lw[2], lw[3], nw[0], lw[4],
+                                                      fold=(fw["wk"], sc))
+                    y = ops.samdec_tok2img_raw_core(qfold, x, pe_bf)
+                    return ops.samdec_tokens_post(q1, None, tokens, lw[5], nw[1], lw[6], lw[7], nw[2], lw[8], lw[9], y=y,
+                                                  vfold=(fw["wv"], fw["bv"]), expand=dict(wq=fw["wq"], bq=fw["bq"], wo=fw["wo"], fold_q=fold_q))
                 q1, qp = ops.samdec_tokens_pre(queries, tokens, not L.skip_first_layer_pe, lw[0], lw[1], lw[2], lw[3], nw[0], lw[4])
                 att = t2i(qp)
                 q3, kt, vt = ops.samdec_tokens_post(q1, att, tokens, lw[5], nw[1], lw[6], lw[7], nw[2], lw[8], lw[9])
@@ -516,14 +536,17 @@ class MaskDecoder(nn.Module):
             return lambda qp: ops.samdec_tok2img_raw(qp, x, pe_, att.k_proj.weight, att.v_proj.weight, att.v_proj.bias, sc)
         ktvt = None
         if raw:
-            queries, ktvt = self._token_side(0, tokens.float(), tokens.float(), t2i_raw(ca, keys0_bf, P["pe_bf"]))
+            queries, ktvt = self._token_side(0, tokens.float(), tokens.float(), t2i_raw(ca, keys0_bf, P["pe_bf"]), x=keys0_bf, pe_bf=P["pe_bf"])
         elif t2i:
             kv0 = torch.cat([ca.k_proj(kp0), ca.v_proj(keys0)], -1).to(bf).contiguous()           # (1, N, 2d)
             queries = L0.token_side(tokens, tokens, None, None,
                                     lambda qp: ops.samdec_tok2img(qp, kv0, 0, ca.internal_dim, None, sc))
         else:
             queries = L0.token_side(tokens, tokens, ca.k_proj(kp0), ca.v_proj(keys0))
-        kexp, vpt = self._expand(ci, queries, tokens, ktvt=ktvt)
+        if isinstance(ktvt, dict):
+            kexp, vpt = ktvt["kexp"], ktvt["vpt"]
+        else:
+            kexp, vpt = self._expand(ci, queries, tokens, ktvt=ktvt)
         n4 = L0.norm4
         keys1 = ops.samdec_img2tok(ci.q_proj(kp0).to(bf).contiguous(), None, kexp, vpt, keys0_bf,
                                    ci.out_proj.bias.float(), n4.weight.float(), n4.bias.float(), n4.eps, T)
@@ -533,7 +556,8 @@ class MaskDecoder(nn.Module):
         fold = raw and ops.have("samdec_img2tok_raw")
         ktvt = None
         if raw:
-            queries, ktvt = self._token_side(1, queries.float(), tokens.float(), t2i_raw(ca, keys1, P["pe_bf"]))
+            queries, ktvt = self._token_side(1, queries.float(), tokens.float(), t2i_raw(ca, keys1, P["pe_bf"]), x=keys1, pe_bf=P["pe_bf"],
+                                             fold_q=fold)
             q1 = None if fold else self._rows_gemm(keys1, P["w_q1"], P["b_q1"])    # (B, N, d) bf16: image->token queries only
         else:
             kvq = self._rows_gemm(keys1, P["w_kvq"], P["b_kvq"])                   # (B, N, 3d) bf16
@@ -545,11 +569,17 @@ class MaskDecoder(nn.Module):
             q1 = kvq[..., 2 * d:]
         n4 = L1.norm4
         if fold:                                                                   # q projection folded into the expanded keys
-            k256, cb, vpt = self._expand(ci, queries, tokens, fold_q=True, ktvt=ktvt)
+            if isinstance(ktvt, dict):
+                k256, cb, vpt = ktvt["k256"], ktvt["cb"], ktvt["vpt"]
+            else:
+                k256, cb, vpt = self._expand(ci, queries, tokens, fold_q=True, ktvt=ktvt)
             keys2 = ops.samdec_img2tok_raw(keys1, P["pe_bf"], k256, cb, vpt, keys1, ci.out_proj.bias.float(),
                                            n4.weight.float(), n4.bias.float(), n4.eps, T)
         else:
-            kexp, vpt = self._expand(ci, queries, tokens, ktvt=ktvt)
+            if isinstance(ktvt, dict):
+                kexp, vpt = ktvt["kexp"], ktvt["vpt"]
+            else:
+                kexp, vpt = self._expand(ci, queries, tokens, ktvt=ktvt)
             keys2 = ops.samdec_img2tok(q1, P["qpe1"], kexp, vpt, keys1, ci.out_proj.bias.float(),
                                        n4.weight.float(), n4.bias.float(), n4.eps, T)
         # ---- final token->image attention + output head ---------------------------------------------------------------

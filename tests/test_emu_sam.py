@@ -165,3 +165,7 @@ def test_dinov2_folded_block_loop_against_float(emu, monkeypatch):
 
 def test_token_side_kernels_on_the_emulator(emu):
     T.test_token_side_kernels_vs_autocast_statement(6, 7)
+
+
+def test_token_side_folds_on_the_emulator(emu):
+    T.test_token_side_kernels_with_the_folds_inside(2, 5)

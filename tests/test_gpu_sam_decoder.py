@@ -434,9 +434,53 @@ def test_token_side_kernels_vs_autocast_statement(B, T):
                 seen["qp"] = qp.clone()
                 return t2i(qp)
             q3, (kt, vt) = dec._token_side(li, queries, pe, spy)
-            lw, nw = dec._token_weights(li)
+            lw, nw, _ = dec._token_weights(li)
             q1, _ = ops.samdec_tokens_pre(queries, pe, not L.skip_first_layer_pe, lw[0], lw[1], lw[2], lw[3], nw[0], lw[4])
         for name, a, b in (("q1", q1, want[0]), ("qp", seen["qp"], want[1]), ("q3", q3, want[2]), ("kt", kt, want[3]), ("vt", vt, want[4])):
             err = (a - b).abs()
             util.record_margin(f"samdec_token_side_L{li}_B{B}_T{T}_{name}", max_abs=err.max().item(), mean_abs=err.mean().item(), ref_abs_max=b.abs().max().item())
             assert err.max().item() < 4e-2 and err.mean().item() < 5e-4, (li, name, err.max().item(), err.mean().item())
+
+
+@pytest.mark.parametrize("B,T", [(5, 7), (2, 5)])
+def test_token_side_kernels_with_the_folds_inside(B, T):
+    """The same two kernels with the per-head products around the attention cores made INSIDE them (round 6): the token->image
+    attention's k projection folded into the queries (first kernel), its W_v product, and the operands of the image->token attention
+    kernels -- block-diagonal scaled keys or their W_q fold + bias term, values with out_proj folded in -- (second kernel), against
+    the library glue they replace (ops.samdec_tok2img_raw's einsums in float32, MaskDecoder._expand) on the same image tokens.
+    Differences: the folds multiply by the bf16-rounded weights (as the autocast Linear of the reference would) where the glue used
+    float32 weights, so the attention output moves by ~2^-9 relative before it is rounded to bf16 for the out projection anyway."""
+    import math
+    from sam6d_amd import ops
+    from sam6d_amd.sam.mask_decoder import build_sam_decoder
+    dec = seeded.load_seeded(build_sam_decoder(), 3).cuda().mask_decoder
+    g = torch.Generator().manual_seed(B * 100 + T)
+    queries = torch.randn(B, T, 256, generator=g).cuda()
+    pe = torch.randn(B, T, 256, generator=g).cuda()
+    N = 256
+    x = torch.randn(B, N, 256, generator=g).cuda().to(torch.bfloat16)
+    pe_bf = torch.randn(N, 256, generator=g).cuda().to(torch.bfloat16)
+    for li, fold_q in ((0, False), (1, True)):
+        L = dec.transformer.layers[li]
+        ca, ci = L.cross_attn_token_to_image, L.cross_attn_image_to_token
+        sc = 1.0 / math.sqrt(ca.internal_dim // ca.num_heads)
+
+        def t2i(qp):
+            return ops.samdec_tok2img_raw(qp.float(), x, pe_bf, ca.k_proj.weight, ca.v_proj.weight, ca.v_proj.bias, sc)
+        with torch.no_grad():
+            q3_w, ktvt = dec._token_side(li, queries, pe, t2i)                     # glue between the kernels
+            want = dec._expand(ci, q3_w, pe, fold_q=fold_q, ktvt=ktvt)
+            q3, got = dec._token_side(li, queries, pe, None, x=x, pe_bf=pe_bf, fold_q=fold_q)
+        assert isinstance(got, dict)
+        pairs = [("q3", q3, q3_w)]
+        if fold_q:
+            pairs += [("k256", got["k256"].float(), want[0].float()), ("cb", got["cb"], want[1]), ("vpt", got["vpt"].float(), want[2].float())]
+        else:
+            pairs += [("kexp", got["kexp"].float(), want[0].float()), ("vpt", got["vpt"].float(), want[1].float())]
+        for name, a, b in pairs:
+            assert a.shape == b.shape, (name, a.shape, b.shape)
+            err = (a - b).abs()
+            util.record_margin(f"samdec_token_side_folds_L{li}_B{B}_T{T}_{name}", max_abs=err.max().item(), mean_abs=err.mean().item(), ref_abs_max=b.abs().max().item())
+            assert err.max().item() < 8e-2 and err.mean().item() < 3e-3, (li, name, err.max().item(), err.mean().item())
+        if not fold_q:
+            assert torch.equal(got["kexp"].float() == 0, want[0].float() == 0)      # the block structure and the zero slots

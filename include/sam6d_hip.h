@@ -217,6 +217,12 @@ int s6d_win_attention_bf16(const void *qkv, const void *qkv_bias, const void *re
 int s6d_win_attention_layout_bf16(const void *qkv, int head_major, const void *qkv_bias, const void *rel_h, const void *rel_w,
                                   int B, int H, int W, int num_heads, int head_dim, int window, float scale,
                                   void *rel_scratch, void *out, void *stream);
+/* The same with the padded table copies made ahead of time: s6d_win_attention_pad_rel_bf16 writes them (s6d_win_attention_scratch_bytes
+ * bytes) from rel_h / rel_w once per weight version, s6d_win_attention_prepadded_bf16 is s6d_win_attention_layout_bf16 reading them --
+ * no padding launch in front of every attention launch. */
+int s6d_win_attention_pad_rel_bf16(const void *rel_h, const void *rel_w, int H, int window, int head_dim, void *rel_padded, void *stream);
+int s6d_win_attention_prepadded_bf16(const void *qkv, int head_major, const void *qkv_bias, const void *rel_padded, int B, int H, int W,
+                                     int num_heads, int head_dim, int window, float scale, void *out, void *stream);
 /* bytes of `rel_scratch` (zero-padded copies of the two tables; may be NULL when rel_h == NULL) */
 long s6d_win_attention_scratch_bytes(int H, int window, int head_dim);
 

@@ -1940,9 +1940,12 @@ extern "C" int s6d_win_attention_bf16(const void *qkv, const void *qkv_bias, con
                                        stream);
 }
 
-extern "C" int s6d_win_attention_layout_bf16(const void *qkv, int head_major, const void *qkv_bias, const void *rel_h, const void *rel_w,
-                                             int B, int H, int W, int num_heads, int head_dim, int window, float scale,
-                                             void *rel_scratch, void *out, void *stream) {
+// prepadded != 0: rel_scratch already holds the padded tables (s6d_win_attention_pad_rel_bf16, made once per weight version: the
+// padding is a function of the two weight tables only and ran as a 5-us launch in front of every one of the 64 attention launches
+// of a step); rel_h / rel_w are then only tested for presence.
+static int win_attention_impl(const void *qkv, int head_major, const void *qkv_bias, const void *rel_h, const void *rel_w,
+                              int B, int H, int W, int num_heads, int head_dim, int window, float scale,
+                              void *rel_scratch, int prepadded, void *out, void *stream) {
   if (B < 0 || H <= 0 || W <= 0 || num_heads <= 0 || window < 0) return S6D_EINVAL;
   if (B == 0) return S6D_OK;
   if (!qkv || !qkv_bias || !out || ((rel_h == nullptr) != (rel_w == nullptr))) return S6D_EINVAL;
@@ -1968,8 +1971,9 @@ extern "C" int s6d_win_attention_layout_bf16(const void *qkv, int head_major, co
   if (rel_h) {                                   // zero-padded table copies: unconditional loads in the kernels
     if (!rel_scratch) return S6D_EINVAL;
     const int HDP = (head_dim + 31) / 32 * 32, rows = p.LT + 16;
-    hipLaunchKernelGGL(pad_rel_kernel, dim3(16), dim3(256), 0, st, p.rel_h, p.rel_w, 2 * p.S - 1, head_dim, HDP, rows,
-                       (u16 *)rel_scratch);
+    if (!prepadded)
+      hipLaunchKernelGGL(pad_rel_kernel, dim3(16), dim3(256), 0, st, p.rel_h, p.rel_w, 2 * p.S - 1, head_dim, HDP, rows,
+                         (u16 *)rel_scratch);
     p.rel_h = (const u16 *)rel_scratch;
     p.rel_w = p.rel_h + (size_t)rows * HDP;
   }
@@ -1978,6 +1982,29 @@ extern "C" int s6d_win_attention_layout_bf16(const void *qkv, int head_major, co
     case 64: return launch_attn<64>(p, st);
     default: return S6D_EUNSUPPORTED;
   }
+}
+
+extern "C" int s6d_win_attention_layout_bf16(const void *qkv, int head_major, const void *qkv_bias, const void *rel_h, const void *rel_w,
+                                             int B, int H, int W, int num_heads, int head_dim, int window, float scale,
+                                             void *rel_scratch, void *out, void *stream) {
+  return win_attention_impl(qkv, head_major, qkv_bias, rel_h, rel_w, B, H, W, num_heads, head_dim, window, scale, rel_scratch, 0, out, stream);
+}
+
+extern "C" int s6d_win_attention_pad_rel_bf16(const void *rel_h, const void *rel_w, int H, int window, int head_dim, void *rel_padded,
+                                              void *stream) {
+  if (!rel_h || !rel_w || !rel_padded || H <= 0 || window < 0 || head_dim <= 0) return S6D_EINVAL;
+  const int S = window ? window : H, LT = ((2 * S - 1) + 15) / 16 * 16;
+  const int HDP = (head_dim + 31) / 32 * 32, rows = LT + 16;
+  hipLaunchKernelGGL(pad_rel_kernel, dim3(16), dim3(256), 0, as_stream(stream), (const u16 *)rel_h, (const u16 *)rel_w, 2 * S - 1, head_dim,
+                     HDP, rows, (u16 *)rel_padded);
+  return launch_status();
+}
+
+extern "C" int s6d_win_attention_prepadded_bf16(const void *qkv, int head_major, const void *qkv_bias, const void *rel_padded, int B, int H,
+                                                int W, int num_heads, int head_dim, int window, float scale, void *out, void *stream) {
+  if (!rel_padded) return S6D_EINVAL;
+  return win_attention_impl(qkv, head_major, qkv_bias, rel_padded, rel_padded, B, H, W, num_heads, head_dim, window, scale,
+                            const_cast<void *>(rel_padded), 1, out, stream);
 }
 
 #endif  // !S6D_ATTN_F16

@@ -652,6 +652,26 @@ def upsample_gather(up, choose, H, W, C):
 
 
 # ------------------------------------------------------------------ SAM image encoder
+_REL_PAD = {}
+
+
+def _padded_rel(rel_h, rel_w, H, window, hd):
+    """The zero-padded copies of a (rel_h, rel_w) table pair in the layout the attention kernels read (s6d_win_attention_pad_rel_bf16),
+    cached on the identity and version of the two tensors (the modules hand in their own cached bf16 tables)."""
+    key = (id(rel_h), id(rel_w), H, window, hd)
+    c = _REL_PAD.get(key)
+    if c is None or c[0] is not rel_h or c[1] is not rel_w or c[2] != (rel_h._version, rel_w._version):
+        fn = _lib.lib().s6d_win_attention_scratch_bytes
+        fn.restype = ctypes.c_long
+        pad = torch.empty(int(fn(H, window, hd)), dtype=torch.uint8, device=rel_h.device)
+        _call("s6d_win_attention_pad_rel_bf16", _ptr(rel_h), _ptr(rel_w), H, window, hd, _ptr(pad), _stream())
+        if len(_REL_PAD) > 256:
+            _REL_PAD.clear()
+        c = (rel_h, rel_w, (rel_h._version, rel_w._version), pad)
+        _REL_PAD[key] = c
+    return c[3]
+
+
 def window_attention(qkv, qkv_bias, rel_h, rel_w, num_heads, window, scale, head_major_shape=None):
     """qkv (B,H,W,3C) bf16, qkv_bias (3C) bf16, rel_h/rel_w (2S-1,hd) bf16 or None -> (B,H,W,C) bf16.
     head_major_shape=(B,H,W): qkv is the head-major tensor (3*num_heads, B*H*W, hd) that gemm_bf16(..., col_block=hd) writes."""
@@ -675,14 +695,15 @@ def window_attention(qkv, qkv_bias, rel_h, rel_w, num_heads, window, scale, head
         if rel_h.shape != (2 * S - 1, hd) or rel_w.shape != (2 * S - 1, hd):
             raise RuntimeError("rel_pos tables must be (2S-1, head_dim)")
     out = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=qkv.device)
-    scratch = None
     if rel_h is not None:
-        fn = _lib.lib().s6d_win_attention_scratch_bytes
-        fn.restype = ctypes.c_long
-        scratch = torch.empty(int(fn(H, int(window), int(hd))), dtype=torch.uint8, device=qkv.device)
-    _call("s6d_win_attention_layout_bf16", _ptr(qkv), 0 if head_major_shape is None else 1, _ptr(qkv_bias),
-          _ptr(rel_h) if rel_h is not None else _vp(0), _ptr(rel_w) if rel_w is not None else _vp(0), B, H, W, int(num_heads), int(hd),
-          int(window), ctypes.c_float(scale), _ptr(scratch) if scratch is not None else _vp(0), _ptr(out), _stream())
+        # the padded copies of the two tables the kernels read are a function of the tables only: made once per (table pair, grid,
+        # window) and kept (round 6: the padding ran as a 5-us launch in front of each of the 64 attention launches of a step)
+        _call("s6d_win_attention_prepadded_bf16", _ptr(qkv), 0 if head_major_shape is None else 1, _ptr(qkv_bias),
+              _ptr(_padded_rel(rel_h, rel_w, H, int(window), int(hd))), B, H, W, int(num_heads), int(hd), int(window), ctypes.c_float(scale),
+              _ptr(out), _stream())
+        return out
+    _call("s6d_win_attention_layout_bf16", _ptr(qkv), 0 if head_major_shape is None else 1, _ptr(qkv_bias), _vp(0), _vp(0), B, H, W,
+          int(num_heads), int(hd), int(window), ctypes.c_float(scale), _vp(0), _ptr(out), _stream())
     return out
 
 

@@ -102,14 +102,16 @@ def _run_late(cases):
 
 
 def test_window_attention_retry_rounds_on_the_emulator(emu):
-    T.test_window_attention_when_scores_outgrow_the_first_key_rows(30.0)
-    T.test_window_attention_when_scores_outgrow_the_first_key_rows(2.0)
+    T.test_window_attention_when_scores_outgrow_the_first_key_rows(30.0, 1.0)
+    T.test_window_attention_when_scores_outgrow_the_first_key_rows(2.0, 1.0)
+    T.test_window_attention_when_scores_outgrow_the_first_key_rows(2.0, 2.0 ** 50)      # non-finite accumulators under an in-range row sum
 
 
 def test_global_attention_fallback_on_the_emulator(emu):
     """Scores that outgrow the first tile's maximum: exp2 overflow -> the workgroup's second pass (30), large finite P (2)."""
-    T.test_global_attention_when_scores_outgrow_the_first_tile(80, 30.0)
-    T.test_global_attention_when_scores_outgrow_the_first_tile(80, 2.0)
+    T.test_global_attention_when_scores_outgrow_the_first_tile(80, 30.0, 1.0)
+    T.test_global_attention_when_scores_outgrow_the_first_tile(80, 2.0, 1.0)
+    T.test_global_attention_when_scores_outgrow_the_first_tile(80, 2.0, 2.0 ** 50)
 
 
 def test_lds_dma_attention_kernels_under_the_late_completion_model():

@@ -184,9 +184,10 @@ def test_smallest_k_and_hypothesis_select_vs_library(ops):
     assert torch.equal(R, Rk[torch.arange(B), best]) and torch.equal(t, tk[torch.arange(B), best])
 
 
-@pytest.mark.parametrize("N,P", [(196, 300), (2048, 1)])
-def test_min_dist_vs_oracle(ops, N, P):
-    B, Nm = 2, 1024
+@pytest.mark.parametrize("N,P,Nm", [(196, 300, 1024), (2048, 1, 1024), (70, 3, 1021), (33, 2, 5)])
+def test_min_dist_vs_oracle(ops, N, P, Nm=1024):
+    """(the model cloud is read four points per trip since round 6: 1021 and 5 points exercise the padded tail)"""
+    B = 2
     g = torch.Generator().manual_seed(N)
     pts = torch.randn(B, N, 3, generator=g)
     model = torch.randn(B, Nm, 3, generator=g)

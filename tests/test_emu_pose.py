@@ -19,7 +19,7 @@ def test_half_stored_geo_embedding_on_the_emulator(emu):
 
 
 def test_min_dist_on_the_emulator(emu):
-    T.test_min_dist_vs_oracle(emu, 196, 3)
+    T.test_min_dist_vs_oracle(emu, 196, 3, 1024)
     T.test_min_dist_vs_oracle(emu, 33, 2, 5)                            # a model cloud that is not a multiple of four points
 
 

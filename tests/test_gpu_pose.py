@@ -185,7 +185,7 @@ def test_smallest_k_and_hypothesis_select_vs_library(ops):
 
 
 @pytest.mark.parametrize("N,P,Nm", [(196, 300, 1024), (2048, 1, 1024), (70, 3, 1021), (33, 2, 5)])
-def test_min_dist_vs_oracle(ops, N, P, Nm=1024):
+def test_min_dist_vs_oracle(ops, N, P, Nm):
     """(the model cloud is read four points per trip since round 6: 1021 and 5 points exercise the padded tail)"""
     B = 2
     g = torch.Generator().manual_seed(N)

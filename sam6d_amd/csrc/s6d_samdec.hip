@@ -36,7 +36,19 @@ constexpr int kSdC = 256;        // embedding dim
 constexpr int kSdD = 128;        // internal dim of the cross attentions (downsample rate 2)
 constexpr int kSdJ = 64;         // (head, token slot) pairs: 8 heads x 8 slots
 constexpr int kSdKRow = kSdD + 8;   // LDS row stride of the expanded keys (bf16): 272 B, conflict-free b128 reads
-constexpr int kSdVRow = kSdJ + 8;   // LDS row stride of the folded values (bf16): 144 B
+#ifndef S6D_SD_LDSFIX
+#define S6D_SD_LDSFIX 1             // 0: the LDS layouts before round 6's conflict fixes (same-box A/B builds)
+#endif
+constexpr int kSdVRow = S6D_SD_LDSFIX ? kSdJ + 4 : kSdJ + 8;   // LDS row stride of the folded values (bf16): 136 B = 34 dwords -- sixteen consecutive rows start on
+                                    // sixteen distinct even banks of the 32 a ds_read2_b64 access sees (round 6: with 144-byte rows
+                                    // rows r and r + 8 met, and the permuted channel order of the same round made it four rows:
+                                    // SQ_LDS_BANK_CONFLICT was 235 M of the kernel's 407 M LDS cycles per 1024 prompts; now 0, at
+                                    // unchanged time: profiles/r06_samdec_ab.md)
+// Fragment reads by ds_read_b128 from rows that are an ODD number of 16-byte slots long: a lane group is {rows 0-3, 12-15 at chunk g}
+// + {rows 4-11 at chunk g + 1} (MI355X_MICROARCH.md, LDS), which meet on one slot (row 11's chunk g + 1 = row 12's chunk g); rows
+// 4-11 therefore keep their chunk pairs swapped -- written and read at chunk ^ sd_kswz(row) (the swizzle of csrc/s6d_geo.hip /
+// s6d_attn.hip, round 6 here: one extra LDS cycle per group on every K / W fragment read of the three kernels below).
+__device__ __forceinline__ int sd_kswz(int row) { return S6D_SD_LDSFIX ? ((row >> 2) ^ (row >> 3)) & 1 : 0; }
 
 // q (Bq,N,128) bf16 with row stride q_ld (+ q_add (N,128) bf16 or null), kexp (B,64,128) bf16: row j = h*8+t holds scale * k_t in the 16
 // columns of head h, zeros elsewhere; vpt (B,256,64) bf16: vpt[n][j] = (v_t W_o^T)[n] restricted to head h;
@@ -57,9 +69,13 @@ __global__ __launch_bounds__(256, 2) void img2tok_kernel(const u16 *__restrict__
   // tile for token c.  With channel = 16 nt + i a lane's four values of a tile were 8 bytes and a store / residual-load instruction
   // touched 32 contiguous bytes per token.  Feeding the value rows in the order chan(nt, i) = 32 (nt / 2) + 8 (i / 4) + 4 (nt % 2) + i % 4
   // makes the four values of tiles 2 p and 2 p + 1 eight consecutive channels: one 16-byte access per lane and tile pair, 64
-  // contiguous bytes per token and instruction (half the instructions, twice the run length).  Per channel the arithmetic is
+  // contiguous bytes per token and instruction (half the instructions, twice the run length; same-box A/B: no difference in time,
+  // profiles/r06_samdec_ab.md).  Per channel the arithmetic is
   // unchanged; the LayerNorm's per-lane partial sums run over another 64 channels, so the result can differ in the last float32 bit.
-  auto chan = [](int nt, int i) { return 32 * (nt >> 1) + 8 * (i >> 2) + 4 * (nt & 1) + (i & 3); };
+#ifndef S6D_SD_CHANPERM
+#define S6D_SD_CHANPERM 1            // 0: channel = 16 nt + i with 8-byte residual loads / stores (rounds 2-5; same-box A/B builds)
+#endif
+  auto chan = [](int nt, int i) { return S6D_SD_CHANPERM ? 32 * (nt >> 1) + 8 * (i >> 2) + 4 * (nt & 1) + (i & 3) : 16 * nt + i; };
   extern __shared__ __attribute__((aligned(16))) char sd_smem[];
   u16 *Kl = reinterpret_cast<u16 *>(sd_smem);                       // [64][KROWL]
   u16 *Vl = Kl + kSdJ * KROWL;                                      // [256][kSdVRow]
@@ -68,13 +84,17 @@ __global__ __launch_bounds__(256, 2) void img2tok_kernel(const u16 *__restrict__
   const int c = lane & 15, g = lane >> 4;
   for (int i = tid; i < kSdJ * KD / 8; i += 256) {                  // 16-byte chunks
     const int row = i / (KD / 8), ch = i - row * (KD / 8);
-    *reinterpret_cast<uint4 *>(Kl + row * KROWL + ch * 8) =
+    *reinterpret_cast<uint4 *>(Kl + row * KROWL + (ch ^ sd_kswz(row)) * 8) =
         *reinterpret_cast<const uint4 *>(kexp + ((size_t)b * kSdJ + row) * KD + ch * 8);
   }
   for (int i = tid; i < kSdC * kSdJ / 8; i += 256) {
     const int row = i / (kSdJ / 8), ch = i - row * (kSdJ / 8);
-    *reinterpret_cast<uint4 *>(Vl + row * kSdVRow + ch * 8) =
-        *reinterpret_cast<const uint4 *>(vpt + ((size_t)b * kSdC + row) * kSdJ + ch * 8);
+    // channel `row` goes to LDS row rho(row) = the position at which the value product reads it: tile nt = 2 (row / 32) + (row / 4 & 1),
+    // row-in-tile i = 4 (row / 8 & 3) + row % 4 (the inverse of chan() below), so that a fragment read walks 16 CONSECUTIVE LDS rows
+    const int rem = row & 31, lrow = (S6D_SD_LDSFIX && S6D_SD_CHANPERM) ? (2 * (row >> 5) + ((rem >> 2) & 1)) * 16 + 4 * (rem >> 3) + (rem & 3) : row;
+    const uint4 v = *reinterpret_cast<const uint4 *>(vpt + ((size_t)b * kSdC + row) * kSdJ + ch * 8);
+    *reinterpret_cast<uint2 *>(Vl + lrow * kSdVRow + ch * 8) = make_uint2(v.x, v.y);          // (136-byte rows: 8-byte aligned pieces)
+    *reinterpret_cast<uint2 *>(Vl + lrow * kSdVRow + ch * 8 + 4) = make_uint2(v.z, v.w);
   }
   pl[tid] = obias[tid];
   pl[256 + tid] = gamma[tid];
@@ -115,7 +135,15 @@ __global__ __launch_bounds__(256, 2) void img2tok_kernel(const u16 *__restrict__
     union RR { uint4 u; u16 h[8]; };
     RR rr[8];                                                        // residual rows of this strip (tile pair p: channels 32 p + 8 g .. + 8), first used in the epilogue
 #pragma unroll
-    for (int pp = 0; pp < 8; ++pp) rr[pp].u = *reinterpret_cast<const uint4 *>(rb + (size_t)tok * kSdC + pp * 32 + g * 8);
+    for (int pp = 0; pp < 8; ++pp) {
+      if (S6D_SD_CHANPERM) {
+        rr[pp].u = *reinterpret_cast<const uint4 *>(rb + (size_t)tok * kSdC + pp * 32 + g * 8);
+      } else {                                                       // tiles 2 pp, 2 pp + 1: channels 16 nt + 4 g .. + 4, 8 bytes each
+        const uint2 a = *reinterpret_cast<const uint2 *>(rb + (size_t)tok * kSdC + (2 * pp) * 16 + g * 4);
+        const uint2 b2 = *reinterpret_cast<const uint2 *>(rb + (size_t)tok * kSdC + (2 * pp + 1) * 16 + g * 4);
+        rr[pp].u = make_uint4(a.x, a.y, b2.x, b2.y);
+      }
+    }
     // ---- scores^T (64 x 16) = Kexp (64 x KD) . Q^T ------------------------------------------------------------
     sd_f32x4 s[4];
 #pragma unroll
@@ -127,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void img2tok_kernel(const u16 *__restrict__
     for (int ks = 0; ks < KSN; ++ks) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const sd_bf16x8 ka = *reinterpret_cast<const sd_bf16x8 *>(Kl + (t * 16 + c) * KROWL + ks * 32 + g * 8);
+        const sd_bf16x8 ka = *reinterpret_cast<const sd_bf16x8 *>(Kl + (t * 16 + c) * KROWL + ((ks * 4 + g) ^ sd_kswz(c)) * 8);
         s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qa[ks].v, s[t], 0, 0, 0);
       }
     }
@@ -165,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void img2tok_kernel(const u16 *__restrict__
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         union { sd_bf16x8 v; uint2 d[2]; } va;
-        const u16 *vr = Vl + chan(nt, c) * kSdVRow + ks * 32 + g * 4;
+        const u16 *vr = Vl + ((S6D_SD_LDSFIX || !S6D_SD_CHANPERM) ? nt * 16 + c : chan(nt, c)) * kSdVRow + ks * 32 + g * 4;      // LDS row nt * 16 + c holds channel chan(nt, c)
         va.d[0] = *reinterpret_cast<const uint2 *>(vr);
         va.d[1] = *reinterpret_cast<const uint2 *>(vr + 16);
         o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va.v, pb[ks].v, o[nt], 0, 0, 0);
@@ -203,10 +231,15 @@ __global__ __launch_bounds__(256, 2) void img2tok_kernel(const u16 *__restrict__
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int nt = 2 * pp + (e >> 2), r = e & 3;
-        const int n = pp * 32 + g * 8 + e;                           // = chan(nt, 4 g + r)
+        const int n = chan(nt, 4 * g + r);                           // (permuted: = pp * 32 + g * 8 + e)
         w.h[e] = sd_f2bf((o[nt][r] - mean) * rstd * pl[256 + n] + pl[512 + n]);
       }
-      *reinterpret_cast<uint4 *>(ob + (size_t)tok * kSdC + pp * 32 + g * 8) = w.u;
+      if (S6D_SD_CHANPERM) {
+        *reinterpret_cast<uint4 *>(ob + (size_t)tok * kSdC + pp * 32 + g * 8) = w.u;
+      } else {
+        *reinterpret_cast<uint2 *>(ob + (size_t)tok * kSdC + (2 * pp) * 16 + g * 4) = make_uint2(w.u.x, w.u.y);
+        *reinterpret_cast<uint2 *>(ob + (size_t)tok * kSdC + (2 * pp + 1) * 16 + g * 4) = make_uint2(w.u.z, w.u.w);
+      }
     }
   }
 }
@@ -231,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void upscale_heads_kernel(const u16 *__rest
   const int N = h * w;
   for (int i = tid; i < 4 * kUpC2 * kUpC1 / 8; i += 256) {
     const int row = i / (kUpC1 / 8), ch = i - row * (kUpC1 / 8);
-    *reinterpret_cast<uint4 *>(Wl + row * kUpWRow + ch * 8) = *reinterpret_cast<const uint4 *>(w2t + row * kUpC1 + ch * 8);
+    *reinterpret_cast<uint4 *>(Wl + row * kUpWRow + (ch ^ sd_kswz(row)) * 8) = *reinterpret_cast<const uint4 *>(w2t + row * kUpC1 + ch * 8);
   }
   if (tid < 4 * kUpC2) hy[tid] = (tid < M * kUpC2) ? hyper[(size_t)b * M * kUpC2 + tid] : 0.f;
   if (tid < kUpC1) { lw[tid] = ln_w[tid]; lb[tid] = ln_b[tid]; }
@@ -325,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void upscale_heads_kernel(const u16 *__rest
         sd_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          const sd_bf16x8 wa = *reinterpret_cast<const sd_bf16x8 *>(Wl + (nt * 16 + c) * kUpWRow + ks * 32 + g * 8);
+          const sd_bf16x8 wa = *reinterpret_cast<const sd_bf16x8 *>(Wl + (nt * 16 + c) * kUpWRow + ((ks * 4 + g) ^ sd_kswz(c)) * 8);
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, ua[ks].v, acc, 0, 0, 0);
         }
         // C layout: row n_local = g*4 + r -> ch = half*16 + g*4 + r, col = token c
@@ -526,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void tok2img_raw_kernel(const u16 *__restri
 #pragma unroll
         for (int k = 0; k < 8; ++k) a.h[k] = sd_f2bf(sd_bf2f(a.h[k]) + sd_bf2f(e.h[k]));
       }
-      *reinterpret_cast<uint4 *>(Kl + tk * kT2RKRow + ch * 8) = a.u;
+      *reinterpret_cast<uint4 *>(Kl + tk * kT2RKRow + (ch ^ sd_kswz(tk)) * 8) = a.u;
     }
   };
   float m_run = -1e30f;
@@ -548,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void tok2img_raw_kernel(const u16 *__restri
       sd_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        const sd_bf16x8 ka = *reinterpret_cast<const sd_bf16x8 *>(Kl + (sub * 16 + c) * kT2RKRow + ks * 32 + g * 8);
+        const sd_bf16x8 ka = *reinterpret_cast<const sd_bf16x8 *>(Kl + (sub * 16 + c) * kT2RKRow + ((ks * 4 + g) ^ sd_kswz(c)) * 8);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[ks], acc, 0, 0, 0);
       }
 #pragma unroll

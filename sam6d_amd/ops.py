@@ -1340,7 +1340,7 @@ def have(name):
                "glb_attention": "s6d_glb_attention_bf16", "pairwise_cosine": "s6d_pairwise_cosine_f32",
                "patch_scores": "s6d_patch_scores_sel_f32", "pose_hypotheses": "s6d_pose_hypotheses_f32",
                "pe_group": "s6d_pe_group_mlp_f32", "masked_depth_mean": "s6d_masked_depth_mean_sel_f32",
-               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "im2col3x3": "s6d_im2col3x3_b16", "nonfinite_rows": "s6d_nonfinite_rows_f32", "patchify": "s6d_patchify_b16", "crop_resize_pad": "s6d_crop_resize_pad_f32", "samdec_img2tok": "s6d_samdec_img2tok_bf16", "samdec_img2tok_raw": "s6d_samdec_img2tok_raw_bf16", "samdec_tok2img": "s6d_samdec_tok2img_f32", "samdec_tok2img_raw": "s6d_samdec_tok2img_raw_bf16", "sam_mask_post": "s6d_sam_mask_post_sel_f32", "gemm_fp8_mx": "s6d_gemm_fp8_mxa", "nms": "s6d_nms_f32", "samdec_upscale_heads": "s6d_samdec_upscale_heads_bf16", "samdec_tokens": "s6d_samdec_tokens_post_bf16", "mha": "s6d_mha_f32",
+               "semantic_select": "s6d_semantic_select_f32", "seq_attention": "s6d_seq_attention_bf16", "sam_preprocess": "s6d_sam_preprocess_f32", "im2col3x3": "s6d_im2col3x3_b16", "nonfinite_rows": "s6d_nonfinite_rows_f32", "patchify": "s6d_patchify_b16", "crop_resize_pad": "s6d_crop_resize_pad_f32", "samdec_img2tok": "s6d_samdec_img2tok_bf16", "samdec_img2tok_raw": "s6d_samdec_img2tok_raw_bf16", "samdec_tok2img": "s6d_samdec_tok2img_f32", "samdec_tok2img_raw": "s6d_samdec_tok2img_raw_bf16", "sam_mask_post": "s6d_sam_mask_post_sel_f32", "gemm_fp8_mx": "s6d_gemm_fp8_mxa", "nms": "s6d_nms_f32", "samdec_upscale_heads": "s6d_samdec_upscale_heads_bf16", "samdec_tokens": "s6d_samdec_tokens_post_bf16", "samdec_token_folds": "s6d_samdec_tokens_post_bf16", "mha": "s6d_mha_f32",
                "linear_attn_focus": "s6d_linear_attn_focus_f32", "linear_attention": "s6d_linear_attention_f32", "project_bbox": "s6d_project_bbox_frames_f32"}.get(name)
         _FUSED[name] = sym is not None and hasattr(_lib.lib(), sym)
     # (policy.disable_fused: kernel names the modules must not use -- the tests' way of forcing the library statement)

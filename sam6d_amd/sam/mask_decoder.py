@@ -449,7 +449,7 @@ class MaskDecoder(nn.Module):
             lw, nw, fw = self._token_weights(li)
             ca = L.cross_attn_token_to_image
             with torch.autocast(device_type="cuda", enabled=False):
-                if x is not None and ops.have("samdec_tok2img_raw"):
+                if x is not None and ops.have("samdec_tok2img_raw") and ops.have("samdec_token_folds"):    # (S6D_DISABLE_FUSED=samdec_token_folds: A/B)
                     sc = 1.4426950408889634 / math.sqrt(ca.internal_dim // ca.num_heads)
                     q1, qfold = ops.samdec_tokens_pre(queries, tokens, not L.skip_first_layer_pe, lw[0], lw[1], lw[2], lw[3], nw[0], lw[4],
                                                       fold=(fw["wk"], sc))

@@ -1,5 +1,5 @@
 import json, re
-p='/root/repo/DESIGN.md'
+p='/root/repo/DESIGN.md'   # (regenerates sections 4 and 5 of DESIGN.md from profiles/r06_bench_line.json: python tools/design_tables.py)
 s=open(p).read()
 d=json.loads(open('/root/repo/profiles/r06_bench_line.json').read().strip().splitlines()[-1])
 K={k['kernel'].split(' ')[0]+('|'+k['pmc_key'] if k.get('pmc_key') else ''): k for k in d['kernels']}
@@ -43,7 +43,7 @@ bf16 products = 0.56 of the nominal figure, at ≈ 1.7 – 2.0 GHz under the pow
 | `pe_group_mlp_kernel` (s6d_pe) | a19 | MFMA 3-term bf16 | 43.7 / 87.3 GFLOP as written (ns = 32 / 64) | 0.24 / 0.36 ms (2 + 2) | 0.22 / 0.30 executed |
 | `fine_split + 3 × fine_sweep_kernel` (s6d_fine) | a22–a23 | MFMA 3-term | 618 GFLOP executed; 4.2 MB / instance | {fine['avg_ms']:.3f} ms (1) | {fine['frac']:.3f} |
 | `samtok_pre / samtok_post_kernel` (s6d_samtok, **round 6**) | f2 | latency / L2 | the sparse-token side of a TwoWayAttentionBlock for 1024 prompts × 7 tokens: 2.9 MB of weights per layer streamed from L2 per 4-prompt workgroup | 25 / 108 µs per launch (2 + 2 per frame), the per-head folds around the attention cores included | replaces ≈ 380 library launches per frame |
-| `img2tok_kernel<RAW>` (s6d_samdec) | f2 | HBM | 2.1 GB read + 2.1 GB written per 1024 prompts | 1.44 ms (was 1.68: 16-byte accesses, round 6) | 0.37 of HBM |
+| `img2tok_kernel<RAW>` (s6d_samdec) | f2 | HBM | 2.1 GB read + 2.1 GB written per 1024 prompts | 1.44 – 1.68 ms by box | 0.32 – 0.37 of HBM; LDS conflicts 235 M → 0 this round at unchanged time (`profiles/r06_samdec_ab.md`) |
 | everything else (a1, a6–a13, a17–a19, f-1 … f-4) | | HBM / latency | see `docs/NOTEBOOK_r1_r4.md` §4 | < 1 % of the step each | |
 
 Stage roofline: SAM ViT-H encoder 5.96 TFLOP × 32 frames in {st['sam_encoder']:.1f} ms = {5.96*32/st['sam_encoder']*1e3:.0f} TFLOP/s = **{5.96*32/st['sam_encoder']/2.5:.3f}** of the nominal peak
@@ -95,11 +95,14 @@ Stage roofline: SAM ViT-H encoder 5.96 TFLOP × 32 frames in {st['sam_encoder']:
   ≈ 1 ms of device time in small operators (the final attention, the hypernetwork MLPs, the prompt encoder, the candidate
   filter: `tools/probes/proposals_ops.py`).  The ask's ≤ 9 ms / ≤ 150 launches is not reached: five streaming kernels over the
   1024 × 4096 × 256 per-prompt token tensor are 9.0 of the 10.5 ms.
-* *`img2tok_kernel`: 16-byte accesses.*  In the accumulator layout a lane held 4 consecutive channels per value tile (8-byte residual
-  loads and stores, 32 contiguous bytes per token and instruction); feeding the value rows in a permuted order gives it 8 consecutive
-  channels per tile pair: 1.675 → 1.440 ms (layer 1) and 1.191 → 1.123 ms (layer 0) per 1024 prompts.  The same regrouping of
-  `upscale_heads_kernel`'s stores (4 × 4 pixel blocks as 16-byte stores) changed nothing (1.73 → 1.76 ms: 3.2 G exact-erf GELU
-  evaluations bind it) and was not kept.
+* *`img2tok_kernel`: 16-byte accesses and LDS conflict fixes — built, counters clean, time unchanged.*  In the accumulator layout a
+  lane held 4 consecutive channels per value tile (8-byte residual loads and stores); a permuted value-row order gives it 8 per tile
+  pair (16-byte accesses, 64 contiguous bytes per token and instruction).  The value fragments are read by `ds_read2_b64`, which
+  banks modulo 32: 136-byte rows in fragment order + the chunk swizzle of the key rows take `SQ_LDS_BANK_CONFLICT` from 235 M (of
+  407 M LDS cycles) to 0 per 1024 prompts, `tok2img_raw_kernel` 33.6 M → 0, `upscale_heads_kernel` 29 M → 12.6 M.  Same-box A/Bs
+  (`profiles/r06_samdec_ab.md`): no difference in time for either change — an intermediate commit's "1.675 → 1.440 ms" compared two
+  `gpurun` calls, i.e. two boxes (± 7 % on these kernels), and is withdrawn.  What the same-box A/Bs do show: the token kernels are
+  worth 1.1 ms per frame, 0.45 ms of it the folds.
 * *`transform_min_dist_kernel`* (the coarse stage's 300 hypotheses × 196 points × 1024 model points per instance): the loop over an
   (x, y, z)-interleaved LDS array compiled to ≈ 10 instructions per point; coordinate arrays + four points per trip on packed fp32
   instructions + `v_min3_f32`: 4.25 per point, the same bits, **0.47 → 0.15 ms** per call at 32 instances.  *Padded rel-pos tables*

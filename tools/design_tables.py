@@ -105,7 +105,8 @@ Stage roofline: SAM ViT-H encoder 5.96 TFLOP × 32 frames in {st['sam_encoder']:
   worth 1.1 ms per frame, 0.45 ms of it the folds.
 * *`transform_min_dist_kernel`* (the coarse stage's 300 hypotheses × 196 points × 1024 model points per instance): the loop over an
   (x, y, z)-interleaved LDS array compiled to ≈ 10 instructions per point; coordinate arrays + four points per trip on packed fp32
-  instructions + `v_min3_f32`: 4.25 per point, the same bits, **0.47 → 0.15 ms** per call at 32 instances.  *Padded rel-pos tables*
+  instructions + `v_min3_f32`: 4.25 per point, the same bits, **0.47 → 0.15 ms** per call at 32 instances (two `gpurun` calls; the
+  change is 3×, the instruction count per point 2.4×).  *Padded rel-pos tables*
   of the SAM attention: made once per table pair instead of by a 5-µs launch in front of each of the 64 attention launches of a step.
 * *Attention range guard* (ADVICE r5): a non-finite O^T accumulator triggers the second pass / raised reference as well as a row sum
   ≥ 2^100 (|V| = 2^50 under P up to 2^90 in `tests/test_gpu_attn.py`); lowering the sum limit to 2^60 instead sent the probe's

@@ -42,6 +42,10 @@ int s6d_set_persistent_grid_limit(int max_workgroups);
  * four-wave form wherever it applies (bf16 / f16, N % 256 == 0, M % 256 == 0, K >= 128).  Both forms give the same bits (the same products in the same order per
  * accumulator); the switch exists for A/B measurements and the parity tests.  Process-wide; returns S6D_EINVAL for other values. */
 int s6d_set_gemm_wave_tile(int columns);
+/* 1 (default): a plain or GELU bf16 / f16 GEMM launch that would put fewer than 160 tiles of 256 x 256 on the chip takes the 256 x 128
+ * tile kernel (two independent workgroups per CU) -- the PEM ViT-B's 6304 x 768 products are 75 tiles otherwise.  0: always the
+ * 256 x 256 kernel.  The same products in the same order per element: the same bits.  Process-wide; other values: S6D_EINVAL. */
+int s6d_set_gemm_small_tile(int enable);
 const char *s6d_strerror(int code);
 /* last HIP error string seen by this thread (empty if none) */
 const char *s6d_last_hip_error(void);

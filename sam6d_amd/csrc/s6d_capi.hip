@@ -33,6 +33,16 @@ extern "C" int s6d_set_gemm_wave_tile(int columns) {
   return S6D_OK;
 }
 
+// 256 x 128 tiles for the plain / GELU GEMM launches that would leave most CUs idle (include/sam6d_hip.h: s6d_set_gemm_small_tile).
+namespace s6d {
+int g_s6d_gemm_small_tile = 1;
+}
+extern "C" int s6d_set_gemm_small_tile(int enable) {
+  if (enable != 0 && enable != 1) return S6D_EINVAL;
+  s6d::g_s6d_gemm_small_tile = enable;
+  return S6D_OK;
+}
+
 extern "C" int s6d_version(void) { return S6D_ABI_VERSION; }
 
 extern "C" const char *s6d_last_hip_error(void) { return s6d::g_hip_err; }

@@ -910,7 +910,10 @@ __global__ void __launch_bounds__(512, 2) gemm_f16_kernel(GemmParams p) {
 //   * per K tile: [counted wait + barrier: the K tile has landed] -> ALL fragments of the K tile into registers (24 ds_read_b128,
 //     96 VGPRs) -> [barrier: its three slots are free] -> the next three stream elements are issued (12 pieces per wave, between
 //     the MFMAs) -> 32 MFMAs from registers.  The stream therefore stays 5 slots = 1.67 K tiles ahead of the matrix work.
-template <int EPI, bool HAS_BIAS>
+// DT (round 6): 0 = bf16, 2 = IEEE half operands and output (as gemm_body's).  Besides N % 256 == 128 this kernel now also serves the
+// plain / GELU launches whose 256 x 256 tiling would leave most CUs idle (gemm_launch: fewer than 160 tiles, e.g. the PEM ViT-B's
+// 6304 x 768 products: 75 tiles -> 150): half the work per tile, twice the tiles, the same products in the same order per element.
+template <int EPI, bool HAS_BIAS, int DT = 0>
 __global__ void __launch_bounds__(256, 2) gemm2_bf16_kernel(GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1027,8 +1030,8 @@ __global__ void __launch_bounds__(256, 2) gemm2_bf16_kernel(GemmParams p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * qd + e];
           if (EPI == 1) gelu_erf4(v);
-          pk[qd][0] = pack_bf16(v[0], v[1]);
-          pk[qd][1] = pack_bf16(v[2], v[3]);
+          pk[qd][0] = pack_out<DT>(v[0], v[1]);
+          pk[qd][1] = pack_out<DT>(v[2], v[3]);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -1088,7 +1091,10 @@ __global__ void __launch_bounds__(256, 2) gemm2_bf16_kernel(GemmParams p) {
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt][ks], xf[mt][ks], acc[mt][nt], 0, 0, 0);
+          if constexpr (DT == 2)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16((f16x8)(wf[nt][ks]), (f16x8)(xf[mt][ks]), acc[mt][nt], 0, 0, 0);
+          else
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt][ks], xf[mt][ks], acc[mt][nt], 0, 0, 0);
     }
     s0 = ring5(s0 + 3);
     if (++ck == p.nk) {
@@ -1214,7 +1220,12 @@ static int gemm_launch(const void *A, long lda, const void *W, long ldw, const f
   if (epilogue < 0 || epilogue > 5 || (epilogue == 5 && dt != 1)) return S6D_EINVAL;
   // staging addresses are 32-bit byte offsets from A / W
   if ((double)M * (double)lda * esz >= 2147483648.0 || (double)N * (double)ldw * esz >= 2147483648.0) return S6D_EUNSUPPORTED;
-  const int impl = (N % 256 != 0) ? 2 : 1;
+  int impl = (N % 256 != 0) ? 2 : 1;
+  // plain / GELU launches that would put fewer than 160 of the 256 x 256 tiles on the 256 CUs take the 256 x 128 kernel (round 6)
+  if (impl == 1 && g_s6d_gemm_small_tile && (dt == 0 || dt == 2) && (epilogue == 0 || epilogue == 1) && col_block == 0 && !x.sa_mx &&
+      (long)((M + 255) / 256) * (N / 256) < 160)
+    impl = 2;
+  if (impl == 2 && dt != 0 && dt != 2) return S6D_EUNSUPPORTED;
   GemmParams p;
   p.A = (const u16 *)A;
   p.W = (const u16 *)W;
@@ -1251,16 +1262,22 @@ static int gemm_launch(const void *A, long lda, const void *W, long ldw, const f
     int grid = p.ntiles < max_blocks ? p.ntiles : max_blocks;
     grid = (grid + 7) & ~7;
     const size_t lds = (size_t)5 * kSlot;
-#define S6D_GEMM2_LAUNCH(E, HB)                                                                                         \
+#define S6D_GEMM2_LAUNCH(E, HB, D)                                                                                      \
   do {                                                                                                                  \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm2_bf16_kernel<E, HB>),                                \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm2_bf16_kernel<E, HB, D>),                             \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                    \
-    hipLaunchKernelGGL((gemm2_bf16_kernel<E, HB>), dim3(grid), dim3(256), lds, st, p);                                  \
+    hipLaunchKernelGGL((gemm2_bf16_kernel<E, HB, D>), dim3(grid), dim3(256), lds, st, p);                               \
   } while (0)
-    if (epilogue == 1) {
-      if (bias) S6D_GEMM2_LAUNCH(1, true); else S6D_GEMM2_LAUNCH(1, false);
+    if (dt == 2) {
+      if (epilogue == 1) {
+        if (bias) S6D_GEMM2_LAUNCH(1, true, 2); else S6D_GEMM2_LAUNCH(1, false, 2);
+      } else {
+        if (bias) S6D_GEMM2_LAUNCH(0, true, 2); else S6D_GEMM2_LAUNCH(0, false, 2);
+      }
+    } else if (epilogue == 1) {
+      if (bias) S6D_GEMM2_LAUNCH(1, true, 0); else S6D_GEMM2_LAUNCH(1, false, 0);
     } else {
-      if (bias) S6D_GEMM2_LAUNCH(0, true); else S6D_GEMM2_LAUNCH(0, false);
+      if (bias) S6D_GEMM2_LAUNCH(0, true, 0); else S6D_GEMM2_LAUNCH(0, false, 0);
     }
 #undef S6D_GEMM2_LAUNCH
     return launch_status();

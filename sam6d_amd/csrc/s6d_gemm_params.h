@@ -85,5 +85,6 @@ int gemm4_launch(const GemmParams &p, int epilogue, int max_blocks, hipStream_t 
 bool gemm4_supports(const GemmParams &p, int epilogue, int dt);
 bool gemm4_default(const GemmParams &p, int epilogue, int dt);   // the library's own choice (measured per shape class)
 extern int g_s6d_gemm_wave_tile;             // csrc/s6d_capi.hip: s6d_set_gemm_wave_tile (0 = by shape, 64 / 128 = forced)
+extern int g_s6d_gemm_small_tile;            // csrc/s6d_capi.hip: s6d_set_gemm_small_tile (1 = 256 x 128 tiles for under-filled plain / GELU launches)
 
 }  // namespace s6d

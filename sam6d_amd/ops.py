@@ -819,6 +819,11 @@ def set_geo_embed_form(form):
     _call("s6d_set_geo_embed_form", int(form))
 
 
+def set_gemm_small_tile(enable):
+    """256 x 128 tiles for under-filled plain / GELU GEMM launches (include/sam6d_hip.h: s6d_set_gemm_small_tile); same bits either way."""
+    _call("s6d_set_gemm_small_tile", 1 if enable else 0)
+
+
 def set_gemm_wave_tile(columns):
     """Which form of the bf16 / f16 GEMM kernel serves the shapes both cover (include/sam6d_hip.h: s6d_set_gemm_wave_tile): 0 = the
     library's choice per shape, 64 = the eight-wave form, 128 = the four-wave form wherever it applies.  Process-wide; for A/B

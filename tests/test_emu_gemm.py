@@ -26,7 +26,12 @@ def _check(ops, M, N, K, bias, gelu, max_blocks, lda_pad=0, seed=0):
     a = a_full[:, :K]
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
     b = torch.randn(N, generator=g) if bias else None
-    out = ops.gemm_bf16(a, w, b, gelu=gelu, max_blocks=max_blocks)
+    ops.set_gemm_small_tile(False)            # these cases walk the 256 x 256 kernel's tile order and ring (round 6: the library would
+    try:                                      # give such small products to the 256 x 128 kernel, covered by the run below)
+        out = ops.gemm_bf16(a, w, b, gelu=gelu, max_blocks=max_blocks)
+    finally:
+        ops.set_gemm_small_tile(True)
+    assert torch.equal(out, ops.gemm_bf16(a, w, b, gelu=gelu, max_blocks=max_blocks))      # ... and must give the same bits
     ref = _ref(a, w, b, gelu)
     err = (out.float() - ref).abs()
     tol = 2.0 ** -8 * ref.abs() + 1e-5        # one bf16 rounding of an fp32-accumulated result
@@ -128,6 +133,9 @@ def _run_res():
     T.test_lnfold_gemm_with_offset_rows(300, 256, 320)
     T.test_float16_gemm_vs_float(300, 256, 320, True)
     T.test_float16_gemm_vs_float(700, 768, 192, False)
+    T.test_small_tile_form_gives_the_bits_of_the_256_tile_form(300, 256, 320, True, False, 0)     # round 6: 256 x 128 tiles for under-filled launches
+    T.test_small_tile_form_gives_the_bits_of_the_256_tile_form(700, 768, 192, False, False, 16)
+    T.test_small_tile_form_gives_the_bits_of_the_256_tile_form(261, 512, 64, True, True, 8)
 
 
 @pytest.mark.parametrize("mode", ["early", "late"])

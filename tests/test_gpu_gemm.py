@@ -323,3 +323,35 @@ def test_wave_tile_switch_rejects_other_values():
     L = _lib.lib()
     assert L.s6d_set_gemm_wave_tile(32) == -1
     assert L.s6d_set_gemm_wave_tile(0) == 0
+
+
+@pytest.mark.parametrize("M,N,K,gelu,half,blocks", [(6304, 768, 3072, False, True, 0), (6304, 768, 768, False, True, 0), (1970, 2304, 768, False, True, 0),
+                                                   (1970, 3072, 768, True, True, 0), (4096, 256, 1280, False, False, 0), (300, 256, 320, True, False, 0),
+                                                   (700, 768, 192, False, False, 16), (261, 512, 64, True, True, 8)])
+def test_small_tile_form_gives_the_bits_of_the_256_tile_form(M, N, K, gelu, half, blocks):
+    """Round 6: plain / GELU launches that would put fewer than 160 tiles of 256 x 256 on the chip take the 256 x 128 kernel
+    (gemm2_bf16_kernel<., ., DT>, now also in IEEE half: the PEM ViT-B's products).  Same products in the same order per element:
+    the result must equal the 256 x 256 kernel's bit for bit (s6d_set_gemm_small_tile(0)), ragged row counts and few persistent
+    workgroups included -- the PEM's group = single property rests on it (the instantiation follows the row count)."""
+    from sam6d_amd import ops
+    if not torch.cuda.is_available() and M > 1000:
+        pytest.skip("emulator: small shapes only")
+    dt = torch.float16 if half else torch.bfloat16
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(dt).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dt).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    try:
+        ops.set_gemm_small_tile(False)
+        big = ops.gemm_bf16(a, w, b, gelu=gelu, max_blocks=blocks)
+        ops.set_gemm_small_tile(True)
+        small = ops.gemm_bf16(a, w, b, gelu=gelu, max_blocks=blocks)
+    finally:
+        ops.set_gemm_small_tile(True)
+    assert small.dtype == dt and torch.equal(small, big)
+    ref = a.float().cpu().double() @ w.float().cpu().double().t() + b.cpu().double()
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    eps = 2.0 ** -11 if half else 2.0 ** -8
+    err = (small.float().cpu().double() - ref).abs()
+    assert (err <= eps * ref.abs() * 1.01 + 1e-3).all()

@@ -108,6 +108,10 @@ Stage roofline: SAM ViT-H encoder 5.96 TFLOP × 32 frames in {st['sam_encoder']:
   instructions + `v_min3_f32`: 4.25 per point, the same bits, **0.47 → 0.15 ms** per call at 32 instances (two `gpurun` calls; the
   change is 3×, the instruction count per point 2.4×).  *Padded rel-pos tables*
   of the SAM attention: made once per table pair instead of by a 5-µs launch in front of each of the 64 attention launches of a step.
+* *256 × 128 tiles for under-filled plain / GELU GEMM launches* (`gemm2_bf16_kernel`, now also in IEEE half): the PEM ViT-B's
+  6304 × 768 products were 75 tiles of 256 × 256 on 256 CUs; launches below 160 tiles take the two-workgroups-per-CU kernel, the same
+  bits (`test_small_tile_form_gives_the_bits_of_the_256_tile_form`): PEM stage 19.75 → 19.64 ms at 32 instances in one process
+  (`profiles/r06_pem_small_tile_ab.json`) — small, kept.
 * *Attention range guard* (ADVICE r5): a non-finite O^T accumulator triggers the second pass / raised reference as well as a row sum
   ≥ 2^100 (|V| = 2^50 under P up to 2^90 in `tests/test_gpu_attn.py`); lowering the sum limit to 2^60 instead sent the probe's
   ordinary rows through the second pass (global kernel 1.81 → 3.25 ms) and was reverted.  `static_assert` on the window kernel's

@@ -44,7 +44,9 @@ int s6d_set_persistent_grid_limit(int max_workgroups);
 int s6d_set_gemm_wave_tile(int columns);
 /* 1 (default): a plain or GELU bf16 / f16 GEMM launch that would put fewer than 160 tiles of 256 x 256 on the chip takes the 256 x 128
  * tile kernel (two independent workgroups per CU) -- the PEM ViT-B's 6304 x 768 products are 75 tiles otherwise.  0: always the
- * 256 x 256 kernel.  The same products in the same order per element: the same bits.  Process-wide; other values: S6D_EINVAL. */
+ * 256 x 256 kernel.  2: as 1, and the residual + row-statistics epilogue (the ViT-H's proj / lin2 at one frame) as well -- built and
+ * bit-equal, measured 6 % slower for the one-frame encoder, hence not part of the default.  The same products in the same order per
+ * element in every mode: the same bits.  Process-wide; other values: S6D_EINVAL. */
 int s6d_set_gemm_small_tile(int enable);
 const char *s6d_strerror(int code);
 /* last HIP error string seen by this thread (empty if none) */

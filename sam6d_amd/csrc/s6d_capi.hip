@@ -38,7 +38,7 @@ namespace s6d {
 int g_s6d_gemm_small_tile = 1;
 }
 extern "C" int s6d_set_gemm_small_tile(int enable) {
-  if (enable != 0 && enable != 1) return S6D_EINVAL;
+  if (enable < 0 || enable > 2) return S6D_EINVAL;
   s6d::g_s6d_gemm_small_tile = enable;
   return S6D_OK;
 }

@@ -997,7 +997,10 @@ __global__ void __launch_bounds__(256, 2) gemm2_bf16_kernel(GemmParams p) {
   int ct = 0, ck = 0, cm0, cn0;
   tile_mn(0, cm0, cn0);
 
-  auto init_acc = [&](int n0) __attribute__((always_inline)) {
+  // EPI 2 (round 6): C = A W^T + bias + R summed in fp32 as in gemm_body -- the accumulators start at bias + residual (this lane's
+  // row, its columns 32 nt + 8 qd + 4 h + e: 8 bytes per (mt, nt, qd), requested at the tile start) -- and the epilogue leaves the
+  // same partial row statistics; see epilogue() for how the same BITS come out of another register layout.
+  auto init_acc = [&](int m0, int n0) __attribute__((always_inline)) {
     const int nb = __builtin_amdgcn_readfirstlane(n0 + wc * 64);
     const S6D_CONST(float) *bs = (const S6D_CONST(float) *)p.bias + nb;
     const bool hi = (lane >> 5) != 0;
@@ -1015,9 +1018,88 @@ __global__ void __launch_bounds__(256, 2) gemm2_bf16_kernel(GemmParams p) {
           for (int mt = 0; mt < 4; ++mt) acc[mt][nt][4 * qd + e] = b;
         }
       }
+    if (EPI == 2) {
+      const int hb = lane >> 5;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int m = min(m0 + wr * 128 + mt * 32 + (lane & 31), p.M - 1);   // rows past M: a valid address, never stored
+        const char *src = (const char *)p.R + (size_t)m * p.ldr2 + (size_t)(n0 + wc * 64 + 4 * hb) * 2;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            const uint2 w = *reinterpret_cast<const uint2 *>(src + (32 * nt + 8 * qd) * 2);
+            acc[mt][nt][4 * qd] += __uint_as_float(w.x << 16);
+            acc[mt][nt][4 * qd + 1] += __uint_as_float(w.x & 0xffff0000u);
+            acc[mt][nt][4 * qd + 2] += __uint_as_float(w.y << 16);
+            acc[mt][nt][4 * qd + 3] += __uint_as_float(w.y & 0xffff0000u);
+          }
+      }
+    }
   };
   auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) {
     const int hb = lane >> 5;
+    if constexpr (EPI == 2) {
+      // The eight-wave kernel feeds the W rows in an order that leaves a lane with the 32 CONSECUTIVE columns 32 h .. 32 h + 31 of
+      // its row, and sums its row statistics over them in ascending order.  Here lane half h holds columns 8 qd + 4 h + e of BOTH
+      // 32-column tiles; one v_permlane32_swap per register pair hands the lower half tile 0 and the upper half tile 1 complete:
+      // lo[r] = columns 8 qd + e, hi[r] = columns 8 qd + 4 + e of tile h (r = 4 qd + e).  Summed qd by qd -- lo, then hi -- that is
+      // the same ascending order over the same fp32 values: the same statistics, bit for bit, and the same rounded outputs.
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + wr * 128 + mt * 32 + (lane & 31);
+        float lo[16], hv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mt][0][r]), __float_as_uint(acc[mt][1][r]), false, false);
+          lo[r] = __uint_as_float(sw[0]);
+          hv[r] = __uint_as_float(sw[1]);
+        }
+        if (p.SP) {
+          float sum = 0.f;
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum += lo[4 * qd + e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum += hv[4 * qd + e];
+          }
+          const float mean = sum * (1.f / 32.f);
+          float m2 = 0.f;
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float d = lo[4 * qd + e] - mean;
+              m2 = fmaf(d, d, m2);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float d = hv[4 * qd + e] - mean;
+              m2 = fmaf(d, d, m2);
+            }
+          }
+          const int pidx = ((n0 + wc * 64) >> 5) + hb;
+          if (m < p.M) {
+            p.SP[(size_t)(2 * pidx) * p.M + m] = sum;
+            p.SP[(size_t)(2 * pidx + 1) * p.M + m] = m2;
+          }
+        }
+        if (m < p.M) {
+          u16 *dst = p.C + (size_t)m * p.ldc + (n0 + wc * 64 + 32 * hb);
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            uint4 o;
+            o.x = pack_out<DT>(lo[4 * qd], lo[4 * qd + 1]);
+            o.y = pack_out<DT>(lo[4 * qd + 2], lo[4 * qd + 3]);
+            o.z = pack_out<DT>(hv[4 * qd], hv[4 * qd + 1]);
+            o.w = pack_out<DT>(hv[4 * qd + 2], hv[4 * qd + 3]);
+            *reinterpret_cast<uint4 *>(dst + 8 * qd) = o;
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const int m = m0 + wr * 128 + mt * 32 + (lane & 31);
@@ -1060,7 +1142,7 @@ __global__ void __launch_bounds__(256, 2) gemm2_bf16_kernel(GemmParams p) {
     issue_w(3);
     issue_a0(4);
   }
-  init_acc(cn0);
+  init_acc(cm0, cn0);
 
   int s0 = 0;                                                            // ring slot of W of K tile g: (3 g) % 5
   for (int g = 0; g < G; ++g) {
@@ -1102,7 +1184,7 @@ __global__ void __launch_bounds__(256, 2) gemm2_bf16_kernel(GemmParams p) {
       epilogue(cm0, cn0);
       if (++ct < my_tiles) {
         tile_mn(ct, cm0, cn0);
-        init_acc(cn0);
+        init_acc(cm0, cn0);
       }
     }
   }
@@ -1222,9 +1304,12 @@ static int gemm_launch(const void *A, long lda, const void *W, long ldw, const f
   if ((double)M * (double)lda * esz >= 2147483648.0 || (double)N * (double)ldw * esz >= 2147483648.0) return S6D_EUNSUPPORTED;
   int impl = (N % 256 != 0) ? 2 : 1;
   // plain / GELU launches that would put fewer than 160 of the 256 x 256 tiles on the 256 CUs take the 256 x 128 kernel (round 6)
-  if (impl == 1 && g_s6d_gemm_small_tile && (dt == 0 || dt == 2) && (epilogue == 0 || epilogue == 1) && col_block == 0 && !x.sa_mx &&
-      (long)((M + 255) / 256) * (N / 256) < 160)
-    impl = 2;
+  if (impl == 1 && g_s6d_gemm_small_tile && col_block == 0 && !x.sa_mx && (long)((M + 255) / 256) * (N / 256) < 160 &&
+      (((dt == 0 || dt == 2) && (epilogue == 0 || epilogue == 1)) || (dt == 0 && epilogue == 2 && g_s6d_gemm_small_tile == 2)))
+    impl = 2;     // (epilogue 2 = + residual + row statistics, the ViT-H's proj / lin2 at one frame: built, bit-equal, and SLOWER --
+                  // 10.73 against 10.11 ms for the encoder on one frame, a lone 4-wave workgroup per CU has nobody to hide its
+                  // barriers -- so only on request: s6d_set_gemm_small_tile(2))
+  if (impl == 2 && epilogue > 2) return S6D_EUNSUPPORTED;
   if (impl == 2 && dt != 0 && dt != 2) return S6D_EUNSUPPORTED;
   GemmParams p;
   p.A = (const u16 *)A;
@@ -1274,6 +1359,8 @@ static int gemm_launch(const void *A, long lda, const void *W, long ldw, const f
       } else {
         if (bias) S6D_GEMM2_LAUNCH(0, true, 2); else S6D_GEMM2_LAUNCH(0, false, 2);
       }
+    } else if (epilogue == 2) {
+      if (bias) S6D_GEMM2_LAUNCH(2, true, 0); else S6D_GEMM2_LAUNCH(2, false, 0);
     } else if (epilogue == 1) {
       if (bias) S6D_GEMM2_LAUNCH(1, true, 0); else S6D_GEMM2_LAUNCH(1, false, 0);
     } else {

@@ -821,7 +821,7 @@ def set_geo_embed_form(form):
 
 def set_gemm_small_tile(enable):
     """256 x 128 tiles for under-filled plain / GELU GEMM launches (include/sam6d_hip.h: s6d_set_gemm_small_tile); same bits either way."""
-    _call("s6d_set_gemm_small_tile", 1 if enable else 0)
+    _call("s6d_set_gemm_small_tile", int(enable))                  # False / True / 2 (= also the residual epilogue)
 
 
 def set_gemm_wave_tile(columns):

@@ -136,6 +136,9 @@ def _run_res():
     T.test_small_tile_form_gives_the_bits_of_the_256_tile_form(300, 256, 320, True, False, 0)     # round 6: 256 x 128 tiles for under-filled launches
     T.test_small_tile_form_gives_the_bits_of_the_256_tile_form(700, 768, 192, False, False, 16)
     T.test_small_tile_form_gives_the_bits_of_the_256_tile_form(261, 512, 64, True, True, 8)
+    T.test_small_tile_residual_form_gives_the_bits_of_the_256_tile_form(700, 768, 192, False, True, True)
+    T.test_small_tile_residual_form_gives_the_bits_of_the_256_tile_form(300, 256, 64, True, False, True)
+    T.test_small_tile_residual_form_gives_the_bits_of_the_256_tile_form(261, 1280, 128, False, True, False)
 
 
 @pytest.mark.parametrize("mode", ["early", "late"])

@@ -355,3 +355,38 @@ def test_small_tile_form_gives_the_bits_of_the_256_tile_form(M, N, K, gelu, half
     eps = 2.0 ** -11 if half else 2.0 ** -8
     err = (small.float().cpu().double() - ref).abs()
     assert (err <= eps * ref.abs() * 1.01 + 1e-3).all()
+
+
+@pytest.mark.parametrize("M,N,K,inplace,stats,bias", [(4096, 1280, 1280, True, True, True), (4096, 1280, 5120, False, True, True),
+                                                     (700, 768, 192, False, True, True), (300, 256, 64, True, False, True),
+                                                     (261, 1280, 128, False, True, False)])
+def test_small_tile_residual_form_gives_the_bits_of_the_256_tile_form(M, N, K, inplace, stats, bias):
+    """Round 6: the residual + row-statistics epilogue (EPI 2: the ViT-H's proj / lin2) in the 256 x 128 kernel for launches whose 256 x 256
+    tiling would put fewer than 160 tiles on the chip (one frame: 4096 x 1280 = 80 tiles) -- selectable (s6d_set_gemm_small_tile(2)), not
+    the default: the encoder on one frame measured 10.73 ms with it against 10.11 ms without.  Its lanes hold other columns than the
+    eight-wave kernel's; one v_permlane32_swap per register pair restores that kernel's 32 consecutive columns per lane, so the
+    outputs AND the partial statistics (summed in the same ascending order) must be bit-identical -- with ragged rows, in place,
+    without statistics and without a bias."""
+    from sam6d_amd import ops
+    if not torch.cuda.is_available() and M > 1000:
+        pytest.skip("emulator: small shapes only")
+    g = torch.Generator().manual_seed(M + N + K + 7)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).cuda()
+    b = (torch.randn(N, generator=g) + 0.5).cuda() if bias else None
+    x = (torch.randn(M, N, generator=g) * 2 + torch.randn(M, 1, generator=g)).to(torch.bfloat16).cuda()
+    res = {}
+    try:
+        for small in (False, True):
+            ops.set_gemm_small_tile(2 if small else 0)                 # 2: the residual epilogue too (not in the default: it is slower)
+            xr = x.clone()
+            sp = torch.full((N // 32, 2, M), float("nan"), device=a.device) if stats else None
+            out = ops.gemm_bf16(a, w, b, residual=xr, out=xr if inplace else None, stats_partial=sp)
+            res[small] = (out.clone(), None if sp is None else sp.clone())
+    finally:
+        ops.set_gemm_small_tile(True)
+    assert torch.equal(res[True][0], res[False][0])
+    if stats:
+        assert torch.isfinite(res[True][1]).all() and torch.equal(res[True][1], res[False][1])
+    ref = a.float() @ w.float().t() + (b if bias else 0) + x.float()
+    _check(res[True][0], ref, "residual sum, 256 x 128 tiles")

@@ -111,7 +111,11 @@ Stage roofline: SAM ViT-H encoder 5.96 TFLOP × 32 frames in {st['sam_encoder']:
 * *256 × 128 tiles for under-filled plain / GELU GEMM launches* (`gemm2_bf16_kernel`, now also in IEEE half): the PEM ViT-B's
   6304 × 768 products were 75 tiles of 256 × 256 on 256 CUs; launches below 160 tiles take the two-workgroups-per-CU kernel, the same
   bits (`test_small_tile_form_gives_the_bits_of_the_256_tile_form`): PEM stage 19.75 → 19.64 ms at 32 instances in one process
-  (`profiles/r06_pem_small_tile_ab.json`) — small, kept.
+  (`profiles/r06_pem_small_tile_ab.json`) — small, kept.  The residual + row-statistics epilogue was added to that kernel as well for
+  the ViT-H's proj / lin2 at ONE frame (80 tiles; VERDICT r5 next #7's small-M form): one `v_permlane32_swap` per register pair
+  restores the eight-wave kernel's 32 consecutive columns per lane, so outputs and statistics are bit-identical (tested) — and the
+  encoder on one frame runs 10.73 ms with it against 10.11 ms without (`profiles/r06_sam_single_frame_ab.json`): a lone four-wave
+  workgroup per CU has nobody to hide its barriers.  Selectable (`s6d_set_gemm_small_tile(2)`), not the default.
 * *Attention range guard* (ADVICE r5): a non-finite O^T accumulator triggers the second pass / raised reference as well as a row sum
   ≥ 2^100 (|V| = 2^50 under P up to 2^90 in `tests/test_gpu_attn.py`); lowering the sum limit to 2^60 instead sent the probe's
   ordinary rows through the second pass (global kernel 1.81 → 3.25 ms) and was reverted.  `static_assert` on the window kernel's
